@@ -1,0 +1,456 @@
+"""CPU oracle for the SP-GAN G+D train-step hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch, functional restatement (plain PyTorch fp32 on the
+CPU) of the arithmetic that the reference performs on its train path.  It is the
+*checker* for the HIP kernels; the product (`sp-gan_amd/spgan`) never imports it.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module.
+
+Parity status: PINNED.  `tests/golden/make_golden.py` imports the real reference
+from /root/reference (build container only), drives it with the deterministic
+weights/inputs of `spgan.fixture_rng`, and stores the outputs under
+`tests/golden/*.npz`.  `tests/test_oracle_golden.py` checks every function below
+against those vectors.
+
+Everything is written against a flat ``params`` dict that uses the reference's
+own ``state_dict`` keys, so a reference checkpoint can be fed in unchanged.
+Reference citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+NEG = 0.01      # Generator.py:22 / Discriminator.py:19  (LeakyReLU slope inside the MLPs)
+NEG_2 = 0.2     # Generator.py:23  (LeakyReLU before each AdaIN)
+BN_EPS = 1e-5   # torch.nn.BatchNorm*/InstanceNorm1d default
+BN_MOM = 0.1
+
+
+# --------------------------------------------------------------------------- #
+# graph ops                                                                   #
+# --------------------------------------------------------------------------- #
+def pairwise_sqdist(x: Tensor) -> Tensor:
+    """dist[b,i,j] = -2 x_i.x_j + |x_i|^2 + |x_j|^2, x: [B,C,N].
+    Generation/modules.py:695-699 (expanded form, evaluated in this order)."""
+    xt = x.permute(0, 2, 1)
+    inner = -2 * torch.bmm(xt, x)
+    sq = torch.sum(xt ** 2, dim=2, keepdim=True)
+    return inner + sq + sq.permute(0, 2, 1)
+
+
+def knn_sorted(x: Tensor, k: int) -> Tensor:
+    """Ranks 1..k of the full ascending sort of each distance row -> int64 [B,N,k].
+    Rank 0 is dropped *positionally* (modules.py:702-703), not by "exclude self"."""
+    order = torch.sort(pairwise_sqdist(x), dim=2)[1]
+    return order[:, :, 1:k + 1].contiguous()
+
+
+def knn_sorted_fp64_direct(x: Tensor, k: int) -> Tensor:
+    """Same selection with distances evaluated as sum((x_i-x_j)^2) in fp64 from the
+    fp32-rounded coordinates, ties broken by the lower index.  This is what the
+    HIP kernel does for coordinate-space inputs (C<=4); on every sphere template
+    it reproduces `knn_sorted` row for row (checked in tests)."""
+    xd = x.double().permute(0, 2, 1)
+    d = ((xd[:, :, None, :] - xd[:, None, :, :]) ** 2).sum(-1)
+    order = torch.sort(d, dim=2, stable=True)[1]
+    return order[:, :, 1:k + 1].contiguous()
+
+
+def gather_neighbors(x: Tensor, idx: Tensor) -> Tensor:
+    """x [B,C,N], idx [B,N,k] -> [B,C,N,k] (modules.py:708-714)."""
+    B, C, N = x.shape
+    k = idx.shape[2]
+    flat = idx.reshape(B, 1, N * k).expand(B, C, N * k)
+    return torch.gather(x, 2, flat).view(B, C, N, k)
+
+
+def get_edge_features(x: Tensor, k: int, idx: Optional[Tensor] = None, return_idx: bool = False):
+    """[B,C,N] -> ee [B,2C,N,k] = cat[central, neighbour-central] (modules.py:683-725).
+    `idx` may be injected as int64 [B,N*k] or [B,N,k]."""
+    B, C, N = x.shape
+    if idx is None:
+        idx = knn_sorted(x, k)
+    idx3 = idx.view(B, N, k)
+    nb = gather_neighbors(x, idx3)
+    central = x.unsqueeze(3).expand(B, C, N, k)
+    ee = torch.cat([central, nb - central], dim=1)
+    if return_idx:
+        return ee, idx3.reshape(B, N * k)
+    return ee
+
+
+# --------------------------------------------------------------------------- #
+# norm helpers (train-mode statistics + running-stat side effects)            #
+# --------------------------------------------------------------------------- #
+def _bn(x: Tensor, p: Dict[str, Tensor], prefix: str, training: bool, buffers: Optional[Dict[str, Tensor]]):
+    """BatchNorm over every dim but 1.  Train mode: biased batch var for the
+    normalisation, unbiased var into running_var, momentum 0.1 (torch defaults;
+    Generator.py:58,61,67,121,124; Discriminator.py:57,60,63,79)."""
+    w, b = p[prefix + ".weight"], p[prefix + ".bias"]
+    if buffers is None:
+        rm = rv = None
+    else:
+        rm, rv = buffers[prefix + ".running_mean"], buffers[prefix + ".running_var"]
+        if training and (prefix + ".num_batches_tracked") in buffers:
+            buffers[prefix + ".num_batches_tracked"] += 1
+    if not training and rm is None:
+        raise ValueError("eval-mode batch norm needs running statistics")
+    return F.batch_norm(x, rm, rv, w, b, training, BN_MOM, BN_EPS)
+
+
+def _conv1x1(x: Tensor, p, prefix: str) -> Tensor:
+    """1x1 Conv1d/Conv2d as a channel contraction."""
+    w = p[prefix + ".weight"]
+    b = p[prefix + ".bias"]
+    w2 = w.reshape(w.shape[0], w.shape[1])
+    y = torch.einsum("oc,bc...->bo...", w2, x)
+    return y + b.view(1, -1, *([1] * (x.dim() - 2)))
+
+
+# --------------------------------------------------------------------------- #
+# Generator pieces                                                            #
+# --------------------------------------------------------------------------- #
+def edge_block(p, prefix: str, x: Tensor, k: int, idx: Optional[Tensor] = None,
+               training: bool = True, buffers=None, return_idx: bool = False):
+    """EdgeBlock.forward, Generation/Generator.py:75-88.  x [B,Fin,N] -> [B,Fout,N]."""
+    B, C, N = x.shape
+    ee, idx_used = get_edge_features(x, k, idx=idx, return_idx=True)
+    # conv_w on the difference half (Generator.py:56-63,78)
+    w = _conv1x1(ee[:, C:], p, prefix + ".conv_w.0")
+    w = F.leaky_relu(_bn(w, p, prefix + ".conv_w.1", training, buffers), NEG)
+    w = _conv1x1(w, p, prefix + ".conv_w.3")
+    w = F.leaky_relu(_bn(w, p, prefix + ".conv_w.4", training, buffers), NEG)
+    w = F.softmax(w, dim=-1)                                   # Generator.py:79
+    # conv_x on the full edge feature (Generator.py:65-69,81)
+    y = _conv1x1(ee, p, prefix + ".conv_x.0")
+    y = F.leaky_relu(_bn(y, p, prefix + ".conv_x.1", training, buffers), NEG)
+    y = y * w                                                  # Generator.py:82
+    # conv_out: [1,k] kernel == contraction over (channel, neighbour rank) (Generator.py:71,84)
+    wo = p[prefix + ".conv_out.weight"]                        # [F,F,1,k]
+    out = torch.einsum("ocr,bcnr->bon", wo[:, :, 0, :], y) + p[prefix + ".conv_out.bias"].view(1, -1, 1)
+    if return_idx:
+        return out, idx_used
+    return out
+
+
+def adaptive_point_norm(p, prefix: str, x: Tensor, style: Tensor) -> Tensor:
+    """AdaptivePointNorm.forward, Generator.py:38-45: per-point gamma/beta from a
+    1x1 conv of the style, applied to the instance-normalised input."""
+    s = _conv1x1(style, p, prefix + ".style")
+    gamma, beta = s.chunk(2, 1)
+    xhat = F.instance_norm(x, eps=BN_EPS)                       # affine=False, biased var over N
+    return gamma * xhat + beta
+
+
+def generator_forward(p, x: Tensor, z: Tensor, k: int = 10, training: bool = True,
+                      buffers=None, idx1: Optional[Tensor] = None, idx2: Optional[Tensor] = None,
+                      off: bool = False, z_norm: bool = False, stages: Optional[dict] = None) -> Tensor:
+    """Generator.forward with default flags (use_head=False, attn=False, eql=False),
+    Generation/Generator.py:160-198.  x [B,N,3], z [B,N,nz] -> [B,3,N].
+    `stages`, when given, receives the intermediate activations (used by the golden tests)."""
+    B, N, _ = x.shape
+    if z_norm:                                                  # Generator.py:163-164
+        z = z / (z.norm(p=2, dim=-1, keepdim=True) + 1e-8)
+    style = torch.cat([x, z], dim=-1).transpose(2, 1).contiguous()
+    style = F.leaky_relu(_conv1x1(style, p, "head.0"), NEG)
+    style = F.leaky_relu(_conv1x1(style, p, "head.2"), NEG)     # [B,128,N]
+    pc = x.transpose(2, 1).contiguous()
+
+    x1, i1 = edge_block(p, "EdgeConv1", pc, k, idx=idx1, training=training, buffers=buffers, return_idx=True)
+    x1 = adaptive_point_norm(p, "adain1", F.leaky_relu(x1, NEG_2), style)
+    x2, i2 = edge_block(p, "EdgeConv2", x1, k, idx=idx2, training=training, buffers=buffers, return_idx=True)
+    x2 = adaptive_point_norm(p, "adain2", F.leaky_relu(x2, NEG_2), style)
+
+    g = torch.max(x2, 2)[0]                                     # [B,128]  Generator.py:183
+    g = F.linear(g, p["global_conv.0.weight"], p["global_conv.0.bias"])
+    g = F.leaky_relu(_bn(g, p, "global_conv.1", training, buffers), NEG)
+    g = F.linear(g, p["global_conv.3.weight"], p["global_conv.3.bias"])
+    g = F.leaky_relu(_bn(g, p, "global_conv.4", training, buffers), NEG)
+    feat = torch.cat([g.view(B, -1, 1).expand(B, g.shape[1], N), x2], dim=1)    # [B,640,N]
+
+    t = F.leaky_relu(_conv1x1(feat, p, "tail.0"), NEG)
+    t = F.leaky_relu(_conv1x1(t, p, "tail.2"), NEG)
+    out = torch.tanh(_conv1x1(t, p, "tail.4"))
+    if stages is not None:
+        stages.update(style=style, x1=x1, x2=x2, idx1=i1, idx2=i2, feat_global=g, out=out)
+    return pc + out if off else out
+
+
+def discriminator_forward(p, x: Tensor, training: bool = True, buffers=None,
+                          stages: Optional[dict] = None) -> Tensor:
+    """Discriminator.forward, Generation/Discriminator.py:97-115. x [B,3,N] -> [B,1]."""
+    h = x
+    for conv, bn in (("mlps.0", "mlps.1"), ("mlps.3", "mlps.4"), ("mlps.6", "mlps.7"), ("fc2.0", "fc2.1")):
+        h = F.leaky_relu(_bn(_conv1x1(h, p, conv), p, bn, training, buffers), NEG)
+    pooled = torch.max(h, 2)[0]                                 # adaptive_max_pool1d(.,1)
+    m = pooled
+    for i in (0, 2, 4):
+        m = F.leaky_relu(F.linear(m, p["mlp.%d.weight" % i], p["mlp.%d.bias" % i]), NEG)
+    out = F.linear(m, p["mlp.6.weight"], p["mlp.6.bias"])
+    if stages is not None:
+        stages.update(pooled=pooled, out=out)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# losses (Common/loss_utils.py) and the WGAN-GP penalty                       #
+# --------------------------------------------------------------------------- #
+def dis_loss(d_real: Tensor, d_fake: Tensor, gan: str = "ls",
+             real_label: Optional[Tensor] = None, fake_label: Optional[Tensor] = None) -> Tensor:
+    """loss_utils.py:854-972.  For 'ls' the labels are shape [B] against logits
+    [B,1]; F.mse_loss then broadcasts to [B,B] (reference quirk, kept)."""
+    gan = gan.lower()
+    if gan == "wgan":                                           # :859-863
+        return d_fake.mean() - d_real.mean()
+    if gan == "hinge":                                          # :870-871,877
+        return F.relu(1.0 - d_real).mean() + F.relu(1.0 + d_fake).mean()
+    if gan == "ls":                                             # :889-939
+        B = d_fake.shape[0]
+        rl = torch.ones(B) if real_label is None else real_label
+        fl = torch.zeros(B) if fake_label is None else fake_label
+        return (_mse_bcast(d_fake, fl) + _mse_bcast(d_real, rl)) / 2.0
+    if gan == "gan":                                            # :947-953 (BCE-with-logits on both)
+        ones = torch.ones_like(d_real)
+        return (F.binary_cross_entropy_with_logits(d_fake, torch.zeros_like(d_fake))
+                + F.binary_cross_entropy_with_logits(d_real, ones)) / 2.0
+    raise NotImplementedError(gan)
+
+
+def gen_loss(d_real: Tensor, d_fake: Tensor, gan: str = "ls", fake_label: Optional[Tensor] = None) -> Tensor:
+    """loss_utils.py:727-802 (d_real is accepted and ignored for ls/wgan/hinge, as there)."""
+    gan = gan.lower()
+    if gan in ("wgan", "hinge"):                                # :728-729, :735-736
+        return -d_fake.mean()
+    if gan == "ls":                                             # :747-763
+        fl = torch.ones(d_fake.shape[0]) if fake_label is None else fake_label
+        return _mse_bcast(d_fake, fl)
+    if gan == "gan":
+        return F.binary_cross_entropy_with_logits(d_fake, torch.ones_like(d_fake))
+    raise NotImplementedError(gan)
+
+
+def _mse_bcast(logit: Tensor, label: Tensor) -> Tensor:
+    """F.mse_loss(logit[B,1], label[B]) -> mean over the broadcast [B,B] square."""
+    return ((logit.view(-1, 1) - label.view(1, -1)) ** 2).mean()
+
+
+def gradient_penalty(d_fn, real: Tensor, fake: Tensor, alpha: Tensor,
+                     lambda_gp: float = 10.0, gamma: float = 1.0) -> Tensor:
+    """Common/gradient_penalty.py:19-37 with the per-sample mixing factor `alpha`
+    [B,1,1] passed in (the reference draws it with torch.rand on the fly)."""
+    B = real.shape[0]
+    xhat = real + alpha * (fake[:B] - real)
+    if not xhat.requires_grad:
+        xhat.requires_grad_(True)
+    out = d_fn(xhat)
+    g = torch.autograd.grad(out, xhat, grad_outputs=torch.ones_like(out),
+                            create_graph=True, retain_graph=True, only_inputs=True)[0]
+    g = g.contiguous().view(B, -1)
+    return (((g.norm(2, dim=1) - gamma) / gamma) ** 2).mean() * lambda_gp
+
+
+# --------------------------------------------------------------------------- #
+# optimiser + one train step (Generation/model.py:239-279)                    #
+# --------------------------------------------------------------------------- #
+def adam_update(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, step: int,
+                lr: float = 1e-4, beta1: float = 0.5, beta2: float = 0.99, eps: float = 1e-8) -> None:
+    """torch.optim.Adam semantics (no weight decay, no amsgrad), in place.
+    Hyper-parameters: Generation/model.py:94-97."""
+    m.mul_(beta1).add_(grad, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    param.addcdiv_(m, denom, value=-lr / bc1)
+
+
+class AdamState:
+    def __init__(self, params: Dict[str, Tensor]):
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.step = 0
+
+    def apply(self, params, grads, lr=1e-4):
+        self.step += 1
+        for k in params:
+            adam_update(params[k].data, grads[k], self.m[k], self.v[k], self.step, lr=lr)
+
+
+def train_step(gp_, gbuf, dp_, dbuf, optG: AdamState, optD: AdamState, sphere: Tensor, real: Tensor,
+               z_d: Tensor, z_g: Tensor, gan: str = "ls", use_gp: bool = False,
+               alpha: Optional[Tensor] = None, lambda_gp: float = 10.0, k: int = 10, lr: float = 1e-4):
+    """One iteration of the reference loop body (Generation/model.py:239-279):
+    D-step (G frozen, no graph through G) then G-step (D frozen: input grads only).
+    `real` is [B,N,3]; sphere [B,N,3]; z_* [B,N,nz].  With use_gp the D loss is
+    dis_loss(gan) + GradientPenalty(lambda_gp, gamma=1).
+    Params are leaf tensors with requires_grad=True; returns dict of scalars + grads."""
+    out = {}
+    # ---- D step (model.py:240-260) ----
+    with torch.no_grad():
+        fake = generator_forward(gp_, sphere, z_d, k=k, training=True, buffers=gbuf)
+    real_t = real.transpose(2, 1).contiguous()
+    d_real = discriminator_forward(dp_, real_t, True, dbuf)
+    d_fake = discriminator_forward(dp_, fake, True, dbuf)
+    loss_d = dis_loss(d_real, d_fake, gan)
+    if use_gp:
+        loss_d = loss_d + gradient_penalty(lambda t: discriminator_forward(dp_, t, True, dbuf),
+                                           real_t, fake, alpha, lambda_gp)
+    dnames = list(dp_.keys())
+    dgrads = dict(zip(dnames, torch.autograd.grad(loss_d, [dp_[n] for n in dnames])))
+    optD.apply(dp_, dgrads, lr)
+    out.update(loss_d=loss_d.detach(), d_grads=dgrads, fake_d=fake)
+    # ---- G step (model.py:264-279) ----
+    fake_g = generator_forward(gp_, sphere, z_g, k=k, training=True, buffers=gbuf)
+    with torch.no_grad():
+        d_real_g = discriminator_forward(dp_, real_t, True, dbuf)   # unused by the loss, but it
+    #                                                                 advances D's BN running stats
+    d_fake_g = discriminator_forward(dp_, fake_g, True, dbuf)
+    loss_g = gen_loss(d_real_g, d_fake_g, gan)
+    gnames = list(gp_.keys())
+    ggrads = dict(zip(gnames, torch.autograd.grad(loss_g, [gp_[n] for n in gnames])))
+    optG.apply(gp_, ggrads, lr)
+    out.update(loss_g=loss_g.detach(), g_grads=ggrads, fake_g=fake_g.detach())
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# ball-query / grouping family (orphans named by the north star)              #
+# --------------------------------------------------------------------------- #
+def square_distance(src: Tensor, dst: Tensor) -> Tensor:
+    """[B,N,C],[B,M,C] -> [B,N,M], same expanded form (Common/pointnet_util.py:19-40)."""
+    d = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    d = d + torch.sum(src ** 2, -1).unsqueeze(-1)
+    d = d + torch.sum(dst ** 2, -1).unsqueeze(1)
+    return d
+
+
+def index_points(points: Tensor, idx: Tensor) -> Tensor:
+    """points [B,N,C], idx [B,S] or [B,S,K] -> [B,S,(K,)C] (pointnet_util.py:43-60)."""
+    B = points.shape[0]
+    bidx = torch.arange(B).view(B, *([1] * (idx.dim() - 1))).expand_as(idx)
+    return points[bidx, idx]
+
+
+def query_ball_point(radius: float, nsample: int, xyz: Tensor, new_xyz: Tensor) -> Tensor:
+    """First `nsample` indices (ascending index order) with d^2 <= r^2, padded with the
+    first hit (pointnet_util.py:87-107; the mask there is `> r^2`)."""
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    d = square_distance(new_xyz, xyz)
+    gi = torch.arange(N).view(1, 1, N).repeat(B, S, 1)
+    gi[d > radius ** 2] = N
+    gi = gi.sort(dim=-1)[0][:, :, :nsample]
+    first = gi[:, :, :1].expand(B, S, gi.shape[2])
+    return torch.where(gi == N, first, gi)
+
+
+def knn_point(nsample: int, xyz: Tensor, new_xyz: Tensor) -> Tensor:
+    """k nearest (self included), order unspecified in the reference (topk sorted=False,
+    Common/pointconv_util.py:107-118); the oracle returns them sorted ascending."""
+    d = square_distance(new_xyz, xyz)
+    return torch.topk(d, nsample, dim=-1, largest=False, sorted=True)[1]
+
+
+def group(nsample: int, xyz: Tensor, points: Optional[Tensor], idx: Optional[Tensor] = None):
+    """kNN-group every point (pointconv_util.py:174-197): returns
+    (new_points [B,N,K,C+D], grouped_xyz_norm [B,N,K,C])."""
+    B, N, C = xyz.shape
+    if idx is None:
+        idx = knn_point(nsample, xyz, xyz)
+    gx = index_points(xyz, idx) - xyz.view(B, N, 1, C)
+    if points is None:
+        return gx, gx
+    return torch.cat([gx, index_points(points, idx)], dim=-1), gx
+
+
+def farthest_point_sample(xyz: Tensor, npoint: int, start: Optional[Tensor] = None) -> Tensor:
+    """Iterative FPS (pointnet_util.py:63-84 draws a random start; pointconv_util.py:60-83
+    starts at 0).  `start` [B] int64; default zeros."""
+    B, N, _ = xyz.shape
+    cent = torch.zeros(B, npoint, dtype=torch.long)
+    dist = torch.full((B, N), 1e10)
+    far = torch.zeros(B, dtype=torch.long) if start is None else start.clone()
+    ar = torch.arange(B)
+    for i in range(npoint):
+        cent[:, i] = far
+        c = xyz[ar, far].view(B, 1, -1)
+        d = torch.sum((xyz - c) ** 2, -1)
+        dist = torch.minimum(dist, d)
+        far = torch.max(dist, -1)[1]
+    return cent
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, start=None):
+    """pointnet_util.py:110-143 -> (new_xyz [B,S,3], new_points [B,S,ns,3+D])."""
+    B, N, C = xyz.shape
+    fps = farthest_point_sample(xyz, npoint, start)
+    new_xyz = index_points(xyz, fps)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    gx = index_points(xyz, idx) - new_xyz.view(B, npoint, 1, C)
+    if points is not None:
+        return new_xyz, torch.cat([gx, index_points(points, idx)], dim=-1)
+    return new_xyz, gx
+
+
+# --------------------------------------------------------------------------- #
+# parameter containers                                                        #
+# --------------------------------------------------------------------------- #
+def generator_shapes(nz: int = 128, k: int = 10) -> Dict[str, Tuple[int, ...]]:
+    """state_dict parameter shapes of Generator(default flags), Generator.py:107-153."""
+    d = 128
+    s = {
+        "head.0.weight": (d, 3 + nz, 1), "head.0.bias": (d,),
+        "head.2.weight": (d, d, 1), "head.2.bias": (d,),
+        "global_conv.0.weight": (d, d), "global_conv.0.bias": (d,),
+        "global_conv.1.weight": (d,), "global_conv.1.bias": (d,),
+        "global_conv.3.weight": (512, d), "global_conv.3.bias": (512,),
+        "global_conv.4.weight": (512,), "global_conv.4.bias": (512,),
+        "tail.0.weight": (256, 512 + d, 1), "tail.0.bias": (256,),
+        "tail.2.weight": (64, 256, 1), "tail.2.bias": (64,),
+        "tail.4.weight": (3, 64, 1), "tail.4.bias": (3,),
+    }
+    for name, fin, fout in (("EdgeConv1", 3, 64), ("EdgeConv2", 64, d)):
+        s.update({
+            name + ".conv_w.0.weight": (fout // 2, fin, 1, 1), name + ".conv_w.0.bias": (fout // 2,),
+            name + ".conv_w.1.weight": (fout // 2,), name + ".conv_w.1.bias": (fout // 2,),
+            name + ".conv_w.3.weight": (fout, fout // 2, 1, 1), name + ".conv_w.3.bias": (fout,),
+            name + ".conv_w.4.weight": (fout,), name + ".conv_w.4.bias": (fout,),
+            name + ".conv_x.0.weight": (fout, 2 * fin, 1, 1), name + ".conv_x.0.bias": (fout,),
+            name + ".conv_x.1.weight": (fout,), name + ".conv_x.1.bias": (fout,),
+            name + ".conv_out.weight": (fout, fout, 1, k), name + ".conv_out.bias": (fout,),
+        })
+    s.update({"adain1.style.weight": (128, d, 1), "adain1.style.bias": (128,),
+              "adain2.style.weight": (256, d, 1), "adain2.style.bias": (256,)})
+    return s
+
+
+def discriminator_shapes(small_d: bool = False) -> Dict[str, Tuple[int, ...]]:
+    """state_dict parameter shapes of Discriminator, Discriminator.py:55-95."""
+    dim = 512 if small_d else 1024
+    return {
+        "mlps.0.weight": (64, 3, 1), "mlps.0.bias": (64,), "mlps.1.weight": (64,), "mlps.1.bias": (64,),
+        "mlps.3.weight": (128, 64, 1), "mlps.3.bias": (128,), "mlps.4.weight": (128,), "mlps.4.bias": (128,),
+        "mlps.6.weight": (256, 128, 1), "mlps.6.bias": (256,), "mlps.7.weight": (256,), "mlps.7.bias": (256,),
+        "fc2.0.weight": (dim, 256, 1), "fc2.0.bias": (dim,), "fc2.1.weight": (dim,), "fc2.1.bias": (dim,),
+        "mlp.0.weight": (512, dim), "mlp.0.bias": (512,), "mlp.2.weight": (256, 512), "mlp.2.bias": (256,),
+        "mlp.4.weight": (64, 256), "mlp.4.bias": (64,), "mlp.6.weight": (1, 64), "mlp.6.bias": (1,),
+    }
+
+
+def bn_buffers(shapes: Dict[str, Tuple[int, ...]]) -> Dict[str, Tensor]:
+    """Fresh running stats for every BN layer implied by `shapes` (1-D weight entries
+    whose sibling conv/linear precedes them: *.1, *.4, *.7 in the Sequentials)."""
+    out = {}
+    for name, shp in shapes.items():
+        if name.endswith(".weight") and len(shp) == 1:
+            base = name[:-len(".weight")]
+            out[base + ".running_mean"] = torch.zeros(shp)
+            out[base + ".running_var"] = torch.ones(shp)
+            out[base + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    return out

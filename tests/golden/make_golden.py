@@ -1,0 +1,365 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (read-only at
+/root/reference) on deterministic inputs.  Runs only in the build container; the
+GPU box never sees the reference, only these vectors.
+
+    python tests/golden/make_golden.py
+
+What is executed from the reference (never copied into this repo):
+  * Generation.Generator.{Generator,EdgeBlock,AdaptivePointNorm}, Generation.Discriminator.Discriminator,
+    Generation.modules.get_edge_features, Common.pointnet_util.*, Common.gradient_penalty.GradientPenalty
+    -- imported normally;
+  * Common/loss_utils.py {dis_loss,gen_loss,...} and Common/pointconv_util.py {knn_point,group,...}
+    -- those modules do not import here (CUDA extensions / removed sklearn API), so the
+    individual function definitions are compiled straight from the reference file with `ast`
+    and executed with `.cuda()` patched to the identity.
+"""
+import ast
+import functools
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "sp-gan_amd"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from spgan import fixture_rng as fr                                   # noqa: E402
+from oracle import spgan_oracle as orc                                # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self                        # reference hard-codes .cuda()
+torch.set_num_threads(8)
+
+from Generation.Generator import Generator, EdgeBlock, AdaptivePointNorm   # noqa: E402
+from Generation.Discriminator import Discriminator                         # noqa: E402
+from Generation.modules import get_edge_features                           # noqa: E402
+import Common.pointnet_util as pnu                                         # noqa: E402
+from Common.gradient_penalty import GradientPenalty                        # noqa: E402
+
+
+def extract_functions(path, names, extra_globals):
+    """Compile selected top-level defs from a reference source file."""
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    mod = ast.Module(body=body, type_ignores=[])
+    ns = dict(extra_globals)
+    exec(compile(mod, path, "exec"), ns)
+    return types.SimpleNamespace(**{n: ns[n] for n in names})
+
+
+from torch.autograd import Variable                                        # noqa: E402
+LU = extract_functions(os.path.join(REF, "Common/loss_utils.py"),
+                       ["dis_loss", "gen_loss", "BCEloss", "BCEfakeloss", "smooth_labels", "noisy_labels"],
+                       dict(torch=torch, nn=nn, F=F, np=np, functools=functools, Variable=Variable))
+PCU = extract_functions(os.path.join(REF, "Common/pointconv_util.py"),
+                        ["square_distance", "index_points", "knn_point", "group", "farthest_point_sample"],
+                        dict(torch=torch, nn=nn, F=F, np=np))
+
+
+class Opts:
+    np = 2048; nk = 20; nz = 128; softmax = True; off = False; attn = False
+    use_head = False; eql = False; z_norm = False; small_d = False
+
+
+def summarize(t, full_limit=4096, nsamp=1024):
+    """Full tensor when small, else (l2, sum, strided samples)."""
+    a = t.detach().cpu().numpy()
+    if a.size <= full_limit:
+        return {"full": a}
+    flat = a.reshape(-1)
+    stride = max(1, flat.size // nsamp)
+    return {"l2": np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum())),
+            "sum": np.float64(flat.astype(np.float64).sum()),
+            "stride": np.int64(stride), "samples": flat[::stride][:nsamp].copy()}
+
+
+def put(d, name, t, **kw):
+    for k, v in summarize(t, **kw).items():
+        d["%s|%s" % (name, k)] = v
+
+
+def save(fname, d):
+    path = os.path.join(HERE, fname)
+    np.savez_compressed(path, **d)
+    print("%-28s %7.1f KB  (%d arrays)" % (fname, os.path.getsize(path) / 1024, len(d)))
+
+
+def load_into(module, params):
+    sd = module.state_dict()
+    for k, v in params.items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+    module.load_state_dict({**sd, **params})
+    return module
+
+
+# ---------------------------------------------------------------- G1: kNN + edge features
+def g1():
+    d = {}
+    for N in (256, 512, 1024, 2048, 4096):
+        x = fr.sphere_template(N)[None].transpose(2, 1).contiguous()       # [1,3,N]
+        ee, idx = get_edge_features(x, 10, return_idx=True)
+        d["sphere%d|idx" % N] = idx.view(N, 10).numpy().astype(np.int32)
+        if N <= 512:
+            d["sphere%d|ee" % N] = ee.numpy()
+    for N, C in ((256, 64), (512, 64), (300, 5)):
+        x = fr.normal("g1.feat.%d.%d" % (N, C), (2, C, N), 0.5)
+        ee, idx = get_edge_features(x, 10, return_idx=True)
+        dist = orc.pairwise_sqdist(x)
+        srt = torch.sort(dist, dim=2)[0][:, :, :12]
+        d["feat%d_%d|idx" % (N, C)] = idx.view(2, N, 10).numpy().astype(np.int32)
+        d["feat%d_%d|sorted_dist" % (N, C)] = srt.numpy()                   # for the tie-aware protocol
+        put(d, "feat%d_%d|ee" % (N, C), ee, full_limit=0, nsamp=2048)
+    save("g1_edge_features.npz", d)
+
+
+# ---------------------------------------------------------------- G2: EdgeBlock
+def g2():
+    d = {}
+    for tag, fin, fout, B, N in (("ec1", 3, 64, 2, 256), ("ec2", 64, 128, 2, 256)):
+        blk = EdgeBlock(fin, fout, 10)
+        pref = "EdgeConv1." if fin == 3 else "EdgeConv2."
+        shapes = {k: v for k, v in orc.generator_shapes().items() if k.startswith(pref)}
+        params = {k[len(pref):]: v for k, v in fr.init_params(shapes, salt=2).items()}
+        load_into(blk, params).train()
+        if fin == 3:
+            x = fr.sphere_template(N)[None].repeat(B, 1, 1).transpose(2, 1).contiguous()
+            x = x + 0.01 * fr.normal("g2.jit", x.shape)                     # distinct clouds per sample
+        else:
+            x = fr.normal("g2.x.%s" % tag, (B, fin, N), 0.7)
+        x.requires_grad_(True)
+        _, idx = get_edge_features(x.detach(), 10, return_idx=True)
+        y = blk(x)
+        dy = fr.normal("g2.dy.%s" % tag, y.shape)
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), dy)
+        d[tag + "|idx"] = idx.view(B, N, 10).numpy().astype(np.int32)
+        put(d, tag + "|y", y, full_limit=1 << 20)
+        put(d, tag + "|dx", grads[0], full_limit=1 << 20)
+        for (n, _), g in zip(blk.named_parameters(), grads[1:]):
+            put(d, tag + "|grad|" + n, g, full_limit=1 << 15)
+        for n, b in blk.named_buffers():
+            d[tag + "|buf|" + n] = b.numpy()
+    save("g2_edgeblock.npz", d)
+
+
+# ---------------------------------------------------------------- G3: AdaptivePointNorm
+def g3():
+    d = {}
+    B, C, N = 2, 64, 256
+    m = AdaptivePointNorm(C, 128)
+    params = fr.init_params({"style.weight": (2 * C, 128, 1), "style.bias": (2 * C,)}, salt=3)
+    load_into(m, params)
+    x = fr.normal("g3.x", (B, C, N)).requires_grad_(True)
+    s = fr.normal("g3.s", (B, 128, N), 0.3).requires_grad_(True)
+    y = m(x, s)
+    dy = fr.normal("g3.dy", y.shape)
+    gx, gs, gw, gb = torch.autograd.grad(y, [x, s, m.style.weight, m.style.bias], dy)
+    for n, t in (("y", y), ("dx", gx), ("dstyle", gs), ("dw", gw), ("db", gb)):
+        put(d, n, t, full_limit=1 << 20)
+    save("g3_adain.npz", d)
+
+
+# ---------------------------------------------------------------- G4/G5: Generator, Discriminator
+def make_gd(salt=4):
+    G = load_into(Generator(Opts), fr.init_params(orc.generator_shapes(), salt=salt)).train()
+    D = load_into(Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=salt)).train()
+    return G, D
+
+
+def g4_g5():
+    B, N = 4, 256
+    G, D = make_gd()
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    z = fr.latent(B, N, seed=44)
+    # --- D alone, on a synthetic real cloud
+    real = fr.synthetic_real(B, N, seed=5).transpose(2, 1).contiguous().requires_grad_(True)
+    d = {}
+    logit = D(real)
+    loss = ((logit - 1.0) ** 2).mean()
+    grads = torch.autograd.grad(loss, [real] + list(D.parameters()))
+    put(d, "logit", logit); put(d, "dx", grads[0], full_limit=1 << 20)
+    for (n, _), g in zip(D.named_parameters(), grads[1:]):
+        put(d, "grad|" + n, g)
+    for n, b in D.named_buffers():
+        d["buf|" + n] = b.numpy()
+    save("g5_discriminator.npz", d)
+    # --- G forward + stages + grads of mse(D(G),1)
+    G, D = make_gd()
+    stages = {}
+    hooks = [G.head.register_forward_hook(lambda m, i, o: stages.__setitem__("style", o.detach().clone())),
+             G.adain1.register_forward_hook(lambda m, i, o: stages.__setitem__("x1", o.detach().clone())),
+             G.adain2.register_forward_hook(lambda m, i, o: stages.__setitem__("x2", o.detach().clone())),
+             G.global_conv.register_forward_hook(lambda m, i, o: stages.__setitem__("feat_global", o.detach().clone()))]
+    out = G(x, z)
+    for h in hooks:
+        h.remove()
+    _, idx1 = get_edge_features(x.transpose(2, 1).contiguous(), 10, return_idx=True)
+    # EdgeConv2's graph is built on adain1's output
+    _, idx2 = get_edge_features(stages["x1"], 10, return_idx=True)
+    logit = D(out)
+    loss = ((logit - 1.0) ** 2).mean()
+    # gradient goldens use an injected dL/d(out): end-to-end gradients through D are
+    # kink-limited and would not pin anything tighter than ~1e-2
+    dy = fr.normal("g4.dy", out.shape)
+    grads = torch.autograd.grad(out, list(G.parameters()), dy)
+    d = {"idx1": idx1.view(B, N, 10).numpy().astype(np.int32), "idx2": idx2.view(B, N, 10).numpy().astype(np.int32)}
+    put(d, "out", out, full_limit=1 << 20)
+    for n in ("style", "x1", "x2", "feat_global"):
+        put(d, "stage|" + n, stages[n], full_limit=1 << 17)
+    put(d, "logit", logit); d["loss"] = loss.detach().numpy()
+    for (n, _), g in zip(G.named_parameters(), grads):
+        put(d, "grad|" + n, g)
+    for n, b in G.named_buffers():
+        d["buf|" + n] = b.numpy()
+    save("g4_generator.npz", d)
+
+
+# ---------------------------------------------------------------- G6: losses
+def g6():
+    d = {}
+    B = 6
+    dr = fr.normal("g6.dreal", (B, 1)).requires_grad_(True)
+    df = fr.normal("g6.dfake", (B, 1)).requires_grad_(True)
+    d["d_real"] = dr.detach().numpy(); d["d_fake"] = df.detach().numpy()
+    for gan in ("ls", "wgan", "hinge", "gan"):
+        l, _ = LU.dis_loss(dr, df, gan=gan)
+        gr, gf = torch.autograd.grad(l, [dr, df], allow_unused=True)
+        d["dis|%s|loss" % gan] = l.detach().numpy()
+        d["dis|%s|g_real" % gan] = gr.numpy(); d["dis|%s|g_fake" % gan] = gf.numpy()
+        l, _ = LU.gen_loss(dr, df, gan=gan)
+        gf, = torch.autograd.grad(l, [df])
+        d["gen|%s|loss" % gan] = l.detach().numpy(); d["gen|%s|g_fake" % gan] = gf.numpy()
+    # the [B,1] x [B] broadcast quirk with non-constant labels (noise_label=True path):
+    np.random.seed(7)
+    l, _ = LU.dis_loss(dr, df, gan="ls", noise_label=True)
+    np.random.seed(7)
+    rl = LU.noisy_labels(LU.smooth_labels(B, ran=[0.9, 1.0]), 0.05)        # same draw order as loss_utils.py:897-901
+    d["dis|ls_noisy|real_label"] = rl.astype(np.float32)
+    d["dis|ls_noisy|loss"] = l.detach().numpy()
+    gr, gf = torch.autograd.grad(l, [dr, df])
+    d["dis|ls_noisy|g_real"] = gr.numpy(); d["dis|ls_noisy|g_fake"] = gf.numpy()
+    save("g6_losses.npz", d)
+
+
+# ---------------------------------------------------------------- G7: WGAN-GP through the reference D
+def g7():
+    d = {}
+    B, N = 3, 256
+    _, D = make_gd(salt=7)
+    real = fr.synthetic_real(B, N, seed=71).transpose(2, 1).contiguous()
+    fake = (0.8 * fr.synthetic_real(B, N, seed=72) + 0.05 * fr.normal("g7.n", (B, N, 3))).transpose(2, 1).contiguous()
+    alpha = fr.uniform("g7.alpha", (B, 1, 1), 0.0, 1.0)
+    orig = torch.rand
+    torch.rand = lambda *a, **k: alpha.clone().requires_grad_(k.get("requires_grad", False))
+    try:
+        gp = GradientPenalty(10.0, gamma=1)(D, real, fake)
+    finally:
+        torch.rand = orig
+    grads = torch.autograd.grad(gp, list(D.parameters()), allow_unused=True)
+    d["alpha"] = alpha.numpy(); d["gp"] = gp.detach().numpy()
+    for (n, p), g in zip(D.named_parameters(), grads):
+        put(d, "grad|" + n, g if g is not None else torch.zeros_like(p))
+    # also the first-order input gradient (what the penalty is a function of)
+    xh = (real + alpha * (fake - real)).requires_grad_(True)
+    _, D2 = make_gd(salt=7)
+    gin, = torch.autograd.grad(D2(xh).sum(), xh)
+    put(d, "input_grad", gin, full_limit=1 << 20)
+    save("g7_gradient_penalty.npz", d)
+
+
+# ---------------------------------------------------------------- G8: one full D-step + G-step
+def g8():
+    for tag, gan, use_gp, B, N in (("ls", "ls", False, 4, 512), ("wgangp", "wgan", True, 2, 256)):
+        d = {}
+        G, D = make_gd(salt=8)
+        optG = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.99))
+        optD = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.99))
+        x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+        real = fr.synthetic_real(B, N, seed=81)
+        z_d, z_g = fr.latent(B, N, seed=82), fr.latent(B, N, seed=83)
+        alpha = fr.uniform("g8.alpha", (B, 1, 1), 0.0, 1.0)
+
+        def req(m, f):
+            for p in m.parameters():
+                p.requires_grad = f
+        # D step (Generation/model.py:240-260)
+        req(G, False); req(D, True); optD.zero_grad()
+        fake = G(x, z_d).detach()
+        real_t = real.transpose(2, 1).contiguous()
+        lossD, _ = LU.dis_loss(D(real_t), D(fake), gan=gan)
+        if use_gp:
+            orig = torch.rand
+            torch.rand = lambda *a, **k: alpha.clone().requires_grad_(k.get("requires_grad", False))
+            try:
+                lossD = lossD + GradientPenalty(10.0, gamma=1)(D, real_t, fake)
+            finally:
+                torch.rand = orig
+        lossD.backward()
+        for n, p in D.named_parameters():
+            put(d, "dgrad|" + n, p.grad)
+        optD.step()
+        # G step (model.py:264-279)
+        req(G, True); req(D, False); optG.zero_grad()
+        g_fake = G(x, z_g)
+        g_real_logit = D(real_t)
+        lossG, _ = LU.gen_loss(g_real_logit, D(g_fake), gan=gan)
+        lossG.backward()
+        for n, p in G.named_parameters():
+            put(d, "ggrad|" + n, p.grad)
+        optG.step()
+        d["lossD"] = lossD.detach().numpy(); d["lossG"] = lossG.detach().numpy(); d["alpha"] = alpha.numpy()
+        put(d, "fake_d", fake, full_limit=1 << 20); put(d, "fake_g", g_fake, full_limit=1 << 20)
+        for n, p in G.named_parameters():
+            put(d, "gparam|" + n, p)
+        for n, p in D.named_parameters():
+            put(d, "dparam|" + n, p)
+        for n, b in G.named_buffers():
+            d["gbuf|" + n] = b.numpy()
+        for n, b in D.named_buffers():
+            d["dbuf|" + n] = b.numpy()
+        save("g8_train_step_%s.npz" % tag, d)
+
+
+# ---------------------------------------------------------------- G9: ball query / grouping family
+def g9():
+    d = {}
+    B, N, S = 2, 256, 32
+    xyz = fr.synthetic_real(B, N, seed=91)
+    feat = fr.normal("g9.feat", (B, N, 5))
+    new_xyz = xyz[:, ::N // S][:, :S].contiguous()
+    d["square_distance"] = pnu.square_distance(new_xyz, xyz).numpy()
+    for r, ns in ((0.3, 16), (0.15, 32), (0.02, 8)):
+        d["query_ball|%g|%d" % (r, ns)] = pnu.query_ball_point(r, ns, xyz, new_xyz).numpy().astype(np.int32)
+    idx = pnu.query_ball_point(0.3, 16, xyz, new_xyz)
+    d["index_points3"] = pnu.index_points(feat, idx).numpy()
+    d["index_points2"] = pnu.index_points(feat, idx[:, :, 0]).numpy()
+    start = torch.tensor([3, 100])
+    orig = torch.randint
+    torch.randint = lambda *a, **k: start.clone()
+    try:
+        d["fps"] = pnu.farthest_point_sample(xyz, 24).numpy().astype(np.int32)
+        nx, npts = pnu.sample_and_group(24, 0.3, 16, xyz, feat)
+    finally:
+        torch.randint = orig
+    d["fps_start"] = start.numpy().astype(np.int32)
+    d["sag|new_xyz"] = nx.numpy(); d["sag|new_points"] = npts.numpy()
+    d["fps0"] = PCU.farthest_point_sample(xyz, 24).numpy().astype(np.int32)          # start index 0 variant
+    knn = PCU.knn_point(10, xyz, xyz)
+    d["knn_point_sorted"] = torch.sort(knn, dim=-1)[0].numpy().astype(np.int32)       # order unspecified -> compare as sets
+    np_, gx = PCU.group(10, xyz, feat)
+    # `group` inherits knn_point's unspecified order: store with the idx it used
+    d["group|idx"] = knn.numpy().astype(np.int32)
+    d["group|new_points"] = np_.numpy(); d["group|xyz_norm"] = gx.numpy()
+    save("g9_ball_group.npz", d)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    g1(); g2(); g3(); g4_g5(); g6(); g7(); g8(); g9()

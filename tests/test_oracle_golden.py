@@ -1,0 +1,244 @@
+"""CPU: the oracle (oracle/spgan_oracle.py) against the vectors captured from the real
+reference (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import check, golden, params_from
+from oracle import spgan_oracle as orc
+from spgan import fixture_rng as fr
+
+
+# conv/linear biases that feed a train-mode BatchNorm have mathematically zero gradient; fp32
+# yields rounding noise there -> compared with an absolute bound only.
+ZERO_GRAD_BIASES = ("conv_w.0.bias", "conv_w.3.bias", "conv_x.0.bias", "global_conv.0.bias", "global_conv.3.bias",
+                    "mlps.0.bias", "mlps.3.bias", "mlps.6.bias", "fc2.0.bias")
+
+
+def _sub(params, prefix):
+    return {k: v for k, v in params.items() if k.startswith(prefix)}
+
+
+# ---------------------------------------------------------------- G1
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
+def test_sphere_knn_exact(N):
+    d = golden("g1_edge_features.npz")
+    x = fr.sphere_template(N)[None].transpose(2, 1).contiguous()
+    ref = d["sphere%d|idx" % N]
+    if N <= 2048:
+        assert np.array_equal(orc.knn_sorted(x, 10)[0].numpy(), ref)
+    # the fp64 direct-difference order reproduces the reference's fp32 order on every template
+    assert np.array_equal(orc.knn_sorted_fp64_direct(x, 10)[0].numpy(), ref)
+    if N <= 512:
+        ee = orc.get_edge_features(x, 10)
+        assert np.array_equal(ee.numpy(), d["sphere%d|ee" % N])
+
+
+@pytest.mark.parametrize("N,C", [(256, 64), (512, 64), (300, 5)])
+def test_feature_knn(N, C):
+    d = golden("g1_edge_features.npz")
+    x = fr.normal("g1.feat.%d.%d" % (N, C), (2, C, N), 0.5)
+    ee, idx = orc.get_edge_features(x, 10, return_idx=True)
+    assert np.array_equal(idx.view(2, N, 10).numpy(), d["feat%d_%d|idx" % (N, C)])
+    check(d, "feat%d_%d|ee" % (N, C), ee, rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------- G2
+@pytest.mark.parametrize("tag,fin,fout", [("ec1", 3, 64), ("ec2", 64, 128)])
+def test_edgeblock(tag, fin, fout):
+    d = golden("g2_edgeblock.npz")
+    B, N = 2, 256
+    pref = "EdgeConv1" if fin == 3 else "EdgeConv2"
+    p = params_from(_sub(orc.generator_shapes(), pref + "."), 2, requires_grad=True)
+    buf = orc.bn_buffers({k: tuple(v.shape) for k, v in p.items()})
+    if fin == 3:
+        x = fr.sphere_template(N)[None].repeat(B, 1, 1).transpose(2, 1).contiguous()
+        x = x + 0.01 * fr.normal("g2.jit", x.shape)
+    else:
+        x = fr.normal("g2.x.%s" % tag, (B, fin, N), 0.7)
+    x.requires_grad_(True)
+    idx = torch.from_numpy(d[tag + "|idx"].astype(np.int64))
+    y, idx_own = orc.edge_block(p, pref, x, 10, training=True, buffers=buf, return_idx=True)
+    assert np.array_equal(idx_own.view(B, N, 10).numpy(), idx.numpy())
+    check(d, tag + "|y", y, rtol=2e-6)
+    dy = fr.normal("g2.dy.%s" % tag, y.shape)
+    names = list(p.keys())
+    grads = torch.autograd.grad(y, [x] + [p[n] for n in names], dy)
+    check(d, tag + "|dx", grads[0], rtol=2e-5)
+    for n, g in zip(names, grads[1:]):
+        check(d, tag + "|grad|" + n[len(pref) + 1:], g, rtol=5e-5, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    for k in buf:
+        np.testing.assert_allclose(buf[k].numpy(), d[tag + "|buf|" + k[len(pref) + 1:]], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------- G3
+def test_adain():
+    d = golden("g3_adain.npz")
+    B, C, N = 2, 64, 256
+    p = params_from({"a.style.weight": (2 * C, 128, 1), "a.style.bias": (2 * C,)}, 3)
+    p = {k: v.clone().requires_grad_(True) for k, v in fr.init_params({"style.weight": (2 * C, 128, 1), "style.bias": (2 * C,)}, salt=3).items()}
+    p = {"a." + k: v for k, v in p.items()}
+    x = fr.normal("g3.x", (B, C, N)).requires_grad_(True)
+    s = fr.normal("g3.s", (B, 128, N), 0.3).requires_grad_(True)
+    y = orc.adaptive_point_norm(p, "a", x, s)
+    dy = fr.normal("g3.dy", y.shape)
+    gx, gs, gw, gb = torch.autograd.grad(y, [x, s, p["a.style.weight"], p["a.style.bias"]], dy)
+    for n, t in (("y", y), ("dx", gx), ("dstyle", gs), ("dw", gw), ("db", gb)):
+        check(d, n, t, rtol=5e-6)
+
+
+# ---------------------------------------------------------------- G4 / G5
+def test_discriminator():
+    d = golden("g5_discriminator.npz")
+    B, N = 4, 256
+    p = params_from(orc.discriminator_shapes(), 4, requires_grad=True)
+    buf = orc.bn_buffers(orc.discriminator_shapes())
+    real = fr.synthetic_real(B, N, seed=5).transpose(2, 1).contiguous().requires_grad_(True)
+    logit = orc.discriminator_forward(p, real, True, buf)
+    check(d, "logit", logit, rtol=2e-6)
+    loss = ((logit - 1.0) ** 2).mean()
+    names = list(p.keys())
+    grads = torch.autograd.grad(loss, [real] + [p[n] for n in names])
+    check(d, "dx", grads[0], rtol=2e-5)
+    for n, g in zip(names, grads[1:]):
+        check(d, "grad|" + n, g, rtol=5e-5, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    for k in buf:
+        np.testing.assert_allclose(buf[k].numpy(), d["buf|" + k], rtol=1e-5, atol=1e-6)
+
+
+def test_generator():
+    d = golden("g4_generator.npz")
+    B, N = 4, 256
+    gp = params_from(orc.generator_shapes(), 4, requires_grad=True)
+    dp = params_from(orc.discriminator_shapes(), 4)
+    gbuf = orc.bn_buffers(orc.generator_shapes())
+    dbuf = orc.bn_buffers(orc.discriminator_shapes())
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    z = fr.latent(B, N, seed=44)
+    st = {}
+    out = orc.generator_forward(gp, x, z, training=True, buffers=gbuf, stages=st)
+    assert np.array_equal(st["idx1"].view(B, N, 10).numpy(), d["idx1"])
+    assert np.array_equal(st["idx2"].view(B, N, 10).numpy(), d["idx2"])
+    for n in ("style", "x1", "x2"):
+        check(d, "stage|" + n, st[n], rtol=5e-6)
+    # BatchNorm1d over only B samples amplifies rounding differences
+    check(d, "stage|feat_global", st["feat_global"], rtol=1e-4)
+    check(d, "out", out, rtol=1e-4)
+    logit = orc.discriminator_forward(dp, out, True, dbuf)
+    loss = ((logit - 1.0) ** 2).mean()
+    np.testing.assert_allclose(loss.item(), float(d["loss"]), rtol=1e-5)
+    names = list(gp.keys())
+    dy = fr.normal("g4.dy", out.shape)
+    grads = torch.autograd.grad(out, [gp[n] for n in names], dy)
+    for n, g in zip(names, grads):
+        # pre-BN conv biases have mathematically zero gradient: fp32 noise only
+        # whole-network gradients are kink-limited: 2 LeakyReLU sign flips out of 65k units (forward
+        # diff 8e-6) already move them by 1e-2 rel-L2, the reference in fp32 vs itself in fp64
+        # included.  Tight gradient pins are the block goldens G2/G3/G5.
+        check(d, "grad|" + n, g, rtol=3e-2, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    for k in gbuf:
+        np.testing.assert_allclose(gbuf[k].numpy(), d["buf|" + k], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------- G6
+def test_losses():
+    d = golden("g6_losses.npz")
+    dr = torch.from_numpy(d["d_real"]).requires_grad_(True)
+    df = torch.from_numpy(d["d_fake"]).requires_grad_(True)
+    for gan in ("ls", "wgan", "hinge", "gan"):
+        l = orc.dis_loss(dr, df, gan)
+        gr, gf = torch.autograd.grad(l, [dr, df])
+        np.testing.assert_allclose(l.item(), float(d["dis|%s|loss" % gan]), rtol=1e-6)
+        np.testing.assert_allclose(gr.numpy(), d["dis|%s|g_real" % gan], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(gf.numpy(), d["dis|%s|g_fake" % gan], rtol=1e-5, atol=1e-8)
+        l = orc.gen_loss(dr, df, gan)
+        gf, = torch.autograd.grad(l, [df])
+        np.testing.assert_allclose(l.item(), float(d["gen|%s|loss" % gan]), rtol=1e-6)
+        np.testing.assert_allclose(gf.numpy(), d["gen|%s|g_fake" % gan], rtol=1e-5, atol=1e-8)
+    rl = torch.from_numpy(d["dis|ls_noisy|real_label"])
+    l = orc.dis_loss(dr, df, "ls", real_label=rl)
+    gr, gf = torch.autograd.grad(l, [dr, df])
+    np.testing.assert_allclose(l.item(), float(d["dis|ls_noisy|loss"]), rtol=1e-6)
+    np.testing.assert_allclose(gr.numpy(), d["dis|ls_noisy|g_real"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(gf.numpy(), d["dis|ls_noisy|g_fake"], rtol=1e-5, atol=1e-8)
+
+
+# ---------------------------------------------------------------- G7
+def test_gradient_penalty():
+    d = golden("g7_gradient_penalty.npz")
+    B, N = 3, 256
+    p = params_from(orc.discriminator_shapes(), 7, requires_grad=True)
+    buf = orc.bn_buffers(orc.discriminator_shapes())
+    real = fr.synthetic_real(B, N, seed=71).transpose(2, 1).contiguous()
+    fake = (0.8 * fr.synthetic_real(B, N, seed=72) + 0.05 * fr.normal("g7.n", (B, N, 3))).transpose(2, 1).contiguous()
+    alpha = torch.from_numpy(d["alpha"])
+    gp = orc.gradient_penalty(lambda t: orc.discriminator_forward(p, t, True, buf), real, fake, alpha, 10.0, 1.0)
+    np.testing.assert_allclose(gp.item(), float(d["gp"]), rtol=2e-5)
+    names = list(p.keys())
+    grads = torch.autograd.grad(gp, [p[n] for n in names], allow_unused=True)
+    for n, g in zip(names, grads):
+        g = torch.zeros_like(p[n]) if g is None else g
+        check(d, "grad|" + n, g, rtol=2e-4, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    xh = (real + alpha * (fake - real)).requires_grad_(True)
+    gin, = torch.autograd.grad(orc.discriminator_forward(p, xh, True, None).sum(), xh)
+    check(d, "input_grad", gin, rtol=2e-5)
+
+
+# ---------------------------------------------------------------- G8
+@pytest.mark.parametrize("tag,gan,use_gp,B,N", [("ls", "ls", False, 4, 512), ("wgangp", "wgan", True, 2, 256)])
+def test_train_step(tag, gan, use_gp, B, N):
+    d = golden("g8_train_step_%s.npz" % tag)
+    gp_ = params_from(orc.generator_shapes(), 8, requires_grad=True)
+    dp_ = params_from(orc.discriminator_shapes(), 8, requires_grad=True)
+    gbuf = orc.bn_buffers(orc.generator_shapes()); dbuf = orc.bn_buffers(orc.discriminator_shapes())
+    optG, optD = orc.AdamState(gp_), orc.AdamState(dp_)
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    real = fr.synthetic_real(B, N, seed=81)
+    z_d, z_g = fr.latent(B, N, seed=82), fr.latent(B, N, seed=83)
+    alpha = torch.from_numpy(d["alpha"])
+    out = orc.train_step(gp_, gbuf, dp_, dbuf, optG, optD, x, real, z_d, z_g, gan=gan, use_gp=use_gp, alpha=alpha)
+    np.testing.assert_allclose(out["loss_d"].item(), float(d["lossD"]), rtol=2e-5)
+    check(d, "fake_d", out["fake_d"], rtol=1e-4)
+    for n, g in out["d_grads"].items():
+        check(d, "dgrad|" + n, g, rtol=3e-2, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    # G-step: runs after D's Adam update (each element moves by ~+-lr, sign-noise for ~0 grads) and
+    # is kink-limited end-to-end: loose bounds here, tight ones in the block tests
+    check(d, "fake_g", out["fake_g"], rtol=2e-4)
+    np.testing.assert_allclose(out["loss_g"].item(), float(d["lossG"]), rtol=2e-3)
+    for n, g in out["g_grads"].items():
+        check(d, "ggrad|" + n, g, rtol=5e-2, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    for n, p in dp_.items():
+        if not n.endswith(ZERO_GRAD_BIASES):          # those random-walk under Adam
+            check(d, "dparam|" + n, p, rtol=1e-3)
+    for n, p in gp_.items():
+        if not n.endswith(ZERO_GRAD_BIASES):
+            check(d, "gparam|" + n, p, rtol=1e-3)
+    for k, v in gbuf.items():
+        np.testing.assert_allclose(v.numpy(), d["gbuf|" + k], rtol=2e-3, atol=2e-4)
+    for k, v in dbuf.items():
+        np.testing.assert_allclose(v.numpy(), d["dbuf|" + k], rtol=2e-3, atol=2e-4)
+
+
+# ---------------------------------------------------------------- G9
+def test_ball_group_family():
+    d = golden("g9_ball_group.npz")
+    B, N, S = 2, 256, 32
+    xyz = fr.synthetic_real(B, N, seed=91)
+    feat = fr.normal("g9.feat", (B, N, 5))
+    new_xyz = xyz[:, ::N // S][:, :S].contiguous()
+    np.testing.assert_allclose(orc.square_distance(new_xyz, xyz).numpy(), d["square_distance"], rtol=0, atol=1e-6)
+    for r, ns in ((0.3, 16), (0.15, 32), (0.02, 8)):
+        assert np.array_equal(orc.query_ball_point(r, ns, xyz, new_xyz).numpy(), d["query_ball|%g|%d" % (r, ns)])
+    idx = orc.query_ball_point(0.3, 16, xyz, new_xyz)
+    assert np.array_equal(orc.index_points(feat, idx).numpy(), d["index_points3"])
+    assert np.array_equal(orc.index_points(feat, idx[:, :, 0]).numpy(), d["index_points2"])
+    start = torch.from_numpy(d["fps_start"].astype(np.int64))
+    assert np.array_equal(orc.farthest_point_sample(xyz, 24, start).numpy(), d["fps"])
+    assert np.array_equal(orc.farthest_point_sample(xyz, 24).numpy(), d["fps0"])
+    nx, npts = orc.sample_and_group(24, 0.3, 16, xyz, feat, start)
+    assert np.array_equal(nx.numpy(), d["sag|new_xyz"]) and np.array_equal(npts.numpy(), d["sag|new_points"])
+    knn = orc.knn_point(10, xyz, xyz)
+    assert np.array_equal(torch.sort(knn, dim=-1)[0].numpy(), d["knn_point_sorted"])
+    gi = torch.from_numpy(d["group|idx"].astype(np.int64))
+    np_, gx = orc.group(10, xyz, feat, idx=gi)
+    assert np.array_equal(np_.numpy(), d["group|new_points"]) and np.array_equal(gx.numpy(), d["group|xyz_norm"])
