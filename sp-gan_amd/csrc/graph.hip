@@ -1,0 +1,380 @@
+// kNN graph construction and the gather-side helpers of the EdgeConv path.
+//
+// spgan_knn never materialises the [B,N,N] distance tensor nor sorts full rows (the reference does
+// both: Generation/modules.py:695-703, 16 bytes per pair).  One lane owns one query point and keeps
+// its k+1 best (distance, index) pairs sorted in registers; candidate points are staged through LDS
+// in tiles and broadcast to all lanes.  Order is the stable ascending (distance, index) order, rank 0
+// is dropped positionally, exactly like `sort(dist)[..., 1:k+1]`.
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ kNN
+// KP = k+1 rounded up to a compiled capacity; CP = feature count padded to a compiled capacity
+// (zero padding leaves every fmaf chain bit-identical).  One query per lane, held in registers;
+// candidates are staged in LDS tiles of TC points and read as wave-wide broadcasts.
+template <int KP, int CP>
+__global__ __launch_bounds__(256) void knn_f32_kernel(const float* __restrict__ x, int N, int C, int k,
+                                                      int32_t* __restrict__ idx) {
+  constexpr int TC = 64;
+  __shared__ __attribute__((aligned(16))) float cand[TC * CP];
+  __shared__ float cnorm[TC];
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;  // query within the shape
+  const float* xb = x + (size_t)b * N * C;
+  const bool qok = q < N;
+
+  float xq[CP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) xq[c] = (qok && c < C) ? xb[(size_t)q * C + c] : 0.f;
+  float qn = 0.f;
+#pragma unroll
+  for (int c = 0; c < CP; ++c) qn = fmaf(xq[c], xq[c], qn);
+
+  float bd[KP];
+  int bi[KP];
+#pragma unroll
+  for (int t = 0; t < KP; ++t) {
+    bd[t] = INFINITY;
+    bi[t] = 0x7fffffff;
+  }
+
+  for (int c0 = 0; c0 < N; c0 += TC) {
+    const int nc = min(TC, N - c0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < TC * CP; e += 256) {
+      const int j = e / CP, c = e % CP;
+      cand[e] = (j < nc && c < C) ? xb[(size_t)(c0 + j) * C + c] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < TC) {
+      float sq = 0.f;
+#pragma unroll
+      for (int c = 0; c < CP; ++c) sq = fmaf(cand[threadIdx.x * CP + c], cand[threadIdx.x * CP + c], sq);
+      cnorm[threadIdx.x] = sq;
+    }
+    __syncthreads();
+    if (!qok) continue;
+    for (int j = 0; j < nc; ++j) {
+      const float4* v = reinterpret_cast<const float4*>(cand + j * CP);
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CP / 4; ++c) {
+        const float4 a = v[c];
+        dot = fmaf(xq[4 * c], a.x, dot);
+        dot = fmaf(xq[4 * c + 1], a.y, dot);
+        dot = fmaf(xq[4 * c + 2], a.z, dot);
+        dot = fmaf(xq[4 * c + 3], a.w, dot);
+      }
+      // modules.py:699: dist = (-2*inner + |x_i|^2) + |x_j|^2
+      const float d = (-2.f * dot + qn) + cnorm[j];
+      if (d < bd[KP - 1]) {
+        bd[KP - 1] = d;
+        bi[KP - 1] = c0 + j;
+#pragma unroll
+        for (int t = KP - 1; t > 0; --t) {
+          if (bd[t] < bd[t - 1]) {  // strict: equal distances keep the lower (earlier) index first
+            const float td = bd[t]; bd[t] = bd[t - 1]; bd[t - 1] = td;
+            const int ti = bi[t]; bi[t] = bi[t - 1]; bi[t - 1] = ti;
+          }
+        }
+      }
+    }
+  }
+  if (qok) {
+    int32_t* o = idx + ((size_t)b * N + q) * k;
+#pragma unroll
+    for (int t = 1; t < KP; ++t)
+      if (t <= k) o[t - 1] = b * N + bi[t];
+  }
+}
+
+// fp64 direct differences for coordinate-space inputs (C <= 8): the query sits in registers.
+template <int KP, int C>
+__global__ __launch_bounds__(256) void knn_f64_kernel(const float* __restrict__ x, int N, int k, int32_t* __restrict__ idx) {
+  constexpr int TC = 256;
+  __shared__ float cand[TC * C];
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const float* xb = x + (size_t)b * N * C;
+  const bool qok = q < N;
+  double xq[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) xq[c] = qok ? (double)xb[(size_t)q * C + c] : 0.0;
+  double bd[KP];
+  int bi[KP];
+#pragma unroll
+  for (int t = 0; t < KP; ++t) {
+    bd[t] = INFINITY;
+    bi[t] = 0x7fffffff;
+  }
+  for (int c0 = 0; c0 < N; c0 += TC) {
+    const int nc = min(TC, N - c0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nc * C; e += 256) cand[e] = xb[(size_t)c0 * C + e];
+    __syncthreads();
+    if (!qok) continue;
+    for (int j = 0; j < nc; ++j) {
+      double d = 0.0;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const double t = xq[c] - (double)cand[j * C + c];
+        d = fma(t, t, d);
+      }
+      if (d < bd[KP - 1]) {
+        bd[KP - 1] = d;
+        bi[KP - 1] = c0 + j;
+#pragma unroll
+        for (int t = KP - 1; t > 0; --t) {
+          if (bd[t] < bd[t - 1]) {
+            const double td = bd[t]; bd[t] = bd[t - 1]; bd[t - 1] = td;
+            const int ti = bi[t]; bi[t] = bi[t - 1]; bi[t - 1] = ti;
+          }
+        }
+      }
+    }
+  }
+  if (qok) {
+    int32_t* o = idx + ((size_t)b * N + q) * k;
+#pragma unroll
+    for (int t = 1; t < KP; ++t)
+      if (t <= k) o[t - 1] = b * N + bi[t];
+  }
+}
+
+template <int KP>
+int launch_knn(const float* x, int B, int N, int C, int k, int mode, int32_t* idx, hipStream_t s) {
+  dim3 grid(cdiv(N, 256), B), block(256);
+  if (mode == 1) {
+    switch (C) {
+      case 1: hipLaunchKernelGGL((knn_f64_kernel<KP, 1>), grid, block, 0, s, x, N, k, idx); break;
+      case 2: hipLaunchKernelGGL((knn_f64_kernel<KP, 2>), grid, block, 0, s, x, N, k, idx); break;
+      case 3: hipLaunchKernelGGL((knn_f64_kernel<KP, 3>), grid, block, 0, s, x, N, k, idx); break;
+      case 4: hipLaunchKernelGGL((knn_f64_kernel<KP, 4>), grid, block, 0, s, x, N, k, idx); break;
+      default: return SPGAN_EINVAL;
+    }
+  } else {
+    if (C <= 8) hipLaunchKernelGGL((knn_f32_kernel<KP, 8>), grid, block, 0, s, x, N, C, k, idx);
+    else if (C <= 16) hipLaunchKernelGGL((knn_f32_kernel<KP, 16>), grid, block, 0, s, x, N, C, k, idx);
+    else if (C <= 32) hipLaunchKernelGGL((knn_f32_kernel<KP, 32>), grid, block, 0, s, x, N, C, k, idx);
+    else if (C <= 64) hipLaunchKernelGGL((knn_f32_kernel<KP, 64>), grid, block, 0, s, x, N, C, k, idx);
+    else if (C <= 128) hipLaunchKernelGGL((knn_f32_kernel<KP, 128>), grid, block, 0, s, x, N, C, k, idx);
+    else return SPGAN_EINVAL;
+  }
+  return spgan_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ CSR of in-edges
+// One workgroup per shape (edges never cross shapes, and each shape has exactly N*k edges, so its
+// segment of `src` starts at b*N*k).  Degree count and slot assignment use LDS integer atomics
+// (order-independent results after the per-segment sort).
+__global__ __launch_bounds__(1024) void csr_kernel(const int32_t* __restrict__ idx, int N, int k,
+                                                   int32_t* __restrict__ rowptr, int32_t* __restrict__ src) {
+  extern __shared__ int ism[];
+  int* deg = ism;          // [N]
+  int* start = ism + N;    // [N]   exclusive scan of deg
+  int* wsum = ism + 2 * N; // [32]
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int E = N * k;
+  const int32_t* ib = idx + (size_t)b * E;
+  for (int i = tid; i < N; i += nt) deg[i] = 0;
+  __syncthreads();
+  for (int e = tid; e < E; e += nt) atomicAdd(&deg[ib[e] - b * N], 1);
+  __syncthreads();
+  // blocked exclusive scan: thread t owns a contiguous chunk
+  const int chunk = (N + nt - 1) / nt;
+  const int lo = min(N, tid * chunk), hi = min(N, lo + chunk);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += deg[i];
+  // scan of per-thread sums: wave scan + cross-wave
+  int incl = s;
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 0; w < (nt + 63) / 64; ++w) {
+      const int v = wsum[w];
+      wsum[w] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  int run = wsum[wv] + incl - s;
+  for (int i = lo; i < hi; ++i) {
+    start[i] = run;
+    run += deg[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += nt) {
+    rowptr[(size_t)b * N + i] = b * E + start[i];
+    deg[i] = 0;  // reuse as cursor
+  }
+  if (b == gridDim.x - 1 && tid == 0) rowptr[(size_t)gridDim.x * N] = gridDim.x * E;
+  __syncthreads();
+  for (int e = tid; e < E; e += nt) {
+    const int j = ib[e] - b * N;
+    const int slot = atomicAdd(&deg[j], 1);
+    src[(size_t)b * E + start[j] + slot] = b * E + e;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // sort each segment ascending (deterministic summation order downstream)
+  for (int i = tid; i < N; i += nt) {
+    int32_t* seg = src + (size_t)b * E + start[i];
+    const int n = deg[i];
+    for (int a = 1; a < n; ++a) {
+      const int v = seg[a];
+      int c = a - 1;
+      while (c >= 0 && seg[c] > v) {
+        seg[c + 1] = seg[c];
+        --c;
+      }
+      seg[c + 1] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ gathers / layout
+__global__ void edge_features_cm_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int C, int N, int k,
+                                        float* __restrict__ ee) {
+  // one thread per (b, c, n, r); output [B,2C,N,k] -- modules.py:708-720
+  const size_t total = (size_t)gridDim.y * C * N * k;  // gridDim.y == B
+  const int b = blockIdx.y;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)C * N * k) return;
+  (void)total;
+  const int r = t % k;
+  const int n = (t / k) % N;
+  const int c = t / ((size_t)k * N);
+  const float* xb = x + (size_t)b * C * N;
+  const int64_t j = idx[(size_t)b * N * k + (size_t)n * k + r];
+  const float ctr = xb[(size_t)c * N + n];
+  const float nb = xb[(size_t)c * N + j];
+  float* eb = ee + (size_t)b * 2 * C * N * k;
+  eb[((size_t)c * N + n) * k + r] = ctr;
+  eb[((size_t)(C + c) * N + n) * k + r] = nb - ctr;
+}
+
+__global__ void idx_to_local64_kernel(const int32_t* __restrict__ idx, int N, size_t total, size_t per_batch, int64_t* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int b = t / per_batch;
+  out[t] = (int64_t)(idx[t] - b * N);
+}
+__global__ void idx_from_local64_kernel(const int64_t* __restrict__ idx, int N, size_t total, size_t per_batch, int32_t* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int b = t / per_batch;
+  out[t] = (int32_t)idx[t] + b * N;
+}
+
+// [B,C,N] -> [B*N,C] through a 32x32 LDS tile (coalesced on both sides)
+__global__ void cm_to_pm_kernel(const float* __restrict__ x, int C, int N, float* __restrict__ y) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, n = n0 + tx;
+    tile[i][tx] = (c < C && n < N) ? x[((size_t)b * C + c) * N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, c = c0 + tx;
+    if (n < N && c < C) y[((size_t)b * N + n) * C + c] = tile[tx][i];
+  }
+}
+__global__ void pm_to_cm_kernel(const float* __restrict__ x, int C, int N, float* __restrict__ y) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, c = c0 + tx;
+    tile[i][tx] = (c < C && n < N) ? x[((size_t)b * N + n) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, n = n0 + tx;
+    if (n < N && c < C) y[((size_t)b * C + c) * N + n] = tile[tx][i];
+  }
+}
+
+__global__ void concat2_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb, size_t M,
+                               float* __restrict__ out) {
+  const int Ct = Ca + Cb;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * Ct) return;
+  const size_t m = t / Ct;
+  const int c = t % Ct;
+  out[t] = c < Ca ? a[m * Ca + c] : b[m * Cb + (c - Ca)];
+}
+
+}  // namespace
+
+extern "C" int spgan_knn(const float* x, int B, int N, int C, int k, int mode, int32_t* idx, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(x && idx && B > 0 && N > 1 && C > 0 && k > 0 && k <= 32 && k + 1 <= N);
+  SPGAN_CHECK_ARG(mode == 0 || (mode == 1 && C <= 4));
+  SPGAN_CHECK_ARG(mode == 1 || C <= 128);
+  if (k <= 10) return launch_knn<11>(x, B, N, C, k, mode, idx, s);
+  if (k <= 20) return launch_knn<21>(x, B, N, C, k, mode, idx, s);
+  return launch_knn<33>(x, B, N, C, k, mode, idx, s);
+}
+
+extern "C" int spgan_csr_build(const int32_t* idx, int B, int N, int k, int32_t* rowptr, int32_t* src, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(idx && rowptr && src && B > 0 && N > 0 && k > 0 && N <= 16384);
+  const size_t sh = (size_t)(2 * N + 32) * sizeof(int);
+  hipLaunchKernelGGL(csr_kernel, dim3(B), dim3(1024), sh, s, idx, N, k, rowptr, src);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_edge_features_cm(const float* x, const int64_t* idx, int B, int C, int N, int k, float* ee, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(x && idx && ee && B > 0 && C > 0 && N > 0 && k > 0);
+  const size_t per = (size_t)C * N * k;
+  hipLaunchKernelGGL(edge_features_cm_kernel, dim3(cdiv(per, 256), B), dim3(256), 0, s, x, idx, C, N, k, ee);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_idx_to_local64(const int32_t* idx, int B, int N, int k, int64_t* out, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(idx && out && B > 0 && N > 0 && k > 0);
+  const size_t total = (size_t)B * N * k;
+  hipLaunchKernelGGL(idx_to_local64_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, idx, N, total, (size_t)N * k, out);
+  return spgan_launch_status();
+}
+extern "C" int spgan_idx_from_local64(const int64_t* idx, int B, int N, int k, int32_t* out, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(idx && out && B > 0 && N > 0 && k > 0);
+  const size_t total = (size_t)B * N * k;
+  hipLaunchKernelGGL(idx_from_local64_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, idx, N, total, (size_t)N * k, out);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_cm_to_pm(const float* x, int B, int C, int N, float* y, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(x && y && B > 0 && C > 0 && N > 0);
+  hipLaunchKernelGGL(cm_to_pm_kernel, dim3(cdiv(N, 32), cdiv(C, 32), B), dim3(256), 0, s, x, C, N, y);
+  return spgan_launch_status();
+}
+extern "C" int spgan_pm_to_cm(const float* x, int B, int C, int N, float* y, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(x && y && B > 0 && C > 0 && N > 0);
+  hipLaunchKernelGGL(pm_to_cm_kernel, dim3(cdiv(N, 32), cdiv(C, 32), B), dim3(256), 0, s, x, C, N, y);
+  return spgan_launch_status();
+}
+extern "C" int spgan_concat2(const float* a, int Ca, const float* b, int Cb, int M, float* out, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(a && b && out && Ca > 0 && Cb > 0 && M > 0);
+  const size_t total = (size_t)M * (Ca + Cb);
+  hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a, Ca, b, Cb, (size_t)M, out);
+  return spgan_launch_status();
+}

@@ -1,0 +1,250 @@
+// Column reductions and the BatchNorm / max-pool bookkeeping around the MFMA contractions.
+// All of these are HBM-bound: lanes run along the channel dimension (coalesced rows of the
+// point-major tensors), row slices are combined through LDS in a fixed order (deterministic).
+#include "common.hpp"
+
+namespace {
+
+constexpr int RT = 128;  // rows per partial tile (== gemm_nt's BM, so fused and standalone partials share a format)
+
+// partials layout: [groups * tiles_per_group][C][2]
+// MODE 0: (sum, centred M2) of f(x);  MODE 1: (sum f(x), 0)
+template <int MODE>
+__global__ __launch_bounds__(256) void colpartials_kernel(const float* __restrict__ X, int ldx, int C, int G, int tiles_per_group,
+                                                          float slope, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int tile = blockIdx.x;
+  const int g = tile / tiles_per_group, q = tile % tiles_per_group;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int sl = threadIdx.x >> 6;
+  const int r0 = q * RT, cnt = min(RT, G - r0);
+  const float* base = X + ((size_t)g * G + r0) * ldx;
+  const bool cok = c < C;
+  float s = 0.f;
+  if (cok)
+    for (int r = sl; r < cnt; r += 4) s += lrelu_f(base[(size_t)r * ldx + c], slope);
+  red[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  const float tot = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63]) + (red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]);
+  float m2tot = 0.f;
+  if (MODE == 0) {
+    const float mean = tot / (float)cnt;
+    __syncthreads();
+    float m2 = 0.f;
+    if (cok)
+      for (int r = sl; r < cnt; r += 4) {
+        const float d = lrelu_f(base[(size_t)r * ldx + c], slope) - mean;
+        m2 = fmaf(d, d, m2);
+      }
+    red[sl][threadIdx.x & 63] = m2;
+    __syncthreads();
+    m2tot = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63]) + (red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]);
+  }
+  if (sl == 0 && cok) {
+    float* o = part + ((size_t)tile * C + c) * 2;
+    o[0] = tot;
+    o[1] = m2tot;
+  }
+}
+
+// Combine per-tile partials over the tiles of each group.  block = 16 slices x 16 columns.
+__global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restrict__ part, int tiles_per_group, int C, int G, int mode,
+                                                          float* __restrict__ out0, float* __restrict__ out1) {
+  __shared__ float sn[16][16], sa[16][16], sb[16][16];
+  const int g = blockIdx.y;
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool cok = c < C;
+  float n = 0.f, a = 0.f, b = 0.f;  // mode 0: (count, mean, M2); mode 1: (-, s0, s1)
+  if (cok) {
+    for (int t = sl; t < tiles_per_group; t += 16) {
+      const float* p = part + (((size_t)g * tiles_per_group + t) * C + c) * 2;
+      if (mode == 0) {
+        const float nb = (float)min(RT, G - t * RT);
+        const float mb = p[0] / nb, m2b = p[1];
+        const float nn = n + nb;
+        const float d = mb - a;
+        a = a + d * (nb / nn);
+        b = b + m2b + d * d * (n * nb / nn);
+        n = nn;
+      } else {
+        a += p[0];
+        b += p[1];
+      }
+    }
+  }
+  sn[sl][cl] = n; sa[sl][cl] = a; sb[sl][cl] = b;
+  __syncthreads();
+  for (int w = 8; w > 0; w >>= 1) {
+    if (sl < w) {
+      const float n2 = sn[sl + w][cl], a2 = sa[sl + w][cl], b2 = sb[sl + w][cl];
+      if (mode == 0) {
+        const float nn = n + n2;
+        if (nn > 0.f) {
+          const float d = a2 - a;
+          a = a + d * (n2 / nn);
+          b = b + b2 + d * d * (n * n2 / nn);
+        }
+        n = nn;
+      } else {
+        a += a2;
+        b += b2;
+      }
+      sn[sl][cl] = n; sa[sl][cl] = a; sb[sl][cl] = b;
+    }
+    __syncthreads();
+  }
+  if (sl == 0 && cok) {
+    out0[(size_t)g * C + c] = a;
+    out1[(size_t)g * C + c] = (mode == 0) ? b / (float)G : b;
+  }
+}
+
+__global__ void bn_prepare_kernel(const float* mean, const float* var, const float* gamma, const float* beta, int C, int count,
+                                  float eps, float momentum, int training, float* rmean, float* rvar, float* scale, float* shift,
+                                  float* invstd, float* mean_used) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float m, v;
+  if (training) {
+    m = mean[c];
+    v = var[c];
+    if (rmean) {
+      const float unb = count > 1 ? v * ((float)count / (float)(count - 1)) : v;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+  } else {
+    m = rmean[c];
+    v = rvar[c];
+  }
+  const float inv = 1.0f / sqrtf(v + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * inv;
+  scale[c] = sc;
+  shift[c] = b - m * sc;
+  invstd[c] = inv;
+  mean_used[c] = m;
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y, int ld, size_t M, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sums, float rcount, float* __restrict__ dy) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * C) return;
+  const size_t m = t / C;
+  const int c = t % C;
+  const float inv = invstd[c];
+  const float xh = (y[m * ld + c] - mean[c]) * inv;
+  const float ga = gamma ? gamma[c] : 1.f;
+  dy[m * ld + c] = ga * inv * (g[m * ld + c] - sums[c] * rcount - xh * (sums[C + c] * rcount));
+}
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ y, int ld, int N, int C, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, float slope, float* __restrict__ out,
+                                                      int32_t* __restrict__ argmax) {
+  __shared__ float rv[4][64];
+  __shared__ int ri[4][64];
+  const int b = blockIdx.x;
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const bool cok = c < C;
+  const float sc = (cok && scale) ? scale[c] : 1.f, sh = (cok && shift) ? shift[c] : 0.f;
+  const float* base = y + (size_t)b * N * ld;
+  float best = -INFINITY;
+  int bi = 0;
+  if (cok)
+    for (int n = sl; n < N; n += 4) {
+      const float v = lrelu_f(fmaf(base[(size_t)n * ld + c], sc, sh), slope);
+      if (v > best) {
+        best = v;
+        bi = n;
+      }
+    }
+  rv[sl][cl] = best;
+  ri[sl][cl] = bi;
+  __syncthreads();
+  if (sl == 0 && cok) {
+#pragma unroll
+    for (int s2 = 1; s2 < 4; ++s2) {
+      const float v = rv[s2][cl];
+      const int i2 = ri[s2][cl];
+      if (v > best || (v == best && i2 < bi)) {
+        best = v;
+        bi = i2;
+      }
+    }
+    out[(size_t)b * C + c] = best;
+    if (argmax) argmax[(size_t)b * C + c] = b * N + bi;  // global row index
+  }
+}
+
+}  // namespace
+
+extern "C" size_t spgan_colreduce_ws_bytes(int M, int C, int G) {
+  if (M <= 0 || C <= 0 || G <= 0) return 0;
+  const size_t groups = M / G;
+  return groups * (size_t)cdiv(G, RT) * C * 2 * sizeof(float);
+}
+
+extern "C" int spgan_colstats_finalize(const float* partials, int groups, int tiles_per_group, int C, int G, int mode, float* out0,
+                                       float* out1, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(partials && out0 && out1 && groups > 0 && tiles_per_group > 0 && C > 0 && G > 0 && (mode == 0 || mode == 1));
+  SPGAN_CHECK_ARG(tiles_per_group == cdiv(G, RT));
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, partials, tiles_per_group, C, G, mode, out0, out1);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_colstats(const float* X, int ldx, int M, int C, int G, float slope, float* out_mean, float* out_var, float* ws,
+                              size_t ws_bytes, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(X && out_mean && out_var && ws && M > 0 && C > 0 && G > 0 && M % G == 0 && ldx >= C);
+  SPGAN_CHECK_ARG(ws_bytes >= spgan_colreduce_ws_bytes(M, C, G));
+  const int groups = M / G, tpg = cdiv(G, RT);
+  hipLaunchKernelGGL((colpartials_kernel<0>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, slope, ws);
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, tpg, C, G, 0, out_mean, out_var);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_colsum(const float* X, int ldx, int M, int C, int G, float* out, float* ws, size_t ws_bytes, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(X && out && ws && M > 0 && C > 0 && G > 0 && M % G == 0 && ldx >= C);
+  const int groups = M / G, tpg = cdiv(G, RT);
+  // ws: partials + a scratch row block for the unused second output
+  SPGAN_CHECK_ARG(ws_bytes >= spgan_colreduce_ws_bytes(M, C, G) + (size_t)groups * C * sizeof(float));
+  float* scratch = ws + (size_t)groups * tpg * C * 2;
+  hipLaunchKernelGGL((colpartials_kernel<1>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, 1.0f, ws);
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, tpg, C, G, 1, out, scratch);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_bn_prepare(const float* mean, const float* var, const float* gamma, const float* beta, int C, int count, float eps,
+                                float momentum, int training, float* running_mean, float* running_var, float* scale, float* shift,
+                                float* invstd, float* mean_used, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(scale && shift && invstd && mean_used && C > 0 && count > 0);
+  if (training) SPGAN_CHECK_ARG(mean && var && ((running_mean == nullptr) == (running_var == nullptr)));
+  else SPGAN_CHECK_ARG(running_mean && running_var);
+  hipLaunchKernelGGL(bn_prepare_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, mean, var, gamma, beta, C, count, eps, momentum, training,
+                     running_mean, running_var, scale, shift, invstd, mean_used);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_bn_bwd_apply(const float* g, const float* y, int ld, int M, int C, const float* mean, const float* invstd,
+                                  const float* gamma, const float* sums, int count, float* dy, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(g && y && dy && mean && invstd && sums && M > 0 && C > 0 && ld >= C && count > 0);
+  const size_t total = (size_t)M * C;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, g, y, ld, (size_t)M, C, mean, invstd, gamma, sums,
+                     1.0f / (float)count, dy);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_maxpool(const float* y, int ld, int B, int N, int C, const float* scale, const float* shift, float slope, float* out,
+                             int32_t* argmax, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(y && out && B > 0 && N > 0 && C > 0 && ld >= C);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(B, cdiv(C, 64)), dim3(256), 0, s, y, ld, N, C, scale, shift, slope, out, argmax);
+  return spgan_launch_status();
+}

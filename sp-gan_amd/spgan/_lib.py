@@ -1,0 +1,112 @@
+"""ctypes binding of libspgan_hip.so (the C ABI declared in include/spgan_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or does not export a
+symbol, importing/using the ops raises.  A CPU path for these ops does not exist in the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspgan_hip.so")
+
+c_f32p = C.c_void_p     # device pointers travel as integers
+c_i32p = C.c_void_p
+c_i64p = C.c_void_p
+stream_t = C.c_void_p
+
+
+class GemmNTArgs(C.Structure):
+    _fields_ = [
+        ("A", c_f32p), ("lda", C.c_int),
+        ("W", c_f32p), ("ldw", C.c_int),
+        ("Y", c_f32p), ("ldy", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("a_mode", C.c_int),
+        ("p_scale", c_f32p), ("p_shift", c_f32p), ("p_slope", C.c_float),
+        ("e_idx", c_i32p), ("e_k", C.c_int), ("e_bias", c_f32p),
+        ("epi_mode", C.c_int),
+        ("bias", c_f32p), ("rowbias", c_f32p), ("rows_per_group", C.c_int), ("ld_rowbias", C.c_int),
+        ("act", C.c_int), ("act_slope", C.c_float),
+        ("stats", c_f32p),
+        ("ref", c_f32p), ("ld_ref", C.c_int),
+        ("b_scale", c_f32p), ("b_shift", c_f32p), ("b_mean", c_f32p), ("b_invstd", c_f32p), ("b_slope", C.c_float),
+        ("e_bias2", c_f32p),
+    ]
+
+
+class GemmTNArgs(C.Structure):
+    _fields_ = [
+        ("A", c_f32p), ("lda", C.c_int),
+        ("B", c_f32p), ("ldb", C.c_int),
+        ("C", c_f32p), ("ldc", C.c_int),
+        ("M", C.c_int), ("Na", C.c_int), ("Nb", C.c_int),
+        ("b_mode", C.c_int),
+        ("p_scale", c_f32p), ("p_shift", c_f32p), ("p_slope", C.c_float),
+        ("e_idx", c_i32p), ("e_k", C.c_int), ("e_bias", c_f32p),
+        ("beta", C.c_float),
+        ("ws", c_f32p), ("ws_bytes", C.c_size_t),
+    ]
+
+
+I, F, P, SZ = C.c_int, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol include/spgan_hip.h declares
+# (tests/test_abi.py cross-checks this table against the header and the .so).
+SIGNATURES = {
+    "spgan_version": (I, []),
+    "spgan_arch": (C.c_char_p, []),
+    "spgan_knn": (I, [P, I, I, I, I, I, P, P]),
+    "spgan_csr_build": (I, [P, I, I, I, P, P, P]),
+    "spgan_edge_features_cm": (I, [P, P, I, I, I, I, P, P]),
+    "spgan_idx_to_local64": (I, [P, I, I, I, P, P]),
+    "spgan_idx_from_local64": (I, [P, I, I, I, P, P]),
+    "spgan_cm_to_pm": (I, [P, I, I, I, P, P]),
+    "spgan_pm_to_cm": (I, [P, I, I, I, P, P]),
+    "spgan_concat2": (I, [P, I, P, I, I, P, P]),
+    "spgan_gemm_nt": (I, [C.POINTER(GemmNTArgs), P]),
+    "spgan_gemm_tn_ws_bytes": (SZ, [I, I, I]),
+    "spgan_gemm_tn": (I, [C.POINTER(GemmTNArgs), P]),
+    "spgan_colreduce_ws_bytes": (SZ, [I, I, I]),
+    "spgan_colstats_finalize": (I, [P, I, I, I, I, I, P, P, P]),
+    "spgan_colstats": (I, [P, I, I, I, I, F, P, P, P, SZ, P]),
+    "spgan_colsum": (I, [P, I, I, I, I, P, P, SZ, P]),
+    "spgan_bn_prepare": (I, [P, P, P, P, I, I, F, F, I, P, P, P, P, P, P, P]),
+    "spgan_bn_bwd_apply": (I, [P, P, I, I, I, P, P, P, P, I, P, P]),
+    "spgan_maxpool": (I, [P, I, I, I, I, P, P, F, P, P, P]),
+}
+
+_lib = None
+
+
+class SpganLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libspgan_hip.so and type every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpganLibraryError(
+            "libspgan_hip.so not found at %s -- build it with `make -C sp-gan_amd` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SpganLibraryError("libspgan_hip.so does not export %s" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str, **shapes):
+    """Status -> exception (SURVEY 8(b) error convention: no exit(-1), no silent failure)."""
+    if status != 0:
+        detail = ", ".join("%s=%s" % kv for kv in shapes.items())
+        raise RuntimeError("spgan HIP op %s failed with status %d (%s)" % (what, status, detail))

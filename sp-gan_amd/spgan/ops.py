@@ -1,0 +1,344 @@
+"""Tensor-level wrappers of the C ABI (include/spgan_hip.h).
+
+Each function validates its arguments (device, dtype, layout -- the reference's CHECK_INPUT,
+metrics/pointops/src/knnquery/knnquery_cuda.cpp:10-18), allocates outputs/workspace through
+PyTorch's caching allocator, and launches on the *current* torch HIP stream.  Native code keeps
+no pointers after return.  PyTorch is only memory + stream plumbing here.
+
+Shapes: "pm" = point-major [M, C]; idx = int32 [M, k] global row ids.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GemmNTArgs, GemmTNArgs, check
+
+A_PLAIN, A_AFFINE_LRELU, A_EDGE = 0, 1, 2
+EPI_LINEAR, EPI_MASK_OUT, EPI_BNBWD, EPI_EDGE_BNBWD = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+ROW_TILE = 128
+
+Tensor = torch.Tensor
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t: Tensor, name: str, dims: Optional[int] = None) -> Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (spgan has no CPU path); got device %s" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if dims is not None and t.dim() != dims:
+        raise ValueError("%s must be %d-D, got shape %s" % (name, dims, tuple(t.shape)))
+    return t
+
+
+def _rowmajor2d(t: Tensor, name: str) -> Tensor:
+    """2-D, unit column stride (row stride may exceed the width: column slices are fine)."""
+    _f32(t, name, 2)
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError("%s must have unit column stride, got strides %s" % (name, t.stride()))
+    return t
+
+
+def _vec(t: Optional[Tensor], n: int, name: str) -> Optional[Tensor]:
+    if t is None:
+        return None
+    _f32(t, name)
+    if not t.is_contiguous() or t.numel() != n:
+        raise ValueError("%s must be contiguous with %d elements, got %s" % (name, n, tuple(t.shape)))
+    return t
+
+
+def _i32(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
+        raise TypeError("%s must be a contiguous int32 GPU tensor" % name)
+    return t
+
+
+def _ld(t: Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+# ----------------------------------------------------------------------------- graph
+def knn(x_pm: Tensor, B: int, N: int, k: int, mode: int = 0) -> Tensor:
+    """x_pm [B*N, C] -> idx int32 [B*N, k] (global rows), sorted ascending, rank 0 dropped.
+    mode 1 = fp64 direct differences (coordinate inputs, C<=4)."""
+    _f32(x_pm, "x_pm", 2)
+    if not x_pm.is_contiguous() or x_pm.shape[0] != B * N:
+        raise ValueError("x_pm must be contiguous [B*N, C]")
+    idx = torch.empty((B * N, k), dtype=torch.int32, device=x_pm.device)
+    check(_lib.load().spgan_knn(_p(x_pm), B, N, x_pm.shape[1], k, mode, _p(idx), _s()), "knn", B=B, N=N, C=x_pm.shape[1], k=k)
+    return idx
+
+
+def csr_build(idx: Tensor, B: int, N: int) -> Tuple[Tensor, Tensor]:
+    _i32(idx, "idx")
+    k = idx.shape[1]
+    rowptr = torch.empty((B * N + 1,), dtype=torch.int32, device=idx.device)
+    src = torch.empty((B * N * k,), dtype=torch.int32, device=idx.device)
+    check(_lib.load().spgan_csr_build(_p(idx), B, N, k, _p(rowptr), _p(src), _s()), "csr_build", B=B, N=N, k=k)
+    return rowptr, src
+
+
+def edge_features_cm(x_cm: Tensor, idx_local: Tensor, k: int) -> Tensor:
+    _f32(x_cm, "x", 3)
+    B, Cc, N = x_cm.shape
+    if not x_cm.is_contiguous():
+        raise ValueError("x must be contiguous [B,C,N]")
+    if idx_local.dtype != torch.int64 or not idx_local.is_contiguous() or idx_local.numel() != B * N * k:
+        raise ValueError("idx must be contiguous int64 with B*N*k elements")
+    ee = torch.empty((B, 2 * Cc, N, k), dtype=torch.float32, device=x_cm.device)
+    check(_lib.load().spgan_edge_features_cm(_p(x_cm), _p(idx_local), B, Cc, N, k, _p(ee), _s()), "edge_features", B=B, C=Cc, N=N, k=k)
+    return ee
+
+
+def idx_to_local64(idx: Tensor, B: int, N: int) -> Tensor:
+    _i32(idx, "idx")
+    k = idx.shape[1]
+    out = torch.empty((B, N * k), dtype=torch.int64, device=idx.device)
+    check(_lib.load().spgan_idx_to_local64(_p(idx), B, N, k, _p(out), _s()), "idx_to_local64")
+    return out
+
+
+def idx_from_local64(idx_local: Tensor, B: int, N: int, k: int) -> Tensor:
+    if idx_local.dtype != torch.int64 or not idx_local.is_cuda:
+        raise TypeError("idx must be an int64 GPU tensor")
+    idx_local = idx_local.contiguous()
+    out = torch.empty((B * N, k), dtype=torch.int32, device=idx_local.device)
+    check(_lib.load().spgan_idx_from_local64(_p(idx_local), B, N, k, _p(out), _s()), "idx_from_local64")
+    return out
+
+
+# ----------------------------------------------------------------------------- layout
+def cm_to_pm(x_cm: Tensor) -> Tensor:
+    _f32(x_cm, "x", 3)
+    x_cm = x_cm.contiguous()
+    B, Cc, N = x_cm.shape
+    y = torch.empty((B * N, Cc), dtype=torch.float32, device=x_cm.device)
+    check(_lib.load().spgan_cm_to_pm(_p(x_cm), B, Cc, N, _p(y), _s()), "cm_to_pm")
+    return y
+
+
+def pm_to_cm(x_pm: Tensor, B: int, N: int) -> Tensor:
+    _f32(x_pm, "x", 2)
+    x_pm = x_pm.contiguous()
+    Cc = x_pm.shape[1]
+    y = torch.empty((B, Cc, N), dtype=torch.float32, device=x_pm.device)
+    check(_lib.load().spgan_pm_to_cm(_p(x_pm), B, Cc, N, _p(y), _s()), "pm_to_cm")
+    return y
+
+
+def concat2(a: Tensor, b: Tensor) -> Tensor:
+    _f32(a, "a", 2); _f32(b, "b", 2)
+    a = a.contiguous(); b = b.contiguous()
+    M = a.shape[0]
+    out = torch.empty((M, a.shape[1] + b.shape[1]), dtype=torch.float32, device=a.device)
+    check(_lib.load().spgan_concat2(_p(a), a.shape[1], _p(b), b.shape[1], M, _p(out), _s()), "concat2")
+    return out
+
+
+# ----------------------------------------------------------------------------- contractions
+def _finalize(partials: Tensor, groups: int, tpg: int, Cn: int, G: int, mode: int) -> Tuple[Tensor, Tensor]:
+    out = torch.empty((2, groups, Cn), dtype=torch.float32, device=partials.device)
+    check(_lib.load().spgan_colstats_finalize(_p(partials), groups, tpg, Cn, G, mode, _p(out[0]), _p(out[1]), _s()), "colstats_finalize")
+    return out[0], out[1]
+
+
+def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, edge=None, rowbias: Optional[Tensor] = None,
+            rows_per_group: int = 0, act: int = ACT_NONE, slope: float = 0.0, stats: bool = False, M: Optional[int] = None):
+    """Y[M,N] = act( pro(A) @ W^T + bias + rowbias[m // rows_per_group] ).
+    pro  = (scale[K], shift[K], slope): operand a = lrelu(A*scale+shift)            (A_AFFINE_LRELU)
+    edge = (idx[M,k], ebias[K]) with pro: rows are edges, a = lrelu((A[j]-A[i]+ebias)*scale+shift)  (A_EDGE)
+    stats=True additionally returns (mean[N], biased var[N]) of the pre-activation output over all M rows."""
+    _rowmajor2d(A, "A"); _rowmajor2d(W, "W")
+    N, K = W.shape
+    a = GemmNTArgs()
+    if edge is not None:
+        idx, ebias = edge
+        _i32(idx, "idx")
+        if pro is None:
+            raise ValueError("edge operand needs pro=(scale, shift, slope)")
+        M_ = idx.shape[0] * idx.shape[1]
+        a.a_mode = A_EDGE; a.e_idx = _p(idx); a.e_k = idx.shape[1]; a.e_bias = _p(_vec(ebias, K, "ebias"))
+    else:
+        M_ = A.shape[0] if M is None else M
+        a.a_mode = A_PLAIN if pro is None else A_AFFINE_LRELU
+    if A.shape[1] != K:
+        raise ValueError("A has %d columns but W has K=%d" % (A.shape[1], K))
+    if pro is not None:
+        sc, sh, ps = pro
+        a.p_scale = _p(_vec(sc, K, "pro.scale")); a.p_shift = _p(_vec(sh, K, "pro.shift")); a.p_slope = float(ps)
+    Y = torch.empty((M_, N), dtype=torch.float32, device=A.device)
+    a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W); a.Y = _p(Y); a.ldy = N
+    a.M, a.N, a.K = M_, N, K
+    a.epi_mode = EPI_LINEAR
+    a.bias = _p(_vec(bias, N, "bias"))
+    if rowbias is not None:
+        _rowmajor2d(rowbias, "rowbias")
+        if rows_per_group <= 0 or rowbias.shape[1] != N or rowbias.shape[0] * rows_per_group < M_:
+            raise ValueError("rowbias [%s] does not cover M=%d rows in groups of %d" % (tuple(rowbias.shape), M_, rows_per_group))
+        a.rowbias = _p(rowbias); a.rows_per_group = rows_per_group; a.ld_rowbias = _ld(rowbias)
+    a.act = act; a.act_slope = float(slope)
+    part = None
+    if stats:
+        tiles = (M_ + ROW_TILE - 1) // ROW_TILE
+        part = torch.empty((tiles, N, 2), dtype=torch.float32, device=A.device)
+        a.stats = _p(part)
+    check(_lib.load().spgan_gemm_nt(C.byref(a), _s()), "gemm_nt", M=M_, N=N, K=K, a_mode=a.a_mode)
+    if stats:
+        mean, var = _finalize(part, 1, part.shape[0], N, M_, 0)
+        return Y, mean[0], var[0]
+    return Y
+
+
+def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float) -> Tensor:
+    """Y = (A @ W^T) * (ref > 0 ? 1 : slope): input-gradient through an (in-place) LeakyReLU whose output `ref` was saved."""
+    _rowmajor2d(A, "A"); _rowmajor2d(W, "W"); _rowmajor2d(ref, "ref")
+    N, K = W.shape
+    M_ = A.shape[0]
+    Y = torch.empty((M_, N), dtype=torch.float32, device=A.device)
+    a = GemmNTArgs()
+    a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W); a.Y = _p(Y); a.ldy = N
+    a.M, a.N, a.K = M_, N, K
+    a.a_mode = A_PLAIN; a.epi_mode = EPI_MASK_OUT
+    a.ref = _p(ref); a.ld_ref = _ld(ref); a.b_slope = float(slope)
+    check(_lib.load().spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_maskout", M=M_, N=N, K=K)
+    return Y
+
+
+def gemm_nt_bnbwd(A: Tensor, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float,
+                  edge=None):
+    """g = (A @ W^T) * lrelu'(z), z = y*scale+shift; returns (g, sum_c g, sum_c g*xhat), xhat = (y-mean)*invstd.
+    With edge=(idx, ebias) y is the per-edge difference y[e] = P[idx[e]] - P[i] + ebias of the point tensor P=y_ref."""
+    _rowmajor2d(A, "A"); _rowmajor2d(W, "W"); _rowmajor2d(y_ref, "y_ref")
+    N, K = W.shape
+    M_ = A.shape[0]
+    g = torch.empty((M_, N), dtype=torch.float32, device=A.device)
+    tiles = (M_ + ROW_TILE - 1) // ROW_TILE
+    part = torch.empty((tiles, N, 2), dtype=torch.float32, device=A.device)
+    a = GemmNTArgs()
+    a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W); a.Y = _p(g); a.ldy = N
+    a.M, a.N, a.K = M_, N, K
+    a.a_mode = A_PLAIN
+    a.ref = _p(y_ref); a.ld_ref = _ld(y_ref)
+    a.b_scale = _p(_vec(scale, N, "scale")); a.b_shift = _p(_vec(shift, N, "shift"))
+    a.b_mean = _p(_vec(mean, N, "mean")); a.b_invstd = _p(_vec(invstd, N, "invstd")); a.b_slope = float(slope)
+    a.stats = _p(part)
+    if edge is None:
+        a.epi_mode = EPI_BNBWD
+    else:
+        idx, ebias = edge
+        _i32(idx, "idx")
+        a.epi_mode = EPI_EDGE_BNBWD; a.e_idx = _p(idx); a.e_k = idx.shape[1]; a.e_bias2 = _p(_vec(ebias, N, "ebias"))
+    check(_lib.load().spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_bnbwd", M=M_, N=N, K=K)
+    s0, s1 = _finalize(part, 1, tiles, N, M_, 1)
+    return g, s0[0], s1[0]
+
+
+def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor] = None, beta: float = 0.0) -> Tensor:
+    """C[Na,Nb] = beta*C + A^T @ pro(Bm): weight gradient, reduction over the M rows (points or edges)."""
+    _rowmajor2d(A, "A"); _rowmajor2d(Bm, "B")
+    M_, Na = A.shape
+    Nb = Bm.shape[1]
+    a = GemmTNArgs()
+    if edge is not None:
+        idx, ebias = edge
+        _i32(idx, "idx")
+        if idx.shape[0] * idx.shape[1] != M_ or pro is None:
+            raise ValueError("edge operand: A must have one row per edge and pro must be given")
+        a.b_mode = A_EDGE; a.e_idx = _p(idx); a.e_k = idx.shape[1]; a.e_bias = _p(_vec(ebias, Nb, "ebias"))
+    else:
+        if Bm.shape[0] != M_:
+            raise ValueError("A and B disagree on the reduction length: %d vs %d" % (M_, Bm.shape[0]))
+        a.b_mode = A_PLAIN if pro is None else A_AFFINE_LRELU
+    if pro is not None:
+        sc, sh, ps = pro
+        a.p_scale = _p(_vec(sc, Nb, "pro.scale")); a.p_shift = _p(_vec(sh, Nb, "pro.shift")); a.p_slope = float(ps)
+    if out is None:
+        out = torch.empty((Na, Nb), dtype=torch.float32, device=A.device)
+        beta = 0.0
+    else:
+        _rowmajor2d(out, "out")
+    lib = _lib.load()
+    wsb = lib.spgan_gemm_tn_ws_bytes(M_, Na, Nb)
+    ws = torch.empty((wsb // 4,), dtype=torch.float32, device=A.device)
+    a.A = _p(A); a.lda = _ld(A); a.B = _p(Bm); a.ldb = _ld(Bm); a.C = _p(out); a.ldc = _ld(out)
+    a.M, a.Na, a.Nb = M_, Na, Nb
+    a.beta = float(beta); a.ws = _p(ws); a.ws_bytes = wsb
+    check(lib.spgan_gemm_tn(C.byref(a), _s()), "gemm_tn", M=M_, Na=Na, Nb=Nb)
+    return out
+
+
+# ----------------------------------------------------------------------------- reductions / norms
+def colstats(X: Tensor, G: int, slope: float = 1.0) -> Tuple[Tensor, Tensor]:
+    """mean / biased var of lrelu(X, slope) over each group of G rows -> ([M/G, C], [M/G, C])."""
+    _rowmajor2d(X, "X")
+    M_, Cn = X.shape
+    lib = _lib.load()
+    wsb = lib.spgan_colreduce_ws_bytes(M_, Cn, G)
+    ws = torch.empty((wsb // 4,), dtype=torch.float32, device=X.device)
+    out = torch.empty((2, M_ // G, Cn), dtype=torch.float32, device=X.device)
+    check(lib.spgan_colstats(_p(X), _ld(X), M_, Cn, G, float(slope), _p(out[0]), _p(out[1]), _p(ws), wsb, _s()), "colstats", M=M_, C=Cn, G=G)
+    return out[0], out[1]
+
+
+def colsum(X: Tensor, G: Optional[int] = None) -> Tensor:
+    """Column sums over each group of G rows (default: all rows) -> [M/G, C]."""
+    _rowmajor2d(X, "X")
+    M_, Cn = X.shape
+    G = M_ if G is None else G
+    lib = _lib.load()
+    wsb = lib.spgan_colreduce_ws_bytes(M_, Cn, G) + (M_ // G) * Cn * 4
+    ws = torch.empty((wsb // 4,), dtype=torch.float32, device=X.device)
+    out = torch.empty((M_ // G, Cn), dtype=torch.float32, device=X.device)
+    check(lib.spgan_colsum(_p(X), _ld(X), M_, Cn, G, _p(out), _p(ws), wsb, _s()), "colsum", M=M_, C=Cn, G=G)
+    return out
+
+
+def bn_prepare(mean: Optional[Tensor], var: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor], count: int,
+               training: bool = True, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
+               momentum: float = BN_MOMENTUM, eps: float = BN_EPS):
+    """-> (scale, shift, invstd, mean_used) each [C]; updates the running statistics in place (train mode)."""
+    ref = mean if mean is not None else running_mean
+    Cn = ref.numel()
+    out = torch.empty((4, Cn), dtype=torch.float32, device=ref.device)
+    check(_lib.load().spgan_bn_prepare(_p(mean), _p(var), _p(gamma), _p(beta), Cn, count, eps, momentum, 1 if training else 0,
+                                       _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _s()),
+          "bn_prepare", C=Cn)
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_bwd_apply(g: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Optional[Tensor], sums: Tensor, count: int) -> Tensor:
+    """dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count);  sums = [sum_g | sum_gx] (2C)."""
+    _f32(g, "g", 2); _f32(y, "y", 2)
+    if not (g.is_contiguous() and y.is_contiguous()) or g.shape != y.shape:
+        raise ValueError("g and y must be contiguous with equal shapes")
+    M_, Cn = g.shape
+    dy = torch.empty_like(g)
+    check(_lib.load().spgan_bn_bwd_apply(_p(g), _p(y), Cn, M_, Cn, _p(mean), _p(invstd), _p(gamma), _p(_vec(sums, 2 * Cn, "sums")),
+                                         count, _p(dy), _s()), "bn_bwd_apply", M=M_, C=Cn)
+    return dy
+
+
+def maxpool(y: Tensor, B: int, N: int, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, slope: float = 1.0):
+    """out[b,c] = max_n lrelu(y[b*N+n,c]*scale[c]+shift[c], slope); argmax = global row index (int32)."""
+    _rowmajor2d(y, "y")
+    Cn = y.shape[1]
+    out = torch.empty((B, Cn), dtype=torch.float32, device=y.device)
+    arg = torch.empty((B, Cn), dtype=torch.int32, device=y.device)
+    check(_lib.load().spgan_maxpool(_p(y), _ld(y), B, N, Cn, _p(scale), _p(shift), float(slope), _p(out), _p(arg), _s()), "maxpool", B=B, N=N, C=Cn)
+    return out, arg

@@ -276,7 +276,7 @@ def g7():
 
 # ---------------------------------------------------------------- G8: one full D-step + G-step
 def g8():
-    for tag, gan, use_gp, B, N in (("ls", "ls", False, 4, 512), ("wgangp", "wgan", True, 2, 256)):
+    for tag, gan, use_gp, B, N in (("ls", "ls", False, 4, 512), ("wgangp", "wgan", True, 4, 256)):
         d = {}
         G, D = make_gd(salt=8)
         optG = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.99))

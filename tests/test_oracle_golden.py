@@ -185,7 +185,7 @@ def test_gradient_penalty():
 
 
 # ---------------------------------------------------------------- G8
-@pytest.mark.parametrize("tag,gan,use_gp,B,N", [("ls", "ls", False, 4, 512), ("wgangp", "wgan", True, 2, 256)])
+@pytest.mark.parametrize("tag,gan,use_gp,B,N", [("ls", "ls", False, 4, 512), ("wgangp", "wgan", True, 4, 256)])
 def test_train_step(tag, gan, use_gp, B, N):
     d = golden("g8_train_step_%s.npz" % tag)
     gp_ = params_from(orc.generator_shapes(), 8, requires_grad=True)
