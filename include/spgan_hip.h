@@ -135,7 +135,7 @@ int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s);
  * Everything is combined in a fixed order: results are run-to-run deterministic. */
 size_t spgan_colreduce_ws_bytes(int M, int C, int G);
 int spgan_colstats_finalize(const float* partials, int groups, int tiles_per_group, int C, int G, int mode,
-                            float* out0, float* out1, spgan_stream_t s);
+                            int tile_rows /* 0 -> 128 */, float* out0, float* out1, spgan_stream_t s);
 /* mean / biased variance over each group of lrelu(X, slope) (slope = 1: plain).  InstanceNorm1d statistics of
  * AdaptivePointNorm (Generator.py:29,42) with G = N; BatchNorm statistics with G = M.  ws >= spgan_colreduce_ws_bytes. */
 int spgan_colstats(const float* X, int ldx, int M, int C, int G, float slope, float* out_mean, float* out_var,
@@ -164,6 +164,101 @@ int spgan_bn_bwd_apply(const float* g, const float* y, int ld, int M, int C, con
  * ---------------------------------------------------------------------------------------- */
 int spgan_maxpool(const float* y, int ld, int B, int N, int C, const float* scale, const float* shift, float slope,
                   float* out, int32_t* argmax, spgan_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * EdgeBlock (Generation/Generator.py:47-88), restructured per point:
+ *   conv_w.0(x_j - x_i) = (P_j - P_i) + b1,  conv_x.0([x_i, x_j-x_i]) = (R_i + Q_j) + bx,
+ *   PQR[M, H+2F] = x . Wcat^T,  Wcat = [W1; Wd; Wc-Wd],  Wx = [Wc | Wd],  H = F/2.
+ * ---------------------------------------------------------------------------------------- */
+int spgan_edge_wcat(const float* Ww0 /*[H,C]*/, const float* Wx /*[F,2C]*/, int H, int F, int C, float* Wcat, spgan_stream_t s);
+int spgan_edge_wcat_bwd(const float* dWcat, int H, int F, int C, float* dWw0, float* dWx, spgan_stream_t s);
+/* BatchNorm2d statistics over the M*k edges of both per-edge pre-activations (Generator.py:58,67):
+ * partials [ceil(M/32)][H+F][2] in the finalize-mode-0 format with tile_rows = spgan_edge_stats_tile_rows(k). */
+int spgan_edge_stats_tile_rows(int k);
+int spgan_edge_stats(const float* PQR, int ld, const int32_t* idx, int M, int k, int H, int F, const float* b1, const float* bx,
+                     float* partials, spgan_stream_t s);
+/* T[i, r*F+f] = softmax_r(lrelu(h2pre[i,r,f]*sc2+sh2)) * lrelu(((R_i+Q_j)+bx)*scx+shx)    (Generator.py:79,81-82) */
+int spgan_edge_attend_fwd(const float* h2pre, const float* sc2, const float* sh2, const float* PQR, int ld, int H, int F,
+                          const int32_t* idx, int M, int k, const float* bx, const float* scx, const float* shx, float slope,
+                          float* T, spgan_stream_t s);
+/* Backward of edge_attend: g2/gy = gradients w.r.t. the two BatchNorm outputs, and plain-sum partials
+ * [ceil(M/spgan_edge_attend_bwd_tile_points())][2F][2]: col f -> (sum g2, sum g2*xhat2), col F+f -> (sum gy, sum gy*xhaty). */
+int spgan_edge_attend_bwd_tile_points(void);
+int spgan_edge_attend_bwd(const float* dT, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
+                          const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k,
+                          const float* bx, const float* scx, const float* shx, const float* meanx, const float* invx,
+                          float slope, float* g2, float* gy, float* partials, spgan_stream_t s);
+/* BatchNorm backward of both per-edge pre-activations fused with the reduction onto points (gather over the CSR
+ * in-edge lists; the backward obligation of modules.py:708-720): dPQR[M, H+2F]. sums* = [sum g | sum g*xhat]. */
+int spgan_edge_scatter(const float* g1, const float* gy, const float* PQR, int ld, int H, int F, const int32_t* idx,
+                       const int32_t* rowptr, const int32_t* src, int M, int k, const float* b1, const float* mean1,
+                       const float* inv1, const float* gam1, const float* sums1, const float* bx, const float* meanx,
+                       const float* invx, const float* gamx, const float* sumsx, float* dPQR, spgan_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * AdaptivePointNorm (Generator.py:24-45): out = gamma*xhat + beta with xhat = InstanceNorm1d(lrelu(x, slope))
+ * (eps 1e-5, biased variance over the N points of each shape; slope = 1 for the bare module, 0.2 when the
+ * Generator's lrelu1/lrelu2 is fused in, Generator.py:175-176,179-180) and [gamma|beta] = gb[M,2C].
+ * ---------------------------------------------------------------------------------------- */
+int spgan_adain_fwd(const float* x, int M, int C, int N, float slope, const float* imean, const float* ivar, float eps,
+                    const float* gb, float* out, spgan_stream_t s);
+/* dgb = [dout*xhat | dout]; partials [(M/N)*ceil(N/128)][C][2] = (sum dxh, sum dxh*xhat), dxh = dout*gamma (finalize mode 1) */
+int spgan_adain_bwd1(const float* dout, const float* x, int M, int C, int N, float slope, const float* imean, const float* ivar,
+                     float eps, const float* gb, float* dgb, float* partials, spgan_stream_t s);
+int spgan_adain_bwd2(const float* dout, const float* x, int M, int C, int N, float slope, const float* imean, const float* ivar,
+                     float eps, const float* gb, const float* S0, const float* S1, float* dx, spgan_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward through [BatchNorm1d -> LeakyReLU -> global max over N] (Discriminator.py:77-81,104): the incoming
+ * gradient is non-zero only at the arg-max rows, the BatchNorm backward makes it dense again.
+ * ---------------------------------------------------------------------------------------- */
+int spgan_pool_bwd_stats(const float* gpool, const float* pooled, const int32_t* argmax, const float* y, int ld, const float* mean,
+                         const float* invstd, float slope, int B, int C, float* gval, float* sums /*[2C]*/, spgan_stream_t s);
+int spgan_bn_bwd_apply_sparse(const float* gval, const int32_t* argmax, const float* y, int ld, int M, int C, int N,
+                              const float* mean, const float* invstd, const float* gamma, const float* sums, int count, float* dy,
+                              spgan_stream_t s);
+/* dst[argmax[b,c], c] += dpool[b,c]   (torch.max backward, Generator.py:183) */
+int spgan_maxpool_bwd_add(const float* dpool, const int32_t* argmax, int B, int C, float* dst, int ld, spgan_stream_t s);
+int spgan_tanh_bwd(const float* dy, const float* y, size_t n, float* out, spgan_stream_t s);
+/* out = dy * act'(y) from the activation OUTPUT y (act = SPGAN_ACT_*; in-place LeakyReLU semantics, Generator.py:110-133) */
+int spgan_act_bwd(const float* dy, const float* y, size_t n, int act, float slope, float* out, spgan_stream_t s);
+/* out[M,C] = 0, out[argmax[b,c], c] = val[b,c];   out[b,c] = src[argmax[b,c], c] */
+int spgan_scatter_rows(const float* val, const int32_t* argmax, int B, int C, int M, float* out, spgan_stream_t s);
+int spgan_gather_rows(const float* src, int ld, const int32_t* argmax, int B, int C, float* out, spgan_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * WGAN-GP double backward through train-mode BatchNorm (Common/gradient_penalty.py:31-35 + .backward();
+ * derivation in DESIGN.md).  u = adjoint of the BN-backward output, gz = first-order gradient w.r.t. the BN output.
+ *   stats partials [ceil(M/128)][2C][2] (finalize mode 1): col c -> (sum u, sum u*xhat), col C+c -> (sum u*gz, 0)
+ *   apply: q = gamma*invstd*(u - U0/M - xhat*U1/M)*lrelu'(y*scale+shift);  xbar = -(gamma*invstd/M)*(u*S1 + gz*U1)
+ * ---------------------------------------------------------------------------------------- */
+int spgan_bn_dbl_stats(const float* u, const float* y, const float* gz, int M, int C, const float* mean, const float* invstd,
+                       float* partials, spgan_stream_t s);
+int spgan_bn_dbl_apply(const float* u, const float* y, const float* gz, int M, int C, const float* mean, const float* invstd,
+                       const float* scale, const float* shift, float slope, const float* gamma, const float* S1, const float* U0,
+                       const float* U1, float* q, float* xbar, spgan_stream_t s);
+/* ------------------------------------------------------------------------------------------
+ * Losses on the [B,1] logits (Common/loss_utils.py:727-802 gen_loss, 854-972 dis_loss) with both logit
+ * gradients in the same launch.  mode: 0 ls (default, config.py:72), 1 wgan, 2 hinge, 3 gan (BCE-with-logits);
+ * which: 0 discriminator loss, 1 generator loss.  Labels [B] or NULL (ls only; the reference's F.mse_loss
+ * broadcast of [B,1] logits against [B] labels to [B,B] is kept).
+ * out5 = (loss, fake term, real term, real_acc, fake_acc).
+ * ---------------------------------------------------------------------------------------- */
+int spgan_gan_loss(int mode, int which, const float* d_real, const float* d_fake, const float* real_label, const float* fake_label,
+                   int B, float* out5, float* g_real, float* g_fake, spgan_stream_t s);
+/* WGAN-GP (Common/gradient_penalty.py:19-37): x_hat = real + alpha[b]*(fake-real);
+ * penalty = lambda*mean_b(((||g_b||-gamma)/gamma)^2) and its gradient w.r.t. g (times upstream[0] if given). */
+int spgan_lerp_rows(const float* real, const float* fake, const float* alpha, int B, size_t L, float* out, spgan_stream_t s);
+int spgan_gp_penalty_fwd(const float* g, int B, size_t L, float gamma, float lambda, float* norms, float* loss, spgan_stream_t s);
+int spgan_gp_penalty_bwd(const float* g, const float* norms, int B, size_t L, float gamma, float lambda, const float* upstream,
+                         float* v, spgan_stream_t s);
+/* out[m,c] = a[m,c] + gamma[c]*b[m,c] */
+int spgan_col_scale_add(const float* a, const float* b, const float* gamma, int M, int C, float* out, spgan_stream_t s);
+/* y = a*x + b*y */
+int spgan_axpby(float a, const float* x, float b, float* y, size_t n, spgan_stream_t s);
+/* torch.optim.Adam step on a flat buffer (Generation/model.py:94-97: lr 1e-4, betas (0.5,0.99)); g is scaled by grad_scale first */
+int spgan_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                    float grad_scale, spgan_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,309 @@
+// EdgeBlock (Generation/Generator.py:47-88) gather-side kernels.
+//
+// The reference materialises ee = cat[x_i, x_j - x_i] [B,2C,N,k] and runs three per-edge 1x1 convs
+// on it.  Here conv_w.0 and conv_x.0 are restructured per POINT:
+//     conv_w.0(x_j - x_i) = P_j - P_i + b1,            P = W1 x
+//     conv_x.0([x_i, x_j - x_i]) = R_i + Q_j + bx,     Q = Wd x,  R = (Wc - Wd) x,  Wx = [Wc | Wd]
+// so one per-point GEMM produces PQR[M, H+2F] (H = F/2) and every per-edge quantity is a gather of
+// 128-512 B rows of PQR -- coalesced, L2-resident, no ee tensor.  The kernels below do the per-edge
+// elementwise work between the MFMA contractions: train-mode BatchNorm statistics over edges, the
+// softmax over the k neighbours times conv_x's activation, and their backward passes.  The backward
+// "scatter" to neighbours is a gather over the CSR in-edge lists (deterministic; no float atomics).
+//
+// Thread mapping everywhere: one wave per point, lanes along channels.
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ weights
+__global__ void edge_wcat_kernel(const float* __restrict__ Ww0, const float* __restrict__ Wx, int H, int F, int C, float* __restrict__ Wcat) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (H + 2 * F) * C) return;
+  const int row = t / C, c = t % C;
+  float v;
+  if (row < H) v = Ww0[row * C + c];
+  else if (row < H + F) v = Wx[(row - H) * 2 * C + C + c];                       // Wd
+  else v = Wx[(row - H - F) * 2 * C + c] - Wx[(row - H - F) * 2 * C + C + c];     // Wc - Wd
+  Wcat[t] = v;
+}
+__global__ void edge_wcat_bwd_kernel(const float* __restrict__ dWcat, int H, int F, int C, float* __restrict__ dWw0, float* __restrict__ dWx) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < H * C) dWw0[t] = dWcat[t];
+  if (t < F * C) {
+    const int f = t / C, c = t % C;
+    const float dq = dWcat[(H + f) * C + c], dr = dWcat[(H + F + f) * C + c];
+    dWx[f * 2 * C + c] = dr;            // d/dWc
+    dWx[f * 2 * C + C + c] = dq - dr;   // d/dWd
+  }
+}
+
+// ------------------------------------------------------------------------------------------ statistics over edges
+// partials [tiles][H+F][2] = (sum, centred M2) of  h1pre = (P_j - P_i) + b1  (channels [0,H))
+//                                             and  ypre  = (R_i + Q_j) + bx  (channels [H,H+F))
+constexpr int ES_PT = 32;  // points per workgroup (tile = ES_PT*k edges)
+
+__device__ __forceinline__ float edge_pre(const float* __restrict__ PQR, int ld, int H, int F, int c, int i, int j, float bias) {
+  if (c < H) return (PQR[(size_t)j * ld + c] - PQR[(size_t)i * ld + c]) + bias;
+  const int f = c - H;
+  return (PQR[(size_t)i * ld + H + F + f] + PQR[(size_t)j * ld + H + f]) + bias;
+}
+
+__global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict__ PQR, int ld, const int32_t* __restrict__ idx, int M, int k,
+                                                         int H, int F, const float* __restrict__ b1, const float* __restrict__ bx,
+                                                         float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int p0 = blockIdx.x * ES_PT;
+  const int np = min(ES_PT, M - p0);
+  const int CH = H + F;
+  const float cnt = (float)(np * k);
+  for (int c0 = 0; c0 < CH; c0 += 64) {
+    const int c = c0 + lane;
+    const bool ok = c < CH;
+    const float bias = ok ? (c < H ? b1[c] : bx[c - H]) : 0.f;
+    float s = 0.f;
+    if (ok)
+      for (int p = w; p < np; p += 4) {
+        const int i = p0 + p;
+        for (int r = 0; r < k; ++r) s += edge_pre(PQR, ld, H, F, c, i, idx[(size_t)i * k + r], bias);
+      }
+    red[w][lane] = s;
+    __syncthreads();
+    const float tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const float mean = tot / cnt;
+    __syncthreads();
+    float m2 = 0.f;
+    if (ok)
+      for (int p = w; p < np; p += 4) {
+        const int i = p0 + p;
+        for (int r = 0; r < k; ++r) {
+          const float d = edge_pre(PQR, ld, H, F, c, i, idx[(size_t)i * k + r], bias) - mean;
+          m2 = fmaf(d, d, m2);
+        }
+      }
+    red[w][lane] = m2;
+    __syncthreads();
+    if (w == 0 && ok) {
+      float* o = part + ((size_t)blockIdx.x * CH + c) * 2;
+      o[0] = tot;
+      o[1] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------ attention over the k neighbours
+// T[i, r*F + f] = softmax_r( lrelu(bn2(h2pre[i,r,f])) ) * lrelu(bnx(ypre[i,r,f]))     Generator.py:79,81-82
+constexpr int EA_PT = 16;  // points per workgroup: 4 waves x 4 points
+
+__global__ __launch_bounds__(256) void edge_attend_fwd_kernel(const float* __restrict__ h2, const float* __restrict__ sc2,
+                                                              const float* __restrict__ sh2, const float* __restrict__ PQR, int ld, int H,
+                                                              int F, const int32_t* __restrict__ idx, int M, int k,
+                                                              const float* __restrict__ bx, const float* __restrict__ scx,
+                                                              const float* __restrict__ shx, float slope, float* __restrict__ T) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int pp = 0; pp < EA_PT / 4; ++pp) {
+    const int i = blockIdx.x * EA_PT + pp * 4 + w;
+    if (i >= M) return;
+    const float* h2i = h2 + (size_t)i * k * F;
+    for (int f = lane; f < F; f += 64) {
+      const float a2 = sc2[f], c2 = sh2[f], ax = scx[f], cx = shx[f], bb = bx[f];
+      const float Ri = PQR[(size_t)i * ld + H + F + f];
+      float mx = -INFINITY;
+      for (int r = 0; r < k; ++r) mx = fmaxf(mx, lrelu_f(fmaf(h2i[(size_t)r * F + f], a2, c2), slope));
+      float den = 0.f;
+      for (int r = 0; r < k; ++r) den += expf(lrelu_f(fmaf(h2i[(size_t)r * F + f], a2, c2), slope) - mx);
+      const float rden = 1.0f / den;
+      for (int r = 0; r < k; ++r) {
+        const float wgt = expf(lrelu_f(fmaf(h2i[(size_t)r * F + f], a2, c2), slope) - mx) * rden;
+        const int j = idx[(size_t)i * k + r];
+        const float yv = lrelu_f(fmaf((Ri + PQR[(size_t)j * ld + H + f]) + bb, ax, cx), slope);
+        T[((size_t)i * k + r) * F + f] = yv * wgt;
+      }
+    }
+  }
+}
+
+// Backward of the above: given dT, produce the gradients w.r.t. the two BatchNorm OUTPUTS (pre-LeakyReLU)
+//   g2[e,f] (conv_w.4 branch) and gy[e,f] (conv_x.1 branch), plus the column sums BatchNorm backward needs:
+//   partials [tiles][2F][2]: column f      -> (sum g2, sum g2*xhat2)
+//                            column F + f  -> (sum gy, sum gy*xhaty)
+constexpr int EB_PT = 32;  // points per workgroup: 4 waves x 8 points
+
+__global__ __launch_bounds__(256) void edge_attend_bwd_kernel(
+    const float* __restrict__ dT, const float* __restrict__ h2, const float* __restrict__ sc2, const float* __restrict__ sh2,
+    const float* __restrict__ mean2, const float* __restrict__ inv2, const float* __restrict__ PQR, int ld, int H, int F,
+    const int32_t* __restrict__ idx, int M, int k, const float* __restrict__ bx, const float* __restrict__ scx,
+    const float* __restrict__ shx, const float* __restrict__ meanx, const float* __restrict__ invx, float slope, float* __restrict__ g2,
+    float* __restrict__ gy, float* __restrict__ part) {
+  __shared__ float red[4][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int f0 = 0; f0 < F; f0 += 64) {
+    const int f = f0 + lane;
+    const bool ok = f < F;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (ok) {
+      const float a2 = sc2[f], c2 = sh2[f], ax = scx[f], cx = shx[f], bb = bx[f];
+      const float m2 = mean2[f], i2 = inv2[f], mxm = meanx[f], ixv = invx[f];
+      for (int pp = 0; pp < EB_PT / 4; ++pp) {
+        const int i = blockIdx.x * EB_PT + pp * 4 + w;
+        if (i >= M) break;
+        const float* h2i = h2 + (size_t)i * k * F;
+        const float* dTi = dT + (size_t)i * k * F;
+        const float Ri = PQR[(size_t)i * ld + H + F + f];
+        float mx = -INFINITY;
+        for (int r = 0; r < k; ++r) mx = fmaxf(mx, lrelu_f(fmaf(h2i[(size_t)r * F + f], a2, c2), slope));
+        float den = 0.f;
+        for (int r = 0; r < k; ++r) den += expf(lrelu_f(fmaf(h2i[(size_t)r * F + f], a2, c2), slope) - mx);
+        const float rden = 1.0f / den;
+        float dot = 0.f;  // sum_r dw[r]*w[r]
+        for (int r = 0; r < k; ++r) {
+          const float wgt = expf(lrelu_f(fmaf(h2i[(size_t)r * F + f], a2, c2), slope) - mx) * rden;
+          const int j = idx[(size_t)i * k + r];
+          const float yv = lrelu_f(fmaf((Ri + PQR[(size_t)j * ld + H + f]) + bb, ax, cx), slope);
+          dot = fmaf(dTi[(size_t)r * F + f] * yv, wgt, dot);
+        }
+        for (int r = 0; r < k; ++r) {
+          const float hp = h2i[(size_t)r * F + f];
+          const float z2 = fmaf(hp, a2, c2);
+          const float wgt = expf(lrelu_f(z2, slope) - mx) * rden;
+          const int j = idx[(size_t)i * k + r];
+          const float yp = (Ri + PQR[(size_t)j * ld + H + f]) + bb;
+          const float zy = fmaf(yp, ax, cx);
+          const float yv = lrelu_f(zy, slope);
+          const float d = dTi[(size_t)r * F + f];
+          const float ds = wgt * (d * yv - dot);            // softmax backward
+          const float o2 = ds * lrelu_mask(z2, slope);
+          const float oy = d * wgt * lrelu_mask(zy, slope);
+          g2[((size_t)i * k + r) * F + f] = o2;
+          gy[((size_t)i * k + r) * F + f] = oy;
+          s0 += o2;
+          s1 = fmaf(o2, (hp - m2) * i2, s1);
+          s2 += oy;
+          s3 = fmaf(oy, (yp - mxm) * ixv, s3);
+        }
+      }
+    }
+    red[0][w][lane] = s0; red[1][w][lane] = s1; red[2][w][lane] = s2; red[3][w][lane] = s3;
+    __syncthreads();
+    if (w == 0 && ok) {
+      float* o = part + (size_t)blockIdx.x * (2 * F) * 2;
+      o[(size_t)f * 2 + 0] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+      o[(size_t)f * 2 + 1] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+      o[(size_t)(F + f) * 2 + 0] = (red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]);
+      o[(size_t)(F + f) * 2 + 1] = (red[3][0][lane] + red[3][1][lane]) + (red[3][2][lane] + red[3][3][lane]);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------ edge -> point gradients
+// BatchNorm backward (train mode) of the two per-edge pre-activations fused with the gather-style
+// reduction onto points:
+//   dh1[e,c] = gam1*inv1*(g1[e,c] - S1[c]/E - xhat1[e,c]*S1x[c]/E)        xhat1 from (P_j - P_i) + b1
+//   dyp[e,f] = gamx*invx*(gy[e,f] - Sy[f]/E - xhaty[e,f]*Syx[f]/E)        xhaty from (R_i + Q_j) + bx
+//   dP[j] = sum_{e in in(j)} dh1[e] - sum_r dh1[(j,r)];  dQ[j] = sum_{e in in(j)} dyp[e];  dR[i] = sum_r dyp[(i,r)]
+__global__ __launch_bounds__(256) void edge_scatter_kernel(
+    const float* __restrict__ g1, const float* __restrict__ gy, const float* __restrict__ PQR, int ld, int H, int F,
+    const int32_t* __restrict__ idx, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, int M, int k,
+    const float* __restrict__ b1, const float* __restrict__ mean1, const float* __restrict__ inv1, const float* __restrict__ gam1,
+    const float* __restrict__ sums1, const float* __restrict__ bx, const float* __restrict__ meanx, const float* __restrict__ invx,
+    const float* __restrict__ gamx, const float* __restrict__ sumsx, float rE, float* __restrict__ dPQR) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + w;
+  if (j >= M) return;
+  const int t0 = rowptr[j], t1 = rowptr[j + 1];
+  for (int c = lane; c < H; c += 64) {
+    const float bb = b1[c], mu = mean1[c], iv = inv1[c];
+    const float coef = gam1[c] * iv, a0 = sums1[c] * rE, a1 = sums1[H + c] * rE;
+    const float Pj = PQR[(size_t)j * ld + c];
+    float acc = 0.f;
+    for (int r = 0; r < k; ++r) {  // out-edges: j is the centre
+      const int e = j * k + r;
+      const int jj = idx[e];
+      const float xh = (((PQR[(size_t)jj * ld + c] - Pj) + bb) - mu) * iv;
+      acc -= coef * (g1[(size_t)e * H + c] - a0 - xh * a1);
+    }
+    for (int t = t0; t < t1; ++t) {  // in-edges: j is the neighbour
+      const int e = src[t];
+      const int i = e / k;
+      const float xh = (((Pj - PQR[(size_t)i * ld + c]) + bb) - mu) * iv;
+      acc += coef * (g1[(size_t)e * H + c] - a0 - xh * a1);
+    }
+    dPQR[(size_t)j * ld + c] = acc;
+  }
+  for (int f = lane; f < F; f += 64) {
+    const float bb = bx[f], mu = meanx[f], iv = invx[f];
+    const float coef = gamx[f] * iv, a0 = sumsx[f] * rE, a1 = sumsx[F + f] * rE;
+    const float Rj = PQR[(size_t)j * ld + H + F + f], Qj = PQR[(size_t)j * ld + H + f];
+    float accR = 0.f, accQ = 0.f;
+    for (int r = 0; r < k; ++r) {
+      const int e = j * k + r;
+      const int jj = idx[e];
+      const float xh = (((Rj + PQR[(size_t)jj * ld + H + f]) + bb) - mu) * iv;
+      accR += coef * (gy[(size_t)e * F + f] - a0 - xh * a1);
+    }
+    for (int t = t0; t < t1; ++t) {
+      const int e = src[t];
+      const int i = e / k;
+      const float xh = (((PQR[(size_t)i * ld + H + F + f] + Qj) + bb) - mu) * iv;
+      accQ += coef * (gy[(size_t)e * F + f] - a0 - xh * a1);
+    }
+    dPQR[(size_t)j * ld + H + f] = accQ;
+    dPQR[(size_t)j * ld + H + F + f] = accR;
+  }
+}
+
+}  // namespace
+
+extern "C" int spgan_edge_wcat(const float* Ww0, const float* Wx, int H, int F, int C, float* Wcat, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(Ww0 && Wx && Wcat && H > 0 && F > 0 && C > 0);
+  hipLaunchKernelGGL(edge_wcat_kernel, dim3(cdiv((H + 2 * F) * C, 256)), dim3(256), 0, (hipStream_t)s_, Ww0, Wx, H, F, C, Wcat);
+  return spgan_launch_status();
+}
+extern "C" int spgan_edge_wcat_bwd(const float* dWcat, int H, int F, int C, float* dWw0, float* dWx, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dWcat && dWw0 && dWx && H > 0 && F > 0 && C > 0);
+  hipLaunchKernelGGL(edge_wcat_bwd_kernel, dim3(cdiv((H > F ? H : F) * C, 256)), dim3(256), 0, (hipStream_t)s_, dWcat, H, F, C, dWw0, dWx);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_edge_stats_tile_rows(int k) { return ES_PT * k; }
+extern "C" int spgan_edge_attend_bwd_tile_points(void) { return EB_PT; }
+
+extern "C" int spgan_edge_stats(const float* PQR, int ld, const int32_t* idx, int M, int k, int H, int F, const float* b1, const float* bx,
+                                float* partials, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(PQR && idx && b1 && bx && partials && M > 0 && k > 0 && H > 0 && F > 0 && ld >= H + 2 * F);
+  hipLaunchKernelGGL(edge_stats_kernel, dim3(cdiv(M, ES_PT)), dim3(256), 0, (hipStream_t)s_, PQR, ld, idx, M, k, H, F, b1, bx, partials);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_edge_attend_fwd(const float* h2pre, const float* sc2, const float* sh2, const float* PQR, int ld, int H, int F,
+                                     const int32_t* idx, int M, int k, const float* bx, const float* scx, const float* shx, float slope,
+                                     float* T, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(h2pre && sc2 && sh2 && PQR && idx && bx && scx && shx && T && M > 0 && k > 0 && ld >= H + 2 * F);
+  hipLaunchKernelGGL(edge_attend_fwd_kernel, dim3(cdiv(M, EA_PT)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, k,
+                     bx, scx, shx, slope, T);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_edge_attend_bwd(const float* dT, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
+                                     const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k,
+                                     const float* bx, const float* scx, const float* shx, const float* meanx, const float* invx,
+                                     float slope, float* g2, float* gy, float* partials, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dT && h2pre && sc2 && sh2 && mean2 && inv2 && PQR && idx && bx && scx && shx && meanx && invx && g2 && gy && partials);
+  SPGAN_CHECK_ARG(M > 0 && k > 0 && ld >= H + 2 * F);
+  hipLaunchKernelGGL(edge_attend_bwd_kernel, dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR, ld,
+                     H, F, idx, M, k, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_edge_scatter(const float* g1, const float* gy, const float* PQR, int ld, int H, int F, const int32_t* idx,
+                                  const int32_t* rowptr, const int32_t* src, int M, int k, const float* b1, const float* mean1,
+                                  const float* inv1, const float* gam1, const float* sums1, const float* bx, const float* meanx,
+                                  const float* invx, const float* gamx, const float* sumsx, float* dPQR, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(g1 && gy && PQR && idx && rowptr && src && b1 && mean1 && inv1 && gam1 && sums1 && bx && meanx && invx && gamx && sumsx && dPQR);
+  SPGAN_CHECK_ARG(M > 0 && k > 0 && ld >= H + 2 * F);
+  hipLaunchKernelGGL(edge_scatter_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, gy, PQR, ld, H, F, idx, rowptr, src, M, k, b1,
+                     mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
+  return spgan_launch_status();
+}

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void colpartials_kernel(const float* __restric
 
 // Combine per-tile partials over the tiles of each group.  block = 16 slices x 16 columns.
 __global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restrict__ part, int tiles_per_group, int C, int G, int mode,
-                                                          float* __restrict__ out0, float* __restrict__ out1) {
+                                                          int tile_rows, float* __restrict__ out0, float* __restrict__ out1) {
   __shared__ float sn[16][16], sa[16][16], sb[16][16];
   const int g = blockIdx.y;
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restric
     for (int t = sl; t < tiles_per_group; t += 16) {
       const float* p = part + (((size_t)g * tiles_per_group + t) * C + c) * 2;
       if (mode == 0) {
-        const float nb = (float)min(RT, G - t * RT);
+        const float nb = (float)min(tile_rows, G - t * tile_rows);
         const float mb = p[0] / nb, m2b = p[1];
         const float nn = n + nb;
         const float d = mb - a;
@@ -187,12 +187,13 @@ extern "C" size_t spgan_colreduce_ws_bytes(int M, int C, int G) {
   return groups * (size_t)cdiv(G, RT) * C * 2 * sizeof(float);
 }
 
-extern "C" int spgan_colstats_finalize(const float* partials, int groups, int tiles_per_group, int C, int G, int mode, float* out0,
-                                       float* out1, spgan_stream_t s_) {
+extern "C" int spgan_colstats_finalize(const float* partials, int groups, int tiles_per_group, int C, int G, int mode, int tile_rows,
+                                       float* out0, float* out1, spgan_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
+  if (tile_rows <= 0) tile_rows = RT;
   SPGAN_CHECK_ARG(partials && out0 && out1 && groups > 0 && tiles_per_group > 0 && C > 0 && G > 0 && (mode == 0 || mode == 1));
-  SPGAN_CHECK_ARG(tiles_per_group == cdiv(G, RT));
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, partials, tiles_per_group, C, G, mode, out0, out1);
+  SPGAN_CHECK_ARG(tiles_per_group == cdiv(G, tile_rows));
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, partials, tiles_per_group, C, G, mode, tile_rows, out0, out1);
   return spgan_launch_status();
 }
 
@@ -203,7 +204,7 @@ extern "C" int spgan_colstats(const float* X, int ldx, int M, int C, int G, floa
   SPGAN_CHECK_ARG(ws_bytes >= spgan_colreduce_ws_bytes(M, C, G));
   const int groups = M / G, tpg = cdiv(G, RT);
   hipLaunchKernelGGL((colpartials_kernel<0>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, slope, ws);
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, tpg, C, G, 0, out_mean, out_var);
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, tpg, C, G, 0, RT, out_mean, out_var);
   return spgan_launch_status();
 }
 
@@ -215,7 +216,7 @@ extern "C" int spgan_colsum(const float* X, int ldx, int M, int C, int G, float*
   SPGAN_CHECK_ARG(ws_bytes >= spgan_colreduce_ws_bytes(M, C, G) + (size_t)groups * C * sizeof(float));
   float* scratch = ws + (size_t)groups * tpg * C * 2;
   hipLaunchKernelGGL((colpartials_kernel<1>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, 1.0f, ws);
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, tpg, C, G, 1, out, scratch);
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, tpg, C, G, 1, RT, out, scratch);
   return spgan_launch_status();
 }
 

@@ -1,0 +1,335 @@
+// HBM-bound per-point kernels: AdaIN (AdaptivePointNorm, Generation/Generator.py:24-45) forward and
+// backward, the sparse BatchNorm backward behind D's global max-pool (Discriminator.py:77-81,104),
+// max-pool gradient routing, tanh backward and the flat Adam update.  Lanes run along channels.
+#include "common.hpp"
+
+namespace {
+
+constexpr int RT = 128;  // rows per partial tile (shared partial format, see norm.hip)
+
+// out = gamma * xhat + beta,  xhat = (lrelu(x, slope) - mean[b,c]) * rsqrt(var[b,c] + eps),  [gamma|beta] = gb[m, 0:2C]
+__global__ void adain_fwd_kernel(const float* __restrict__ x, size_t M, int C, int N, float slope, const float* __restrict__ imean,
+                                 const float* __restrict__ ivar, float eps, const float* __restrict__ gb, float* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * C) return;
+  const size_t m = t / C;
+  const int c = t % C;
+  const size_t b = m / N;
+  const float xh = (lrelu_f(x[t], slope) - imean[b * C + c]) * rsqrtf(ivar[b * C + c] + eps);
+  out[t] = fmaf(gb[m * 2 * C + c], xh, gb[m * 2 * C + C + c]);
+}
+
+// stage 1: dgb = [dout*xhat | dout];  partials over each shape's N rows of (sum dxh, sum dxh*xhat), dxh = dout*gamma
+__global__ __launch_bounds__(256) void adain_bwd1_kernel(const float* __restrict__ dout, const float* __restrict__ x, int C, int N, float slope,
+                                                         const float* __restrict__ imean, const float* __restrict__ ivar, float eps,
+                                                         const float* __restrict__ gb, int tiles_per_group, float* __restrict__ dgb,
+                                                         float* __restrict__ part) {
+  __shared__ float r0[4][64], r1[4][64];
+  const int tile = blockIdx.x;
+  const int b = tile / tiles_per_group, q = tile % tiles_per_group;
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
+  const bool ok = c < C;
+  const int n0 = q * RT, cnt = min(RT, N - n0);
+  float s0 = 0.f, s1 = 0.f;
+  if (ok) {
+    const float mu = imean[(size_t)b * C + c], iv = rsqrtf(ivar[(size_t)b * C + c] + eps);
+    for (int r = sl; r < cnt; r += 4) {
+      const size_t m = (size_t)b * N + n0 + r;
+      const float d = dout[m * C + c];
+      const float xh = (lrelu_f(x[m * C + c], slope) - mu) * iv;
+      dgb[m * 2 * C + c] = d * xh;
+      dgb[m * 2 * C + C + c] = d;
+      const float dxh = d * gb[m * 2 * C + c];
+      s0 += dxh;
+      s1 = fmaf(dxh, xh, s1);
+    }
+  }
+  r0[sl][lane] = s0; r1[sl][lane] = s1;
+  __syncthreads();
+  if (sl == 0 && ok) {
+    float* o = part + ((size_t)tile * C + c) * 2;
+    o[0] = (r0[0][lane] + r0[1][lane]) + (r0[2][lane] + r0[3][lane]);
+    o[1] = (r1[0][lane] + r1[1][lane]) + (r1[2][lane] + r1[3][lane]);
+  }
+}
+
+// stage 2: dx = invstd * (dxh - S0/N - xhat*S1/N) * lrelu'(x)
+__global__ void adain_bwd2_kernel(const float* __restrict__ dout, const float* __restrict__ x, size_t M, int C, int N, float slope,
+                                  const float* __restrict__ imean, const float* __restrict__ ivar, float eps, const float* __restrict__ gb,
+                                  const float* __restrict__ S0, const float* __restrict__ S1, float* __restrict__ dx) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * C) return;
+  const size_t m = t / C;
+  const int c = t % C;
+  const size_t b = m / N;
+  const float xv = x[t];
+  const float iv = rsqrtf(ivar[b * C + c] + eps);
+  const float xh = (lrelu_f(xv, slope) - imean[b * C + c]) * iv;
+  const float dxh = dout[t] * gb[m * 2 * C + c];
+  const float rn = 1.0f / (float)N;
+  dx[t] = iv * (dxh - S0[b * C + c] * rn - xh * (S1[b * C + c] * rn)) * lrelu_mask(xv, slope);
+}
+
+// gval = gpool * lrelu'(pooled);  sums[c] = sum_b gval, sums[C+c] = sum_b gval * xhat(argmax row)
+__global__ void pool_bwd_stats_kernel(const float* __restrict__ gpool, const float* __restrict__ pooled, const int32_t* __restrict__ argmax,
+                                      const float* __restrict__ y, int ld, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                      float slope, int B, int C, float* __restrict__ gval, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  const float mu = mean[c], iv = invstd[c];
+  for (int b = 0; b < B; ++b) {
+    const float g = gpool[(size_t)b * C + c] * lrelu_mask(pooled[(size_t)b * C + c], slope);
+    gval[(size_t)b * C + c] = g;
+    const float xh = (y[(size_t)argmax[(size_t)b * C + c] * ld + c] - mu) * iv;
+    s0 += g;
+    s1 = fmaf(g, xh, s1);
+  }
+  sums[c] = s0;
+  sums[C + c] = s1;
+}
+
+// dy[m,c] = gamma*invstd*( (argmax[b,c]==m ? gval[b,c] : 0) - sums[c]/count - xhat*sums[C+c]/count )
+__global__ void bn_bwd_apply_sparse_kernel(const float* __restrict__ gval, const int32_t* __restrict__ argmax, const float* __restrict__ y,
+                                           int ld, size_t M, int C, int N, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                           const float* __restrict__ gamma, const float* __restrict__ sums, float rcount,
+                                           float* __restrict__ dy) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * C) return;
+  const size_t m = t / C;
+  const int c = t % C;
+  const size_t b = m / N;
+  const float iv = invstd[c];
+  const float xh = (y[m * ld + c] - mean[c]) * iv;
+  const float g = ((size_t)argmax[b * C + c] == m) ? gval[b * C + c] : 0.f;
+  dy[m * C + c] = gamma[c] * iv * (g - sums[c] * rcount - xh * (sums[C + c] * rcount));
+}
+
+__global__ void maxpool_bwd_add_kernel(const float* __restrict__ dpool, const int32_t* __restrict__ argmax, int BC, int C,
+                                       float* __restrict__ dst, int ld) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= BC) return;
+  const int c = t % C;
+  dst[(size_t)argmax[t] * ld + c] += dpool[t];  // (b,c) pairs hit distinct elements: no race
+}
+
+__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, size_t n, float* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = dy[t] * (1.f - y[t] * y[t]);
+}
+
+// dpre = dy * act'(y) from the activation OUTPUT y (LeakyReLU in place / tanh)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, size_t n, int act, float slope, float* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float yv = y[t];
+  float d = dy[t];
+  if (act == SPGAN_ACT_LRELU) d *= lrelu_mask(yv, slope);
+  else if (act == SPGAN_ACT_TANH) d *= (1.f - yv * yv);
+  out[t] = d;
+}
+
+// out[M,C] = 0 except out[argmax[b,c], c] = val[b,c]
+__global__ void scatter_rows_kernel(const float* __restrict__ val, const int32_t* __restrict__ argmax, int BC, int C, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= BC) return;
+  out[(size_t)argmax[t] * C + (t % C)] = val[t];
+}
+__global__ void gather_rows_kernel(const float* __restrict__ src, int ld, const int32_t* __restrict__ argmax, int BC, int C, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= BC) return;
+  out[t] = src[(size_t)argmax[t] * ld + (t % C)];
+}
+
+// WGAN-GP double backward through train-mode BatchNorm: column sums of
+//   u, u*xhat, u*gz  ->  partials [tiles][2C][2]: col c -> (sum u, sum u*xhat), col C+c -> (sum u*gz, 0)
+__global__ __launch_bounds__(256) void bn_dbl_stats_kernel(const float* __restrict__ u, const float* __restrict__ y, const float* __restrict__ gz,
+                                                           int M, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float* __restrict__ part) {
+  __shared__ float r0[4][64], r1[4][64], r2[4][64];
+  const int tile = blockIdx.x;
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
+  const bool ok = c < C;
+  const int m0 = tile * RT, cnt = min(RT, M - m0);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (ok) {
+    const float mu = mean[c], iv = invstd[c];
+    for (int r = sl; r < cnt; r += 4) {
+      const size_t o = (size_t)(m0 + r) * C + c;
+      const float uv = u[o];
+      s0 += uv;
+      s1 = fmaf(uv, (y[o] - mu) * iv, s1);
+      s2 = fmaf(uv, gz[o], s2);
+    }
+  }
+  r0[sl][lane] = s0; r1[sl][lane] = s1; r2[sl][lane] = s2;
+  __syncthreads();
+  if (sl == 0 && ok) {
+    float* o = part + (size_t)tile * (2 * C) * 2;
+    o[(size_t)c * 2 + 0] = (r0[0][lane] + r0[1][lane]) + (r0[2][lane] + r0[3][lane]);
+    o[(size_t)c * 2 + 1] = (r1[0][lane] + r1[1][lane]) + (r1[2][lane] + r1[3][lane]);
+    o[(size_t)(C + c) * 2 + 0] = (r2[0][lane] + r2[1][lane]) + (r2[2][lane] + r2[3][lane]);
+    o[(size_t)(C + c) * 2 + 1] = 0.f;
+  }
+}
+
+//   q     = gamma*invstd*(u - U0/M - xhat*U1/M) * lrelu'(z),  z = y*scale + shift      (adjoint handed to the next layer)
+//   xbarA = -(gamma*invstd/M) * (u*S1 + gz*U1)                                          (adjoint deposited on xhat)
+__global__ void bn_dbl_apply_kernel(const float* __restrict__ u, const float* __restrict__ y, const float* __restrict__ gz, size_t M, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, float slope, const float* __restrict__ gamma, const float* __restrict__ S1,
+                                    const float* __restrict__ U0, const float* __restrict__ U1, float rM, float* __restrict__ q,
+                                    float* __restrict__ xbar) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * C) return;
+  const int c = t % C;
+  const float yv = y[t], uv = u[t];
+  const float iv = invstd[c];
+  const float xh = (yv - mean[c]) * iv;
+  const float gs = gamma[c] * iv;
+  const float z = fmaf(yv, scale[c], shift[c]);
+  q[t] = gs * (uv - U0[c] * rM - xh * (U1[c] * rM)) * lrelu_mask(z, slope);
+  xbar[t] = -(gs * rM) * (uv * S1[c] + gz[t] * U1[c]);
+}
+
+// out = a + gamma[c]*b
+__global__ void col_scale_add_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma, size_t M, int C,
+                                     float* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < M * C) out[t] = fmaf(gamma[t % C], b[t], a[t]);
+}
+
+__global__ void axpby_kernel(float a, const float* __restrict__ x, float b, float* __restrict__ y, size_t n) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) y[t] = a * x[t] + (b == 0.f ? 0.f : b * y[t]);
+}
+
+// torch.optim.Adam (no weight decay / amsgrad): Generation/model.py:94-97
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float lr, float b1, float b2, float eps, float bc1, float rsqrt_bc2, float gscale) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float gr = g[t] * gscale;
+  const float mm = b1 * m[t] + (1.f - b1) * gr;
+  const float vv = b2 * v[t] + (1.f - b2) * gr * gr;
+  m[t] = mm;
+  v[t] = vv;
+  const float denom = sqrtf(vv) * rsqrt_bc2 + eps;
+  p[t] -= (lr / bc1) * (mm / denom);
+}
+
+}  // namespace
+
+extern "C" int spgan_adain_fwd(const float* x, int M, int C, int N, float slope, const float* imean, const float* ivar, float eps,
+                               const float* gb, float* out, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(x && imean && ivar && gb && out && M > 0 && C > 0 && N > 0 && M % N == 0);
+  const size_t total = (size_t)M * C;
+  hipLaunchKernelGGL(adain_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s_, x, (size_t)M, C, N, slope, imean, ivar, eps, gb, out);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_adain_bwd1(const float* dout, const float* x, int M, int C, int N, float slope, const float* imean, const float* ivar,
+                                float eps, const float* gb, float* dgb, float* partials, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dout && x && imean && ivar && gb && dgb && partials && M > 0 && C > 0 && N > 0 && M % N == 0);
+  const int tpg = cdiv(N, RT);
+  hipLaunchKernelGGL(adain_bwd1_kernel, dim3((M / N) * tpg, cdiv(C, 64)), dim3(256), 0, (hipStream_t)s_, dout, x, C, N, slope, imean, ivar, eps,
+                     gb, tpg, dgb, partials);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_adain_bwd2(const float* dout, const float* x, int M, int C, int N, float slope, const float* imean, const float* ivar,
+                                float eps, const float* gb, const float* S0, const float* S1, float* dx, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dout && x && imean && ivar && gb && S0 && S1 && dx && M > 0 && C > 0 && N > 0 && M % N == 0);
+  const size_t total = (size_t)M * C;
+  hipLaunchKernelGGL(adain_bwd2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s_, dout, x, (size_t)M, C, N, slope, imean, ivar, eps,
+                     gb, S0, S1, dx);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_pool_bwd_stats(const float* gpool, const float* pooled, const int32_t* argmax, const float* y, int ld, const float* mean,
+                                    const float* invstd, float slope, int B, int C, float* gval, float* sums, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(gpool && pooled && argmax && y && mean && invstd && gval && sums && B > 0 && C > 0 && ld >= C);
+  hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)s_, gpool, pooled, argmax, y, ld, mean, invstd, slope, B,
+                     C, gval, sums);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_bn_bwd_apply_sparse(const float* gval, const int32_t* argmax, const float* y, int ld, int M, int C, int N,
+                                         const float* mean, const float* invstd, const float* gamma, const float* sums, int count, float* dy,
+                                         spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(gval && argmax && y && mean && invstd && gamma && sums && dy && M > 0 && C > 0 && N > 0 && M % N == 0 && ld >= C && count > 0);
+  const size_t total = (size_t)M * C;
+  hipLaunchKernelGGL(bn_bwd_apply_sparse_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s_, gval, argmax, y, ld, (size_t)M, C, N,
+                     mean, invstd, gamma, sums, 1.0f / (float)count, dy);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_maxpool_bwd_add(const float* dpool, const int32_t* argmax, int B, int C, float* dst, int ld, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dpool && argmax && dst && B > 0 && C > 0 && ld >= C);
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)s_, dpool, argmax, B * C, C, dst, ld);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_tanh_bwd(const float* dy, const float* y, size_t n, float* out, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dy && y && out && n > 0);
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, dy, y, n, out);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_act_bwd(const float* dy, const float* y, size_t n, int act, float slope, float* out, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dy && y && out && n > 0);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, dy, y, n, act, slope, out);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_scatter_rows(const float* val, const int32_t* argmax, int B, int C, int M, float* out, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(val && argmax && out && B > 0 && C > 0 && M > 0);
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)M * C * sizeof(float), (hipStream_t)s_);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)s_, val, argmax, B * C, C, out);
+  return spgan_launch_status();
+}
+extern "C" int spgan_gather_rows(const float* src, int ld, const int32_t* argmax, int B, int C, float* out, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(src && argmax && out && B > 0 && C > 0 && ld >= C);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)s_, src, ld, argmax, B * C, C, out);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_bn_dbl_stats(const float* u, const float* y, const float* gz, int M, int C, const float* mean, const float* invstd,
+                                  float* partials, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(u && y && gz && mean && invstd && partials && M > 0 && C > 0);
+  hipLaunchKernelGGL(bn_dbl_stats_kernel, dim3(cdiv(M, RT), cdiv(C, 64)), dim3(256), 0, (hipStream_t)s_, u, y, gz, M, C, mean, invstd, partials);
+  return spgan_launch_status();
+}
+extern "C" int spgan_bn_dbl_apply(const float* u, const float* y, const float* gz, int M, int C, const float* mean, const float* invstd,
+                                  const float* scale, const float* shift, float slope, const float* gamma, const float* S1, const float* U0,
+                                  const float* U1, float* q, float* xbar, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(u && y && gz && mean && invstd && scale && shift && gamma && S1 && U0 && U1 && q && xbar && M > 0 && C > 0);
+  const size_t total = (size_t)M * C;
+  hipLaunchKernelGGL(bn_dbl_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s_, u, y, gz, (size_t)M, C, mean, invstd, scale,
+                     shift, slope, gamma, S1, U0, U1, 1.0f / (float)M, q, xbar);
+  return spgan_launch_status();
+}
+extern "C" int spgan_col_scale_add(const float* a, const float* b, const float* gamma, int M, int C, float* out, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && b && gamma && out && M > 0 && C > 0);
+  const size_t total = (size_t)M * C;
+  hipLaunchKernelGGL(col_scale_add_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s_, a, b, gamma, (size_t)M, C, out);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_axpby(float a, const float* x, float b, float* y, size_t n, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(x && y && n > 0);
+  hipLaunchKernelGGL(axpby_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, a, x, b, y, n);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                               float grad_scale, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(p && g && m && v && n > 0 && step > 0);
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1,
+                     (float)(1.0 / sqrt(bc2)), grad_scale);
+  return spgan_launch_status();
+}

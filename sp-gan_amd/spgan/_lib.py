@@ -69,12 +69,39 @@ SIGNATURES = {
     "spgan_gemm_tn_ws_bytes": (SZ, [I, I, I]),
     "spgan_gemm_tn": (I, [C.POINTER(GemmTNArgs), P]),
     "spgan_colreduce_ws_bytes": (SZ, [I, I, I]),
-    "spgan_colstats_finalize": (I, [P, I, I, I, I, I, P, P, P]),
+    "spgan_colstats_finalize": (I, [P, I, I, I, I, I, I, P, P, P]),
     "spgan_colstats": (I, [P, I, I, I, I, F, P, P, P, SZ, P]),
     "spgan_colsum": (I, [P, I, I, I, I, P, P, SZ, P]),
     "spgan_bn_prepare": (I, [P, P, P, P, I, I, F, F, I, P, P, P, P, P, P, P]),
     "spgan_bn_bwd_apply": (I, [P, P, I, I, I, P, P, P, P, I, P, P]),
     "spgan_maxpool": (I, [P, I, I, I, I, P, P, F, P, P, P]),
+    "spgan_edge_wcat": (I, [P, P, I, I, I, P, P]),
+    "spgan_edge_wcat_bwd": (I, [P, I, I, I, P, P, P]),
+    "spgan_edge_stats_tile_rows": (I, [I]),
+    "spgan_edge_stats": (I, [P, I, P, I, I, I, I, P, P, P, P]),
+    "spgan_edge_attend_fwd": (I, [P, P, P, P, I, I, I, P, I, I, P, P, P, F, P, P]),
+    "spgan_edge_attend_bwd_tile_points": (I, []),
+    "spgan_edge_attend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, I, I, P, P, P, P, P, F, P, P, P, P]),
+    "spgan_edge_scatter": (I, [P, P, P, I, I, I, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "spgan_adain_fwd": (I, [P, I, I, I, F, P, P, F, P, P, P]),
+    "spgan_adain_bwd1": (I, [P, P, I, I, I, F, P, P, F, P, P, P, P]),
+    "spgan_adain_bwd2": (I, [P, P, I, I, I, F, P, P, F, P, P, P, P, P]),
+    "spgan_pool_bwd_stats": (I, [P, P, P, P, I, P, P, F, I, I, P, P, P]),
+    "spgan_bn_bwd_apply_sparse": (I, [P, P, P, I, I, I, I, P, P, P, P, I, P, P]),
+    "spgan_maxpool_bwd_add": (I, [P, P, I, I, P, I, P]),
+    "spgan_tanh_bwd": (I, [P, P, SZ, P, P]),
+    "spgan_act_bwd": (I, [P, P, SZ, I, F, P, P]),
+    "spgan_scatter_rows": (I, [P, P, I, I, I, P, P]),
+    "spgan_gather_rows": (I, [P, I, P, I, I, P, P]),
+    "spgan_bn_dbl_stats": (I, [P, P, P, I, I, P, P, P, P]),
+    "spgan_bn_dbl_apply": (I, [P, P, P, I, I, P, P, P, P, F, P, P, P, P, P, P, P]),
+    "spgan_col_scale_add": (I, [P, P, P, I, I, P, P]),
+    "spgan_gan_loss": (I, [I, I, P, P, P, P, I, P, P, P, P]),
+    "spgan_lerp_rows": (I, [P, P, P, I, SZ, P, P]),
+    "spgan_gp_penalty_fwd": (I, [P, I, SZ, F, F, P, P, P]),
+    "spgan_gp_penalty_bwd": (I, [P, P, I, SZ, F, F, P, P, P]),
+    "spgan_axpby": (I, [F, P, F, P, SZ, P]),
+    "spgan_adam_step": (I, [P, P, P, P, SZ, F, F, F, F, I, F, P]),
 }
 
 _lib = None

@@ -1,0 +1,232 @@
+"""torch.autograd.Function wrappers around the hand-written pipelines of `nets.py`.
+
+autograd is used as plumbing only: it sequences our forward/backward pipelines, sums the two
+style gradients, and hands parameter gradients to the optimiser.  Every Function computes its own
+backward with HIP kernels; the Discriminator additionally supports double backward (WGAN-GP,
+Common/gradient_penalty.py:31-35) by exposing its backward as a second Function.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from . import nets, ops
+
+Tensor = torch.Tensor
+
+
+def _engine_needs(ctx, pos: int, tpos: int) -> bool:
+    """True if the running autograd task will actually consume the gradient of input `pos`
+    (autograd.grad(inputs=[x]) does not need parameter gradients although they require grad).
+    `tpos` is the input's index among the *tensor* arguments (next_functions skips non-tensors)."""
+    if not ctx.needs_input_grad[pos]:
+        return False
+    try:
+        fn = ctx.next_functions[tpos][0]
+        if fn is None:
+            return False
+        return bool(torch._C._will_engine_execute_node(fn))
+    except Exception:
+        return True
+
+
+class _Holder:
+    """Non-tensor bag passed through Function.apply (module buffers, flags)."""
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+# ---------------------------------------------------------------------------------------------
+# layout
+# ---------------------------------------------------------------------------------------------
+class CmToPm(Function):
+    @staticmethod
+    def forward(ctx, x_cm):
+        ctx.B, _, ctx.N = x_cm.shape
+        return ops.cm_to_pm(x_cm)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.pm_to_cm(g.contiguous(), ctx.B, ctx.N)
+
+
+class PmToCm(Function):
+    @staticmethod
+    def forward(ctx, x_pm, B, N):
+        return ops.pm_to_cm(x_pm, B, N)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.cm_to_pm(g.contiguous()), None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# Discriminator (with double backward)
+# ---------------------------------------------------------------------------------------------
+class DiscriminatorFn(Function):
+    """logits = D(x);  inputs: holder, x [B,3,N], *params (in `holder.names` order)."""
+
+    @staticmethod
+    def forward(ctx, holder, x, *params):
+        P = dict(zip(holder.names, params))
+        out, dctx = nets.d_forward(P, holder.buffers, x, holder.training, True)
+        ctx.holder, ctx.dctx = holder, dctx
+        ctx.save_for_backward(x, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, *params = ctx.saved_tensors
+        names = ctx.holder.names
+        need_dx = _engine_needs(ctx, 1, 0)
+        need_dp = any(_engine_needs(ctx, 2 + i, 1 + i) for i in range(len(params)))
+        if torch.is_grad_enabled() and need_dx and not need_dp:
+            # create_graph=True and only the input gradient is wanted: differentiable backward
+            dx = DiscriminatorBackwardFn.apply(ctx.holder, ctx.dctx, dout, x, *params)
+            return (None, dx) + (None,) * len(params)
+        P = dict(zip(names, [p.detach() for p in params]))
+        dx, grads, _ = nets.d_backward(P, ctx.dctx, dout.detach(), need_dx, need_dp, False)
+        gp = tuple(grads[n] if (grads is not None and ctx.needs_input_grad[2 + i]) else None for i, n in enumerate(names))
+        return (None, dx) + gp
+
+
+class DiscriminatorBackwardFn(Function):
+    """dx = dD(x)/dx contracted with dout, as a differentiable node (its backward is the double backward)."""
+
+    @staticmethod
+    def forward(ctx, holder, dctx, dout, x, *params):
+        P = dict(zip(holder.names, params))
+        dx, _, saved = nets.d_backward(P, dctx, dout, True, False, keep_for_double=True)
+        ctx.holder, ctx.dctx, ctx.saved = holder, dctx, saved
+        ctx.save_for_backward(*params)
+        return dx
+
+    @staticmethod
+    def backward(ctx, v):
+        params = ctx.saved_tensors
+        names = ctx.holder.names
+        if not ctx.dctx["training"]:
+            raise NotImplementedError("double backward through eval-mode BatchNorm is not implemented")
+        P = dict(zip(names, [p.detach() for p in params]))
+        need_x = ctx.needs_input_grad[3]
+        grads, dx2 = nets.d_double_backward(P, ctx.dctx, ctx.saved, v.detach(), need_dx=need_x)
+        gp = tuple(grads[n] if ctx.needs_input_grad[4 + i] else None for i, n in enumerate(names))
+        # (holder, dctx, dout, x, *params); the gradient w.r.t. dout is not provided (constant ones in WGAN-GP)
+        return (None, None, None, dx2) + gp
+
+
+# ---------------------------------------------------------------------------------------------
+# Generator pieces (first-order only)
+# ---------------------------------------------------------------------------------------------
+class EdgeBlockFn(Function):
+    """out[M,F] = EdgeBlock(x[M,C]); inputs: holder(prefix, names, buffers, B, N, k, training, knn_mode, idx), x, *params."""
+
+    @staticmethod
+    def forward(ctx, holder, x, *params):
+        P = dict(zip(holder.names, params))
+        x = x.contiguous()
+        idx = holder.idx if holder.idx is not None else ops.knn(x, holder.B, holder.N, holder.k, holder.knn_mode)
+        out, ectx = nets.edgeblock_forward(P, holder.buffers, holder.prefix, x, idx, holder.B, holder.N, holder.training, True)
+        ctx.holder, ctx.ectx = holder, ectx
+        holder.last_idx = idx
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        params = ctx.saved_tensors
+        h = ctx.holder
+        P = dict(zip(h.names, [p.detach() for p in params]))
+        csr = ops.csr_build(ctx.ectx["idx"], h.B, h.N)
+        dx, g = nets.edgeblock_backward(P, h.prefix, ctx.ectx, dout, csr, need_dx=ctx.needs_input_grad[1])
+        return (None, dx) + tuple(g[n] if ctx.needs_input_grad[2 + i] else None for i, n in enumerate(h.names))
+
+
+class AdaINFn(Function):
+    """inputs: holder(prefix, N, slope), x [M,C], style [M,S], weight, bias"""
+
+    @staticmethod
+    def forward(ctx, holder, x, style, w, b):
+        P = {holder.prefix + ".style.weight": w, holder.prefix + ".style.bias": b}
+        out, actx = nets.adain_forward(P, holder.prefix, x.contiguous(), style.contiguous(), holder.N, holder.slope)
+        ctx.holder, ctx.actx = holder, actx
+        ctx.save_for_backward(w, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w, b = ctx.saved_tensors
+        pre = ctx.holder.prefix
+        P = {pre + ".style.weight": w.detach(), pre + ".style.bias": b.detach()}
+        need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        dx, ds, g = nets.adain_backward(P, pre, ctx.actx, dout, ctx.needs_input_grad[1], ctx.needs_input_grad[2], need_p)
+        return None, dx, ds, g.get(pre + ".style.weight"), g.get(pre + ".style.bias")
+
+
+class MLPFn(Function):
+    """Chain of 1x1 convs + activations.  inputs: holder(names, acts, slope), x [M,C], *params (w0,b0,w1,b1,...)"""
+
+    @staticmethod
+    def forward(ctx, holder, x, *params):
+        P = {}
+        for i, n in enumerate(holder.names):
+            P[n + ".weight"], P[n + ".bias"] = params[2 * i], params[2 * i + 1]
+        out, mctx = nets.mlp_forward(P, holder.names, holder.acts, x.contiguous(), holder.slope)
+        ctx.holder, ctx.mctx = holder, mctx
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        params = ctx.saved_tensors
+        h = ctx.holder
+        P = {}
+        for i, n in enumerate(h.names):
+            P[n + ".weight"], P[n + ".bias"] = params[2 * i].detach(), params[2 * i + 1].detach()
+        need_p = any(ctx.needs_input_grad[2:])
+        dx, g, _ = nets.mlp_backward(P, ctx.mctx, dout, ctx.needs_input_grad[1], need_p)
+        out = []
+        for i, n in enumerate(h.names):
+            out.append(g.get(n + ".weight") if ctx.needs_input_grad[2 + 2 * i] else None)
+            out.append(g.get(n + ".bias") if ctx.needs_input_grad[3 + 2 * i] else None)
+        return (None, dx) + tuple(out)
+
+
+GT_NAMES = ("global_conv.0.weight", "global_conv.0.bias", "global_conv.1.weight", "global_conv.1.bias",
+            "global_conv.3.weight", "global_conv.3.bias", "global_conv.4.weight", "global_conv.4.bias",
+            "tail.0.weight", "tail.0.bias", "tail.2.weight", "tail.2.bias", "tail.4.weight", "tail.4.bias")
+
+
+class GlobalTailFn(Function):
+    """out[M,3] = tanh(tail(cat[global_conv(max_N a2) repeated, a2]))  (Generator.py:183-194).
+    The concat never exists: tail.0 = per-shape bias (512 global channels) + per-point GEMM (128 channels)."""
+
+    @staticmethod
+    def forward(ctx, holder, a2, *params):
+        P = dict(zip(GT_NAMES, params))
+        a2 = a2.contiguous()
+        B, N = holder.B, holder.N
+        gctx = nets.global_forward(P, holder.buffers, a2, B, N, holder.training, True)
+        Wt0 = P["tail.0.weight"].view(P["tail.0.weight"].shape[0], -1)
+        Cg = gctx["y3"].shape[1]
+        W_g, W_x = Wt0[:, :Cg], Wt0[:, Cg:]
+        rb = ops.gemm_nt(gctx["y3"], W_g, P["tail.0.bias"], pro=(gctx["bn3"][0], gctx["bn3"][1], nets.NEG))     # [B,256]
+        out, mctx = nets.mlp_forward(P, ["tail.0", "tail.2", "tail.4"], [ops.ACT_LRELU, ops.ACT_LRELU, ops.ACT_TANH], a2, nets.NEG,
+                                     rowbias=rb, N=N, first_weight=W_x)
+        ctx.holder, ctx.gctx, ctx.mctx, ctx.Cg = holder, gctx, mctx, Cg
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        params = ctx.saved_tensors
+        P = dict(zip(GT_NAMES, [p.detach() for p in params]))
+        Wt0 = P["tail.0.weight"].view(P["tail.0.weight"].shape[0], -1)
+        ctx.mctx["first_weight"] = Wt0[:, ctx.Cg:]
+        da2, g, drb = nets.mlp_backward(P, ctx.mctx, dout, True, True)
+        gg = nets.global_backward(P, ctx.gctx, Wt0[:, :ctx.Cg], drb, da2)
+        g.update({k: v for k, v in gg.items() if k != "tail.0.weight.global"})
+        g["tail.0.weight"] = torch.cat([gg["tail.0.weight.global"], g.pop("tail.0.weight.part")], dim=1).view_as(P["tail.0.weight"])
+        return (None, da2 if ctx.needs_input_grad[1] else None) + tuple(g[n] if ctx.needs_input_grad[2 + i] else None for i, n in enumerate(GT_NAMES))

@@ -1,0 +1,123 @@
+"""GAN losses and the WGAN-GP penalty with the reference's call signatures.
+
+  dis_loss / gen_loss : Common/loss_utils.py:854-972 / 727-802  -> (loss, info-dict)
+  GradientPenalty     : Common/gradient_penalty.py:4-37         -> callable(netD, real, fake)
+
+Value and logit-gradients come from one HIP launch (spgan_gan_loss); the penalty's norm,
+value and gradient are HIP kernels as well.  Unlike the reference, nothing here forces a
+device->host sync: the info dict holds 0-dim device tensors (the reference calls .item()).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+class _GanLossFn(Function):
+    @staticmethod
+    def forward(ctx, mode, which, d_real, d_fake, real_label, fake_label):
+        out5, g_real, g_fake = ops.gan_loss(mode, which, d_real if which == 0 else None, d_fake, real_label, fake_label)
+        ctx.save_for_backward(g_real, g_fake)
+        ctx.which = which
+        ctx.mark_non_differentiable(out5)
+        return out5[0].clone(), out5
+
+    @staticmethod
+    def backward(ctx, gl, _):
+        g_real, g_fake = ctx.saved_tensors
+        gr = g_real * gl if (ctx.which == 0 and ctx.needs_input_grad[2]) else None
+        gf = g_fake * gl if ctx.needs_input_grad[3] else None
+        return None, None, gr, gf, None, None
+
+
+def _smooth_labels(B, ran=(0.9, 1.0)):
+    return (ran[1] - ran[0]) * np.random.random(B) + ran[0]          # loss_utils.py:698-700
+
+
+def _noisy_labels(y, p_flip=0.05):
+    n = int(p_flip * y.shape[0])                                      # loss_utils.py:718-725
+    ix = np.random.choice([i for i in range(y.shape[0])], size=n)
+    y[ix] = 1 - y[ix]
+    return y
+
+
+def _mode(gan: str) -> int:
+    g = gan.lower()
+    if g not in ops.GAN_MODES:
+        raise NotImplementedError("Not implement: %s" % gan)          # same message as loss_utils.py:972
+    return ops.GAN_MODES[g]
+
+
+def dis_loss(d_real, d_fake, gan="wgan", weight=1., d_real_p=None, d_fake_p=None, noise_label=False,
+             real_label: Optional[torch.Tensor] = None, fake_label: Optional[torch.Tensor] = None):
+    """Discriminator loss; `noise_label` draws smoothed/flipped real labels with numpy like the reference
+    (loss_utils.py:897-901).  Explicit label tensors [B] may be passed instead (tests)."""
+    if d_real_p is not None or d_fake_p is not None:
+        raise NotImplementedError("patch logits (d_real_p/d_fake_p) are not produced by this Discriminator")
+    mode = _mode(gan)
+    B = d_fake.shape[0]
+    if mode == 0 and noise_label and real_label is None:
+        real_label = torch.from_numpy(_noisy_labels(_smooth_labels(B)).astype(np.float32)).to(d_fake.device)
+    loss, out5 = _GanLossFn.apply(mode, 0, d_real, d_fake, real_label, fake_label)
+    if weight != 1.:
+        loss = loss * weight
+    info = {"loss": loss.detach(), "loss_fake": out5[1], "loss_real": out5[2], "real_acc": out5[3], "fake_acc": out5[4]}
+    return loss, info
+
+
+def gen_loss(d_real, d_fake, gan="wgan", weight=1., d_real_p=None, d_fake_p=None, noise_label=False,
+             fake_label: Optional[torch.Tensor] = None):
+    """Generator loss (d_real is accepted and unused, as in the reference for ls/wgan/hinge/gan)."""
+    if d_real_p is not None or d_fake_p is not None:
+        raise NotImplementedError("patch logits (d_real_p/d_fake_p) are not produced by this Discriminator")
+    mode = _mode(gan)
+    B = d_fake.shape[0]
+    if mode == 0 and noise_label and fake_label is None:
+        fake_label = torch.from_numpy(_noisy_labels(np.ones((B,))).astype(np.float32)).to(d_fake.device)   # loss_utils.py:753-755
+    loss, out5 = _GanLossFn.apply(mode, 1, d_real, d_fake, None, fake_label)
+    if weight != 1.:
+        loss = loss * weight
+    return loss, {"loss": loss.detach(), "g_loss": out5[1]}
+
+
+class _GPPenaltyFn(Function):
+    @staticmethod
+    def forward(ctx, g, gamma, lam):
+        loss, norms = ops.gp_penalty_fwd(g, gamma, lam)
+        ctx.save_for_backward(g, norms)
+        ctx.gamma, ctx.lam = gamma, lam
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, up):
+        g, norms = ctx.saved_tensors
+        return ops.gp_penalty_bwd(g, norms, ctx.gamma, ctx.lam, up), None, None
+
+
+class GradientPenalty:
+    """WGAN-GP penalty, Common/gradient_penalty.py:4-37:
+        alpha ~ U[0,1] per sample; x_hat = real + alpha*(fake-real); g = d netD(x_hat)/d x_hat (create_graph);
+        penalty = lambdaGP * mean(((||g_b||_2 - gamma)/gamma)^2).
+    `netD` must be an spgan.Discriminator (its input-gradient node is differentiable once more)."""
+
+    def __init__(self, lambdaGP, gamma=1, vertex_num=2500, device=None):
+        self.lambdaGP = lambdaGP
+        self.gamma = gamma
+        self.vertex_num = vertex_num
+        self.device = device
+
+    def __call__(self, netD, real_data, fake_data, alpha: Optional[torch.Tensor] = None):
+        B = real_data.size(0)
+        fake_data = fake_data[:B]
+        if alpha is None:
+            alpha = torch.rand(B, 1, 1, device=real_data.device)
+        interpolates = ops.lerp_rows(real_data.detach(), fake_data.detach(), alpha.reshape(B)).requires_grad_(True)
+        disc = netD(interpolates)
+        grads = torch.autograd.grad(outputs=disc, inputs=interpolates, grad_outputs=torch.ones_like(disc),
+                                    create_graph=True, retain_graph=True, only_inputs=True)[0]
+        return _GPPenaltyFn.apply(grads.contiguous().view(B, -1), float(self.gamma), float(self.lambdaGP))

@@ -1,0 +1,232 @@
+"""nn.Module surface of the hot path: drop-in for the reference's `Generator`, `Discriminator`,
+`EdgeBlock`, `AdaptivePointNorm` (Generation/Generator.py, Generation/Discriminator.py).
+
+The modules own torch.nn layers purely as *parameter containers*: constructed in the reference's
+order, so `state_dict()` keys/shapes and default initial values match and reference checkpoints
+load both ways.  Their `forward` never calls those layers: it runs the HIP pipelines of
+`functions.py` / `nets.py`.  There is no CPU path: inputs must be on the GPU.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import functions as Fn
+from . import nets, ops
+from .functions import _Holder
+
+NEG = nets.NEG
+
+
+def _stack(spec):
+    """spec: list of ('conv1d'|'conv2d'|'linear', cin, cout[, ksize]) | ('bn1d'|'bn2d', c) | ('lrelu',) | ('tanh',)."""
+    layers = []
+    for s in spec:
+        kind = s[0]
+        if kind == "conv1d":
+            layers.append(nn.Conv1d(s[1], s[2], 1))
+        elif kind == "conv2d":
+            layers.append(nn.Conv2d(s[1], s[2], s[3] if len(s) > 3 else 1))
+        elif kind == "linear":
+            layers.append(nn.Linear(s[1], s[2]))
+        elif kind == "bn1d":
+            layers.append(nn.BatchNorm1d(s[1]))
+        elif kind == "bn2d":
+            layers.append(nn.BatchNorm2d(s[1]))
+        elif kind == "lrelu":
+            layers.append(nn.LeakyReLU(NEG, inplace=True))
+        elif kind == "tanh":
+            layers.append(nn.Tanh())
+        else:
+            raise ValueError(kind)
+    return nn.Sequential(*layers)
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError("%s: spgan modules run only on the GPU through libspgan_hip.so (no CPU fallback); got a %s tensor" % (what, t.device))
+
+
+def _named(module: nn.Module, prefix: str = ""):
+    names = [n for n, _ in module.named_parameters()]
+    params = [p for _, p in module.named_parameters()]
+    return [prefix + n for n in names], params
+
+
+def _buffers(module: nn.Module, prefix: str = ""):
+    return {prefix + n: b for n, b in module.named_buffers()}
+
+
+class AdaptivePointNorm(nn.Module):
+    """Generator.py:24-45: out = gamma*InstanceNorm(x) + beta, [gamma|beta] = Conv1d(style_dim, 2C, 1)(style) per point.
+    forward(input [B,C,N], style [B,S,N]) -> [B,C,N]"""
+
+    def __init__(self, in_channel: int, style_dim: int, use_eql: bool = False):
+        super().__init__()
+        if use_eql:
+            raise NotImplementedError("equalised-LR AdaIN (--eql) is not part of the accelerated path yet")
+        self.norm = nn.InstanceNorm1d(in_channel)
+        self.style = nn.Conv1d(style_dim, in_channel * 2, 1)
+        with torch.no_grad():
+            self.style.weight.normal_()
+            self.style.bias.zero_()
+            self.style.bias[:in_channel] = 1
+
+    def forward_pm(self, x_pm, style_pm, N: int, slope: float = 1.0):
+        return Fn.AdaINFn.apply(_Holder(prefix="a", N=N, slope=slope), x_pm, style_pm, self.style.weight, self.style.bias)
+
+    def forward(self, input, style):
+        _require_gpu(input, "AdaptivePointNorm")
+        B, C, N = input.shape
+        out = self.forward_pm(Fn.CmToPm.apply(input), Fn.CmToPm.apply(style), N)
+        return Fn.PmToCm.apply(out, B, N)
+
+
+class EdgeBlock(nn.Module):
+    """Generator.py:47-88.  forward(x [B,Fin,N]) -> [B,Fout,N]."""
+
+    def __init__(self, Fin: int, Fout: int, k: int, attn: bool = True):
+        super().__init__()
+        self.k, self.Fin, self.Fout = k, Fin, Fout
+        self.conv_w = _stack([("conv2d", Fin, Fout // 2), ("bn2d", Fout // 2), ("lrelu",), ("conv2d", Fout // 2, Fout), ("bn2d", Fout), ("lrelu",)])
+        self.conv_x = _stack([("conv2d", 2 * Fin, Fout, [1, 1]), ("bn2d", Fout), ("lrelu",)])
+        self.conv_out = nn.Conv2d(Fout, Fout, [1, k], [1, 1])
+        self.last_idx: Optional[torch.Tensor] = None      # int32 [B*N, k] global rows of the most recent forward
+
+    def forward_pm(self, x_pm, B: int, N: int, idx: Optional[torch.Tensor] = None, knn_mode: Optional[int] = None):
+        names, params = _named(self, "e.")
+        if knn_mode is None:
+            knn_mode = 1 if self.Fin <= 4 else 0          # coordinates: exact fp64 order; features: fp32 expanded form
+        h = _Holder(prefix="e", names=names, buffers=_buffers(self, "e."), B=B, N=N, k=self.k, training=self.training,
+                    knn_mode=knn_mode, idx=idx, last_idx=None)
+        out = Fn.EdgeBlockFn.apply(h, x_pm, *params)
+        self.last_idx = h.last_idx
+        return out
+
+    def forward(self, x, idx: Optional[torch.Tensor] = None):
+        _require_gpu(x, "EdgeBlock")
+        B, C, N = x.shape
+        if idx is not None and idx.dtype == torch.int64:
+            idx = ops.idx_from_local64(idx, B, N, self.k)
+        out = self.forward_pm(Fn.CmToPm.apply(x), B, N, idx)
+        return Fn.PmToCm.apply(out, B, N)
+
+
+class Generator(nn.Module):
+    """Generation/Generator.py:91-198.  forward(x [B,N,3], z [B,N,nz]) -> [B,3,N].
+    opts fields read: np, nk, nz, softmax, off, attn, use_head, eql, z_norm."""
+
+    def __init__(self, opts):
+        super().__init__()
+        self.opts = opts
+        self.np = opts.np
+        self.nk = opts.nk // 2
+        self.nz = opts.nz
+        self.off = opts.off
+        self.use_attn = opts.attn
+        self.use_head = opts.use_head
+        if getattr(opts, "eql", False) or self.use_attn:
+            raise NotImplementedError("--eql / --attn variants are not part of the accelerated path yet (SURVEY 8(f) N4)")
+        dim = 128
+        self.head = _stack([("conv1d", 3 + self.nz, dim), ("lrelu",), ("conv1d", dim, dim), ("lrelu",)])
+        self.global_conv = _stack([("linear", dim, dim), ("bn1d", dim), ("lrelu",), ("linear", dim, 512), ("bn1d", 512), ("lrelu",)])
+        self.tail = _stack([("conv1d", 512 + dim, 256), ("lrelu",), ("conv1d", 256, 64), ("lrelu",), ("conv1d", 64, 3), ("tanh",)])
+        if self.use_head:
+            self.pc_head = _stack([("conv1d", 3, dim // 2), ("lrelu",), ("conv1d", dim // 2, dim), ("lrelu",)])
+            self.EdgeConv1 = EdgeBlock(dim, dim, self.nk)
+            self.adain1 = AdaptivePointNorm(dim, dim)
+            self.EdgeConv2 = EdgeBlock(dim, dim, self.nk)
+            self.adain2 = AdaptivePointNorm(dim, dim)
+        else:
+            self.EdgeConv1 = EdgeBlock(3, 64, self.nk)
+            self.adain1 = AdaptivePointNorm(64, dim)
+            self.EdgeConv2 = EdgeBlock(64, dim, self.nk)
+            self.adain2 = AdaptivePointNorm(dim, dim)
+        self.lrelu1 = nn.LeakyReLU(nets.NEG_2)
+        self.lrelu2 = nn.LeakyReLU(nets.NEG_2)
+
+    def _mlp2(self, seq: nn.Sequential, x_pm):
+        h = _Holder(names=["l0", "l2"], acts=[ops.ACT_LRELU, ops.ACT_LRELU], slope=NEG)
+        return Fn.MLPFn.apply(h, x_pm, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias)
+
+    def _style(self, x, z):
+        B, N, _ = x.shape
+        if self.opts.z_norm:
+            z = z / (z.norm(p=2, dim=-1, keepdim=True) + 1e-8)
+        hz = ops.concat2(x.reshape(B * N, 3), z.reshape(B * N, -1))
+        return self._mlp2(self.head, hz)
+
+    def _body(self, x, style):
+        B, N, _ = x.shape
+        pc = x.reshape(B * N, 3).contiguous()
+        feat = self._mlp2(self.pc_head, pc) if self.use_head else pc
+        slope = nets.NEG_2
+        x1 = self.EdgeConv1.forward_pm(feat, B, N, knn_mode=0 if self.use_head else 1)
+        x1 = self.adain1.forward_pm(x1, style, N, slope)           # lrelu1 fused into the instance norm (Generator.py:175-176)
+        x2 = self.EdgeConv2.forward_pm(x1, B, N, knn_mode=0)
+        x2 = self.adain2.forward_pm(x2, style, N, slope)
+        gt_params = [dict(self.named_parameters())[n] for n in Fn.GT_NAMES]
+        h = _Holder(buffers=_buffers(self), B=B, N=N, training=self.training)
+        out = Fn.GlobalTailFn.apply(h, x2, *gt_params)
+        out = Fn.PmToCm.apply(out, B, N)
+        return x.transpose(2, 1) + out if self.off else out
+
+    def forward(self, x, z):
+        _require_gpu(x, "Generator")
+        return self._body(x, self._style(x, z))
+
+    def interpolate(self, x, z1, z2, selection, alpha, use_latent: bool = False):
+        """Generator.py:200-261: blend two latents (or two styles) on the selected points."""
+        sel = selection == 1
+        if not use_latent:
+            z = z1
+            z[:, sel] = z1[:, sel] * (1 - alpha) + z2[:, sel] * alpha
+            style = self._style(x, z)
+        else:
+            s1, s2 = self._style(x, z1), self._style(x, z2)
+            B, N, _ = x.shape
+            s1 = s1.view(B, N, -1); s2 = s2.view(B, N, -1)
+            s1[:, sel] = s1[:, sel] * (1 - alpha) + s2[:, sel] * alpha
+            style = s1.reshape(B * N, -1)
+        return self._body(x, style)
+
+
+class Discriminator(nn.Module):
+    """Generation/Discriminator.py:48-115.  forward(x [B,3,N]) -> [B,1].  Supports autograd.grad(create_graph=True)
+    w.r.t. its input followed by backward() (WGAN-GP)."""
+
+    def __init__(self, opts, num_point: int = 2048):
+        super().__init__()
+        self.num_point = num_point
+        self.small_d = opts.small_d
+        self.mlps = _stack([("conv1d", 3, 64), ("bn1d", 64), ("lrelu",), ("conv1d", 64, 128), ("bn1d", 128), ("lrelu",),
+                            ("conv1d", 128, 256), ("bn1d", 256), ("lrelu",)])
+        self.mode = "max"
+        dim = 512 if self.small_d else 1024
+        self.fc2 = _stack([("conv1d", 256, dim), ("bn1d", dim), ("lrelu",)])
+        self.mlp = _stack([("linear", dim, 512), ("lrelu",), ("linear", 512, 256), ("lrelu",), ("linear", 256, 64), ("lrelu",), ("linear", 64, 1)])
+
+    def forward(self, x):
+        _require_gpu(x, "Discriminator")
+        names, params = _named(self)
+        h = _Holder(names=names, buffers=_buffers(self), training=self.training)
+        return Fn.DiscriminatorFn.apply(h, x.contiguous(), *params)
+
+
+def get_edge_features(x, k, num=-1, idx=None, return_idx=False):
+    """Generation/modules.py:683-725: x [B,C,N] -> ee [B,2C,N,k] (= cat[central, neighbour-central]); optional injected /
+    returned idx is int64 [B, N*k] with per-shape local indices, like the reference.  Forward only (the Generator path
+    never materialises ee; EdgeBlock carries the gradient)."""
+    _require_gpu(x, "get_edge_features")
+    if x.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("get_edge_features is forward-only; use EdgeBlock for a differentiable edge convolution")
+    B, C, N = x.shape
+    x = x.contiguous()
+    if idx is None:
+        gidx = ops.knn(ops.cm_to_pm(x), B, N, k, 1 if C <= 4 else 0)
+        idx = ops.idx_to_local64(gidx, B, N)
+    idx = idx.contiguous().view(B, N * k)
+    ee = ops.edge_features_cm(x, idx, k)
+    return (ee, idx) if return_idx else ee

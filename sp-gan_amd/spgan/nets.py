@@ -1,0 +1,430 @@
+"""Hand-written forward / backward / double-backward pipelines over the HIP ops.
+
+Everything here works on raw tensors in the point-major layout ([M, C], M = B*N) and on
+parameter dicts keyed by the reference's state_dict names; `functions.py` wraps these
+pipelines into torch.autograd.Functions and `modules.py` into nn.Modules.
+
+All arithmetic goes through `spgan.ops` (HIP kernels).  torch is used for allocation, views,
+weight transposes (`.t().contiguous()`: data movement) and a few O(C) per-channel scalar
+formulas in the WGAN-GP double backward.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+NEG = 0.01     # Generator.py:22, Discriminator.py:19
+NEG_2 = 0.2    # Generator.py:23
+
+
+def _w2(w: Tensor) -> Tensor:
+    """[Cout, Cin, 1(,1)] conv weight -> [Cout, Cin] view."""
+    return w.view(w.shape[0], w.shape[1])
+
+
+def _t(w: Tensor) -> Tensor:
+    return w.t().contiguous()
+
+
+def _bn_train(mean, var, P, bufs, bn, count, training, update_running):
+    g, b = P[bn + ".weight"], P[bn + ".bias"]
+    rm = rv = None
+    if bufs is not None and (not training or update_running):
+        rm, rv = bufs[bn + ".running_mean"], bufs[bn + ".running_var"]
+    if training:
+        out = ops.bn_prepare(mean, var, g, b, count, True, rm, rv)
+        if rm is not None and (bn + ".num_batches_tracked") in bufs:
+            bufs[bn + ".num_batches_tracked"] += 1
+        return out
+    return ops.bn_prepare(None, None, g, b, count, False, rm, rv)
+
+
+# =============================================================================================
+# Discriminator (Generation/Discriminator.py:97-115)
+# =============================================================================================
+D_LAYERS = (("mlps.0", "mlps.1"), ("mlps.3", "mlps.4"), ("mlps.6", "mlps.7"), ("fc2.0", "fc2.1"))
+D_MLP = ("mlp.0", "mlp.2", "mlp.4", "mlp.6")
+
+
+def d_forward(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], x_cm: Tensor, training: bool = True,
+              update_running: bool = True):
+    """x [B,3,N] -> logits [B,1] plus the saved context for backward."""
+    B, _, N = x_cm.shape
+    M = B * N
+    x_pm = ops.cm_to_pm(x_cm)
+    ys, bns = [], []
+    a, pro = x_pm, None
+    for conv, bn in D_LAYERS:
+        W, b = _w2(P[conv + ".weight"]), P[conv + ".bias"]
+        if training:
+            y, mean, var = ops.gemm_nt(a, W, b, pro=pro, stats=True)
+        else:
+            y, mean, var = ops.gemm_nt(a, W, b, pro=pro), None, None
+        sc, sh, inv, mu = _bn_train(mean, var, P, bufs, bn, M, training, update_running)
+        ys.append(y); bns.append((sc, sh, inv, mu))
+        a, pro = y, (sc, sh, NEG)
+    pooled, argmax = ops.maxpool(ys[3], B, N, bns[3][0], bns[3][1], NEG)        # BN + LeakyReLU + max over N fused
+    h, hs = pooled, []
+    for i, name in enumerate(D_MLP):
+        last = i == len(D_MLP) - 1
+        h = ops.gemm_nt(h, P[name + ".weight"], P[name + ".bias"], act=ops.ACT_NONE if last else ops.ACT_LRELU, slope=NEG)
+        hs.append(h)
+    ctx = dict(B=B, N=N, x_pm=x_pm, ys=ys, bns=bns, pooled=pooled, argmax=argmax, hs=hs, training=training)
+    return hs[-1], ctx
+
+
+def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for_double: bool = False):
+    """First-order backward.  Returns (dx_cm | None, {name: grad} | None, saved-for-double-backward | None)."""
+    B, N = ctx["B"], ctx["N"]
+    M = B * N
+    ys, bns, hs, pooled, argmax = ctx["ys"], ctx["bns"], ctx["hs"], ctx["pooled"], ctx["argmax"]
+    grads: Dict[str, Tensor] = {}
+    dout = dout.contiguous()
+    # ---- MLP head (mlp.6 <- mlp.4 <- mlp.2 <- mlp.0)
+    acts = [pooled, hs[0], hs[1], hs[2]]          # input of mlp.0/2/4/6
+    d = dout
+    dhs = [None, None, None, dout]               # gradient w.r.t. the *pre-activation* output of each MLP layer
+    for li in (3, 2, 1, 0):
+        name = D_MLP[li]
+        if need_dparams:
+            grads[name + ".weight"] = ops.gemm_tn(d, acts[li])
+            grads[name + ".bias"] = ops.colsum(d)[0]
+        Wt = _t(P[name + ".weight"])
+        if li > 0:
+            d = ops.gemm_nt_maskout(d, Wt, acts[li], NEG)     # through the (in-place) LeakyReLU of the layer below
+            dhs[li - 1] = d
+        else:
+            gpool = ops.gemm_nt(d, Wt)
+    # ---- max-pool + BN4 (sparse incoming gradient)
+    sc4, sh4, inv4, mu4 = bns[3]
+    gval, sums4 = ops.pool_bwd_stats(gpool, pooled, argmax, ys[3], mu4, inv4, NEG)
+    C4 = gval.shape[1]
+    if need_dparams:
+        grads["fc2.1.weight"] = sums4[C4:].clone(); grads["fc2.1.bias"] = sums4[:C4].clone()
+    if not ctx["training"]:
+        sums4 = torch.zeros_like(sums4)
+    dy = ops.bn_bwd_apply_sparse(gval, argmax, ys[3], N, mu4, inv4, P["fc2.1.weight"], sums4, M)
+    dys = [None, None, None, dy]
+    gs = [None, None, None, None]
+    sums_all = [None, None, None, sums4]
+    # ---- conv stack fc2.0 <- mlps.6 <- mlps.3 <- mlps.0
+    for li in (3, 2, 1, 0):
+        conv, bn = D_LAYERS[li]
+        W = _w2(P[conv + ".weight"])
+        if need_dparams:
+            if li > 0:
+                grads[conv + ".weight"] = ops.gemm_tn(dy, ys[li - 1], pro=(bns[li - 1][0], bns[li - 1][1], NEG)).view_as(P[conv + ".weight"])
+            else:
+                grads[conv + ".weight"] = ops.gemm_tn(dy, ctx["x_pm"]).view_as(P[conv + ".weight"])
+            grads[conv + ".bias"] = torch.zeros_like(P[conv + ".bias"])     # bias before a train-mode BN: exactly zero gradient
+            if not ctx["training"]:
+                grads[conv + ".bias"] = ops.colsum(dy)[0]
+        if li > 0:
+            pconv, pbn = D_LAYERS[li - 1]
+            sc, sh, inv, mu = bns[li - 1]
+            g, s0, s1 = ops.gemm_nt_bnbwd(dy, _t(W), ys[li - 1], sc, sh, mu, inv, NEG)
+            if need_dparams:
+                grads[pbn + ".weight"] = s1; grads[pbn + ".bias"] = s0
+            sums = torch.cat([s0, s1]) if ctx["training"] else torch.zeros(2 * s0.numel(), device=s0.device)
+            dy = ops.bn_bwd_apply(g, ys[li - 1], mu, inv, P[pbn + ".weight"], sums, M)
+            dys[li - 1] = dy; gs[li - 1] = g; sums_all[li - 1] = sums
+    dx_cm = None
+    if need_dx:
+        dx_pm = ops.gemm_nt(dy, _t(_w2(P["mlps.0.weight"])))
+        dx_cm = ops.pm_to_cm(dx_pm, B, N)
+    saved = None
+    if keep_for_double:
+        saved = dict(dout=dout, dhs=dhs, gval=gval, dys=dys, gs=gs, sums=sums_all)
+    return dx_cm, (grads if need_dparams else None), saved
+
+
+def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
+    """Gradient of a scalar R(dx) w.r.t. D's parameters, where dx = d_backward(...)[0] (WGAN-GP:
+    Common/gradient_penalty.py:31-35 followed by .backward()).  v = dR/d(dx) [B,3,N].
+    Phase A walks the first-order backward graph in reverse (layer 1 -> top), phase B is an ordinary
+    backward sweep of the adjoints that phase A deposits on the forward activations (derivation in
+    DESIGN.md).  Returns ({name: grad}, dR/dx [B,3,N] | None)."""
+    B, N = ctx["B"], ctx["N"]
+    M = B * N
+    ys, bns, hs, pooled, argmax = ctx["ys"], ctx["bns"], ctx["hs"], ctx["pooled"], ctx["argmax"]
+    dys, gs, sums_all = saved["dys"], saved["gs"], saved["sums"]
+    grads: Dict[str, Tensor] = {}
+    rM = 1.0 / M
+    q = ops.cm_to_pm(v_dx_cm.contiguous())                       # adjoint of ga_0 [M,3]
+    xbarA: List[Optional[Tensor]] = [None] * 4                   # phase-A adjoint on xhat_l
+    sbarA: List[Optional[Tensor]] = [None] * 4                   # phase-A adjoint on invstd_l   [C]
+    xsum0: List[Optional[Tensor]] = [None] * 4                   # sum_m xbarA, sum_m xbarA*xhat (closed form)
+    xsum1: List[Optional[Tensor]] = [None] * 4
+    # ---------------------------------------------------------------- phase A
+    for li in range(4):
+        conv, bn = D_LAYERS[li]
+        W = _w2(P[conv + ".weight"])
+        sc, sh, inv, mu = bns[li]
+        gamma = P[bn + ".weight"]
+        C = W.shape[0]
+        grads[conv + ".weight"] = ops.gemm_tn(dys[li], q)                       # gy_l^T q_{l-1}
+        u = ops.gemm_nt(q, W)                                                    # adjoint of gy_l
+        if li == 3:
+            gz = ops.scatter_rows(saved["gval"], argmax, M)
+        else:
+            gz = gs[li]
+        S0, S1 = sums_all[li][:C], sums_all[li][C:]
+        U0, U1, Ugz = ops.bn_dbl_stats(u, ys[li], gz, mu, inv)
+        core = Ugz - (U0 * S0 + U1 * S1) * rM
+        grads[bn + ".weight"] = inv * core                                       # adjoint of gamma via gy
+        sbarA[li] = gamma * core
+        q, xbarA[li] = ops.bn_dbl_apply(u, ys[li], gz, mu, inv, sc, sh, NEG, gamma, S1, U0, U1, M)
+        gsM = gamma * inv * rM
+        xsum0[li] = -gsM * (U0 * S1 + S0 * U1)
+        xsum1[li] = -2.0 * gsM * (U1 * S1)
+    # top: ga_4 = scatter(gpool) -> MLP backward graph in reverse
+    t = ops.gather_rows(q, argmax)                                               # adjoint of gpool [B,C4]
+    dhs, dout = saved["dhs"], saved["dout"]
+    acts = [pooled, hs[0], hs[1], hs[2]]
+    for li in (0, 1, 2, 3):
+        name = D_MLP[li]
+        grads[name + ".weight"] = ops.gemm_tn(dhs[li], t)                        # (grad wrt pre-act of layer li)^T . adjoint
+        grads[name + ".bias"] = torch.zeros_like(P[name + ".bias"])
+        if li < 3:
+            t = ops.gemm_nt_maskout(t, P[name + ".weight"], hs[li], NEG)
+    # ---------------------------------------------------------------- phase B
+    abar_g = None      # (abar_l * mask_l) and its column sums, produced by the dgrad epilogue of layer l+1
+    dx = None
+    for li in (3, 2, 1, 0):
+        conv, bn = D_LAYERS[li]
+        W = _w2(P[conv + ".weight"])
+        sc, sh, inv, mu = bns[li]
+        gamma = P[bn + ".weight"]
+        C = W.shape[0]
+        if abar_g is None:
+            X = xbarA[li]
+            T0, T1 = xsum0[li], xsum1[li]
+            grads[bn + ".bias"] = torch.zeros_like(gamma)
+        else:
+            g, s0, s1 = abar_g
+            X = ops.col_scale_add(xbarA[li], g, gamma)                           # xbarA + gamma*g
+            T0, T1 = xsum0[li] + gamma * s0, xsum1[li] + gamma * s1
+            grads[bn + ".weight"] = grads[bn + ".weight"] + s1
+            grads[bn + ".bias"] = s0
+        sums = torch.cat([T0, T1 + inv * sbarA[li]])
+        ybar = ops.bn_bwd_apply(X, ys[li], mu, inv, None, sums, M)
+        if li > 0:
+            psc, psh, pinv, pmu = bns[li - 1]
+            gw = ops.gemm_tn(ybar, ys[li - 1], pro=(psc, psh, NEG))
+            abar_g = ops.gemm_nt_bnbwd(ybar, _t(W), ys[li - 1], psc, psh, pmu, pinv, NEG)
+        else:
+            gw = ops.gemm_tn(ybar, ctx["x_pm"])
+            if need_dx:
+                dx = ops.pm_to_cm(ops.gemm_nt(ybar, _t(W)), B, N)
+        grads[conv + ".weight"] = (grads[conv + ".weight"] + gw).view_as(P[conv + ".weight"])
+        grads[conv + ".bias"] = torch.zeros_like(P[conv + ".bias"])
+    return grads, dx
+
+
+# =============================================================================================
+# EdgeBlock (Generation/Generator.py:47-88), point-major, restructured per point
+# =============================================================================================
+def conv_out_weight_pm(w: Tensor) -> Tensor:
+    """conv_out.weight [F,F,1,k] -> [F, k*F] with K index r*F + c (matches T's layout)."""
+    F_, _, _, k = w.shape
+    return w[:, :, 0, :].permute(0, 2, 1).reshape(F_, k * F_).contiguous()
+
+
+def conv_out_weight_grad_from_pm(g: Tensor, F_: int, k: int) -> Tensor:
+    return g.view(F_, k, F_).permute(0, 2, 1).reshape(F_, F_, 1, k).contiguous()
+
+
+def edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int, training: bool = True, update_running: bool = True):
+    """x [M,C] (point-major), idx int32 [M,k] -> out [M,F] + ctx."""
+    M, C = x.shape
+    k = idx.shape[1]
+    Ww0 = P[pre + ".conv_w.0.weight"]; Wx = P[pre + ".conv_x.0.weight"]
+    H, F_ = Ww0.shape[0], Wx.shape[0]
+    b1, bx = P[pre + ".conv_w.0.bias"], P[pre + ".conv_x.0.bias"]
+    Wcat = ops.edge_wcat(_w2(Ww0), _w2(Wx))
+    PQR = ops.gemm_nt(x, Wcat)                                                   # [M, H+2F]
+    E = M * k
+    if training:
+        mean, var = ops.edge_stats(PQR, idx, b1, bx)
+        bn1 = _bn_train(mean[:H].contiguous(), var[:H].contiguous(), P, bufs, pre + ".conv_w.1", E, True, update_running)
+        bnx = _bn_train(mean[H:].contiguous(), var[H:].contiguous(), P, bufs, pre + ".conv_x.1", E, True, update_running)
+    else:
+        bn1 = _bn_train(None, None, P, bufs, pre + ".conv_w.1", E, False, False)
+        bnx = _bn_train(None, None, P, bufs, pre + ".conv_x.1", E, False, False)
+    W2, b2 = _w2(P[pre + ".conv_w.3.weight"]), P[pre + ".conv_w.3.bias"]
+    if training:
+        h2pre, m2, v2 = ops.gemm_nt(PQR[:, :H], W2, b2, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1), stats=True)
+    else:
+        h2pre, m2, v2 = ops.gemm_nt(PQR[:, :H], W2, b2, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1)), None, None
+    bn2 = _bn_train(m2, v2, P, bufs, pre + ".conv_w.4", E, training, update_running)
+    T = ops.edge_attend_fwd(h2pre, bn2[0], bn2[1], PQR, idx, bx, bnx[0], bnx[1], NEG)
+    Wo = conv_out_weight_pm(P[pre + ".conv_out.weight"])
+    out = ops.gemm_nt(T, Wo, P[pre + ".conv_out.bias"])
+    ctx = dict(x=x, idx=idx, B=B, N=N, PQR=PQR, Wcat=Wcat, bn1=bn1, bnx=bnx, bn2=bn2, h2pre=h2pre, T=T, Wo=Wo, H=H, F=F_, k=k, training=training)
+    return out, ctx
+
+
+def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor], need_dx: bool = True):
+    """-> (dx [M,C] | None, {name: grad})"""
+    x, idx, PQR, H, F_, k = ctx["x"], ctx["idx"], ctx["PQR"], ctx["H"], ctx["F"], ctx["k"]
+    M = x.shape[0]
+    E = M * k
+    bn1, bnx, bn2 = ctx["bn1"], ctx["bnx"], ctx["bn2"]
+    b1, bx = P[pre + ".conv_w.0.bias"], P[pre + ".conv_x.0.bias"]
+    g: Dict[str, Tensor] = {}
+    dout = dout.contiguous()
+    # conv_out
+    g[pre + ".conv_out.bias"] = ops.colsum(dout)[0]
+    g[pre + ".conv_out.weight"] = conv_out_weight_grad_from_pm(ops.gemm_tn(dout, ctx["T"]), F_, k)
+    dT = ops.gemm_nt(dout, _t(ctx["Wo"]))                                         # [M, k*F]
+    # softmax * conv_x product, both LeakyReLUs
+    g2, gy, sums2, sumsy = ops.edge_attend_bwd(dT, ctx["h2pre"], bn2[0], bn2[1], bn2[3], bn2[2], PQR, idx, bx, bnx[0], bnx[1], bnx[3], bnx[2], NEG)
+    g[pre + ".conv_w.4.weight"] = sums2[F_:].clone(); g[pre + ".conv_w.4.bias"] = sums2[:F_].clone()
+    g[pre + ".conv_x.1.weight"] = sumsy[F_:].clone(); g[pre + ".conv_x.1.bias"] = sumsy[:F_].clone()
+    if not ctx["training"]:
+        sums2 = torch.zeros_like(sums2); sumsy = torch.zeros_like(sumsy)
+    # conv_w.4 BN backward -> conv_w.3
+    dh2 = ops.bn_bwd_apply(g2, ctx["h2pre"], bn2[3], bn2[2], P[pre + ".conv_w.4.weight"], sums2, E)
+    W2 = _w2(P[pre + ".conv_w.3.weight"])
+    g[pre + ".conv_w.3.weight"] = ops.gemm_tn(dh2, PQR[:, :H], pro=(bn1[0], bn1[1], NEG), edge=(idx, b1)).view_as(P[pre + ".conv_w.3.weight"])
+    g[pre + ".conv_w.3.bias"] = torch.zeros_like(P[pre + ".conv_w.3.bias"]) if ctx["training"] else ops.colsum(dh2)[0]
+    g1, s10, s11 = ops.gemm_nt_bnbwd(dh2, _t(W2), PQR[:, :H], bn1[0], bn1[1], bn1[3], bn1[2], NEG, edge=(idx, b1))
+    g[pre + ".conv_w.1.weight"] = s11; g[pre + ".conv_w.1.bias"] = s10
+    sums1 = torch.cat([s10, s11]) if ctx["training"] else torch.zeros(2 * H, device=x.device)
+    # BN backward of conv_w.0 / conv_x.0 outputs fused with the edge -> point reduction
+    dPQR = ops.edge_scatter(g1, gy, PQR, idx, csr[0], csr[1], b1, bn1[3], bn1[2], P[pre + ".conv_w.1.weight"], sums1,
+                            bx, bnx[3], bnx[2], P[pre + ".conv_x.1.weight"], sumsy)
+    dWcat = ops.gemm_tn(dPQR, x)
+    dW0, dWx = ops.edge_wcat_bwd(dWcat, H, F_)
+    g[pre + ".conv_w.0.weight"] = dW0.view_as(P[pre + ".conv_w.0.weight"])
+    g[pre + ".conv_x.0.weight"] = dWx.view_as(P[pre + ".conv_x.0.weight"])
+    # biases in front of a train-mode BatchNorm: mathematically zero gradient
+    g[pre + ".conv_w.0.bias"] = torch.zeros_like(b1)
+    g[pre + ".conv_x.0.bias"] = torch.zeros_like(bx)
+    dx = ops.gemm_nt(dPQR, _t(ctx["Wcat"])) if need_dx else None
+    return dx, g
+
+
+# =============================================================================================
+# AdaptivePointNorm (Generator.py:24-45) with the preceding LeakyReLU(0.2) optionally fused (slope)
+# =============================================================================================
+def adain_forward(P, pre: str, x: Tensor, style: Tensor, N: int, slope: float = 1.0):
+    Ws, bs = _w2(P[pre + ".style.weight"]), P[pre + ".style.bias"]
+    gb = ops.gemm_nt(style, Ws, bs)                                              # [M, 2C] = [gamma | beta]
+    imean, ivar = ops.colstats(x, N, slope)
+    imean = imean.contiguous(); ivar = ivar.contiguous()
+    out = ops.adain_fwd(x, N, slope, imean, ivar, gb)
+    return out, dict(x=x, style=style, gb=gb, imean=imean, ivar=ivar, N=N, slope=slope)
+
+
+def adain_backward(P, pre: str, ctx, dout: Tensor, need_dx: bool = True, need_dstyle: bool = True, need_dparams: bool = True):
+    dx, dgb = ops.adain_bwd(dout.contiguous(), ctx["x"], ctx["N"], ctx["slope"], ctx["imean"], ctx["ivar"], ctx["gb"])
+    g = {}
+    if need_dparams:
+        g[pre + ".style.weight"] = ops.gemm_tn(dgb, ctx["style"]).view_as(P[pre + ".style.weight"])
+        g[pre + ".style.bias"] = ops.colsum(dgb)[0]
+    dstyle = ops.gemm_nt(dgb, _t(_w2(P[pre + ".style.weight"]))) if need_dstyle else None
+    return (dx if need_dx else None), dstyle, g
+
+
+# =============================================================================================
+# point-wise MLP chains (Generator head / tail) and the global feature branch
+# =============================================================================================
+def mlp_forward(P, names: List[str], acts: List[int], x: Tensor, slope: float = NEG, rowbias: Optional[Tensor] = None, N: int = 0,
+                first_weight: Optional[Tensor] = None):
+    """Chain of 1x1 convs with fused bias + activation.  `first_weight` overrides the first layer's
+    weight view (tail.0 uses only the last 128 input columns; the global part enters as `rowbias`)."""
+    hs = []
+    h = x
+    for i, (n, a) in enumerate(zip(names, acts)):
+        W = first_weight if (i == 0 and first_weight is not None) else _w2(P[n + ".weight"])
+        if i == 0 and rowbias is not None:
+            h = ops.gemm_nt(h, W, None, rowbias=rowbias, rows_per_group=N, act=a, slope=slope)
+        else:
+            h = ops.gemm_nt(h, W, P[n + ".bias"], act=a, slope=slope)
+        hs.append(h)
+    return h, dict(x=x, hs=hs, names=names, acts=acts, slope=slope, first_weight=first_weight, rowbias=rowbias is not None, N=N)
+
+
+def mlp_backward(P, ctx, dout: Tensor, need_dx: bool = True, need_dparams: bool = True):
+    """-> (dx | None, {name: grad}, drowbias | None).  For the first layer with `first_weight`, the weight
+    gradient returned under key names[0]+'.weight.part' covers only those columns."""
+    names, acts, hs, slope = ctx["names"], ctx["acts"], ctx["hs"], ctx["slope"]
+    g: Dict[str, Tensor] = {}
+    d = ops.act_bwd(dout.contiguous(), hs[-1], acts[-1], slope)                  # gradient w.r.t. the last pre-activation
+    drb = None
+    for i in range(len(names) - 1, -1, -1):
+        inp = hs[i - 1] if i > 0 else ctx["x"]
+        first_part = i == 0 and ctx["first_weight"] is not None
+        W = ctx["first_weight"] if first_part else _w2(P[names[i] + ".weight"])
+        if need_dparams:
+            gw = ops.gemm_tn(d, inp)
+            if first_part:
+                g[names[i] + ".weight.part"] = gw
+            else:
+                g[names[i] + ".weight"] = gw.view_as(P[names[i] + ".weight"])
+            if i == 0 and ctx["rowbias"]:
+                drb = ops.colsum(d, ctx["N"])                                    # per-shape bias gradient [B, C]
+            else:
+                g[names[i] + ".bias"] = ops.colsum(d)[0]
+        elif i == 0 and ctx["rowbias"]:
+            drb = ops.colsum(d, ctx["N"])
+        if i > 0:
+            if acts[i - 1] == ops.ACT_LRELU:
+                d = ops.gemm_nt_maskout(d, _t(W), hs[i - 1], slope)
+            else:
+                d = ops.act_bwd(ops.gemm_nt(d, _t(W)), hs[i - 1], acts[i - 1], slope)
+        elif need_dx:
+            d = ops.gemm_nt(d, _t(W))
+        else:
+            d = None
+    return d, g, drb
+
+
+def global_forward(P, bufs, a2: Tensor, B: int, N: int, training: bool = True, update_running: bool = True):
+    """max over N -> Linear+BN1d+LReLU -> Linear+BN1d+LReLU (Generator.py:119-126,183-186).  Returns the
+    second pre-BN tensor and its BN affine (the activation is applied by the consumer's prologue)."""
+    gmax, garg = ops.maxpool(a2, B, N)
+    W0, b0 = P["global_conv.0.weight"], P["global_conv.0.bias"]
+    W3, b3 = P["global_conv.3.weight"], P["global_conv.3.bias"]
+    if training:
+        y0, m0, v0 = ops.gemm_nt(gmax, W0, b0, stats=True)
+    else:
+        y0, m0, v0 = ops.gemm_nt(gmax, W0, b0), None, None
+    bn0 = _bn_train(m0, v0, P, bufs, "global_conv.1", B, training, update_running)
+    if training:
+        y3, m3, v3 = ops.gemm_nt(y0, W3, b3, pro=(bn0[0], bn0[1], NEG), stats=True)
+    else:
+        y3, m3, v3 = ops.gemm_nt(y0, W3, b3, pro=(bn0[0], bn0[1], NEG)), None, None
+    bn3 = _bn_train(m3, v3, P, bufs, "global_conv.4", B, training, update_running)
+    return dict(gmax=gmax, garg=garg, y0=y0, bn0=bn0, y3=y3, bn3=bn3, B=B, N=N, training=training)
+
+
+def global_backward(P, gctx, W_g: Tensor, drb: Tensor, da2: Tensor):
+    """drb [B,256] = gradient w.r.t. the per-shape bias of tail.0 (= W_g . lrelu(bn(y3)) + b).
+    Adds the max-pool gradient into da2 in place.  -> {name: grad} incl. 'tail.0.weight.global' [256,512]."""
+    B = gctx["B"]
+    g: Dict[str, Tensor] = {}
+    bn0, bn3, y0, y3 = gctx["bn0"], gctx["bn3"], gctx["y0"], gctx["y3"]
+    tr = gctx["training"]
+    g["tail.0.weight.global"] = ops.gemm_tn(drb, y3, pro=(bn3[0], bn3[1], NEG))
+    g["tail.0.bias"] = ops.colsum(drb)[0]
+    g3, s0, s1 = ops.gemm_nt_bnbwd(drb, _t(W_g), y3, bn3[0], bn3[1], bn3[3], bn3[2], NEG)
+    g["global_conv.4.weight"] = s1; g["global_conv.4.bias"] = s0
+    sums = torch.cat([s0, s1]) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
+    dy3 = ops.bn_bwd_apply(g3, y3, bn3[3], bn3[2], P["global_conv.4.weight"], sums, B)
+    g["global_conv.3.weight"] = ops.gemm_tn(dy3, y0, pro=(bn0[0], bn0[1], NEG))
+    g["global_conv.3.bias"] = torch.zeros_like(P["global_conv.3.bias"]) if tr else ops.colsum(dy3)[0]
+    g0, s0, s1 = ops.gemm_nt_bnbwd(dy3, _t(P["global_conv.3.weight"]), y0, bn0[0], bn0[1], bn0[3], bn0[2], NEG)
+    g["global_conv.1.weight"] = s1; g["global_conv.1.bias"] = s0
+    sums = torch.cat([s0, s1]) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
+    dy0 = ops.bn_bwd_apply(g0, y0, bn0[3], bn0[2], P["global_conv.1.weight"], sums, B)
+    g["global_conv.0.weight"] = ops.gemm_tn(dy0, gctx["gmax"])
+    g["global_conv.0.bias"] = torch.zeros_like(P["global_conv.0.bias"]) if tr else ops.colsum(dy0)[0]
+    dgmax = ops.gemm_nt(dy0, _t(P["global_conv.0.weight"]))
+    ops.maxpool_bwd_add(dgmax, gctx["garg"], da2)
+    return g

@@ -152,9 +152,9 @@ def concat2(a: Tensor, b: Tensor) -> Tensor:
 
 
 # ----------------------------------------------------------------------------- contractions
-def _finalize(partials: Tensor, groups: int, tpg: int, Cn: int, G: int, mode: int) -> Tuple[Tensor, Tensor]:
+def _finalize(partials: Tensor, groups: int, tpg: int, Cn: int, G: int, mode: int, tile_rows: int = 0) -> Tuple[Tensor, Tensor]:
     out = torch.empty((2, groups, Cn), dtype=torch.float32, device=partials.device)
-    check(_lib.load().spgan_colstats_finalize(_p(partials), groups, tpg, Cn, G, mode, _p(out[0]), _p(out[1]), _s()), "colstats_finalize")
+    check(_lib.load().spgan_colstats_finalize(_p(partials), groups, tpg, Cn, G, mode, tile_rows, _p(out[0]), _p(out[1]), _s()), "colstats_finalize")
     return out[0], out[1]
 
 
@@ -342,3 +342,303 @@ def maxpool(y: Tensor, B: int, N: int, scale: Optional[Tensor] = None, shift: Op
     arg = torch.empty((B, Cn), dtype=torch.int32, device=y.device)
     check(_lib.load().spgan_maxpool(_p(y), _ld(y), B, N, Cn, _p(scale), _p(shift), float(slope), _p(out), _p(arg), _s()), "maxpool", B=B, N=N, C=Cn)
     return out, arg
+
+
+# ----------------------------------------------------------------------------- EdgeBlock gather-side ops
+def edge_wcat(Ww0: Tensor, Wx: Tensor) -> Tensor:
+    """[W1; Wd; Wc-Wd] from conv_w.0.weight [H,C] and conv_x.0.weight [F,2C] = [Wc|Wd] -> [H+2F, C]."""
+    _f32(Ww0, "Ww0", 2); _f32(Wx, "Wx", 2)
+    H, Cc = Ww0.shape
+    F_ = Wx.shape[0]
+    if not (Ww0.is_contiguous() and Wx.is_contiguous()) or Wx.shape[1] != 2 * Cc:
+        raise ValueError("expected contiguous Ww0 [H,C] and Wx [F,2C]")
+    out = torch.empty((H + 2 * F_, Cc), dtype=torch.float32, device=Ww0.device)
+    check(_lib.load().spgan_edge_wcat(_p(Ww0), _p(Wx), H, F_, Cc, _p(out), _s()), "edge_wcat")
+    return out
+
+
+def edge_wcat_bwd(dWcat: Tensor, H: int, F_: int) -> Tuple[Tensor, Tensor]:
+    _f32(dWcat, "dWcat", 2)
+    Cc = dWcat.shape[1]
+    if not dWcat.is_contiguous() or dWcat.shape[0] != H + 2 * F_:
+        raise ValueError("dWcat must be contiguous [H+2F, C]")
+    dW0 = torch.empty((H, Cc), dtype=torch.float32, device=dWcat.device)
+    dWx = torch.empty((F_, 2 * Cc), dtype=torch.float32, device=dWcat.device)
+    check(_lib.load().spgan_edge_wcat_bwd(_p(dWcat), H, F_, Cc, _p(dW0), _p(dWx), _s()), "edge_wcat_bwd")
+    return dW0, dWx
+
+
+def _pqr(PQR: Tensor, H: int, F_: int) -> Tensor:
+    _f32(PQR, "PQR", 2)
+    if not PQR.is_contiguous() or PQR.shape[1] != H + 2 * F_:
+        raise ValueError("PQR must be contiguous [M, H+2F]")
+    return PQR
+
+
+def edge_stats(PQR: Tensor, idx: Tensor, b1: Tensor, bx: Tensor) -> Tuple[Tensor, Tensor]:
+    """mean/biased var over all M*k edges of [ (P_j-P_i)+b1 | (R_i+Q_j)+bx ] -> ([H+F], [H+F])."""
+    H, F_ = b1.numel(), bx.numel()
+    _pqr(PQR, H, F_); _i32(idx, "idx")
+    M_, k = idx.shape
+    lib = _lib.load()
+    tr = lib.spgan_edge_stats_tile_rows(k)
+    tiles = (M_ * k + tr - 1) // tr
+    part = torch.empty((tiles, H + F_, 2), dtype=torch.float32, device=PQR.device)
+    check(lib.spgan_edge_stats(_p(PQR), PQR.shape[1], _p(idx), M_, k, H, F_, _p(_vec(b1, H, "b1")), _p(_vec(bx, F_, "bx")), _p(part), _s()),
+          "edge_stats", M=M_, k=k, H=H, F=F_)
+    mean, var = _finalize(part, 1, tiles, H + F_, M_ * k, 0, tr)
+    return mean[0], var[0]
+
+
+def edge_attend_fwd(h2pre: Tensor, sc2: Tensor, sh2: Tensor, PQR: Tensor, idx: Tensor, bx: Tensor, scx: Tensor, shx: Tensor,
+                    slope: float) -> Tensor:
+    """T[M, k*F]: softmax over the k neighbours of lrelu(bn(h2pre)) times lrelu(bn((R_i+Q_j)+bx))."""
+    F_ = bx.numel()
+    H = PQR.shape[1] - 2 * F_
+    _pqr(PQR, H, F_); _i32(idx, "idx")
+    M_, k = idx.shape
+    _f32(h2pre, "h2pre", 2)
+    if not h2pre.is_contiguous() or h2pre.shape != (M_ * k, F_):
+        raise ValueError("h2pre must be contiguous [M*k, F]")
+    T = torch.empty((M_, k * F_), dtype=torch.float32, device=PQR.device)
+    check(_lib.load().spgan_edge_attend_fwd(_p(h2pre), _p(_vec(sc2, F_, "sc2")), _p(_vec(sh2, F_, "sh2")), _p(PQR), PQR.shape[1], H, F_,
+                                            _p(idx), M_, k, _p(_vec(bx, F_, "bx")), _p(_vec(scx, F_, "scx")), _p(_vec(shx, F_, "shx")),
+                                            float(slope), _p(T), _s()), "edge_attend_fwd", M=M_, k=k, F=F_)
+    return T
+
+
+def edge_attend_bwd(dT: Tensor, h2pre: Tensor, sc2, sh2, mean2, inv2, PQR: Tensor, idx: Tensor, bx, scx, shx, meanx, invx, slope: float):
+    """-> (g2 [E,F], gy [E,F], sums2 [2F] = [sum g2 | sum g2*xhat2], sumsy [2F])."""
+    F_ = bx.numel()
+    H = PQR.shape[1] - 2 * F_
+    _pqr(PQR, H, F_); _i32(idx, "idx")
+    M_, k = idx.shape
+    _f32(dT, "dT", 2); _f32(h2pre, "h2pre", 2)
+    if not (dT.is_contiguous() and h2pre.is_contiguous()) or dT.numel() != M_ * k * F_ or h2pre.numel() != M_ * k * F_:
+        raise ValueError("dT / h2pre must be contiguous with M*k*F elements")
+    lib = _lib.load()
+    tp = lib.spgan_edge_attend_bwd_tile_points()
+    tiles = (M_ + tp - 1) // tp
+    g2 = torch.empty((M_ * k, F_), dtype=torch.float32, device=PQR.device)
+    gy = torch.empty((M_ * k, F_), dtype=torch.float32, device=PQR.device)
+    part = torch.empty((tiles, 2 * F_, 2), dtype=torch.float32, device=PQR.device)
+    v = lambda t, n: _p(_vec(t, F_, n))
+    check(lib.spgan_edge_attend_bwd(_p(dT), _p(h2pre), v(sc2, "sc2"), v(sh2, "sh2"), v(mean2, "mean2"), v(inv2, "inv2"), _p(PQR), PQR.shape[1],
+                                    H, F_, _p(idx), M_, k, v(bx, "bx"), v(scx, "scx"), v(shx, "shx"), v(meanx, "meanx"), v(invx, "invx"),
+                                    float(slope), _p(g2), _p(gy), _p(part), _s()), "edge_attend_bwd", M=M_, k=k, F=F_)
+    s0, s1 = _finalize(part, 1, tiles, 2 * F_, tiles * tp, 1, tp)
+    sums2 = torch.cat([s0[0, :F_], s1[0, :F_]])
+    sumsy = torch.cat([s0[0, F_:], s1[0, F_:]])
+    return g2, gy, sums2, sumsy
+
+
+def edge_scatter(g1: Tensor, gy: Tensor, PQR: Tensor, idx: Tensor, rowptr: Tensor, src: Tensor, b1, mean1, inv1, gam1, sums1, bx, meanx,
+                 invx, gamx, sumsx) -> Tensor:
+    """BatchNorm backward of both per-edge pre-activations + reduction onto points -> dPQR [M, H+2F]."""
+    H, F_ = b1.numel(), bx.numel()
+    _pqr(PQR, H, F_); _i32(idx, "idx"); _i32(rowptr, "rowptr"); _i32(src, "src")
+    M_, k = idx.shape
+    _f32(g1, "g1", 2); _f32(gy, "gy", 2)
+    if not (g1.is_contiguous() and gy.is_contiguous()) or g1.shape != (M_ * k, H) or gy.shape != (M_ * k, F_):
+        raise ValueError("g1 [E,H] / gy [E,F] shape mismatch")
+    out = torch.empty_like(PQR)
+    vh = lambda t, n: _p(_vec(t, H, n))
+    vf = lambda t, n: _p(_vec(t, F_, n))
+    check(_lib.load().spgan_edge_scatter(_p(g1), _p(gy), _p(PQR), PQR.shape[1], H, F_, _p(idx), _p(rowptr), _p(src), M_, k, vh(b1, "b1"),
+                                         vh(mean1, "mean1"), vh(inv1, "inv1"), vh(gam1, "gam1"), _p(_vec(sums1, 2 * H, "sums1")), vf(bx, "bx"),
+                                         vf(meanx, "meanx"), vf(invx, "invx"), vf(gamx, "gamx"), _p(_vec(sumsx, 2 * F_, "sumsx")), _p(out), _s()),
+          "edge_scatter", M=M_, k=k, H=H, F=F_)
+    return out
+
+
+# ----------------------------------------------------------------------------- AdaIN
+def adain_fwd(x: Tensor, N: int, slope: float, imean: Tensor, ivar: Tensor, gb: Tensor) -> Tensor:
+    _f32(x, "x", 2); _f32(gb, "gb", 2)
+    M_, Cn = x.shape
+    if not (x.is_contiguous() and gb.is_contiguous()) or gb.shape != (M_, 2 * Cn):
+        raise ValueError("x [M,C] and gb [M,2C] must be contiguous")
+    out = torch.empty_like(x)
+    check(_lib.load().spgan_adain_fwd(_p(x), M_, Cn, N, float(slope), _p(_vec(imean, (M_ // N) * Cn, "imean")),
+                                      _p(_vec(ivar, (M_ // N) * Cn, "ivar")), BN_EPS, _p(gb), _p(out), _s()), "adain_fwd", M=M_, C=Cn, N=N)
+    return out
+
+
+def adain_bwd(dout: Tensor, x: Tensor, N: int, slope: float, imean: Tensor, ivar: Tensor, gb: Tensor) -> Tuple[Tensor, Tensor]:
+    """-> (dx [M,C], dgb [M,2C])"""
+    _f32(dout, "dout", 2); _f32(x, "x", 2); _f32(gb, "gb", 2)
+    M_, Cn = x.shape
+    if not (dout.is_contiguous() and x.is_contiguous() and gb.is_contiguous()) or dout.shape != x.shape:
+        raise ValueError("dout/x/gb must be contiguous")
+    B = M_ // N
+    tpg = (N + ROW_TILE - 1) // ROW_TILE
+    dgb = torch.empty_like(gb)
+    part = torch.empty((B * tpg, Cn, 2), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    check(lib.spgan_adain_bwd1(_p(dout), _p(x), M_, Cn, N, float(slope), _p(imean), _p(ivar), BN_EPS, _p(gb), _p(dgb), _p(part), _s()), "adain_bwd1")
+    S0, S1 = _finalize(part, B, tpg, Cn, N, 1)
+    dx = torch.empty_like(x)
+    check(lib.spgan_adain_bwd2(_p(dout), _p(x), M_, Cn, N, float(slope), _p(imean), _p(ivar), BN_EPS, _p(gb), _p(S0), _p(S1), _p(dx), _s()), "adain_bwd2")
+    return dx, dgb
+
+
+# ----------------------------------------------------------------------------- pooled BN backward, misc
+def pool_bwd_stats(gpool: Tensor, pooled: Tensor, argmax: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, slope: float):
+    """gval = gpool*lrelu'(pooled); sums [2C] = [sum_b gval | sum_b gval*xhat(argmax row)]."""
+    _f32(gpool, "gpool", 2); _rowmajor2d(y, "y")
+    B, Cn = gpool.shape
+    gpool = gpool.contiguous()
+    gval = torch.empty_like(gpool)
+    sums = torch.empty((2 * Cn,), dtype=torch.float32, device=y.device)
+    check(_lib.load().spgan_pool_bwd_stats(_p(gpool), _p(pooled), _p(_i32(argmax, "argmax")), _p(y), _ld(y), _p(mean), _p(invstd), float(slope), B, Cn,
+                                           _p(gval), _p(sums), _s()), "pool_bwd_stats")
+    return gval, sums
+
+
+def bn_bwd_apply_sparse(gval: Tensor, argmax: Tensor, y: Tensor, N: int, mean, invstd, gamma, sums, count: int) -> Tensor:
+    _rowmajor2d(y, "y")
+    M_, Cn = y.shape
+    dy = torch.empty((M_, Cn), dtype=torch.float32, device=y.device)
+    check(_lib.load().spgan_bn_bwd_apply_sparse(_p(gval), _p(argmax), _p(y), _ld(y), M_, Cn, N, _p(mean), _p(invstd), _p(gamma),
+                                                _p(_vec(sums, 2 * Cn, "sums")), count, _p(dy), _s()), "bn_bwd_apply_sparse")
+    return dy
+
+
+def maxpool_bwd_add(dpool: Tensor, argmax: Tensor, dst: Tensor) -> Tensor:
+    """dst[argmax[b,c], c] += dpool[b,c] (in place)."""
+    _rowmajor2d(dst, "dst")
+    dpool = dpool.contiguous()
+    B, Cn = dpool.shape
+    check(_lib.load().spgan_maxpool_bwd_add(_p(dpool), _p(_i32(argmax, "argmax")), B, Cn, _p(dst), _ld(dst), _s()), "maxpool_bwd_add")
+    return dst
+
+
+def tanh_bwd(dy: Tensor, y: Tensor) -> Tensor:
+    dy = dy.contiguous(); y = y.contiguous()
+    out = torch.empty_like(dy)
+    check(_lib.load().spgan_tanh_bwd(_p(dy), _p(y), dy.numel(), _p(out), _s()), "tanh_bwd")
+    return out
+
+
+def act_bwd(dy: Tensor, y: Tensor, act: int, slope: float = 0.0) -> Tensor:
+    """dy * act'(y) computed from the activation output y."""
+    dy = dy.contiguous(); y = y.contiguous()
+    if act == ACT_NONE:
+        return dy
+    _f32(dy, "dy"); _f32(y, "y")
+    out = torch.empty_like(dy)
+    check(_lib.load().spgan_act_bwd(_p(dy), _p(y), dy.numel(), act, float(slope), _p(out), _s()), "act_bwd")
+    return out
+
+
+def scatter_rows(val: Tensor, argmax: Tensor, M: int) -> Tensor:
+    """[B,C] values -> dense [M,C] with out[argmax[b,c], c] = val[b,c]."""
+    val = _f32(val, "val", 2).contiguous()
+    B, Cn = val.shape
+    out = torch.empty((M, Cn), dtype=torch.float32, device=val.device)
+    check(_lib.load().spgan_scatter_rows(_p(val), _p(_i32(argmax, "argmax")), B, Cn, M, _p(out), _s()), "scatter_rows")
+    return out
+
+
+def gather_rows(src: Tensor, argmax: Tensor) -> Tensor:
+    _rowmajor2d(src, "src")
+    B, Cn = argmax.shape
+    out = torch.empty((B, Cn), dtype=torch.float32, device=src.device)
+    check(_lib.load().spgan_gather_rows(_p(src), _ld(src), _p(_i32(argmax, "argmax")), B, Cn, _p(out), _s()), "gather_rows")
+    return out
+
+
+def bn_dbl_stats(u: Tensor, y: Tensor, gz: Tensor, mean: Tensor, invstd: Tensor):
+    """-> (sum u, sum u*xhat, sum u*gz) each [C]."""
+    for t, n in ((u, "u"), (y, "y"), (gz, "gz")):
+        _f32(t, n, 2)
+        if not t.is_contiguous() or t.shape != u.shape:
+            raise ValueError("bn_dbl_stats: %s must be contiguous [M,C]" % n)
+    M_, Cn = u.shape
+    tiles = (M_ + ROW_TILE - 1) // ROW_TILE
+    part = torch.empty((tiles, 2 * Cn, 2), dtype=torch.float32, device=u.device)
+    check(_lib.load().spgan_bn_dbl_stats(_p(u), _p(y), _p(gz), M_, Cn, _p(_vec(mean, Cn, "mean")), _p(_vec(invstd, Cn, "invstd")), _p(part), _s()),
+          "bn_dbl_stats")
+    s0, s1 = _finalize(part, 1, tiles, 2 * Cn, M_, 1)
+    return s0[0, :Cn].contiguous(), s1[0, :Cn].contiguous(), s0[0, Cn:].contiguous()
+
+
+def bn_dbl_apply(u, y, gz, mean, invstd, scale, shift, slope: float, gamma, S1, U0, U1, count: int):
+    """-> (q, xbar) [M,C]; see spgan_hip.h."""
+    M_, Cn = u.shape
+    q = torch.empty_like(u); xbar = torch.empty_like(u)
+    v = lambda t, n: _p(_vec(t.contiguous(), Cn, n))
+    check(_lib.load().spgan_bn_dbl_apply(_p(u), _p(y), _p(gz), M_, Cn, v(mean, "mean"), v(invstd, "invstd"), v(scale, "scale"), v(shift, "shift"),
+                                         float(slope), v(gamma, "gamma"), v(S1, "S1"), v(U0, "U0"), v(U1, "U1"), _p(q), _p(xbar), _s()), "bn_dbl_apply")
+    return q, xbar
+
+
+def col_scale_add(a: Tensor, b: Tensor, gamma: Tensor) -> Tensor:
+    """a + gamma[c]*b"""
+    M_, Cn = a.shape
+    out = torch.empty_like(a)
+    check(_lib.load().spgan_col_scale_add(_p(a.contiguous()), _p(b.contiguous()), _p(_vec(gamma.contiguous(), Cn, "gamma")), M_, Cn, _p(out), _s()),
+          "col_scale_add")
+    return out
+
+
+GAN_MODES = {"ls": 0, "wgan": 1, "hinge": 2, "gan": 3}
+
+
+def gan_loss(mode: int, which: int, d_real: Optional[Tensor], d_fake: Tensor, real_label: Optional[Tensor] = None,
+             fake_label: Optional[Tensor] = None):
+    """-> (out5 = [loss, fake term, real term, real_acc, fake_acc], g_real [B,1] | None, g_fake [B,1])."""
+    d_fake = _f32(d_fake, "d_fake").contiguous()
+    B = d_fake.shape[0]
+    if d_real is not None:
+        d_real = _f32(d_real, "d_real").contiguous()
+    out5 = torch.empty((5,), dtype=torch.float32, device=d_fake.device)
+    g_fake = torch.empty_like(d_fake)
+    g_real = torch.empty_like(d_real) if d_real is not None else None
+    check(_lib.load().spgan_gan_loss(mode, which, _p(d_real), _p(d_fake), _p(_vec(real_label, B, "real_label")), _p(_vec(fake_label, B, "fake_label")),
+                                     B, _p(out5), _p(g_real), _p(g_fake), _s()), "gan_loss", mode=mode, which=which, B=B)
+    return out5, g_real, g_fake
+
+
+def lerp_rows(real: Tensor, fake: Tensor, alpha: Tensor) -> Tensor:
+    """real + alpha[b]*(fake-real), alpha has B elements."""
+    real = _f32(real, "real").contiguous(); fake = _f32(fake, "fake").contiguous()
+    B = real.shape[0]
+    out = torch.empty_like(real)
+    check(_lib.load().spgan_lerp_rows(_p(real), _p(fake), _p(_vec(alpha.contiguous(), B, "alpha")), B, real.numel() // B, _p(out), _s()), "lerp_rows")
+    return out
+
+
+def gp_penalty_fwd(g: Tensor, gamma: float, lam: float):
+    """-> (loss [1], norms [B])"""
+    g = _f32(g, "g").contiguous()
+    B = g.shape[0]
+    norms = torch.empty((B,), dtype=torch.float32, device=g.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=g.device)
+    check(_lib.load().spgan_gp_penalty_fwd(_p(g), B, g.numel() // B, float(gamma), float(lam), _p(norms), _p(loss), _s()), "gp_penalty_fwd")
+    return loss, norms
+
+
+def gp_penalty_bwd(g: Tensor, norms: Tensor, gamma: float, lam: float, upstream: Optional[Tensor]) -> Tensor:
+    g = g.contiguous()
+    B = g.shape[0]
+    v = torch.empty_like(g)
+    up = None if upstream is None else upstream.reshape(1).contiguous()
+    check(_lib.load().spgan_gp_penalty_bwd(_p(g), _p(norms), B, g.numel() // B, float(gamma), float(lam), _p(up), _p(v), _s()), "gp_penalty_bwd")
+    return v
+
+
+def axpby(a: float, x: Tensor, b: float, y: Tensor) -> Tensor:
+    """y = a*x + b*y in place (contiguous fp32)."""
+    if not (x.is_contiguous() and y.is_contiguous()) or x.numel() != y.numel():
+        raise ValueError("axpby needs contiguous tensors of equal size")
+    check(_lib.load().spgan_axpby(float(a), _p(x), float(b), _p(y), x.numel(), _s()), "axpby")
+    return y
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float = 1e-4, beta1: float = 0.5, beta2: float = 0.99,
+              eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _f32(t, n)
+        if not t.is_contiguous() or t.numel() != p.numel():
+            raise ValueError("adam_step: %s must be contiguous with %d elements" % (n, p.numel()))
+    check(_lib.load().spgan_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _s()), "adam_step")

@@ -1,0 +1,81 @@
+"""Flat-buffer Adam (torch.optim.Adam semantics, Generation/model.py:94-97) and the flat
+parameter/gradient layout shared with the data-parallel reducer.
+
+`flatten_module(m)` re-points every parameter of `m` at a slice of ONE contiguous fp32 buffer and
+pre-binds `.grad` to the matching slice of ONE gradient buffer: the optimiser update is a single
+HIP launch and the data-parallel all-reduce a single RCCL collective per network.
+state_dict() is unaffected (parameters keep their names/shapes).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class FlatParams:
+    def __init__(self, module: nn.Module):
+        params = [p for p in module.parameters()]
+        if not params:
+            raise ValueError("module has no parameters")
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.params = params
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat[off:off + k].view_as(p)
+                p.grad = self.grad[off:off + k].view_as(p)
+                off += k
+        self.numel = n
+
+    def zero_grad(self):
+        """Zero in place and re-bind (autograd accumulates into the flat slices)."""
+        self.grad.zero_()
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + k].view_as(p)
+            off += k
+
+
+def flatten_module(module: nn.Module) -> FlatParams:
+    fp = getattr(module, "_spgan_flat", None)
+    if fp is None or any(p.data_ptr() < fp.flat.data_ptr() or p.data_ptr() >= fp.flat.data_ptr() + 4 * fp.numel for p in module.parameters()):
+        fp = FlatParams(module)
+        module.__dict__["_spgan_flat"] = fp
+    return fp
+
+
+class Adam:
+    """Adam over a module's flat buffer.  `step()` == torch.optim.Adam(lr, betas, eps=1e-8).step();
+    `zero_grad()` zeroes the flat gradient buffer in place."""
+
+    def __init__(self, module: nn.Module, lr: float = 1e-4, betas=(0.5, 0.99), eps: float = 1e-8):
+        self.fp = flatten_module(module)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.m = torch.zeros_like(self.fp.flat)
+        self.v = torch.zeros_like(self.fp.flat)
+        self.t = 0
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.fp.zero_grad()
+
+    def step(self, grad_scale: float = 1.0):
+        self.t += 1
+        ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps, grad_scale)
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr, "betas": self.betas, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = int(sd["t"])
+        self.lr, self.betas, self.eps = sd["lr"], tuple(sd["betas"]), sd["eps"]

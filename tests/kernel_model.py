@@ -188,3 +188,261 @@ def maxpool(y, B, N, scale=None, shift=None, slope=1.0):
     out, arg = v.max(1)
     off = (torch.arange(B, device=y.device) * N).view(B, 1)
     return out.contiguous(), (arg + off).to(torch.int32)
+
+
+# ----------------------------------------------------------------------------- EdgeBlock gather-side ops
+def edge_wcat(Ww0, Wx):
+    C = Ww0.shape[1]
+    return torch.cat([Ww0, Wx[:, C:], Wx[:, :C] - Wx[:, C:]], dim=0).contiguous()
+
+
+def edge_wcat_bwd(dWcat, H, F_):
+    dq, dr = dWcat[H:H + F_], dWcat[H + F_:]
+    return dWcat[:H].contiguous(), torch.cat([dr, dq - dr], dim=1).contiguous()
+
+
+def _edges(idx):
+    M, k = idx.shape
+    i = torch.arange(M, device=idx.device).repeat_interleave(k)
+    return i, idx.reshape(-1).long()
+
+
+def _edge_pre(PQR, idx, b1, bx):
+    H, F_ = b1.numel(), bx.numel()
+    i, j = _edges(idx)
+    h1 = (PQR[j, :H] - PQR[i, :H]) + b1
+    yp = (PQR[i, H + F_:] + PQR[j, H:H + F_]) + bx
+    return h1, yp
+
+
+def edge_stats(PQR, idx, b1, bx):
+    h1, yp = _edge_pre(PQR, idx, b1, bx)
+    v = torch.cat([h1, yp], dim=1)
+    return v.mean(0), v.var(0, unbiased=False)
+
+
+def _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope):
+    M, k = idx.shape
+    F_ = bx.numel()
+    H = PQR.shape[1] - 2 * F_
+    _, yp = _edge_pre(PQR, idx, torch.zeros(H, device=PQR.device), bx)
+    z2 = (h2pre * sc2 + sh2).view(M, k, F_)
+    zy = (yp * scx + shx).view(M, k, F_)
+    w = torch.softmax(_lrelu(z2, slope), dim=1)
+    return z2, zy, w, _lrelu(zy, slope), yp.view(M, k, F_)
+
+
+def edge_attend_fwd(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope):
+    M, k = idx.shape
+    z2, zy, w, yv, _ = _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope)
+    return (w * yv).reshape(M, k * bx.numel()).contiguous()
+
+
+def edge_attend_bwd(dT, h2pre, sc2, sh2, mean2, inv2, PQR, idx, bx, scx, shx, meanx, invx, slope):
+    M, k = idx.shape
+    F_ = bx.numel()
+    z2, zy, w, yv, yp = _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope)
+    d = dT.view(M, k, F_)
+    dw = d * yv
+    ds = w * (dw - (dw * w).sum(1, keepdim=True))
+    g2 = (ds * torch.where(z2 > 0, 1.0, slope)).reshape(M * k, F_)
+    gy = (d * w * torch.where(zy > 0, 1.0, slope)).reshape(M * k, F_)
+    xh2 = (h2pre - mean2) * inv2
+    xhy = (yp.reshape(M * k, F_) - meanx) * invx
+    return (g2.contiguous(), gy.contiguous(), torch.cat([g2.sum(0), (g2 * xh2).sum(0)]), torch.cat([gy.sum(0), (gy * xhy).sum(0)]))
+
+
+def edge_scatter(g1, gy, PQR, idx, rowptr, src, b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx):
+    M, k = idx.shape
+    H, F_ = b1.numel(), bx.numel()
+    E = M * k
+    i, j = _edges(idx)
+    h1, yp = _edge_pre(PQR, idx, b1, bx)
+    xh1 = (h1 - mean1) * inv1
+    xhy = (yp - meanx) * invx
+    dh1 = gam1 * inv1 * (g1 - sums1[:H] / E - xh1 * (sums1[H:] / E))
+    dyp = gamx * invx * (gy - sumsx[:F_] / E - xhy * (sumsx[F_:] / E))
+    out = torch.zeros_like(PQR)
+    out[:, :H].index_add_(0, j, dh1)
+    out[:, :H].index_add_(0, i, -dh1)
+    out[:, H:H + F_].index_add_(0, j, dyp)
+    out[:, H + F_:].index_add_(0, i, dyp)
+    return out
+
+
+# ----------------------------------------------------------------------------- AdaIN
+def _inorm(x, N, slope, imean, ivar):
+    M, C = x.shape
+    B = M // N
+    xa = _lrelu(x, slope).view(B, N, C)
+    iv = torch.rsqrt(ivar.view(B, 1, C) + BN_EPS)
+    return ((xa - imean.view(B, 1, C)) * iv).reshape(M, C), iv
+
+
+def adain_fwd(x, N, slope, imean, ivar, gb):
+    C = x.shape[1]
+    xh, _ = _inorm(x, N, slope, imean, ivar)
+    return (gb[:, :C] * xh + gb[:, C:]).contiguous()
+
+
+def adain_bwd(dout, x, N, slope, imean, ivar, gb):
+    M, C = x.shape
+    B = M // N
+    xh, iv = _inorm(x, N, slope, imean, ivar)
+    dgb = torch.cat([dout * xh, dout], dim=1).contiguous()
+    dxh = (dout * gb[:, :C]).view(B, N, C)
+    xh3 = xh.view(B, N, C)
+    dl = iv * (dxh - dxh.mean(1, keepdim=True) - xh3 * (dxh * xh3).mean(1, keepdim=True))
+    dx = dl.reshape(M, C) * torch.where(x > 0, 1.0, slope)
+    return dx.contiguous(), dgb
+
+
+# ----------------------------------------------------------------------------- pooled BN backward, misc
+def pool_bwd_stats(gpool, pooled, argmax, y, mean, invstd, slope):
+    B, C = gpool.shape
+    gval = gpool * torch.where(pooled > 0, 1.0, slope)
+    cols = torch.arange(C, device=y.device).view(1, C).expand(B, C)
+    xh = (y[argmax.long(), cols] - mean) * invstd
+    return gval.contiguous(), torch.cat([gval.sum(0), (gval * xh).sum(0)])
+
+
+def bn_bwd_apply_sparse(gval, argmax, y, N, mean, invstd, gamma, sums, count):
+    M, C = y.shape
+    B = M // N
+    g = torch.zeros((M, C), dtype=y.dtype, device=y.device)
+    cols = torch.arange(C, device=y.device).view(1, C).expand(B, C)
+    g[argmax.long(), cols] = gval
+    xh = (y - mean) * invstd
+    return (gamma * invstd * (g - sums[:C] / count - xh * (sums[C:] / count))).contiguous()
+
+
+def maxpool_bwd_add(dpool, argmax, dst):
+    B, C = dpool.shape
+    cols = torch.arange(C, device=dst.device).view(1, C).expand(B, C)
+    dst[argmax.long(), cols] += dpool
+    return dst
+
+
+def tanh_bwd(dy, y):
+    return (dy * (1 - y * y)).contiguous()
+
+
+def axpby(a, x, b, y):
+    y.copy_(a * x + (b * y if b != 0 else 0))
+    return y
+
+
+def adam_step(p, g, m, v, step, lr=1e-4, beta1=0.5, beta2=0.99, eps=1e-8, grad_scale=1.0):
+    import math
+    gr = g * grad_scale
+    m.mul_(beta1).add_(gr, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gr, gr, value=1 - beta2)
+    denom = v.sqrt() / math.sqrt(1 - beta2 ** step) + eps
+    p.addcdiv_(m, denom, value=-lr / (1 - beta1 ** step))
+
+
+def act_bwd(dy, y, act, slope=0.0):
+    if act == ACT_LRELU:
+        return (dy * torch.where(y > 0, 1.0, slope)).contiguous()
+    if act == ACT_TANH:
+        return (dy * (1 - y * y)).contiguous()
+    return dy.contiguous()
+
+
+def scatter_rows(val, argmax, M):
+    B, C = val.shape
+    out = torch.zeros((M, C), dtype=val.dtype, device=val.device)
+    cols = torch.arange(C, device=val.device).view(1, C).expand(B, C)
+    out[argmax.long(), cols] = val
+    return out
+
+
+def gather_rows(src, argmax):
+    B, C = argmax.shape
+    cols = torch.arange(C, device=src.device).view(1, C).expand(B, C)
+    return src[argmax.long(), cols].contiguous()
+
+
+def bn_dbl_stats(u, y, gz, mean, invstd):
+    xh = (y - mean) * invstd
+    return u.sum(0), (u * xh).sum(0), (u * gz).sum(0)
+
+
+def bn_dbl_apply(u, y, gz, mean, invstd, scale, shift, slope, gamma, S1, U0, U1, count):
+    xh = (y - mean) * invstd
+    gs = gamma * invstd
+    z = y * scale + shift
+    q = gs * (u - U0 / count - xh * (U1 / count)) * torch.where(z > 0, 1.0, slope)
+    xbar = -(gs / count) * (u * S1 + gz * U1)
+    return q.contiguous(), xbar.contiguous()
+
+
+def col_scale_add(a, b, gamma):
+    return (a + gamma * b).contiguous()
+
+
+# ----------------------------------------------------------------------------- losses / GP
+def gan_loss(mode, which, d_real, d_fake, real_label=None, fake_label=None):
+    with torch.enable_grad():
+        return _gan_loss(mode, which, d_real, d_fake, real_label, fake_label)
+
+
+def _gan_loss(mode, which, d_real, d_fake, real_label=None, fake_label=None):
+    import torch.nn.functional as F_
+    df = d_fake.detach().clone().requires_grad_(True)
+    dr = d_real.detach().clone().requires_grad_(True) if d_real is not None else None
+    B = df.shape[0]
+    acc_r = acc_f = torch.zeros(())
+    mse = lambda logit, label: ((logit.view(-1, 1) - label.view(1, -1)) ** 2).mean()
+    if mode == 0:
+        fl = fake_label if fake_label is not None else (torch.ones(B) if which == 1 else torch.zeros(B))
+        lf = mse(df, fl.to(df.device))
+        if which == 0:
+            rl = real_label if real_label is not None else torch.ones(B)
+            lr = mse(dr, rl.to(df.device)); loss = (lf + lr) / 2
+            acc_r = (dr >= 0.5).float().mean(); acc_f = (df < 0.5).float().mean()
+        else:
+            lr = torch.zeros(()); loss = lf
+    elif mode == 1:
+        lf = df.mean() if which == 0 else -df.mean()
+        lr = dr.mean() if which == 0 else torch.zeros(())
+        loss = lf - lr if which == 0 else lf
+    elif mode == 2:
+        if which == 0:
+            lr = F_.relu(1.0 - dr).mean(); lf = F_.relu(1.0 + df).mean(); loss = lf + lr
+            acc_r = (dr >= 0).float().mean(); acc_f = (df < 0).float().mean()
+        else:
+            lf = -df.mean(); lr = torch.zeros(()); loss = lf
+            acc_f = (df < 0).float().mean()
+            acc_r = (dr >= 0).float().mean() if dr is not None else (torch.zeros(B) >= 0).float().mean()
+    else:
+        if which == 0:
+            lf = F_.binary_cross_entropy_with_logits(df, torch.zeros_like(df)); lr = F_.binary_cross_entropy_with_logits(dr, torch.ones_like(dr))
+            loss = (lf + lr) / 2
+        else:
+            lf = F_.binary_cross_entropy_with_logits(df, torch.ones_like(df)); lr = torch.zeros(()); loss = lf
+    ins = [df] + ([dr] if (dr is not None and which == 0) else [])
+    gs = torch.autograd.grad(loss, ins)
+    out5 = torch.stack([loss.detach().reshape(()), lf.detach().reshape(()), torch.as_tensor(lr).detach().reshape(()).to(loss.device),
+                        torch.as_tensor(acc_r).reshape(()).to(loss.device), torch.as_tensor(acc_f).reshape(()).to(loss.device)]).float()
+    g_real = gs[1] if len(gs) > 1 else (torch.zeros_like(d_real) if d_real is not None else None)
+    return out5, g_real, gs[0]
+
+
+def lerp_rows(real, fake, alpha):
+    B = real.shape[0]
+    a = alpha.reshape(B, *([1] * (real.dim() - 1)))
+    return (real + a * (fake - real)).contiguous()
+
+
+def gp_penalty_fwd(g, gamma, lam):
+    B = g.shape[0]
+    norms = g.reshape(B, -1).norm(2, dim=1)
+    return (lam * (((norms - gamma) / gamma) ** 2).mean()).reshape(1), norms
+
+
+def gp_penalty_bwd(g, norms, gamma, lam, upstream):
+    B = g.shape[0]
+    up = 1.0 if upstream is None else upstream.reshape(())
+    c = up * lam * (2.0 / B) * ((norms - gamma) / (gamma * gamma)) / norms
+    return (c.reshape(B, *([1] * (g.dim() - 1))) * g).contiguous()

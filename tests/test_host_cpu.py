@@ -1,0 +1,210 @@
+"""CPU: the host composition (spgan.nets / functions / modules: forward, backward, WGAN-GP double
+backward, state_dict surface) checked against the oracle, with every HIP op replaced by its
+plain-PyTorch model from tests/kernel_model.py (test double, injected here only)."""
+import inspect
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import kernel_model as km
+from helpers import rel_l2
+from oracle import spgan_oracle as orc
+from spgan import fixture_rng as fr
+
+
+class Opts:
+    np = 256; nk = 20; nz = 128; softmax = True; off = False; attn = False
+    use_head = False; eql = False; z_norm = False; small_d = False
+
+
+ZERO_GRAD_BIASES = ("conv_w.0.bias", "conv_w.3.bias", "conv_x.0.bias", "global_conv.0.bias", "global_conv.3.bias",
+                    "mlps.0.bias", "mlps.3.bias", "mlps.6.bias", "fc2.0.bias")
+
+
+@pytest.fixture()
+def spgan_cpu(monkeypatch):
+    """spgan with ops -> kernel models, GPU guard off."""
+    import spgan.ops as ops
+    import spgan.modules as modules
+    for name, fn in inspect.getmembers(km, inspect.isfunction):
+        if name.startswith("_"):
+            continue
+        assert hasattr(ops, name), "kernel_model.%s has no counterpart in spgan.ops" % name
+        monkeypatch.setattr(ops, name, fn)
+    monkeypatch.setattr(modules, "_require_gpu", lambda t, what: None)
+    return types.SimpleNamespace(ops=ops, modules=modules)
+
+
+def test_every_op_has_a_model():
+    import spgan.ops as ops
+    public = [n for n, f in inspect.getmembers(ops, inspect.isfunction) if not n.startswith("_") and f.__module__ == ops.__name__]
+    missing = [n for n in public if not hasattr(km, n)]
+    assert not missing, "ops without a kernel model: %s" % missing
+
+
+def _load(module, params):
+    sd = module.state_dict()
+    module.load_state_dict({**sd, **{k: v.detach().clone() for k, v in params.items()}})
+    return module
+
+
+def _cmp(name, got, ref, rtol, atol=1e-6):
+    e = rel_l2(got.detach().numpy(), ref.detach().numpy())
+    mx = (got - ref).abs().max().item()
+    assert e <= rtol or mx <= atol, "%s: rel-L2 %.3e max-abs %.3e" % (name, e, mx)
+
+
+def test_state_dict_surface(spgan_cpu):
+    G = spgan_cpu.modules.Generator(Opts)
+    D = spgan_cpu.modules.Discriminator(Opts)
+    gs, ds = orc.generator_shapes(), orc.discriminator_shapes()
+    gsd, dsd = G.state_dict(), D.state_dict()
+    for k, shp in gs.items():
+        assert tuple(gsd[k].shape) == shp, k
+    for k, shp in ds.items():
+        assert tuple(dsd[k].shape) == shp, k
+    assert len([k for k in gsd if k not in gs]) == 24 and len([k for k in dsd if k not in ds]) == 12     # BN buffers
+    assert sum(p.numel() for p in G.parameters()) == 585155 and sum(p.numel() for p in D.parameters()) == 980353
+    assert torch.equal(G.adain1.style.bias.detach(), torch.cat([torch.ones(64), torch.zeros(64)]))
+
+
+def test_discriminator_fwd_bwd(spgan_cpu):
+    B, N = 3, 128
+    p = fr.init_params(orc.discriminator_shapes(), salt=11)
+    D = _load(spgan_cpu.modules.Discriminator(Opts), p).train()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    buf = orc.bn_buffers(orc.discriminator_shapes())
+    x = fr.synthetic_real(B, N, seed=12).transpose(2, 1).contiguous()
+    x1 = x.clone().requires_grad_(True); x2 = x.clone().requires_grad_(True)
+    out = D(x1)
+    ref = orc.discriminator_forward(po, x2, True, buf)
+    _cmp("logit", out, ref, 1e-5)
+    w = fr.normal("hd.w", out.shape)
+    (out * w).sum().backward()
+    names = list(po.keys())
+    grads = torch.autograd.grad((ref * w).sum(), [x2] + [po[n] for n in names])
+    _cmp("dx", x1.grad, grads[0], 2e-4)
+    for n, g in zip(names, grads[1:]):
+        _cmp("grad " + n, dict(D.named_parameters())[n].grad, g, 5e-4, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    for k, v in buf.items():
+        np.testing.assert_allclose(D.state_dict()[k].numpy(), v.numpy(), rtol=1e-5, atol=1e-6)
+    # frozen D (G-step): input gradient only
+    for q in D.parameters():
+        q.requires_grad_(False)
+    x3 = x.clone().requires_grad_(True)
+    (D(x3) * w).sum().backward()
+    buf2 = orc.bn_buffers(orc.discriminator_shapes())
+    _cmp("dx frozen", x3.grad, grads[0], 2e-4)
+
+
+def test_discriminator_gradient_penalty(spgan_cpu):
+    """autograd.grad(create_graph=True) + backward through our Function pair == oracle autograd double backward."""
+    B, N = 3, 128
+    p = fr.init_params(orc.discriminator_shapes(), salt=13)
+    D = _load(spgan_cpu.modules.Discriminator(Opts), p).train()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    real = fr.synthetic_real(B, N, seed=14).transpose(2, 1).contiguous()
+    fake = (0.8 * fr.synthetic_real(B, N, seed=15) + 0.05 * fr.normal("hgp.n", (B, N, 3))).transpose(2, 1).contiguous()
+    alpha = fr.uniform("hgp.alpha", (B, 1, 1), 0.0, 1.0)
+    gp_ref = orc.gradient_penalty(lambda t: orc.discriminator_forward(po, t, True, None), real, fake, alpha, 10.0, 1.0)
+    names = list(po.keys())
+    gref = torch.autograd.grad(gp_ref, [po[n] for n in names], allow_unused=True)
+    gp = orc.gradient_penalty(D, real, fake, alpha, 10.0, 1.0)         # same formula, our module as netD
+    np.testing.assert_allclose(gp.item(), gp_ref.item(), rtol=1e-4)
+    gp.backward()
+    for n, g in zip(names, gref):
+        mine = dict(D.named_parameters())[n].grad
+        g = torch.zeros_like(po[n]) if g is None else g
+        mine = torch.zeros_like(g) if mine is None else mine
+        _cmp("gp grad " + n, mine, g, 2e-3, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 2e-6)
+
+
+@pytest.mark.parametrize("fin,fout", [(3, 64), (64, 128)])
+def test_edgeblock(spgan_cpu, fin, fout):
+    B, N, k = 2, 96, 10
+    pref = "EdgeConv1" if fin == 3 else "EdgeConv2"
+    shapes = {kk: v for kk, v in orc.generator_shapes().items() if kk.startswith(pref + ".")}
+    p = fr.init_params(shapes, salt=21)
+    blk = _load(spgan_cpu.modules.EdgeBlock(fin, fout, k), {kk[len(pref) + 1:]: v for kk, v in p.items()}).train()
+    po = {kk: v.clone().requires_grad_(True) for kk, v in p.items()}
+    buf = orc.bn_buffers({kk: tuple(v.shape) for kk, v in p.items()})
+    x = fr.normal("heb.x%d" % fin, (B, fin, N), 0.7)
+    x1 = x.clone().requires_grad_(True); x2 = x.clone().requires_grad_(True)
+    y = blk(x1)
+    idx = spgan_cpu.ops.idx_to_local64(blk.last_idx, B, N)
+    yr = orc.edge_block(po, pref, x2, k, idx=idx, training=True, buffers=buf)
+    _cmp("y", y, yr, 2e-5)
+    dy = fr.normal("heb.dy%d" % fin, y.shape)
+    (y * dy).sum().backward()
+    names = list(po.keys())
+    grads = torch.autograd.grad((yr * dy).sum(), [x2] + [po[n] for n in names])
+    _cmp("dx", x1.grad, grads[0], 2e-4)
+    for n, g in zip(names, grads[1:]):
+        _cmp("grad " + n, dict(blk.named_parameters())[n[len(pref) + 1:]].grad, g, 5e-4, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    for kk, v in buf.items():
+        np.testing.assert_allclose(blk.state_dict()[kk[len(pref) + 1:]].numpy(), v.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_adain(spgan_cpu):
+    B, C, N = 2, 64, 96
+    p = fr.init_params({"a.style.weight": (2 * C, 128, 1), "a.style.bias": (2 * C,)}, salt=3)
+    m = _load(spgan_cpu.modules.AdaptivePointNorm(C, 128), {"style.weight": p["a.style.weight"], "style.bias": p["a.style.bias"]})
+    po = {kk: v.clone().requires_grad_(True) for kk, v in p.items()}
+    x = fr.normal("had.x", (B, C, N)); s = fr.normal("had.s", (B, 128, N), 0.3)
+    x1, s1 = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    x2, s2 = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    y, yr = m(x1, s1), orc.adaptive_point_norm(po, "a", x2, s2)
+    _cmp("y", y, yr, 1e-5)
+    dy = fr.normal("had.dy", y.shape)
+    (y * dy).sum().backward()
+    gx, gs, gw, gb = torch.autograd.grad((yr * dy).sum(), [x2, s2, po["a.style.weight"], po["a.style.bias"]])
+    _cmp("dx", x1.grad, gx, 1e-4); _cmp("dstyle", s1.grad, gs, 1e-4)
+    _cmp("dw", m.style.weight.grad, gw, 1e-4); _cmp("db", m.style.bias.grad, gb, 1e-4)
+
+
+def test_generator(spgan_cpu):
+    B, N = 4, 128
+    p = fr.init_params(orc.generator_shapes(), salt=31)
+    G = _load(spgan_cpu.modules.Generator(Opts), p).train()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    buf = orc.bn_buffers(orc.generator_shapes())
+    x = fr.synthetic_real(B, N, seed=32)
+    z = fr.latent(B, N, seed=33)
+    out = G(x, z)
+    idx1 = spgan_cpu.ops.idx_to_local64(G.EdgeConv1.last_idx, B, N)
+    idx2 = spgan_cpu.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N)
+    st = {}
+    ref = orc.generator_forward(po, x, z, training=True, buffers=buf, idx1=idx1, idx2=idx2, stages=st)
+    # kNN agreement with the oracle's own graph construction (tie-aware: rows may differ only at near-ties)
+    own1 = orc.knn_sorted(x.transpose(2, 1).contiguous(), 10)
+    assert (own1.reshape(B, -1) == idx1).float().mean().item() > 0.999
+    _cmp("out", out, ref, 5e-4)
+    dy = fr.normal("hg.dy", out.shape)
+    (out * dy).sum().backward()
+    names = list(po.keys())
+    grads = torch.autograd.grad((ref * dy).sum(), [po[n] for n in names])
+    for n, g in zip(names, grads):
+        # kink-limited end to end (see tests/test_oracle_golden.py::test_generator)
+        _cmp("grad " + n, dict(G.named_parameters())[n].grad, g, 3e-2, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    for kk, v in buf.items():
+        np.testing.assert_allclose(G.state_dict()[kk].numpy(), v.numpy(), rtol=2e-4, atol=1e-5)
+
+
+def test_generator_no_grad_and_eval(spgan_cpu):
+    B, N = 2, 96
+    p = fr.init_params(orc.generator_shapes(), salt=41)
+    G = _load(spgan_cpu.modules.Generator(Opts), p).train()
+    x = fr.synthetic_real(B, N, seed=42); z = fr.latent(B, N, seed=43)
+    for q in G.parameters():
+        q.requires_grad_(False)
+    out = G(x, z)                                  # D-step: frozen G, no graph
+    assert not out.requires_grad
+    G.eval()
+    buf = {k: v.clone() for k, v in G.state_dict().items() if "running" in k or "num_batches" in k}
+    oe = G(x, z)
+    idx1 = spgan_cpu.ops.idx_to_local64(G.EdgeConv1.last_idx, B, N)
+    idx2 = spgan_cpu.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N)
+    ref = orc.generator_forward(p, x, z, training=False, buffers=buf, idx1=idx1, idx2=idx2)
+    _cmp("eval out", oe, ref, 1e-4)

@@ -1,0 +1,130 @@
+"""GPU: EdgeBlock gather-side kernels, AdaIN, pooled-BN backward, double-backward helpers, Adam --
+each HIP kernel (through the C ABI) against its plain-PyTorch model."""
+import pytest
+import torch
+
+import kernel_model as km
+from spgan import fixture_rng as fr
+from test_kernels_gpu import close, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from spgan import ops as o
+    from spgan import _lib
+    _lib.load()
+    return o
+
+
+def _graph(ops, B, N, k, tag):
+    x = rnd("k2.x." + tag, (B * N, 3))
+    idx = ops.knn(x, B, N, k, mode=1)
+    return idx, ops.csr_build(idx, B, N)
+
+
+@pytest.mark.parametrize("H,F_,C", [(32, 64, 3), (64, 128, 64)])
+def test_edge_wcat(ops, H, F_, C):
+    Ww0, Wx = rnd("wc.a", (H, C)), rnd("wc.b", (F_, 2 * C))
+    assert torch.equal(ops.edge_wcat(Ww0, Wx), km.edge_wcat(Ww0, Wx))
+    d = rnd("wc.d", (H + 2 * F_, C))
+    for a, b in zip(ops.edge_wcat_bwd(d, H, F_), km.edge_wcat_bwd(d, H, F_)):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,N,k,H,F_", [(2, 200, 10, 32, 64), (2, 130, 10, 64, 128), (1, 77, 5, 16, 32)])
+def test_edge_pipeline_kernels(ops, B, N, k, H, F_):
+    M = B * N
+    idx, (rowptr, src) = _graph(ops, B, N, k, "%d" % N)
+    PQR = rnd("ep.PQR%d" % N, (M, H + 2 * F_))
+    b1, bx = rnd("ep.b1", (H,), 0.1), rnd("ep.bx", (F_,), 0.1)
+    for a, b in zip(ops.edge_stats(PQR, idx, b1, bx), km.edge_stats(PQR, idx, b1, bx)):
+        close(a, b, rtol=2e-5, atol=2e-6, what="edge_stats")
+    h2 = rnd("ep.h2%d" % N, (M * k, F_))
+    sc2, sh2 = rnd("ep.sc2", (F_,)).abs() + 0.5, rnd("ep.sh2", (F_,), 0.3)
+    scx, shx = rnd("ep.scx", (F_,)).abs() + 0.5, rnd("ep.shx", (F_,), 0.3)
+    T = ops.edge_attend_fwd(h2, sc2, sh2, PQR, idx, bx, scx, shx, 0.01)
+    close(T, km.edge_attend_fwd(h2, sc2, sh2, PQR, idx, bx, scx, shx, 0.01), rtol=1e-5, what="attend_fwd")
+    dT = rnd("ep.dT%d" % N, (M, k * F_))
+    m2, i2 = rnd("ep.m2", (F_,), 0.2), rnd("ep.i2", (F_,)).abs() + 0.5
+    mx, ix = rnd("ep.mx", (F_,), 0.2), rnd("ep.ix", (F_,)).abs() + 0.5
+    got = ops.edge_attend_bwd(dT, h2, sc2, sh2, m2, i2, PQR, idx, bx, scx, shx, mx, ix, 0.01)
+    ref = km.edge_attend_bwd(dT, h2, sc2, sh2, m2, i2, PQR, idx, bx, scx, shx, mx, ix, 0.01)
+    for a, b, w in zip(got, ref, ("g2", "gy", "sums2", "sumsy")):
+        close(a, b, rtol=5e-5, atol=5e-5, what="attend_bwd." + w)
+    g1 = rnd("ep.g1%d" % N, (M * k, H))
+    gam1, gamx = rnd("ep.gam1", (H,)).abs() + 0.5, rnd("ep.gamx", (F_,)).abs() + 0.5
+    m1, i1 = rnd("ep.m1", (H,), 0.2), rnd("ep.i1", (H,)).abs() + 0.5
+    s1, sx = rnd("ep.s1", (2 * H,), 3.0), rnd("ep.sx", (2 * F_,), 3.0)
+    d1 = ops.edge_scatter(g1, got[1], PQR, idx, rowptr, src, b1, m1, i1, gam1, s1, bx, mx, ix, gamx, sx)
+    d2 = km.edge_scatter(g1, got[1], PQR, idx, rowptr, src, b1, m1, i1, gam1, s1, bx, mx, ix, gamx, sx)
+    close(d1, d2, rtol=2e-5, atol=1e-5, what="edge_scatter")
+    # determinism: two runs are bit-identical (no float atomics anywhere)
+    assert torch.equal(d1, ops.edge_scatter(g1, got[1], PQR, idx, rowptr, src, b1, m1, i1, gam1, s1, bx, mx, ix, gamx, sx))
+
+
+@pytest.mark.parametrize("B,N,C", [(3, 200, 64), (2, 128, 128), (2, 77, 20)])
+def test_adain(ops, B, N, C):
+    M = B * N
+    x, gb, dout = rnd("ad.x%d" % C, (M, C)), rnd("ad.gb%d" % C, (M, 2 * C)), rnd("ad.do%d" % C, (M, C))
+    for slope in (1.0, 0.2):
+        mean, var = km.colstats(x, N, slope)
+        mean, var = mean.contiguous(), var.contiguous()
+        close(ops.adain_fwd(x, N, slope, mean, var, gb), km.adain_fwd(x, N, slope, mean, var, gb), rtol=1e-6, what="adain_fwd")
+        for a, b, w in zip(ops.adain_bwd(dout, x, N, slope, mean, var, gb), km.adain_bwd(dout, x, N, slope, mean, var, gb), ("dx", "dgb")):
+            close(a, b, rtol=2e-5, atol=1e-5, what="adain_bwd." + w)
+
+
+def test_pool_bn_backward(ops):
+    B, N, C = 4, 160, 200
+    M = B * N
+    y = rnd("pb.y", (M, C)) * 2
+    mean, var = km.colstats(y, M)
+    gamma, beta = rnd("pb.g", (C,)).abs() + 0.5, rnd("pb.b", (C,), 0.2)
+    sc, sh, inv, mu = km.bn_prepare(mean[0], var[0], gamma, beta, M)
+    pooled, arg = km.maxpool(y, B, N, sc, sh, 0.01)
+    gpool = rnd("pb.gp", (B, C))
+    gv, sums = ops.pool_bwd_stats(gpool, pooled, arg, y, mu, inv, 0.01)
+    gv2, sums2 = km.pool_bwd_stats(gpool, pooled, arg, y, mu, inv, 0.01)
+    close(gv, gv2, rtol=1e-6); close(sums, sums2, rtol=1e-5, atol=1e-5)
+    close(ops.bn_bwd_apply_sparse(gv, arg, y, N, mu, inv, gamma, sums, M), km.bn_bwd_apply_sparse(gv2, arg, y, N, mu, inv, gamma, sums2, M), rtol=1e-5)
+    dst = rnd("pb.dst", (M, C)); dst2 = dst.clone()
+    ops.maxpool_bwd_add(gpool, arg, dst); km.maxpool_bwd_add(gpool, arg, dst2)
+    assert torch.equal(dst, dst2)
+    assert torch.equal(ops.scatter_rows(gv, arg, M), km.scatter_rows(gv, arg, M))
+    assert torch.equal(ops.gather_rows(y, arg), km.gather_rows(y, arg))
+
+
+def test_double_backward_helpers(ops):
+    M, C = 700, 96
+    u, y, gz = rnd("db.u", (M, C)), rnd("db.y", (M, C)) * 2, rnd("db.gz", (M, C))
+    mean, var = km.colstats(y, M)
+    gamma, beta = rnd("db.g", (C,)).abs() + 0.5, rnd("db.b", (C,), 0.2)
+    sc, sh, inv, mu = km.bn_prepare(mean[0], var[0], gamma, beta, M)
+    got = ops.bn_dbl_stats(u, y, gz, mu, inv)
+    ref = km.bn_dbl_stats(u, y, gz, mu, inv)
+    for a, b in zip(got, ref):
+        close(a, b, rtol=2e-5, atol=2e-4, what="bn_dbl_stats")
+    S1 = rnd("db.S1", (C,), 3.0)
+    for a, b in zip(ops.bn_dbl_apply(u, y, gz, mu, inv, sc, sh, 0.01, gamma, S1, ref[0], ref[1], M),
+                    km.bn_dbl_apply(u, y, gz, mu, inv, sc, sh, 0.01, gamma, S1, ref[0], ref[1], M)):
+        close(a, b, rtol=1e-5, what="bn_dbl_apply")
+    close(ops.col_scale_add(u, gz, gamma), km.col_scale_add(u, gz, gamma), rtol=1e-6)
+    for act in (0, 1, 2):
+        close(ops.act_bwd(u, torch.tanh(y), act, 0.01), km.act_bwd(u, torch.tanh(y), act, 0.01), rtol=1e-6)
+    close(ops.tanh_bwd(u, torch.tanh(y)), km.tanh_bwd(u, torch.tanh(y)), rtol=1e-6)
+
+
+def test_adam_and_axpby(ops):
+    n = 100003
+    p, g = rnd("am.p", (n,)), rnd("am.g", (n,), 0.01)
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    p2, m2, v2 = p.clone(), m.clone(), v.clone()
+    for step in (1, 2, 3):
+        ops.adam_step(p, g, m, v, step)
+        km.adam_step(p2, g, m2, v2, step)
+    close(p, p2, rtol=1e-6); close(m, m2, rtol=1e-6); close(v, v2, rtol=1e-6)
+    y = rnd("am.y", (n,)); y2 = y.clone()
+    ops.axpby(0.5, g, 2.0, y); km.axpby(0.5, g, 2.0, y2)
+    close(y, y2, rtol=1e-6)
