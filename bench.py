@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""G+D train-step throughput of the MI355X-native SP-GAN hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one iteration of the reference loop body (Generation/model.py:239-279): D-step + G-step
+with both Adam updates (and, for N>1, both flat gradient all-reduces), on BASELINE config 2:
+Chair-shaped synthetic clouds, 2048 points, per-GPU batch 32, WGAN loss + gradient penalty (lambda 10),
+fp32.  Weak scaling: the per-GPU batch is fixed, global batch = 32*N.  Inputs are resident in HBM.
+
+The JSON line also carries
+  roofline     : the dominant kernel (the fp32-MFMA gemm_nt), its algorithmic FLOPs per launch / average
+                 launch time measured with HIP events on the launch stream, against the 157.3 TFLOP/s fp32 matrix peak;
+  cpu_baseline : the CPU oracle (a PyTorch restatement of the reference, kind "port") timed on this box's host
+                 cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "sp-gan_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch   # noqa: E402
+
+N_POINTS = 2048
+PER_GPU_BATCH = 32
+NZ = 128
+K_NN = 10
+FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+# algorithmic FLOPs per shape per step, reference formulation: WGAN-GP at N=2048
+GF_PER_SHAPE_STEP = 32.6
+
+
+class Opts:
+    np = N_POINTS; nk = 2 * K_NN; nz = NZ; softmax = True; off = False; attn = False
+    use_head = False; eql = False; z_norm = False; small_d = False
+
+
+def build_models(dev):
+    import spgan
+    torch.manual_seed(123)                      # Generation/model.py:38-41
+    G, D = spgan.Generator(Opts), spgan.Discriminator(Opts)
+    return G.to(dev), D.to(dev)
+
+
+def make_inputs(dev, rank, b):
+    from spgan import fixture_rng as fr
+    x = fr.sphere_template(N_POINTS)[None].repeat(b, 1, 1).to(dev)
+    real = fr.synthetic_real(b, N_POINTS, seed=1234 + rank).to(dev)
+    zs = [fr.latent(b, N_POINTS, NZ, seed=4321 + rank + i).to(dev) for i in range(4)]
+    alpha = fr.uniform("bench.alpha.%d" % rank, (b, 1, 1), 0.0, 1.0).to(dev)
+    return x, real, zs, alpha
+
+
+def gemm_roofline(dev):
+    """Dominant kernel = gemm_nt (all forward/dgrad contractions).  Time its largest instance of the step,
+    conv_out of EdgeConv2 (M = B*N, N = 128, K = 1280), with HIP events on the launch stream."""
+    from spgan import ops
+    M, Nn, K = PER_GPU_BATCH * N_POINTS, 128, 1280
+    A = torch.randn(M, K, device=dev); W = torch.randn(Nn, K, device=dev) * 0.05; b = torch.randn(Nn, device=dev)
+    for _ in range(3):
+        ops.gemm_nt(A, W, b)
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record(stream)
+    for _ in range(reps):
+        ops.gemm_nt(A, W, b)
+    e1.record(stream)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * M * Nn * K
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_nt_kernel<plain,linear,TN=4> (EdgeConv2.conv_out, M=%d N=%d K=%d)" % (M, Nn, K),
+            "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
+            "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "traffic": None}
+
+
+def cpu_baseline(budget_s=25.0):
+    """The oracle's train step (same loss composition) on the host cores, bounded sample: C2 shape at a reduced
+    batch (the [B,N,N] sort of the reference formulation needs ~64 MB per shape per EdgeConv)."""
+    from oracle import spgan_oracle as orc
+    from spgan import fixture_rng as fr
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = 4
+    gp_ = {k: v.requires_grad_(True) for k, v in fr.init_params(orc.generator_shapes(), salt=1, perturb_bn=False).items()}
+    dp_ = {k: v.requires_grad_(True) for k, v in fr.init_params(orc.discriminator_shapes(), salt=1, perturb_bn=False).items()}
+    gbuf, dbuf = orc.bn_buffers(orc.generator_shapes()), orc.bn_buffers(orc.discriminator_shapes())
+    optG, optD = orc.AdamState(gp_), orc.AdamState(dp_)
+    x = fr.sphere_template(N_POINTS)[None].repeat(b, 1, 1)
+    real = fr.synthetic_real(b, N_POINTS, seed=1234)
+    z1, z2 = fr.latent(b, N_POINTS, NZ, seed=1), fr.latent(b, N_POINTS, NZ, seed=2)
+    alpha = fr.uniform("bench.alpha.cpu", (b, 1, 1), 0.0, 1.0)
+    orc.train_step(gp_, gbuf, dp_, dbuf, optG, optD, x, real, z1, z2, gan="wgan", use_gp=True, alpha=alpha)   # warm-up
+    t0 = time.time(); n = 0
+    while True:
+        orc.train_step(gp_, gbuf, dp_, dbuf, optG, optD, x, real, z1, z2, gan="wgan", use_gp=True, alpha=alpha)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 8:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": round(b / dt, 3), "unit": "shapes/s", "cores": cores, "kind": "port",
+            "sample": "%d oracle train steps (WGAN-GP, N=%d, batch %d; PyTorch CPU fp32, %d threads), %.1f s/step" % (n, N_POINTS, b, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import spgan
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = spgan.init_process_group_from_env("nccl") if world > 1 else 0
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+
+    G, D = build_models(dev)
+    tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=world > 1)
+    x, real, zs, alpha = make_inputs(dev, rank, PER_GPU_BATCH)
+
+    def one_step(i):
+        tr.step(x, real, zs[(2 * i) % 4], zs[(2 * i + 1) % 4], alpha=alpha)
+
+    for i in range(args.warmup):
+        one_step(i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        shapes_s = PER_GPU_BATCH * world * args.steps / dt
+        line = {
+            "metric": "G+D train-step shapes/sec @2048 pts, bs=32 per GPU (WGAN-GP)", "value": round(shapes_s, 2), "unit": "shapes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Chair-shaped synthetic clouds, 2048 pts, per-GPU batch 32, WGAN + gradient penalty (lambda 10), "
+                                   "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10", "global_batch": PER_GPU_BATCH * world, "n_points": N_POINTS,
+                       "parallelism": "dp%d" % world},
+            "step_tflops_algorithmic": round(shapes_s * GF_PER_SHAPE_STEP / 1e3, 2),
+            "step_frac_of_fp32_matrix_peak": round(shapes_s * GF_PER_SHAPE_STEP / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
+        }
+        line["roofline"] = gemm_roofline(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            line["speedup_vs_cpu_baseline"] = round(shapes_s / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

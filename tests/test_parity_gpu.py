@@ -204,9 +204,9 @@ def test_train_step_golden(sp, tag, gan, use_gp, B, N):
         check(d, "ggrad|" + n, g, rtol=1.5e-1, atol=_atol(n))   # after D's Adam step and through D's kinks
     for n, p in D.named_parameters():
         if not n.endswith(ZERO_GRAD_BIASES):
-            check(d, "dparam|" + n, p, rtol=1e-3)
+            check(d, "dparam|" + n, p, rtol=1e-3, atol=2.5e-4)      # one Adam step moves an element by <= lr; sign noise => 2*lr
     for n, p in G.named_parameters():
         if not n.endswith(ZERO_GRAD_BIASES):
-            check(d, "gparam|" + n, p, rtol=1e-3)
+            check(d, "gparam|" + n, p, rtol=1e-3, atol=2.5e-4)      # one Adam step moves an element by <= lr; sign noise => 2*lr
     for n, b in D.named_buffers():
         np.testing.assert_allclose(b.cpu().numpy(), d["dbuf|" + n], rtol=2e-3, atol=2e-4)

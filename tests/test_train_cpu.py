@@ -57,10 +57,10 @@ def test_train_step_golden(spgan_cpu, tag, gan, use_gp, B, N):
         check(d, "ggrad|" + n, g, rtol=1.5e-1, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
     for n, p in D.named_parameters():
         if not n.endswith(ZERO_GRAD_BIASES):
-            check(d, "dparam|" + n, p, rtol=1e-3)
+            check(d, "dparam|" + n, p, rtol=1e-3, atol=2.5e-4)      # one Adam step moves an element by <= lr; sign noise => 2*lr
     for n, p in G.named_parameters():
         if not n.endswith(ZERO_GRAD_BIASES):
-            check(d, "gparam|" + n, p, rtol=1e-3)
+            check(d, "gparam|" + n, p, rtol=1e-3, atol=2.5e-4)      # one Adam step moves an element by <= lr; sign noise => 2*lr
     for n, b in list(G.named_buffers()):
         np.testing.assert_allclose(b.numpy(), d["gbuf|" + n], rtol=2e-3, atol=2e-4)
     for n, b in list(D.named_buffers()):
