@@ -87,27 +87,49 @@ def cpu_baseline(budget_s=25.0):
     batch (the [B,N,N] sort of the reference formulation needs ~64 MB per shape per EdgeConv)."""
     from oracle import spgan_oracle as orc
     from spgan import fixture_rng as fr
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
+
+    def setup(b, n_pts):
+        gp_ = {k: v.requires_grad_(True) for k, v in fr.init_params(orc.generator_shapes(), salt=1, perturb_bn=False).items()}
+        dp_ = {k: v.requires_grad_(True) for k, v in fr.init_params(orc.discriminator_shapes(), salt=1, perturb_bn=False).items()}
+        st = dict(gp_=gp_, dp_=dp_, gbuf=orc.bn_buffers(orc.generator_shapes()), dbuf=orc.bn_buffers(orc.discriminator_shapes()),
+                  optG=orc.AdamState(gp_), optD=orc.AdamState(dp_), x=fr.sphere_template(n_pts)[None].repeat(b, 1, 1),
+                  real=fr.synthetic_real(b, n_pts, seed=1234), z1=fr.latent(b, n_pts, NZ, seed=1), z2=fr.latent(b, n_pts, NZ, seed=2),
+                  alpha=fr.uniform("bench.alpha.cpu", (b, 1, 1), 0.0, 1.0))
+        return st
+
+    def run(st):
+        t = time.time()
+        orc.train_step(st["gp_"], st["gbuf"], st["dp_"], st["dbuf"], st["optG"], st["optD"], st["x"], st["real"], st["z1"], st["z2"],
+                       gan="wgan", use_gp=True, alpha=st["alpha"])
+        return time.time() - t
+
+    # PyTorch CPU oversubscribes badly on many-core hosts (256 threads: 143 s/step measured vs 1.5 s/step on 8):
+    # pick the fastest thread count on a tiny probe first, then time the bounded sample with it.
+    probe = setup(2, 512)
+    best, best_t = 1, None
+    for th in [t for t in (4, 8, 16, 32, 64) if t <= ncpu] or [ncpu]:
+        torch.set_num_threads(th)
+        run(probe)
+        dt = min(run(probe), run(probe))
+        if best_t is None or dt < best_t:
+            best, best_t = th, dt
+        if dt > 5.0:
+            break
+    torch.set_num_threads(best)
     b = 4
-    gp_ = {k: v.requires_grad_(True) for k, v in fr.init_params(orc.generator_shapes(), salt=1, perturb_bn=False).items()}
-    dp_ = {k: v.requires_grad_(True) for k, v in fr.init_params(orc.discriminator_shapes(), salt=1, perturb_bn=False).items()}
-    gbuf, dbuf = orc.bn_buffers(orc.generator_shapes()), orc.bn_buffers(orc.discriminator_shapes())
-    optG, optD = orc.AdamState(gp_), orc.AdamState(dp_)
-    x = fr.sphere_template(N_POINTS)[None].repeat(b, 1, 1)
-    real = fr.synthetic_real(b, N_POINTS, seed=1234)
-    z1, z2 = fr.latent(b, N_POINTS, NZ, seed=1), fr.latent(b, N_POINTS, NZ, seed=2)
-    alpha = fr.uniform("bench.alpha.cpu", (b, 1, 1), 0.0, 1.0)
-    orc.train_step(gp_, gbuf, dp_, dbuf, optG, optD, x, real, z1, z2, gan="wgan", use_gp=True, alpha=alpha)   # warm-up
+    st = setup(b, N_POINTS)
+    run(st)                                                          # warm-up
     t0 = time.time(); n = 0
     while True:
-        orc.train_step(gp_, gbuf, dp_, dbuf, optG, optD, x, real, z1, z2, gan="wgan", use_gp=True, alpha=alpha)
+        run(st)
         n += 1
         if time.time() - t0 > budget_s or n >= 8:
             break
     dt = (time.time() - t0) / n
-    return {"value": round(b / dt, 3), "unit": "shapes/s", "cores": cores, "kind": "port",
-            "sample": "%d oracle train steps (WGAN-GP, N=%d, batch %d; PyTorch CPU fp32, %d threads), %.1f s/step" % (n, N_POINTS, b, cores, dt)}
+    return {"value": round(b / dt, 3), "unit": "shapes/s", "cores": best, "kind": "port", "host_cpus": ncpu,
+            "sample": "%d oracle train steps (WGAN-GP, N=%d, batch %d; PyTorch CPU fp32, %d threads = fastest of a probe over 4..64 "
+                      "on a %d-CPU host), %.2f s/step" % (n, N_POINTS, b, best, ncpu, dt)}
 
 
 def main():

@@ -165,6 +165,7 @@ class Generator(nn.Module):
         slope = nets.NEG_2
         x1 = self.EdgeConv1.forward_pm(feat, B, N, knn_mode=0 if self.use_head else 1)
         x1 = self.adain1.forward_pm(x1, style, N, slope)           # lrelu1 fused into the instance norm (Generator.py:175-176)
+        self.last_x1 = x1.detach()                                 # [M,64] input of EdgeConv2's graph (diagnostics / parity tests)
         x2 = self.EdgeConv2.forward_pm(x1, B, N, knn_mode=0)
         x2 = self.adain2.forward_pm(x2, style, N, slope)
         gt_params = [dict(self.named_parameters())[n] for n in Fn.GT_NAMES]

@@ -144,14 +144,21 @@ def test_generator_golden(sp):
     assert np.array_equal(i1, d["idx1"]), "sphere graph must be bit-exact (SURVEY H1a)"
     rows2 = (i2 == d["idx2"]).all(axis=2).mean()
     assert rows2 >= 0.995, "EdgeConv2 kNN row agreement %.4f" % rows2
-    # fraction of output elements within 1e-3 (tie rows can move single points)
-    ref = d["out|full"]
-    frac = (np.abs(out.detach().cpu().numpy() - ref) <= 1e-3 * np.maximum(np.abs(ref), 1.0)).mean()
-    assert frac >= 0.999, frac
+    # every disagreeing EdgeConv2 row must be a near-tie in the reference's own distances (tie-aware protocol):
+    x1 = torch.from_numpy(d["stage|x1|full"])
+    srt = torch.sort(orc.pairwise_sqdist(x1), dim=2)[0][:, :, :12]
+    gaps = srt.diff(dim=2).abs().min(dim=2)[0].numpy()
+    bad = ~(i2 == d["idx2"]).all(axis=2)
+    assert (gaps[bad] < 1e-4).all(), "a non-tie EdgeConv2 row disagrees with the reference"
+    # A single flipped row moves ~all outputs by >1e-3 through the batch-of-4 BatchNorm1d + global max coupling
+    # (measured on the reference against itself), so the raw output is only comparable when the
+    # graphs coincide; otherwise test_generator_vs_oracle_with_injected_graph carries the comparison.
     if rows2 == 1.0:
         check(d, "out", out, rtol=2e-4)
-    for n, b in G.named_buffers():
-        np.testing.assert_allclose(b.cpu().numpy(), d["buf|" + n], rtol=2e-3, atol=1e-4)
+        for n, b in G.named_buffers():
+            np.testing.assert_allclose(b.cpu().numpy(), d["buf|" + n], rtol=2e-3, atol=1e-4)
+    # the stage feeding EdgeConv2's graph is tie-independent and must be tight (<= 1e-5 class)
+    check(d, "stage|x1", sp.ops.pm_to_cm(G.last_x1, B, N), rtol=2e-5)
 
 
 def test_generator_vs_oracle_with_injected_graph(sp):
