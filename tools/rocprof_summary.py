@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd database (--kernel-trace --stats) into a per-kernel table (text).
+usage: rocprof_summary.py results.db [steps] > profiles/xxx.txt"""
+import re, sqlite3, sys
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"\(.*$", "", n) if len(n) > 90 else n
+    return n[:110]
+
+db = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+c = sqlite3.connect(db)
+rows = c.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
+tot = sum(r[2] for r in rows)
+print("# rocprofv3 --kernel-trace --stats summary; durations in microseconds; %d kernels; total %.1f us (%.3f ms per step over %g steps)" % (len(rows), tot, tot / steps / 1e3, steps))
+print("%-112s %8s %12s %10s %7s %12s" % ("kernel", "calls", "total_us", "avg_us", "pct", "us_per_step"))
+for n, calls, td, avg, pct in rows:
+    print("%-112s %8d %12.1f %10.2f %6.2f%% %12.1f" % (short(n), calls, td, avg, pct, td / steps))
