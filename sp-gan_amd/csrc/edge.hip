@@ -197,6 +197,178 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_kernel(
   }
 }
 
+// ---- register-resident variants for compile-time k (k = 10 is the reference default, nk//2, Generator.py:96) ----
+// One wave per point; a lane owns VEC consecutive channels and keeps all k pre-activations in registers, so
+// h2pre / dT are read exactly once (the generic kernels above re-read them for max, sum and output passes).
+template <int VEC> struct VecT;
+template <> struct VecT<1> { typedef float T; };
+template <> struct VecT<2> { typedef float2 T; };
+template <> struct VecT<4> { typedef float4 T; };
+
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* p, float (&o)[VEC]) {
+  const typename VecT<VEC>::T v = *reinterpret_cast<const typename VecT<VEC>::T*>(p);
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) o[q] = f[q];
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float* p, const float (&o)[VEC]) {
+  typename VecT<VEC>::T v;
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) f[q] = o[q];
+  *reinterpret_cast<typename VecT<VEC>::T*>(p) = v;
+}
+
+template <int K, int VEC>
+__global__ __launch_bounds__(256) void edge_attend_fwd_k_kernel(const float* __restrict__ h2, const float* __restrict__ sc2,
+                                                                const float* __restrict__ sh2, const float* __restrict__ PQR, int ld, int H,
+                                                                int F, const int32_t* __restrict__ idx, int M, const float* __restrict__ bx,
+                                                                const float* __restrict__ scx, const float* __restrict__ shx, float slope,
+                                                                float* __restrict__ T) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
+  if (i >= M) return;
+  int nb[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) nb[r] = __builtin_amdgcn_readfirstlane(idx[(size_t)i * K + r]);
+  const float* h2i = h2 + (size_t)i * K * F;
+  for (int f = lane * VEC; f < F; f += 64 * VEC) {
+    float a2[VEC], c2[VEC], ax[VEC], cx[VEC], bb[VEC], Ri[VEC];
+    ldv<VEC>(sc2 + f, a2); ldv<VEC>(sh2 + f, c2); ldv<VEC>(scx + f, ax); ldv<VEC>(shx + f, cx); ldv<VEC>(bx + f, bb);
+    ldv<VEC>(PQR + (size_t)i * ld + H + F + f, Ri);
+    float z[K][VEC], qv[K][VEC];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      ldv<VEC>(h2i + (size_t)r * F + f, z[r]);
+      ldv<VEC>(PQR + (size_t)nb[r] * ld + H + f, qv[r]);
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        z[r][q] = lrelu_f(fmaf(z[r][q], a2[q], c2[q]), slope);
+        mx = fmaxf(mx, z[r][q]);
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        z[r][q] = expf(z[r][q] - mx);
+        den += z[r][q];
+      }
+      const float rden = 1.0f / den;
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        const float yv = lrelu_f(fmaf((Ri[q] + qv[r][q]) + bb[q], ax[q], cx[q]), slope);
+        z[r][q] = yv * (z[r][q] * rden);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r) stv<VEC>(T + ((size_t)i * K + r) * F + f, z[r]);
+  }
+}
+
+template <int K, int VEC>
+__global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
+    const float* __restrict__ dT, const float* __restrict__ h2, const float* __restrict__ sc2, const float* __restrict__ sh2,
+    const float* __restrict__ mean2, const float* __restrict__ inv2, const float* __restrict__ PQR, int ld, int H, int F,
+    const int32_t* __restrict__ idx, int M, const float* __restrict__ bx, const float* __restrict__ scx, const float* __restrict__ shx,
+    const float* __restrict__ meanx, const float* __restrict__ invx, float slope, float* __restrict__ g2, float* __restrict__ gy,
+    float* __restrict__ part) {
+  // EB_PT points per workgroup (4 waves x EB_PT/4 points) so the partial format matches the generic kernel
+  __shared__ float red[4][4][64 * VEC];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int f0 = 0; f0 < F; f0 += 64 * VEC) {
+    const int f = f0 + lane * VEC;
+    const bool ok = f < F;
+    float s0[VEC], s1[VEC], s2[VEC], s3[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) s0[q] = s1[q] = s2[q] = s3[q] = 0.f;
+    if (ok) {
+      float a2[VEC], c2[VEC], ax[VEC], cx[VEC], bb[VEC], m2[VEC], i2[VEC], mxm[VEC], ixv[VEC];
+      ldv<VEC>(sc2 + f, a2); ldv<VEC>(sh2 + f, c2); ldv<VEC>(scx + f, ax); ldv<VEC>(shx + f, cx); ldv<VEC>(bx + f, bb);
+      ldv<VEC>(mean2 + f, m2); ldv<VEC>(inv2 + f, i2); ldv<VEC>(meanx + f, mxm); ldv<VEC>(invx + f, ixv);
+      for (int pp = 0; pp < EB_PT / 4; ++pp) {
+        const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * EB_PT + pp * 4 + w);
+        if (i >= M) break;
+        float Ri[VEC];
+        ldv<VEC>(PQR + (size_t)i * ld + H + F + f, Ri);
+        float hp[K][VEC], d[K][VEC], yp[K][VEC];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          const int j = __builtin_amdgcn_readfirstlane(idx[(size_t)i * K + r]);
+          ldv<VEC>(h2 + ((size_t)i * K + r) * F + f, hp[r]);
+          ldv<VEC>(dT + ((size_t)i * K + r) * F + f, d[r]);
+          ldv<VEC>(PQR + (size_t)j * ld + H + f, yp[r]);
+        }
+        float o2[K][VEC], oy[K][VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          float e[K], mx = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < K; ++r) {
+            e[r] = lrelu_f(fmaf(hp[r][q], a2[q], c2[q]), slope);
+            mx = fmaxf(mx, e[r]);
+          }
+          float den = 0.f;
+#pragma unroll
+          for (int r = 0; r < K; ++r) {
+            e[r] = expf(e[r] - mx);
+            den += e[r];
+          }
+          const float rden = 1.0f / den;
+          float dot = 0.f;
+#pragma unroll
+          for (int r = 0; r < K; ++r) {
+            yp[r][q] = (Ri[q] + yp[r][q]) + bb[q];
+            e[r] *= rden;
+            const float yv = lrelu_f(fmaf(yp[r][q], ax[q], cx[q]), slope);
+            dot = fmaf(d[r][q] * yv, e[r], dot);
+          }
+#pragma unroll
+          for (int r = 0; r < K; ++r) {
+            const float z2 = fmaf(hp[r][q], a2[q], c2[q]);
+            const float zy = fmaf(yp[r][q], ax[q], cx[q]);
+            const float yv = lrelu_f(zy, slope);
+            const float ds = e[r] * (d[r][q] * yv - dot);
+            const float v2 = ds * lrelu_mask(z2, slope);
+            const float vy = d[r][q] * e[r] * lrelu_mask(zy, slope);
+            o2[r][q] = v2; oy[r][q] = vy;
+            s0[q] += v2;
+            s1[q] = fmaf(v2, (hp[r][q] - m2[q]) * i2[q], s1[q]);
+            s2[q] += vy;
+            s3[q] = fmaf(vy, (yp[r][q] - mxm[q]) * ixv[q], s3[q]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          stv<VEC>(g2 + ((size_t)i * K + r) * F + f, o2[r]);
+          stv<VEC>(gy + ((size_t)i * K + r) * F + f, oy[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      red[0][w][lane * VEC + q] = s0[q]; red[1][w][lane * VEC + q] = s1[q];
+      red[2][w][lane * VEC + q] = s2[q]; red[3][w][lane * VEC + q] = s3[q];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 64 * VEC; c += 256) {
+      const int ff = f0 + c;
+      if (ff < F) {
+        float* o = part + (size_t)blockIdx.x * (2 * F) * 2;
+        o[(size_t)ff * 2 + 0] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        o[(size_t)ff * 2 + 1] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+        o[(size_t)(F + ff) * 2 + 0] = (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]);
+        o[(size_t)(F + ff) * 2 + 1] = (red[3][0][c] + red[3][1][c]) + (red[3][2][c] + red[3][3][c]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------ edge -> point gradients
 // BatchNorm backward (train mode) of the two per-edge pre-activations fused with the gather-style
 // reduction onto points:
@@ -281,8 +453,16 @@ extern "C" int spgan_edge_attend_fwd(const float* h2pre, const float* sc2, const
                                      const int32_t* idx, int M, int k, const float* bx, const float* scx, const float* shx, float slope,
                                      float* T, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(h2pre && sc2 && sh2 && PQR && idx && bx && scx && shx && T && M > 0 && k > 0 && ld >= H + 2 * F);
-  hipLaunchKernelGGL(edge_attend_fwd_kernel, dim3(cdiv(M, EA_PT)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, k,
-                     bx, scx, shx, slope, T);
+  const bool al = ((ld | H | F) % 2 == 0);
+  if (k == 10 && al && F % 128 == 0)
+    hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 2>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, bx,
+                       scx, shx, slope, T);
+  else if (k == 10)
+    hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, bx,
+                       scx, shx, slope, T);
+  else
+    hipLaunchKernelGGL(edge_attend_fwd_kernel, dim3(cdiv(M, EA_PT)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, k,
+                       bx, scx, shx, slope, T);
   return spgan_launch_status();
 }
 
@@ -292,8 +472,16 @@ extern "C" int spgan_edge_attend_bwd(const float* dT, const float* h2pre, const 
                                      float slope, float* g2, float* gy, float* partials, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(dT && h2pre && sc2 && sh2 && mean2 && inv2 && PQR && idx && bx && scx && shx && meanx && invx && g2 && gy && partials);
   SPGAN_CHECK_ARG(M > 0 && k > 0 && ld >= H + 2 * F);
-  hipLaunchKernelGGL(edge_attend_bwd_kernel, dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR, ld,
-                     H, F, idx, M, k, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
+  const bool al = ((ld | H | F) % 2 == 0);
+  if (k == 10 && al && F % 128 == 0)
+    hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 2>), dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR,
+                       ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
+  else if (k == 10)
+    hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 1>), dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR,
+                       ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
+  else
+    hipLaunchKernelGGL(edge_attend_bwd_kernel, dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR, ld,
+                       H, F, idx, M, k, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
   return spgan_launch_status();
 }
 

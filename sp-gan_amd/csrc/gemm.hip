@@ -342,7 +342,6 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------ gemm_tn
 constexpr int TKM = 16;         // m-rows per staging step
 constexpr int TA = 128;         // output rows (columns of A) per workgroup
-constexpr int TN_MAX_ROWS = 2048;  // m-rows per split (upper bound; chosen per problem)
 
 template <int BMODE>
 __device__ __forceinline__ float4 load_b_tn(const spgan_gemm_tn_args& p, int m, int c, bool vecB) {
@@ -472,21 +471,37 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
       }
 }
 
-__global__ void splitk_reduce_kernel(const float* ws, int splits, int Na, int Nb, float* C, int ldc, float beta) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Na * Nb) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += ws[(size_t)k * Na * Nb + i];
-  const int r = i / Nb, c = i % Nb;
-  float* o = C + (size_t)r * ldc + c;
-  *o = (beta == 0.f) ? s : fmaf(beta, *o, s);
+// Fixed-order sum over the split partials: 64 consecutive outputs x 4 split-slices per workgroup.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int Na, int Nb, float* __restrict__ C,
+                                                            int ldc, float beta) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const size_t stride = (size_t)Na * Nb;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < Na * Nb) {
+    int k = sl;
+    for (; k + 4 < splits; k += 8) {
+      s0 += ws[(size_t)k * stride + i];
+      s1 += ws[(size_t)(k + 4) * stride + i];
+    }
+    if (k < splits) s0 += ws[(size_t)k * stride + i];
+  }
+  red[sl][lane] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && i < Na * Nb) {
+    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int r = i / Nb, c = i % Nb;
+    float* o = C + (size_t)r * ldc + c;
+    *o = (beta == 0.f) ? s : fmaf(beta, *o, s);
+  }
 }
 
-// Split choice: enough workgroups to fill 256 CUs a few times over, but at least 256 m-rows each.
+// Split choice: about two workgroups per CU in total, at least 256 m-rows each.
 inline void tn_plan(int M, int Na, int Nb, int* splits, int* rows) {
   const int TB = Nb > 64 ? 128 : (Nb > 32 ? 64 : 32);
   const int tiles = cdiv(Na, TA) * cdiv(Nb, TB);
-  int want = cdiv(1024, tiles);
+  int want = cdiv(512, tiles);
   int r = cdiv(M, want);
   if (r < 256) r = 256;
   r = cdiv(r, TKM) * TKM;
@@ -506,7 +521,7 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 1>), dim3(cdiv(a.Na, TA) * cdiv(a.Nb, 32), splits), dim3(256), 0, s, a, rows);
   }
   const int n = a.Na * a.Nb;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
   return spgan_launch_status();
 }
 

@@ -47,49 +47,62 @@ __global__ __launch_bounds__(256) void colpartials_kernel(const float* __restric
   }
 }
 
-// Combine per-tile partials over the tiles of each group.  block = 16 slices x 16 columns.
+// Combine per-tile partials over the tiles of each group.  block = 32 slices x 8 columns (one 64-byte
+// segment of the partial row per slice); slices are merged through LDS in a fixed tree order.
+constexpr int FS = 32, FC = 8;
+
+__device__ __forceinline__ void chan_merge(float& n, float& a, float& b, float n2, float a2, float b2) {
+  const float nn = n + n2;
+  if (nn > 0.f) {
+    const float d = a2 - a;
+    a = a + d * (n2 / nn);
+    b = b + b2 + d * d * (n * n2 / nn);
+  }
+  n = nn;
+}
+
 __global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restrict__ part, int tiles_per_group, int C, int G, int mode,
                                                           int tile_rows, float* __restrict__ out0, float* __restrict__ out1) {
-  __shared__ float sn[16][16], sa[16][16], sb[16][16];
+  __shared__ float sn[FS][FC], sa[FS][FC], sb[FS][FC];
   const int g = blockIdx.y;
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int cl = threadIdx.x & (FC - 1), sl = threadIdx.x / FC;
+  const int c = blockIdx.x * FC + cl;
   const bool cok = c < C;
   float n = 0.f, a = 0.f, b = 0.f;  // mode 0: (count, mean, M2); mode 1: (-, s0, s1)
   if (cok) {
-    for (int t = sl; t < tiles_per_group; t += 16) {
-      const float* p = part + (((size_t)g * tiles_per_group + t) * C + c) * 2;
+    const float2* base = reinterpret_cast<const float2*>(part) + (size_t)g * tiles_per_group * C + c;
+    int t = sl;
+    for (; t + 3 * FS < tiles_per_group; t += 4 * FS) {  // four independent loads in flight
+      const float2 p0 = base[(size_t)t * C], p1 = base[(size_t)(t + FS) * C], p2 = base[(size_t)(t + 2 * FS) * C],
+                   p3 = base[(size_t)(t + 3 * FS) * C];
+      if (mode == 0) {
+        chan_merge(n, a, b, (float)min(tile_rows, G - t * tile_rows), p0.x / (float)min(tile_rows, G - t * tile_rows), p0.y);
+        chan_merge(n, a, b, (float)min(tile_rows, G - (t + FS) * tile_rows), p1.x / (float)min(tile_rows, G - (t + FS) * tile_rows), p1.y);
+        chan_merge(n, a, b, (float)min(tile_rows, G - (t + 2 * FS) * tile_rows), p2.x / (float)min(tile_rows, G - (t + 2 * FS) * tile_rows), p2.y);
+        chan_merge(n, a, b, (float)min(tile_rows, G - (t + 3 * FS) * tile_rows), p3.x / (float)min(tile_rows, G - (t + 3 * FS) * tile_rows), p3.y);
+      } else {
+        a += (p0.x + p1.x) + (p2.x + p3.x);
+        b += (p0.y + p1.y) + (p2.y + p3.y);
+      }
+    }
+    for (; t < tiles_per_group; t += FS) {
+      const float2 p0 = base[(size_t)t * C];
       if (mode == 0) {
         const float nb = (float)min(tile_rows, G - t * tile_rows);
-        const float mb = p[0] / nb, m2b = p[1];
-        const float nn = n + nb;
-        const float d = mb - a;
-        a = a + d * (nb / nn);
-        b = b + m2b + d * d * (n * nb / nn);
-        n = nn;
+        chan_merge(n, a, b, nb, p0.x / nb, p0.y);
       } else {
-        a += p[0];
-        b += p[1];
+        a += p0.x;
+        b += p0.y;
       }
     }
   }
   sn[sl][cl] = n; sa[sl][cl] = a; sb[sl][cl] = b;
   __syncthreads();
-  for (int w = 8; w > 0; w >>= 1) {
+  for (int w = FS / 2; w > 0; w >>= 1) {
     if (sl < w) {
       const float n2 = sn[sl + w][cl], a2 = sa[sl + w][cl], b2 = sb[sl + w][cl];
-      if (mode == 0) {
-        const float nn = n + n2;
-        if (nn > 0.f) {
-          const float d = a2 - a;
-          a = a + d * (n2 / nn);
-          b = b + b2 + d * d * (n * n2 / nn);
-        }
-        n = nn;
-      } else {
-        a += a2;
-        b += b2;
-      }
+      if (mode == 0) chan_merge(n, a, b, n2, a2, b2);
+      else { a += a2; b += b2; }
       sn[sl][cl] = n; sa[sl][cl] = a; sb[sl][cl] = b;
     }
     __syncthreads();
@@ -179,6 +192,50 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
   }
 }
 
+// float4 variant: 16 lanes x 16 B cover 64 channels of a row, 16 row-slices per workgroup.
+__global__ __launch_bounds__(256) void maxpool_v4_kernel(const float* __restrict__ y, int ld, int N, int C, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float slope, float* __restrict__ out,
+                                                         int32_t* __restrict__ argmax) {
+  __shared__ float rv[16][64];
+  __shared__ int ri[16][64];
+  const int b = blockIdx.x;
+  const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.y * 64 + q * 4;
+  const bool cok = c < C;  // C % 4 == 0
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cok && scale) { sc = *reinterpret_cast<const float4*>(scale + c); sh = *reinterpret_cast<const float4*>(shift + c); }
+  const float* base = y + (size_t)b * N * ld + c;
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {0, 0, 0, 0};
+  if (cok)
+    for (int n = sl; n < N; n += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)n * ld);
+      const float t0 = lrelu_f(fmaf(v.x, sc.x, sh.x), slope), t1 = lrelu_f(fmaf(v.y, sc.y, sh.y), slope);
+      const float t2 = lrelu_f(fmaf(v.z, sc.z, sh.z), slope), t3 = lrelu_f(fmaf(v.w, sc.w, sh.w), slope);
+      if (t0 > best[0]) { best[0] = t0; bi[0] = n; }
+      if (t1 > best[1]) { best[1] = t1; bi[1] = n; }
+      if (t2 > best[2]) { best[2] = t2; bi[2] = n; }
+      if (t3 > best[3]) { best[3] = t3; bi[3] = n; }
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { rv[sl][q * 4 + j] = best[j]; ri[sl][q * 4 + j] = bi[j]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.y * 64 + threadIdx.x;
+    if (cc < C) {
+      float bv = rv[0][threadIdx.x];
+      int bn = ri[0][threadIdx.x];
+      for (int s2 = 1; s2 < 16; ++s2) {
+        const float v = rv[s2][threadIdx.x];
+        const int i2 = ri[s2][threadIdx.x];
+        if (v > bv || (v == bv && i2 < bn)) { bv = v; bn = i2; }
+      }
+      out[(size_t)b * C + cc] = bv;
+      if (argmax) argmax[(size_t)b * C + cc] = b * N + bn;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t spgan_colreduce_ws_bytes(int M, int C, int G) {
@@ -193,7 +250,7 @@ extern "C" int spgan_colstats_finalize(const float* partials, int groups, int ti
   if (tile_rows <= 0) tile_rows = RT;
   SPGAN_CHECK_ARG(partials && out0 && out1 && groups > 0 && tiles_per_group > 0 && C > 0 && G > 0 && (mode == 0 || mode == 1));
   SPGAN_CHECK_ARG(tiles_per_group == cdiv(G, tile_rows));
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, partials, tiles_per_group, C, G, mode, tile_rows, out0, out1);
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, partials, tiles_per_group, C, G, mode, tile_rows, out0, out1);
   return spgan_launch_status();
 }
 
@@ -204,7 +261,7 @@ extern "C" int spgan_colstats(const float* X, int ldx, int M, int C, int G, floa
   SPGAN_CHECK_ARG(ws_bytes >= spgan_colreduce_ws_bytes(M, C, G));
   const int groups = M / G, tpg = cdiv(G, RT);
   hipLaunchKernelGGL((colpartials_kernel<0>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, slope, ws);
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, tpg, C, G, 0, RT, out_mean, out_var);
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, ws, tpg, C, G, 0, RT, out_mean, out_var);
   return spgan_launch_status();
 }
 
@@ -216,7 +273,7 @@ extern "C" int spgan_colsum(const float* X, int ldx, int M, int C, int G, float*
   SPGAN_CHECK_ARG(ws_bytes >= spgan_colreduce_ws_bytes(M, C, G) + (size_t)groups * C * sizeof(float));
   float* scratch = ws + (size_t)groups * tpg * C * 2;
   hipLaunchKernelGGL((colpartials_kernel<1>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, 1.0f, ws);
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, 16), groups), dim3(256), 0, s, ws, tpg, C, G, 1, RT, out, scratch);
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, ws, tpg, C, G, 1, RT, out, scratch);
   return spgan_launch_status();
 }
 
@@ -246,6 +303,9 @@ extern "C" int spgan_maxpool(const float* y, int ld, int B, int N, int C, const 
                              int32_t* argmax, spgan_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   SPGAN_CHECK_ARG(y && out && B > 0 && N > 0 && C > 0 && ld >= C);
-  hipLaunchKernelGGL(maxpool_kernel, dim3(B, cdiv(C, 64)), dim3(256), 0, s, y, ld, N, C, scale, shift, slope, out, argmax);
+  const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                  (!scale || (((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0));
+  if (v4) hipLaunchKernelGGL(maxpool_v4_kernel, dim3(B, cdiv(C, 64)), dim3(256), 0, s, y, ld, N, C, scale, shift, slope, out, argmax);
+  else hipLaunchKernelGGL(maxpool_kernel, dim3(B, cdiv(C, 64)), dim3(256), 0, s, y, ld, N, C, scale, shift, slope, out, argmax);
   return spgan_launch_status();
 }

@@ -139,7 +139,13 @@ class EdgeBlockFn(Function):
         params = ctx.saved_tensors
         h = ctx.holder
         P = dict(zip(h.names, [p.detach() for p in params]))
-        csr = ops.csr_build(ctx.ectx["idx"], h.B, h.N)
+        cache = getattr(h, "graph_cache", None)                      # static-sphere graph: CSR built once, reused every step
+        if cache is not None and cache.get("csr") is not None:
+            csr = cache["csr"]
+        else:
+            csr = ops.csr_build(ctx.ectx["idx"], h.B, h.N)
+            if cache is not None:
+                cache["csr"] = csr
         dx, g = nets.edgeblock_backward(P, h.prefix, ctx.ectx, dout, csr, need_dx=ctx.needs_input_grad[1])
         return (None, dx) + tuple(g[n] if ctx.needs_input_grad[2 + i] else None for i, n in enumerate(h.names))
 

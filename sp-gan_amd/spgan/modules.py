@@ -8,6 +8,7 @@ load both ways.  Their `forward` never calls those layers: it runs the HIP pipel
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional
 
 import torch
@@ -95,14 +96,19 @@ class EdgeBlock(nn.Module):
         self.conv_out = nn.Conv2d(Fout, Fout, [1, k], [1, 1])
         self.last_idx: Optional[torch.Tensor] = None      # int32 [B*N, k] global rows of the most recent forward
 
-    def forward_pm(self, x_pm, B: int, N: int, idx: Optional[torch.Tensor] = None, knn_mode: Optional[int] = None):
+    def forward_pm(self, x_pm, B: int, N: int, idx: Optional[torch.Tensor] = None, knn_mode: Optional[int] = None,
+                   graph_cache: Optional[dict] = None):
         names, params = _named(self, "e.")
         if knn_mode is None:
             knn_mode = 1 if self.Fin <= 4 else 0          # coordinates: exact fp64 order; features: fp32 expanded form
+        if graph_cache is not None and idx is None:
+            idx = graph_cache.get("idx")
         h = _Holder(prefix="e", names=names, buffers=_buffers(self, "e."), B=B, N=N, k=self.k, training=self.training,
-                    knn_mode=knn_mode, idx=idx, last_idx=None)
+                    knn_mode=knn_mode, idx=idx, last_idx=None, graph_cache=graph_cache)
         out = Fn.EdgeBlockFn.apply(h, x_pm, *params)
         self.last_idx = h.last_idx
+        if graph_cache is not None and graph_cache.get("idx") is None:
+            graph_cache["idx"] = h.last_idx
         return out
 
     def forward(self, x, idx: Optional[torch.Tensor] = None):
@@ -163,7 +169,18 @@ class Generator(nn.Module):
         pc = x.reshape(B * N, 3).contiguous()
         feat = self._mlp2(self.pc_head, pc) if self.use_head else pc
         slope = nets.NEG_2
-        x1 = self.EdgeConv1.forward_pm(feat, B, N, knn_mode=0 if self.use_head else 1)
+        # The sphere prior is the same tensor every step (Generation/model.py:231): its kNN graph (and the CSR of
+        # its in-edges) is built once per (buffer, version, shape) and reused.  Any in-place write
+        # to x bumps _version and invalidates the cache.
+        cache = None
+        if not self.use_head:
+            sg = getattr(self, "_sphere_graph", None)
+            key = (x._version, tuple(x.shape), self.nk)
+            if sg is None or sg["ref"]() is not x or sg["key"] != key:       # same tensor OBJECT (not just address), unmodified
+                sg = {"ref": weakref.ref(x), "key": key, "idx": None, "csr": None}
+                self.__dict__["_sphere_graph"] = sg
+            cache = sg
+        x1 = self.EdgeConv1.forward_pm(feat, B, N, knn_mode=0 if self.use_head else 1, graph_cache=cache)
         x1 = self.adain1.forward_pm(x1, style, N, slope)           # lrelu1 fused into the instance norm (Generator.py:175-176)
         self.last_x1 = x1.detach()                                 # [M,64] input of EdgeConv2's graph (diagnostics / parity tests)
         x2 = self.EdgeConv2.forward_pm(x1, B, N, knn_mode=0)

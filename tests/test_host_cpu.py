@@ -192,6 +192,25 @@ def test_generator(spgan_cpu):
         np.testing.assert_allclose(G.state_dict()[kk].numpy(), v.numpy(), rtol=2e-4, atol=1e-5)
 
 
+def test_sphere_graph_cache(spgan_cpu, monkeypatch):
+    """EdgeConv1's kNN graph is rebuilt only when the sphere tensor object or its version changes."""
+    B, N = 2, 96
+    G = _load(spgan_cpu.modules.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=51)).train()
+    calls = []
+    real_knn = spgan_cpu.ops.knn
+    monkeypatch.setattr(spgan_cpu.ops, "knn", lambda x, B_, N_, k, mode=0: (calls.append(x.shape[1]), real_knn(x, B_, N_, k, mode))[1])
+    x = fr.synthetic_real(B, N, seed=52); z = fr.latent(B, N, seed=53)
+    o1 = G(x, z); o2 = G(x, z)
+    assert calls.count(3) == 1 and calls.count(64) == 2              # sphere graph once, feature graph every call
+    assert torch.equal(G.EdgeConv1.last_idx, G._sphere_graph["idx"])
+    x.mul_(1.0)                                                       # in-place write -> version bump -> rebuild
+    G(x, z)
+    assert calls.count(3) == 2
+    x2 = x.clone()                                                    # different tensor object -> rebuild
+    G(x2, z)
+    assert calls.count(3) == 3
+
+
 def test_generator_no_grad_and_eval(spgan_cpu):
     B, N = 2, 96
     p = fr.init_params(orc.generator_shapes(), salt=41)
