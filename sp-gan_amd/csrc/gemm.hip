@@ -1,21 +1,22 @@
-// Shared-MLP contractions on the CDNA4 matrix cores (v_mfma_f32_16x16x4_f32: f32 in, f32
-// accumulate, bit-exact fmaf chains).  Two kernels:
+// Shared-MLP contractions on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32
+// accumulate, bit-exact fmaf chains; 157.3 TFLOP/s peak).  Two kernels:
 //
 //   gemm_nt  Y[M,N] = epi( pro(A)[M,K] . W[N,K]^T )   forward 1x1 convs / linears and input-gradients
 //   gemm_tn  C[Na,Nb] = sum_m A[m,Na]^T . pro(B)[m,Nb] weight-gradients (deterministic split over m)
 //
-// Tiling (wave64, 4 waves / workgroup):
-//   gemm_nt: 128 x (32*TN) output tile, BK=32.  Each wave owns 64 x (16*TN) as 4 x TN MFMA tiles.
-//            LDS tiles are row-major [row][BK+4]: (BK+4)/4 is odd, so the ds_read_b64 fragment reads
-//            (16 rows x 2 k-pairs per half-wave) touch all 64 banks exactly once, and rows stay 16-byte
-//            aligned for ds_write_b128 staging.  One lane's b64 read supplies the k-operands of TWO
-//            consecutive MFMAs (any permutation of k inside a tile is legal as long as A and B agree).
-//   gemm_tn: both operands are staged [m][cols+16] exactly as they lie in memory (no transpose); a
-//            fragment read is lanes-along-columns b32, leading dimension == 16 (mod 32) keeps the two
-//            m-rows of a half-wave on disjoint banks.
+// Tiling (wave64, 4 waves / workgroup, 128-row output tiles):
+//   gemm_nt: 128 x BN tile, BK = 32; BN = 128 (waves 2x2, 2x2 MFMA tiles each), 64 (2x2 waves, 2x1 tiles)
+//            or 32 (4x1 waves, 1x1 tile).  LDS tiles are row-major [row][BK+2]: the leading dimension
+//            34 == 2 (mod 64) makes the 32 rows x one k-pair that a half-wave reads with ds_read_b64 land on
+//            64 distinct banks.  One lane's b64 read feeds the k-operands of TWO consecutive MFMAs (any
+//            permutation of k inside a tile is legal as long as A and B agree).  For long K the LDS tiles
+//            are double-buffered (one barrier per k-tile); the next tile's global loads always fly under
+//            the current tile's MFMAs.  Measured on MI355X (tools/exp): 104-117 TFLOP/s on the big shapes vs
+//            88-100 for the earlier 16x16x4 / single-buffer structure.
+//   gemm_tn: both operands are staged [m][cols] exactly as they lie in memory (no transpose); a fragment
+//            read is 32 lanes along the columns of one m-row (b32, conflict-free), double-buffered.
 //   Workgroup -> tile map is XCD-aware: the 8 XCDs each have a private L2 and block b lands on XCD b%8,
-//   so all N-tiles of one M-tile are given ids with the same (b % 8): the A rows they share are fetched
-//   into one L2 only.
+//   so all N-tiles of one M-tile get ids with the same (b % 8): the A rows they share are fetched into one L2.
 //
 // Fused prologues/epilogues (see spgan_hip.h): BatchNorm-apply + LeakyReLU on the operand load, the
 // EdgeBlock per-edge difference gather, bias / per-shape bias / activation, per-tile column statistics
@@ -23,11 +24,13 @@
 // column sums.
 #include "common.hpp"
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 namespace {
 
 constexpr int BM = 128;
 constexpr int BK = 32;
-constexpr int LDT = BK + 4;  // 36 floats: 16B-aligned rows, (LDT/4) odd -> conflict-free b64 fragment reads
+constexpr int LDT = BK + 2;  // 34
 
 struct Tile {
   int tm, tn;
@@ -72,10 +75,27 @@ __device__ __forceinline__ float4 mask_tail(float4 v, int k, int K) {
   return v;
 }
 
-template <int AMODE>
+// FAST: every operand pointer is 16-byte aligned, leading dimensions and K are multiples of 4 -> unconditional float4 loads
+// (no divergent scalar tail path; the loads of a k-tile issue back to back and stay in flight under the MFMAs).
+template <int AMODE, int FAST>
 __device__ __forceinline__ float4 load_a(const spgan_gemm_nt_args& p, int m, int k, bool vecA) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (m >= p.M || k >= p.K) return v;
+  if (FAST) {
+    const float4* A4 = reinterpret_cast<const float4*>(p.A + k);
+    if (AMODE == SPGAN_A_PLAIN) return A4[(size_t)m * (p.lda >> 2)];
+    const float4 sc = *reinterpret_cast<const float4*>(p.p_scale + k), sh = *reinterpret_cast<const float4*>(p.p_shift + k);
+    if (AMODE == SPGAN_A_AFFINE_LRELU) return affine_lrelu4(A4[(size_t)m * (p.lda >> 2)], sc, sh, p.p_slope);
+    const int i = m / p.e_k;
+    const int j = p.e_idx[m];
+    const float4 vj = A4[(size_t)j * (p.lda >> 2)], vi = A4[(size_t)i * (p.lda >> 2)];
+    const float4 eb = *reinterpret_cast<const float4*>(p.e_bias + k);
+    v.x = (vj.x - vi.x) + eb.x;
+    v.y = (vj.y - vi.y) + eb.y;
+    v.z = (vj.z - vi.z) + eb.z;
+    v.w = (vj.w - vi.w) + eb.w;
+    return affine_lrelu4(v, sc, sh, p.p_slope);
+  }
   if (AMODE == SPGAN_A_PLAIN) {
     return ld4(p.A + (size_t)m * p.lda + k, vecA, k, p.K);
   } else if (AMODE == SPGAN_A_AFFINE_LRELU) {
@@ -99,34 +119,52 @@ __device__ __forceinline__ float4 load_a(const spgan_gemm_nt_args& p, int m, int
   }
 }
 
-// Sum per-lane column partials over the 4 row groups of a wave (lanes l, l^16, l^32, l^48) and
-// over the two M-waves of the workgroup.  `red` is [2][BN] floats of LDS.
-template <int TN>
-__device__ __forceinline__ void col_reduce(float (&part)[TN], float* red, int wm, int wn, int lane) {
-  constexpr int BN = 32 * TN;
+__device__ __forceinline__ void st_row4(float* p, float4 v) {  // rows are 8-byte aligned (LDT even)
+  *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
+  *reinterpret_cast<float2*>(p + 2) = make_float2(v.z, v.w);
+}
+
+// Geometry of one workgroup: WGM x WGN waves, each owning TI x TJ MFMA tiles of 32x32.
+template <int CFG> struct Geo;
+template <> struct Geo<0> { static constexpr int WGM = 2, WGN = 2, TI = 2, TJ = 2; };  // BN = 128
+template <> struct Geo<1> { static constexpr int WGM = 2, WGN = 2, TI = 2, TJ = 1; };  // BN = 64
+template <> struct Geo<2> { static constexpr int WGM = 4, WGN = 1, TI = 1, TJ = 1; };  // BN = 32
+
+// Sum per-lane column partials over the two row halves of a wave (lanes l, l^32) and over the
+// WGM M-waves of the workgroup.  `red` is [WGM][BN] floats of LDS.
+template <int CFG>
+__device__ __forceinline__ void col_reduce(float (&part)[Geo<CFG>::TJ], float* red, int wm, int wn, int lane) {
+  using G = Geo<CFG>;
+  constexpr int BN = G::WGN * G::TJ * 32;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    float v = part[tn];
-    v += __shfl_xor(v, 16);
+  for (int j = 0; j < G::TJ; ++j) {
+    float v = part[j];
     v += __shfl_xor(v, 32);
-    if (lane < 16) red[wm * BN + wn * TN * 16 + tn * 16 + lane] = v;
+    if (lane < 32) red[wm * BN + (wn * G::TJ + j) * 32 + lane] = v;
   }
   __syncthreads();
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int c = wn * TN * 16 + tn * 16 + (lane & 15);
-    part[tn] = red[c] + red[BN + c];
+  for (int j = 0; j < G::TJ; ++j) {
+    const int c = (wn * G::TJ + j) * 32 + (lane & 31);
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < G::WGM; ++w) s += red[w * BN + c];
+    part[j] = s;
   }
   __syncthreads();
 }
 
-template <int AMODE, int EPI, int TN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const spgan_gemm_nt_args p) {
-  constexpr int BN = 32 * TN;
-  __shared__ __attribute__((aligned(16))) float smem[BM * LDT + BN * LDT + 2 * BN];
-  float* As = smem;
-  float* Bs = smem + BM * LDT;
-  float* red = Bs + BN * LDT;
+template <int AMODE, int EPI, int CFG, int DB, int FAST>
+__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_args p) {  // <= 168 VGPRs: 3 waves/SIMD
+  using G = Geo<CFG>;
+  constexpr int TI = G::TI, TJ = G::TJ;
+  constexpr int BN = G::WGN * TJ * 32;
+  constexpr int NB = DB + 1;
+  constexpr int BSLOT = BN / 32;  // float4 staging slots per thread for the weight tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [NB][BM*LDT]
+  float* Bs = smem + NB * BM * LDT;  // [NB][BN*LDT]
+  float* red = Bs + NB * BN * LDT;   // [WGM][BN]
 
   const int tilesN = (p.N + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
@@ -136,87 +174,102 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const spgan_gemm_nt_args p
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, lg = lane >> 4;
+  const int wm = wave / G::WGN, wn = wave % G::WGN;
+  const int l31 = lane & 31, lh = lane >> 5;
 
   const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
   const bool vecW = ((p.ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.W) & 15) == 0);
 
-  f32x4 acc[4][TN];
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[4], rb[TN];
+  float4 ra[4], rb[BSLOT];
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;  // staging slot: row (tid/8 + 32*i), k offset 4*(tid%8)
 
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = load_a<AMODE>(p, m0 + lrow + 32 * i, k0 + lc4, vecA);
+    for (int i = 0; i < 4; ++i) ra[i] = load_a<AMODE, FAST>(p, m0 + lrow + 32 * i, k0 + lc4, vecA);
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
+    for (int i = 0; i < BSLOT; ++i) {
       const int n = n0 + lrow + 32 * i, k = k0 + lc4;
-      rb[i] = (n < p.N && k < p.K) ? ld4(p.W + (size_t)n * p.ldw + k, vecW, k, p.K) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (FAST) rb[i] = (n < p.N && k < p.K) ? reinterpret_cast<const float4*>(p.W + k)[(size_t)n * (p.ldw >> 2)] : make_float4(0.f, 0.f, 0.f, 0.f);
+      else rb[i] = (n < p.N && k < p.K) ? ld4(p.W + (size_t)n * p.ldw + k, vecW, k, p.K) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto sstore = [&]() {
+  auto sstore = [&](int buf) {
+    float* a = As + buf * BM * LDT;
+    float* b = Bs + buf * BN * LDT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[(lrow + 32 * i) * LDT + lc4]) = ra[i];
+    for (int i = 0; i < 4; ++i) st_row4(&a[(lrow + 32 * i) * LDT + lc4], ra[i]);
 #pragma unroll
-    for (int i = 0; i < TN; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * LDT + lc4]) = rb[i];
+    for (int i = 0; i < BSLOT; ++i) st_row4(&b[(lrow + 32 * i) * LDT + lc4], rb[i]);
+  };
+  auto compute = [&](int buf) {
+    const float* a = As + buf * BM * LDT + (wm * TI * 32 + l31) * LDT + 2 * lh;
+    const float* b = Bs + buf * BN * LDT + (wn * TJ * 32 + l31) * LDT + 2 * lh;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      float2 af[TI], bf[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float2*>(a + i * 32 * LDT + kk * 4);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float2*>(b + j * 32 * LDT + kk * 4);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+    }
   };
 
   const int nk = (p.K + BK - 1) / BK;
   gload(0);
-  sstore();
+  sstore(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload((kt + 1) * BK);  // next tile's HBM loads fly under this tile's MFMAs
-#pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      float2 af[4], bf[TN];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        af[i] = *reinterpret_cast<const float2*>(&As[(wm * 64 + i * 16 + l15) * LDT + kk * 8 + 2 * lg]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const float2*>(&Bs[(wn * TN * 16 + j * 16 + l15) * LDT + kk * 8 + 2 * lg]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      sstore();
+    if (kt + 1 < nk) gload((kt + 1) * BK);  // next tile's HBM/L2 loads fly under this tile's MFMAs
+    if (DB) {
+      compute(kt & 1);
+      if (kt + 1 < nk) sstore((kt + 1) & 1);  // other buffer: its last readers passed the previous barrier
       __syncthreads();
+    } else {
+      compute(0);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        sstore(0);
+        __syncthreads();
+      }
     }
   }
 
   // ---------------------------------------------------------------- epilogue
-  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane&15, row = 4*(lane>>4) + reg.
-  const int rbase = m0 + wm * 64 + 4 * lg;
-  const int cbase = n0 + wn * TN * 16 + l15;
+  // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  const int rbase = m0 + wm * TI * 32 + 4 * lh;
+  const int cbase = n0 + wn * TJ * 32 + l31;
   const int rows_valid = min(BM, p.M - m0);
+#define ROW_OF(i, r) (rbase + (i) * 32 + ((r) & 3) + 8 * ((r) >> 2))
 
   if (EPI == SPGAN_EPI_LINEAR) {
-    float csum[TN];
+    float csum[TJ];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = cbase + j * 16;
+    for (int j = 0; j < TJ; ++j) {
+      const int col = cbase + j * 32;
       const bool cok = col < p.N;
       const float b = (cok && p.bias) ? p.bias[col] : 0.f;
       csum[j] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + i * 16 + r;
+        for (int r = 0; r < 16; ++r) {
+          const int row = ROW_OF(i, r);
           float v = acc[i][j][r] + b;
           if (p.rowbias && cok && row < p.M) v += p.rowbias[(size_t)(row / p.rows_per_group) * p.ld_rowbias + col];
           acc[i][j][r] = v;  // keep the pre-activation value for the statistics pass
@@ -231,26 +284,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const spgan_gemm_nt_args p
     }
     if (p.stats) {
       // per-tile (sum, centred M2): combined later with Chan's formula -> no E[x^2]-E[x]^2 cancellation
-      col_reduce<TN>(csum, red, wm, wn, lane);
-      float m2[TN];
+      col_reduce<CFG>(csum, red, wm, wn, lane);
+      float m2[TJ];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
+      for (int j = 0; j < TJ; ++j) {
         const float mean = csum[j] / (float)rows_valid;
         m2[j] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = rbase + i * 16 + r;
+          for (int r = 0; r < 16; ++r) {
             const float d = acc[i][j][r] - mean;
-            if (row < p.M) m2[j] = fmaf(d, d, m2[j]);
+            if (ROW_OF(i, r) < p.M) m2[j] = fmaf(d, d, m2[j]);
           }
       }
-      col_reduce<TN>(m2, red, wm, wn, lane);
-      if (wm == 0 && lg == 0) {
+      col_reduce<CFG>(m2, red, wm, wn, lane);
+      if (wm == 0 && lh == 0) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = cbase + j * 16;
+        for (int j = 0; j < TJ; ++j) {
+          const int col = cbase + j * 32;
           if (col < p.N) {
             float* o = p.stats + ((size_t)t.tm * p.N + col) * 2;
             o[0] = csum[j];
@@ -261,13 +313,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const spgan_gemm_nt_args p
     }
   } else if (EPI == SPGAN_EPI_MASK_OUT) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = cbase + j * 16;
+    for (int j = 0; j < TJ; ++j) {
+      const int col = cbase + j * 32;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + i * 16 + r;
+        for (int r = 0; r < 16; ++r) {
+          const int row = ROW_OF(i, r);
           if (col < p.N && row < p.M) {
             const float ref = p.ref[(size_t)row * p.ld_ref + col];
             p.Y[(size_t)row * p.ldy + col] = acc[i][j][r] * lrelu_mask(ref, p.b_slope);
@@ -275,10 +327,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const spgan_gemm_nt_args p
         }
     }
   } else {  // BNBWD / EDGE_BNBWD
-    float s0[TN], s1[TN];
+    float s0[TJ], s1[TJ];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = cbase + j * 16;
+    for (int j = 0; j < TJ; ++j) {
+      const int col = cbase + j * 32;
       const bool cok = col < p.N;
       const float sc = cok ? p.b_scale[col] : 0.f, sh = cok ? p.b_shift[col] : 0.f;
       const float mu = cok ? p.b_mean[col] : 0.f, inv = cok ? p.b_invstd[col] : 0.f;
@@ -286,10 +338,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const spgan_gemm_nt_args p
       s0[j] = 0.f;
       s1[j] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + i * 16 + r;
+        for (int r = 0; r < 16; ++r) {
+          const int row = ROW_OF(i, r);
           if (cok && row < p.M) {
             float y;
             if (EPI == SPGAN_EPI_EDGE_BNBWD) {
@@ -308,12 +360,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const spgan_gemm_nt_args p
         }
     }
     if (p.stats) {
-      col_reduce<TN>(s0, red, wm, wn, lane);
-      col_reduce<TN>(s1, red, wm, wn, lane);
-      if (wm == 0 && lg == 0) {
+      col_reduce<CFG>(s0, red, wm, wn, lane);
+      col_reduce<CFG>(s1, red, wm, wn, lane);
+      if (wm == 0 && lh == 0) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = cbase + j * 16;
+        for (int j = 0; j < TJ; ++j) {
+          const int col = cbase + j * 32;
           if (col < p.N) {
             float* o = p.stats + ((size_t)t.tm * p.N + col) * 2;
             o[0] = s0[j];
@@ -323,62 +375,93 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const spgan_gemm_nt_args p
       }
     }
   }
+#undef ROW_OF
 }
+
+template <int CFG, int DB>
+constexpr size_t nt_lds_bytes() {
+  return (size_t)((DB + 1) * (BM + Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * LDT + Geo<CFG>::WGM * Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * sizeof(float);
+}
+
+template <int AMODE, int EPI, int CFG, int DB, int FAST>
+void launch_nt_cfg(const spgan_gemm_nt_args& a, hipStream_t s) {
+  constexpr int BN = Geo<CFG>::WGN * Geo<CFG>::TJ * 32;
+  constexpr size_t lds = nt_lds_bytes<CFG, DB>();
+  static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int tm8 = cdiv(cdiv(a.M, BM), 8) * 8;
+  hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST>), dim3(tm8 * cdiv(a.N, BN)), dim3(256), lds, s, a);
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 template <int AMODE, int EPI>
 int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
-  const int tilesM = cdiv(a.M, BM);
-  const int tm8 = cdiv(tilesM, 8) * 8;
+  bool fast = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A) && al16(a.W);
+  if (AMODE != SPGAN_A_PLAIN) fast = fast && al16(a.p_scale) && al16(a.p_shift);
+  if (AMODE == SPGAN_A_EDGE) fast = fast && al16(a.e_bias);
   if (a.N > 64) {
-    hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, 4>), dim3(tm8 * cdiv(a.N, 128)), dim3(256), 0, s, a);
+    if (a.K >= 512) {  // long K: double-buffered LDS, one barrier per k-tile
+      if (fast) launch_nt_cfg<AMODE, EPI, 0, 1, 1>(a, s);
+      else launch_nt_cfg<AMODE, EPI, 0, 1, 0>(a, s);
+    } else {
+      if (fast) launch_nt_cfg<AMODE, EPI, 0, 0, 1>(a, s);
+      else launch_nt_cfg<AMODE, EPI, 0, 0, 0>(a, s);
+    }
   } else if (a.N > 32) {
-    hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, 2>), dim3(tm8 * cdiv(a.N, 64)), dim3(256), 0, s, a);
+    if (fast) launch_nt_cfg<AMODE, EPI, 1, 0, 1>(a, s);
+    else launch_nt_cfg<AMODE, EPI, 1, 0, 0>(a, s);
   } else {
-    hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, 1>), dim3(tm8 * cdiv(a.N, 32)), dim3(256), 0, s, a);
+    launch_nt_cfg<AMODE, EPI, 2, 0, 0>(a, s);
   }
   return spgan_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------ gemm_tn
-constexpr int TKM = 16;         // m-rows per staging step
-constexpr int TA = 128;         // output rows (columns of A) per workgroup
+constexpr int TKM = 16;  // m-rows per staging step
+constexpr int TA = 128;  // output rows (columns of A) per workgroup
+
+// Column-constant prologue parameters of this thread's staging slot (hoisted out of the m loop).
+struct ColPro {
+  float4 sc, sh, eb;
+};
 
 template <int BMODE>
-__device__ __forceinline__ float4 load_b_tn(const spgan_gemm_tn_args& p, int m, int c, bool vecB) {
+__device__ __forceinline__ float4 load_b_tn(const spgan_gemm_tn_args& p, int m, int c, bool vecB, const ColPro& cp) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (m >= p.M || c >= p.Nb) return v;
   if (BMODE == SPGAN_A_PLAIN) {
     return ld4(p.B + (size_t)m * p.ldb + c, vecB, c, p.Nb);
   } else if (BMODE == SPGAN_A_AFFINE_LRELU) {
     v = ld4(p.B + (size_t)m * p.ldb + c, vecB, c, p.Nb);
-    float4 sc = ld4(p.p_scale + c, false, c, p.Nb);
-    float4 sh = ld4(p.p_shift + c, false, c, p.Nb);
-    return mask_tail(affine_lrelu4(v, sc, sh, p.p_slope), c, p.Nb);
+    return mask_tail(affine_lrelu4(v, cp.sc, cp.sh, p.p_slope), c, p.Nb);
   } else {
     const int i = m / p.e_k;
     const int j = p.e_idx[m];
     float4 vj = ld4(p.B + (size_t)j * p.ldb + c, vecB, c, p.Nb);
     float4 vi = ld4(p.B + (size_t)i * p.ldb + c, vecB, c, p.Nb);
-    float4 eb = ld4(p.e_bias + c, false, c, p.Nb);
-    float4 sc = ld4(p.p_scale + c, false, c, p.Nb);
-    float4 sh = ld4(p.p_shift + c, false, c, p.Nb);
-    v.x = (vj.x - vi.x) + eb.x;
-    v.y = (vj.y - vi.y) + eb.y;
-    v.z = (vj.z - vi.z) + eb.z;
-    v.w = (vj.w - vi.w) + eb.w;
-    return mask_tail(affine_lrelu4(v, sc, sh, p.p_slope), c, p.Nb);
+    v.x = (vj.x - vi.x) + cp.eb.x;
+    v.y = (vj.y - vi.y) + cp.eb.y;
+    v.z = (vj.z - vi.z) + cp.eb.z;
+    v.w = (vj.w - vi.w) + cp.eb.w;
+    return mask_tail(affine_lrelu4(v, cp.sc, cp.sh, p.p_slope), c, p.Nb);
   }
 }
 
 // grid: (tilesA * tilesB, splits).  Each workgroup reduces `rows_per_split` m-rows into one
-// TA x (32*TN) partial tile written to ws[split][Na][Nb].
-template <int BMODE, int TN>
+// TA x TB partial tile written to ws[split][Na][Nb].  CFG as in gemm_nt: TB = 128 / 64 / 32.
+template <int BMODE, int CFG>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p, int rows_per_split) {
-  constexpr int TB = 32 * TN;
-  constexpr int LDA_ = TA + 16, LDB_ = TB + 16;
-  __shared__ __attribute__((aligned(16))) float smem[TKM * LDA_ + TKM * LDB_];
-  float* As = smem;
-  float* Bs = smem + TKM * LDA_;
+  using G = Geo<CFG>;
+  constexpr int TI = G::TI, TJ = G::TJ;
+  constexpr int TB = G::WGN * TJ * 32;
+  constexpr int LDA_ = TA, LDB_ = TB;  // fragment reads are 32 consecutive floats of one row: conflict-free as is
+  __shared__ __attribute__((aligned(16))) float smem[2 * TKM * (LDA_ + LDB_)];
+  float* As = smem;                   // [2][TKM*LDA_]
+  float* Bs = smem + 2 * TKM * LDA_;  // [2][TKM*LDB_]
 
   const int tilesB = (p.Nb + TB - 1) / TB;
   const int ta = blockIdx.x / tilesB, tb = blockIdx.x % tilesB;
@@ -388,20 +471,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
   const int mend = min(p.M, mbeg + rows_per_split);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;  // wave owns A-cols [wm*64, +64), B-cols [wn*16*TN, +16*TN)
-  const int l15 = lane & 15, lg = lane >> 4;
+  const int wm = wave / G::WGN, wn = wave % G::WGN;  // wave owns A-cols [wm*TI*32, +TI*32), B-cols [wn*TJ*32, +TJ*32)
+  const int l31 = lane & 31, lh = lane >> 5;
   const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
   const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
 
-  f32x4 acc[4][TN];
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging: A tile 16 x 128 floats = 512 float4 -> 2 per thread; B tile 16 x TB -> (TB/4*16)/256 per thread
+  // staging: A tile 16 x 128 floats = 512 float4 -> 2 per thread; B tile 16 x TB -> TB/64 per thread (TB=32: half the threads)
   constexpr int BSLOTS = (TKM * TB / 4 + 255) / 256;
   float4 ra[2], rb[BSLOTS];
+  ColPro cp[BSLOTS];
+#pragma unroll
+  for (int i = 0; i < BSLOTS; ++i) {
+    const int s = tid + 256 * i;
+    const int c = b0 + (s % (TB / 4)) * 4;
+    cp[i].sc = cp[i].sh = cp[i].eb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BMODE != SPGAN_A_PLAIN && c < p.Nb) {
+      cp[i].sc = ld4(p.p_scale + c, false, c, p.Nb);
+      cp[i].sh = ld4(p.p_shift + c, false, c, p.Nb);
+      if (BMODE == SPGAN_A_EDGE) cp[i].eb = ld4(p.e_bias + c, false, c, p.Nb);
+    }
+  }
   auto gload = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -414,59 +511,61 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
       const int s = tid + 256 * i;
       const int r = s / (TB / 4), c = (s % (TB / 4)) * 4;
       const int m = mb + r;
-      rb[i] = (r < TKM && m < mend) ? load_b_tn<BMODE>(p, m, b0 + c, vecB) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = (r < TKM && m < mend) ? load_b_tn<BMODE>(p, m, b0 + c, vecB, cp[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto sstore = [&]() {
+  auto sstore = [&](int buf) {
+    float* a = As + buf * TKM * LDA_;
+    float* b = Bs + buf * TKM * LDB_;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int s = tid + 256 * i, r = s >> 5, c = (s & 31) * 4;
-      *reinterpret_cast<float4*>(&As[r * LDA_ + c]) = ra[i];
+      *reinterpret_cast<float4*>(&a[r * LDA_ + c]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < BSLOTS; ++i) {
       const int s = tid + 256 * i;
       const int r = s / (TB / 4), c = (s % (TB / 4)) * 4;
-      if (r < TKM) *reinterpret_cast<float4*>(&Bs[r * LDB_ + c]) = rb[i];
+      if (r < TKM) *reinterpret_cast<float4*>(&b[r * LDB_ + c]) = rb[i];
     }
   };
 
   if (mbeg < mend) {
     gload(mbeg);
-    sstore();
+    sstore(0);
     __syncthreads();
-    for (int mb = mbeg; mb < mend; mb += TKM) {
+    int buf = 0;
+    for (int mb = mbeg; mb < mend; mb += TKM, buf ^= 1) {
       const bool more = mb + TKM < mend;
       if (more) gload(mb + TKM);
+      const float* a = As + buf * TKM * LDA_ + wm * TI * 32 + l31;
+      const float* b = Bs + buf * TKM * LDB_ + wn * TJ * 32 + l31;
 #pragma unroll
-      for (int kq = 0; kq < TKM / 4; ++kq) {
-        float af[4], bf[TN];
+      for (int kq = 0; kq < TKM / 2; ++kq) {  // MFMA k = 2 m-rows: lane half lh takes row 2*kq + lh
+        float af[TI], bf[TJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = As[(kq * 4 + lg) * LDA_ + wm * 64 + i * 16 + l15];
+        for (int i = 0; i < TI; ++i) af[i] = a[(kq * 2 + lh) * LDA_ + i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = Bs[(kq * 4 + lg) * LDB_ + wn * TN * 16 + j * 16 + l15];
+        for (int j = 0; j < TJ; ++j) bf[j] = b[(kq * 2 + lh) * LDB_ + j * 32];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
+      if (more) sstore(buf ^ 1);
       __syncthreads();
-      if (more) {
-        sstore();
-        __syncthreads();
-      }
     }
   }
   // partial tile -> ws[split][Na][Nb]   (D: row = A-col index, col = B-col index)
   float* out = p.ws + (size_t)split * p.Na * p.Nb;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = a0 + wm * 64 + i * 16 + 4 * lg + r;
-        const int col = b0 + wn * TN * 16 + j * 16 + l15;
+      for (int r = 0; r < 16; ++r) {
+        const int row = a0 + (wm * TI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = b0 + (wn * TJ + j) * 32 + l31;
         if (row < p.Na && col < p.Nb) out[(size_t)row * p.Nb + col] = acc[i][j][r];
       }
 }
@@ -497,10 +596,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+inline int tn_tb(int Nb) { return Nb > 64 ? 128 : (Nb > 32 ? 64 : 32); }
+
 // Split choice: about two workgroups per CU in total, at least 256 m-rows each.
 inline void tn_plan(int M, int Na, int Nb, int* splits, int* rows) {
-  const int TB = Nb > 64 ? 128 : (Nb > 32 ? 64 : 32);
-  const int tiles = cdiv(Na, TA) * cdiv(Nb, TB);
+  const int tiles = cdiv(Na, TA) * cdiv(Nb, tn_tb(Nb));
   int want = cdiv(512, tiles);
   int r = cdiv(M, want);
   if (r < 256) r = 256;
@@ -513,13 +613,11 @@ template <int BMODE>
 int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
   int splits, rows;
   tn_plan(a.M, a.Na, a.Nb, &splits, &rows);
-  if (a.Nb > 64) {
-    hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 4>), dim3(cdiv(a.Na, TA) * cdiv(a.Nb, 128), splits), dim3(256), 0, s, a, rows);
-  } else if (a.Nb > 32) {
-    hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 2>), dim3(cdiv(a.Na, TA) * cdiv(a.Nb, 64), splits), dim3(256), 0, s, a, rows);
-  } else {
-    hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 1>), dim3(cdiv(a.Na, TA) * cdiv(a.Nb, 32), splits), dim3(256), 0, s, a, rows);
-  }
+  const int TB = tn_tb(a.Nb);
+  const dim3 grid(cdiv(a.Na, TA) * cdiv(a.Nb, TB), splits);
+  if (TB == 128) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 0>), grid, dim3(256), 0, s, a, rows);
+  else if (TB == 64) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 1>), grid, dim3(256), 0, s, a, rows);
+  else hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 2>), grid, dim3(256), 0, s, a, rows);
   const int n = a.Na * a.Nb;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
   return spgan_launch_status();
@@ -530,7 +628,7 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
 extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   SPGAN_CHECK_ARG(a && a->A && a->W && a->Y && a->M > 0 && a->N > 0 && a->K > 0);
-  SPGAN_CHECK_ARG(a->lda >= (a->a_mode == SPGAN_A_EDGE ? a->K : a->K) && a->ldw >= a->K && a->ldy >= a->N);
+  SPGAN_CHECK_ARG(a->lda >= a->K && a->ldw >= a->K && a->ldy >= a->N);
   if (a->a_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
   if (a->a_mode == SPGAN_A_EDGE) SPGAN_CHECK_ARG(a->e_idx && a->e_bias && a->e_k > 0);
   if (a->rowbias) SPGAN_CHECK_ARG(a->rows_per_group > 0 && a->ld_rowbias >= a->N);
