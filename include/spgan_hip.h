@@ -106,6 +106,10 @@ typedef struct spgan_gemm_nt_args {
   const float* ref; int ld_ref;
   const float* b_scale; const float* b_shift; const float* b_mean; const float* b_invstd; float b_slope;
   const float* e_bias2;
+  /* Optional sparse addend of the A operand (A_AFFINE_LRELU only): a += sp_val[b,k] where sp_arg[b,k] == m, b = m / sp_rows.
+   * With p_slope = 1 this expresses the BatchNorm backward behind a global max-pool without materialising it:
+   *   dy[m,k] = alpha[k]*y[m,k] + beta[k] + (argmax[b,k]==m ? coef[k]*gval[b,k] : 0)   (Discriminator.py:77-81,104) */
+  const float* sp_val; const int32_t* sp_arg; int sp_rows;
 } spgan_gemm_nt_args;
 
 int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s);
@@ -122,6 +126,9 @@ typedef struct spgan_gemm_tn_args {
   const int32_t* e_idx; int e_k; const float* e_bias;
   float beta;
   float* ws; size_t ws_bytes; /* >= spgan_gemm_tn_ws_bytes(M,Na,Nb) */
+  /* Optional prologue on A (per column of A): a = A*a_scale[c] + a_shift[c] + (a_sp_arg[b,c]==m ? a_sp_val[b,c] : 0), b = m / a_sp_rows.
+   * a_scale == NULL: A is used as is. */
+  const float* a_scale; const float* a_shift; const float* a_sp_val; const int32_t* a_sp_arg; int a_sp_rows;
 } spgan_gemm_tn_args;
 
 size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb);

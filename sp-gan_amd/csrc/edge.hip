@@ -57,36 +57,34 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
   const int np = min(ES_PT, M - p0);
   const int CH = H + F;
   const float cnt = (float)(np * k);
+  // Single gather pass with shifted sums: d = v - v0 (v0 = the tile's first edge value of this channel), so
+  // M2 = sum d^2 - (sum d)^2/n is free of catastrophic cancellation (|d| is of the order of the std).
+  __shared__ float red2[4][64];
   for (int c0 = 0; c0 < CH; c0 += 64) {
     const int c = c0 + lane;
     const bool ok = c < CH;
     const float bias = ok ? (c < H ? b1[c] : bx[c - H]) : 0.f;
-    float s = 0.f;
-    if (ok)
-      for (int p = w; p < np; p += 4) {
-        const int i = p0 + p;
-        for (int r = 0; r < k; ++r) s += edge_pre(PQR, ld, H, F, c, i, idx[(size_t)i * k + r], bias);
-      }
-    red[w][lane] = s;
-    __syncthreads();
-    const float tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    const float mean = tot / cnt;
-    __syncthreads();
-    float m2 = 0.f;
-    if (ok)
+    float s1 = 0.f, s2 = 0.f, v0 = 0.f;
+    if (ok) {
+      v0 = edge_pre(PQR, ld, H, F, c, p0, idx[(size_t)p0 * k], bias);
       for (int p = w; p < np; p += 4) {
         const int i = p0 + p;
         for (int r = 0; r < k; ++r) {
-          const float d = edge_pre(PQR, ld, H, F, c, i, idx[(size_t)i * k + r], bias) - mean;
-          m2 = fmaf(d, d, m2);
+          const float d = edge_pre(PQR, ld, H, F, c, i, idx[(size_t)i * k + r], bias) - v0;
+          s1 += d;
+          s2 = fmaf(d, d, s2);
         }
       }
-    red[w][lane] = m2;
+    }
+    red[w][lane] = s1;
+    red2[w][lane] = s2;
     __syncthreads();
     if (w == 0 && ok) {
+      const float t1 = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+      const float t2 = (red2[0][lane] + red2[1][lane]) + (red2[2][lane] + red2[3][lane]);
       float* o = part + ((size_t)blockIdx.x * CH + c) * 2;
-      o[0] = tot;
-      o[1] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+      o[0] = fmaf(cnt, v0, t1);
+      o[1] = fmaxf(t2 - t1 * t1 / cnt, 0.f);
     }
     __syncthreads();
   }

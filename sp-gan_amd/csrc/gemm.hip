@@ -75,6 +75,14 @@ __device__ __forceinline__ float4 mask_tail(float4 v, int k, int K) {
   return v;
 }
 
+// v[q] += val[off+q] where arg[off+q] == m   (q < n valid elements): the sparse gradient behind a global max-pool
+__device__ __forceinline__ void sparse_add4(float4& v, const float* __restrict__ val, const int32_t* __restrict__ arg, size_t off, int m, int n) {
+  if (n > 0 && arg[off] == m) v.x += val[off];
+  if (n > 1 && arg[off + 1] == m) v.y += val[off + 1];
+  if (n > 2 && arg[off + 2] == m) v.z += val[off + 2];
+  if (n > 3 && arg[off + 3] == m) v.w += val[off + 3];
+}
+
 // FAST: every operand pointer is 16-byte aligned, leading dimensions and K are multiples of 4 -> unconditional float4 loads
 // (no divergent scalar tail path; the loads of a k-tile issue back to back and stay in flight under the MFMAs).
 template <int AMODE, int FAST>
@@ -85,7 +93,19 @@ __device__ __forceinline__ float4 load_a(const spgan_gemm_nt_args& p, int m, int
     const float4* A4 = reinterpret_cast<const float4*>(p.A + k);
     if (AMODE == SPGAN_A_PLAIN) return A4[(size_t)m * (p.lda >> 2)];
     const float4 sc = *reinterpret_cast<const float4*>(p.p_scale + k), sh = *reinterpret_cast<const float4*>(p.p_shift + k);
-    if (AMODE == SPGAN_A_AFFINE_LRELU) return affine_lrelu4(A4[(size_t)m * (p.lda >> 2)], sc, sh, p.p_slope);
+    if (AMODE == SPGAN_A_AFFINE_LRELU) {
+      v = affine_lrelu4(A4[(size_t)m * (p.lda >> 2)], sc, sh, p.p_slope);
+      if (p.sp_val) {  // K % 4 == 0 and torch-allocated [B,K] arrays: 16-byte aligned rows
+        const size_t off = (size_t)(m / p.sp_rows) * p.K + k;
+        const int4 ar = *reinterpret_cast<const int4*>(p.sp_arg + off);
+        const float4 va = *reinterpret_cast<const float4*>(p.sp_val + off);
+        v.x += (ar.x == m) ? va.x : 0.f;
+        v.y += (ar.y == m) ? va.y : 0.f;
+        v.z += (ar.z == m) ? va.z : 0.f;
+        v.w += (ar.w == m) ? va.w : 0.f;
+      }
+      return v;
+    }
     const int i = m / p.e_k;
     const int j = p.e_idx[m];
     const float4 vj = A4[(size_t)j * (p.lda >> 2)], vi = A4[(size_t)i * (p.lda >> 2)];
@@ -102,7 +122,9 @@ __device__ __forceinline__ float4 load_a(const spgan_gemm_nt_args& p, int m, int
     v = ld4(p.A + (size_t)m * p.lda + k, vecA, k, p.K);
     float4 sc = ld4(p.p_scale + k, false, k, p.K);
     float4 sh = ld4(p.p_shift + k, false, k, p.K);
-    return mask_tail(affine_lrelu4(v, sc, sh, p.p_slope), k, p.K);
+    v = mask_tail(affine_lrelu4(v, sc, sh, p.p_slope), k, p.K);
+    if (p.sp_val) sparse_add4(v, p.sp_val, p.sp_arg, (size_t)(m / p.sp_rows) * p.K + k, m, p.K - k);
+    return v;
   } else {  // SPGAN_A_EDGE
     const int i = m / p.e_k;
     const int j = p.e_idx[m];
@@ -403,6 +425,7 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   bool fast = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A) && al16(a.W);
   if (AMODE != SPGAN_A_PLAIN) fast = fast && al16(a.p_scale) && al16(a.p_shift);
   if (AMODE == SPGAN_A_EDGE) fast = fast && al16(a.e_bias);
+  if (a.sp_val) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
   if (a.N > 64) {
     if (a.K >= 512) {  // long K: double-buffered LDS, one barrier per k-tile
       if (fast) launch_nt_cfg<AMODE, EPI, 0, 1, 1>(a, s);
@@ -499,12 +522,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
       if (BMODE == SPGAN_A_EDGE) cp[i].eb = ld4(p.e_bias + c, false, c, p.Nb);
     }
   }
+  // optional A-side prologue (per column of A; the column of a staging slot is fixed -> parameters hoisted)
+  const bool apro = p.a_scale != nullptr;
+  float4 asc[2], ash[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int col = a0 + ((tid + 256 * i) & 31) * 4;
+    asc[i] = ash[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (apro && col < p.Na) {
+      asc[i] = ld4(p.a_scale + col, false, col, p.Na);
+      ash[i] = ld4(p.a_shift + col, false, col, p.Na);
+    }
+  }
   auto gload = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int s = tid + 256 * i, r = s >> 5, c = (s & 31) * 4;
       const int m = mb + r, col = a0 + c;
-      ra[i] = (m < mend && col < p.Na) ? ld4(p.A + (size_t)m * p.lda + col, vecA, col, p.Na) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = (m < mend && col < p.Na) ? ld4(p.A + (size_t)m * p.lda + col, vecA, col, p.Na) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (apro && m < mend && col < p.Na) {
+        v = mask_tail(affine_lrelu4(v, asc[i], ash[i], 1.0f), col, p.Na);
+        if (p.a_sp_val) sparse_add4(v, p.a_sp_val, p.a_sp_arg, (size_t)(m / p.a_sp_rows) * p.Na + col, m, p.Na - col);
+      }
+      ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < BSLOTS; ++i) {
@@ -632,6 +672,7 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   if (a->a_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
   if (a->a_mode == SPGAN_A_EDGE) SPGAN_CHECK_ARG(a->e_idx && a->e_bias && a->e_k > 0);
   if (a->rowbias) SPGAN_CHECK_ARG(a->rows_per_group > 0 && a->ld_rowbias >= a->N);
+  if (a->sp_val) SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_AFFINE_LRELU && a->sp_arg && a->sp_rows > 0);
   switch (a->epi_mode) {
     case SPGAN_EPI_LINEAR:
       if (a->a_mode == SPGAN_A_PLAIN) return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_LINEAR>(*a, s);
@@ -642,7 +683,8 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
       SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->ref && a->ld_ref >= a->N);
       return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_MASK_OUT>(*a, s);
     case SPGAN_EPI_BNBWD:
-      SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->ref && a->ld_ref >= a->N && a->b_scale && a->b_shift && a->b_mean && a->b_invstd);
+      SPGAN_CHECK_ARG(a->a_mode != SPGAN_A_EDGE && a->ref && a->ld_ref >= a->N && a->b_scale && a->b_shift && a->b_mean && a->b_invstd);
+      if (a->a_mode == SPGAN_A_AFFINE_LRELU) return launch_nt<SPGAN_A_AFFINE_LRELU, SPGAN_EPI_BNBWD>(*a, s);
       return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_BNBWD>(*a, s);
     case SPGAN_EPI_EDGE_BNBWD:
       SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->ref && a->ld_ref >= a->N && a->b_scale && a->b_shift && a->b_mean && a->b_invstd &&
@@ -666,6 +708,7 @@ extern "C" int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a->lda >= a->Na && a->ldb >= a->Nb && a->ldc >= a->Nb);
   SPGAN_CHECK_ARG(a->ws_bytes >= spgan_gemm_tn_ws_bytes(a->M, a->Na, a->Nb));
   if (a->b_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
+  if (a->a_scale) SPGAN_CHECK_ARG(a->a_shift && (!a->a_sp_val || (a->a_sp_arg && a->a_sp_rows > 0)));
   switch (a->b_mode) {
     case SPGAN_A_PLAIN: return launch_tn<SPGAN_A_PLAIN>(*a, s);
     case SPGAN_A_AFFINE_LRELU: return launch_tn<SPGAN_A_AFFINE_LRELU>(*a, s);

@@ -33,6 +33,7 @@ class GemmNTArgs(C.Structure):
         ("ref", c_f32p), ("ld_ref", C.c_int),
         ("b_scale", c_f32p), ("b_shift", c_f32p), ("b_mean", c_f32p), ("b_invstd", c_f32p), ("b_slope", C.c_float),
         ("e_bias2", c_f32p),
+        ("sp_val", c_f32p), ("sp_arg", c_i32p), ("sp_rows", C.c_int),
     ]
 
 
@@ -47,6 +48,7 @@ class GemmTNArgs(C.Structure):
         ("e_idx", c_i32p), ("e_k", C.c_int), ("e_bias", c_f32p),
         ("beta", C.c_float),
         ("ws", c_f32p), ("ws_bytes", C.c_size_t),
+        ("a_scale", c_f32p), ("a_shift", c_f32p), ("a_sp_val", c_f32p), ("a_sp_arg", c_i32p), ("a_sp_rows", C.c_int),
     ]
 
 

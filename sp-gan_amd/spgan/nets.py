@@ -105,9 +105,12 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
     C4 = gval.shape[1]
     if need_dparams:
         grads["fc2.1.weight"] = sums4[C4:].clone(); grads["fc2.1.bias"] = sums4[:C4].clone()
-    if not ctx["training"]:
+    if ctx["training"]:
+        # dense [M,1024] BatchNorm backward of a sparse gradient: never materialised, evaluated on the GEMM operand loads
+        dy = ops.sparse_bn_bwd_operand(gval, argmax, ys[3], N, mu4, inv4, P["fc2.1.weight"], sums4, M)
+    else:
         sums4 = torch.zeros_like(sums4)
-    dy = ops.bn_bwd_apply_sparse(gval, argmax, ys[3], N, mu4, inv4, P["fc2.1.weight"], sums4, M)
+        dy = ops.bn_bwd_apply_sparse(gval, argmax, ys[3], N, mu4, inv4, P["fc2.1.weight"], sums4, M)
     dys = [None, None, None, dy]
     gs = [None, None, None, None]
     sums_all = [None, None, None, sums4]

@@ -220,10 +220,34 @@ def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float) -> Tensor:
     return Y
 
 
-def gemm_nt_bnbwd(A: Tensor, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float,
+class SparseAffine:
+    """A lazily evaluated [M,C] operand  y*alpha[c] + beta[c] + (sp_arg[b,c] == m ? sp_val[b,c] : 0),  b = m // rows.
+    It stands for the BatchNorm backward behind D's global max-pool (dense, but a function of y and B*C numbers):
+    the GEMMs that consume it evaluate it on their operand load instead of reading a materialised [M,C] tensor."""
+
+    def __init__(self, y: Tensor, alpha: Tensor, beta: Tensor, sp_val: Tensor, sp_arg: Tensor, rows: int):
+        self.y, self.alpha, self.beta, self.sp_val, self.sp_arg, self.rows = y, alpha.contiguous(), beta.contiguous(), sp_val.contiguous(), sp_arg, rows
+        self.shape = y.shape
+        self.device = y.device
+
+
+def sparse_bn_bwd_operand(gval: Tensor, argmax: Tensor, y: Tensor, N: int, mean, invstd, gamma, sums, count: int) -> SparseAffine:
+    """The same quantity bn_bwd_apply_sparse materialises, as a lazy operand (O(C) + O(B*C) preparation only)."""
+    Cn = y.shape[1]
+    coef = gamma * invstd
+    alpha = -(coef * invstd) * (sums[Cn:] / count)
+    beta = -(coef * (sums[:Cn] / count)) - alpha * mean
+    return SparseAffine(y, alpha, beta, gval * coef, argmax, N)
+
+
+def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float,
                   edge=None):
     """g = (A @ W^T) * lrelu'(z), z = y*scale+shift; returns (g, sum_c g, sum_c g*xhat), xhat = (y-mean)*invstd.
-    With edge=(idx, ebias) y is the per-edge difference y[e] = P[idx[e]] - P[i] + ebias of the point tensor P=y_ref."""
+    With edge=(idx, ebias) y is the per-edge difference y[e] = P[idx[e]] - P[i] + ebias of the point tensor P=y_ref.
+    A may be a SparseAffine operand."""
+    sa = A if isinstance(A, SparseAffine) else None
+    if sa is not None:
+        A = sa.y
     _rowmajor2d(A, "A"); _rowmajor2d(W, "W"); _rowmajor2d(y_ref, "y_ref")
     N, K = W.shape
     M_ = A.shape[0]
@@ -234,6 +258,10 @@ def gemm_nt_bnbwd(A: Tensor, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Ten
     a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W); a.Y = _p(g); a.ldy = N
     a.M, a.N, a.K = M_, N, K
     a.a_mode = A_PLAIN
+    if sa is not None:
+        a.a_mode = A_AFFINE_LRELU
+        a.p_scale = _p(_vec(sa.alpha, K, "alpha")); a.p_shift = _p(_vec(sa.beta, K, "beta")); a.p_slope = 1.0
+        a.sp_val = _p(sa.sp_val); a.sp_arg = _p(_i32(sa.sp_arg, "sp_arg")); a.sp_rows = sa.rows
     a.ref = _p(y_ref); a.ld_ref = _ld(y_ref)
     a.b_scale = _p(_vec(scale, N, "scale")); a.b_shift = _p(_vec(shift, N, "shift"))
     a.b_mean = _p(_vec(mean, N, "mean")); a.b_invstd = _p(_vec(invstd, N, "invstd")); a.b_slope = float(slope)
@@ -250,11 +278,18 @@ def gemm_nt_bnbwd(A: Tensor, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Ten
 
 
 def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor] = None, beta: float = 0.0) -> Tensor:
-    """C[Na,Nb] = beta*C + A^T @ pro(Bm): weight gradient, reduction over the M rows (points or edges)."""
+    """C[Na,Nb] = beta*C + A^T @ pro(Bm): weight gradient, reduction over the M rows (points or edges).
+    A may be a SparseAffine operand (evaluated on load)."""
+    sa = A if isinstance(A, SparseAffine) else None
+    if sa is not None:
+        A = sa.y
     _rowmajor2d(A, "A"); _rowmajor2d(Bm, "B")
     M_, Na = A.shape
     Nb = Bm.shape[1]
     a = GemmTNArgs()
+    if sa is not None:
+        a.a_scale = _p(_vec(sa.alpha, Na, "alpha")); a.a_shift = _p(_vec(sa.beta, Na, "beta"))
+        a.a_sp_val = _p(sa.sp_val); a.a_sp_arg = _p(_i32(sa.sp_arg, "sp_arg")); a.a_sp_rows = sa.rows
     if edge is not None:
         idx, ebias = edge
         _i32(idx, "idx")

@@ -22,29 +22,31 @@ class FlatParams:
         if not params:
             raise ValueError("module has no parameters")
         dev = params[0].device
-        n = sum(p.numel() for p in params)
-        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        # every slice starts on a 16-byte boundary (float4 operand loads in the GEMM fast path); the padding
+        # elements stay zero in both buffers, so Adam and the all-reduce may run over the whole buffer.
+        self.offsets = []
+        n = 0
+        for p in params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.params = params
-        off = 0
         with torch.no_grad():
-            for p in params:
+            for p, off in zip(params, self.offsets):
                 k = p.numel()
                 self.flat[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat[off:off + k].view_as(p)
                 p.grad = self.grad[off:off + k].view_as(p)
-                off += k
         self.numel = n
 
     def zero_grad(self):
         """Zero in place and re-bind (autograd accumulates into the flat slices)."""
         self.grad.zero_()
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + k].view_as(p)
-            off += k
 
 
 def flatten_module(module: nn.Module) -> FlatParams:

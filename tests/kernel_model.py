@@ -119,7 +119,29 @@ def gemm_nt_maskout(A, W, ref, slope):
     return ((A @ W.t()) * torch.where(ref > 0, 1.0, slope)).contiguous()
 
 
+class SparseAffine:
+    def __init__(self, y, alpha, beta, sp_val, sp_arg, rows):
+        self.y, self.alpha, self.beta, self.sp_val, self.sp_arg, self.rows = y, alpha, beta, sp_val, sp_arg, rows
+        self.shape = y.shape
+        self.device = y.device
+
+
+def sparse_bn_bwd_operand(gval, argmax, y, N, mean, invstd, gamma, sums, count):
+    C = y.shape[1]
+    coef = gamma * invstd
+    alpha = -(coef * invstd) * (sums[C:] / count)
+    beta = -(coef * (sums[:C] / count)) - alpha * mean
+    return SparseAffine(y, alpha, beta, gval * coef, argmax, N)
+
+
+def _dense(A):
+    if isinstance(A, SparseAffine):
+        return A.y * A.alpha + A.beta + scatter_rows(A.sp_val, A.sp_arg, A.y.shape[0])
+    return A
+
+
 def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None):
+    A = _dense(A)
     N = W.shape[0]
     if edge is not None:
         idx, ebias = edge
@@ -135,6 +157,7 @@ def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None):
 
 
 def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0):
+    A = _dense(A)
     b = _operand(Bm, pro, edge, Bm.shape[1])
     c = A.t() @ b
     if out is None:

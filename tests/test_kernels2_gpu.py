@@ -96,6 +96,33 @@ def test_pool_bn_backward(ops):
     assert torch.equal(ops.gather_rows(y, arg), km.gather_rows(y, arg))
 
 
+def test_sparse_affine_operand(ops):
+    """The lazily evaluated BatchNorm-backward operand inside gemm_tn / gemm_nt_bnbwd == the materialised one."""
+    B, N, C, Cp = 4, 160, 200, 72
+    M = B * N
+    y = rnd("sa.y", (M, C)) * 2
+    mean, var = km.colstats(y, M)
+    gamma, beta = rnd("sa.g", (C,)).abs() + 0.5, rnd("sa.b", (C,), 0.2)
+    sc, sh, inv, mu = km.bn_prepare(mean[0], var[0], gamma, beta, M)
+    pooled, arg = km.maxpool(y, B, N, sc, sh, 0.01)
+    gval, sums = km.pool_bwd_stats(rnd("sa.gp", (B, C)), pooled, arg, y, mu, inv, 0.01)
+    dense = km.bn_bwd_apply_sparse(gval, arg, y, N, mu, inv, gamma, sums, M)
+    sa = ops.sparse_bn_bwd_operand(gval, arg, y, N, mu, inv, gamma, sums, M)
+    Bm = rnd("sa.B", (M, Cp))
+    psc, psh = rnd("sa.psc", (Cp,)).abs() + 0.5, rnd("sa.psh", (Cp,), 0.3)
+    close(ops.gemm_tn(sa, Bm, pro=(psc, psh, 0.01)), km.gemm_tn(dense, Bm, pro=(psc, psh, 0.01)), rtol=5e-5, what="tn.sparse_affine")
+    W = rnd("sa.W", (Cp, C), 0.2)
+    yref = rnd("sa.yref", (M, Cp))
+    m2, i2 = rnd("sa.m2", (Cp,), 0.2), rnd("sa.i2", (Cp,)).abs() + 0.5
+    for a, b in zip(ops.gemm_nt_bnbwd(sa, W, yref, psc, psh, m2, i2, 0.01), km.gemm_nt_bnbwd(dense, W, yref, psc, psh, m2, i2, 0.01)):
+        close(a, b, rtol=5e-5, atol=2e-4, what="nt_bnbwd.sparse_affine")
+    # aligned fast path (C % 4 == 0) and the generic path (odd leading dimension) agree
+    y2 = y[:, :197].contiguous()
+    sa2 = ops.SparseAffine(y2, sa.alpha[:197].contiguous(), sa.beta[:197].contiguous(), sa.sp_val[:, :197].contiguous(), arg[:, :197].contiguous(), N)
+    d2 = dense[:, :197].contiguous()
+    close(ops.gemm_tn(sa2, Bm), km.gemm_tn(d2, Bm), rtol=5e-5, what="tn.sparse_affine.unaligned")
+
+
 def test_double_backward_helpers(ops):
     M, C = 700, 96
     u, y, gz = rnd("db.u", (M, C)), rnd("db.y", (M, C)) * 2, rnd("db.gz", (M, C))
