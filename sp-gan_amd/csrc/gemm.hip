@@ -75,6 +75,14 @@ __device__ __forceinline__ float4 mask_tail(float4 v, int k, int K) {
   return v;
 }
 
+// m / d for 0 <= m < 2^24 without the ~40-instruction integer division (float estimate + one fix-up each way)
+__device__ __forceinline__ int fast_div(int m, int d) {
+  int q = (int)((float)m * (1.0f / (float)d));
+  q -= (q * d > m) ? 1 : 0;
+  q += ((q + 1) * d <= m) ? 1 : 0;
+  return q;
+}
+
 // v[q] += val[off+q] where arg[off+q] == m   (q < n valid elements): the sparse gradient behind a global max-pool
 __device__ __forceinline__ void sparse_add4(float4& v, const float* __restrict__ val, const int32_t* __restrict__ arg, size_t off, int m, int n) {
   if (n > 0 && arg[off] == m) v.x += val[off];
@@ -93,20 +101,8 @@ __device__ __forceinline__ float4 load_a(const spgan_gemm_nt_args& p, int m, int
     const float4* A4 = reinterpret_cast<const float4*>(p.A + k);
     if (AMODE == SPGAN_A_PLAIN) return A4[(size_t)m * (p.lda >> 2)];
     const float4 sc = *reinterpret_cast<const float4*>(p.p_scale + k), sh = *reinterpret_cast<const float4*>(p.p_shift + k);
-    if (AMODE == SPGAN_A_AFFINE_LRELU) {
-      v = affine_lrelu4(A4[(size_t)m * (p.lda >> 2)], sc, sh, p.p_slope);
-      if (p.sp_val) {  // K % 4 == 0 and torch-allocated [B,K] arrays: 16-byte aligned rows
-        const size_t off = (size_t)(m / p.sp_rows) * p.K + k;
-        const int4 ar = *reinterpret_cast<const int4*>(p.sp_arg + off);
-        const float4 va = *reinterpret_cast<const float4*>(p.sp_val + off);
-        v.x += (ar.x == m) ? va.x : 0.f;
-        v.y += (ar.y == m) ? va.y : 0.f;
-        v.z += (ar.z == m) ? va.z : 0.f;
-        v.w += (ar.w == m) ? va.w : 0.f;
-      }
-      return v;
-    }
-    const int i = m / p.e_k;
+    if (AMODE == SPGAN_A_AFFINE_LRELU) return affine_lrelu4(A4[(size_t)m * (p.lda >> 2)], sc, sh, p.p_slope);
+    const int i = fast_div(m, p.e_k);
     const int j = p.e_idx[m];
     const float4 vj = A4[(size_t)j * (p.lda >> 2)], vi = A4[(size_t)i * (p.lda >> 2)];
     const float4 eb = *reinterpret_cast<const float4*>(p.e_bias + k);
@@ -122,11 +118,9 @@ __device__ __forceinline__ float4 load_a(const spgan_gemm_nt_args& p, int m, int
     v = ld4(p.A + (size_t)m * p.lda + k, vecA, k, p.K);
     float4 sc = ld4(p.p_scale + k, false, k, p.K);
     float4 sh = ld4(p.p_shift + k, false, k, p.K);
-    v = mask_tail(affine_lrelu4(v, sc, sh, p.p_slope), k, p.K);
-    if (p.sp_val) sparse_add4(v, p.sp_val, p.sp_arg, (size_t)(m / p.sp_rows) * p.K + k, m, p.K - k);
-    return v;
+    return mask_tail(affine_lrelu4(v, sc, sh, p.p_slope), k, p.K);
   } else {  // SPGAN_A_EDGE
-    const int i = m / p.e_k;
+    const int i = fast_div(m, p.e_k);
     const int j = p.e_idx[m];
     float4 vj = ld4(p.A + (size_t)j * p.lda + k, vecA, k, p.K);
     float4 vi = ld4(p.A + (size_t)i * p.lda + k, vecA, k, p.K);
@@ -252,22 +246,49 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
     }
   };
 
+  // Sparse addend of the A operand (sp_val/sp_arg): per column k at most one row of a shape carries it, so it is
+  // patched into the staged LDS tile by BK threads per k-tile instead of being tested on every operand load.
+  const bool sparse = (AMODE == SPGAN_A_AFFINE_LRELU) && p.sp_val != nullptr;
+  auto sfix = [&](int buf, int k0) {
+    if (tid < BK && k0 + tid < p.K) {
+      float* a = As + buf * BM * LDT;
+      const int b_lo = fast_div(m0, p.sp_rows), b_hi = fast_div(min(m0 + BM, p.M) - 1, p.sp_rows);
+      for (int b = b_lo; b <= b_hi; ++b) {
+        const size_t off = (size_t)b * p.K + k0 + tid;
+        const int r = p.sp_arg[off] - m0;
+        if (r >= 0 && r < BM) a[r * LDT + tid] += p.sp_val[off];
+      }
+    }
+  };
+
   const int nk = (p.K + BK - 1) / BK;
   gload(0);
   sstore(0);
   __syncthreads();
+  if (sparse) {
+    sfix(0, 0);
+    __syncthreads();
+  }
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) gload((kt + 1) * BK);  // next tile's HBM/L2 loads fly under this tile's MFMAs
     if (DB) {
       compute(kt & 1);
       if (kt + 1 < nk) sstore((kt + 1) & 1);  // other buffer: its last readers passed the previous barrier
       __syncthreads();
+      if (sparse && kt + 1 < nk) {
+        sfix((kt + 1) & 1, (kt + 1) * BK);
+        __syncthreads();
+      }
     } else {
       compute(0);
       __syncthreads();
       if (kt + 1 < nk) {
         sstore(0);
         __syncthreads();
+        if (sparse) {
+          sfix(0, (kt + 1) * BK);
+          __syncthreads();
+        }
       }
     }
   }
@@ -293,7 +314,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
         for (int r = 0; r < 16; ++r) {
           const int row = ROW_OF(i, r);
           float v = acc[i][j][r] + b;
-          if (p.rowbias && cok && row < p.M) v += p.rowbias[(size_t)(row / p.rows_per_group) * p.ld_rowbias + col];
+          if (p.rowbias && cok && row < p.M) v += p.rowbias[(size_t)fast_div(row, p.rows_per_group) * p.ld_rowbias + col];
           acc[i][j][r] = v;  // keep the pre-activation value for the statistics pass
           if (row < p.M) csum[j] += v;
           if (cok && row < p.M) {
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           if (cok && row < p.M) {
             float y;
             if (EPI == SPGAN_EPI_EDGE_BNBWD) {
-              const int pi = row / p.e_k, pj = p.e_idx[row];
+              const int pi = fast_div(row, p.e_k), pj = p.e_idx[row];
               y = (p.ref[(size_t)pj * p.ld_ref + col] - p.ref[(size_t)pi * p.ld_ref + col]) + eb;
             } else {
               y = p.ref[(size_t)row * p.ld_ref + col];
@@ -462,7 +483,7 @@ __device__ __forceinline__ float4 load_b_tn(const spgan_gemm_tn_args& p, int m, 
     v = ld4(p.B + (size_t)m * p.ldb + c, vecB, c, p.Nb);
     return mask_tail(affine_lrelu4(v, cp.sc, cp.sh, p.p_slope), c, p.Nb);
   } else {
-    const int i = m / p.e_k;
+    const int i = fast_div(m, p.e_k);
     const int j = p.e_idx[m];
     float4 vj = ld4(p.B + (size_t)j * p.ldb + c, vecB, c, p.Nb);
     float4 vi = ld4(p.B + (size_t)i * p.ldb + c, vecB, c, p.Nb);
@@ -540,10 +561,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
       const int s = tid + 256 * i, r = s >> 5, c = (s & 31) * 4;
       const int m = mb + r, col = a0 + c;
       float4 v = (m < mend && col < p.Na) ? ld4(p.A + (size_t)m * p.lda + col, vecA, col, p.Na) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (apro && m < mend && col < p.Na) {
-        v = mask_tail(affine_lrelu4(v, asc[i], ash[i], 1.0f), col, p.Na);
-        if (p.a_sp_val) sparse_add4(v, p.a_sp_val, p.a_sp_arg, (size_t)(m / p.a_sp_rows) * p.Na + col, m, p.Na - col);
-      }
+      if (apro && m < mend && col < p.Na) v = mask_tail(affine_lrelu4(v, asc[i], ash[i], 1.0f), col, p.Na);
       ra[i] = v;
     }
 #pragma unroll
@@ -608,6 +626,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
         const int col = b0 + (wn * TJ + j) * 32 + l31;
         if (row < p.Na && col < p.Nb) out[(size_t)row * p.Nb + col] = acc[i][j][r];
       }
+  // Sparse addend of A (a_sp_val/a_sp_arg): each (shape b, A-column a) contributes val * pro(B)[arg[b,a], :] to output
+  // row a -- a handful of rank-1 updates per workgroup, applied to its own partial tile after the dense part.
+  if (p.a_sp_val && mbeg < mend) {
+    __syncthreads();  // the partial tile written above is visible to the whole workgroup
+    const int b_lo = fast_div(mbeg, p.a_sp_rows), b_hi = fast_div(mend - 1, p.a_sp_rows);
+    const int col = b0 + (tid & (TB - 1));
+    const bool cok = col < p.Nb;
+    float sc = 1.f, sh = 0.f;
+    if (BMODE == SPGAN_A_AFFINE_LRELU && cok) { sc = p.p_scale[col]; sh = p.p_shift[col]; }
+    for (int ac = tid / TB; ac < TA; ac += 256 / TB) {
+      const int arow = a0 + ac;
+      if (arow >= p.Na || !cok) continue;
+      float add = 0.f;
+      for (int b = b_lo; b <= b_hi; ++b) {
+        const int r = p.a_sp_arg[(size_t)b * p.Na + arow];
+        if (r >= mbeg && r < mend) {
+          float bv = p.B[(size_t)r * p.ldb + col];
+          if (BMODE == SPGAN_A_AFFINE_LRELU) bv = lrelu_f(fmaf(bv, sc, sh), p.p_slope);
+          add = fmaf(p.a_sp_val[(size_t)b * p.Na + arow], bv, add);
+        }
+      }
+      if (add != 0.f) out[(size_t)arow * p.Nb + col] += add;
+    }
+  }
 }
 
 // Fixed-order sum over the split partials: 64 consecutive outputs x 4 split-slices per workgroup.
@@ -708,7 +750,8 @@ extern "C" int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a->lda >= a->Na && a->ldb >= a->Nb && a->ldc >= a->Nb);
   SPGAN_CHECK_ARG(a->ws_bytes >= spgan_gemm_tn_ws_bytes(a->M, a->Na, a->Nb));
   if (a->b_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
-  if (a->a_scale) SPGAN_CHECK_ARG(a->a_shift && (!a->a_sp_val || (a->a_sp_arg && a->a_sp_rows > 0)));
+  if (a->a_scale) SPGAN_CHECK_ARG(a->a_shift && (!a->a_sp_val || (a->a_sp_arg && a->a_sp_rows > 0 && a->b_mode != SPGAN_A_EDGE)));
+  SPGAN_CHECK_ARG(a->M < (1 << 24));  // fast_div domain
   switch (a->b_mode) {
     case SPGAN_A_PLAIN: return launch_tn<SPGAN_A_PLAIN>(*a, s);
     case SPGAN_A_AFFINE_LRELU: return launch_tn<SPGAN_A_AFFINE_LRELU>(*a, s);
