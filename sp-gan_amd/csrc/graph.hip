@@ -13,14 +13,16 @@ namespace {
 // KP = k+1 rounded up to a compiled capacity; CP = feature count padded to a compiled capacity
 // (zero padding leaves every fmaf chain bit-identical).  One query per lane, held in registers;
 // candidates are staged in LDS tiles of TC points and read as wave-wide broadcasts.
+constexpr int KNN_T = 256;  // queries (threads) per workgroup (128 measured slower on MI355X: 1.22 vs 1.00 ms at C=64, B*N=65536)
+
 template <int KP, int CP>
-__global__ __launch_bounds__(256) void knn_f32_kernel(const float* __restrict__ x, int N, int C, int k,
-                                                      int32_t* __restrict__ idx) {
+__global__ __launch_bounds__(KNN_T) void knn_f32_kernel(const float* __restrict__ x, int N, int C, int k,
+                                                        int32_t* __restrict__ idx) {
   constexpr int TC = 64;
   __shared__ __attribute__((aligned(16))) float cand[TC * CP];
   __shared__ float cnorm[TC];
   const int b = blockIdx.y;
-  const int q = blockIdx.x * 256 + threadIdx.x;  // query within the shape
+  const int q = blockIdx.x * KNN_T + threadIdx.x;  // query within the shape
   const float* xb = x + (size_t)b * N * C;
   const bool qok = q < N;
 
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void knn_f32_kernel(const float* __restrict__ 
   for (int c0 = 0; c0 < N; c0 += TC) {
     const int nc = min(TC, N - c0);
     __syncthreads();
-    for (int e = threadIdx.x; e < TC * CP; e += 256) {
+    for (int e = threadIdx.x; e < TC * CP; e += KNN_T) {
       const int j = e / CP, c = e % CP;
       cand[e] = (j < nc && c < C) ? xb[(size_t)(c0 + j) * C + c] : 0.f;
     }
@@ -57,15 +59,17 @@ __global__ __launch_bounds__(256) void knn_f32_kernel(const float* __restrict__ 
     if (!qok) continue;
     for (int j = 0; j < nc; ++j) {
       const float4* v = reinterpret_cast<const float4*>(cand + j * CP);
-      float dot = 0.f;
+      // four independent fmaf chains (channels c%4): a single chain is latency-bound at 64-128 dependent FMAs
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
       for (int c = 0; c < CP / 4; ++c) {
         const float4 a = v[c];
-        dot = fmaf(xq[4 * c], a.x, dot);
-        dot = fmaf(xq[4 * c + 1], a.y, dot);
-        dot = fmaf(xq[4 * c + 2], a.z, dot);
-        dot = fmaf(xq[4 * c + 3], a.w, dot);
+        d0 = fmaf(xq[4 * c], a.x, d0);
+        d1 = fmaf(xq[4 * c + 1], a.y, d1);
+        d2 = fmaf(xq[4 * c + 2], a.z, d2);
+        d3 = fmaf(xq[4 * c + 3], a.w, d3);
       }
+      const float dot = (d0 + d1) + (d2 + d3);
       // modules.py:699: dist = (-2*inner + |x_i|^2) + |x_j|^2
       const float d = (-2.f * dot + qn) + cnorm[j];
       if (d < bd[KP - 1]) {
@@ -154,6 +158,8 @@ int launch_knn(const float* x, int B, int N, int C, int k, int mode, int32_t* id
       default: return SPGAN_EINVAL;
     }
   } else {
+    grid = dim3(cdiv(N, KNN_T), B);
+    block = dim3(KNN_T);
     if (C <= 8) hipLaunchKernelGGL((knn_f32_kernel<KP, 8>), grid, block, 0, s, x, N, C, k, idx);
     else if (C <= 16) hipLaunchKernelGGL((knn_f32_kernel<KP, 16>), grid, block, 0, s, x, N, C, k, idx);
     else if (C <= 32) hipLaunchKernelGGL((knn_f32_kernel<KP, 32>), grid, block, 0, s, x, N, C, k, idx);
