@@ -58,6 +58,16 @@ def make_inputs(dev, rank, b):
     return x, real, zs, alpha
 
 
+def _pmc_traffic():
+    """HBM bytes per launch of the same kernel/shape from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+    gfx950 correction, + WRITE_SIZE); PMC counters cannot be sampled from inside this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_nt.json")) as f:
+            return json.load(f)["kernels"]["gemm_nt conv_out M=65536 N=128 K=1280"]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
+
+
 def gemm_roofline(dev):
     """Dominant kernel = gemm_nt (all forward/dgrad contractions).  Time its largest instance of the step,
     conv_out of EdgeConv2 (M = B*N, N = 128, K = 1280), with HIP events on the launch stream."""
@@ -79,7 +89,7 @@ def gemm_roofline(dev):
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "gemm_nt_kernel<plain,linear,TN=4> (EdgeConv2.conv_out, M=%d N=%d K=%d)" % (M, Nn, K),
             "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
-            "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "traffic": None}
+            "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "traffic": _pmc_traffic()}
 
 
 def cpu_baseline(budget_s=25.0):
