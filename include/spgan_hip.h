@@ -259,6 +259,25 @@ int spgan_lerp_rows(const float* real, const float* fake, const float* alpha, in
 int spgan_gp_penalty_fwd(const float* g, int B, size_t L, float gamma, float lambda, float* norms, float* loss, spgan_stream_t s);
 int spgan_gp_penalty_bwd(const float* g, const float* norms, int B, size_t L, float gamma, float lambda, const float* upstream,
                          float* v, spgan_stream_t s);
+/* ------------------------------------------------------------------------------------------
+ * Ball-query / grouping family (Common/pointnet_util.py, Common/pointconv_util.py; orphans in the reference,
+ * named by the north star).  xyz/new_xyz/points are [B,N,C] row-major like the reference; indices are int64.
+ * ---------------------------------------------------------------------------------------- */
+/* out[b,n,m] = -2<src_n,dst_m> + |src_n|^2 + |dst_m|^2            pointnet_util.py:19-40 */
+int spgan_square_distance(const float* src, const float* dst, int B, int N, int M, int C, float* out, spgan_stream_t s);
+/* out[b,s,:] = points[b, idx[b,s], :]  (idx [B,S] or [B,S,K] flattened to S*K)   pointnet_util.py:43-60 */
+int spgan_index_points(const float* points, const int64_t* idx, int B, int N, int C, int S, float* out, spgan_stream_t s);
+/* iterative farthest point sampling from start[b] (NULL: 0); dist_ws: B*N floats   pointnet_util.py:63-84, pointconv_util.py:60-83 */
+int spgan_farthest_point_sample(const float* xyz, int B, int N, int npoint, const int64_t* start, int64_t* out, float* dist_ws,
+                                spgan_stream_t s);
+/* first nsample indices (ascending) with d^2 <= r^2, padded with the first hit     pointnet_util.py:87-107 */
+int spgan_query_ball_point(float radius, int nsample, const float* xyz, const float* new_xyz, int B, int N, int S, int C,
+                           int64_t* out, spgan_stream_t s);
+/* nsample nearest (self included), ascending (distance, index)                      pointconv_util.py:107-118 */
+int spgan_knn_point(int nsample, const float* xyz, const float* new_xyz, int B, int N, int S, int C, int64_t* out, spgan_stream_t s);
+/* out[b,s,j,:] = [xyz[b,idx] - center[b,s] | feat[b,idx]]   pointnet_util.py:127-139, pointconv_util.py:186-195 */
+int spgan_group_concat(const float* xyz, const float* center, const float* feat, const int64_t* idx, int B, int N, int S, int K,
+                       int C, int D, float* out, spgan_stream_t s);
 /* out[m,c] = a[m,c] + gamma[c]*b[m,c] */
 int spgan_col_scale_add(const float* a, const float* b, const float* gamma, int M, int C, float* out, spgan_stream_t s);
 /* y = a*x + b*y */

@@ -102,6 +102,12 @@ SIGNATURES = {
     "spgan_lerp_rows": (I, [P, P, P, I, SZ, P, P]),
     "spgan_gp_penalty_fwd": (I, [P, I, SZ, F, F, P, P, P]),
     "spgan_gp_penalty_bwd": (I, [P, P, I, SZ, F, F, P, P, P]),
+    "spgan_square_distance": (I, [P, P, I, I, I, I, P, P]),
+    "spgan_index_points": (I, [P, P, I, I, I, I, P, P]),
+    "spgan_farthest_point_sample": (I, [P, I, I, I, P, P, P, P]),
+    "spgan_query_ball_point": (I, [F, I, P, P, I, I, I, I, P, P]),
+    "spgan_knn_point": (I, [I, P, P, I, I, I, I, P, P]),
+    "spgan_group_concat": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
     "spgan_axpby": (I, [F, P, F, P, SZ, P]),
     "spgan_adam_step": (I, [P, P, P, P, SZ, F, F, F, F, I, F, P]),
 }

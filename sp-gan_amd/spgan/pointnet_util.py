@@ -1,0 +1,116 @@
+"""Drop-in for the ball-query / grouping helpers of the reference
+(Common/pointnet_util.py:19-143, Common/pointconv_util.py:60-197): same names, argument order and return
+shapes/dtypes; HIP kernels underneath (libspgan_hip.so), GPU tensors only, forward only (index ops).
+
+    square_distance(src, dst)                          [B,N,C],[B,M,C] -> [B,N,M]
+    index_points(points, idx)                          [B,N,C],[B,S(,K)] -> [B,S(,K),C]
+    farthest_point_sample(xyz, npoint, start=None)     -> int64 [B,npoint]   (start=None: random, like pointnet_util;
+                                                          start=0-tensor: pointconv_util's variant)
+    query_ball_point(radius, nsample, xyz, new_xyz)    -> int64 [B,S,nsample]
+    knn_point(nsample, xyz, new_xyz)                   -> int64 [B,S,nsample]  (ascending; the reference's order is unspecified)
+    group(nsample, xyz, points)                        -> (new_points [B,N,K,C+D], grouped_xyz_norm [B,N,K,C])
+    sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, start=None)
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import _f32, _p, _s
+
+Tensor = torch.Tensor
+
+
+def _xyz(t: Tensor, name: str) -> Tensor:
+    _f32(t, name, 3)
+    return t.contiguous()
+
+
+def square_distance(src: Tensor, dst: Tensor) -> Tensor:
+    src, dst = _xyz(src, "src"), _xyz(dst, "dst")
+    B, N, C = src.shape
+    M = dst.shape[1]
+    out = torch.empty((B, N, M), dtype=torch.float32, device=src.device)
+    check(_lib.load().spgan_square_distance(_p(src), _p(dst), B, N, M, C, _p(out), _s()), "square_distance", B=B, N=N, M=M, C=C)
+    return out
+
+
+def index_points(points: Tensor, idx: Tensor) -> Tensor:
+    points = _xyz(points, "points")
+    if idx.dtype != torch.int64 or not idx.is_cuda:
+        raise TypeError("idx must be an int64 GPU tensor")
+    idx = idx.contiguous()
+    B, N, C = points.shape
+    S = idx.numel() // B
+    out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=points.device)
+    check(_lib.load().spgan_index_points(_p(points), _p(idx), B, N, C, S, _p(out), _s()), "index_points", B=B, N=N, C=C, S=S)
+    return out
+
+
+def farthest_point_sample(xyz: Tensor, npoint: int, start: Optional[Tensor] = None) -> Tensor:
+    xyz = _xyz(xyz, "xyz")
+    B, N, C = xyz.shape
+    if C != 3:
+        raise ValueError("farthest_point_sample expects xyz [B,N,3]")
+    if start is None:
+        start = torch.randint(0, N, (B,), dtype=torch.long, device=xyz.device)        # pointnet_util.py:75
+    start = start.to(device=xyz.device, dtype=torch.long).contiguous()
+    out = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
+    ws = torch.empty((B, N), dtype=torch.float32, device=xyz.device)
+    check(_lib.load().spgan_farthest_point_sample(_p(xyz), B, N, npoint, _p(start), _p(out), _p(ws), _s()), "farthest_point_sample", B=B, N=N)
+    return out
+
+
+def query_ball_point(radius: float, nsample: int, xyz: Tensor, new_xyz: Tensor) -> Tensor:
+    xyz, new_xyz = _xyz(xyz, "xyz"), _xyz(new_xyz, "new_xyz")
+    B, N, C = xyz.shape
+    S = new_xyz.shape[1]
+    out = torch.empty((B, S, nsample), dtype=torch.int64, device=xyz.device)
+    check(_lib.load().spgan_query_ball_point(float(radius), nsample, _p(xyz), _p(new_xyz), B, N, S, C, _p(out), _s()), "query_ball_point",
+          B=B, N=N, S=S, C=C)
+    return out
+
+
+def knn_point(nsample: int, xyz: Tensor, new_xyz: Tensor) -> Tensor:
+    xyz, new_xyz = _xyz(xyz, "xyz"), _xyz(new_xyz, "new_xyz")
+    B, N, C = xyz.shape
+    S = new_xyz.shape[1]
+    out = torch.empty((B, S, nsample), dtype=torch.int64, device=xyz.device)
+    check(_lib.load().spgan_knn_point(nsample, _p(xyz), _p(new_xyz), B, N, S, C, _p(out), _s()), "knn_point", B=B, N=N, S=S, C=C)
+    return out
+
+
+def _group_concat(xyz: Tensor, center: Tensor, feat: Optional[Tensor], idx: Tensor) -> Tensor:
+    B, N, C = xyz.shape
+    S, K = idx.shape[1], idx.shape[2]
+    D = 0 if feat is None else feat.shape[2]
+    out = torch.empty((B, S, K, C + D), dtype=torch.float32, device=xyz.device)
+    check(_lib.load().spgan_group_concat(_p(xyz), _p(center.contiguous()), _p(None if feat is None else feat.contiguous()), _p(idx.contiguous()),
+                                         B, N, S, K, C, D, _p(out), _s()), "group_concat", B=B, N=N, S=S, K=K)
+    return out
+
+
+def group(nsample: int, xyz: Tensor, points: Optional[Tensor]):
+    """kNN-group every point around itself (pointconv_util.py:174-197)."""
+    xyz = _xyz(xyz, "xyz")
+    idx = knn_point(nsample, xyz, xyz)
+    C = xyz.shape[2]
+    new_points = _group_concat(xyz, xyz, None if points is None else _xyz(points, "points"), idx)
+    grouped_xyz_norm = new_points[..., :C].contiguous() if points is not None else new_points
+    return new_points, grouped_xyz_norm
+
+
+def sample_and_group(npoint: int, radius: float, nsample: int, xyz: Tensor, points: Optional[Tensor], returnfps: bool = False,
+                     start: Optional[Tensor] = None):
+    """FPS centres + ball query + centred grouping (pointnet_util.py:110-143)."""
+    xyz = _xyz(xyz, "xyz")
+    fps_idx = farthest_point_sample(xyz, npoint, start)
+    new_xyz = index_points(xyz, fps_idx)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    new_points = _group_concat(xyz, new_xyz, None if points is None else _xyz(points, "points"), idx)
+    if returnfps:
+        return new_xyz, new_points, index_points(xyz, idx), fps_idx
+    return new_xyz, new_points
