@@ -280,6 +280,15 @@ int spgan_group_concat(const float* xyz, const float* center, const float* feat,
                        int C, int D, float* out, spgan_stream_t s);
 /* out[m,c] = a[m,c] + gamma[c]*b[m,c] */
 int spgan_col_scale_add(const float* a, const float* b, const float* gamma, int M, int C, float* out, spgan_stream_t s);
+/* dst[t][i] += src[t][i], t < count <= SPGAN_MULTI_MAX, in ONE launch (gradient accumulation into the flat buffer) */
+#define SPGAN_MULTI_MAX 64
+typedef struct spgan_multi_add_args {
+  int count;
+  float* dst[SPGAN_MULTI_MAX];
+  const float* src[SPGAN_MULTI_MAX];
+  int n[SPGAN_MULTI_MAX];
+} spgan_multi_add_args;
+int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s);
 /* y = a*x + b*y */
 int spgan_axpby(float a, const float* x, float b, float* y, size_t n, spgan_stream_t s);
 /* torch.optim.Adam step on a flat buffer (Generation/model.py:94-97: lr 1e-4, betas (0.5,0.99)); g is scaled by grad_scale first */

@@ -319,6 +319,29 @@ extern "C" int spgan_col_scale_add(const float* a, const float* b, const float* 
   return spgan_launch_status();
 }
 
+// dst[t][i] += src[t][i] for up to SPGAN_MULTI_MAX tensors in one launch (parameter-gradient accumulation into the
+// flat gradient buffer: replaces one elementwise launch per parameter tensor).
+__global__ void multi_add_kernel(const spgan_multi_add_args a) {
+  const int t = blockIdx.y;
+  const int n = a.n[t];
+  float* __restrict__ d = a.dst[t];
+  const float* __restrict__ s = a.src[t];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] += s[i];
+}
+
+extern "C" int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && a->count > 0 && a->count <= SPGAN_MULTI_MAX);
+  int nmax = 0;
+  for (int t = 0; t < a->count; ++t) {
+    SPGAN_CHECK_ARG(a->dst[t] && a->src[t] && a->n[t] > 0);
+    nmax = a->n[t] > nmax ? a->n[t] : nmax;
+  }
+  int bx = cdiv(nmax, 256 * 4);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(multi_add_kernel, dim3(bx, a->count), dim3(256), 0, (hipStream_t)s_, *a);
+  return spgan_launch_status();
+}
+
 extern "C" int spgan_axpby(float a, const float* x, float b, float* y, size_t n, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(x && y && n > 0);
   hipLaunchKernelGGL(axpby_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, a, x, b, y, n);

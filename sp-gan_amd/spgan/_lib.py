@@ -52,6 +52,13 @@ class GemmTNArgs(C.Structure):
     ]
 
 
+MULTI_MAX = 64
+
+
+class MultiAddArgs(C.Structure):
+    _fields_ = [("count", C.c_int), ("dst", C.c_void_p * MULTI_MAX), ("src", C.c_void_p * MULTI_MAX), ("n", C.c_int * MULTI_MAX)]
+
+
 I, F, P, SZ = C.c_int, C.c_float, C.c_void_p, C.c_size_t
 
 # name -> (restype, argtypes).  Must list every symbol include/spgan_hip.h declares
@@ -108,6 +115,7 @@ SIGNATURES = {
     "spgan_query_ball_point": (I, [F, I, P, P, I, I, I, I, P, P]),
     "spgan_knn_point": (I, [I, P, P, I, I, I, I, P, P]),
     "spgan_group_concat": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+    "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
     "spgan_axpby": (I, [F, P, F, P, SZ, P]),
     "spgan_adam_step": (I, [P, P, P, P, SZ, F, F, F, F, I, F, P]),
 }

@@ -32,6 +32,32 @@ def _engine_needs(ctx, pos: int, tpos: int) -> bool:
         return True
 
 
+FUSED_GRAD_ACCUMULATION = True
+
+
+def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool]):
+    """Hand parameter gradients back to autograd -- or, when every wanted parameter already owns a contiguous `.grad`
+    (the flat buffer of spgan.optim.flatten_module) and no graph is being recorded, add them into `.grad` with ONE
+    fused launch (spgan_multi_add) and return None for all of them: the same sums AccumulateGrad would form with one
+    elementwise launch per parameter tensor.  Exact-zero gradients (nets.ZERO_GRAD) cost nothing on that path."""
+    live = [(p, g) for p, g, need in zip(params, grads, needs) if need and g is not None]
+    if FUSED_GRAD_ACCUMULATION and not torch.is_grad_enabled() and live and all(
+            p.grad is not None and p.grad.is_contiguous() and (isinstance(g, int) or p.grad.numel() == g.numel()) for p, g in live):
+        pairs = [(p.grad, g.contiguous()) for p, g in live if not isinstance(g, int)]
+        if pairs:
+            ops.multi_add([d for d, _ in pairs], [s for _, s in pairs])
+        return (None,) * len(params)
+    out = []
+    for p, g, need in zip(params, grads, needs):
+        if not need or g is None:
+            out.append(None)
+        elif isinstance(g, int):
+            out.append(torch.zeros_like(p))
+        else:
+            out.append(g.view_as(p) if g.shape != p.shape else g)
+    return tuple(out)
+
+
 class _Holder:
     """Non-tensor bag passed through Function.apply (module buffers, flags)."""
     def __init__(self, **kw):
@@ -88,8 +114,9 @@ class DiscriminatorFn(Function):
             return (None, dx) + (None,) * len(params)
         P = dict(zip(names, [p.detach() for p in params]))
         dx, grads, _ = nets.d_backward(P, ctx.dctx, dout.detach(), need_dx, need_dp, False)
-        gp = tuple(grads[n] if (grads is not None and ctx.needs_input_grad[2 + i]) else None for i, n in enumerate(names))
-        return (None, dx) + gp
+        if grads is None:
+            return (None, dx) + (None,) * len(params)
+        return (None, dx) + _deliver(params, [grads[n] for n in names], ctx.needs_input_grad[2:])
 
 
 class DiscriminatorBackwardFn(Function):
@@ -112,9 +139,8 @@ class DiscriminatorBackwardFn(Function):
         P = dict(zip(names, [p.detach() for p in params]))
         need_x = ctx.needs_input_grad[3]
         grads, dx2 = nets.d_double_backward(P, ctx.dctx, ctx.saved, v.detach(), need_dx=need_x)
-        gp = tuple(grads[n] if ctx.needs_input_grad[4 + i] else None for i, n in enumerate(names))
         # (holder, dctx, dout, x, *params); the gradient w.r.t. dout is not provided (constant ones in WGAN-GP)
-        return (None, None, None, dx2) + gp
+        return (None, None, None, dx2) + _deliver(params, [grads[n] for n in names], ctx.needs_input_grad[4:])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -147,7 +173,7 @@ class EdgeBlockFn(Function):
             if cache is not None:
                 cache["csr"] = csr
         dx, g = nets.edgeblock_backward(P, h.prefix, ctx.ectx, dout, csr, need_dx=ctx.needs_input_grad[1])
-        return (None, dx) + tuple(g[n] if ctx.needs_input_grad[2 + i] else None for i, n in enumerate(h.names))
+        return (None, dx) + _deliver(params, [g[n] for n in h.names], ctx.needs_input_grad[2:])
 
 
 class AdaINFn(Function):
@@ -168,7 +194,7 @@ class AdaINFn(Function):
         P = {pre + ".style.weight": w.detach(), pre + ".style.bias": b.detach()}
         need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         dx, ds, g = nets.adain_backward(P, pre, ctx.actx, dout, ctx.needs_input_grad[1], ctx.needs_input_grad[2], need_p)
-        return None, dx, ds, g.get(pre + ".style.weight"), g.get(pre + ".style.bias")
+        return (None, dx, ds) + _deliver((w, b), [g.get(pre + ".style.weight"), g.get(pre + ".style.bias")], ctx.needs_input_grad[3:])
 
 
 class MLPFn(Function):
@@ -194,10 +220,10 @@ class MLPFn(Function):
         need_p = any(ctx.needs_input_grad[2:])
         dx, g, _ = nets.mlp_backward(P, ctx.mctx, dout, ctx.needs_input_grad[1], need_p)
         out = []
-        for i, n in enumerate(h.names):
-            out.append(g.get(n + ".weight") if ctx.needs_input_grad[2 + 2 * i] else None)
-            out.append(g.get(n + ".bias") if ctx.needs_input_grad[3 + 2 * i] else None)
-        return (None, dx) + tuple(out)
+        for n in h.names:
+            out.append(g.get(n + ".weight"))
+            out.append(g.get(n + ".bias"))
+        return (None, dx) + _deliver(params, out, ctx.needs_input_grad[2:])
 
 
 GT_NAMES = ("global_conv.0.weight", "global_conv.0.bias", "global_conv.1.weight", "global_conv.1.bias",
@@ -235,4 +261,4 @@ class GlobalTailFn(Function):
         gg = nets.global_backward(P, ctx.gctx, Wt0[:, :ctx.Cg], drb, da2)
         g.update({k: v for k, v in gg.items() if k != "tail.0.weight.global"})
         g["tail.0.weight"] = torch.cat([gg["tail.0.weight.global"], g.pop("tail.0.weight.part")], dim=1).view_as(P["tail.0.weight"])
-        return (None, da2 if ctx.needs_input_grad[1] else None) + tuple(g[n] if ctx.needs_input_grad[2 + i] else None for i, n in enumerate(GT_NAMES))
+        return (None, da2 if ctx.needs_input_grad[1] else None) + _deliver(params, [g[n] for n in GT_NAMES], ctx.needs_input_grad[2:])

@@ -57,7 +57,37 @@ def _named(module: nn.Module, prefix: str = ""):
 
 
 def _buffers(module: nn.Module, prefix: str = ""):
-    return {prefix + n: b for n, b in module.named_buffers()}
+    d = {prefix + n: b for n, b in module.named_buffers()}
+    if isinstance(module, _BNCounts):
+        d["__pending_counts__"] = module._pending(prefix)
+    return d
+
+
+class _BNCounts:
+    """BatchNorm's `num_batches_tracked` is bookkeeping only (momentum is fixed): the increments are counted on the host
+    and written to the int64 buffers when somebody looks (state_dict(), flush_bn_counts()), instead of one tiny
+    kernel launch per BatchNorm per forward (36 per train step)."""
+
+    def _pending(self, prefix: str) -> dict:
+        store = self.__dict__.setdefault("_bn_pending", {})
+        return store.setdefault(prefix, {})
+
+    def _flush_own(self):
+        bufs = dict(self.named_buffers())
+        for prefix, pend in self.__dict__.get("_bn_pending", {}).items():
+            for key, n in pend.items():
+                if n:
+                    bufs[key[len(prefix):]] += n
+            pend.clear()
+
+    def flush_bn_counts(self):
+        """Write the host-side BatchNorm call counts of this module and its sub-modules into `num_batches_tracked`."""
+        for m in self.modules():
+            if isinstance(m, _BNCounts):
+                m._flush_own()
+
+    def _install_count_hook(self):
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_own())
 
 
 class AdaptivePointNorm(nn.Module):
@@ -85,7 +115,7 @@ class AdaptivePointNorm(nn.Module):
         return Fn.PmToCm.apply(out, B, N)
 
 
-class EdgeBlock(nn.Module):
+class EdgeBlock(nn.Module, _BNCounts):
     """Generator.py:47-88.  forward(x [B,Fin,N]) -> [B,Fout,N]."""
 
     def __init__(self, Fin: int, Fout: int, k: int, attn: bool = True):
@@ -95,6 +125,7 @@ class EdgeBlock(nn.Module):
         self.conv_x = _stack([("conv2d", 2 * Fin, Fout, [1, 1]), ("bn2d", Fout), ("lrelu",)])
         self.conv_out = nn.Conv2d(Fout, Fout, [1, k], [1, 1])
         self.last_idx: Optional[torch.Tensor] = None      # int32 [B*N, k] global rows of the most recent forward
+        self._install_count_hook()
 
     def forward_pm(self, x_pm, B: int, N: int, idx: Optional[torch.Tensor] = None, knn_mode: Optional[int] = None,
                    graph_cache: Optional[dict] = None):
@@ -120,7 +151,7 @@ class EdgeBlock(nn.Module):
         return Fn.PmToCm.apply(out, B, N)
 
 
-class Generator(nn.Module):
+class Generator(nn.Module, _BNCounts):
     """Generation/Generator.py:91-198.  forward(x [B,N,3], z [B,N,nz]) -> [B,3,N].
     opts fields read: np, nk, nz, softmax, off, attn, use_head, eql, z_norm."""
 
@@ -152,6 +183,7 @@ class Generator(nn.Module):
             self.adain2 = AdaptivePointNorm(dim, dim)
         self.lrelu1 = nn.LeakyReLU(nets.NEG_2)
         self.lrelu2 = nn.LeakyReLU(nets.NEG_2)
+        self._install_count_hook()
 
     def _mlp2(self, seq: nn.Sequential, x_pm):
         h = _Holder(names=["l0", "l2"], acts=[ops.ACT_LRELU, ops.ACT_LRELU], slope=NEG)
@@ -211,7 +243,7 @@ class Generator(nn.Module):
         return self._body(x, style)
 
 
-class Discriminator(nn.Module):
+class Discriminator(nn.Module, _BNCounts):
     """Generation/Discriminator.py:48-115.  forward(x [B,3,N]) -> [B,1].  Supports autograd.grad(create_graph=True)
     w.r.t. its input followed by backward() (WGAN-GP)."""
 
@@ -225,6 +257,7 @@ class Discriminator(nn.Module):
         dim = 512 if self.small_d else 1024
         self.fc2 = _stack([("conv1d", 256, dim), ("bn1d", dim), ("lrelu",)])
         self.mlp = _stack([("linear", dim, 512), ("lrelu",), ("linear", 512, 256), ("lrelu",), ("linear", 256, 64), ("lrelu",), ("linear", 64, 1)])
+        self._install_count_hook()
 
     def forward(self, x):
         _require_gpu(x, "Discriminator")

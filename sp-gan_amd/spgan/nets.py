@@ -19,6 +19,7 @@ from . import ops
 Tensor = torch.Tensor
 NEG = 0.01     # Generator.py:22, Discriminator.py:19
 NEG_2 = 0.2    # Generator.py:23
+ZERO_GRAD = 0  # sentinel for a gradient that is exactly zero (e.g. a conv bias in front of a train-mode BatchNorm)
 
 
 def _w2(w: Tensor) -> Tensor:
@@ -38,7 +39,11 @@ def _bn_train(mean, var, P, bufs, bn, count, training, update_running):
     if training:
         out = ops.bn_prepare(mean, var, g, b, count, True, rm, rv)
         if rm is not None and (bn + ".num_batches_tracked") in bufs:
-            bufs[bn + ".num_batches_tracked"] += 1
+            pend = bufs.get("__pending_counts__")
+            if pend is not None:        # counted on the host, flushed into the int64 buffer by the module's state_dict hook
+                pend[bn + ".num_batches_tracked"] = pend.get(bn + ".num_batches_tracked", 0) + 1
+            else:
+                bufs[bn + ".num_batches_tracked"] += 1
         return out
     return ops.bn_prepare(None, None, g, b, count, False, rm, rv)
 
@@ -123,7 +128,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
                 grads[conv + ".weight"] = ops.gemm_tn(dy, ys[li - 1], pro=(bns[li - 1][0], bns[li - 1][1], NEG)).view_as(P[conv + ".weight"])
             else:
                 grads[conv + ".weight"] = ops.gemm_tn(dy, ctx["x_pm"]).view_as(P[conv + ".weight"])
-            grads[conv + ".bias"] = torch.zeros_like(P[conv + ".bias"])     # bias before a train-mode BN: exactly zero gradient
+            grads[conv + ".bias"] = ZERO_GRAD     # bias before a train-mode BN: exactly zero gradient
             if not ctx["training"]:
                 grads[conv + ".bias"] = ops.colsum(dy)[0]
         if li > 0:
@@ -191,7 +196,7 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
     for li in (0, 1, 2, 3):
         name = D_MLP[li]
         grads[name + ".weight"] = ops.gemm_tn(dhs[li], t)                        # (grad wrt pre-act of layer li)^T . adjoint
-        grads[name + ".bias"] = torch.zeros_like(P[name + ".bias"])
+        grads[name + ".bias"] = ZERO_GRAD
         if li < 3:
             t = ops.gemm_nt_maskout(t, P[name + ".weight"], hs[li], NEG)
     # ---------------------------------------------------------------- phase B
@@ -206,7 +211,7 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         if abar_g is None:
             X = xbarA[li]
             T0, T1 = xsum0[li], xsum1[li]
-            grads[bn + ".bias"] = torch.zeros_like(gamma)
+            grads[bn + ".bias"] = ZERO_GRAD
         else:
             g, s0, s1 = abar_g
             X = ops.col_scale_add(xbarA[li], g, gamma)                           # xbarA + gamma*g
@@ -224,7 +229,7 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
             if need_dx:
                 dx = ops.pm_to_cm(ops.gemm_nt(ybar, _t(W)), B, N)
         grads[conv + ".weight"] = (grads[conv + ".weight"] + gw).view_as(P[conv + ".weight"])
-        grads[conv + ".bias"] = torch.zeros_like(P[conv + ".bias"])
+        grads[conv + ".bias"] = ZERO_GRAD
     return grads, dx
 
 
@@ -294,7 +299,7 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     dh2 = ops.bn_bwd_apply(g2, ctx["h2pre"], bn2[3], bn2[2], P[pre + ".conv_w.4.weight"], sums2, E)
     W2 = _w2(P[pre + ".conv_w.3.weight"])
     g[pre + ".conv_w.3.weight"] = ops.gemm_tn(dh2, PQR[:, :H], pro=(bn1[0], bn1[1], NEG), edge=(idx, b1)).view_as(P[pre + ".conv_w.3.weight"])
-    g[pre + ".conv_w.3.bias"] = torch.zeros_like(P[pre + ".conv_w.3.bias"]) if ctx["training"] else ops.colsum(dh2)[0]
+    g[pre + ".conv_w.3.bias"] = ZERO_GRAD if ctx["training"] else ops.colsum(dh2)[0]
     g1, s10, s11 = ops.gemm_nt_bnbwd(dh2, _t(W2), PQR[:, :H], bn1[0], bn1[1], bn1[3], bn1[2], NEG, edge=(idx, b1))
     g[pre + ".conv_w.1.weight"] = s11; g[pre + ".conv_w.1.bias"] = s10
     sums1 = torch.cat([s10, s11]) if ctx["training"] else torch.zeros(2 * H, device=x.device)
@@ -306,8 +311,8 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     g[pre + ".conv_w.0.weight"] = dW0.view_as(P[pre + ".conv_w.0.weight"])
     g[pre + ".conv_x.0.weight"] = dWx.view_as(P[pre + ".conv_x.0.weight"])
     # biases in front of a train-mode BatchNorm: mathematically zero gradient
-    g[pre + ".conv_w.0.bias"] = torch.zeros_like(b1)
-    g[pre + ".conv_x.0.bias"] = torch.zeros_like(bx)
+    g[pre + ".conv_w.0.bias"] = ZERO_GRAD
+    g[pre + ".conv_x.0.bias"] = ZERO_GRAD
     dx = ops.gemm_nt(dPQR, _t(ctx["Wcat"])) if need_dx else None
     return dx, g
 
@@ -421,13 +426,13 @@ def global_backward(P, gctx, W_g: Tensor, drb: Tensor, da2: Tensor):
     sums = torch.cat([s0, s1]) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
     dy3 = ops.bn_bwd_apply(g3, y3, bn3[3], bn3[2], P["global_conv.4.weight"], sums, B)
     g["global_conv.3.weight"] = ops.gemm_tn(dy3, y0, pro=(bn0[0], bn0[1], NEG))
-    g["global_conv.3.bias"] = torch.zeros_like(P["global_conv.3.bias"]) if tr else ops.colsum(dy3)[0]
+    g["global_conv.3.bias"] = ZERO_GRAD if tr else ops.colsum(dy3)[0]
     g0, s0, s1 = ops.gemm_nt_bnbwd(dy3, _t(P["global_conv.3.weight"]), y0, bn0[0], bn0[1], bn0[3], bn0[2], NEG)
     g["global_conv.1.weight"] = s1; g["global_conv.1.bias"] = s0
     sums = torch.cat([s0, s1]) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
     dy0 = ops.bn_bwd_apply(g0, y0, bn0[3], bn0[2], P["global_conv.1.weight"], sums, B)
     g["global_conv.0.weight"] = ops.gemm_tn(dy0, gctx["gmax"])
-    g["global_conv.0.bias"] = torch.zeros_like(P["global_conv.0.bias"]) if tr else ops.colsum(dy0)[0]
+    g["global_conv.0.bias"] = ZERO_GRAD if tr else ops.colsum(dy0)[0]
     dgmax = ops.gemm_nt(dy0, _t(P["global_conv.0.weight"]))
     ops.maxpool_bwd_add(dgmax, gctx["garg"], da2)
     return g

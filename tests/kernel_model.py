@@ -469,3 +469,8 @@ def gp_penalty_bwd(g, norms, gamma, lam, upstream):
     up = 1.0 if upstream is None else upstream.reshape(())
     c = up * lam * (2.0 / B) * ((norms - gamma) / (gamma * gamma)) / norms
     return (c.reshape(B, *([1] * (g.dim() - 1))) * g).contiguous()
+
+
+def multi_add(dsts, srcs):
+    for d, s in zip(dsts, srcs):
+        d.add_(s.reshape(d.shape))

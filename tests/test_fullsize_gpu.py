@@ -50,6 +50,7 @@ def test_c2_step_properties():
         ref = torch.from_numpy(golden("g1_edge_features.npz")["sphere2048|idx"].astype(np.int64))
         loc = spgan.ops.idx_to_local64(G.EdgeConv1.last_idx, B, N).view(B, N, 10).cpu()
         assert (loc == ref[None]).all()
+        G.flush_bn_counts(); D.flush_bn_counts()
         assert int(G.global_conv[1].num_batches_tracked) == 2 and int(D.fc2[1].num_batches_tracked) == 5   # model.py call order
         assert torch.isfinite(G.EdgeConv2.conv_w[4].running_var).all()
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), "train step is not bit-deterministic"
