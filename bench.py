@@ -29,7 +29,7 @@ for p in (ROOT, os.path.join(ROOT, "sp-gan_amd")):
 import torch   # noqa: E402
 
 N_POINTS = 2048
-PER_GPU_BATCH = 32
+PER_GPU_BATCH = int(os.environ.get("SPGAN_BENCH_BATCH", "32"))   # 32 = BASELINE configs[1]; the override is for experiments only
 NZ = 128
 K_NN = 10
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak

@@ -143,6 +143,11 @@ int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s);
 size_t spgan_colreduce_ws_bytes(int M, int C, int G);
 int spgan_colstats_finalize(const float* partials, int groups, int tiles_per_group, int C, int G, int mode,
                             int tile_rows /* 0 -> 128 */, float* out0, float* out1, spgan_stream_t s);
+/* One group of G rows: finalize (sum, M2) partials AND do the train-mode BatchNorm bookkeeping of spgan_bn_prepare in the
+ * same launch (scale, shift, invstd, mean; running stats updated when given). */
+int spgan_colstats_finalize_bn(const float* partials, int tiles, int C, int G, int tile_rows, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                               float* invstd, float* mean_out, spgan_stream_t s);
 /* mean / biased variance over each group of lrelu(X, slope) (slope = 1: plain).  InstanceNorm1d statistics of
  * AdaptivePointNorm (Generator.py:29,42) with G = N; BatchNorm statistics with G = M.  ws >= spgan_colreduce_ws_bytes. */
 int spgan_colstats(const float* X, int ldx, int M, int C, int G, float slope, float* out_mean, float* out_var,
@@ -278,6 +283,15 @@ int spgan_knn_point(int nsample, const float* xyz, const float* new_xyz, int B, 
 /* out[b,s,j,:] = [xyz[b,idx] - center[b,s] | feat[b,idx]]   pointnet_util.py:127-139, pointconv_util.py:186-195 */
 int spgan_group_concat(const float* xyz, const float* center, const float* feat, const int64_t* idx, int B, int N, int S, int K,
                        int C, int D, float* out, spgan_stream_t s);
+/* Per-channel scalar algebra of the double backward, one launch each:
+ *   coeffs out4C = [dgammaA | sbarA | xsum0 | xsum1];  phaseb: sums2C = [xsum0+gamma*s0 | xsum1+gamma*s1+invstd*sbarA], dgamma = dgammaA+s1 */
+int spgan_bn_dbl_coeffs(const float* U0, const float* U1, const float* Ugz, const float* S0, const float* S1, const float* gamma,
+                        const float* invstd, int C, int count, float* out4C, spgan_stream_t s);
+int spgan_bn_dbl_phaseb(const float* coeffs4C, const float* gamma, const float* invstd, const float* s0, const float* s1, int C,
+                        float* sums2C, float* dgamma, spgan_stream_t s);
+/* Lazy-operand form of the BatchNorm backward behind the max-pool: dy = alpha[c]*y + beta[c] + (argmax hit ? cg[b,c] : 0) */
+int spgan_sparse_bn_prep(const float* gval, const float* mean, const float* invstd, const float* gamma, const float* sums, int B,
+                         int C, int count, float* alpha, float* beta, float* cg, spgan_stream_t s);
 /* out[m,c] = a[m,c] + gamma[c]*b[m,c] */
 int spgan_col_scale_add(const float* a, const float* b, const float* gamma, int M, int C, float* out, spgan_stream_t s);
 /* dst[t][i] += src[t][i], t < count <= SPGAN_MULTI_MAX, in ONE launch (gradient accumulation into the flat buffer) */

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_kernel(
     if (w == 0 && ok) {
       float* o = part + (size_t)blockIdx.x * (2 * F) * 2;
       o[(size_t)f * 2 + 0] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-      o[(size_t)f * 2 + 1] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
-      o[(size_t)(F + f) * 2 + 0] = (red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]);
+      o[(size_t)f * 2 + 1] = (red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]);
+      o[(size_t)(F + f) * 2 + 0] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
       o[(size_t)(F + f) * 2 + 1] = (red[3][0][lane] + red[3][1][lane]) + (red[3][2][lane] + red[3][3][lane]);
     }
     __syncthreads();
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
       if (ff < F) {
         float* o = part + (size_t)blockIdx.x * (2 * F) * 2;
         o[(size_t)ff * 2 + 0] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-        o[(size_t)ff * 2 + 1] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
-        o[(size_t)(F + ff) * 2 + 0] = (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]);
+        o[(size_t)ff * 2 + 1] = (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]);
+        o[(size_t)(F + ff) * 2 + 0] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
         o[(size_t)(F + ff) * 2 + 1] = (red[3][0][c] + red[3][1][c]) + (red[3][2][c] + red[3][3][c]);
       }
     }

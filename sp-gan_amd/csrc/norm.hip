@@ -61,8 +61,16 @@ __device__ __forceinline__ void chan_merge(float& n, float& a, float& b, float n
   n = nn;
 }
 
+// Optional tail of the finalize kernel: train-mode BatchNorm bookkeeping from the just-computed (mean, var)
+struct BnTail {
+  const float* gamma; const float* beta;
+  float* rmean; float* rvar;            // running stats (may be NULL)
+  float* scale; float* shift; float* invstd; float* mean_out;   // NULL scale: no tail
+  float eps, momentum;
+};
+
 __global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restrict__ part, int tiles_per_group, int C, int G, int mode,
-                                                          int tile_rows, float* __restrict__ out0, float* __restrict__ out1) {
+                                                          int tile_rows, float* __restrict__ out0, float* __restrict__ out1, const BnTail bn) {
   __shared__ float sn[FS][FC], sa[FS][FC], sb[FS][FC];
   const int g = blockIdx.y;
   const int cl = threadIdx.x & (FC - 1), sl = threadIdx.x / FC;
@@ -108,8 +116,23 @@ __global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restric
     __syncthreads();
   }
   if (sl == 0 && cok) {
-    out0[(size_t)g * C + c] = a;
-    out1[(size_t)g * C + c] = (mode == 0) ? b / (float)G : b;
+    const float var = (mode == 0) ? b / (float)G : b;
+    if (out0) out0[(size_t)g * C + c] = a;
+    if (out1) out1[(size_t)g * C + c] = var;
+    if (bn.scale) {  // single group, mode 0: same arithmetic as bn_prepare_kernel
+      if (bn.rmean) {
+        const float unb = G > 1 ? var * ((float)G / (float)(G - 1)) : var;
+        bn.rmean[c] = (1.f - bn.momentum) * bn.rmean[c] + bn.momentum * a;
+        bn.rvar[c] = (1.f - bn.momentum) * bn.rvar[c] + bn.momentum * unb;
+      }
+      const float inv = 1.0f / sqrtf(var + bn.eps);
+      const float ga = bn.gamma ? bn.gamma[c] : 1.f, be = bn.beta ? bn.beta[c] : 0.f;
+      const float sc = ga * inv;
+      bn.scale[c] = sc;
+      bn.shift[c] = be - a * sc;
+      bn.invstd[c] = inv;
+      bn.mean_out[c] = a;
+    }
   }
 }
 
@@ -250,7 +273,22 @@ extern "C" int spgan_colstats_finalize(const float* partials, int groups, int ti
   if (tile_rows <= 0) tile_rows = RT;
   SPGAN_CHECK_ARG(partials && out0 && out1 && groups > 0 && tiles_per_group > 0 && C > 0 && G > 0 && (mode == 0 || mode == 1));
   SPGAN_CHECK_ARG(tiles_per_group == cdiv(G, tile_rows));
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, partials, tiles_per_group, C, G, mode, tile_rows, out0, out1);
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, partials, tiles_per_group, C, G, mode, tile_rows, out0, out1, BnTail{});
+  return spgan_launch_status();
+}
+
+// Finalize the (sum, M2) partials of ONE group of G rows and do the train-mode BatchNorm bookkeeping in the same launch:
+// scale = gamma*invstd, shift = beta - mean*scale, invstd, mean; running stats updated in place when given.
+extern "C" int spgan_colstats_finalize_bn(const float* partials, int tiles, int C, int G, int tile_rows, const float* gamma, const float* beta,
+                                          float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                                          float* invstd, float* mean_out, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (tile_rows <= 0) tile_rows = RT;
+  SPGAN_CHECK_ARG(partials && scale && shift && invstd && mean_out && tiles > 0 && C > 0 && G > 0 && tiles == cdiv(G, tile_rows));
+  SPGAN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  BnTail bn{gamma, beta, running_mean, running_var, scale, shift, invstd, mean_out, eps, momentum};
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), 1), dim3(256), 0, s, partials, tiles, C, G, 0, tile_rows, (float*)nullptr,
+                     (float*)nullptr, bn);
   return spgan_launch_status();
 }
 
@@ -261,7 +299,7 @@ extern "C" int spgan_colstats(const float* X, int ldx, int M, int C, int G, floa
   SPGAN_CHECK_ARG(ws_bytes >= spgan_colreduce_ws_bytes(M, C, G));
   const int groups = M / G, tpg = cdiv(G, RT);
   hipLaunchKernelGGL((colpartials_kernel<0>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, slope, ws);
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, ws, tpg, C, G, 0, RT, out_mean, out_var);
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, ws, tpg, C, G, 0, RT, out_mean, out_var, BnTail{});
   return spgan_launch_status();
 }
 
@@ -273,7 +311,7 @@ extern "C" int spgan_colsum(const float* X, int ldx, int M, int C, int G, float*
   SPGAN_CHECK_ARG(ws_bytes >= spgan_colreduce_ws_bytes(M, C, G) + (size_t)groups * C * sizeof(float));
   float* scratch = ws + (size_t)groups * tpg * C * 2;
   hipLaunchKernelGGL((colpartials_kernel<1>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, 1.0f, ws);
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, ws, tpg, C, G, 1, RT, out, scratch);
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, ws, tpg, C, G, 1, RT, out, scratch, BnTail{});
   return spgan_launch_status();
 }
 

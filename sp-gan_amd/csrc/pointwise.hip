@@ -194,6 +194,43 @@ __global__ void bn_dbl_apply_kernel(const float* __restrict__ u, const float* __
   xbar[t] = -(gs * rM) * (uv * S1[c] + gz[t] * U1[c]);
 }
 
+// Per-channel scalar algebra of the double backward, one launch each instead of ~15 elementwise ones.
+//   phase A: core = Ugz - (U0*S0 + U1*S1)/M;  out[0]=dgammaA = inv*core;  out[1]=sbarA = gamma*core;
+//            out[2]=xsum0 = -(gamma*inv/M)*(U0*S1 + S0*U1);  out[3]=xsum1 = -2*(gamma*inv/M)*U1*S1
+__global__ void bn_dbl_coeffs_kernel(const float* U0, const float* U1, const float* Ugz, const float* S0, const float* S1, const float* gamma,
+                                     const float* inv, int C, float rM, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float core = Ugz[c] - (U0[c] * S0[c] + U1[c] * S1[c]) * rM;
+  const float gsM = gamma[c] * inv[c] * rM;
+  out[c] = inv[c] * core;
+  out[C + c] = gamma[c] * core;
+  out[2 * C + c] = -gsM * (U0[c] * S1[c] + S0[c] * U1[c]);
+  out[3 * C + c] = -2.0f * gsM * (U1[c] * S1[c]);
+}
+//   phase B: sums[0:C] = xsum0 + gamma*s0;  sums[C:2C] = xsum1 + gamma*s1 + inv*sbarA;  dgamma = dgammaA + s1   (s0/s1 NULL: zeros)
+__global__ void bn_dbl_phaseb_kernel(const float* coeffs, const float* gamma, const float* inv, const float* s0, const float* s1, int C,
+                                     float* sums, float* dgamma) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float a0 = s0 ? s0[c] : 0.f, a1 = s1 ? s1[c] : 0.f;
+  sums[c] = coeffs[2 * C + c] + gamma[c] * a0;
+  sums[C + c] = coeffs[3 * C + c] + gamma[c] * a1 + inv[c] * coeffs[C + c];
+  dgamma[c] = coeffs[c] + a1;
+}
+// BatchNorm backward behind the max-pool as a lazy operand: alpha = -(gamma*inv)*inv*S1/M, beta = -(gamma*inv)*S0/M - alpha*mean,
+// cg[b,c] = gamma*inv*gval[b,c]
+__global__ void sparse_bn_prep_kernel(const float* gval, const float* mean, const float* inv, const float* gamma, const float* sums, int B,
+                                      int C, float rM, float* alpha, float* beta, float* cg) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float coef = gamma[c] * inv[c];
+  const float al = -(coef * inv[c]) * (sums[C + c] * rM);
+  alpha[c] = al;
+  beta[c] = -(coef * (sums[c] * rM)) - al * mean[c];
+  for (int b = 0; b < B; ++b) cg[(size_t)b * C + c] = gval[(size_t)b * C + c] * coef;
+}
+
 // out = a + gamma[c]*b
 __global__ void col_scale_add_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gamma, size_t M, int C,
                                      float* __restrict__ out) {
@@ -312,6 +349,27 @@ extern "C" int spgan_bn_dbl_apply(const float* u, const float* y, const float* g
                      shift, slope, gamma, S1, U0, U1, 1.0f / (float)M, q, xbar);
   return spgan_launch_status();
 }
+extern "C" int spgan_bn_dbl_coeffs(const float* U0, const float* U1, const float* Ugz, const float* S0, const float* S1, const float* gamma,
+                                   const float* invstd, int C, int count, float* out4C, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(U0 && U1 && Ugz && S0 && S1 && gamma && invstd && out4C && C > 0 && count > 0);
+  hipLaunchKernelGGL(bn_dbl_coeffs_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s_, U0, U1, Ugz, S0, S1, gamma, invstd, C,
+                     1.0f / (float)count, out4C);
+  return spgan_launch_status();
+}
+extern "C" int spgan_bn_dbl_phaseb(const float* coeffs4C, const float* gamma, const float* invstd, const float* s0, const float* s1, int C,
+                                   float* sums2C, float* dgamma, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(coeffs4C && gamma && invstd && sums2C && dgamma && C > 0 && ((s0 == nullptr) == (s1 == nullptr)));
+  hipLaunchKernelGGL(bn_dbl_phaseb_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s_, coeffs4C, gamma, invstd, s0, s1, C, sums2C, dgamma);
+  return spgan_launch_status();
+}
+extern "C" int spgan_sparse_bn_prep(const float* gval, const float* mean, const float* invstd, const float* gamma, const float* sums, int B,
+                                    int C, int count, float* alpha, float* beta, float* cg, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(gval && mean && invstd && gamma && sums && alpha && beta && cg && B > 0 && C > 0 && count > 0);
+  hipLaunchKernelGGL(sparse_bn_prep_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s_, gval, mean, invstd, gamma, sums, B, C,
+                     1.0f / (float)count, alpha, beta, cg);
+  return spgan_launch_status();
+}
+
 extern "C" int spgan_col_scale_add(const float* a, const float* b, const float* gamma, int M, int C, float* out, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a && b && gamma && out && M > 0 && C > 0);
   const size_t total = (size_t)M * C;

@@ -79,6 +79,7 @@ SIGNATURES = {
     "spgan_gemm_tn": (I, [C.POINTER(GemmTNArgs), P]),
     "spgan_colreduce_ws_bytes": (SZ, [I, I, I]),
     "spgan_colstats_finalize": (I, [P, I, I, I, I, I, I, P, P, P]),
+    "spgan_colstats_finalize_bn": (I, [P, I, I, I, I, P, P, F, F, P, P, P, P, P, P, P]),
     "spgan_colstats": (I, [P, I, I, I, I, F, P, P, P, SZ, P]),
     "spgan_colsum": (I, [P, I, I, I, I, P, P, SZ, P]),
     "spgan_bn_prepare": (I, [P, P, P, P, I, I, F, F, I, P, P, P, P, P, P, P]),
@@ -104,6 +105,9 @@ SIGNATURES = {
     "spgan_gather_rows": (I, [P, I, P, I, I, P, P]),
     "spgan_bn_dbl_stats": (I, [P, P, P, I, I, P, P, P, P]),
     "spgan_bn_dbl_apply": (I, [P, P, P, I, I, P, P, P, P, F, P, P, P, P, P, P, P]),
+    "spgan_bn_dbl_coeffs": (I, [P, P, P, P, P, P, P, I, I, P, P]),
+    "spgan_bn_dbl_phaseb": (I, [P, P, P, P, P, I, P, P, P]),
+    "spgan_sparse_bn_prep": (I, [P, P, P, P, P, I, I, I, P, P, P, P]),
     "spgan_col_scale_add": (I, [P, P, P, I, I, P, P]),
     "spgan_gan_loss": (I, [I, I, P, P, P, P, I, P, P, P, P]),
     "spgan_lerp_rows": (I, [P, P, P, I, SZ, P, P]),

@@ -31,6 +31,16 @@ def _t(w: Tensor) -> Tensor:
     return w.t().contiguous()
 
 
+def _cat2(s0: Tensor, s1: Tensor) -> Tensor:
+    """[s0 | s1] without a copy when the two vectors already sit back to back in one allocation (the finalize kernels
+    write (sum0, sum1) into one [2,C] buffer)."""
+    n = s0.numel()
+    if (s0.is_contiguous() and s1.is_contiguous() and s1.numel() == n and s1.data_ptr() == s0.data_ptr() + 4 * n
+            and s0.untyped_storage().data_ptr() == s1.untyped_storage().data_ptr()):
+        return torch.as_strided(s0, (2 * n,), (1,), s0.storage_offset())
+    return torch.cat([s0, s1])
+
+
 def _bn_train(mean, var, P, bufs, bn, count, training, update_running):
     g, b = P[bn + ".weight"], P[bn + ".bias"]
     rm = rv = None
@@ -46,6 +56,29 @@ def _bn_train(mean, var, P, bufs, bn, count, training, update_running):
                 bufs[bn + ".num_batches_tracked"] += 1
         return out
     return ops.bn_prepare(None, None, g, b, count, False, rm, rv)
+
+
+def _count_bn_call(bufs, bn):
+    if bufs is not None and (bn + ".num_batches_tracked") in bufs:
+        pend = bufs.get("__pending_counts__")
+        if pend is not None:
+            pend[bn + ".num_batches_tracked"] = pend.get(bn + ".num_batches_tracked", 0) + 1
+        else:
+            bufs[bn + ".num_batches_tracked"] += 1
+
+
+def _gemm_bn(A, W, b, P, bufs, bn, count, training, update_running, **kw):
+    """GEMM followed by a BatchNorm whose statistics come out of the GEMM epilogue: returns (y_pre_bn, (scale, shift, invstd, mean)).
+    Train mode: ONE extra launch (finalize + BN bookkeeping) after the GEMM."""
+    if training:
+        rm = rv = None
+        if bufs is not None and update_running:
+            rm, rv = bufs[bn + ".running_mean"], bufs[bn + ".running_var"]
+        y, st = ops.gemm_nt(A, W, b, bn=(P[bn + ".weight"], P[bn + ".bias"], rm, rv), **kw)
+        if rm is not None:
+            _count_bn_call(bufs, bn)
+        return y, st
+    return ops.gemm_nt(A, W, b, **kw), _bn_train(None, None, P, bufs, bn, count, False, False)
 
 
 # =============================================================================================
@@ -65,11 +98,7 @@ def d_forward(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], x_cm: Ten
     a, pro = x_pm, None
     for conv, bn in D_LAYERS:
         W, b = _w2(P[conv + ".weight"]), P[conv + ".bias"]
-        if training:
-            y, mean, var = ops.gemm_nt(a, W, b, pro=pro, stats=True)
-        else:
-            y, mean, var = ops.gemm_nt(a, W, b, pro=pro), None, None
-        sc, sh, inv, mu = _bn_train(mean, var, P, bufs, bn, M, training, update_running)
+        y, (sc, sh, inv, mu) = _gemm_bn(a, W, b, P, bufs, bn, M, training, update_running, pro=pro)
         ys.append(y); bns.append((sc, sh, inv, mu))
         a, pro = y, (sc, sh, NEG)
     pooled, argmax = ops.maxpool(ys[3], B, N, bns[3][0], bns[3][1], NEG)        # BN + LeakyReLU + max over N fused
@@ -109,7 +138,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
     gval, sums4 = ops.pool_bwd_stats(gpool, pooled, argmax, ys[3], mu4, inv4, NEG)
     C4 = gval.shape[1]
     if need_dparams:
-        grads["fc2.1.weight"] = sums4[C4:].clone(); grads["fc2.1.bias"] = sums4[:C4].clone()
+        grads["fc2.1.weight"] = sums4[C4:]; grads["fc2.1.bias"] = sums4[:C4]
     if ctx["training"]:
         # dense [M,1024] BatchNorm backward of a sparse gradient: never materialised, evaluated on the GEMM operand loads
         dy = ops.sparse_bn_bwd_operand(gval, argmax, ys[3], N, mu4, inv4, P["fc2.1.weight"], sums4, M)
@@ -137,7 +166,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             g, s0, s1 = ops.gemm_nt_bnbwd(dy, _t(W), ys[li - 1], sc, sh, mu, inv, NEG)
             if need_dparams:
                 grads[pbn + ".weight"] = s1; grads[pbn + ".bias"] = s0
-            sums = torch.cat([s0, s1]) if ctx["training"] else torch.zeros(2 * s0.numel(), device=s0.device)
+            sums = _cat2(s0, s1) if ctx["training"] else torch.zeros(2 * s0.numel(), device=s0.device)
             dy = ops.bn_bwd_apply(g, ys[li - 1], mu, inv, P[pbn + ".weight"], sums, M)
             dys[li - 1] = dy; gs[li - 1] = g; sums_all[li - 1] = sums
     dx_cm = None
@@ -164,9 +193,7 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
     rM = 1.0 / M
     q = ops.cm_to_pm(v_dx_cm.contiguous())                       # adjoint of ga_0 [M,3]
     xbarA: List[Optional[Tensor]] = [None] * 4                   # phase-A adjoint on xhat_l
-    sbarA: List[Optional[Tensor]] = [None] * 4                   # phase-A adjoint on invstd_l   [C]
-    xsum0: List[Optional[Tensor]] = [None] * 4                   # sum_m xbarA, sum_m xbarA*xhat (closed form)
-    xsum1: List[Optional[Tensor]] = [None] * 4
+    coeffs: List[Optional[Tensor]] = [None] * 4                  # per-channel phase-A results [4,C] (see ops.bn_dbl_coeffs)
     # ---------------------------------------------------------------- phase A
     for li in range(4):
         conv, bn = D_LAYERS[li]
@@ -182,13 +209,8 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
             gz = gs[li]
         S0, S1 = sums_all[li][:C], sums_all[li][C:]
         U0, U1, Ugz = ops.bn_dbl_stats(u, ys[li], gz, mu, inv)
-        core = Ugz - (U0 * S0 + U1 * S1) * rM
-        grads[bn + ".weight"] = inv * core                                       # adjoint of gamma via gy
-        sbarA[li] = gamma * core
+        coeffs[li] = ops.bn_dbl_coeffs(U0, U1, Ugz, S0, S1, gamma, inv, M)       # [dgammaA | sbarA | sum xbarA | sum xbarA*xhat]
         q, xbarA[li] = ops.bn_dbl_apply(u, ys[li], gz, mu, inv, sc, sh, NEG, gamma, S1, U0, U1, M)
-        gsM = gamma * inv * rM
-        xsum0[li] = -gsM * (U0 * S1 + S0 * U1)
-        xsum1[li] = -2.0 * gsM * (U1 * S1)
     # top: ga_4 = scatter(gpool) -> MLP backward graph in reverse
     t = ops.gather_rows(q, argmax)                                               # adjoint of gpool [B,C4]
     dhs, dout = saved["dhs"], saved["dout"]
@@ -210,15 +232,13 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         C = W.shape[0]
         if abar_g is None:
             X = xbarA[li]
-            T0, T1 = xsum0[li], xsum1[li]
+            sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, None, None)
             grads[bn + ".bias"] = ZERO_GRAD
         else:
             g, s0, s1 = abar_g
             X = ops.col_scale_add(xbarA[li], g, gamma)                           # xbarA + gamma*g
-            T0, T1 = xsum0[li] + gamma * s0, xsum1[li] + gamma * s1
-            grads[bn + ".weight"] = grads[bn + ".weight"] + s1
+            sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, s0, s1)
             grads[bn + ".bias"] = s0
-        sums = torch.cat([T0, T1 + inv * sbarA[li]])
         ybar = ops.bn_bwd_apply(X, ys[li], mu, inv, None, sums, M)
         if li > 0:
             psc, psh, pinv, pmu = bns[li - 1]
@@ -228,7 +248,7 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
             gw = ops.gemm_tn(ybar, ctx["x_pm"])
             if need_dx:
                 dx = ops.pm_to_cm(ops.gemm_nt(ybar, _t(W)), B, N)
-        grads[conv + ".weight"] = (grads[conv + ".weight"] + gw).view_as(P[conv + ".weight"])
+        grads[conv + ".weight"] = ops.axpby(1.0, gw, 1.0, grads[conv + ".weight"]).view_as(P[conv + ".weight"])
         grads[conv + ".bias"] = ZERO_GRAD
     return grads, dx
 
@@ -264,11 +284,7 @@ def edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int,
         bn1 = _bn_train(None, None, P, bufs, pre + ".conv_w.1", E, False, False)
         bnx = _bn_train(None, None, P, bufs, pre + ".conv_x.1", E, False, False)
     W2, b2 = _w2(P[pre + ".conv_w.3.weight"]), P[pre + ".conv_w.3.bias"]
-    if training:
-        h2pre, m2, v2 = ops.gemm_nt(PQR[:, :H], W2, b2, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1), stats=True)
-    else:
-        h2pre, m2, v2 = ops.gemm_nt(PQR[:, :H], W2, b2, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1)), None, None
-    bn2 = _bn_train(m2, v2, P, bufs, pre + ".conv_w.4", E, training, update_running)
+    h2pre, bn2 = _gemm_bn(PQR[:, :H], W2, b2, P, bufs, pre + ".conv_w.4", E, training, update_running, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1))
     T = ops.edge_attend_fwd(h2pre, bn2[0], bn2[1], PQR, idx, bx, bnx[0], bnx[1], NEG)
     Wo = conv_out_weight_pm(P[pre + ".conv_out.weight"])
     out = ops.gemm_nt(T, Wo, P[pre + ".conv_out.bias"])
@@ -291,8 +307,8 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     dT = ops.gemm_nt(dout, _t(ctx["Wo"]))                                         # [M, k*F]
     # softmax * conv_x product, both LeakyReLUs
     g2, gy, sums2, sumsy = ops.edge_attend_bwd(dT, ctx["h2pre"], bn2[0], bn2[1], bn2[3], bn2[2], PQR, idx, bx, bnx[0], bnx[1], bnx[3], bnx[2], NEG)
-    g[pre + ".conv_w.4.weight"] = sums2[F_:].clone(); g[pre + ".conv_w.4.bias"] = sums2[:F_].clone()
-    g[pre + ".conv_x.1.weight"] = sumsy[F_:].clone(); g[pre + ".conv_x.1.bias"] = sumsy[:F_].clone()
+    g[pre + ".conv_w.4.weight"] = sums2[F_:]; g[pre + ".conv_w.4.bias"] = sums2[:F_]
+    g[pre + ".conv_x.1.weight"] = sumsy[F_:]; g[pre + ".conv_x.1.bias"] = sumsy[:F_]
     if not ctx["training"]:
         sums2 = torch.zeros_like(sums2); sumsy = torch.zeros_like(sumsy)
     # conv_w.4 BN backward -> conv_w.3
@@ -302,7 +318,7 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     g[pre + ".conv_w.3.bias"] = ZERO_GRAD if ctx["training"] else ops.colsum(dh2)[0]
     g1, s10, s11 = ops.gemm_nt_bnbwd(dh2, _t(W2), PQR[:, :H], bn1[0], bn1[1], bn1[3], bn1[2], NEG, edge=(idx, b1))
     g[pre + ".conv_w.1.weight"] = s11; g[pre + ".conv_w.1.bias"] = s10
-    sums1 = torch.cat([s10, s11]) if ctx["training"] else torch.zeros(2 * H, device=x.device)
+    sums1 = _cat2(s10, s11) if ctx["training"] else torch.zeros(2 * H, device=x.device)
     # BN backward of conv_w.0 / conv_x.0 outputs fused with the edge -> point reduction
     dPQR = ops.edge_scatter(g1, gy, PQR, idx, csr[0], csr[1], b1, bn1[3], bn1[2], P[pre + ".conv_w.1.weight"], sums1,
                             bx, bnx[3], bnx[2], P[pre + ".conv_x.1.weight"], sumsy)
@@ -399,16 +415,8 @@ def global_forward(P, bufs, a2: Tensor, B: int, N: int, training: bool = True, u
     gmax, garg = ops.maxpool(a2, B, N)
     W0, b0 = P["global_conv.0.weight"], P["global_conv.0.bias"]
     W3, b3 = P["global_conv.3.weight"], P["global_conv.3.bias"]
-    if training:
-        y0, m0, v0 = ops.gemm_nt(gmax, W0, b0, stats=True)
-    else:
-        y0, m0, v0 = ops.gemm_nt(gmax, W0, b0), None, None
-    bn0 = _bn_train(m0, v0, P, bufs, "global_conv.1", B, training, update_running)
-    if training:
-        y3, m3, v3 = ops.gemm_nt(y0, W3, b3, pro=(bn0[0], bn0[1], NEG), stats=True)
-    else:
-        y3, m3, v3 = ops.gemm_nt(y0, W3, b3, pro=(bn0[0], bn0[1], NEG)), None, None
-    bn3 = _bn_train(m3, v3, P, bufs, "global_conv.4", B, training, update_running)
+    y0, bn0 = _gemm_bn(gmax, W0, b0, P, bufs, "global_conv.1", B, training, update_running)
+    y3, bn3 = _gemm_bn(y0, W3, b3, P, bufs, "global_conv.4", B, training, update_running, pro=(bn0[0], bn0[1], NEG))
     return dict(gmax=gmax, garg=garg, y0=y0, bn0=bn0, y3=y3, bn3=bn3, B=B, N=N, training=training)
 
 
@@ -423,13 +431,13 @@ def global_backward(P, gctx, W_g: Tensor, drb: Tensor, da2: Tensor):
     g["tail.0.bias"] = ops.colsum(drb)[0]
     g3, s0, s1 = ops.gemm_nt_bnbwd(drb, _t(W_g), y3, bn3[0], bn3[1], bn3[3], bn3[2], NEG)
     g["global_conv.4.weight"] = s1; g["global_conv.4.bias"] = s0
-    sums = torch.cat([s0, s1]) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
+    sums = _cat2(s0, s1) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
     dy3 = ops.bn_bwd_apply(g3, y3, bn3[3], bn3[2], P["global_conv.4.weight"], sums, B)
     g["global_conv.3.weight"] = ops.gemm_tn(dy3, y0, pro=(bn0[0], bn0[1], NEG))
     g["global_conv.3.bias"] = ZERO_GRAD if tr else ops.colsum(dy3)[0]
     g0, s0, s1 = ops.gemm_nt_bnbwd(dy3, _t(P["global_conv.3.weight"]), y0, bn0[0], bn0[1], bn0[3], bn0[2], NEG)
     g["global_conv.1.weight"] = s1; g["global_conv.1.bias"] = s0
-    sums = torch.cat([s0, s1]) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
+    sums = _cat2(s0, s1) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
     dy0 = ops.bn_bwd_apply(g0, y0, bn0[3], bn0[2], P["global_conv.1.weight"], sums, B)
     g["global_conv.0.weight"] = ops.gemm_tn(dy0, gctx["gmax"])
     g["global_conv.0.bias"] = ZERO_GRAD if tr else ops.colsum(dy0)[0]

@@ -159,8 +159,10 @@ def _finalize(partials: Tensor, groups: int, tpg: int, Cn: int, G: int, mode: in
 
 
 def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, edge=None, rowbias: Optional[Tensor] = None,
-            rows_per_group: int = 0, act: int = ACT_NONE, slope: float = 0.0, stats: bool = False, M: Optional[int] = None):
+            rows_per_group: int = 0, act: int = ACT_NONE, slope: float = 0.0, stats: bool = False, M: Optional[int] = None, bn=None):
     """Y[M,N] = act( pro(A) @ W^T + bias + rowbias[m // rows_per_group] ).
+    bn = (gamma, beta, running_mean | None, running_var | None): train-mode BatchNorm of Y fused behind the GEMM: returns
+         (Y, (scale, shift, invstd, mean)) and updates the running statistics (column statistics in the epilogue + one finalize launch).
     pro  = (scale[K], shift[K], slope): operand a = lrelu(A*scale+shift)            (A_AFFINE_LRELU)
     edge = (idx[M,k], ebias[K]) with pro: rows are edges, a = lrelu((A[j]-A[i]+ebias)*scale+shift)  (A_EDGE)
     stats=True additionally returns (mean[N], biased var[N]) of the pre-activation output over all M rows."""
@@ -194,11 +196,18 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
         a.rowbias = _p(rowbias); a.rows_per_group = rows_per_group; a.ld_rowbias = _ld(rowbias)
     a.act = act; a.act_slope = float(slope)
     part = None
-    if stats:
+    if stats or bn is not None:
         tiles = (M_ + ROW_TILE - 1) // ROW_TILE
         part = torch.empty((tiles, N, 2), dtype=torch.float32, device=A.device)
         a.stats = _p(part)
-    check(_lib.load().spgan_gemm_nt(C.byref(a), _s()), "gemm_nt", M=M_, N=N, K=K, a_mode=a.a_mode)
+    lib = _lib.load()
+    check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt", M=M_, N=N, K=K, a_mode=a.a_mode)
+    if bn is not None:
+        gamma, beta, rm, rv = bn
+        out = torch.empty((4, N), dtype=torch.float32, device=A.device)
+        check(lib.spgan_colstats_finalize_bn(_p(part), part.shape[0], N, M_, 0, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM, _p(rm), _p(rv),
+                                             _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _s()), "colstats_finalize_bn", N=N, M=M_)
+        return Y, (out[0], out[1], out[2], out[3])
     if stats:
         mean, var = _finalize(part, 1, part.shape[0], N, M_, 0)
         return Y, mean[0], var[0]
@@ -233,11 +242,33 @@ class SparseAffine:
 
 def sparse_bn_bwd_operand(gval: Tensor, argmax: Tensor, y: Tensor, N: int, mean, invstd, gamma, sums, count: int) -> SparseAffine:
     """The same quantity bn_bwd_apply_sparse materialises, as a lazy operand (O(C) + O(B*C) preparation only)."""
-    Cn = y.shape[1]
-    coef = gamma * invstd
-    alpha = -(coef * invstd) * (sums[Cn:] / count)
-    beta = -(coef * (sums[:Cn] / count)) - alpha * mean
-    return SparseAffine(y, alpha, beta, gval * coef, argmax, N)
+    B, Cn = gval.shape
+    ab = torch.empty((2, Cn), dtype=torch.float32, device=y.device)
+    cg = torch.empty_like(gval)
+    check(_lib.load().spgan_sparse_bn_prep(_p(gval.contiguous()), _p(_vec(mean, Cn, "mean")), _p(_vec(invstd, Cn, "invstd")), _p(_vec(gamma, Cn, "gamma")),
+                                           _p(_vec(sums, 2 * Cn, "sums")), B, Cn, count, _p(ab[0]), _p(ab[1]), _p(cg), _s()), "sparse_bn_prep")
+    return SparseAffine(y, ab[0], ab[1], cg, argmax, N)
+
+
+def bn_dbl_coeffs(U0, U1, Ugz, S0, S1, gamma, invstd, count: int) -> Tensor:
+    """-> [4, C] = [dgammaA | sbarA | xsum0 | xsum1] (phase A of the double backward, per channel)."""
+    Cn = U0.numel()
+    out = torch.empty((4, Cn), dtype=torch.float32, device=U0.device)
+    v = lambda t, n: _p(_vec(t.contiguous(), Cn, n))
+    check(_lib.load().spgan_bn_dbl_coeffs(v(U0, "U0"), v(U1, "U1"), v(Ugz, "Ugz"), v(S0, "S0"), v(S1, "S1"), v(gamma, "gamma"), v(invstd, "invstd"),
+                                          Cn, count, _p(out), _s()), "bn_dbl_coeffs")
+    return out
+
+
+def bn_dbl_phaseb(coeffs: Tensor, gamma: Tensor, invstd: Tensor, s0: Optional[Tensor], s1: Optional[Tensor]):
+    """-> (sums [2C] for bn_bwd_apply, dgamma [C]) (phase B of the double backward, per channel)."""
+    Cn = gamma.numel()
+    sums = torch.empty((2 * Cn,), dtype=torch.float32, device=gamma.device)
+    dg = torch.empty((Cn,), dtype=torch.float32, device=gamma.device)
+    check(_lib.load().spgan_bn_dbl_phaseb(_p(coeffs), _p(_vec(gamma.contiguous(), Cn, "gamma")), _p(_vec(invstd.contiguous(), Cn, "invstd")),
+                                          _p(None if s0 is None else s0.contiguous()), _p(None if s1 is None else s1.contiguous()), Cn, _p(sums), _p(dg), _s()),
+          "bn_dbl_phaseb")
+    return sums, dg
 
 
 def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float,
@@ -461,10 +492,9 @@ def edge_attend_bwd(dT: Tensor, h2pre: Tensor, sc2, sh2, mean2, inv2, PQR: Tenso
     check(lib.spgan_edge_attend_bwd(_p(dT), _p(h2pre), v(sc2, "sc2"), v(sh2, "sh2"), v(mean2, "mean2"), v(inv2, "inv2"), _p(PQR), PQR.shape[1],
                                     H, F_, _p(idx), M_, k, v(bx, "bx"), v(scx, "scx"), v(shx, "shx"), v(meanx, "meanx"), v(invx, "invx"),
                                     float(slope), _p(g2), _p(gy), _p(part), _s()), "edge_attend_bwd", M=M_, k=k, F=F_)
+    # partial columns are laid out so that the two finalize outputs ARE [sum g2 | sum g2*xhat2] and [sum gy | sum gy*xhaty]
     s0, s1 = _finalize(part, 1, tiles, 2 * F_, tiles * tp, 1, tp)
-    sums2 = torch.cat([s0[0, :F_], s1[0, :F_]])
-    sumsy = torch.cat([s0[0, F_:], s1[0, F_:]])
-    return g2, gy, sums2, sumsy
+    return g2, gy, s0[0], s1[0]
 
 
 def edge_scatter(g1: Tensor, gy: Tensor, PQR: Tensor, idx: Tensor, rowptr: Tensor, src: Tensor, b1, mean1, inv1, gam1, sums1, bx, meanx,

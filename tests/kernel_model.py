@@ -95,7 +95,11 @@ def _operand(A, pro, edge, K):
     return a
 
 
-def gemm_nt(A, W, bias=None, *, pro=None, edge=None, rowbias=None, rows_per_group=0, act=ACT_NONE, slope=0.0, stats=False, M=None):
+def gemm_nt(A, W, bias=None, *, pro=None, edge=None, rowbias=None, rows_per_group=0, act=ACT_NONE, slope=0.0, stats=False, M=None, bn=None):
+    if bn is not None:
+        y, mean, var = gemm_nt(A, W, bias, pro=pro, edge=edge, rowbias=rowbias, rows_per_group=rows_per_group, act=act, slope=slope, stats=True, M=M)
+        gamma, beta, rm, rv = bn
+        return y, bn_prepare(mean, var, gamma, beta, y.shape[0], True, rm, rv)
     N, K = W.shape
     a = _operand(A, pro, edge, K)
     if M is not None:
@@ -132,6 +136,18 @@ def sparse_bn_bwd_operand(gval, argmax, y, N, mean, invstd, gamma, sums, count):
     alpha = -(coef * invstd) * (sums[C:] / count)
     beta = -(coef * (sums[:C] / count)) - alpha * mean
     return SparseAffine(y, alpha, beta, gval * coef, argmax, N)
+
+
+def bn_dbl_coeffs(U0, U1, Ugz, S0, S1, gamma, invstd, count):
+    core = Ugz - (U0 * S0 + U1 * S1) / count
+    gsM = gamma * invstd / count
+    return torch.stack([invstd * core, gamma * core, -gsM * (U0 * S1 + S0 * U1), -2.0 * gsM * (U1 * S1)])
+
+
+def bn_dbl_phaseb(coeffs, gamma, invstd, s0, s1):
+    a0 = s0 if s0 is not None else torch.zeros_like(gamma)
+    a1 = s1 if s1 is not None else torch.zeros_like(gamma)
+    return torch.cat([coeffs[2] + gamma * a0, coeffs[3] + gamma * a1 + invstd * coeffs[1]]), coeffs[0] + a1
 
 
 def _dense(A):

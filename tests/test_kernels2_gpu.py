@@ -143,6 +143,38 @@ def test_double_backward_helpers(ops):
     close(ops.tanh_bwd(u, torch.tanh(y)), km.tanh_bwd(u, torch.tanh(y)), rtol=1e-6)
 
 
+def test_fused_bn_finalize_and_small_kernels(ops):
+    M, N, K = 1000, 96, 64
+    A, W, b = rnd("fb.A", (M, K)), rnd("fb.W", (N, K), 0.2), rnd("fb.b", (N,))
+    gamma, beta = rnd("fb.g", (N,)).abs() + 0.5, rnd("fb.be", (N,), 0.2)
+    rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    rm2, rv2 = rm.clone(), rv.clone()
+    y, st = ops.gemm_nt(A, W, b, bn=(gamma, beta, rm, rv))
+    y2, st2 = km.gemm_nt(A, W, b, bn=(gamma, beta, rm2, rv2))
+    close(y, y2, what="gemm_bn.y")
+    for a, c in zip(st, st2):
+        close(a, c, rtol=2e-5, atol=1e-6, what="gemm_bn.stats")
+    close(rm, rm2, rtol=1e-5, atol=1e-7); close(rv, rv2, rtol=1e-5)
+    y, st = ops.gemm_nt(A, W, b, bn=(gamma, beta, None, None))          # no running stats
+    close(st[0], st2[0], rtol=2e-5)
+    C = 70
+    vec = [rnd("fb.v%d" % i, (C,)) for i in range(7)]
+    vec[5] = vec[5].abs() + 0.5; vec[6] = vec[6].abs() + 0.5
+    co, co2 = ops.bn_dbl_coeffs(*vec, 640), km.bn_dbl_coeffs(*vec, 640)
+    close(co, co2, rtol=1e-5, atol=1e-6, what="bn_dbl_coeffs")
+    s0, s1 = rnd("fb.s0", (C,)), rnd("fb.s1", (C,))
+    for a, c in zip(ops.bn_dbl_phaseb(co2.contiguous(), vec[5], vec[6], s0, s1), km.bn_dbl_phaseb(co2, vec[5], vec[6], s0, s1)):
+        close(a, c, rtol=1e-5, atol=1e-6, what="bn_dbl_phaseb")
+    for a, c in zip(ops.bn_dbl_phaseb(co2.contiguous(), vec[5], vec[6], None, None), km.bn_dbl_phaseb(co2, vec[5], vec[6], None, None)):
+        close(a, c, rtol=1e-5, atol=1e-6, what="bn_dbl_phaseb.none")
+    dsts = [rnd("fb.d%d" % i, (n,)) for i, n in enumerate((5, 1000, 70001, 3))]
+    srcs = [rnd("fb.s%d" % i, (n,)) for i, n in enumerate((5, 1000, 70001, 3))]
+    ref = [d + s for d, s in zip(dsts, srcs)]
+    ops.multi_add(dsts, srcs)
+    for a, c in zip(dsts, ref):
+        assert torch.equal(a, c)
+
+
 def test_adam_and_axpby(ops):
     n = 100003
     p, g = rnd("am.p", (n,)), rnd("am.g", (n,), 0.01)
