@@ -152,7 +152,8 @@ def main():
 
     import spgan
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = spgan.init_process_group_from_env("nccl") if world > 1 else 0
+    rank = spgan.init_process_group_from_env("nccl")        # no-op for a plain single-process launch
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
@@ -163,7 +164,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
 
     G, D = build_models(dev)
-    tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=world > 1)
+    tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=dist_on)
     x, real, zs, alpha = make_inputs(dev, rank, PER_GPU_BATCH)
 
     def one_step(i):
@@ -171,17 +172,17 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
@@ -204,7 +205,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(shapes_s / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

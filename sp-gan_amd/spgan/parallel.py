@@ -21,7 +21,8 @@ from .optim import flatten_module
 def init_process_group_from_env(backend: Optional[str] = None) -> int:
     """torchrun-style rendezvous (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  'nccl' is RCCL on ROCm."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 or dist.is_initialized():
+    force = os.environ.get("SPGAN_FORCE_DIST", "0") == "1" and "RANK" in os.environ      # exercise the RCCL path with one rank
+    if (world <= 1 and not force) or dist.is_initialized():
         return int(os.environ.get("RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
