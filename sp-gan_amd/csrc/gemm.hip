@@ -207,9 +207,28 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   float4 ra[4], rb[BSLOT];
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;  // staging slot: row (tid/8 + 32*i), k offset 4*(tid%8)
 
+  // Sparse addend of the A operand (sp_val/sp_arg, one hit per (shape, column)).  Fast form: when every row of this
+  // tile lies in ONE shape and the loads are 16-byte aligned, each thread fetches the (arg, val) quads of its 4 staging
+  // columns together with the operand loads (in flight under the MFMAs) and patches its own 4x4 values before the LDS
+  // store: no extra barrier, no exposed latency.  Otherwise the staged LDS tile is patched (sfix below).
+  const bool sparse = (AMODE == SPGAN_A_AFFINE_LRELU) && p.sp_val != nullptr;
+  const int sp_b = sparse ? fast_div(m0, p.sp_rows) : 0;
+  const bool sp_reg = sparse && FAST && (fast_div(min(m0 + BM, p.M) - 1, p.sp_rows) == sp_b);
+  int4 spa = make_int4(-1, -1, -1, -1);
+  float4 spv = make_float4(0.f, 0.f, 0.f, 0.f);
+
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = load_a<AMODE, FAST>(p, m0 + lrow + 32 * i, k0 + lc4, vecA);
+    if (sp_reg) {
+      if (k0 + lc4 < p.K) {
+        const size_t off = (size_t)sp_b * p.K + k0 + lc4;
+        spa = *reinterpret_cast<const int4*>(p.sp_arg + off);
+        spv = *reinterpret_cast<const float4*>(p.sp_val + off);
+      } else {
+        spa = make_int4(-1, -1, -1, -1);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < BSLOT; ++i) {
       const int n = n0 + lrow + 32 * i, k = k0 + lc4;
@@ -220,6 +239,16 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   auto sstore = [&](int buf) {
     float* a = As + buf * BM * LDT;
     float* b = Bs + buf * BN * LDT;
+    if (sp_reg) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        ra[i].x += (spa.x == m) ? spv.x : 0.f;
+        ra[i].y += (spa.y == m) ? spv.y : 0.f;
+        ra[i].z += (spa.z == m) ? spv.z : 0.f;
+        ra[i].w += (spa.w == m) ? spv.w : 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) st_row4(&a[(lrow + 32 * i) * LDT + lc4], ra[i]);
 #pragma unroll
@@ -248,7 +277,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 
   // Sparse addend of the A operand (sp_val/sp_arg): per column k at most one row of a shape carries it, so it is
   // patched into the staged LDS tile by BK threads per k-tile instead of being tested on every operand load.
-  const bool sparse = (AMODE == SPGAN_A_AFFINE_LRELU) && p.sp_val != nullptr;
+  const bool sp_lds = sparse && !sp_reg;
   auto sfix = [&](int buf, int k0) {
     if (tid < BK && k0 + tid < p.K) {
       float* a = As + buf * BM * LDT;
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   gload(0);
   sstore(0);
   __syncthreads();
-  if (sparse) {
+  if (sp_lds) {
     sfix(0, 0);
     __syncthreads();
   }
@@ -275,7 +304,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       compute(kt & 1);
       if (kt + 1 < nk) sstore((kt + 1) & 1);  // other buffer: its last readers passed the previous barrier
       __syncthreads();
-      if (sparse && kt + 1 < nk) {
+      if (sp_lds && kt + 1 < nk) {
         sfix((kt + 1) & 1, (kt + 1) * BK);
         __syncthreads();
       }
@@ -285,7 +314,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       if (kt + 1 < nk) {
         sstore(0);
         __syncthreads();
-        if (sparse) {
+        if (sp_lds) {
           sfix(0, (kt + 1) * BK);
           __syncthreads();
         }
