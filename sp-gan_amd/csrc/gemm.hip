@@ -470,12 +470,89 @@ void launch_nt_cfg(const spgan_gemm_nt_args& a, hipStream_t s) {
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+// ------------------------------------------------------------------------------------------ gemm_nt, M <= 64
+// The per-shape linears (D's fc head, G's global_conv: M = batch size, Discriminator.py:83-95, Generator.py:119-126)
+// have no use for 128-row MFMA tiles: one workgroup would walk all of K alone (87 us for 32x512x1024).  Here a
+// workgroup owns SC = 4 output columns, its 256 threads split K (one float4 per thread and step), the rows go
+// through the registers in chunks of SR = 16, and the 64 partial dot products of a thread are summed over the
+// workgroup in a fixed order (a butterfly that halves the value count per step, then the 4 waves through LDS).
+constexpr int SR = 16, SC = 4;
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_args p) {
+  __shared__ float red[4][SR * SC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * SC;
+  for (int mc = 0; mc < p.M; mc += SR) {
+    float v[SR * SC];
+#pragma unroll
+    for (int i = 0; i < SR * SC; ++i) v[i] = 0.f;
+    for (int k = tid * 4; k < p.K; k += 1024) {
+      float4 w[SC];
+#pragma unroll
+      for (int c = 0; c < SC; ++c)
+        w[c] = (n0 + c < p.N) ? *reinterpret_cast<const float4*>(p.W + (size_t)(n0 + c) * p.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AMODE == SPGAN_A_AFFINE_LRELU) {
+        sc = *reinterpret_cast<const float4*>(p.p_scale + k);
+        sh = *reinterpret_cast<const float4*>(p.p_shift + k);
+      }
+#pragma unroll
+      for (int r = 0; r < SR; ++r) {
+        if (mc + r < p.M) {
+          float4 a = *reinterpret_cast<const float4*>(p.A + (size_t)(mc + r) * p.lda + k);
+          if (AMODE == SPGAN_A_AFFINE_LRELU) a = affine_lrelu4(a, sc, sh, p.p_slope);
+#pragma unroll
+          for (int c = 0; c < SC; ++c)
+            v[r * SC + c] = fmaf(a.w, w[c].w, fmaf(a.z, w[c].z, fmaf(a.y, w[c].y, fmaf(a.x, w[c].x, v[r * SC + c]))));
+        }
+      }
+    }
+    // wave total of value i ends up in lane i
+#pragma unroll
+    for (int half = SR * SC / 2; half >= 1; half >>= 1) {
+      const bool up = (lane & half) != 0;
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        const float keep = up ? v[i + half] : v[i];
+        const float send = up ? v[i] : v[i + half];
+        v[i] = keep + __shfl_xor(send, half);
+      }
+    }
+    red[wave][lane] = v[0];
+    __syncthreads();
+    if (tid < SR * SC) {
+      const float acc = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      const int row = mc + tid / SC, col = n0 + tid % SC;
+      if (row < p.M && col < p.N) {
+        float o;
+        if (EPI == SPGAN_EPI_LINEAR) {
+          o = acc + (p.bias ? p.bias[col] : 0.f);
+          if (p.rowbias) o += p.rowbias[(size_t)(row / p.rows_per_group) * p.ld_rowbias + col];
+          if (p.act == SPGAN_ACT_LRELU) o = lrelu_f(o, p.act_slope);
+          else if (p.act == SPGAN_ACT_TANH) o = tanhf(o);
+        } else {
+          o = acc * lrelu_mask(p.ref[(size_t)row * p.ld_ref + col], p.b_slope);
+        }
+        p.Y[(size_t)row * p.ldy + col] = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int AMODE, int EPI>
 int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   bool fast = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A) && al16(a.W);
   if (AMODE != SPGAN_A_PLAIN) fast = fast && al16(a.p_scale) && al16(a.p_shift);
   if (AMODE == SPGAN_A_EDGE) fast = fast && al16(a.e_bias);
   if (a.sp_val) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
+  if constexpr (AMODE != SPGAN_A_EDGE && (EPI == SPGAN_EPI_LINEAR || EPI == SPGAN_EPI_MASK_OUT)) {
+    if (a.M <= 64 && fast && !a.stats && !a.sp_val) {
+      hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(cdiv(a.N, SC)), dim3(256), 0, s, a);
+      return spgan_launch_status();
+    }
+  }
   if (a.N > 64) {
     if (a.K >= 512) {  // long K: double-buffered LDS, one barrier per k-tile
       if (fast) launch_nt_cfg<AMODE, EPI, 0, 1, 1>(a, s);
