@@ -571,7 +571,7 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------ gemm_tn
-constexpr int TKM = 16;  // m-rows per staging step
+constexpr int TKM = 32;  // m-rows per staging step (= MFMA k-steps * 2 between two barriers)
 constexpr int TA = 128;  // output rows (columns of A) per workgroup
 
 // Column-constant prologue parameters of this thread's staging slot (hoisted out of the m loop).
@@ -634,9 +634,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging: A tile 16 x 128 floats = 512 float4 -> 2 per thread; B tile 16 x TB -> TB/64 per thread (TB=32: half the threads)
+  // staging: A tile TKM x 128 floats -> ASLOTS float4 per thread; B tile TKM x TB -> BSLOTS per thread
+  constexpr int ASLOTS = TKM * TA / 4 / 256;
   constexpr int BSLOTS = (TKM * TB / 4 + 255) / 256;
-  float4 ra[2], rb[BSLOTS];
+  float4 ra[ASLOTS], rb[BSLOTS];
   ColPro cp[BSLOTS];
 #pragma unroll
   for (int i = 0; i < BSLOTS; ++i) {
@@ -651,23 +652,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
   }
   // optional A-side prologue (per column of A; the column of a staging slot is fixed -> parameters hoisted)
   const bool apro = p.a_scale != nullptr;
-  float4 asc[2], ash[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int col = a0 + ((tid + 256 * i) & 31) * 4;
-    asc[i] = ash[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 asc = make_float4(0.f, 0.f, 0.f, 0.f), ash = asc;  // slot i covers column (tid + 256 i) & 31: the same for every i
+  {
+    const int col = a0 + (tid & 31) * 4;
     if (apro && col < p.Na) {
-      asc[i] = ld4(p.a_scale + col, false, col, p.Na);
-      ash[i] = ld4(p.a_shift + col, false, col, p.Na);
+      asc = ld4(p.a_scale + col, false, col, p.Na);
+      ash = ld4(p.a_shift + col, false, col, p.Na);
     }
   }
   auto gload = [&](int mb) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < ASLOTS; ++i) {
       const int s = tid + 256 * i, r = s >> 5, c = (s & 31) * 4;
       const int m = mb + r, col = a0 + c;
       float4 v = (m < mend && col < p.Na) ? ld4(p.A + (size_t)m * p.lda + col, vecA, col, p.Na) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (apro && m < mend && col < p.Na) v = mask_tail(affine_lrelu4(v, asc[i], ash[i], 1.0f), col, p.Na);
+      if (apro && m < mend && col < p.Na) v = mask_tail(affine_lrelu4(v, asc, ash, 1.0f), col, p.Na);
       ra[i] = v;
     }
 #pragma unroll
@@ -682,7 +681,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
     float* a = As + buf * TKM * LDA_;
     float* b = Bs + buf * TKM * LDB_;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < ASLOTS; ++i) {
       const int s = tid + 256 * i, r = s >> 5, c = (s & 31) * 4;
       *reinterpret_cast<float4*>(&a[r * LDA_ + c]) = ra[i];
     }
@@ -732,29 +731,43 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
         const int col = b0 + (wn * TJ + j) * 32 + l31;
         if (row < p.Na && col < p.Nb) out[(size_t)row * p.Nb + col] = acc[i][j][r];
       }
-  // Sparse addend of A (a_sp_val/a_sp_arg): each (shape b, A-column a) contributes val * pro(B)[arg[b,a], :] to output
-  // row a -- a handful of rank-1 updates per workgroup, applied to its own partial tile after the dense part.
-  if (p.a_sp_val && mbeg < mend) {
-    __syncthreads();  // the partial tile written above is visible to the whole workgroup
-    const int b_lo = fast_div(mbeg, p.a_sp_rows), b_hi = fast_div(mend - 1, p.a_sp_rows);
-    const int col = b0 + (tid & (TB - 1));
+}
+
+// Sparse addend of A (a_sp_val/a_sp_arg): each (shape b, A-column a) contributes val[b,a] * pro(B)[arg[b,a], :] to output
+// row a.  That is a gather of one B row per (b, a) -- done here after the dense reduction, one workgroup per A-column,
+// shapes in ascending order (deterministic), the gathers of a chunk of shapes all in flight together.
+template <int BMODE>
+__global__ __launch_bounds__(256) void tn_sparse_rows_kernel(const spgan_gemm_tn_args p) {
+  __shared__ int sarg[256];
+  __shared__ float sval[256];
+  const int a = blockIdx.x, tid = threadIdx.x;
+  const int shapes = (p.M + p.a_sp_rows - 1) / p.a_sp_rows;
+  for (int c0 = 0; c0 < p.Nb; c0 += 256) {
+    const int col = c0 + tid;
     const bool cok = col < p.Nb;
     float sc = 1.f, sh = 0.f;
     if (BMODE == SPGAN_A_AFFINE_LRELU && cok) { sc = p.p_scale[col]; sh = p.p_shift[col]; }
-    for (int ac = tid / TB; ac < TA; ac += 256 / TB) {
-      const int arow = a0 + ac;
-      if (arow >= p.Na || !cok) continue;
-      float add = 0.f;
-      for (int b = b_lo; b <= b_hi; ++b) {
-        const int r = p.a_sp_arg[(size_t)b * p.Na + arow];
-        if (r >= mbeg && r < mend) {
-          float bv = p.B[(size_t)r * p.ldb + col];
+    float add = 0.f;
+    for (int s0 = 0; s0 < shapes; s0 += 256) {
+      __syncthreads();
+      if (s0 + tid < shapes) {
+        const int r = p.a_sp_arg[(size_t)(s0 + tid) * p.Na + a];
+        sarg[tid] = (r >= 0 && r < p.M) ? r : -1;
+        sval[tid] = p.a_sp_val[(size_t)(s0 + tid) * p.Na + a];
+      }
+      __syncthreads();
+      const int n = min(256, shapes - s0);
+      if (cok) {
+#pragma unroll 8
+        for (int b = 0; b < n; ++b) {
+          const int r = sarg[b];
+          float bv = (r >= 0) ? p.B[(size_t)r * p.ldb + col] : 0.f;
           if (BMODE == SPGAN_A_AFFINE_LRELU) bv = lrelu_f(fmaf(bv, sc, sh), p.p_slope);
-          add = fmaf(p.a_sp_val[(size_t)b * p.Na + arow], bv, add);
+          add = (r >= 0) ? fmaf(sval[b], bv, add) : add;
         }
       }
-      if (add != 0.f) out[(size_t)arow * p.Nb + col] += add;
     }
+    if (cok) p.C[(size_t)a * p.ldc + col] += add;
   }
 }
 
@@ -808,6 +821,9 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 2>), grid, dim3(256), 0, s, a, rows);
   const int n = a.Na * a.Nb;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
+  if constexpr (BMODE != SPGAN_A_EDGE) {
+    if (a.a_sp_val) hipLaunchKernelGGL((tn_sparse_rows_kernel<BMODE>), dim3(a.Na), dim3(256), 0, s, a);
+  }
   return spgan_launch_status();
 }
 
