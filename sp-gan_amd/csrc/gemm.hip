@@ -91,50 +91,8 @@ __device__ __forceinline__ void sparse_add4(float4& v, const float* __restrict__
   if (n > 3 && arg[off + 3] == m) v.w += val[off + 3];
 }
 
-// FAST: every operand pointer is 16-byte aligned, leading dimensions and K are multiples of 4 -> unconditional float4 loads
-// (no divergent scalar tail path; the loads of a k-tile issue back to back and stay in flight under the MFMAs).
-template <int AMODE, int FAST>
-__device__ __forceinline__ float4 load_a(const spgan_gemm_nt_args& p, int m, int k, bool vecA) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (m >= p.M || k >= p.K) return v;
-  if (FAST) {
-    const float4* A4 = reinterpret_cast<const float4*>(p.A + k);
-    if (AMODE == SPGAN_A_PLAIN) return A4[(size_t)m * (p.lda >> 2)];
-    const float4 sc = *reinterpret_cast<const float4*>(p.p_scale + k), sh = *reinterpret_cast<const float4*>(p.p_shift + k);
-    if (AMODE == SPGAN_A_AFFINE_LRELU) return affine_lrelu4(A4[(size_t)m * (p.lda >> 2)], sc, sh, p.p_slope);
-    const int i = fast_div(m, p.e_k);
-    const int j = p.e_idx[m];
-    const float4 vj = A4[(size_t)j * (p.lda >> 2)], vi = A4[(size_t)i * (p.lda >> 2)];
-    const float4 eb = *reinterpret_cast<const float4*>(p.e_bias + k);
-    v.x = (vj.x - vi.x) + eb.x;
-    v.y = (vj.y - vi.y) + eb.y;
-    v.z = (vj.z - vi.z) + eb.z;
-    v.w = (vj.w - vi.w) + eb.w;
-    return affine_lrelu4(v, sc, sh, p.p_slope);
-  }
-  if (AMODE == SPGAN_A_PLAIN) {
-    return ld4(p.A + (size_t)m * p.lda + k, vecA, k, p.K);
-  } else if (AMODE == SPGAN_A_AFFINE_LRELU) {
-    v = ld4(p.A + (size_t)m * p.lda + k, vecA, k, p.K);
-    float4 sc = ld4(p.p_scale + k, false, k, p.K);
-    float4 sh = ld4(p.p_shift + k, false, k, p.K);
-    return mask_tail(affine_lrelu4(v, sc, sh, p.p_slope), k, p.K);
-  } else {  // SPGAN_A_EDGE
-    const int i = fast_div(m, p.e_k);
-    const int j = p.e_idx[m];
-    float4 vj = ld4(p.A + (size_t)j * p.lda + k, vecA, k, p.K);
-    float4 vi = ld4(p.A + (size_t)i * p.lda + k, vecA, k, p.K);
-    float4 eb = ld4(p.e_bias + k, false, k, p.K);
-    float4 sc = ld4(p.p_scale + k, false, k, p.K);
-    float4 sh = ld4(p.p_shift + k, false, k, p.K);
-    v.x = (vj.x - vi.x) + eb.x;
-    v.y = (vj.y - vi.y) + eb.y;
-    v.z = (vj.z - vi.z) + eb.z;
-    v.w = (vj.w - vi.w) + eb.w;
-    return mask_tail(affine_lrelu4(v, sc, sh, p.p_slope), k, p.K);
-  }
-}
-
+// FAST (template flag below): every operand pointer is 16-byte aligned, leading dimensions and K are multiples of 4 ->
+// unconditional float4 loads (no divergent scalar tail path; the loads of a k-tile issue back to back).
 __device__ __forceinline__ void st_row4(float* p, float4 v) {  // rows are 8-byte aligned (LDT even)
   *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
   *reinterpret_cast<float2*>(p + 2) = make_float2(v.z, v.w);
@@ -204,25 +162,62 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Staging registers hold the RAW loads of the tile in flight; every prologue transform (affine + LeakyReLU, the edge
+  // difference, the sparse addend) is applied in sstore, i.e. after this tile's MFMAs were issued.  Transforming at load
+  // time would put a vmcnt wait in front of the MFMAs and expose the whole HBM/L2 latency once per k-tile.
   float4 ra[4], rb[BSLOT];
+  float4 ra2[AMODE == SPGAN_A_EDGE ? 4 : 1];  // EDGE: the centre rows
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f), peb = psh;
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;  // staging slot: row (tid/8 + 32*i), k offset 4*(tid%8)
+  int rowA[4], rowC[4];                            // operand row (EDGE: neighbour j) and centre row i; -1 = out of range
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    rowA[i] = rowC[i] = -1;
+    if (m < p.M) {
+      rowA[i] = (AMODE == SPGAN_A_EDGE) ? p.e_idx[m] : m;
+      if (AMODE == SPGAN_A_EDGE) rowC[i] = fast_div(m, p.e_k);
+    }
+  }
 
   // Sparse addend of the A operand (sp_val/sp_arg, one hit per (shape, column)).  Fast form: when every row of this
   // tile lies in ONE shape and the loads are 16-byte aligned, each thread fetches the (arg, val) quads of its 4 staging
-  // columns together with the operand loads (in flight under the MFMAs) and patches its own 4x4 values before the LDS
-  // store: no extra barrier, no exposed latency.  Otherwise the staged LDS tile is patched (sfix below).
+  // columns together with the operand loads and patches its own 4x4 values before the LDS store.  Otherwise the staged
+  // LDS tile is patched (sfix below).
   const bool sparse = (AMODE == SPGAN_A_AFFINE_LRELU) && p.sp_val != nullptr;
   const int sp_b = sparse ? fast_div(m0, p.sp_rows) : 0;
   const bool sp_reg = sparse && FAST && (fast_div(min(m0 + BM, p.M) - 1, p.sp_rows) == sp_b);
   int4 spa = make_int4(-1, -1, -1, -1);
   float4 spv = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  auto ldrow = [&](const float* base, int ld, int row, int k, bool vec) -> float4 {
+    if (FAST) return reinterpret_cast<const float4*>(base + k)[(size_t)row * (ld >> 2)];
+    return ld4(base + (size_t)row * ld + k, vec, k, p.K);
+  };
+  auto ldpar = [&](const float* q, int k) -> float4 {
+    if (FAST) return *reinterpret_cast<const float4*>(q + k);
+    return ld4(q + k, false, k, p.K);
+  };
   auto gload = [&](int k0) {
+    const int k = k0 + lc4;
+    const bool kok = k < p.K;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = load_a<AMODE, FAST>(p, m0 + lrow + 32 * i, k0 + lc4, vecA);
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AMODE == SPGAN_A_EDGE) ra2[i] = ra[i];
+      if (rowA[i] >= 0 && kok) {
+        ra[i] = ldrow(p.A, p.lda, rowA[i], k, vecA);
+        if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(p.A, p.lda, rowC[i], k, vecA);
+      }
+    }
+    if (AMODE != SPGAN_A_PLAIN && kok) {
+      psc = ldpar(p.p_scale, k);
+      psh = ldpar(p.p_shift, k);
+      if (AMODE == SPGAN_A_EDGE) peb = ldpar(p.e_bias, k);
+    }
     if (sp_reg) {
-      if (k0 + lc4 < p.K) {
-        const size_t off = (size_t)sp_b * p.K + k0 + lc4;
+      if (kok) {
+        const size_t off = (size_t)sp_b * p.K + k;
         spa = *reinterpret_cast<const int4*>(p.sp_arg + off);
         spv = *reinterpret_cast<const float4*>(p.sp_val + off);
       } else {
@@ -231,14 +226,31 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
     }
 #pragma unroll
     for (int i = 0; i < BSLOT; ++i) {
-      const int n = n0 + lrow + 32 * i, k = k0 + lc4;
-      if (FAST) rb[i] = (n < p.N && k < p.K) ? reinterpret_cast<const float4*>(p.W + k)[(size_t)n * (p.ldw >> 2)] : make_float4(0.f, 0.f, 0.f, 0.f);
-      else rb[i] = (n < p.N && k < p.K) ? ld4(p.W + (size_t)n * p.ldw + k, vecW, k, p.K) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int n = n0 + lrow + 32 * i;
+      rb[i] = (n < p.N && kok) ? ldrow(p.W, p.ldw, n, k, vecW) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, int k0) {
     float* a = As + buf * BM * LDT;
     float* b = Bs + buf * BN * LDT;
+    if (AMODE != SPGAN_A_PLAIN) {
+      const int k = k0 + lc4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (rowA[i] >= 0 && k < p.K) {
+          float4 v = ra[i];
+          if (AMODE == SPGAN_A_EDGE) {
+            v.x = (v.x - ra2[i].x) + peb.x;
+            v.y = (v.y - ra2[i].y) + peb.y;
+            v.z = (v.z - ra2[i].z) + peb.z;
+            v.w = (v.w - ra2[i].w) + peb.w;
+          }
+          v = affine_lrelu4(v, psc, psh, p.p_slope);
+          if (!FAST) v = mask_tail(v, k, p.K);
+          ra[i] = v;
+        }
+      }
+    }
     if (sp_reg) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 
   const int nk = (p.K + BK - 1) / BK;
   gload(0);
-  sstore(0);
+  sstore(0, 0);
   __syncthreads();
   if (sp_lds) {
     sfix(0, 0);
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
     if (kt + 1 < nk) gload((kt + 1) * BK);  // next tile's HBM/L2 loads fly under this tile's MFMAs
     if (DB) {
       compute(kt & 1);
-      if (kt + 1 < nk) sstore((kt + 1) & 1);  // other buffer: its last readers passed the previous barrier
+      if (kt + 1 < nk) sstore((kt + 1) & 1, (kt + 1) * BK);  // other buffer: its last readers passed the previous barrier
       __syncthreads();
       if (sp_lds && kt + 1 < nk) {
         sfix((kt + 1) & 1, (kt + 1) * BK);
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       compute(0);
       __syncthreads();
       if (kt + 1 < nk) {
-        sstore(0);
+        sstore(0, (kt + 1) * BK);
         __syncthreads();
         if (sp_lds) {
           sfix(0, (kt + 1) * BK);
@@ -579,31 +591,9 @@ struct ColPro {
   float4 sc, sh, eb;
 };
 
-template <int BMODE>
-__device__ __forceinline__ float4 load_b_tn(const spgan_gemm_tn_args& p, int m, int c, bool vecB, const ColPro& cp) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (m >= p.M || c >= p.Nb) return v;
-  if (BMODE == SPGAN_A_PLAIN) {
-    return ld4(p.B + (size_t)m * p.ldb + c, vecB, c, p.Nb);
-  } else if (BMODE == SPGAN_A_AFFINE_LRELU) {
-    v = ld4(p.B + (size_t)m * p.ldb + c, vecB, c, p.Nb);
-    return mask_tail(affine_lrelu4(v, cp.sc, cp.sh, p.p_slope), c, p.Nb);
-  } else {
-    const int i = fast_div(m, p.e_k);
-    const int j = p.e_idx[m];
-    float4 vj = ld4(p.B + (size_t)j * p.ldb + c, vecB, c, p.Nb);
-    float4 vi = ld4(p.B + (size_t)i * p.ldb + c, vecB, c, p.Nb);
-    v.x = (vj.x - vi.x) + cp.eb.x;
-    v.y = (vj.y - vi.y) + cp.eb.y;
-    v.z = (vj.z - vi.z) + cp.eb.z;
-    v.w = (vj.w - vi.w) + cp.eb.w;
-    return mask_tail(affine_lrelu4(v, cp.sc, cp.sh, p.p_slope), c, p.Nb);
-  }
-}
-
 // grid: (tilesA * tilesB, splits).  Each workgroup reduces `rows_per_split` m-rows into one
 // TA x TB partial tile written to ws[split][Na][Nb].  CFG as in gemm_nt: TB = 128 / 64 / 32.
-template <int BMODE, int CFG>
+template <int BMODE, int CFG, int FAST>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p, int rows_per_split) {
   using G = Geo<CFG>;
   constexpr int TI = G::TI, TJ = G::TJ;
@@ -660,42 +650,84 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
       ash = ld4(p.a_shift + col, false, col, p.Na);
     }
   }
+  // As in gemm_nt the staging registers keep RAW loads; the prologues run in sstore, after the MFMAs of the current tile.
+  float4 rb2[BMODE == SPGAN_A_EDGE ? BSLOTS : 1];
+  // FAST (16-byte aligned operands, Na/Nb/lda/ldb multiples of 4): straight-line float4 loads from clamped addresses --
+  // no divergent tail handling, all loads of a tile issue back to back; out-of-range slots are zeroed in sstore.
   auto gload = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < ASLOTS; ++i) {
       const int s = tid + 256 * i, r = s >> 5, c = (s & 31) * 4;
       const int m = mb + r, col = a0 + c;
-      float4 v = (m < mend && col < p.Na) ? ld4(p.A + (size_t)m * p.lda + col, vecA, col, p.Na) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (apro && m < mend && col < p.Na) v = mask_tail(affine_lrelu4(v, asc, ash, 1.0f), col, p.Na);
-      ra[i] = v;
+      if (FAST) ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)min(m, p.M - 1) * p.lda + (col < p.Na ? col : 0));
+      else ra[i] = (m < mend && col < p.Na) ? ld4(p.A + (size_t)m * p.lda + col, vecA, col, p.Na) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < BSLOTS; ++i) {
       const int s = tid + 256 * i;
-      const int r = s / (TB / 4), c = (s % (TB / 4)) * 4;
+      const int r = s / (TB / 4), c = b0 + (s % (TB / 4)) * 4;
       const int m = mb + r;
-      rb[i] = (r < TKM && m < mend) ? load_b_tn<BMODE>(p, m, b0 + c, vecB, cp[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (FAST) {
+        if (r < TKM) {
+          const int mc = min(m, p.M - 1), cc = c < p.Nb ? c : 0;
+          if (BMODE == SPGAN_A_EDGE) {
+            rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)p.e_idx[mc] * p.ldb + cc);
+            rb2[i] = *reinterpret_cast<const float4*>(p.B + (size_t)fast_div(mc, p.e_k) * p.ldb + cc);
+          } else {
+            rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)mc * p.ldb + cc);
+          }
+        }
+      } else {
+        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BMODE == SPGAN_A_EDGE) rb2[i] = rb[i];
+        if (r < TKM && m < mend && c < p.Nb) {
+          if (BMODE == SPGAN_A_EDGE) {
+            rb[i] = ld4(p.B + (size_t)p.e_idx[m] * p.ldb + c, vecB, c, p.Nb);
+            rb2[i] = ld4(p.B + (size_t)fast_div(m, p.e_k) * p.ldb + c, vecB, c, p.Nb);
+          } else {
+            rb[i] = ld4(p.B + (size_t)m * p.ldb + c, vecB, c, p.Nb);
+          }
+        }
+      }
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, int mb) {
     float* a = As + buf * TKM * LDA_;
     float* b = Bs + buf * TKM * LDB_;
 #pragma unroll
     for (int i = 0; i < ASLOTS; ++i) {
       const int s = tid + 256 * i, r = s >> 5, c = (s & 31) * 4;
-      *reinterpret_cast<float4*>(&a[r * LDA_ + c]) = ra[i];
+      float4 v = ra[i];
+      const bool ok = mb + r < mend && a0 + c < p.Na;
+      if (apro && ok) v = mask_tail(affine_lrelu4(v, asc, ash, 1.0f), a0 + c, p.Na);
+      if (FAST && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&a[r * LDA_ + c]) = v;
     }
 #pragma unroll
     for (int i = 0; i < BSLOTS; ++i) {
       const int s = tid + 256 * i;
       const int r = s / (TB / 4), c = (s % (TB / 4)) * 4;
-      if (r < TKM) *reinterpret_cast<float4*>(&b[r * LDB_ + c]) = rb[i];
+      if (r < TKM) {
+        float4 v = rb[i];
+        const bool ok = mb + r < mend && b0 + c < p.Nb;
+        if (FAST && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BMODE != SPGAN_A_PLAIN && ok) {
+          if (BMODE == SPGAN_A_EDGE) {
+            v.x = (v.x - rb2[i].x) + cp[i].eb.x;
+            v.y = (v.y - rb2[i].y) + cp[i].eb.y;
+            v.z = (v.z - rb2[i].z) + cp[i].eb.z;
+            v.w = (v.w - rb2[i].w) + cp[i].eb.w;
+          }
+          v = mask_tail(affine_lrelu4(v, cp[i].sc, cp[i].sh, p.p_slope), b0 + c, p.Nb);
+        }
+        *reinterpret_cast<float4*>(&b[r * LDB_ + c]) = v;
+      }
     }
   };
 
   if (mbeg < mend) {
     gload(mbeg);
-    sstore(0);
+    sstore(0, mbeg);
     __syncthreads();
     int buf = 0;
     for (int mb = mbeg; mb < mend; mb += TKM, buf ^= 1) {
@@ -715,7 +747,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
 #pragma unroll
           for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
-      if (more) sstore(buf ^ 1);
+      if (more) sstore(buf ^ 1, mb + TKM);
       __syncthreads();
     }
   }
@@ -816,9 +848,16 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
   tn_plan(a.M, a.Na, a.Nb, &splits, &rows);
   const int TB = tn_tb(a.Nb);
   const dim3 grid(cdiv(a.Na, TA) * cdiv(a.Nb, TB), splits);
-  if (TB == 128) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 0>), grid, dim3(256), 0, s, a, rows);
-  else if (TB == 64) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 1>), grid, dim3(256), 0, s, a, rows);
-  else hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 2>), grid, dim3(256), 0, s, a, rows);
+  const bool fast = (a.Na % 4 == 0) && (a.Nb % 4 == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && al16(a.A) && al16(a.B);
+  if (fast) {
+    if (TB == 128) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 0, 1>), grid, dim3(256), 0, s, a, rows);
+    else if (TB == 64) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 1, 1>), grid, dim3(256), 0, s, a, rows);
+    else hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 2, 1>), grid, dim3(256), 0, s, a, rows);
+  } else {
+    if (TB == 128) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 0, 0>), grid, dim3(256), 0, s, a, rows);
+    else if (TB == 64) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 1, 0>), grid, dim3(256), 0, s, a, rows);
+    else hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 2, 0>), grid, dim3(256), 0, s, a, rows);
+  }
   const int n = a.Na * a.Nb;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
   if constexpr (BMODE != SPGAN_A_EDGE) {
