@@ -28,6 +28,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+// internal operand mode: A_AFFINE_LRELU with the sparse addend (sp_val != NULL) -- its own instantiation, so the plain
+// affine kernels do not carry the addend's registers and LDS-patch code
+constexpr int A_AFFINE_SPARSE = 3;
+
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDT = BK + 2;  // 34
@@ -169,30 +173,33 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   float4 ra2[AMODE == SPGAN_A_EDGE ? 4 : 1];  // EDGE: the centre rows
   float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f), peb = psh;
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;  // staging slot: row (tid/8 + 32*i), k offset 4*(tid%8)
-  int rowA[4], rowC[4];                            // operand row (EDGE: neighbour j) and centre row i; -1 = out of range
+  // Element offset of the operand row (EDGE: neighbour j) and centre row i of each staging slot, 32-bit (checked on the
+  // host: M*lda, N*ldw < 2^32) so the loads use the scalar-base + 32-bit-offset addressing form.  Rows >= M are clamped
+  // to M-1: what they stage only reaches accumulator rows >= M, which no epilogue reads -- so the aligned path loads
+  // unconditionally.  Likewise weight rows >= N only feed output columns >= N.
+  unsigned offA[4], offC[AMODE == SPGAN_A_EDGE ? 4 : 1], offW[BSLOT];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + lrow + 32 * i;
-    rowA[i] = rowC[i] = -1;
-    if (m < p.M) {
-      rowA[i] = (AMODE == SPGAN_A_EDGE) ? p.e_idx[m] : m;
-      if (AMODE == SPGAN_A_EDGE) rowC[i] = fast_div(m, p.e_k);
-    }
+    const int m = min(m0 + lrow + 32 * i, p.M - 1);
+    offA[i] = (unsigned)((AMODE == SPGAN_A_EDGE) ? p.e_idx[m] : m) * (unsigned)p.lda;
+    if (AMODE == SPGAN_A_EDGE) offC[i] = (unsigned)fast_div(m, p.e_k) * (unsigned)p.lda;
   }
+#pragma unroll
+  for (int i = 0; i < BSLOT; ++i) offW[i] = (unsigned)min(n0 + lrow + 32 * i, p.N - 1) * (unsigned)p.ldw;
 
   // Sparse addend of the A operand (sp_val/sp_arg, one hit per (shape, column)).  Fast form: when every row of this
   // tile lies in ONE shape and the loads are 16-byte aligned, each thread fetches the (arg, val) quads of its 4 staging
   // columns together with the operand loads and patches its own 4x4 values before the LDS store.  Otherwise the staged
   // LDS tile is patched (sfix below).
-  const bool sparse = (AMODE == SPGAN_A_AFFINE_LRELU) && p.sp_val != nullptr;
+  constexpr bool sparse = AMODE == A_AFFINE_SPARSE;
   const int sp_b = sparse ? fast_div(m0, p.sp_rows) : 0;
   const bool sp_reg = sparse && FAST && (fast_div(min(m0 + BM, p.M) - 1, p.sp_rows) == sp_b);
   int4 spa = make_int4(-1, -1, -1, -1);
   float4 spv = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto ldrow = [&](const float* base, int ld, int row, int k, bool vec) -> float4 {
-    if (FAST) return reinterpret_cast<const float4*>(base + k)[(size_t)row * (ld >> 2)];
-    return ld4(base + (size_t)row * ld + k, vec, k, p.K);
+  auto ldrow = [&](const float* base, unsigned off, int k, bool vec) -> float4 {
+    if (FAST) return *reinterpret_cast<const float4*>(base + (off + (unsigned)k));
+    return ld4(base + (off + (unsigned)k), vec, k, p.K);
   };
   auto ldpar = [&](const float* q, int k) -> float4 {
     if (FAST) return *reinterpret_cast<const float4*>(q + k);
@@ -201,13 +208,34 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   auto gload = [&](int k0) {
     const int k = k0 + lc4;
     const bool kok = k < p.K;
+    if (FAST) {  // straight-line: every load of the tile issues back to back; k >= K slots are zeroed in sstore
+      const int kc = kok ? k : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = ldrow(p.A, offA[i], kc, true);
+        if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(p.A, offC[i], kc, true);
+      }
+      if (AMODE != SPGAN_A_PLAIN) {
+        psc = ldpar(p.p_scale, kc);
+        psh = ldpar(p.p_shift, kc);
+        if (AMODE == SPGAN_A_EDGE) peb = ldpar(p.e_bias, kc);
+      }
+      if (sp_reg) {
+        const size_t off = (size_t)sp_b * p.K + kc;
+        spa = *reinterpret_cast<const int4*>(p.sp_arg + off);
+        spv = *reinterpret_cast<const float4*>(p.sp_val + off);
+      }
+#pragma unroll
+      for (int i = 0; i < BSLOT; ++i) rb[i] = ldrow(p.W, offW[i], kc, true);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (AMODE == SPGAN_A_EDGE) ra2[i] = ra[i];
-      if (rowA[i] >= 0 && kok) {
-        ra[i] = ldrow(p.A, p.lda, rowA[i], k, vecA);
-        if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(p.A, p.lda, rowC[i], k, vecA);
+      if (kok) {
+        ra[i] = ldrow(p.A, offA[i], k, vecA);
+        if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(p.A, offC[i], k, vecA);
       }
     }
     if (AMODE != SPGAN_A_PLAIN && kok) {
@@ -215,40 +243,27 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       psh = ldpar(p.p_shift, k);
       if (AMODE == SPGAN_A_EDGE) peb = ldpar(p.e_bias, k);
     }
-    if (sp_reg) {
-      if (kok) {
-        const size_t off = (size_t)sp_b * p.K + k;
-        spa = *reinterpret_cast<const int4*>(p.sp_arg + off);
-        spv = *reinterpret_cast<const float4*>(p.sp_val + off);
-      } else {
-        spa = make_int4(-1, -1, -1, -1);
-      }
-    }
 #pragma unroll
-    for (int i = 0; i < BSLOT; ++i) {
-      const int n = n0 + lrow + 32 * i;
-      rb[i] = (n < p.N && kok) ? ldrow(p.W, p.ldw, n, k, vecW) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < BSLOT; ++i) rb[i] = kok ? ldrow(p.W, offW[i], k, vecW) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto sstore = [&](int buf, int k0) {
     float* a = As + buf * BM * LDT;
     float* b = Bs + buf * BN * LDT;
+    const int k = k0 + lc4;
+    const bool kok = k < p.K;
     if (AMODE != SPGAN_A_PLAIN) {
-      const int k = k0 + lc4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (rowA[i] >= 0 && k < p.K) {
-          float4 v = ra[i];
-          if (AMODE == SPGAN_A_EDGE) {
-            v.x = (v.x - ra2[i].x) + peb.x;
-            v.y = (v.y - ra2[i].y) + peb.y;
-            v.z = (v.z - ra2[i].z) + peb.z;
-            v.w = (v.w - ra2[i].w) + peb.w;
-          }
-          v = affine_lrelu4(v, psc, psh, p.p_slope);
-          if (!FAST) v = mask_tail(v, k, p.K);
-          ra[i] = v;
+        float4 v = ra[i];
+        if (AMODE == SPGAN_A_EDGE) {
+          v.x = (v.x - ra2[i].x) + peb.x;
+          v.y = (v.y - ra2[i].y) + peb.y;
+          v.z = (v.z - ra2[i].z) + peb.z;
+          v.w = (v.w - ra2[i].w) + peb.w;
         }
+        v = affine_lrelu4(v, psc, psh, p.p_slope);
+        if (!FAST) v = mask_tail(v, k, p.K);
+        ra[i] = v;
       }
     }
     if (sp_reg) {
@@ -260,6 +275,12 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
         ra[i].z += (spa.z == m) ? spv.z : 0.f;
         ra[i].w += (spa.w == m) ? spv.w : 0.f;
       }
+    }
+    if (FAST && !kok) {  // K % 32 != 0: the tail slots of the last k-tile
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < BSLOT; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) st_row4(&a[(lrow + 32 * i) * LDT + lc4], ra[i]);
@@ -558,8 +579,8 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   bool fast = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A) && al16(a.W);
   if (AMODE != SPGAN_A_PLAIN) fast = fast && al16(a.p_scale) && al16(a.p_shift);
   if (AMODE == SPGAN_A_EDGE) fast = fast && al16(a.e_bias);
-  if (a.sp_val) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
-  if constexpr (AMODE != SPGAN_A_EDGE && (EPI == SPGAN_EPI_LINEAR || EPI == SPGAN_EPI_MASK_OUT)) {
+  if (AMODE == A_AFFINE_SPARSE) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
+  if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE_SPARSE && (EPI == SPGAN_EPI_LINEAR || EPI == SPGAN_EPI_MASK_OUT)) {
     if (a.M <= 64 && fast && !a.stats && !a.sp_val) {
       hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(cdiv(a.N, SC)), dim3(256), 0, s, a);
       return spgan_launch_status();
@@ -872,6 +893,7 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   SPGAN_CHECK_ARG(a && a->A && a->W && a->Y && a->M > 0 && a->N > 0 && a->K > 0);
   SPGAN_CHECK_ARG(a->lda >= a->K && a->ldw >= a->K && a->ldy >= a->N);
+  SPGAN_CHECK_ARG((uint64_t)a->M * (uint64_t)a->lda < (1ull << 32) && (uint64_t)a->N * (uint64_t)a->ldw < (1ull << 32));  // 32-bit operand offsets
   if (a->a_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
   if (a->a_mode == SPGAN_A_EDGE) SPGAN_CHECK_ARG(a->e_idx && a->e_bias && a->e_k > 0);
   if (a->rowbias) SPGAN_CHECK_ARG(a->rows_per_group > 0 && a->ld_rowbias >= a->N);
@@ -879,7 +901,8 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   switch (a->epi_mode) {
     case SPGAN_EPI_LINEAR:
       if (a->a_mode == SPGAN_A_PLAIN) return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_LINEAR>(*a, s);
-      if (a->a_mode == SPGAN_A_AFFINE_LRELU) return launch_nt<SPGAN_A_AFFINE_LRELU, SPGAN_EPI_LINEAR>(*a, s);
+      if (a->a_mode == SPGAN_A_AFFINE_LRELU)
+        return a->sp_val ? launch_nt<A_AFFINE_SPARSE, SPGAN_EPI_LINEAR>(*a, s) : launch_nt<SPGAN_A_AFFINE_LRELU, SPGAN_EPI_LINEAR>(*a, s);
       if (a->a_mode == SPGAN_A_EDGE) return launch_nt<SPGAN_A_EDGE, SPGAN_EPI_LINEAR>(*a, s);
       return SPGAN_EINVAL;
     case SPGAN_EPI_MASK_OUT:
@@ -887,7 +910,8 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
       return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_MASK_OUT>(*a, s);
     case SPGAN_EPI_BNBWD:
       SPGAN_CHECK_ARG(a->a_mode != SPGAN_A_EDGE && a->ref && a->ld_ref >= a->N && a->b_scale && a->b_shift && a->b_mean && a->b_invstd);
-      if (a->a_mode == SPGAN_A_AFFINE_LRELU) return launch_nt<SPGAN_A_AFFINE_LRELU, SPGAN_EPI_BNBWD>(*a, s);
+      if (a->a_mode == SPGAN_A_AFFINE_LRELU)
+        return a->sp_val ? launch_nt<A_AFFINE_SPARSE, SPGAN_EPI_BNBWD>(*a, s) : launch_nt<SPGAN_A_AFFINE_LRELU, SPGAN_EPI_BNBWD>(*a, s);
       return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_BNBWD>(*a, s);
     case SPGAN_EPI_EDGE_BNBWD:
       SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->ref && a->ld_ref >= a->N && a->b_scale && a->b_shift && a->b_mean && a->b_invstd &&
