@@ -48,11 +48,16 @@ __device__ __forceinline__ float edge_pre(const float* __restrict__ PQR, int ld,
   return (PQR[(size_t)i * ld + H + F + f] + PQR[(size_t)j * ld + H + f]) + bias;
 }
 
-__global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict__ PQR, int ld, const int32_t* __restrict__ idx, int M, int k,
+// KT > 0: compile-time k -- a point's neighbour indices are wave-uniform (scalar loads), its centre value is read once
+// and the k neighbour gathers are all in flight together.
+template <int KT>
+__global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict__ PQR, int ld, const int32_t* __restrict__ idx, int M, int k_,
                                                          int H, int F, const float* __restrict__ b1, const float* __restrict__ bx,
                                                          float* __restrict__ part) {
+  constexpr int KU = KT > 0 ? KT : 1;
+  const int k = KT > 0 ? KT : k_;
   __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p0 = blockIdx.x * ES_PT;
   const int np = min(ES_PT, M - p0);
   const int CH = H + F;
@@ -67,12 +72,33 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
     float s1 = 0.f, s2 = 0.f, v0 = 0.f;
     if (ok) {
       v0 = edge_pre(PQR, ld, H, F, c, p0, idx[(size_t)p0 * k], bias);
-      for (int p = w; p < np; p += 4) {
-        const int i = p0 + p;
-        for (int r = 0; r < k; ++r) {
-          const float d = edge_pre(PQR, ld, H, F, c, i, idx[(size_t)i * k + r], bias) - v0;
-          s1 += d;
-          s2 = fmaf(d, d, s2);
+      if (KT > 0) {
+        const int colI = c < H ? c : c + F, colJ = c;  // centre column: P | R, neighbour column: P | Q
+        const float sgn = c < H ? -1.f : 1.f;
+        for (int p = w; p < np; p += 4) {
+          const int i = p0 + p;
+          int jn[KU];
+#pragma unroll
+          for (int r = 0; r < KU; ++r) jn[r] = idx[(size_t)i * KT + r];
+          const float vi = sgn * PQR[(size_t)i * ld + colI];
+          float vj[KU];
+#pragma unroll
+          for (int r = 0; r < KU; ++r) vj[r] = PQR[(size_t)jn[r] * ld + colJ];
+#pragma unroll
+          for (int r = 0; r < KU; ++r) {
+            const float d = ((c < H ? vj[r] + vi : vi + vj[r]) + bias) - v0;  // (P_j - P_i) + b1  |  (R_i + Q_j) + bx
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+          }
+        }
+      } else {
+        for (int p = w; p < np; p += 4) {
+          const int i = p0 + p;
+          for (int r = 0; r < k; ++r) {
+            const float d = edge_pre(PQR, ld, H, F, c, i, idx[(size_t)i * k + r], bias) - v0;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+          }
         }
       }
     }
@@ -373,32 +399,67 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
 //   dh1[e,c] = gam1*inv1*(g1[e,c] - S1[c]/E - xhat1[e,c]*S1x[c]/E)        xhat1 from (P_j - P_i) + b1
 //   dyp[e,f] = gamx*invx*(gy[e,f] - Sy[f]/E - xhaty[e,f]*Syx[f]/E)        xhaty from (R_i + Q_j) + bx
 //   dP[j] = sum_{e in in(j)} dh1[e] - sum_r dh1[(j,r)];  dQ[j] = sum_{e in in(j)} dyp[e];  dR[i] = sum_r dyp[(i,r)]
+// One wave per point, lanes over channels.  The loads of a point's k out-edges (KT > 0: compile-time k) and of its
+// in-edges (chunks of 4) are issued together before they are consumed -- a serial edge loop leaves one row in flight per
+// wave and ran at 1.7 TB/s; sums are still taken in edge order (deterministic).
+template <int KT>
 __global__ __launch_bounds__(256) void edge_scatter_kernel(
     const float* __restrict__ g1, const float* __restrict__ gy, const float* __restrict__ PQR, int ld, int H, int F,
-    const int32_t* __restrict__ idx, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, int M, int k,
+    const int32_t* __restrict__ idx, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, int M, int k_,
     const float* __restrict__ b1, const float* __restrict__ mean1, const float* __restrict__ inv1, const float* __restrict__ gam1,
     const float* __restrict__ sums1, const float* __restrict__ bx, const float* __restrict__ meanx, const float* __restrict__ invx,
     const float* __restrict__ gamx, const float* __restrict__ sumsx, float rE, float* __restrict__ dPQR) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int j = blockIdx.x * 4 + w;
+  constexpr int KU = KT > 0 ? KT : 1;
+  const int k = KT > 0 ? KT : k_;
+  const int lane = threadIdx.x & 63;
+  const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // wave-uniform: scalar index loads
   if (j >= M) return;
   const int t0 = rowptr[j], t1 = rowptr[j + 1];
+  int jo[KU];  // out-edge neighbours
+  if (KT > 0) {
+#pragma unroll
+    for (int r = 0; r < KU; ++r) jo[r] = idx[j * KT + r];
+  }
+  // channel c of segment `seg` (0: P/g1, width H; 1: Q,R/gy, width F)
   for (int c = lane; c < H; c += 64) {
     const float bb = b1[c], mu = mean1[c], iv = inv1[c];
     const float coef = gam1[c] * iv, a0 = sums1[c] * rE, a1 = sums1[H + c] * rE;
     const float Pj = PQR[(size_t)j * ld + c];
     float acc = 0.f;
-    for (int r = 0; r < k; ++r) {  // out-edges: j is the centre
-      const int e = j * k + r;
-      const int jj = idx[e];
-      const float xh = (((PQR[(size_t)jj * ld + c] - Pj) + bb) - mu) * iv;
-      acc -= coef * (g1[(size_t)e * H + c] - a0 - xh * a1);
+    if (KT > 0) {
+      float pv[KU], gv[KU];
+#pragma unroll
+      for (int r = 0; r < KU; ++r) {
+        pv[r] = PQR[(size_t)jo[r] * ld + c];
+        gv[r] = g1[(size_t)(j * KT + r) * H + c];
+      }
+#pragma unroll
+      for (int r = 0; r < KU; ++r) {
+        const float xh = (((pv[r] - Pj) + bb) - mu) * iv;
+        acc -= coef * (gv[r] - a0 - xh * a1);
+      }
+    } else {
+      for (int r = 0; r < k; ++r) {  // out-edges: j is the centre
+        const int e = j * k + r;
+        const float xh = (((PQR[(size_t)idx[e] * ld + c] - Pj) + bb) - mu) * iv;
+        acc -= coef * (g1[(size_t)e * H + c] - a0 - xh * a1);
+      }
     }
-    for (int t = t0; t < t1; ++t) {  // in-edges: j is the neighbour
-      const int e = src[t];
-      const int i = e / k;
-      const float xh = (((Pj - PQR[(size_t)i * ld + c]) + bb) - mu) * iv;
-      acc += coef * (g1[(size_t)e * H + c] - a0 - xh * a1);
+    for (int t = t0; t < t1; t += 4) {  // in-edges: j is the neighbour
+      float pv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = src[min(t + u, t1 - 1)];
+        pv[u] = PQR[(size_t)(e / k) * ld + c];
+        gv[u] = g1[(size_t)e * H + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (t + u < t1) {
+          const float xh = (((Pj - pv[u]) + bb) - mu) * iv;
+          acc += coef * (gv[u] - a0 - xh * a1);
+        }
+      }
     }
     dPQR[(size_t)j * ld + c] = acc;
   }
@@ -407,17 +468,40 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
     const float coef = gamx[f] * iv, a0 = sumsx[f] * rE, a1 = sumsx[F + f] * rE;
     const float Rj = PQR[(size_t)j * ld + H + F + f], Qj = PQR[(size_t)j * ld + H + f];
     float accR = 0.f, accQ = 0.f;
-    for (int r = 0; r < k; ++r) {
-      const int e = j * k + r;
-      const int jj = idx[e];
-      const float xh = (((Rj + PQR[(size_t)jj * ld + H + f]) + bb) - mu) * iv;
-      accR += coef * (gy[(size_t)e * F + f] - a0 - xh * a1);
+    if (KT > 0) {
+      float qv[KU], gv[KU];
+#pragma unroll
+      for (int r = 0; r < KU; ++r) {
+        qv[r] = PQR[(size_t)jo[r] * ld + H + f];
+        gv[r] = gy[(size_t)(j * KT + r) * F + f];
+      }
+#pragma unroll
+      for (int r = 0; r < KU; ++r) {
+        const float xh = (((Rj + qv[r]) + bb) - mu) * iv;
+        accR += coef * (gv[r] - a0 - xh * a1);
+      }
+    } else {
+      for (int r = 0; r < k; ++r) {
+        const int e = j * k + r;
+        const float xh = (((Rj + PQR[(size_t)idx[e] * ld + H + f]) + bb) - mu) * iv;
+        accR += coef * (gy[(size_t)e * F + f] - a0 - xh * a1);
+      }
     }
-    for (int t = t0; t < t1; ++t) {
-      const int e = src[t];
-      const int i = e / k;
-      const float xh = (((PQR[(size_t)i * ld + H + F + f] + Qj) + bb) - mu) * iv;
-      accQ += coef * (gy[(size_t)e * F + f] - a0 - xh * a1);
+    for (int t = t0; t < t1; t += 4) {
+      float rv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = src[min(t + u, t1 - 1)];
+        rv[u] = PQR[(size_t)(e / k) * ld + H + F + f];
+        gv[u] = gy[(size_t)e * F + f];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (t + u < t1) {
+          const float xh = (((rv[u] + Qj) + bb) - mu) * iv;
+          accQ += coef * (gv[u] - a0 - xh * a1);
+        }
+      }
     }
     dPQR[(size_t)j * ld + H + f] = accQ;
     dPQR[(size_t)j * ld + H + F + f] = accR;
@@ -443,7 +527,8 @@ extern "C" int spgan_edge_attend_bwd_tile_points(void) { return EB_PT; }
 extern "C" int spgan_edge_stats(const float* PQR, int ld, const int32_t* idx, int M, int k, int H, int F, const float* b1, const float* bx,
                                 float* partials, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(PQR && idx && b1 && bx && partials && M > 0 && k > 0 && H > 0 && F > 0 && ld >= H + 2 * F);
-  hipLaunchKernelGGL(edge_stats_kernel, dim3(cdiv(M, ES_PT)), dim3(256), 0, (hipStream_t)s_, PQR, ld, idx, M, k, H, F, b1, bx, partials);
+  if (k == 10) hipLaunchKernelGGL(edge_stats_kernel<10>, dim3(cdiv(M, ES_PT)), dim3(256), 0, (hipStream_t)s_, PQR, ld, idx, M, k, H, F, b1, bx, partials);
+  else hipLaunchKernelGGL(edge_stats_kernel<0>, dim3(cdiv(M, ES_PT)), dim3(256), 0, (hipStream_t)s_, PQR, ld, idx, M, k, H, F, b1, bx, partials);
   return spgan_launch_status();
 }
 
@@ -489,7 +574,11 @@ extern "C" int spgan_edge_scatter(const float* g1, const float* gy, const float*
                                   const float* invx, const float* gamx, const float* sumsx, float* dPQR, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(g1 && gy && PQR && idx && rowptr && src && b1 && mean1 && inv1 && gam1 && sums1 && bx && meanx && invx && gamx && sumsx && dPQR);
   SPGAN_CHECK_ARG(M > 0 && k > 0 && ld >= H + 2 * F);
-  hipLaunchKernelGGL(edge_scatter_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, gy, PQR, ld, H, F, idx, rowptr, src, M, k, b1,
-                     mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
+  if (k == 10)
+    hipLaunchKernelGGL(edge_scatter_kernel<10>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, gy, PQR, ld, H, F, idx, rowptr, src, M, k,
+                       b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
+  else
+    hipLaunchKernelGGL(edge_scatter_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, gy, PQR, ld, H, F, idx, rowptr, src, M, k,
+                       b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
   return spgan_launch_status();
 }
