@@ -100,7 +100,8 @@ typedef struct spgan_gemm_nt_args {
   int act; float act_slope;
   float* stats;               /* NULL or partials [ceil(M/128), N, 2]: (sum, centred M2) per 128-row tile (pre-activation) */
   /* EPI_MASK_OUT:   y = acc * (ref[m,n] > 0 ? 1 : slope)                 (LeakyReLU backward from its output)
-   * EPI_BNBWD:      z = ref*b_scale[n]+b_shift[n]; g = acc*(z>0?1:slope); xhat=(ref-b_mean[n])*b_invstd[n];
+   * EPI_BNBWD:      z = ref*b_scale[n]+b_shift[n]; g = (acc + bias[n] + rowbias[m / rows_per_group, n])*(z>0?1:slope)
+   *                 (bias / rowbias optional); xhat=(ref-b_mean[n])*b_invstd[n];
    *                 y = g; stats partials [tilesM, N, 2] = (sum g, sum g*xhat)   (plain sums)
    * EPI_EDGE_BNBWD: same with ref[e,n] := (P[idx[e],n] - P[i,n] + e_bias2[n])  (P = ref, ld_ref) */
   const float* ref; int ld_ref;
@@ -133,6 +134,24 @@ typedef struct spgan_gemm_tn_args {
 
 size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb);
 int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s);
+
+/* Row-sparse products with the max-pool gradient pattern S (Discriminator.py:104 backward): one (value, row) pair per
+ * shape b and channel c, val/arg [B, Cs], arg = global row (b*rows + local).  They let the backward of the layer in front
+ * of the pool collapse algebraically (DESIGN.md "collapsed L4 backward"): with dz = alpha*y + beta + S and y = a.W^T + b,
+ *   dz.W      = a.(W^T diag(alpha) W) + (alpha*b + beta).W + S.W          -- a [M,Cin]x[Cin,Cin] GEMM instead of [M,Cout]x[Cout,Cin]
+ *   dz^T.a    = diag(alpha).W.(a^T a) + (alpha*b + beta) (x) colsum(a) + S^T.a
+ * spgan_sparse_rows_nt: E[m, n]  = sum_{c: arg[b,c]==m} val[b,c] * W[c, n]      E [B*rows, N] is fully written (zero rows too)
+ * spgan_sparse_rows_tn: C[c, n] += sum_b val[b,c] * pro(Bm)[arg[b,c], n]         pro = lrelu(x*p_scale[n]+p_shift[n], p_slope) or none
+ * Both sum in ascending c / b order (deterministic). */
+int spgan_sparse_rows_nt(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* W, int ldw, int N, float* E, int lde,
+                         spgan_stream_t s);
+int spgan_sparse_rows_tn(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* Bm, int ldb, int Nb,
+                         const float* p_scale, const float* p_shift, float p_slope, float* C, int ldc, spgan_stream_t s);
+/* out[m,c] = lrelu(X[m,c]*scale[c] + shift[c], slope)   (train-mode BatchNorm + LeakyReLU output, Discriminator.py:57-64) */
+int spgan_affine_act(const float* X, int ldx, size_t M, int C, const float* scale, const float* shift, float slope, float* out, spgan_stream_t s);
+/* out[r,c] = a[r]*X[r,c] + (a[r]*b[r] + d[r])*v[c]   (v == NULL: first term only); weight-shaped [R,C] tensors */
+int spgan_rowscale_outer(const float* X, int ldx, int R, int C, const float* a, const float* b, const float* d, const float* v, float* out,
+                         int ldo, spgan_stream_t s);
 
 /* Column reductions over row groups (group = G consecutive rows; M % G == 0).  Partials are
  * [groups * ceil(G/128)][C][2] floats: one (a, b) pair per 128-row tile and column -- the format

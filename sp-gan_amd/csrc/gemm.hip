@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       const float sc = cok ? p.b_scale[col] : 0.f, sh = cok ? p.b_shift[col] : 0.f;
       const float mu = cok ? p.b_mean[col] : 0.f, inv = cok ? p.b_invstd[col] : 0.f;
       const float eb = (EPI == SPGAN_EPI_EDGE_BNBWD && cok) ? p.e_bias2[col] : 0.f;
+      const float bia = (cok && p.bias) ? p.bias[col] : 0.f;
       s0[j] = 0.f;
       s1[j] = 0.f;
 #pragma unroll
@@ -456,7 +457,9 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
               y = p.ref[(size_t)row * p.ld_ref + col];
             }
             const float z = fmaf(y, sc, sh);
-            const float g = acc[i][j][r] * lrelu_mask(z, p.b_slope);
+            float a = acc[i][j][r] + bia;
+            if (p.rowbias) a += p.rowbias[(size_t)fast_div(row, p.rows_per_group) * p.ld_rowbias + col];
+            const float g = a * lrelu_mask(z, p.b_slope);
             const float xh = (y - mu) * inv;
             p.Y[(size_t)row * p.ldy + col] = g;
             s0[j] += g;
@@ -824,6 +827,52 @@ __global__ __launch_bounds__(256) void tn_sparse_rows_kernel(const spgan_gemm_tn
   }
 }
 
+// E[m, :] = sum over the channels c whose arg[b,c] == m of val[b,c] * W[c, :]   (b = m / rows): the row-sparse product
+// S.W of the max-pool gradient pattern, written densely (zero rows included) so that a GEMM epilogue can add it as a
+// per-row bias.  Workgroup = (shape, 256-row chunk); a wave owns every 4th row of the chunk, finds the row's channels
+// with ballots over the LDS copy of arg[b,:] (ascending c: deterministic sums) and accumulates W rows, lanes over columns.
+__global__ __launch_bounds__(256) void sparse_rows_nt_kernel(const float* __restrict__ val, const int32_t* __restrict__ arg, int rows, int Cs,
+                                                             const float* __restrict__ W, int ldw, int N, float* __restrict__ E, int lde) {
+  extern __shared__ int sm_i[];
+  int* sarg = sm_i;                                   // [Cs]
+  float* sval = reinterpret_cast<float*>(sm_i + Cs);  // [Cs]
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < Cs; c += 256) {
+    sarg[c] = arg[(size_t)b * Cs + c] - b * rows;  // local row
+    sval[c] = val[(size_t)b * Cs + c];
+  }
+  __syncthreads();
+  const int r0 = blockIdx.x * 256;
+  for (int r = r0 + wave; r < min(rows, r0 + 256); r += 4) {
+    float* e = E + ((size_t)b * rows + r) * lde;
+    for (int n0 = 0; n0 < N; n0 += 256) {
+      const int n = n0 + lane * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int c0 = 0; c0 < Cs; c0 += 64) {
+        const int c = c0 + lane;
+        unsigned long long hit = __ballot(c < Cs && sarg[c] == r);
+        while (hit) {
+          const int cc = c0 + __ffsll((long long)hit) - 1;
+          hit &= hit - 1;
+          const float v = sval[cc];
+          const float* w = W + (size_t)cc * ldw + n;
+          if (n + 3 < N) {
+            acc.x = fmaf(v, w[0], acc.x); acc.y = fmaf(v, w[1], acc.y); acc.z = fmaf(v, w[2], acc.z); acc.w = fmaf(v, w[3], acc.w);
+          } else {
+            if (n < N) acc.x = fmaf(v, w[0], acc.x);
+            if (n + 1 < N) acc.y = fmaf(v, w[1], acc.y);
+            if (n + 2 < N) acc.z = fmaf(v, w[2], acc.z);
+          }
+        }
+      }
+      if (n < N) e[n] = acc.x;
+      if (n + 1 < N) e[n + 1] = acc.y;
+      if (n + 2 < N) e[n + 2] = acc.z;
+      if (n + 3 < N) e[n + 3] = acc.w;
+    }
+  }
+}
+
 // Fixed-order sum over the split partials: 64 consecutive outputs x 4 split-slices per workgroup.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int Na, int Nb, float* __restrict__ C,
                                                             int ldc, float beta) {
@@ -920,6 +969,26 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
     default:
       return SPGAN_EINVAL;
   }
+}
+
+extern "C" int spgan_sparse_rows_nt(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* W, int ldw, int N, float* E,
+                                    int lde, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(val && arg && W && E && B > 0 && rows > 0 && Cs > 0 && N > 0 && ldw >= N && lde >= N && Cs <= 8192);
+  hipLaunchKernelGGL(sparse_rows_nt_kernel, dim3(cdiv(rows, 256), B), dim3(256), (size_t)Cs * 8, (hipStream_t)s_, val, arg, rows, Cs, W, ldw, N, E, lde);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_sparse_rows_tn(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* Bm, int ldb, int Nb,
+                                    const float* p_scale, const float* p_shift, float p_slope, float* C, int ldc, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(val && arg && Bm && C && B > 0 && rows > 0 && Cs > 0 && Nb > 0 && ldb >= Nb && ldc >= Nb && (!p_scale == !p_shift));
+  spgan_gemm_tn_args a = {};
+  a.B = Bm; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.M = B * rows; a.Na = Cs; a.Nb = Nb;
+  a.p_scale = p_scale; a.p_shift = p_shift; a.p_slope = p_slope;
+  a.a_sp_val = val; a.a_sp_arg = arg; a.a_sp_rows = rows;
+  if (p_scale) hipLaunchKernelGGL((tn_sparse_rows_kernel<SPGAN_A_AFFINE_LRELU>), dim3(Cs), dim3(256), 0, (hipStream_t)s_, a);
+  else hipLaunchKernelGGL((tn_sparse_rows_kernel<SPGAN_A_PLAIN>), dim3(Cs), dim3(256), 0, (hipStream_t)s_, a);
+  return spgan_launch_status();
 }
 
 extern "C" size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb) {

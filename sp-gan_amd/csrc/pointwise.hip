@@ -238,6 +238,41 @@ __global__ void col_scale_add_kernel(const float* __restrict__ a, const float* _
   if (t < M * C) out[t] = fmaf(gamma[t % C], b[t], a[t]);
 }
 
+// out[m,c] = lrelu(X[m,c]*scale[c] + shift[c], slope): a train-mode BatchNorm + LeakyReLU output materialised
+// (Discriminator.py:57-64); 4 channels per thread when the layout allows.
+template <int VEC>
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ X, int ldx, size_t M, int C, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float slope, float* __restrict__ out) {
+  const size_t per = (size_t)(C / VEC);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * per) return;
+  const size_t m = t / per;
+  const int c = (int)(t % per) * VEC;
+  if (VEC == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(X + m * ldx + c);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    float4 o;
+    o.x = lrelu_f(fmaf(v.x, sc.x, sh.x), slope);
+    o.y = lrelu_f(fmaf(v.y, sc.y, sh.y), slope);
+    o.z = lrelu_f(fmaf(v.z, sc.z, sh.z), slope);
+    o.w = lrelu_f(fmaf(v.w, sc.w, sh.w), slope);
+    *reinterpret_cast<float4*>(out + m * C + c) = o;
+  } else {
+    out[m * C + c] = lrelu_f(fmaf(X[m * ldx + c], scale[c], shift[c]), slope);
+  }
+}
+
+// out[r,c] = a[r]*X[r,c] + (a[r]*b[r] + d[r])*v[c]   (v == NULL: first term only).  Small [R,C] weight-shaped tensors.
+__global__ void rowscale_outer_kernel(const float* __restrict__ X, int ldx, int R, int C, const float* __restrict__ a, const float* __restrict__ b,
+                                      const float* __restrict__ d, const float* __restrict__ v, float* __restrict__ out, int ldo) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= R * C) return;
+  const int r = t / C, c = t % C;
+  float o = a[r] * X[(size_t)r * ldx + c];
+  if (v) o = fmaf(fmaf(a[r], b[r], d[r]), v[c], o);
+  out[(size_t)r * ldo + c] = o;
+}
+
 __global__ void axpby_kernel(float a, const float* __restrict__ x, float b, float* __restrict__ y, size_t n) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) y[t] = a * x[t] + (b == 0.f ? 0.f : b * y[t]);
@@ -397,6 +432,23 @@ extern "C" int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s_)
   int bx = cdiv(nmax, 256 * 4);
   if (bx > 64) bx = 64;
   hipLaunchKernelGGL(multi_add_kernel, dim3(bx, a->count), dim3(256), 0, (hipStream_t)s_, *a);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_affine_act(const float* X, int ldx, size_t M, int C, const float* scale, const float* shift, float slope, float* out,
+                                spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(X && scale && shift && out && M > 0 && C > 0 && ldx >= C);
+  const bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out) |
+                                                     reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0;
+  if (v4) hipLaunchKernelGGL(affine_act_kernel<4>, dim3(cdiv(M * (size_t)(C / 4), 256)), dim3(256), 0, (hipStream_t)s_, X, ldx, M, C, scale, shift, slope, out);
+  else hipLaunchKernelGGL(affine_act_kernel<1>, dim3(cdiv(M * (size_t)C, 256)), dim3(256), 0, (hipStream_t)s_, X, ldx, M, C, scale, shift, slope, out);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_rowscale_outer(const float* X, int ldx, int R, int C, const float* a, const float* b, const float* d, const float* v,
+                                    float* out, int ldo, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(X && a && out && R > 0 && C > 0 && ldx >= C && ldo >= C && (!v || (b && d)));
+  hipLaunchKernelGGL(rowscale_outer_kernel, dim3(cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)s_, X, ldx, R, C, a, b, d, v, out, ldo);
   return spgan_launch_status();
 }
 

@@ -77,6 +77,10 @@ SIGNATURES = {
     "spgan_gemm_nt": (I, [C.POINTER(GemmNTArgs), P]),
     "spgan_gemm_tn_ws_bytes": (SZ, [I, I, I]),
     "spgan_gemm_tn": (I, [C.POINTER(GemmTNArgs), P]),
+    "spgan_sparse_rows_nt": (I, [P, P, I, I, I, P, I, I, P, I, P]),
+    "spgan_sparse_rows_tn": (I, [P, P, I, I, I, P, I, I, P, P, F, P, I, P]),
+    "spgan_affine_act": (I, [P, I, SZ, I, P, P, F, P, P]),
+    "spgan_rowscale_outer": (I, [P, I, I, I, P, P, P, P, P, I, P]),
     "spgan_colreduce_ws_bytes": (SZ, [I, I, I]),
     "spgan_colstats_finalize": (I, [P, I, I, I, I, I, I, P, P, P]),
     "spgan_colstats_finalize_bn": (I, [P, I, I, I, I, P, P, F, F, P, P, P, P, P, P, P]),

@@ -152,6 +152,30 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
     for li in (3, 2, 1, 0):
         conv, bn = D_LAYERS[li]
         W = _w2(P[conv + ".weight"])
+        if li == 3 and isinstance(dy, ops.SparseAffine):
+            # Collapsed backward of the 256->1024 layer: dz4 = alpha*y4 + beta + S is affine in y4 = a3.W^T + b4, so
+            #   dz4.W    = a3.(W^T diag(alpha) W) + (alpha*b4 + beta).W + S.W            [M,256]x[256,256] instead of [M,1024]x[1024,256]
+            #   dz4^T.a3 = diag(alpha).W.(a3^T a3) + (alpha*b4 + beta) (x) colsum(a3) + S^T.a3
+            # -- a quarter of the FLOPs, and y4 is not read at all.
+            sc, sh, inv, mu = bns[2]
+            alpha, beta, b4 = dy.alpha, dy.beta, P[conv + ".bias"]
+            a3 = ops.affine_act(ys[2], sc, sh, NEG)
+            if need_dparams:
+                gram = ops.gemm_tn(a3, a3)                                        # [256,256]
+                dW = ops.rowscale_outer(ops.gemm_nt(W, gram), alpha, b4, beta, ops.colsum(a3)[0])
+                ops.sparse_rows_tn(dy.sp_val, dy.sp_arg, N, a3, dW)
+                grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
+                grads[conv + ".bias"] = ZERO_GRAD
+            G4 = ops.gemm_tn(W, ops.rowscale_outer(W, alpha))                     # W^T diag(alpha) W
+            cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(alpha, beta, 1.0))[0]  # (alpha*b4 + beta).W
+            E = ops.sparse_rows_nt(dy.sp_val, dy.sp_arg, N, W)                    # S.W, dense rows
+            g, s0, s1 = ops.gemm_nt_bnbwd(a3, G4, ys[2], sc, sh, mu, inv, NEG, bias=cvec, rowadd=E)
+            if need_dparams:
+                grads[D_LAYERS[2][1] + ".weight"] = s1; grads[D_LAYERS[2][1] + ".bias"] = s0
+            sums = _cat2(s0, s1)
+            dy = ops.bn_bwd_apply(g, ys[2], mu, inv, P[D_LAYERS[2][1] + ".weight"], sums, M)
+            dys[2] = dy; gs[2] = g; sums_all[2] = sums
+            continue
         if need_dparams:
             if li > 0:
                 grads[conv + ".weight"] = ops.gemm_tn(dy, ys[li - 1], pro=(bns[li - 1][0], bns[li - 1][1], NEG)).view_as(P[conv + ".weight"])

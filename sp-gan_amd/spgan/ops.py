@@ -272,10 +272,10 @@ def bn_dbl_phaseb(coeffs: Tensor, gamma: Tensor, invstd: Tensor, s0: Optional[Te
 
 
 def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float,
-                  edge=None):
-    """g = (A @ W^T) * lrelu'(z), z = y*scale+shift; returns (g, sum_c g, sum_c g*xhat), xhat = (y-mean)*invstd.
+                  edge=None, pro=None, bias: Optional[Tensor] = None, rowadd: Optional[Tensor] = None):
+    """g = (pro(A) @ W^T + bias + rowadd) * lrelu'(z), z = y*scale+shift; returns (g, sum_c g, sum_c g*xhat), xhat = (y-mean)*invstd.
     With edge=(idx, ebias) y is the per-edge difference y[e] = P[idx[e]] - P[i] + ebias of the point tensor P=y_ref.
-    A may be a SparseAffine operand."""
+    A may be a SparseAffine operand; pro=(scale[K], shift[K], slope) as in gemm_nt; rowadd is a dense [M,N] addend."""
     sa = A if isinstance(A, SparseAffine) else None
     if sa is not None:
         A = sa.y
@@ -293,6 +293,16 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
         a.a_mode = A_AFFINE_LRELU
         a.p_scale = _p(_vec(sa.alpha, K, "alpha")); a.p_shift = _p(_vec(sa.beta, K, "beta")); a.p_slope = 1.0
         a.sp_val = _p(sa.sp_val); a.sp_arg = _p(_i32(sa.sp_arg, "sp_arg")); a.sp_rows = sa.rows
+    elif pro is not None:
+        a.a_mode = A_AFFINE_LRELU
+        a.p_scale = _p(_vec(pro[0], K, "pro.scale")); a.p_shift = _p(_vec(pro[1], K, "pro.shift")); a.p_slope = float(pro[2])
+    if bias is not None:
+        a.bias = _p(_vec(bias, N, "bias"))
+    if rowadd is not None:
+        _rowmajor2d(rowadd, "rowadd")
+        if rowadd.shape != (M_, N):
+            raise ValueError("rowadd must be [M,N]")
+        a.rowbias = _p(rowadd); a.rows_per_group = 1; a.ld_rowbias = _ld(rowadd)
     a.ref = _p(y_ref); a.ld_ref = _ld(y_ref)
     a.b_scale = _p(_vec(scale, N, "scale")); a.b_shift = _p(_vec(shift, N, "shift"))
     a.b_mean = _p(_vec(mean, N, "mean")); a.b_invstd = _p(_vec(invstd, N, "invstd")); a.b_slope = float(slope)
@@ -350,6 +360,57 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
 
 
 # ----------------------------------------------------------------------------- reductions / norms
+def sparse_rows_nt(val: Tensor, arg: Tensor, rows: int, W: Tensor) -> Tensor:
+    """E[m,:] = sum_{c: arg[b,c]==m} val[b,c] * W[c,:]  (b = m // rows): the row-sparse product S @ W, written densely [B*rows, N]."""
+    _f32(val, "val", 2); _rowmajor2d(W, "W")
+    B, Cs = val.shape
+    if W.shape[0] != Cs:
+        raise ValueError("W must have one row per channel of val")
+    N = W.shape[1]
+    E = torch.empty((B * rows, N), dtype=torch.float32, device=val.device)
+    check(_lib.load().spgan_sparse_rows_nt(_p(val.contiguous()), _p(_i32(arg, "arg")), B, rows, Cs, _p(W), _ld(W), N, _p(E), N, _s()),
+          "sparse_rows_nt", B=B, rows=rows, Cs=Cs, N=N)
+    return E
+
+
+def sparse_rows_tn(val: Tensor, arg: Tensor, rows: int, Bm: Tensor, out: Tensor, pro=None) -> Tensor:
+    """out[c,:] += sum_b val[b,c] * pro(Bm)[arg[b,c],:]  -- S^T @ pro(Bm) accumulated into out [Cs, Nb]."""
+    _f32(val, "val", 2); _rowmajor2d(Bm, "Bm"); _rowmajor2d(out, "out")
+    B, Cs = val.shape
+    Nb = Bm.shape[1]
+    if out.shape != (Cs, Nb) or Bm.shape[0] != B * rows:
+        raise ValueError("shape mismatch in sparse_rows_tn")
+    sc = sh = None; slope = 1.0
+    if pro is not None:
+        sc, sh, slope = _vec(pro[0], Nb, "pro.scale"), _vec(pro[1], Nb, "pro.shift"), float(pro[2])
+    check(_lib.load().spgan_sparse_rows_tn(_p(val.contiguous()), _p(_i32(arg, "arg")), B, rows, Cs, _p(Bm), _ld(Bm), Nb, _p(sc), _p(sh), slope,
+                                           _p(out), _ld(out), _s()), "sparse_rows_tn", B=B, rows=rows, Cs=Cs, Nb=Nb)
+    return out
+
+
+def affine_act(X: Tensor, scale: Tensor, shift: Tensor, slope: float) -> Tensor:
+    """lrelu(X*scale[c] + shift[c], slope) materialised (train-mode BatchNorm + LeakyReLU output)."""
+    _rowmajor2d(X, "X")
+    M_, Cn = X.shape
+    out = torch.empty((M_, Cn), dtype=torch.float32, device=X.device)
+    check(_lib.load().spgan_affine_act(_p(X), _ld(X), M_, Cn, _p(_vec(scale, Cn, "scale")), _p(_vec(shift, Cn, "shift")), float(slope), _p(out), _s()),
+          "affine_act", M=M_, C=Cn)
+    return out
+
+
+def rowscale_outer(X: Tensor, a: Tensor, b: Optional[Tensor] = None, d: Optional[Tensor] = None, v: Optional[Tensor] = None) -> Tensor:
+    """out[r,c] = a[r]*X[r,c] + (a[r]*b[r] + d[r])*v[c]   (v None: first term only)."""
+    _rowmajor2d(X, "X")
+    R, Cn = X.shape
+    out = torch.empty((R, Cn), dtype=torch.float32, device=X.device)
+    vb = vd = vv = None
+    if v is not None:
+        vb, vd, vv = _vec(b, R, "b"), _vec(d, R, "d"), _vec(v, Cn, "v")
+    check(_lib.load().spgan_rowscale_outer(_p(X), _ld(X), R, Cn, _p(_vec(a, R, "a")), _p(vb), _p(vd), _p(vv), _p(out), Cn, _s()),
+          "rowscale_outer", R=R, C=Cn)
+    return out
+
+
 def colstats(X: Tensor, G: int, slope: float = 1.0) -> Tuple[Tensor, Tensor]:
     """mean / biased var of lrelu(X, slope) over each group of G rows -> ([M/G, C], [M/G, C])."""
     _rowmajor2d(X, "X")

@@ -156,8 +156,10 @@ def _dense(A):
     return A
 
 
-def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None):
+def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None, pro=None, bias=None, rowadd=None):
     A = _dense(A)
+    if pro is not None:
+        A = _lrelu(A * pro[0] + pro[1], pro[2])
     N = W.shape[0]
     if edge is not None:
         idx, ebias = edge
@@ -167,9 +169,43 @@ def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None):
     else:
         y = y_ref[:, :N]
     z = y * scale + shift
-    g = (A @ W.t()) * torch.where(z > 0, 1.0, slope)
+    acc = A @ W.t()
+    if bias is not None:
+        acc = acc + bias
+    if rowadd is not None:
+        acc = acc + rowadd
+    g = acc * torch.where(z > 0, 1.0, slope)
     xh = (y - mean) * invstd
     return g.contiguous(), g.sum(0), (g * xh).sum(0)
+
+
+def _sparse_dense(val, arg, rows):
+    """S [B*rows, Cs] with S[arg[b,c], c] = val[b,c]."""
+    B, Cs = val.shape
+    S = torch.zeros((B * rows, Cs), dtype=val.dtype, device=val.device)
+    S[arg.long().reshape(-1), torch.arange(Cs, device=val.device).repeat(B)] = val.reshape(-1)
+    return S
+
+
+def sparse_rows_nt(val, arg, rows, W):
+    return (_sparse_dense(val, arg, rows) @ W).contiguous()
+
+
+def sparse_rows_tn(val, arg, rows, Bm, out, pro=None):
+    b = Bm if pro is None else _lrelu(Bm * pro[0] + pro[1], pro[2])
+    out += _sparse_dense(val, arg, rows).t() @ b
+    return out
+
+
+def affine_act(X, scale, shift, slope):
+    return _lrelu(X * scale + shift, slope).contiguous()
+
+
+def rowscale_outer(X, a, b=None, d=None, v=None):
+    out = a[:, None] * X
+    if v is not None:
+        out = out + (a * b + d)[:, None] * v[None, :]
+    return out.contiguous()
 
 
 def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0):

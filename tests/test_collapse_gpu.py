@@ -1,0 +1,82 @@
+"""GPU: the pieces of the collapsed backward of the layer in front of D's max-pool (row-sparse products, materialised
+BN+LeakyReLU, row scaling, BNBWD epilogue with bias / dense addend) and the collapsed form against the direct one."""
+import pytest
+import torch
+
+import kernel_model as km
+from test_kernels_gpu import close, ops, rnd  # noqa: F401  (ops is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _sparse(name, B, rows, Cs):
+    val = rnd(name + ".val", (B, Cs))
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    arg = (torch.randint(0, rows, (B, Cs), generator=g) + torch.arange(B)[:, None] * rows).int().cuda()
+    return val, arg
+
+
+@pytest.mark.parametrize("B,rows,Cs,N", [(3, 300, 1024, 256), (2, 128, 70, 37), (1, 2048, 1024, 256), (2, 64, 1000, 600)])
+def test_sparse_rows(ops, B, rows, Cs, N):
+    val, arg = _sparse("sr%d" % Cs, B, rows, Cs)
+    if Cs == 70:
+        arg[:, :40] = arg[:, :1]                      # many channels share one row
+    W = rnd("sr.W%d" % N, (Cs, N), 0.3)
+    E = ops.sparse_rows_nt(val, arg, rows, W)
+    close(E, km.sparse_rows_nt(val, arg, rows, W), what="nt")
+    assert torch.equal(E, ops.sparse_rows_nt(val, arg, rows, W)), "not deterministic"
+    Bm = rnd("sr.B%d" % N, (B * rows, N))
+    out = rnd("sr.out", (Cs, N)); out2 = out.clone()
+    ops.sparse_rows_tn(val, arg, rows, Bm, out); km.sparse_rows_tn(val, arg, rows, Bm, out2)
+    close(out, out2, what="tn")
+    sc, sh = rnd("sr.sc", (N,)).abs() + 0.5, rnd("sr.sh", (N,), 0.3)
+    out = torch.zeros(Cs, N, device="cuda"); out2 = out.clone()
+    ops.sparse_rows_tn(val, arg, rows, Bm, out, pro=(sc, sh, 0.01)); km.sparse_rows_tn(val, arg, rows, Bm, out2, pro=(sc, sh, 0.01))
+    close(out, out2, what="tn.pro")
+
+
+def test_affine_act_rowscale(ops):
+    X = rnd("aa.X", (777, 256)); sc, sh = rnd("aa.sc", (256,)), rnd("aa.sh", (256,), 0.3)
+    close(ops.affine_act(X, sc, sh, 0.01), km.affine_act(X, sc, sh, 0.01), what="affine_act")
+    Xv = rnd("aa.Xv", (100, 90))[:, 7:70]             # unaligned view -> scalar kernel
+    close(ops.affine_act(Xv, sc[:63].contiguous(), sh[:63].contiguous(), 0.2), km.affine_act(Xv, sc[:63], sh[:63], 0.2), what="affine_act.view")
+    W = rnd("aa.W", (1024, 256), 0.2); a, b, d, v = rnd("aa.a", (1024,)), rnd("aa.b", (1024,)), rnd("aa.d", (1024,)), rnd("aa.v", (256,))
+    close(ops.rowscale_outer(W, a), km.rowscale_outer(W, a), what="rowscale")
+    close(ops.rowscale_outer(W, a, b, d, v), km.rowscale_outer(W, a, b, d, v), what="rowscale_outer")
+
+
+def test_bnbwd_with_prologue_bias_rowadd(ops):
+    M, N, K = 900, 256, 256
+    A, W, ref = rnd("bb.A", (M, K)), rnd("bb.W", (N, K), 0.2), rnd("bb.ref", (M, N))
+    psc, psh = rnd("bb.psc", (K,)).abs() + 0.5, rnd("bb.psh", (K,), 0.3)
+    sc, sh, mean, inv = rnd("bb.sc", (N,)), rnd("bb.sh", (N,), 0.3), rnd("bb.mu", (N,), 0.2), rnd("bb.inv", (N,)).abs() + 0.5
+    bias, E = rnd("bb.bias", (N,)), rnd("bb.E", (M, N))
+    for a, b in zip(ops.gemm_nt_bnbwd(A, W, ref, sc, sh, mean, inv, 0.01, pro=(psc, psh, 0.01), bias=bias, rowadd=E),
+                    km.gemm_nt_bnbwd(A, W, ref, sc, sh, mean, inv, 0.01, pro=(psc, psh, 0.01), bias=bias, rowadd=E)):
+        close(a, b, rtol=5e-5, atol=2e-4, what="bnbwd+")
+
+
+def test_collapsed_equals_direct(ops):
+    """dz.W and dz^T.a through the collapsed identities == the direct GEMMs on the lazily evaluated operand."""
+    B, N, Cin, Cout = 4, 512, 256, 1024
+    M = B * N
+    y3 = rnd("cd.y3", (M, Cin)); sc3, sh3 = rnd("cd.sc3", (Cin,)).abs() + 0.5, rnd("cd.sh3", (Cin,), 0.3)
+    W, b4 = rnd("cd.W", (Cout, Cin), 0.06), rnd("cd.b4", (Cout,), 0.1)
+    a3 = ops.affine_act(y3, sc3, sh3, 0.01)
+    y4 = ops.gemm_nt(a3, W, b4)
+    alpha, beta = rnd("cd.al", (Cout,), 0.05), rnd("cd.be", (Cout,), 0.05)
+    val, arg = _sparse("cd", B, N, Cout)
+    dz = ops.SparseAffine(y4, alpha, beta, val, arg, N)
+    # direct
+    dW_ref = ops.gemm_tn(dz, y3, pro=(sc3, sh3, 0.01))
+    dz_dense = (y4 * alpha + beta + km._sparse_dense(val, arg, N)).contiguous()
+    dx_ref = ops.gemm_nt(dz_dense, W.t().contiguous())
+    # collapsed
+    gram = ops.gemm_tn(a3, a3)
+    dW = ops.rowscale_outer(ops.gemm_nt(W, gram), alpha, b4, beta, ops.colsum(a3)[0])
+    ops.sparse_rows_tn(val, arg, N, a3, dW)
+    G4 = ops.gemm_tn(W, ops.rowscale_outer(W, alpha))
+    cvec = ops.gemm_nt(b4.view(1, -1), W.t().contiguous(), pro=(alpha, beta, 1.0))[0]
+    dx = ops.gemm_nt(a3, G4, cvec) + ops.sparse_rows_nt(val, arg, N, W)
+    close(dW, dW_ref, rtol=2e-4, what="collapsed dW")
+    close(dx, dx_ref, rtol=2e-4, what="collapsed dx")
