@@ -519,7 +519,8 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_
   __shared__ float red[4][SR * SC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * SC;
-  for (int mc = 0; mc < p.M; mc += SR) {
+  {
+    const int mc = blockIdx.y * SR;  // one SR-row chunk per workgroup
     float v[SR * SC];
 #pragma unroll
     for (int i = 0; i < SR * SC; ++i) v[i] = 0.f;
@@ -533,15 +534,16 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_
         sc = *reinterpret_cast<const float4*>(p.p_scale + k);
         sh = *reinterpret_cast<const float4*>(p.p_shift + k);
       }
+      float4 av[SR];  // rows >= M are clamped (their sums are never stored): all loads issue together, no branches
+#pragma unroll
+      for (int r = 0; r < SR; ++r) av[r] = *reinterpret_cast<const float4*>(p.A + (size_t)min(mc + r, p.M - 1) * p.lda + k);
 #pragma unroll
       for (int r = 0; r < SR; ++r) {
-        if (mc + r < p.M) {
-          float4 a = *reinterpret_cast<const float4*>(p.A + (size_t)(mc + r) * p.lda + k);
-          if (AMODE == SPGAN_A_AFFINE_LRELU) a = affine_lrelu4(a, sc, sh, p.p_slope);
+        float4 a = av[r];
+        if (AMODE == SPGAN_A_AFFINE_LRELU) a = affine_lrelu4(a, sc, sh, p.p_slope);
 #pragma unroll
-          for (int c = 0; c < SC; ++c)
-            v[r * SC + c] = fmaf(a.w, w[c].w, fmaf(a.z, w[c].z, fmaf(a.y, w[c].y, fmaf(a.x, w[c].x, v[r * SC + c]))));
-        }
+        for (int c = 0; c < SC; ++c)
+          v[r * SC + c] = fmaf(a.w, w[c].w, fmaf(a.z, w[c].z, fmaf(a.y, w[c].y, fmaf(a.x, w[c].x, v[r * SC + c]))));
       }
     }
     // wave total of value i ends up in lane i
@@ -573,7 +575,6 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_
         p.Y[(size_t)row * p.ldy + col] = o;
       }
     }
-    __syncthreads();
   }
 }
 
@@ -585,7 +586,7 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   if (AMODE == A_AFFINE_SPARSE) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
   if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE_SPARSE && (EPI == SPGAN_EPI_LINEAR || EPI == SPGAN_EPI_MASK_OUT)) {
     if (a.M <= 64 && fast && !a.stats && !a.sp_val) {
-      hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(cdiv(a.N, SC)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(cdiv(a.N, SC), cdiv(a.M, SR)), dim3(256), 0, s, a);
       return spgan_launch_status();
     }
   }
@@ -829,46 +830,62 @@ __global__ __launch_bounds__(256) void tn_sparse_rows_kernel(const spgan_gemm_tn
 
 // E[m, :] = sum over the channels c whose arg[b,c] == m of val[b,c] * W[c, :]   (b = m / rows): the row-sparse product
 // S.W of the max-pool gradient pattern, written densely (zero rows included) so that a GEMM epilogue can add it as a
-// per-row bias.  Workgroup = (shape, 256-row chunk); a wave owns every 4th row of the chunk, finds the row's channels
-// with ballots over the LDS copy of arg[b,:] (ascending c: deterministic sums) and accumulates W rows, lanes over columns.
+// per-row addend.  Workgroup = (shape, chunk of RB rows).  The incidence is inverted in LDS as one Cs-bit mask per row
+// (atomicOr: the result does not depend on the order), then a wave walks its rows, skips the (mostly) empty masks with a
+// single ballot and adds the W rows of the set bits in ascending c (deterministic), lanes over columns.
 __global__ __launch_bounds__(256) void sparse_rows_nt_kernel(const float* __restrict__ val, const int32_t* __restrict__ arg, int rows, int Cs,
-                                                             const float* __restrict__ W, int ldw, int N, float* __restrict__ E, int lde) {
-  extern __shared__ int sm_i[];
-  int* sarg = sm_i;                                   // [Cs]
-  float* sval = reinterpret_cast<float*>(sm_i + Cs);  // [Cs]
+                                                             const float* __restrict__ W, int ldw, int N, float* __restrict__ E, int lde,
+                                                             int RB) {
+  extern __shared__ unsigned sm_u[];
+  const int words = (Cs + 63) / 64;                             // 64-bit words per row mask
+  unsigned* mask = sm_u;                                        // [RB][2*words]
+  float* sval = reinterpret_cast<float*>(sm_u + RB * 2 * words);  // [Cs]
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * RB;
+  for (int i = tid; i < RB * 2 * words; i += 256) mask[i] = 0u;
+  __syncthreads();
   for (int c = tid; c < Cs; c += 256) {
-    sarg[c] = arg[(size_t)b * Cs + c] - b * rows;  // local row
     sval[c] = val[(size_t)b * Cs + c];
+    const int r = arg[(size_t)b * Cs + c] - b * rows - r0;
+    if (r >= 0 && r < RB) atomicOr(&mask[r * 2 * words + (c >> 5)], 1u << (c & 31));
   }
   __syncthreads();
-  const int r0 = blockIdx.x * 256;
-  for (int r = r0 + wave; r < min(rows, r0 + 256); r += 4) {
-    float* e = E + ((size_t)b * rows + r) * lde;
+  for (int rl = wave; rl < RB && r0 + rl < rows; rl += 4) {
+    float* e = E + ((size_t)b * rows + r0 + rl) * lde;
+    const unsigned long long* mrow = reinterpret_cast<const unsigned long long*>(mask + rl * 2 * words);
     for (int n0 = 0; n0 < N; n0 += 256) {
       const int n = n0 + lane * 4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int c0 = 0; c0 < Cs; c0 += 64) {
-        const int c = c0 + lane;
-        unsigned long long hit = __ballot(c < Cs && sarg[c] == r);
-        while (hit) {
-          const int cc = c0 + __ffsll((long long)hit) - 1;
-          hit &= hit - 1;
-          const float v = sval[cc];
-          const float* w = W + (size_t)cc * ldw + n;
-          if (n + 3 < N) {
-            acc.x = fmaf(v, w[0], acc.x); acc.y = fmaf(v, w[1], acc.y); acc.z = fmaf(v, w[2], acc.z); acc.w = fmaf(v, w[3], acc.w);
-          } else {
-            if (n < N) acc.x = fmaf(v, w[0], acc.x);
-            if (n + 1 < N) acc.y = fmaf(v, w[1], acc.y);
-            if (n + 2 < N) acc.z = fmaf(v, w[2], acc.z);
+      for (int w0 = 0; w0 < words; w0 += 64) {
+        const unsigned long long mine = (w0 + lane < words) ? mrow[w0 + lane] : 0ull;
+        unsigned long long nz = __ballot(mine != 0ull);
+        while (nz) {
+          const int wl = __ffsll((long long)nz) - 1;
+          nz &= nz - 1;
+          unsigned long long bits = __shfl(mine, wl);
+          while (bits) {
+            const int cc = (w0 + wl) * 64 + __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            const float v = sval[cc];
+            const float* w = W + (size_t)cc * ldw + n;
+            if (n + 3 < N) {
+              acc.x = fmaf(v, w[0], acc.x); acc.y = fmaf(v, w[1], acc.y); acc.z = fmaf(v, w[2], acc.z); acc.w = fmaf(v, w[3], acc.w);
+            } else {
+              if (n < N) acc.x = fmaf(v, w[0], acc.x);
+              if (n + 1 < N) acc.y = fmaf(v, w[1], acc.y);
+              if (n + 2 < N) acc.z = fmaf(v, w[2], acc.z);
+            }
           }
         }
       }
-      if (n < N) e[n] = acc.x;
-      if (n + 1 < N) e[n + 1] = acc.y;
-      if (n + 2 < N) e[n + 2] = acc.z;
-      if (n + 3 < N) e[n + 3] = acc.w;
+      if (n + 3 < N && (lde & 3) == 0 && (reinterpret_cast<uintptr_t>(E) & 15) == 0) {
+        *reinterpret_cast<float4*>(e + n) = acc;
+      } else {
+        if (n < N) e[n] = acc.x;
+        if (n + 1 < N) e[n + 1] = acc.y;
+        if (n + 2 < N) e[n + 2] = acc.z;
+        if (n + 3 < N) e[n + 3] = acc.w;
+      }
     }
   }
 }
@@ -974,7 +991,12 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
 extern "C" int spgan_sparse_rows_nt(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* W, int ldw, int N, float* E,
                                     int lde, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(val && arg && W && E && B > 0 && rows > 0 && Cs > 0 && N > 0 && ldw >= N && lde >= N && Cs <= 8192);
-  hipLaunchKernelGGL(sparse_rows_nt_kernel, dim3(cdiv(rows, 256), B), dim3(256), (size_t)Cs * 8, (hipStream_t)s_, val, arg, rows, Cs, W, ldw, N, E, lde);
+  const int words = cdiv(Cs, 64);
+  int RB = (32 * 1024) / (words * 8);  // 32 KB of row masks per workgroup
+  if (RB > 256) RB = 256;
+  if (RB > rows) RB = rows;
+  const size_t lds = (size_t)RB * words * 8 + (size_t)Cs * 4;
+  hipLaunchKernelGGL(sparse_rows_nt_kernel, dim3(cdiv(rows, RB), B), dim3(256), lds, (hipStream_t)s_, val, arg, rows, Cs, W, ldw, N, E, lde, RB);
   return spgan_launch_status();
 }
 
