@@ -73,6 +73,11 @@ def _ld(t: Tensor) -> int:
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
 
 
+# Measurement hook (bench.py's roofline leg): launch_timer(kind, args_struct) may return a callable that is invoked right after
+# the launch was enqueued -- the bench brackets selected launches with HIP events on the launch stream.  None in normal use.
+launch_timer = None
+
+
 # ----------------------------------------------------------------------------- graph
 def knn(x_pm: Tensor, B: int, N: int, k: int, mode: int = 0) -> Tensor:
     """x_pm [B*N, C] -> idx int32 [B*N, k] (global rows), sorted ascending, rank 0 dropped.
@@ -201,7 +206,10 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
         part = torch.empty((tiles, N, 2), dtype=torch.float32, device=A.device)
         a.stats = _p(part)
     lib = _lib.load()
+    done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt", M=M_, N=N, K=K, a_mode=a.a_mode)
+    if done is not None:
+        done()
     if bn is not None:
         gamma, beta, rm, rv = bn
         out = torch.empty((4, N), dtype=torch.float32, device=A.device)
