@@ -590,15 +590,13 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
       return spgan_launch_status();
     }
   }
-  if (a.N > 64) {
-    if (a.K >= 512) {  // long K: double-buffered LDS, one barrier per k-tile
-      if (fast) launch_nt_cfg<AMODE, EPI, 0, 1, 1>(a, s);
-      else launch_nt_cfg<AMODE, EPI, 0, 1, 0>(a, s);
-    } else {
-      if (fast) launch_nt_cfg<AMODE, EPI, 0, 0, 1>(a, s);
-      else launch_nt_cfg<AMODE, EPI, 0, 0, 0>(a, s);
-    }
+  if (a.N > 64 && a.K >= 512) {  // long K: 128x128 tiles, double-buffered LDS, one barrier per k-tile
+    if (fast) launch_nt_cfg<AMODE, EPI, 0, 1, 1>(a, s);
+    else launch_nt_cfg<AMODE, EPI, 0, 1, 0>(a, s);
   } else if (a.N > 32) {
+    // short K: 128x64 tiles.  With 2-8 k-tiles per workgroup the fixed load/epilogue latency dominates; the narrower tile
+    // doubles the workgroups (2048 instead of 1024 at M=65536, N=256: finer quantisation over the 256 CUs, 5 resident per
+    // CU instead of 3) -- measured 15-30 % faster than 128x128 on every N <= 1280, K <= 256 shape of the step.
     if (fast) launch_nt_cfg<AMODE, EPI, 1, 0, 1>(a, s);
     else launch_nt_cfg<AMODE, EPI, 1, 0, 0>(a, s);
   } else {
