@@ -190,6 +190,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+    t_issue = time.perf_counter() - t0        # host time to enqueue the K steps (the GPU may still be running)
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
@@ -210,6 +211,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Chair-shaped synthetic clouds, 2048 pts, per-GPU batch 32, WGAN + gradient penalty (lambda 10), "
                                    "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10", "global_batch": PER_GPU_BATCH * world, "n_points": N_POINTS,
                        "parallelism": "dp%d" % world},
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
             "step_tflops_algorithmic": round(shapes_s * GF_PER_SHAPE_STEP / 1e3, 2),
             "step_frac_of_fp32_matrix_peak": round(shapes_s * GF_PER_SHAPE_STEP / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
         }

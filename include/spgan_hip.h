@@ -308,6 +308,17 @@ int spgan_bn_dbl_coeffs(const float* U0, const float* U1, const float* Ugz, cons
                         const float* invstd, int C, int count, float* out4C, spgan_stream_t s);
 int spgan_bn_dbl_phaseb(const float* coeffs4C, const float* gamma, const float* invstd, const float* s0, const float* s1, int C,
                         float* sums2C, float* dgamma, spgan_stream_t s);
+/* Collapsed double backward of the layer in front of the max-pool (Discriminator.py:74-81,104): the dense [M,C]
+ * tensors of the generic path are only needed as per-channel sums and at the B*C arg-max positions.
+ * spgan_gather_rowdot: out[b,c] = Q[arg[b,c], :] . W[c, :]          (u = q.W^T at the arg-max rows)
+ * spgan_rowdot:        out[r]   = X[r,:] . Y[r,:]
+ * spgan_bn_dbl_pool:   per channel: U1, Ugz, the phase-A coefficients; t [B,C] = adjoint of the pooled gradient;
+ *                      out4C = [dgamma | c1 | c2 | c3], spB [B,C]: phase B's ybar = c1*u + c2*y + c3 + scatter(spB). */
+int spgan_gather_rowdot(const float* Q, int ldq, const int32_t* arg, const float* W, int ldw, int B, int C, int K, float* out, spgan_stream_t s);
+int spgan_rowdot(const float* X, int ldx, const float* Y, int ldy, int R, int K, float* out, spgan_stream_t s);
+int spgan_bn_dbl_pool(const float* uarg, const float* gval, const float* yarg, const float* pooled, const float* U0, const float* quad,
+                      const float* bias, const float* mean, const float* invstd, const float* gamma, const float* S0, const float* S1,
+                      int B, int C, int count, float slope, float* t, float* spB, float* out4C, spgan_stream_t s);
 /* Lazy-operand form of the BatchNorm backward behind the max-pool: dy = alpha[c]*y + beta[c] + (argmax hit ? cg[b,c] : 0) */
 int spgan_sparse_bn_prep(const float* gval, const float* mean, const float* invstd, const float* gamma, const float* sums, int B,
                          int C, int count, float* alpha, float* beta, float* cg, spgan_stream_t s);

@@ -218,6 +218,67 @@ __global__ void bn_dbl_phaseb_kernel(const float* coeffs, const float* gamma, co
   sums[C + c] = coeffs[3 * C + c] + gamma[c] * a1 + inv[c] * coeffs[C + c];
   dgamma[c] = coeffs[c] + a1;
 }
+// ---- collapsed double backward of the layer in front of the max-pool: everything that used to need the dense
+// [M,C] tensors u = q.W^T, y, gz and q_out is only needed (a) as per-channel sums and (b) at the B*C arg-max positions.
+// out[b,c] = Q[arg[b,c], :] . W[c, :]     (u at the arg-max rows); 16 lanes per (b,c), fixed shuffle tree
+__global__ __launch_bounds__(256) void gather_rowdot_kernel(const float* __restrict__ Q, int ldq, const int32_t* __restrict__ arg,
+                                                            const float* __restrict__ W, int ldw, int BC, int C, int K, float* __restrict__ out) {
+  const int pair = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  float s = 0.f;
+  if (pair < BC) {
+    const float* q = Q + (size_t)arg[pair] * ldq;
+    const float* w = W + (size_t)(pair % C) * ldw;
+    for (int k = l; k < K; k += 16) s = fmaf(q[k], w[k], s);
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+  if (pair < BC && l == 0) out[pair] = s;
+}
+// out[r] = X[r,:] . Y[r,:]
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ Y, int ldy, int R, int K,
+                                                     float* __restrict__ out) {
+  const int r = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  float s = 0.f;
+  if (r < R)
+    for (int k = l; k < K; k += 16) s = fmaf(X[(size_t)r * ldx + k], Y[(size_t)r * ldy + k], s);
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+  if (r < R && l == 0) out[r] = s;
+}
+// One thread per channel, loop over the B shapes.  With u = q.W^T, xhat = (y-mean)*inv, gz = scatter(gval):
+//   U0 = sum_m u (given), U1 = sum_m u*xhat = inv*(quad + (bias-mean)*U0)   (quad[c] = w_c^T (q^T a) w_c), Ugz = sum_b gval*uarg
+//   phase A coefficients as bn_dbl_coeffs; top adjoint t[b,c] = gamma*inv*(uarg - U0/M - xhat_arg*U1/M)*lrelu'(pooled)
+//   phase B: ybar = c1*u + c2*y + c3 + scatter(spB)  with sum0 = xsum0, sum1 = xsum1 + inv*sbarA:
+//     c1 = -gamma*inv^2*S1/M,  c2 = -inv^2*sum1/M,  c3 = -inv*sum0/M + inv^2*mean*sum1/M,  spB = -(gamma*inv^2/M)*U1*gval
+__global__ void bn_dbl_pool_kernel(const float* __restrict__ uarg, const float* __restrict__ gval, const float* __restrict__ yarg,
+                                   const float* __restrict__ pooled, const float* __restrict__ U0, const float* __restrict__ quad,
+                                   const float* __restrict__ bias, const float* __restrict__ mean, const float* __restrict__ inv,
+                                   const float* __restrict__ gamma, const float* __restrict__ S0, const float* __restrict__ S1, int B, int C,
+                                   float rM, float slope, float* __restrict__ t, float* __restrict__ spB, float* __restrict__ out4) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float iv = inv[c], ga = gamma[c], mu = mean[c], u0 = U0[c];
+  const float u1 = iv * (quad[c] + (bias[c] - mu) * u0);
+  float ugz = 0.f;
+  for (int b = 0; b < B; ++b) ugz = fmaf(gval[(size_t)b * C + c], uarg[(size_t)b * C + c], ugz);
+  const float core = ugz - (u0 * S0[c] + u1 * S1[c]) * rM;
+  const float gsM = ga * iv * rM;
+  const float sbarA = ga * core;
+  const float sum0 = -gsM * (u0 * S1[c] + S0[c] * u1);
+  const float sum1 = -2.0f * gsM * (u1 * S1[c]) + iv * sbarA;
+  out4[c] = iv * core;                                       // dgamma
+  out4[C + c] = -gsM * iv * S1[c];                           // c1
+  out4[2 * C + c] = -iv * iv * sum1 * rM;                    // c2
+  out4[3 * C + c] = -iv * sum0 * rM + iv * iv * mu * sum1 * rM;  // c3
+  const float gs = ga * iv, spc = -gsM * iv * u1;
+  for (int b = 0; b < B; ++b) {
+    const size_t i = (size_t)b * C + c;
+    const float xh = (yarg[i] - mu) * iv;
+    t[i] = gs * (uarg[i] - u0 * rM - xh * (u1 * rM)) * lrelu_mask(pooled[i], slope);
+    spB[i] = spc * gval[i];
+  }
+}
+
 // BatchNorm backward behind the max-pool as a lazy operand: alpha = -(gamma*inv)*inv*S1/M, beta = -(gamma*inv)*S0/M - alpha*mean,
 // cg[b,c] = gamma*inv*gval[b,c]
 __global__ void sparse_bn_prep_kernel(const float* gval, const float* mean, const float* inv, const float* gamma, const float* sums, int B,
@@ -395,6 +456,26 @@ extern "C" int spgan_bn_dbl_phaseb(const float* coeffs4C, const float* gamma, co
                                    float* sums2C, float* dgamma, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(coeffs4C && gamma && invstd && sums2C && dgamma && C > 0 && ((s0 == nullptr) == (s1 == nullptr)));
   hipLaunchKernelGGL(bn_dbl_phaseb_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s_, coeffs4C, gamma, invstd, s0, s1, C, sums2C, dgamma);
+  return spgan_launch_status();
+}
+extern "C" int spgan_gather_rowdot(const float* Q, int ldq, const int32_t* arg, const float* W, int ldw, int B, int C, int K, float* out,
+                                   spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(Q && arg && W && out && B > 0 && C > 0 && K > 0 && ldq >= K && ldw >= K);
+  hipLaunchKernelGGL(gather_rowdot_kernel, dim3(cdiv(B * C, 16)), dim3(256), 0, (hipStream_t)s_, Q, ldq, arg, W, ldw, B * C, C, K, out);
+  return spgan_launch_status();
+}
+extern "C" int spgan_rowdot(const float* X, int ldx, const float* Y, int ldy, int R, int K, float* out, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(X && Y && out && R > 0 && K > 0 && ldx >= K && ldy >= K);
+  hipLaunchKernelGGL(rowdot_kernel, dim3(cdiv(R, 16)), dim3(256), 0, (hipStream_t)s_, X, ldx, Y, ldy, R, K, out);
+  return spgan_launch_status();
+}
+extern "C" int spgan_bn_dbl_pool(const float* uarg, const float* gval, const float* yarg, const float* pooled, const float* U0, const float* quad,
+                                 const float* bias, const float* mean, const float* invstd, const float* gamma, const float* S0, const float* S1,
+                                 int B, int C, int count, float slope, float* t, float* spB, float* out4C, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(uarg && gval && yarg && pooled && U0 && quad && bias && mean && invstd && gamma && S0 && S1 && t && spB && out4C);
+  SPGAN_CHECK_ARG(B > 0 && C > 0 && count > 0);
+  hipLaunchKernelGGL(bn_dbl_pool_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)s_, uarg, gval, yarg, pooled, U0, quad, bias, mean, invstd,
+                     gamma, S0, S1, B, C, 1.0f / (float)count, slope, t, spB, out4C);
   return spgan_launch_status();
 }
 extern "C" int spgan_sparse_bn_prep(const float* gval, const float* mean, const float* invstd, const float* gamma, const float* sums, int B,

@@ -111,6 +111,9 @@ SIGNATURES = {
     "spgan_bn_dbl_apply": (I, [P, P, P, I, I, P, P, P, P, F, P, P, P, P, P, P, P]),
     "spgan_bn_dbl_coeffs": (I, [P, P, P, P, P, P, P, I, I, P, P]),
     "spgan_bn_dbl_phaseb": (I, [P, P, P, P, P, I, P, P, P]),
+    "spgan_gather_rowdot": (I, [P, I, P, P, I, I, I, I, P, P]),
+    "spgan_rowdot": (I, [P, I, P, I, I, I, P, P]),
+    "spgan_bn_dbl_pool": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P]),
     "spgan_sparse_bn_prep": (I, [P, P, P, P, P, I, I, I, P, P, P, P]),
     "spgan_col_scale_add": (I, [P, P, P, I, I, P, P]),
     "spgan_gan_loss": (I, [I, I, P, P, P, P, I, P, P, P, P]),

@@ -203,6 +203,62 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
     return dx_cm, (grads if need_dparams else None), saved
 
 
+def _d_double_top_phase_a(P, ctx, saved, q3: Tensor, grads) -> dict:
+    """Phase A of the double backward at fc2.0/fc2.1 (the layer in front of the max-pool) without [M,1024] tensors.
+    q3 [M,256] is the adjoint arriving from layer 3.  With W [1024,256], a3 = lrelu(bn3(y3)), y4 = a3.W^T + b4, u = q3.W^T:
+      gy4^T q3 = (alpha*y4 + beta + S)^T q3 = diag(alpha).W.(a3^T q3) + (alpha*b4 + beta) (x) colsum(q3) + S^T q3
+      U0 = colsum(q3).W^T,  U1[c] = inv*(w_c^T (q3^T a3) w_c + (b4 - mean)*U0),  Ugz[c] = sum_b gval[b,c]*u[arg[b,c], c]
+    and the outgoing adjoint is only needed at the arg-max rows (it is gathered there by the max-pool)."""
+    B, N = ctx["B"], ctx["N"]
+    M = B * N
+    ys, bns, pooled, argmax = ctx["ys"], ctx["bns"], ctx["pooled"], ctx["argmax"]
+    conv, bn = D_LAYERS[3]
+    W, b4, gamma = _w2(P[conv + ".weight"]), P[conv + ".bias"], P[bn + ".weight"]
+    sc, sh, inv, mu = bns[3]
+    C = W.shape[0]
+    dz = saved["dys"][3]
+    S0, S1 = saved["sums"][3][:C], saved["sums"][3][C:]
+    a3 = ops.affine_act(ys[2], bns[2][0], bns[2][1], NEG)
+    Qqa = ops.gemm_tn(q3, a3)                                                    # q3^T a3 [256,256]
+    cq = ops.colsum(q3)[0]
+    T = ops.gemm_nt(W, Qqa)                                                      # W.(a3^T q3) [1024,256]
+    dW = ops.rowscale_outer(T, dz.alpha, b4, dz.beta, cq)
+    ops.sparse_rows_tn(dz.sp_val, dz.sp_arg, N, q3, dW)
+    grads[conv + ".weight"] = dW
+    U0 = ops.gemm_nt(cq.view(1, -1), W)[0]
+    quad = ops.rowdot(W, T)                                                      # w_c^T (q3^T a3) w_c
+    uarg = ops.gather_rowdot(q3, argmax, W)                                      # u at the arg-max rows [B,1024]
+    yarg = ctx["yarg"] if ctx.get("yarg") is not None else ops.gather_rows(ys[3], argmax)
+    t, spB, c4 = ops.bn_dbl_pool(uarg, saved["gval"], yarg, pooled, U0, quad, b4, mu, inv, gamma, S0, S1, M, NEG)
+    return dict(t=t, spB=spB, c4=c4, a3=a3, q3=q3, Qqa=Qqa)
+
+
+def _d_double_top_phase_b(P, ctx, top: dict, grads):
+    """Phase B at the same layer: ybar = c1*u + c2*y4 + c3 + scatter(spB) (never formed) ->
+      ybar^T a3 = diag(c1).W.(q3^T a3) + diag(c2).W.(a3^T a3) + (c2*b4 + c3) (x) colsum(a3) + spB^T a3
+      ybar.W    = q3.(W^T diag(c1) W) + a3.(W^T diag(c2) W) + (c2*b4 + c3).W + spB.W      (then layer 3's mask / sums epilogue)"""
+    B, N = ctx["B"], ctx["N"]
+    ys, bns, argmax = ctx["ys"], ctx["bns"], ctx["argmax"]
+    conv, bn = D_LAYERS[3]
+    W, b4 = _w2(P[conv + ".weight"]), P[conv + ".bias"]
+    c4, a3, q3, spB = top["c4"], top["a3"], top["q3"], top["spB"]
+    dgamma, c1, c2, c3 = c4[0], c4[1], c4[2], c4[3]
+    grads[bn + ".weight"] = dgamma
+    grads[bn + ".bias"] = ZERO_GRAD
+    Wc1, Wc2 = ops.rowscale_outer(W, c1), ops.rowscale_outer(W, c2)
+    gram = ops.gemm_tn(a3, a3)
+    gw = ops.rowscale_outer(ops.gemm_nt(W, gram), c2, b4, c3, ops.colsum(a3)[0])
+    gw = ops.axpby(1.0, ops.gemm_nt(Wc1, _t(top["Qqa"])), 1.0, gw)             # + diag(c1).W.(q3^T a3)
+    ops.sparse_rows_tn(spB, argmax, N, a3, gw)
+    grads[conv + ".weight"] = ops.axpby(1.0, gw, 1.0, grads[conv + ".weight"]).view_as(P[conv + ".weight"])
+    grads[conv + ".bias"] = ZERO_GRAD
+    G1, G2 = ops.gemm_tn(W, Wc1), ops.gemm_tn(W, Wc2)
+    cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(c2, c3, 1.0))[0]
+    part = ops.gemm_nt(q3, G1, rowbias=ops.sparse_rows_nt(spB, argmax, N, W), rows_per_group=1)
+    psc, psh, pinv, pmu = bns[2]
+    return ops.gemm_nt_bnbwd(a3, G2, ys[2], psc, psh, pmu, pinv, NEG, bias=cvec, rowadd=part)
+
+
 def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
     """Gradient of a scalar R(dx) w.r.t. D's parameters, where dx = d_backward(...)[0] (WGAN-GP:
     Common/gradient_penalty.py:31-35 followed by .backward()).  v = dR/d(dx) [B,3,N].
@@ -225,6 +281,12 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         sc, sh, inv, mu = bns[li]
         gamma = P[bn + ".weight"]
         C = W.shape[0]
+        if li == 3 and isinstance(dys[3], ops.SparseAffine):
+            # Collapsed top layer: u = q.W^T, y4 = a3.W^T + b4 and gz (the max-pool scatter) enter only through
+            # the K x K matrices q^T a3 / a3^T a3, per-channel sums and their values at the B*C arg-max rows -- no [M,1024]
+            # tensor is formed in either phase.
+            top = _d_double_top_phase_a(P, ctx, saved, q, grads)
+            break
         grads[conv + ".weight"] = ops.gemm_tn(dys[li], q)                       # gy_l^T q_{l-1}
         u = ops.gemm_nt(q, W)                                                    # adjoint of gy_l
         if li == 3:
@@ -235,8 +297,10 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         U0, U1, Ugz = ops.bn_dbl_stats(u, ys[li], gz, mu, inv)
         coeffs[li] = ops.bn_dbl_coeffs(U0, U1, Ugz, S0, S1, gamma, inv, M)       # [dgammaA | sbarA | sum xbarA | sum xbarA*xhat]
         q, xbarA[li] = ops.bn_dbl_apply(u, ys[li], gz, mu, inv, sc, sh, NEG, gamma, S1, U0, U1, M)
+    else:
+        top = None
     # top: ga_4 = scatter(gpool) -> MLP backward graph in reverse
-    t = ops.gather_rows(q, argmax)                                               # adjoint of gpool [B,C4]
+    t = top["t"] if top is not None else ops.gather_rows(q, argmax)             # adjoint of gpool [B,C4]
     dhs, dout = saved["dhs"], saved["dout"]
     acts = [pooled, hs[0], hs[1], hs[2]]
     for li in (0, 1, 2, 3):
@@ -254,6 +318,9 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         sc, sh, inv, mu = bns[li]
         gamma = P[bn + ".weight"]
         C = W.shape[0]
+        if li == 3 and top is not None:
+            abar_g = _d_double_top_phase_b(P, ctx, top, grads)
+            continue
         if abar_g is None:
             X = xbarA[li]
             sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, None, None)

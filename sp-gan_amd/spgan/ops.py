@@ -419,6 +419,43 @@ def rowscale_outer(X: Tensor, a: Tensor, b: Optional[Tensor] = None, d: Optional
     return out
 
 
+def gather_rowdot(Q: Tensor, arg: Tensor, W: Tensor) -> Tensor:
+    """out[b,c] = Q[arg[b,c], :] . W[c, :]"""
+    _rowmajor2d(Q, "Q"); _rowmajor2d(W, "W"); _i32(arg, "arg")
+    B, Cn = arg.shape
+    K = W.shape[1]
+    if W.shape[0] != Cn or Q.shape[1] != K:
+        raise ValueError("shape mismatch in gather_rowdot")
+    out = torch.empty((B, Cn), dtype=torch.float32, device=Q.device)
+    check(_lib.load().spgan_gather_rowdot(_p(Q), _ld(Q), _p(arg), _p(W), _ld(W), B, Cn, K, _p(out), _s()), "gather_rowdot", B=B, C=Cn, K=K)
+    return out
+
+
+def rowdot(X: Tensor, Y: Tensor) -> Tensor:
+    """out[r] = X[r,:] . Y[r,:]"""
+    _rowmajor2d(X, "X"); _rowmajor2d(Y, "Y")
+    if X.shape != Y.shape:
+        raise ValueError("shape mismatch in rowdot")
+    R, K = X.shape
+    out = torch.empty((R,), dtype=torch.float32, device=X.device)
+    check(_lib.load().spgan_rowdot(_p(X), _ld(X), _p(Y), _ld(Y), R, K, _p(out), _s()), "rowdot", R=R, K=K)
+    return out
+
+
+def bn_dbl_pool(uarg: Tensor, gval: Tensor, yarg: Tensor, pooled: Tensor, U0, quad, bias, mean, invstd, gamma, S0, S1, count: int, slope: float):
+    """Per-channel algebra of the collapsed double backward in front of the max-pool -> (t [B,C], spB [B,C], [dgamma | c1 | c2 | c3] [4,C])."""
+    B, Cn = uarg.shape
+    t = torch.empty((B, Cn), dtype=torch.float32, device=uarg.device)
+    spB = torch.empty_like(t)
+    out4 = torch.empty((4, Cn), dtype=torch.float32, device=uarg.device)
+    m = lambda x, n: _p(_f32(x.contiguous(), n, 2))
+    v = lambda x, n: _p(_vec(x.contiguous(), Cn, n))
+    check(_lib.load().spgan_bn_dbl_pool(m(uarg, "uarg"), m(gval, "gval"), m(yarg, "yarg"), m(pooled, "pooled"), v(U0, "U0"), v(quad, "quad"),
+                                        v(bias, "bias"), v(mean, "mean"), v(invstd, "invstd"), v(gamma, "gamma"), v(S0, "S0"), v(S1, "S1"),
+                                        B, Cn, count, float(slope), _p(t), _p(spB), _p(out4), _s()), "bn_dbl_pool", B=B, C=Cn)
+    return t, spB, out4
+
+
 def colstats(X: Tensor, G: int, slope: float = 1.0) -> Tuple[Tensor, Tensor]:
     """mean / biased var of lrelu(X, slope) over each group of G rows -> ([M/G, C], [M/G, C])."""
     _rowmajor2d(X, "X")

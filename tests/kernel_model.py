@@ -197,6 +197,31 @@ def sparse_rows_tn(val, arg, rows, Bm, out, pro=None):
     return out
 
 
+def gather_rowdot(Q, arg, W):
+    B, C = arg.shape
+    return (Q[arg.long().reshape(-1)] * W.repeat(B, 1)).sum(1).view(B, C).contiguous()
+
+
+def rowdot(X, Y):
+    return (X * Y).sum(1)
+
+
+def bn_dbl_pool(uarg, gval, yarg, pooled, U0, quad, bias, mean, invstd, gamma, S0, S1, count, slope):
+    rM = 1.0 / count
+    U1 = invstd * (quad + (bias - mean) * U0)
+    Ugz = (gval * uarg).sum(0)
+    core = Ugz - (U0 * S0 + U1 * S1) * rM
+    gsM = gamma * invstd * rM
+    sbarA = gamma * core
+    sum0 = -gsM * (U0 * S1 + S0 * U1)
+    sum1 = -2.0 * gsM * (U1 * S1) + invstd * sbarA
+    out4 = torch.stack([invstd * core, -gsM * invstd * S1, -invstd * invstd * sum1 * rM, -invstd * sum0 * rM + invstd * invstd * mean * sum1 * rM])
+    xh = (yarg - mean) * invstd
+    t = gamma * invstd * (uarg - U0 * rM - xh * (U1 * rM)) * torch.where(pooled > 0, 1.0, slope)
+    spB = (-gsM * invstd * U1) * gval
+    return t.contiguous(), spB.contiguous(), out4.contiguous()
+
+
 def affine_act(X, scale, shift, slope):
     return _lrelu(X * scale + shift, slope).contiguous()
 

@@ -80,3 +80,17 @@ def test_collapsed_equals_direct(ops):
     dx = ops.gemm_nt(a3, G4, cvec) + ops.sparse_rows_nt(val, arg, N, W)
     close(dW, dW_ref, rtol=2e-4, what="collapsed dW")
     close(dx, dx_ref, rtol=2e-4, what="collapsed dx")
+
+
+def test_double_backward_collapse_pieces(ops):
+    B, N, K, C = 4, 256, 256, 1024
+    q = rnd("dc.q", (B * N, K)); W = rnd("dc.W", (C, K), 0.06)
+    val, arg = _sparse("dc", B, N, C)
+    close(ops.gather_rowdot(q, arg, W), km.gather_rowdot(q, arg, W), rtol=3e-5, what="gather_rowdot")
+    T = rnd("dc.T", (C, K))
+    close(ops.rowdot(W, T), km.rowdot(W, T), rtol=3e-5, what="rowdot")
+    v = lambda n, s=1.0: rnd("dc." + n, (C,), s)
+    uarg, gval, yarg, pooled = rnd("dc.ua", (B, C)), rnd("dc.gv", (B, C)), rnd("dc.ya", (B, C)), rnd("dc.po", (B, C))
+    args = (uarg, gval, yarg, pooled, v("U0"), v("quad"), v("b", 0.1), v("mu", 0.2), v("inv").abs() + 0.5, v("ga").abs() + 0.5, v("S0"), v("S1"), B * N, 0.01)
+    for a, b, n in zip(ops.bn_dbl_pool(*args), km.bn_dbl_pool(*args), ("t", "spB", "coeffs")):
+        close(a, b, rtol=3e-5, what="bn_dbl_pool." + n)

@@ -31,6 +31,7 @@ def _worker(rank, world, port, out):
     for name, fn in inspect.getmembers(km, inspect.isfunction):
         if not name.startswith("_"):
             setattr(ops, name, fn)
+    ops.SparseAffine = km.SparseAffine
     modules._require_gpu = lambda t, what: None
     from oracle import spgan_oracle as orc
     from spgan import fixture_rng as fr
