@@ -111,9 +111,20 @@ typedef struct spgan_gemm_nt_args {
    * With p_slope = 1 this expresses the BatchNorm backward behind a global max-pool without materialising it:
    *   dy[m,k] = alpha[k]*y[m,k] + beta[k] + (argmax[b,k]==m ? coef[k]*gval[b,k] : 0)   (Discriminator.py:77-81,104) */
   const float* sp_val; const int32_t* sp_arg; int sp_rows;
+  /* Optional pooling partials (EPI_LINEAR, M > 64): per 128-row tile and column the max and min of the pre-activation output
+   * and their rows (first row on ties): pool_val / pool_arg [ceil(M/128), N, 2] = (max, min) / (arg-max row, arg-min row).
+   * With them Y may be NULL (the output is not stored): adaptive_max_pool1d behind BatchNorm + LeakyReLU
+   * (Discriminator.py:77-81,104) is finished by spgan_pool_finalize once the batch statistics are known. */
+  float* pool_val; int32_t* pool_arg;
 } spgan_gemm_nt_args;
 
 int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s);
+/* pooled[b,c] = max_n lrelu(scale[c]*y[b*rows+n, c] + shift[c], slope) from the tile partials above (rows % 128 == 0, so
+ * that no tile straddles two shapes): scale >= 0 takes the tile maxima, scale < 0 the minima.  argmax = global row,
+ * yarg = the pre-BatchNorm value there.  Ties go to the lowest row of equal PRE-activation values; scale == 0 (all rows tie):
+ * argmax = the first row like torch.max, yarg = the column maximum (y at the first row is not available without Y). */
+int spgan_pool_finalize(const float* pool_val, const int32_t* pool_arg, int B, int rows, int C, const float* scale, const float* shift,
+                        float slope, float* pooled, int32_t* argmax, float* yarg, spgan_stream_t s);
 
 typedef struct spgan_gemm_tn_args {
   /* C[Na,Nb] = beta*C + sum_m A[m,Na]^T . prologue(B)[m,Nb]  -- weight gradients (reduction over points/edges).

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   float* As = smem;                  // [NB][BM*LDT]
   float* Bs = smem + NB * BM * LDT;  // [NB][BN*LDT]
   float* red = Bs + NB * BN * LDT;   // [WGM][BN]
+  float* pool = red + G::WGM * BN;   // [4][WGM][BN]: column max / arg-max / min / arg-min exchange of the pooling epilogue
 
   const int tilesN = (p.N + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
@@ -379,13 +380,65 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           if (p.rowbias && cok && row < p.M) v += p.rowbias[(size_t)fast_div(row, p.rows_per_group) * p.ld_rowbias + col];
           acc[i][j][r] = v;  // keep the pre-activation value for the statistics pass
           if (row < p.M) csum[j] += v;
-          if (cok && row < p.M) {
+          if (cok && row < p.M && p.Y) {
             float o = v;
             if (p.act == SPGAN_ACT_LRELU) o = lrelu_f(v, p.act_slope);
             else if (p.act == SPGAN_ACT_TANH) o = tanhf(v);
             p.Y[(size_t)row * p.ldy + col] = o;
           }
         }
+    }
+    if (p.pool_val) {
+      // Per-tile column max / min of the pre-activation output with their rows (first row on ties): a global max-pool behind a
+      // per-channel monotone map (BatchNorm affine of either sign + LeakyReLU) is finished from these by spgan_pool_finalize
+      // once the batch statistics are known -- the [M,N] output itself need not be stored (Y == NULL).
+      constexpr int WGM = G::WGM;
+      float* pvx = pool;
+      int* pax = reinterpret_cast<int*>(pool + WGM * BN);
+      float* pvn = pool + 2 * WGM * BN;
+      int* pan = reinterpret_cast<int*>(pool + 3 * WGM * BN);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        float vx = -INFINITY, vn = INFINITY;
+        int ax = 0x7fffffff, an = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {  // rows ascend with (i, r): strict compares keep the first
+            const int row = ROW_OF(i, r);
+            const float v = acc[i][j][r];
+            if (row < p.M && v > vx) { vx = v; ax = row; }
+            if (row < p.M && v < vn) { vn = v; an = row; }
+          }
+        const float ovx = __shfl_xor(vx, 32), ovn = __shfl_xor(vn, 32);
+        const int oax = __shfl_xor(ax, 32), oan = __shfl_xor(an, 32);
+        if (ovx > vx || (ovx == vx && oax < ax)) { vx = ovx; ax = oax; }
+        if (ovn < vn || (ovn == vn && oan < an)) { vn = ovn; an = oan; }
+        if (lh == 0) {
+          const int c = wm * BN + (wn * TJ + j) * 32 + l31;
+          pvx[c] = vx; pax[c] = ax; pvn[c] = vn; pan[c] = an;
+        }
+      }
+      __syncthreads();
+      if (wm == 0 && lh == 0) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int c = (wn * TJ + j) * 32 + l31, col = cbase + j * 32;
+          float vx = pvx[c], vn = pvn[c];
+          int ax = pax[c], an = pan[c];
+#pragma unroll
+          for (int w = 1; w < WGM; ++w) {  // wave w holds higher rows than wave w-1: strict compares keep the first
+            if (pvx[w * BN + c] > vx) { vx = pvx[w * BN + c]; ax = pax[w * BN + c]; }
+            if (pvn[w * BN + c] < vn) { vn = pvn[w * BN + c]; an = pan[w * BN + c]; }
+          }
+          if (col < p.N) {
+            const size_t o = ((size_t)t.tm * p.N + col) * 2;
+            p.pool_val[o] = vx; p.pool_val[o + 1] = vn;
+            p.pool_arg[o] = ax; p.pool_arg[o + 1] = an;
+          }
+        }
+      }
+      __syncthreads();
     }
     if (p.stats) {
       // per-tile (sum, centred M2): combined later with Chan's formula -> no E[x^2]-E[x]^2 cancellation
@@ -488,7 +541,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 
 template <int CFG, int DB>
 constexpr size_t nt_lds_bytes() {
-  return (size_t)((DB + 1) * (BM + Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * LDT + Geo<CFG>::WGM * Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * sizeof(float);
+  return (size_t)((DB + 1) * (BM + Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * LDT + 5 * Geo<CFG>::WGM * Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * sizeof(float);
 }
 
 template <int AMODE, int EPI, int CFG, int DB, int FAST>
@@ -955,7 +1008,9 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
 
 extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
-  SPGAN_CHECK_ARG(a && a->A && a->W && a->Y && a->M > 0 && a->N > 0 && a->K > 0);
+  SPGAN_CHECK_ARG(a && a->A && a->W && a->M > 0 && a->N > 0 && a->K > 0);
+  SPGAN_CHECK_ARG(a->Y || (a->pool_val && a->epi_mode == SPGAN_EPI_LINEAR));
+  if (a->pool_val) SPGAN_CHECK_ARG(a->pool_arg && a->epi_mode == SPGAN_EPI_LINEAR && a->M > 64);
   SPGAN_CHECK_ARG(a->lda >= a->K && a->ldw >= a->K && a->ldy >= a->N);
   SPGAN_CHECK_ARG((uint64_t)a->M * (uint64_t)a->lda < (1ull << 32) && (uint64_t)a->N * (uint64_t)a->ldw < (1ull << 32));  // 32-bit operand offsets
   if (a->a_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);

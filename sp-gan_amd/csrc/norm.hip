@@ -259,7 +259,39 @@ __global__ __launch_bounds__(256) void maxpool_v4_kernel(const float* __restrict
   }
 }
 
+// Global max-pool over each shape from per-tile column (max, min, arg-max, arg-min) partials of the PRE-BatchNorm output
+// (spgan_gemm_nt pooling epilogue): z = scale*y + shift is increasing in y for scale > 0 and decreasing for scale < 0, and
+// LeakyReLU (slope > 0) is increasing, so the pooled value sits at the max resp. min of y.  scale == 0: every row ties, the
+// first row wins (like torch.max).  Tiles are visited in ascending row order with strict compares: first row on ties.
+__global__ void pool_finalize_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pa, int B, int tiles, int C,
+                                     const float* __restrict__ scale, const float* __restrict__ shift, float slope, int rows,
+                                     float* __restrict__ pooled, int32_t* __restrict__ argmax, float* __restrict__ yarg) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  const float sc = scale[c], sh = shift[c];
+  const int pick = sc >= 0.f ? 0 : 1;
+  float best = 0.f;
+  int arg = -1;
+  for (int t = 0; t < tiles; ++t) {
+    const size_t o = ((size_t)(b * tiles + t) * C + c) * 2 + pick;
+    const float v = pv[o];
+    if (arg < 0 || (pick == 0 ? v > best : v < best)) { best = v; arg = pa[o]; }
+  }
+  if (sc == 0.f) arg = b * rows;
+  pooled[(size_t)b * C + c] = lrelu_f(fmaf(best, sc, sh), slope);
+  argmax[(size_t)b * C + c] = arg;
+  if (yarg) yarg[(size_t)b * C + c] = best;
+}
+
 }  // namespace
+
+extern "C" int spgan_pool_finalize(const float* pool_val, const int32_t* pool_arg, int B, int rows, int C, const float* scale, const float* shift,
+                                   float slope, float* pooled, int32_t* argmax, float* yarg, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(pool_val && pool_arg && scale && shift && pooled && argmax && B > 0 && rows > 0 && C > 0 && rows % 128 == 0 && slope > 0.f);
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3(cdiv(C, 128), B), dim3(128), 0, (hipStream_t)s_, pool_val, pool_arg, B, rows / 128, C, scale, shift,
+                     slope, rows, pooled, argmax, yarg);
+  return spgan_launch_status();
+}
 
 extern "C" size_t spgan_colreduce_ws_bytes(int M, int C, int G) {
   if (M <= 0 || C <= 0 || G <= 0) return 0;

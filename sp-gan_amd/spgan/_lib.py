@@ -34,6 +34,7 @@ class GemmNTArgs(C.Structure):
         ("b_scale", c_f32p), ("b_shift", c_f32p), ("b_mean", c_f32p), ("b_invstd", c_f32p), ("b_slope", C.c_float),
         ("e_bias2", c_f32p),
         ("sp_val", c_f32p), ("sp_arg", c_i32p), ("sp_rows", C.c_int),
+        ("pool_val", c_f32p), ("pool_arg", c_i32p),
     ]
 
 
@@ -75,6 +76,7 @@ SIGNATURES = {
     "spgan_pm_to_cm": (I, [P, I, I, I, P, P]),
     "spgan_concat2": (I, [P, I, P, I, I, P, P]),
     "spgan_gemm_nt": (I, [C.POINTER(GemmNTArgs), P]),
+    "spgan_pool_finalize": (I, [P, P, I, I, I, P, P, F, P, P, P, P]),
     "spgan_gemm_tn_ws_bytes": (SZ, [I, I, I]),
     "spgan_gemm_tn": (I, [C.POINTER(GemmTNArgs), P]),
     "spgan_sparse_rows_nt": (I, [P, P, I, I, I, P, I, I, P, I, P]),

@@ -96,18 +96,31 @@ def d_forward(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], x_cm: Ten
     x_pm = ops.cm_to_pm(x_cm)
     ys, bns = [], []
     a, pro = x_pm, None
-    for conv, bn in D_LAYERS:
+    yarg = None
+    for li, (conv, bn) in enumerate(D_LAYERS):
         W, b = _w2(P[conv + ".weight"]), P[conv + ".bias"]
+        if li == 3 and training and N % ops.ROW_TILE == 0:
+            # fc2.0 + BatchNorm + LeakyReLU + max over N in one GEMM: the [M,1024] output is never stored -- every backward of this
+            # layer is collapsed (d_backward / d_double_backward) and needs y4 only at the arg-max rows (yarg)
+            rm = rv = None
+            if bufs is not None and update_running:
+                rm, rv = bufs[bn + ".running_mean"], bufs[bn + ".running_var"]
+            y, (sc, sh, inv, mu), pooled, argmax, yarg = ops.gemm_bn_pool(a, W, b, (P[bn + ".weight"], P[bn + ".bias"], rm, rv), N, NEG, pro=pro)
+            if rm is not None:
+                _count_bn_call(bufs, bn)
+            ys.append(y); bns.append((sc, sh, inv, mu))
+            break
         y, (sc, sh, inv, mu) = _gemm_bn(a, W, b, P, bufs, bn, M, training, update_running, pro=pro)
         ys.append(y); bns.append((sc, sh, inv, mu))
         a, pro = y, (sc, sh, NEG)
-    pooled, argmax = ops.maxpool(ys[3], B, N, bns[3][0], bns[3][1], NEG)        # BN + LeakyReLU + max over N fused
+    if yarg is None:
+        pooled, argmax = ops.maxpool(ys[3], B, N, bns[3][0], bns[3][1], NEG)    # BN + LeakyReLU + max over N fused
     h, hs = pooled, []
     for i, name in enumerate(D_MLP):
         last = i == len(D_MLP) - 1
         h = ops.gemm_nt(h, P[name + ".weight"], P[name + ".bias"], act=ops.ACT_NONE if last else ops.ACT_LRELU, slope=NEG)
         hs.append(h)
-    ctx = dict(B=B, N=N, x_pm=x_pm, ys=ys, bns=bns, pooled=pooled, argmax=argmax, hs=hs, training=training)
+    ctx = dict(B=B, N=N, x_pm=x_pm, ys=ys, bns=bns, pooled=pooled, argmax=argmax, yarg=yarg, hs=hs, training=training)
     return hs[-1], ctx
 
 
@@ -135,7 +148,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             gpool = ops.gemm_nt(d, Wt)
     # ---- max-pool + BN4 (sparse incoming gradient)
     sc4, sh4, inv4, mu4 = bns[3]
-    gval, sums4 = ops.pool_bwd_stats(gpool, pooled, argmax, ys[3], mu4, inv4, NEG)
+    gval, sums4 = ops.pool_bwd_stats(gpool, pooled, argmax, ys[3] if ys[3] is not None else ctx["yarg"], mu4, inv4, NEG)
     C4 = gval.shape[1]
     if need_dparams:
         grads["fc2.1.weight"] = sums4[C4:]; grads["fc2.1.bias"] = sums4[:C4]

@@ -242,16 +242,17 @@ class SparseAffine:
     It stands for the BatchNorm backward behind D's global max-pool (dense, but a function of y and B*C numbers):
     the GEMMs that consume it evaluate it on their operand load instead of reading a materialised [M,C] tensor."""
 
-    def __init__(self, y: Tensor, alpha: Tensor, beta: Tensor, sp_val: Tensor, sp_arg: Tensor, rows: int):
+    def __init__(self, y: Optional[Tensor], alpha: Tensor, beta: Tensor, sp_val: Tensor, sp_arg: Tensor, rows: int):
+        # y may be None when the consumer is the collapsed backward (nets.d_backward), which never evaluates the operand
         self.y, self.alpha, self.beta, self.sp_val, self.sp_arg, self.rows = y, alpha.contiguous(), beta.contiguous(), sp_val.contiguous(), sp_arg, rows
-        self.shape = y.shape
-        self.device = y.device
+        self.shape = y.shape if y is not None else (sp_val.shape[0] * rows, sp_val.shape[1])
+        self.device = sp_val.device
 
 
 def sparse_bn_bwd_operand(gval: Tensor, argmax: Tensor, y: Tensor, N: int, mean, invstd, gamma, sums, count: int) -> SparseAffine:
     """The same quantity bn_bwd_apply_sparse materialises, as a lazy operand (O(C) + O(B*C) preparation only)."""
     B, Cn = gval.shape
-    ab = torch.empty((2, Cn), dtype=torch.float32, device=y.device)
+    ab = torch.empty((2, Cn), dtype=torch.float32, device=gval.device)
     cg = torch.empty_like(gval)
     check(_lib.load().spgan_sparse_bn_prep(_p(gval.contiguous()), _p(_vec(mean, Cn, "mean")), _p(_vec(invstd, Cn, "invstd")), _p(_vec(gamma, Cn, "gamma")),
                                            _p(_vec(sums, 2 * Cn, "sums")), B, Cn, count, _p(ab[0]), _p(ab[1]), _p(cg), _s()), "sparse_bn_prep")
@@ -516,6 +517,51 @@ def maxpool(y: Tensor, B: int, N: int, scale: Optional[Tensor] = None, shift: Op
     return out, arg
 
 
+def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, slope: float, pro=None, keep_y: bool = False):
+    """Y = pro(A) @ W^T + bias, train-mode BatchNorm over all rows, LeakyReLU, max over each group of `rows` rows -- the
+    tail of the Discriminator's conv stack (Discriminator.py:74-81,104) in one GEMM launch + two small finalize launches; Y
+    itself is only written when keep_y.  bn = (gamma, beta, running_mean | None, running_var | None).
+    Returns (Y | None, (scale, shift, invstd, mean), pooled [B,C], argmax int32 [B,C] (global rows), yarg [B,C])."""
+    _rowmajor2d(A, "A"); _rowmajor2d(W, "W")
+    N, K = W.shape
+    M_ = A.shape[0]
+    if rows % ROW_TILE or M_ % rows:
+        raise ValueError("gemm_bn_pool needs rows %% %d == 0 and M %% rows == 0" % ROW_TILE)
+    B = M_ // rows
+    tiles = M_ // ROW_TILE
+    dev = A.device
+    a = GemmNTArgs()
+    a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W)
+    Y = torch.empty((M_, N), dtype=torch.float32, device=dev) if keep_y else None
+    a.Y = _p(Y); a.ldy = N
+    a.M, a.N, a.K = M_, N, K
+    a.a_mode = A_PLAIN
+    if pro is not None:
+        a.a_mode = A_AFFINE_LRELU
+        a.p_scale = _p(_vec(pro[0], K, "pro.scale")); a.p_shift = _p(_vec(pro[1], K, "pro.shift")); a.p_slope = float(pro[2])
+    a.epi_mode = EPI_LINEAR
+    a.bias = _p(_vec(bias, N, "bias"))
+    part = torch.empty((tiles, N, 2), dtype=torch.float32, device=dev)
+    pval = torch.empty((tiles, N, 2), dtype=torch.float32, device=dev)
+    parg = torch.empty((tiles, N, 2), dtype=torch.int32, device=dev)
+    a.stats = _p(part); a.pool_val = _p(pval); a.pool_arg = _p(parg)
+    lib = _lib.load()
+    done = launch_timer("gemm_nt", a) if launch_timer is not None else None
+    check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_bn_pool", M=M_, N=N, K=K)
+    if done is not None:
+        done()
+    gamma, beta, rm, rv = bn
+    st = torch.empty((4, N), dtype=torch.float32, device=dev)
+    check(lib.spgan_colstats_finalize_bn(_p(part), tiles, N, M_, 0, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM, _p(rm), _p(rv),
+                                         _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _s()), "colstats_finalize_bn", N=N, M=M_)
+    pooled = torch.empty((B, N), dtype=torch.float32, device=dev)
+    yarg = torch.empty((B, N), dtype=torch.float32, device=dev)
+    arg = torch.empty((B, N), dtype=torch.int32, device=dev)
+    check(lib.spgan_pool_finalize(_p(pval), _p(parg), B, rows, N, _p(st[0]), _p(st[1]), float(slope), _p(pooled), _p(arg), _p(yarg), _s()),
+          "pool_finalize", B=B, rows=rows, C=N)
+    return Y, (st[0], st[1], st[2], st[3]), pooled, arg, yarg
+
+
 # ----------------------------------------------------------------------------- EdgeBlock gather-side ops
 def edge_wcat(Ww0: Tensor, Wx: Tensor) -> Tensor:
     """[W1; Wd; Wc-Wd] from conv_w.0.weight [H,C] and conv_x.0.weight [F,2C] = [Wc|Wd] -> [H+2F, C]."""
@@ -653,10 +699,23 @@ def adain_bwd(dout: Tensor, x: Tensor, N: int, slope: float, imean: Tensor, ivar
 
 
 # ----------------------------------------------------------------------------- pooled BN backward, misc
+_ROWIDS = {}
+
+
+def _rowids(B: int, Cn: int, device) -> Tensor:
+    key = (B, Cn, str(device))
+    if key not in _ROWIDS:
+        _ROWIDS[key] = torch.arange(B, dtype=torch.int32, device=device).view(B, 1).expand(B, Cn).contiguous()
+    return _ROWIDS[key]
+
+
 def pool_bwd_stats(gpool: Tensor, pooled: Tensor, argmax: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, slope: float):
-    """gval = gpool*lrelu'(pooled); sums [2C] = [sum_b gval | sum_b gval*xhat(argmax row)]."""
+    """gval = gpool*lrelu'(pooled); sums [2C] = [sum_b gval | sum_b gval*xhat(argmax row)].
+    y is either the full [M,C] pre-BN tensor or, when that was never stored, its values at the arg-max rows [B,C]."""
     _f32(gpool, "gpool", 2); _rowmajor2d(y, "y")
     B, Cn = gpool.shape
+    if y.shape[0] == B:                     # yarg [B,C]: "row b" of it is the arg-max row of shape b
+        argmax = _rowids(B, Cn, y.device)
     gpool = gpool.contiguous()
     gval = torch.empty_like(gpool)
     sums = torch.empty((2 * Cn,), dtype=torch.float32, device=y.device)

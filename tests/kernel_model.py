@@ -126,12 +126,11 @@ def gemm_nt_maskout(A, W, ref, slope):
 class SparseAffine:
     def __init__(self, y, alpha, beta, sp_val, sp_arg, rows):
         self.y, self.alpha, self.beta, self.sp_val, self.sp_arg, self.rows = y, alpha, beta, sp_val, sp_arg, rows
-        self.shape = y.shape
-        self.device = y.device
+        self.device = sp_val.device
 
 
 def sparse_bn_bwd_operand(gval, argmax, y, N, mean, invstd, gamma, sums, count):
-    C = y.shape[1]
+    C = gval.shape[1]
     coef = gamma * invstd
     alpha = -(coef * invstd) * (sums[C:] / count)
     beta = -(coef * (sums[:C] / count)) - alpha * mean
@@ -398,10 +397,20 @@ def adain_bwd(dout, x, N, slope, imean, ivar, gb):
 
 
 # ----------------------------------------------------------------------------- pooled BN backward, misc
+def gemm_bn_pool(A, W, bias, bn, rows, slope, pro=None, keep_y=False):
+    y, st = gemm_nt(A, W, bias, pro=pro, bn=bn)
+    B = y.shape[0] // rows
+    pooled, arg = maxpool(y, B, rows, st[0], st[1], slope)
+    cols = torch.arange(y.shape[1], device=y.device).view(1, -1).expand(B, -1)
+    return (y if keep_y else None), st, pooled, arg, y[arg.long(), cols].contiguous()
+
+
 def pool_bwd_stats(gpool, pooled, argmax, y, mean, invstd, slope):
     B, C = gpool.shape
     gval = gpool * torch.where(pooled > 0, 1.0, slope)
     cols = torch.arange(C, device=y.device).view(1, C).expand(B, C)
+    if y.shape[0] == B:
+        argmax = torch.arange(B, device=y.device).view(B, 1).expand(B, C)
     xh = (y[argmax.long(), cols] - mean) * invstd
     return gval.contiguous(), torch.cat([gval.sum(0), (gval * xh).sum(0)])
 

@@ -94,3 +94,34 @@ def test_double_backward_collapse_pieces(ops):
     args = (uarg, gval, yarg, pooled, v("U0"), v("quad"), v("b", 0.1), v("mu", 0.2), v("inv").abs() + 0.5, v("ga").abs() + 0.5, v("S0"), v("S1"), B * N, 0.01)
     for a, b, n in zip(ops.bn_dbl_pool(*args), km.bn_dbl_pool(*args), ("t", "spB", "coeffs")):
         close(a, b, rtol=3e-5, what="bn_dbl_pool." + n)
+
+
+@pytest.mark.parametrize("B,N,K,C", [(3, 256, 64, 128), (2, 1024, 256, 1024), (4, 128, 16, 70)])
+def test_gemm_bn_pool(ops, B, N, K, C):
+    """GEMM + train-mode BN + LeakyReLU + max over N with the pooling partials in the GEMM epilogue == GEMM, BN, maxpool."""
+    M = B * N
+    A, W, b = rnd("gp.A%d" % K, (M, K)), rnd("gp.W%d" % C, (C, K), 0.2), rnd("gp.b%d" % C, (C,), 0.1)
+    gamma, beta = rnd("gp.g%d" % C, (C,)), rnd("gp.be%d" % C, (C,), 0.2)      # gamma of both signs: max and min branches
+    gamma[3] = 0.0
+    psc, psh = rnd("gp.psc%d" % K, (K,)).abs() + 0.5, rnd("gp.psh%d" % K, (K,), 0.3)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    rm2, rv2 = rm.clone(), rv.clone()
+    for keep in (False, True):
+        y, st, pooled, arg, yarg = ops.gemm_bn_pool(A, W, b, (gamma, beta, rm, rv), N, 0.01, pro=(psc, psh, 0.01), keep_y=keep)
+        y2, st2, pooled2, arg2, yarg2 = km.gemm_bn_pool(A, W, b, (gamma, beta, rm2, rv2), N, 0.01, pro=(psc, psh, 0.01), keep_y=True)
+        assert (y is None) == (not keep)
+        if keep:
+            close(y, y2, what="y")
+        for a_, b_ in zip(st, st2):
+            close(a_, b_, rtol=2e-5, atol=2e-6, what="bn state")
+        close(pooled, pooled2, rtol=2e-5, atol=2e-6, what="pooled")
+        live = gamma != 0          # gamma == 0: every row ties; the fused path reports the first row but cannot know y there
+        close(yarg[:, live], yarg2[:, live], rtol=2e-5, atol=2e-6, what="yarg")
+        # the arg-max rows carry the pooled value (exact index equality is only guaranteed up to rounding ties)
+        cols = torch.arange(C, device="cuda").view(1, C).expand(B, C)
+        assert ((arg.long() // N) == torch.arange(B, device="cuda").view(B, 1)).all()
+        close(y2[arg.long(), cols][:, live], yarg2[:, live], rtol=2e-5, atol=2e-6, what="y at argmax")
+        assert (arg[:, ~live] == arg2[:, ~live]).all()
+        agree = (arg == arg2).float().mean().item()
+        assert agree > 0.99 or C == 70, agree
+    close(rm, rm2, rtol=1e-5, atol=1e-6, what="running_mean"); close(rv, rv2, rtol=1e-5, what="running_var")
