@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
     import spgan
@@ -174,16 +175,26 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
 
     G, D = build_models(dev)
-    tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=dist_on)
+    # The step is captured once into a hipGraph and replayed (TrainStep(graph=True)): issuing its ~580 launches from Python takes
+    # as long as the GPU needs to run them.  Data-parallel runs capture the two RCCL all-reduces with it; SPGAN_GRAPH=0 / --no-graph
+    # fall back to eager issue.
+    use_graph = not args.no_graph and os.environ.get("SPGAN_GRAPH", "1") != "0"
+    graph_warmup = 3
+    tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=dist_on, graph=use_graph,
+                         graph_warmup=graph_warmup)
     x, real, zs, alpha = make_inputs(dev, rank, PER_GPU_BATCH)
 
     def one_step(i):
         tr.step(x, real, zs[(2 * i) % 4], zs[(2 * i + 1) % 4], alpha=alpha)
 
+    if use_graph:
+        for i in range(graph_warmup + 1):     # eager priming steps + the capture, before the W warm-up steps
+            one_step(i)
     for i in range(args.warmup):
         one_step(i)
     timer = DominantKernelTimer(PER_GPU_BATCH * N_POINTS) if rank == 0 else None
-    spgan.ops.launch_timer = timer
+    if not use_graph:
+        spgan.ops.launch_timer = timer
     if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -200,6 +211,14 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     spgan.ops.launch_timer = None
+    if use_graph and rank == 0:
+        # a replayed graph offers no per-launch hook: the dominant kernel's launches are bracketed with HIP events over a few
+        # eager steps of the same TrainStep right after the timed region (same process, same tensors; not part of `value`)
+        spgan.ops.launch_timer = timer
+        for i in range(4):
+            tr._eager_step(x, real, zs[(2 * i) % 4], zs[(2 * i + 1) % 4], alpha=alpha)
+        torch.cuda.synchronize()
+        spgan.ops.launch_timer = None
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -211,7 +230,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Chair-shaped synthetic clouds, 2048 pts, per-GPU batch 32, WGAN + gradient penalty (lambda 10), "
                                    "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10", "global_batch": PER_GPU_BATCH * world, "n_points": N_POINTS,
                        "parallelism": "dp%d" % world},
-            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3), "hipgraph_replay": bool(use_graph),
             "step_tflops_algorithmic": round(shapes_s * GF_PER_SHAPE_STEP / 1e3, 2),
             "step_frac_of_fp32_matrix_peak": round(shapes_s * GF_PER_SHAPE_STEP / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
         }

@@ -349,6 +349,10 @@ int spgan_axpby(float a, const float* x, float b, float* y, size_t n, spgan_stre
 /* torch.optim.Adam step on a flat buffer (Generation/model.py:94-97: lr 1e-4, betas (0.5,0.99)); g is scaled by grad_scale first */
 int spgan_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
                     float grad_scale, spgan_stream_t s);
+/* The same update with the step count in device memory (state3[0] holds the int step count, advanced by this call; state3[1..2]
+ * its bias corrections): no host value changes from one step to the next, so a captured hipGraph of the train step replays it. */
+int spgan_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                        float* state3, float grad_scale, spgan_stream_t s);
 
 #ifdef __cplusplus
 }

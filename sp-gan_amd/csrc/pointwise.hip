@@ -353,6 +353,29 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   p[t] -= (lr / bc1) * (mm / denom);
 }
 
+// Capturable variant (hipGraph replay): the step count lives in device memory.  state[0] = step (as float bits of an int),
+// state[1] = 1 - beta1^step, state[2] = 1/sqrt(1 - beta2^step); adam_prep advances it once per optimiser step.
+__global__ void adam_prep_kernel(float beta1, float beta2, float* __restrict__ state) {
+  int* st = reinterpret_cast<int*>(state);
+  const int t = st[0] + 1;
+  st[0] = t;
+  state[1] = (float)(1.0 - pow((double)beta1, (double)t));
+  state[2] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)t)));
+}
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                float lr, float b1, float b2, float eps, const float* __restrict__ state, float gscale) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float bc1 = state[1], rsqrt_bc2 = state[2];
+  const float gr = g[t] * gscale;
+  const float mm = b1 * m[t] + (1.f - b1) * gr;
+  const float vv = b2 * v[t] + (1.f - b2) * gr * gr;
+  m[t] = mm;
+  v[t] = vv;
+  const float denom = sqrtf(vv) * rsqrt_bc2 + eps;
+  p[t] -= (lr / bc1) * (mm / denom);
+}
+
 }  // namespace
 
 extern "C" int spgan_adain_fwd(const float* x, int M, int C, int N, float slope, const float* imean, const float* ivar, float eps,
@@ -536,6 +559,14 @@ extern "C" int spgan_rowscale_outer(const float* X, int ldx, int R, int C, const
 extern "C" int spgan_axpby(float a, const float* x, float b, float* y, size_t n, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(x && y && n > 0);
   hipLaunchKernelGGL(axpby_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, a, x, b, y, n);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                                   float* state3, float grad_scale, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(p && g && m && v && state3 && n > 0);
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)s_, beta1, beta2, state3);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, p, g, m, v, n, lr, beta1, beta2, eps, state3, grad_scale);
   return spgan_launch_status();
 }
 

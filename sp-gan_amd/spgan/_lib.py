@@ -131,6 +131,7 @@ SIGNATURES = {
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
     "spgan_axpby": (I, [F, P, F, P, SZ, P]),
     "spgan_adam_step": (I, [P, P, P, P, SZ, F, F, F, F, I, F, P]),
+    "spgan_adam_step_dev": (I, [P, P, P, P, SZ, F, F, F, F, P, F, P]),
 }
 
 _lib = None

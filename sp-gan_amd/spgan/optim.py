@@ -61,19 +61,26 @@ class Adam:
     """Adam over a module's flat buffer.  `step()` == torch.optim.Adam(lr, betas, eps=1e-8).step();
     `zero_grad()` zeroes the flat gradient buffer in place."""
 
-    def __init__(self, module: nn.Module, lr: float = 1e-4, betas=(0.5, 0.99), eps: float = 1e-8):
+    def __init__(self, module: nn.Module, lr: float = 1e-4, betas=(0.5, 0.99), eps: float = 1e-8, capturable: bool = False):
         self.fp = flatten_module(module)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
         self.t = 0
+        # capturable: the step count (and its bias corrections) live on the device, so that a hipGraph of the train step can
+        # be replayed; `t` stays the host-side mirror (state_dict)
+        self.capturable = capturable
+        self.dev_state = torch.zeros(3, dtype=torch.float32, device=self.fp.flat.device) if capturable else None
 
     def zero_grad(self, set_to_none: bool = False):
         self.fp.zero_grad()
 
     def step(self, grad_scale: float = 1.0):
         self.t += 1
-        ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps, grad_scale)
+        if self.capturable:
+            ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.dev_state, self.lr, self.betas[0], self.betas[1], self.eps, grad_scale)
+        else:
+            ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps, grad_scale)
 
     def state_dict(self):
         return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr, "betas": self.betas, "eps": self.eps}
@@ -81,3 +88,5 @@ class Adam:
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = int(sd["t"])
         self.lr, self.betas, self.eps = sd["lr"], tuple(sd["betas"]), sd["eps"]
+        if self.capturable:
+            self.dev_state[:1].view(torch.int32).fill_(self.t)

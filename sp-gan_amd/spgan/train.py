@@ -6,6 +6,11 @@ BatchNorm running statistics -- and Adam(lr, betas=(0.5, 0.99)) (model.py:94-97)
 With `use_gp` the discriminator loss is dis_loss(gan) + GradientPenalty(lambda_gp, gamma=1): the
 "WGAN-GP" composition of reference pieces that BASELINE config 2 names.
 No host<->device synchronisation happens inside step(); losses are returned as device tensors.
+
+`graph=True`: after `graph_warmup` eager steps the whole iteration (2 G forwards, 5 D forwards, all backwards, the gradient
+penalty's double backward, both Adam updates and, data-parallel, both all-reduces: ~580 kernel launches) is captured once into
+a hipGraph and replayed.  The Python/launch cost of a step (~14 ms, as long as the GPU work itself) drops to one graph launch;
+inputs are copied into static buffers (or adopted, when the caller keeps passing the same tensors).
 """
 from __future__ import annotations
 
@@ -29,7 +34,7 @@ def requires_grad(model: nn.Module, flag: bool = True):
 class TrainStep:
     def __init__(self, G: nn.Module, D: nn.Module, gan: str = "ls", use_gp: bool = False, lambda_gp: float = 10.0,
                  lr_g: float = 1e-4, lr_d: float = 1e-4, betas=(0.5, 0.99), flip_d: bool = False, flip_g: bool = False,
-                 distributed: bool = False, process_group=None):
+                 distributed: bool = False, process_group=None, graph: bool = False, graph_warmup: int = 3):
         self.G, self.D = G, D
         self.gan, self.use_gp = gan, use_gp
         self.flip_d, self.flip_g = flip_d, flip_g
@@ -38,17 +43,123 @@ class TrainStep:
         self.dpD = DataParallel(D, process_group) if distributed else None
         if distributed:
             self.dpG.sync_params(); self.dpD.sync_params()
-        self.optG = Adam(G, lr_g, betas)
-        self.optD = Adam(D, lr_d, betas)
+        self.optG = Adam(G, lr_g, betas, capturable=graph)
+        self.optD = Adam(D, lr_d, betas, capturable=graph)
         G.train(); D.train()
+        self.use_graph, self.graph_warmup = graph, graph_warmup
+        self._graph = None
+        self._static = None          # [x, real, z_d, z_g, alpha]
+        self._last_src = None
+        self._static_info = None
+        self._eager_calls = 0
+        self._bn_delta = None        # host-side BatchNorm call counts of one step (replayed on the host)
+        self._side = None
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def _bn_modules(self):
+        from .modules import _BNCounts
+        return [m for net in (self.G, self.D) for m in net.modules() if isinstance(m, _BNCounts)]
+
+    def _bn_snapshot(self):
+        return [{pre: dict(pend) for pre, pend in m.__dict__.get("_bn_pending", {}).items()} for m in self._bn_modules()]
+
+    def _bind(self, tensors):
+        """Copy the step's inputs into the static buffers the graph reads.  An input that is the same tensor (storage and
+        version) as on the previous step is not copied again -- the constant sphere template keeps its cached kNN graph."""
+        if self._static is None:
+            self._static = [None if t is None else t.detach().clone() for t in tensors]
+            self._last_src = [None if t is None else (t.data_ptr(), t._version) for t in tensors]
+            return
+        for i, t in enumerate(tensors):
+            st = self._static[i]
+            if t is None or st is None:
+                if (t is None) != (st is None):
+                    raise ValueError("graph mode: alpha must be given on every step or on none")
+                continue
+            key = (t.data_ptr(), t._version)
+            if key != self._last_src[i]:
+                if t.shape != st.shape:
+                    raise ValueError("graph mode needs static shapes: got %s, captured %s" % (tuple(t.shape), tuple(st.shape)))
+                st.copy_(t)
+                self._last_src[i] = key
+
+    def _graph_step(self, x, real, z_d, z_g, alpha):
+        self._bind((x, real, z_d, z_g, alpha))
+        if self._graph is None and self._eager_calls < self.graph_warmup:
+            # eager warm-up on a side stream (allocator / autograd state as the capture will see it)
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                info = self._eager_step(*self._static)
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._eager_calls += 1
+            return info
+        if self._graph is None:
+            before = self._bn_snapshot()
+            tG, tD = self.optG.t, self.optD.t
+            if self.dpD is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._static_info = self._eager_step(*self._static)
+                graphs = [g]
+            else:
+                # data parallel: three graphs, the two flat all-reduces are issued eagerly between them (RCCL stays outside
+                # the capture); all three share one memory pool
+                sx, sreal, szd, szg, salpha = self._static
+                info: Dict[str, torch.Tensor] = {}
+                g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                w = 1.0 / self.dpD.world_size
+                with torch.cuda.graph(g1):
+                    real_t = self._seg_d(sx, sreal, szd, salpha, False, info)
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self._seg_g(sx, real_t, szg, w, False, info)
+                with torch.cuda.graph(g3, pool=g1.pool()):
+                    self._seg_opt_g(w, False, info)
+                self._static_info = info
+                graphs = [g1, g2, g3]
+            after = self._bn_snapshot()
+            # nothing ran during the capture: take the host-side bookkeeping of that step back, keep it as the per-replay delta
+            self._bn_delta = []
+            for m, b, a in zip(self._bn_modules(), before, after):
+                d = {pre: {k: n - b.get(pre, {}).get(k, 0) for k, n in pend.items()} for pre, pend in a.items()}
+                self._bn_delta.append(d)
+                store = m.__dict__.setdefault("_bn_pending", {})
+                for pre, pend in d.items():
+                    for k, n in pend.items():
+                        store[pre][k] -= n
+            self.optG.t, self.optD.t = tG, tD
+            self._graph = graphs
+        if len(self._graph) == 1:
+            self._graph[0].replay()
+        else:
+            self._graph[0].replay()
+            self.dpD.allreduce_grads()
+            self._graph[1].replay()
+            self.dpG.allreduce_grads()
+            self._graph[2].replay()
+        for m, d in zip(self._bn_modules(), self._bn_delta):
+            store = m.__dict__.setdefault("_bn_pending", {})
+            for pre, pend in d.items():
+                tgt = store.setdefault(pre, {})
+                for k, n in pend.items():
+                    tgt[k] = tgt.get(k, 0) + n
+        self.optG.t += 1; self.optD.t += 1
+        return self._static_info
 
     def step(self, x: torch.Tensor, real: torch.Tensor, z_d: torch.Tensor, z_g: torch.Tensor, alpha: Optional[torch.Tensor] = None,
              keep_grads: bool = False) -> Dict[str, torch.Tensor]:
-        """x: sphere [B,N,3]; real [B,N,3]; z_d, z_g [B,N,nz] (noise for the D- and the G-step)."""
+        """x: sphere [B,N,3]; real [B,N,3]; z_d, z_g [B,N,nz] (noise for the D- and the G-step).
+        In graph mode the returned tensors are static buffers that the next step overwrites."""
+        if self.use_graph and not keep_grads:
+            return self._graph_step(x, real, z_d, z_g, alpha)
+        return self._eager_step(x, real, z_d, z_g, alpha, keep_grads)
+
+    # The iteration in three segments, split where the data-parallel all-reduces sit (they stay outside the captured graphs).
+    def _seg_d(self, x, real, z_d, alpha, keep_grads, info):
+        """D step up to lossD.backward() (model.py:240-258)."""
         G, D = self.G, self.D
         B, N, _ = real.shape
-        info: Dict[str, torch.Tensor] = {}
-        # ------------------------------------------------------------ D step (model.py:240-260)
         requires_grad(G, False); requires_grad(D, True)
         self.optD.zero_grad()
         fake = G(x, z_d).detach()
@@ -59,12 +170,17 @@ class TrainStep:
         if self.use_gp:
             loss_d = loss_d + self.gp(D, real_t, fake, alpha=alpha)
         loss_d.backward()
-        scale = self.dpD.allreduce_grads() if self.dpD is not None else 1.0
         if keep_grads:
-            info["d_grads"] = {n: p.grad.detach().clone() * scale for n, p in D.named_parameters()}
             info["fake_d"] = fake
-        self.optD.step(scale)
-        # ------------------------------------------------------------ G step (model.py:264-279)
+        info.update(loss_d=loss_d.detach(), real_acc=dinfo["real_acc"], fake_acc=dinfo["fake_acc"])
+        return real_t
+
+    def _seg_g(self, x, real_t, z_g, scale_d, keep_grads, info):
+        """optimizerD.step(), then the G step up to lossG.backward() (model.py:259-277)."""
+        G, D = self.G, self.D
+        if keep_grads:
+            info["d_grads"] = {n: p.grad.detach().clone() * scale_d for n, p in D.named_parameters()}
+        self.optD.step(scale_d)
         requires_grad(G, True); requires_grad(D, False)
         self.optG.zero_grad()
         g_fake = G(x, z_g)
@@ -72,10 +188,20 @@ class TrainStep:
         g_fake_logit = D(g_fake)
         loss_g, _ = gen_loss(g_real_logit, g_fake_logit, gan=self.gan, noise_label=self.flip_g)
         loss_g.backward()
-        scale = self.dpG.allreduce_grads() if self.dpG is not None else 1.0
         if keep_grads:
-            info["g_grads"] = {n: p.grad.detach().clone() * scale for n, p in G.named_parameters()}
             info["fake_g"] = g_fake.detach()
-        self.optG.step(scale)
-        info.update(loss_d=loss_d.detach(), loss_g=loss_g.detach(), real_acc=dinfo["real_acc"], fake_acc=dinfo["fake_acc"])
+        info["loss_g"] = loss_g.detach()
+
+    def _seg_opt_g(self, scale_g, keep_grads, info):
+        if keep_grads:
+            info["g_grads"] = {n: p.grad.detach().clone() * scale_g for n, p in self.G.named_parameters()}
+        self.optG.step(scale_g)
+
+    def _eager_step(self, x, real, z_d, z_g, alpha=None, keep_grads: bool = False) -> Dict[str, torch.Tensor]:
+        info: Dict[str, torch.Tensor] = {}
+        real_t = self._seg_d(x, real, z_d, alpha, keep_grads, info)
+        scale = self.dpD.allreduce_grads() if self.dpD is not None else 1.0
+        self._seg_g(x, real_t, z_g, scale, keep_grads, info)
+        scale = self.dpG.allreduce_grads() if self.dpG is not None else 1.0
+        self._seg_opt_g(scale, keep_grads, info)
         return info

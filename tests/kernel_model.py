@@ -7,6 +7,7 @@ Two uses:
     oracle on the CPU.  The product never imports this file.
 Signatures mirror spgan/ops.py one to one.
 """
+import math
 from typing import Optional
 
 import torch
@@ -448,6 +449,14 @@ def adam_step(p, g, m, v, step, lr=1e-4, beta1=0.5, beta2=0.99, eps=1e-8, grad_s
     v.mul_(beta2).addcmul_(gr, gr, value=1 - beta2)
     denom = v.sqrt() / math.sqrt(1 - beta2 ** step) + eps
     p.addcdiv_(m, denom, value=-lr / (1 - beta1 ** step))
+
+
+def adam_step_dev(p, g, m, v, state, lr=1e-4, beta1=0.5, beta2=0.99, eps=1e-8, grad_scale=1.0):
+    step = int(state[:1].view(torch.int32).item()) + 1
+    state[:1].view(torch.int32).fill_(step)
+    state[1] = 1.0 - beta1 ** step
+    state[2] = 1.0 / math.sqrt(1.0 - beta2 ** step)
+    adam_step(p, g, m, v, step, lr, beta1, beta2, eps, grad_scale)
 
 
 def act_bwd(dy, y, act, slope=0.0):

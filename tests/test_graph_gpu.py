@@ -1,0 +1,75 @@
+"""GPU: the hipGraph-captured train step replays exactly the eager step (same kernels, same order: bit-identical parameters,
+buffers and optimiser state), including the host-side BatchNorm call counts and Adam's step count."""
+import pytest
+import torch
+
+from spgan import fixture_rng as fr
+from oracle import spgan_oracle as orc
+from test_parity_gpu import Opts, _load, sp  # noqa: F401  (sp is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(sp, graph, steps, B=4, N=256):
+    o = Opts()
+    G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(), salt=8))
+    D = _load(sp.Discriminator(o), fr.init_params(orc.discriminator_shapes(), salt=8))
+    tr = sp.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, graph=graph, graph_warmup=2)
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    real = [fr.synthetic_real(B, N, seed=90 + i).cuda() for i in range(2)]
+    zs = [fr.latent(B, N, seed=70 + i).cuda() for i in range(3)]
+    alpha = fr.uniform("graph.alpha", (B, 1, 1), 0.0, 1.0).cuda()
+    losses = []
+    for i in range(steps):
+        info = tr.step(x, real[i % 2], zs[i % 3], zs[(i + 1) % 3], alpha=alpha)
+        losses.append((info["loss_d"].item(), info["loss_g"].item()))
+    torch.cuda.synchronize()
+    return G, D, tr, losses
+
+
+def test_graph_replay_equals_eager(sp):
+    steps = 6                                    # 2 eager warm-up steps, capture + 4 replays
+    Ge, De, tre, le = _run(sp, False, steps)
+    Gg, Dg, trg, lg = _run(sp, True, steps)
+    assert trg._graph is not None, "the step was never captured"
+    assert le == lg, (le, lg)
+    for (n, a), (_, b) in zip(list(Ge.state_dict().items()) + list(De.state_dict().items()),
+                              list(Gg.state_dict().items()) + list(Dg.state_dict().items())):
+        assert torch.equal(a, b), n
+    assert (tre.optG.t, tre.optD.t) == (trg.optG.t, trg.optD.t) == (steps, steps)
+    assert torch.equal(tre.optD.m, trg.optD.m) and torch.equal(tre.optG.v, trg.optG.v)
+    assert int(trg.optD.dev_state[:1].view(torch.int32).item()) == steps
+
+
+def test_graph_replay_data_parallel_segments(sp):
+    """Data-parallel mode captures three graphs with the RCCL all-reduces issued eagerly between them (one rank here)."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    try:
+        steps = 5
+        Ge, De, tre, le = _run(sp, False, steps)
+
+        def run_dp():
+            o = Opts()
+            G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(), salt=8))
+            D = _load(sp.Discriminator(o), fr.init_params(orc.discriminator_shapes(), salt=8))
+            tr = sp.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, graph=True, graph_warmup=2, distributed=True)
+            B, N = 4, 256
+            x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+            real = [fr.synthetic_real(B, N, seed=90 + i).cuda() for i in range(2)]
+            zs = [fr.latent(B, N, seed=70 + i).cuda() for i in range(3)]
+            alpha = fr.uniform("graph.alpha", (B, 1, 1), 0.0, 1.0).cuda()
+            for i in range(steps):
+                tr.step(x, real[i % 2], zs[i % 3], zs[(i + 1) % 3], alpha=alpha)
+            torch.cuda.synchronize()
+            return G, D, tr
+        Gg, Dg, trg = run_dp()
+        assert len(trg._graph) == 3
+        for (n, a), (_, b) in zip(list(Ge.state_dict().items()) + list(De.state_dict().items()),
+                                  list(Gg.state_dict().items()) + list(Dg.state_dict().items())):
+            assert torch.equal(a, b), n
+    finally:
+        dist.destroy_process_group()
