@@ -69,9 +69,10 @@ def _pmc_traffic():
 
 
 # Dominant kernel of the step (profiles/r01_bench_*_kernel_stats.txt): gemm_nt_kernel<affine prologue, linear epilogue + column
-# statistics, 128x64 tile> at the Discriminator's 256->1024 layer (Discriminator.py:74-81): M = B*N points, N = 1024, K = 256;
-# 5 launches per step (4 D forwards + the tangent pass of the WGAN-GP double backward).
-DOMINANT = {"N": 1024, "K": 256, "a_mode": 1, "pmc_key": "gemm_nt D.L4 M=65536 N=1024 K=256 (affine prologue + statistics)"}
+# statistics + max-pool partials, 128x64 tile> at the Discriminator's 256->1024 layer (Discriminator.py:74-81,104): M = B*N points,
+# N = 1024, K = 256; 5 launches per step (the 5 D forwards of the reference loop body).
+DOMINANT = {"N": 1024, "K": 256, "a_mode": 1,
+            "pmc_key": "gemm_nt D.fc2.0 M=65536 N=1024 K=256 (affine prologue + statistics + pooling partials, output not stored)"}
 
 
 class DominantKernelTimer:
@@ -96,7 +97,7 @@ class DominantKernelTimer:
         ms = sum(e0.elapsed_time(e1) for e0, e1 in self.events) / len(self.events)
         flops = 2.0 * self.M * DOMINANT["N"] * DOMINANT["K"]          # 2*N*256*1024 per shape x the shapes of one launch
         achieved = flops / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "gemm_nt_kernel<1,0,1,0,1> at D.fc2.0 (M=%d N=%d K=%d, BN+LeakyReLU prologue, column-statistics epilogue)"
+        return {"bound": "mfma", "kernel": "gemm_nt_kernel<1,0,1,0,1> at D.fc2.0 (M=%d N=%d K=%d, BN+LeakyReLU prologue, column-statistics + max-pool epilogue, output not stored)"
                                            % (self.M, DOMINANT["N"], DOMINANT["K"]),
                 "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
                 "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches_timed": len(self.events), "traffic": _pmc_traffic()}
