@@ -10,6 +10,7 @@ formulas in the WGAN-GP double backward.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -27,8 +28,24 @@ def _w2(w: Tensor) -> Tensor:
     return w.view(w.shape[0], w.shape[1])
 
 
+_T_CACHE: Dict[Tuple[int, Tuple[int, ...]], tuple] = {}      # (data_ptr, shape) -> (stamp, w^T, weakref to the owning Parameter)
+
+
 def _t(w: Tensor) -> Tensor:
-    return w.t().contiguous()
+    """w^T, contiguous.  For (views of) parameters the copy is cached until the weights change: the four backward passes of a
+    D-step transpose the same matrices.  "Changed" = an in-place torch op (version counter) or an optimiser step of
+    spgan.optim.Adam, whose HIP kernel updates the flat buffer behind torch's back and bumps ops.WEIGHTS_EPOCH instead."""
+    base = w._base if w._base is not None else w
+    if not isinstance(base, torch.nn.Parameter):
+        return w.t().contiguous()
+    key = (w.data_ptr(), tuple(w.shape))
+    stamp = (ops.WEIGHTS_EPOCH[0], base._version)
+    hit = _T_CACHE.get(key)
+    if hit is not None and hit[0] == stamp and hit[2]() is base:     # same live Parameter object (not a new one at a recycled address)
+        return hit[1]
+    t = w.t().contiguous()
+    _T_CACHE[key] = (stamp, t, weakref.ref(base))
+    return t
 
 
 def _cat2(s0: Tensor, s1: Tensor) -> Tensor:

@@ -77,6 +77,10 @@ def _ld(t: Tensor) -> int:
 # the launch was enqueued -- the bench brackets selected launches with HIP events on the launch stream.  None in normal use.
 launch_timer = None
 
+# Bumped by every optimiser step that rewrites parameters through a HIP kernel (invisible to torch's version counters);
+# host-side caches of weight-derived tensors (nets._t) key on it.
+WEIGHTS_EPOCH = [0]
+
 
 # ----------------------------------------------------------------------------- graph
 def knn(x_pm: Tensor, B: int, N: int, k: int, mode: int = 0) -> Tensor:

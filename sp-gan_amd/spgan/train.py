@@ -100,7 +100,7 @@ class TrainStep:
             tG, tD = self.optG.t, self.optD.t
             if self.dpD is None:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._static_info = self._eager_step(*self._static)
                 graphs = [g]
             else:
@@ -110,11 +110,11 @@ class TrainStep:
                 info: Dict[str, torch.Tensor] = {}
                 g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 w = 1.0 / self.dpD.world_size
-                with torch.cuda.graph(g1):
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to call HIP
                     real_t = self._seg_d(sx, sreal, szd, salpha, False, info)
-                with torch.cuda.graph(g2, pool=g1.pool()):
+                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
                     self._seg_g(sx, real_t, szg, w, False, info)
-                with torch.cuda.graph(g3, pool=g1.pool()):
+                with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode="thread_local"):
                     self._seg_opt_g(w, False, info)
                 self._static_info = info
                 graphs = [g1, g2, g3]
