@@ -148,20 +148,22 @@ def adaptive_point_norm(p, prefix: str, x: Tensor, style: Tensor) -> Tensor:
     return gamma * xhat + beta
 
 
-def generator_forward(p, x: Tensor, z: Tensor, k: int = 10, training: bool = True,
-                      buffers=None, idx1: Optional[Tensor] = None, idx2: Optional[Tensor] = None,
-                      off: bool = False, z_norm: bool = False, stages: Optional[dict] = None) -> Tensor:
-    """Generator.forward with default flags (use_head=False, attn=False, eql=False),
-    Generation/Generator.py:160-198.  x [B,N,3], z [B,N,nz] -> [B,3,N].
-    `stages`, when given, receives the intermediate activations (used by the golden tests)."""
-    B, N, _ = x.shape
+def generator_style(p, x: Tensor, z: Tensor, z_norm: bool = False) -> Tensor:
+    """The style branch: head MLP on cat[x, z] (Generator.py:163-169 / 203-215).  -> [B,128,N]"""
     if z_norm:                                                  # Generator.py:163-164
         z = z / (z.norm(p=2, dim=-1, keepdim=True) + 1e-8)
     style = torch.cat([x, z], dim=-1).transpose(2, 1).contiguous()
     style = F.leaky_relu(_conv1x1(style, p, "head.0"), NEG)
-    style = F.leaky_relu(_conv1x1(style, p, "head.2"), NEG)     # [B,128,N]
-    pc = x.transpose(2, 1).contiguous()
+    return F.leaky_relu(_conv1x1(style, p, "head.2"), NEG)
 
+
+def generator_body(p, x: Tensor, style: Tensor, k: int = 10, training: bool = True, buffers=None,
+                   idx1: Optional[Tensor] = None, idx2: Optional[Tensor] = None, off: bool = False,
+                   stages: Optional[dict] = None) -> Tensor:
+    """Everything behind the style branch (Generator.py:170-198 == 232-261): the two EdgeConv + AdaIN stages, the global
+    feature, the tail."""
+    B, N, _ = x.shape
+    pc = x.transpose(2, 1).contiguous()
     x1, i1 = edge_block(p, "EdgeConv1", pc, k, idx=idx1, training=training, buffers=buffers, return_idx=True)
     x1 = adaptive_point_norm(p, "adain1", F.leaky_relu(x1, NEG_2), style)
     x2, i2 = edge_block(p, "EdgeConv2", x1, k, idx=idx2, training=training, buffers=buffers, return_idx=True)
@@ -180,6 +182,34 @@ def generator_forward(p, x: Tensor, z: Tensor, k: int = 10, training: bool = Tru
     if stages is not None:
         stages.update(style=style, x1=x1, x2=x2, idx1=i1, idx2=i2, feat_global=g, out=out)
     return pc + out if off else out
+
+
+def generator_forward(p, x: Tensor, z: Tensor, k: int = 10, training: bool = True,
+                      buffers=None, idx1: Optional[Tensor] = None, idx2: Optional[Tensor] = None,
+                      off: bool = False, z_norm: bool = False, stages: Optional[dict] = None) -> Tensor:
+    """Generator.forward with default flags (use_head=False, attn=False, eql=False),
+    Generation/Generator.py:160-198.  x [B,N,3], z [B,N,nz] -> [B,3,N].
+    `stages`, when given, receives the intermediate activations (used by the golden tests)."""
+    return generator_body(p, x, generator_style(p, x, z, z_norm), k, training, buffers, idx1, idx2, off, stages)
+
+
+def generator_interpolate(p, x: Tensor, z1: Tensor, z2: Tensor, selection: Tensor, alpha: float, use_latent: bool = False,
+                          k: int = 10, training: bool = False, buffers=None, idx1: Optional[Tensor] = None,
+                          idx2: Optional[Tensor] = None, off: bool = False, z_norm: bool = False,
+                          stages: Optional[dict] = None) -> Tensor:
+    """Generator.interpolate, Generation/Generator.py:200-261: on the points with selection == 1 blend the two latents
+    (use_latent=False, :204-206) or the two styles (use_latent=True, :217-230) with weight alpha, then the common body.
+    (The reference blends in place into z1 / style_1; inputs are not modified here.)"""
+    sel = selection == 1
+    if not use_latent:
+        z = z1.clone()
+        z[:, sel] = z1[:, sel] * (1 - alpha) + z2[:, sel] * alpha
+        style = generator_style(p, x, z, z_norm)
+    else:
+        s1, s2 = generator_style(p, x, z1, z_norm), generator_style(p, x, z2, z_norm)
+        style = s1.clone()
+        style[:, :, sel] = s1[:, :, sel] * (1 - alpha) + s2[:, :, sel] * alpha
+    return generator_body(p, x, style, k, training, buffers, idx1, idx2, off, stages)
 
 
 def discriminator_forward(p, x: Tensor, training: bool = True, buffers=None,

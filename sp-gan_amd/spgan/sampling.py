@@ -1,0 +1,100 @@
+"""Input sampling of the reference's train/test loops, generated on the device (Generation/model.py:46-52,122-180):
+the per-shape (or per-point / region-mixed) latent noise, the sphere prior and the `.xyz` sample dump.
+
+The reference draws from numpy's global, never-seeded RNG on the host and uploads 33 MB of tiled noise per call; here the
+draws come from a seedable torch.Generator on the GPU (reproducible, no PCIe traffic).  Distributions and shapes are the
+reference's; the individual random numbers necessarily differ (the reference's are not reproducible either, model.py:40).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import fixture_rng
+
+
+def pc_normalize(pc: torch.Tensor) -> torch.Tensor:
+    """model.py:46-52: centre on the centroid, scale the farthest point to radius 1.  pc [N,3]."""
+    pc = pc - pc.mean(dim=0, keepdim=True)
+    return pc / pc.norm(dim=1).max()
+
+
+class InputSampler:
+    """`noise_generator` / `sphere_generator` of Generation/model.py:122-180 as device-side samplers.
+    opts fields read: np (points), nz (latent size), nv (noise std), n_rand, n_mix."""
+
+    def __init__(self, opts, device="cuda", seed: Optional[int] = None):
+        self.opts = opts
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        if seed is not None:
+            self.gen.manual_seed(seed)
+        self.ball: Optional[torch.Tensor] = None          # [np,3] normalised template
+        self.ball_order: Optional[torch.Tensor] = None    # lazily: argsort of the reference's ball_dist rows
+
+    # ------------------------------------------------------------------ sphere prior
+    def _load_ball(self):
+        if self.ball is None:
+            self.ball = fixture_rng.sphere_template(self.opts.np).to(self.device)      # template/balls/<np>.xyz, pc_normalize'd
+
+    def sphere_generator(self, bs: int = 2, static: bool = True) -> torch.Tensor:
+        """model.py:156-180.  static: the template tiled to [bs,np,3]; otherwise np points drawn with replacement per shape."""
+        self._load_ball()
+        if static:
+            return self.ball[None].repeat(bs, 1, 1)
+        idx = torch.randint(0, self.ball.shape[0], (bs, self.opts.np), generator=self.gen, device=self.device)
+        return self.ball[idx]
+
+    def _region_order(self, centre: torch.Tensor) -> torch.Tensor:
+        """Rows of argsort(ball_dist) for the given centre points.  ball_dist is the reference's expression
+        -2*|x|^2|y|^2 + |x|^2 + |y|^2 (model.py:164-167: it multiplies the squared norms instead of taking the inner
+        product) -- kept, since it defines which points a 'region' contains."""
+        self._load_ball()
+        xx = (self.ball ** 2).sum(dim=1)                                              # [np]
+        d = -2.0 * xx[centre][:, None] * xx[None, :] + xx[centre][:, None] + xx[None, :]
+        return torch.argsort(d, dim=1, stable=True)
+
+    # ------------------------------------------------------------------ latent noise
+    def noise_generator(self, bs: int = 1, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """model.py:122-154 -> [bs, np, nz].
+        default: one N(0, nv^2) vector per shape, tiled over the points; n_rand: independent per point; n_mix: with
+        probability 1/2 a random region (the `num` points closest to a random centre in ball_dist order, num =
+        max(U,0.1)*np) of every shape gets a second vector.  masks [bs,np] (part labels): one N(0, 0.2^2) vector per part
+        (the reference's masks branch assigns the index array instead of the drawn vector, model.py:151 -- the evident
+        intent is implemented)."""
+        o, dev, g = self.opts, self.device, self.gen
+        if masks is not None:
+            masks = torch.as_tensor(masks, device=dev)
+            noise = torch.zeros((masks.shape[0], o.np, o.nz), device=dev)
+            for i in range(masks.shape[0]):
+                for j in torch.unique(masks[i]).tolist():
+                    noise[i, masks[i] == j] = torch.randn((o.nz,), generator=g, device=dev) * 0.2
+            return noise
+        if o.n_rand:
+            noise = torch.randn((bs, o.np, o.nz), generator=g, device=dev) * o.nv
+        else:
+            noise = (torch.randn((bs, 1, o.nz), generator=g, device=dev) * o.nv).repeat(1, o.np, 1)
+        if getattr(o, "n_mix", False) and torch.rand((), generator=g, device=dev).item() < 0.5:
+            noise2 = torch.randn((bs, o.nz), generator=g, device=dev) * o.nv
+            centre = torch.randint(0, o.np, (bs,), generator=g, device=dev)
+            order = self._region_order(centre)                                        # [bs, np]
+            num = (torch.rand((bs,), generator=g, device=dev).clamp_min(0.1) * o.np).long()
+            inside = torch.arange(o.np, device=dev)[None, :] < num[:, None]           # first `num` entries of each order row
+            sel = torch.zeros((bs, o.np), dtype=torch.bool, device=dev).scatter_(1, order, inside)
+            noise = torch.where(sel[:, :, None], noise2[:, None, :], noise)
+        return noise
+
+
+def save_xyz(path: str, points: torch.Tensor) -> None:
+    """One shape per file, `x y z` per line with 6 decimals (the np.savetxt(fmt='%.6f') dump of model.py:371-410).
+    points [N,3] or [3,N]."""
+    p = points.detach().float().cpu()
+    if p.dim() != 2 or 3 not in p.shape:
+        raise ValueError("save_xyz expects [N,3] or [3,N], got %s" % (tuple(p.shape),))
+    if p.shape[1] != 3:
+        p = p.t()
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    np.savetxt(path, p.numpy(), fmt="%.6f")

@@ -360,6 +360,46 @@ def g9():
     save("g9_ball_group.npz", d)
 
 
+# ---------------------------------------------------------------- G10: eval-mode generation + interpolate
+def g10():
+    """model_test.py:63-64 calls G.eval() before generating: BatchNorm uses running statistics (advanced here by two
+    train-mode forwards), InstanceNorm is unchanged.  Generator.forward, Generator.interpolate (both modes) and the
+    Discriminator in eval mode on the generated clouds."""
+    B, N = 2, 256
+    G, D = make_gd(salt=10)
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    with torch.no_grad():
+        for s in (0, 1):
+            D(G(x, fr.latent(B, N, seed=100 + s)))            # train mode: running statistics move away from (0, 1)
+    G.eval(); D.eval()
+    d = {}
+    for n, b in G.named_buffers():
+        d["gbuf|" + n] = b.numpy().copy()
+    for n, b in D.named_buffers():
+        d["dbuf|" + n] = b.numpy().copy()
+    z1, z2 = fr.latent(B, N, seed=110), fr.latent(B, N, seed=111)
+    selection = (fr.uniform("g10.sel", (N,), 0.0, 1.0) < 0.4).to(torch.int64)
+    alpha = 0.3
+    stage = {}
+    hook = G.adain1.register_forward_hook(lambda m, i, o: stage.__setitem__("x1", o.detach().clone()))
+    with torch.no_grad():
+        for tag, fn in (("fwd", lambda: G(x, z1.clone())),
+                        ("interp_z", lambda: G.interpolate(x, z1.clone(), z2.clone(), selection, alpha, use_latent=False)),
+                        ("interp_style", lambda: G.interpolate(x, z1.clone(), z2.clone(), selection, alpha, use_latent=True))):
+            out = fn()
+            _, idx2 = get_edge_features(stage["x1"], 10, return_idx=True)
+            put(d, tag + "|out", out, full_limit=1 << 20)
+            put(d, tag + "|x1", stage["x1"], full_limit=1 << 17)
+            d[tag + "|idx2"] = idx2.view(B, N, 10).numpy().astype(np.int32)
+            put(d, tag + "|logit", D(out))
+    hook.remove()
+    d["selection"] = selection.numpy().astype(np.int32)
+    d["alpha"] = np.float32(alpha)
+    save("g10_eval_interpolate.npz", d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    g1(); g2(); g3(); g4_g5(); g6(); g7(); g8(); g9()
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10"]
+    for name in which:
+        globals()[name]()

@@ -242,3 +242,35 @@ def test_ball_group_family():
     gi = torch.from_numpy(d["group|idx"].astype(np.int64))
     np_, gx = orc.group(10, xyz, feat, idx=gi)
     assert np.array_equal(np_.numpy(), d["group|new_points"]) and np.array_equal(gx.numpy(), d["group|xyz_norm"])
+
+
+# ---------------------------------------------------------------- G10: eval-mode generation + interpolate
+def _eval_setup():
+    d = golden("g10_eval_interpolate.npz")
+    B, N = 2, 256
+    pg = fr.init_params(orc.generator_shapes(), salt=10)
+    pd = fr.init_params(orc.discriminator_shapes(), salt=10)
+    bg = {k[5:]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith("gbuf|")}
+    bd = {k[5:]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith("dbuf|")}
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    z1, z2 = fr.latent(B, N, seed=110), fr.latent(B, N, seed=111)
+    sel = torch.from_numpy(d["selection"].astype(np.int64))
+    return d, pg, pd, bg, bd, x, z1, z2, sel, float(d["alpha"])
+
+
+@pytest.mark.parametrize("tag", ["fwd", "interp_z", "interp_style"])
+def test_eval_generation_and_interpolate(tag):
+    d, pg, pd, bg, bd, x, z1, z2, sel, alpha = _eval_setup()
+    B, N = x.shape[:2]
+    idx2 = torch.from_numpy(d[tag + "|idx2"].astype(np.int64)).view(B, N * 10)      # the reference's own feature graph (tie-aware protocol)
+    st = {}
+    with torch.no_grad():
+        if tag == "fwd":
+            out = orc.generator_forward(pg, x, z1, training=False, buffers=bg, idx2=idx2, stages=st)
+        else:
+            out = orc.generator_interpolate(pg, x, z1, z2, sel, alpha, use_latent=(tag == "interp_style"), training=False, buffers=bg,
+                                            idx2=idx2, stages=st)
+        logit = orc.discriminator_forward(pd, out, training=False, buffers=bd)
+    check(d, tag + "|x1", st["x1"], rtol=2e-5)
+    check(d, tag + "|out", out, rtol=1e-4)
+    check(d, tag + "|logit", logit, rtol=1e-3)

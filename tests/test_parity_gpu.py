@@ -217,3 +217,46 @@ def test_train_step_golden(sp, tag, gan, use_gp, B, N):
             check(d, "gparam|" + n, p, rtol=1e-3, atol=2.5e-4)      # one Adam step moves an element by <= lr; sign noise => 2*lr
     for n, b in [(k, v) for k, v in D.state_dict().items() if k in dict(D.named_buffers())]:
         np.testing.assert_allclose(b.cpu().numpy(), d["dbuf|" + n], rtol=2e-3, atol=2e-4)
+
+
+# ---------------------------------------------------------------- eval-mode generation + interpolate (G10)
+@pytest.mark.parametrize("tag", ["fwd", "interp_z", "interp_style"])
+def test_eval_generation_and_interpolate_golden(sp, tag):
+    """model_test.py:63-64: G.eval() + G(x, z) / G.interpolate(...): BatchNorm on running statistics, no autograd."""
+    d = golden("g10_eval_interpolate.npz")
+    B, N = 2, 256
+    G = _load(sp.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=10))
+    D = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=10))
+    G.load_state_dict({k[5:]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith("gbuf|")}, strict=False)
+    D.load_state_dict({k[5:]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith("dbuf|")}, strict=False)
+    G.eval(); D.eval()
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    z1, z2 = fr.latent(B, N, seed=110).cuda(), fr.latent(B, N, seed=111).cuda()
+    sel = torch.from_numpy(d["selection"].astype(np.int64)).cuda()
+    alpha = float(d["alpha"])
+    with torch.no_grad():
+        if tag == "fwd":
+            out = G(x, z1.clone())
+        else:
+            out = G.interpolate(x, z1.clone(), z2.clone(), sel, alpha, use_latent=(tag == "interp_style"))
+        logit = D(out)
+    check(d, tag + "|x1", sp.ops.pm_to_cm(G.last_x1, B, N), rtol=2e-5)          # tie-independent stage: tight
+    i2 = sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).view(B, N, 10).cpu().numpy()
+    same = (i2 == d[tag + "|idx2"]).all(axis=2)
+    assert same.mean() >= 0.995, "EdgeConv2 kNN row agreement %.4f" % same.mean()
+    if same.all():
+        check(d, tag + "|out", out, rtol=2e-4)
+        check(d, tag + "|logit", logit, rtol=2e-3)
+    else:
+        # a flipped near-tie row: compare with the oracle run on OUR graph instead (tie-aware protocol)
+        pg = fr.init_params(orc.generator_shapes(), salt=10)
+        bg = {k[5:]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith("gbuf|")}
+        idx2 = sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).cpu()
+        xc, z1c, z2c = x.cpu(), z1.cpu(), z2.cpu()
+        with torch.no_grad():
+            if tag == "fwd":
+                ref = orc.generator_forward(pg, xc, z1c, training=False, buffers=bg, idx2=idx2)
+            else:
+                ref = orc.generator_interpolate(pg, xc, z1c, z2c, sel.cpu(), alpha, use_latent=(tag == "interp_style"), training=False,
+                                                buffers=bg, idx2=idx2)
+        assert rel_l2(out.cpu().numpy(), ref.numpy()) <= 2e-4
