@@ -96,3 +96,28 @@ def test_knn_full_size_invariants(N, C, mode):
         tol = 0.0 if mode == 1 else 3e-5 * C
         assert (got - srt[1:k + 1]).abs().max().item() <= tol, (r, (got - srt[1:k + 1]).abs().max().item())
         assert (idx[r] >= b * N).all() and (idx[r] < (b + 1) * N).all()
+
+
+@pytest.mark.parametrize("B,N,gan,use_gp", [(16, 4096, "wgan", True), (4, 512, "ls", False)])
+def test_c4_c1_step_properties(B, N, gan, use_gp):
+    """BASELINE configs[3] per-GPU shape (N=4096, b=16) and configs[0] (N=512, bs=4, LS): the step is finite, replayable as a
+    hipGraph with bit-identical results, and the sphere graph equals the reference's."""
+    import spgan
+
+    class O(Opts):
+        np = N
+    x, real, z1, z2, alpha = _inputs(B, N)
+    res = []
+    for graph in (False, True):
+        torch.manual_seed(123)
+        G, D = spgan.Generator(O).cuda(), spgan.Discriminator(O, num_point=N).cuda()
+        tr = spgan.TrainStep(G, D, gan=gan, use_gp=use_gp, lambda_gp=10.0, graph=graph, graph_warmup=1)
+        for i in range(3):
+            info = tr.step(x, real, z1 if i % 2 == 0 else z2, z2 if i % 2 == 0 else z1, alpha=alpha if use_gp else None)
+        torch.cuda.synchronize()
+        assert torch.isfinite(info["loss_d"]).item() and torch.isfinite(info["loss_g"]).item()
+        res.append(torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())]).clone())
+        ref = torch.from_numpy(golden("g1_edge_features.npz")["sphere%d|idx" % N].astype(np.int64))
+        loc = spgan.ops.idx_to_local64(G.EdgeConv1.last_idx, B, N).view(B, N, 10).cpu()
+        assert (loc == ref[None]).all()
+    assert torch.equal(res[0], res[1]), "graph replay differs from eager issue"
