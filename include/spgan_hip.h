@@ -354,6 +354,20 @@ int spgan_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
 int spgan_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                         float* state3, float grad_scale, spgan_stream_t s);
 
+/* ------------------------------------------------------------------------------------------
+ * Evaluation metrics: Chamfer distance.
+ * ---------------------------------------------------------------------------------------- */
+/* dist[b,i] = min_j |xyz1[b,i] - xyz2[b,j]|^2, idx[b,i] = the first j attaining it (index into xyz2[b]): one direction of
+ * chamfer.forward (metrics/CD_EMD/cd/chamferdist/chamfer.cu:12-113, ChamferDistance.py:13-31); xyz1 [B,N,3], xyz2 [B,M,3]. */
+int spgan_nn_distance(const float* xyz1, const float* xyz2, int B, int N, int M, float* dist, int32_t* idx, spgan_stream_t s);
+/* grad_a[b,i] = 2*ga[b,i]*(xa_i - xb[idxa[b,i]]) + sum_{j: idxb[b,j]==i} 2*gb[b,j]*(xa_i - xb_j): d/d(xa) of
+ * sum(ga*dist_a) + sum(gb*dist_b) (chamfer.cu:155-195, gather form: deterministic, no float atomics).  Call once per cloud. */
+int spgan_chamfer_bwd(const float* xa, const float* xb, int B, int Na, int Nb, const float* ga, const int32_t* idxa, const float* gb,
+                      const int32_t* idxb, float* grad_a, spgan_stream_t s);
+/* out[s,r] = mean_i min_j |A[s,i]-Bc[r,j]|^2 + mean_j min_i |A[s,i]-Bc[r,j]|^2 for every pair of clouds A[s] ([S,N,3]) and
+ * Bc[r] ([R,M,3]): the all-pairs Chamfer matrix behind MMD-CD / COV-CD / 1-NNA-CD (metrics/evaluation_metrics.py:89-126). */
+int spgan_chamfer_pairs(const float* A, const float* Bc, int S, int R, int N, int M, float* out, spgan_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

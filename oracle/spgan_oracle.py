@@ -484,3 +484,63 @@ def bn_buffers(shapes: Dict[str, Tuple[int, ...]]) -> Dict[str, Tensor]:
             out[base + ".running_var"] = torch.ones(shp)
             out[base + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
     return out
+
+
+# --------------------------------------------------------------------------- #
+# evaluation metrics, Chamfer part (metrics/evaluation_metrics.py)            #
+# --------------------------------------------------------------------------- #
+def dist_chamfer(a: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
+    """distChamfer, evaluation_metrics.py:39-50 (expanded form |x|^2 + |y|^2 - 2xy; bs x N x 3 both, same N):
+    returns (min over the points of a for every point of b, min over the points of b for every point of a)."""
+    xx = torch.bmm(a, a.transpose(2, 1))
+    yy = torch.bmm(b, b.transpose(2, 1))
+    zz = torch.bmm(a, b.transpose(2, 1))
+    n = a.shape[1]
+    d = torch.arange(n)
+    rx = xx[:, d, d].unsqueeze(1).expand_as(xx)
+    ry = yy[:, d, d].unsqueeze(1).expand_as(yy)
+    P = rx.transpose(2, 1) + ry - 2 * zz
+    return P.min(1)[0], P.min(2)[0]
+
+
+def nn_distance(a: Tensor, b: Tensor):
+    """chamferFunction.forward (ChamferDistance.py:13-31 over chamfer.cu:12-113): direct differences; for every point of a the
+    squared distance to and the index of its nearest point of b (first minimum), and vice versa."""
+    d = ((a[:, :, None, :] - b[:, None, :, :]) ** 2).sum(-1)
+    d1, i1 = d.min(2)
+    d2, i2 = d.min(1)
+    return d1, d2, i1.int(), i2.int()
+
+
+def pairwise_cd(sample: Tensor, ref: Tensor) -> Tensor:
+    """The CD half of _pairwise_EMD_CD_ (evaluation_metrics.py:89-126): [S, R] with dl.mean + dr.mean per pair."""
+    rows = []
+    for s in range(sample.shape[0]):
+        dl, dr = dist_chamfer(sample[s:s + 1].expand(ref.shape[0], -1, -1).contiguous(), ref)
+        rows.append((dl.mean(dim=1) + dr.mean(dim=1)).view(1, -1))
+    return torch.cat(rows, dim=0)
+
+
+def lgan_mmd_cov(all_dist: Tensor) -> dict:
+    """evaluation_metrics.py:161-173: all_dist [N_sample, N_ref]."""
+    n_ref = all_dist.shape[1]
+    min_val_fromsmp, min_idx = torch.min(all_dist, dim=1)
+    min_val, _ = torch.min(all_dist, dim=0)
+    return {"lgan_mmd": min_val.mean(), "lgan_cov": torch.tensor(float(min_idx.unique().numel()) / float(n_ref)),
+            "lgan_mmd_smp": min_val_fromsmp.mean()}
+
+
+def one_nn_accuracy(Mxx: Tensor, Mxy: Tensor, Myy: Tensor, k: int = 1) -> dict:
+    """knn, evaluation_metrics.py:129-158 (leave-one-out k-NN two-sample test on the joint distance matrix)."""
+    n0, n1 = Mxx.shape[0], Myy.shape[0]
+    label = torch.cat((torch.ones(n0), torch.zeros(n1)))
+    M = torch.cat((torch.cat((Mxx, Mxy), 1), torch.cat((Mxy.t(), Myy), 1)), 0)
+    M = M + torch.diag(float("inf") * torch.ones(n0 + n1))
+    _, idx = M.topk(k, 0, False)
+    count = torch.zeros(n0 + n1)
+    for i in range(k):
+        count = count + label.index_select(0, idx[i])
+    pred = (count >= float(k) / 2).float()
+    tp, fp = (pred * label).sum(), (pred * (1 - label)).sum()
+    fn, tn = ((1 - pred) * label).sum(), ((1 - pred) * (1 - label)).sum()
+    return {"acc_t": tp / (tp + fn + 1e-10), "acc_f": tn / (tn + fp + 1e-10), "acc": (label == pred).float().mean()}

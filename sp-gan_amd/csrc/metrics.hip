@@ -1,0 +1,174 @@
+// Chamfer distance for the evaluation metrics: nearest-neighbour distances between two clouds
+// (metrics/CD_EMD/cd/chamferdist/chamfer.cu:12-113), their gradient (chamfer.cu:155-195, here as a deterministic gather
+// instead of float atomics), and the all-pairs Chamfer matrix between two SETS of clouds that MMD-CD / COV-CD / 1-NNA-CD
+// are computed from (metrics/evaluation_metrics.py:89-126 calls the pairwise routine once per sample cloud).
+// 3-D coordinates: VALU work on direct differences (the reference CUDA kernel's formula), candidates staged in LDS.
+#include "common.hpp"
+
+namespace {
+
+constexpr int CT = 512;  // candidate points per LDS chunk
+
+// dist[b,i] = min_j |x1[b,i] - x2[b,j]|^2, idx[b,i] = the first j attaining it (strict <, ascending j: chamfer.cu:40-49)
+__global__ __launch_bounds__(256) void nn_distance_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int N, int M,
+                                                          float* __restrict__ dist, int32_t* __restrict__ idx) {
+  __shared__ float4 buf[CT];  // (x, y, z, -): one wave-wide broadcast ds_read_b128 per candidate
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = i < N;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (ok) {
+    const float* p = x1 + ((size_t)b * N + i) * 3;
+    px = p[0]; py = p[1]; pz = p[2];
+  }
+  float best = INFINITY;
+  int bi = 0;
+  for (int c0 = 0; c0 < M; c0 += CT) {
+    const int nc = min(CT, M - c0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nc; e += 256) {
+      const float* q = x2 + ((size_t)b * M + c0 + e) * 3;
+      buf[e] = make_float4(q[0], q[1], q[2], 0.f);
+    }
+    __syncthreads();
+    if (ok) {
+      for (int j = 0; j < nc; ++j) {
+        const float4 c = buf[j];
+        const float dx = c.x - px, dy = c.y - py, dz = c.z - pz;
+        const float d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; bi = c0 + j; }
+      }
+    }
+  }
+  if (ok) {
+    dist[(size_t)b * N + i] = best;
+    idx[(size_t)b * N + i] = bi;
+  }
+}
+
+// grad_a[b,i] = 2*ga[b,i]*(xa_i - xb[idxa[b,i]]) + sum_{j: idxb[b,j] == i} 2*gb[b,j]*(xa_i - xb_j)      (ascending j)
+// -- both terms of d(sum ga*dist_a + sum gb*dist_b)/d xa_i: its own nearest neighbour, and every xb_j that chose xa_i.
+__global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float* __restrict__ xa, const float* __restrict__ xb, int Na, int Nb,
+                                                          const float* __restrict__ ga, const int32_t* __restrict__ idxa,
+                                                          const float* __restrict__ gb, const int32_t* __restrict__ idxb,
+                                                          float* __restrict__ grad_a) {
+  __shared__ float buf[CT * 3];
+  __shared__ float gbuf[CT];
+  __shared__ int ibuf[CT];
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = i < Na;
+  float px = 0.f, py = 0.f, pz = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+  if (ok) {
+    const float* p = xa + ((size_t)b * Na + i) * 3;
+    px = p[0]; py = p[1]; pz = p[2];
+    const float* q = xb + ((size_t)b * Nb + idxa[(size_t)b * Na + i]) * 3;
+    const float g = 2.f * ga[(size_t)b * Na + i];
+    ax = g * (px - q[0]); ay = g * (py - q[1]); az = g * (pz - q[2]);
+  }
+  for (int c0 = 0; c0 < Nb; c0 += CT) {
+    const int nc = min(CT, Nb - c0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nc * 3; e += 256) buf[e] = xb[((size_t)b * Nb + c0) * 3 + e];
+    for (int e = threadIdx.x; e < nc; e += 256) {
+      gbuf[e] = gb[(size_t)b * Nb + c0 + e];
+      ibuf[e] = idxb[(size_t)b * Nb + c0 + e];
+    }
+    __syncthreads();
+    if (ok) {
+      for (int j = 0; j < nc; ++j) {
+        if (ibuf[j] == i) {
+          const float g = 2.f * gbuf[j];
+          ax += g * (px - buf[j * 3]); ay += g * (py - buf[j * 3 + 1]); az += g * (pz - buf[j * 3 + 2]);
+        }
+      }
+    }
+  }
+  if (ok) {
+    float* o = grad_a + ((size_t)b * Na + i) * 3;
+    o[0] = ax; o[1] = ay; o[2] = az;
+  }
+}
+
+// out[s,r] = mean_i min_j |a_i - b_j|^2 + mean_j min_i |a_i - b_j|^2   for cloud a = A[s] (N points), b = Bc[r] (M points).
+// One workgroup per pair; both directions share the LDS copies of the two clouds (float4 per point; N + M <= 8192: 128 KB);
+// fixed-order sums.
+__global__ __launch_bounds__(256) void chamfer_pairs_kernel(const float* __restrict__ A, const float* __restrict__ Bc, int N, int M, int R,
+                                                            float* __restrict__ out) {
+  extern __shared__ float4 sm4[];
+  float4* pa = sm4;       // [N] (x, y, z, -)
+  float4* pb = sm4 + N;   // [M]
+  __shared__ float red[4];
+  const int s = blockIdx.x / R, r = blockIdx.x % R;
+  for (int e = threadIdx.x; e < N; e += 256) {
+    const float* q = A + ((size_t)s * N + e) * 3;
+    pa[e] = make_float4(q[0], q[1], q[2], 0.f);
+  }
+  for (int e = threadIdx.x; e < M; e += 256) {
+    const float* q = Bc + ((size_t)r * M + e) * 3;
+    pb[e] = make_float4(q[0], q[1], q[2], 0.f);
+  }
+  __syncthreads();
+  float total = 0.f;
+  for (int dir = 0; dir < 2; ++dir) {
+    const float4* q = dir == 0 ? pa : pb;
+    const float4* c = dir == 0 ? pb : pa;
+    const int nq = dir == 0 ? N : M, nc = dir == 0 ? M : N;
+    float acc = 0.f;
+    // 4 queries per thread and pass: one broadcast LDS read of a candidate feeds 4 distance evaluations
+    for (int i0 = threadIdx.x; i0 < nq; i0 += 4 * 256) {
+      float4 p[4];
+      float best[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p[u] = q[min(i0 + u * 256, nq - 1)];
+        best[u] = INFINITY;
+      }
+#pragma unroll 2
+      for (int j = 0; j < nc; ++j) {
+        const float4 cj = c[j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float dx = cj.x - p[u].x, dy = cj.y - p[u].y, dz = cj.z - p[u].z;
+          best[u] = fminf(best[u], dx * dx + dy * dy + dz * dz);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * 256 < nq) acc += best[u];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) total += ((red[0] + red[1]) + (red[2] + red[3])) / (float)nq;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(size_t)s * R + r] = total;
+}
+
+}  // namespace
+
+extern "C" int spgan_nn_distance(const float* xyz1, const float* xyz2, int B, int N, int M, float* dist, int32_t* idx, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(xyz1 && xyz2 && dist && idx && B > 0 && N > 0 && M > 0);
+  hipLaunchKernelGGL(nn_distance_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, (hipStream_t)s_, xyz1, xyz2, N, M, dist, idx);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_chamfer_bwd(const float* xa, const float* xb, int B, int Na, int Nb, const float* ga, const int32_t* idxa, const float* gb,
+                                 const int32_t* idxb, float* grad_a, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(xa && xb && ga && idxa && gb && idxb && grad_a && B > 0 && Na > 0 && Nb > 0);
+  hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(cdiv(Na, 256), B), dim3(256), 0, (hipStream_t)s_, xa, xb, Na, Nb, ga, idxa, gb, idxb, grad_a);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_chamfer_pairs(const float* A, const float* Bc, int S, int R, int N, int M, float* out, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(A && Bc && out && S > 0 && R > 0 && N > 0 && M > 0 && N <= 4096 && M <= 4096 && (long)S * R < (1L << 31));
+  const size_t lds = (size_t)(N + M) * sizeof(float4);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chamfer_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(chamfer_pairs_kernel, dim3(S * R), dim3(256), lds, (hipStream_t)s_, A, Bc, N, M, R, out);
+  return spgan_launch_status();
+}

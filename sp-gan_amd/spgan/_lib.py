@@ -128,6 +128,9 @@ SIGNATURES = {
     "spgan_query_ball_point": (I, [F, I, P, P, I, I, I, I, P, P]),
     "spgan_knn_point": (I, [I, P, P, I, I, I, I, P, P]),
     "spgan_group_concat": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+    "spgan_nn_distance": (I, [P, P, I, I, I, P, P, P]),
+    "spgan_chamfer_bwd": (I, [P, P, I, I, I, P, P, P, P, P, P]),
+    "spgan_chamfer_pairs": (I, [P, P, I, I, I, I, P, P]),
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
     "spgan_axpby": (I, [F, P, F, P, SZ, P]),
     "spgan_adam_step": (I, [P, P, P, P, SZ, F, F, F, F, I, F, P]),

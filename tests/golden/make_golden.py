@@ -398,8 +398,38 @@ def g10():
     save("g10_eval_interpolate.npz", d)
 
 
+# ---------------------------------------------------------------- G11: Chamfer-based evaluation metrics
+def g11():
+    """metrics/evaluation_metrics.py does not import here (its CUDA extensions are absent): distChamfer, lgan_mmd_cov and knn
+    are compiled from the reference file with `ast` (they are plain torch) and the CD half of _pairwise_EMD_CD_ is replayed
+    with the reference's distChamfer."""
+    EM = extract_functions(os.path.join(REF, "metrics/evaluation_metrics.py"), ["distChamfer", "lgan_mmd_cov", "knn"],
+                           {"torch": torch, "np": np})
+    S, R, N = 6, 5, 128
+    smp = torch.stack([fr.synthetic_real(1, N, seed=300 + i)[0] for i in range(S)])
+    ref = torch.stack([fr.synthetic_real(1, N, seed=400 + i)[0] * (0.8 + 0.05 * i) for i in range(R)])
+    d = {}
+    dl, dr = EM.distChamfer(smp[:R].contiguous(), ref)
+    put(d, "dl", dl, full_limit=1 << 20); put(d, "dr", dr, full_limit=1 << 20)
+
+    def pairwise(a, b):
+        rows = []
+        for i in range(a.shape[0]):
+            x, y = EM.distChamfer(a[i].view(1, -1, 3).expand(b.shape[0], -1, -1).contiguous(), b)
+            rows.append((x.mean(dim=1) + y.mean(dim=1)).view(1, -1))
+        return torch.cat(rows, dim=0)
+    M_rs, M_rr, M_ss = pairwise(ref, smp), pairwise(ref, ref), pairwise(smp, smp)
+    d["M_rs"], d["M_rr"], d["M_ss"] = M_rs.numpy(), M_rr.numpy(), M_ss.numpy()
+    for k, v in EM.lgan_mmd_cov(M_rs.t()).items():
+        d["mmdcov|" + k] = np.float32(v.item())
+    for k, v in EM.knn(M_rr, M_rs, M_ss, 1, sqrt=False).items():
+        if "acc" in k:
+            d["1nn|" + k] = np.float32(v.item())
+    save("g11_chamfer_metrics.npz", d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name in which:
         globals()[name]()

@@ -1,0 +1,66 @@
+"""GPU: Chamfer distance kernels and the CD evaluation metrics against the oracle and the golden vectors
+captured from the reference's own metric functions (tests/golden/make_golden.py g11)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden
+from oracle import spgan_oracle as orc
+from spgan import fixture_rng as fr
+from test_oracle_golden import _metric_sets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,N,M", [(3, 128, 128), (2, 700, 513), (1, 2048, 2048), (4, 5, 9)])
+def test_chamfer_forward_backward(B, N, M):
+    from spgan import metrics
+    a = (fr.normal("cd.a%d" % N, (B, N, 3)) * 0.5).cuda().requires_grad_(True)
+    b = (fr.normal("cd.b%d" % M, (B, M, 3)) * 0.5 + 0.1).cuda().requires_grad_(True)
+    d1, d2, i1, i2 = metrics.ChamferDistance()(a, b)
+    ac, bc = a.detach().cpu().requires_grad_(True), b.detach().cpu().requires_grad_(True)
+    r1, r2, j1, j2 = orc.nn_distance(ac, bc)
+    np.testing.assert_allclose(d1.detach().cpu().numpy(), r1.detach().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(d2.detach().cpu().numpy(), r2.detach().numpy(), rtol=1e-5, atol=1e-7)
+    assert (i1.cpu() == j1).float().mean() > 0.999 and (i2.cpu() == j2).float().mean() > 0.999     # equal up to rounding ties
+    w1, w2 = fr.normal("cd.w1%d" % N, (B, N)), fr.normal("cd.w2%d" % M, (B, M))
+    ((d1 * w1.cuda()).sum() + (d2 * w2.cuda()).sum()).backward()
+    ((r1 * w1).sum() + (r2 * w2).sum()).backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), ac.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), bc.grad.numpy(), rtol=1e-4, atol=1e-5)
+    # deterministic (gather-style backward, no float atomics)
+    a2 = a.detach().clone().requires_grad_(True); b2 = b.detach().clone().requires_grad_(True)
+    e1, e2, _, _ = metrics.ChamferDistance()(a2, b2)
+    ((e1 * w1.cuda()).sum() + (e2 * w2.cuda()).sum()).backward()
+    assert torch.equal(a2.grad, a.grad) and torch.equal(b2.grad, b.grad)
+
+
+def test_cd_metrics_golden():
+    from spgan import metrics
+    d = golden("g11_chamfer_metrics.npz")
+    smp, ref = _metric_sets()
+    smp, ref = smp.cuda(), ref.cuda()
+    M_rs = metrics.pairwise_cd(ref, smp)
+    np.testing.assert_allclose(M_rs.cpu().numpy(), d["M_rs"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(metrics.pairwise_cd(ref, ref).cpu().numpy(), d["M_rr"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(metrics.pairwise_cd(smp, smp).cpu().numpy(), d["M_ss"], rtol=2e-5, atol=2e-6)
+    dl, dr = metrics.nn_distance(smp[:5].contiguous(), ref)                      # (per point of smp, per point of ref)
+    np.testing.assert_allclose(dl.cpu().numpy(), np.asarray(d["dr|full"]).reshape(5, -1), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(dr.cpu().numpy(), np.asarray(d["dl|full"]).reshape(5, -1), rtol=1e-4, atol=2e-6)
+    res = metrics.compute_all_metrics_cd(smp, ref)
+    for k in ("lgan_mmd", "lgan_cov", "lgan_mmd_smp"):
+        np.testing.assert_allclose(res[k + "-CD"].item(), float(d["mmdcov|" + k]), rtol=2e-5)
+    for k in ("acc_t", "acc_f", "acc"):
+        np.testing.assert_allclose(res["1-NN-CD-" + k].item(), float(d["1nn|" + k]), rtol=1e-6)
+
+
+def test_pairwise_cd_full_size_properties():
+    """2048-point clouds: symmetry in the arguments, zero diagonal against itself, agreement with the per-pair kernel."""
+    from spgan import metrics
+    A = torch.stack([fr.synthetic_real(1, 2048, seed=500 + i)[0] for i in range(7)]).cuda()
+    Bc = torch.stack([fr.synthetic_real(1, 2048, seed=600 + i)[0] for i in range(5)]).cuda()
+    M = metrics.pairwise_cd(A, Bc)
+    assert torch.equal(M, metrics.pairwise_cd(Bc, A).t().contiguous()) or torch.allclose(M, metrics.pairwise_cd(Bc, A).t(), rtol=1e-6)
+    assert metrics.pairwise_cd(A, A).diagonal().abs().max().item() == 0.0
+    d1, d2 = metrics.nn_distance(A[2:3].expand(5, -1, -1).contiguous(), Bc)
+    np.testing.assert_allclose((d1.mean(1) + d2.mean(1)).cpu().numpy(), M[2].cpu().numpy(), rtol=1e-5)

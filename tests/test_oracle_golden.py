@@ -274,3 +274,28 @@ def test_eval_generation_and_interpolate(tag):
     check(d, tag + "|x1", st["x1"], rtol=2e-5)
     check(d, tag + "|out", out, rtol=1e-4)
     check(d, tag + "|logit", logit, rtol=1e-3)
+
+
+# ---------------------------------------------------------------- G11: Chamfer-based evaluation metrics
+def _metric_sets():
+    S, R, N = 6, 5, 128
+    smp = torch.stack([fr.synthetic_real(1, N, seed=300 + i)[0] for i in range(S)])
+    ref = torch.stack([fr.synthetic_real(1, N, seed=400 + i)[0] * (0.8 + 0.05 * i) for i in range(R)])
+    return smp, ref
+
+
+def test_chamfer_metrics():
+    d = golden("g11_chamfer_metrics.npz")
+    smp, ref = _metric_sets()
+    dl, dr = orc.dist_chamfer(smp[:5].contiguous(), ref)
+    check(d, "dl", dl, rtol=1e-5); check(d, "dr", dr, rtol=1e-5)
+    M_rs, M_rr, M_ss = orc.pairwise_cd(ref, smp), orc.pairwise_cd(ref, ref), orc.pairwise_cd(smp, smp)
+    np.testing.assert_allclose(M_rs.numpy(), d["M_rs"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(M_rr.numpy(), d["M_rr"], rtol=1e-5, atol=1e-6)
+    for k, v in orc.lgan_mmd_cov(M_rs.t()).items():
+        np.testing.assert_allclose(float(v), float(d["mmdcov|" + k]), rtol=1e-5)
+    for k, v in orc.one_nn_accuracy(M_rr, M_rs, M_ss, 1).items():
+        np.testing.assert_allclose(float(v), float(d["1nn|" + k]), rtol=1e-6)
+    # the direct-difference form (the CUDA kernel's) agrees with the expanded form up to rounding
+    d1, d2, i1, i2 = orc.nn_distance(smp[:5], ref)
+    np.testing.assert_allclose(d1.numpy(), dr.numpy(), atol=2e-6); np.testing.assert_allclose(d2.numpy(), dl.numpy(), atol=2e-6)
