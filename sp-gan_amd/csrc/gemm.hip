@@ -288,11 +288,11 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 #pragma unroll
     for (int i = 0; i < BSLOT; ++i) st_row4(&b[(lrow + 32 * i) * LDT + lc4], rb[i]);
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int kk0 = 0, int kk1 = BK / 4) {
     const float* a = As + buf * BM * LDT + (wm * TI * 32 + l31) * LDT + 2 * lh;
     const float* b = Bs + buf * BN * LDT + (wn * TJ * 32 + l31) * LDT + 2 * lh;
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
+    for (int kk = kk0; kk < kk1; ++kk) {
       float2 af[TI], bf[TJ];
 #pragma unroll
       for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float2*>(a + i * 32 * LDT + kk * 4);
@@ -335,8 +335,11 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) gload((kt + 1) * BK);  // next tile's HBM/L2 loads fly under this tile's MFMAs
     if (DB) {
-      compute(kt & 1);
-      if (kt + 1 < nk) sstore((kt + 1) & 1, (kt + 1) * BK);  // other buffer: its last readers passed the previous barrier
+      // the next tile's LDS stores go between the two halves of this tile's MFMAs (other buffer: its last readers passed the
+      // previous barrier): they overlap with the second half instead of sitting between the last MFMA and the barrier
+      compute(kt & 1, 0, BK / 8);
+      if (kt + 1 < nk) sstore((kt + 1) & 1, (kt + 1) * BK);
+      compute(kt & 1, BK / 8, BK / 4);
       __syncthreads();
       if (sp_lds && kt + 1 < nk) {
         sfix((kt + 1) & 1, (kt + 1) * BK);
