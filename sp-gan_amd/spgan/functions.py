@@ -154,7 +154,8 @@ class EdgeBlockFn(Function):
         P = dict(zip(holder.names, params))
         x = x.contiguous()
         idx = holder.idx if holder.idx is not None else ops.knn(x, holder.B, holder.N, holder.k, holder.knn_mode)
-        out, ectx = nets.edgeblock_forward(P, holder.buffers, holder.prefix, x, idx, holder.B, holder.N, holder.training, True)
+        out, ectx = nets.edgeblock_forward(P, holder.buffers, holder.prefix, x, idx, holder.B, holder.N, holder.training, True,
+                                           getattr(holder, "count_rep", 1))
         ctx.holder, ctx.ectx = holder, ectx
         holder.last_idx = idx
         ctx.save_for_backward(*params)
@@ -174,6 +175,22 @@ class EdgeBlockFn(Function):
                 cache["csr"] = csr
         dx, g = nets.edgeblock_backward(P, h.prefix, ctx.ectx, dout, csr, need_dx=ctx.needs_input_grad[1])
         return (None, dx) + _deliver(params, [g[n] for n in h.names], ctx.needs_input_grad[2:])
+
+
+class RepeatRowsFn(Function):
+    """[N,C] -> [B*N,C]: B copies of the rows (the EdgeConv1 features of the tiled sphere prior are the same for every shape of the
+    batch); backward sums the B row blocks (deterministic column reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, B):
+        ctx.B = B
+        return x.repeat(B, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        B = ctx.B
+        M, Cn = g.shape
+        return ops.colsum(g.contiguous().view(B, (M // B) * Cn))[0].view(M // B, Cn), None
 
 
 class AdaINFn(Function):

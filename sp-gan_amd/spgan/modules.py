@@ -128,14 +128,14 @@ class EdgeBlock(nn.Module, _BNCounts):
         self._install_count_hook()
 
     def forward_pm(self, x_pm, B: int, N: int, idx: Optional[torch.Tensor] = None, knn_mode: Optional[int] = None,
-                   graph_cache: Optional[dict] = None):
+                   graph_cache: Optional[dict] = None, count_rep: int = 1):
         names, params = _named(self, "e.")
         if knn_mode is None:
             knn_mode = 1 if self.Fin <= 4 else 0          # coordinates: exact fp64 order; features: fp32 expanded form
         if graph_cache is not None and idx is None:
             idx = graph_cache.get("idx")
         h = _Holder(prefix="e", names=names, buffers=_buffers(self, "e."), B=B, N=N, k=self.k, training=self.training,
-                    knn_mode=knn_mode, idx=idx, last_idx=None, graph_cache=graph_cache)
+                    knn_mode=knn_mode, idx=idx, last_idx=None, graph_cache=graph_cache, count_rep=count_rep)
         out = Fn.EdgeBlockFn.apply(h, x_pm, *params)
         self.last_idx = h.last_idx
         if graph_cache is not None and graph_cache.get("idx") is None:
@@ -209,10 +209,24 @@ class Generator(nn.Module, _BNCounts):
             sg = getattr(self, "_sphere_graph", None)
             key = (x._version, tuple(x.shape), self.nk)
             if sg is None or sg["ref"]() is not x or sg["key"] != key:       # same tensor OBJECT (not just address), unmodified
-                sg = {"ref": weakref.ref(x), "key": key, "idx": None, "csr": None}
+                # Does every shape of the batch carry the SAME prior (sphere_generator(static=True) tiles one template,
+                # model.py:169-171)?  Checked once per (tensor, version) -- one host sync when the cache entry is built.
+                shared = B > 1 and bool(torch.equal(x, x[:1].expand_as(x)))
+                sg = {"ref": weakref.ref(x), "key": key, "idx": None, "csr": None, "shared": shared, "idx_full": None}
                 self.__dict__["_sphere_graph"] = sg
             cache = sg
-        x1 = self.EdgeConv1.forward_pm(feat, B, N, knn_mode=0 if self.use_head else 1, graph_cache=cache)
+        if cache is not None and cache["shared"]:
+            # EdgeConv1 sees the same N points in every shape: evaluate it for ONE copy (B times less work in forward and
+            # backward; exact -- batch statistics of identical copies are those of one copy, and the backward is linear in the
+            # upstream gradient, which RepeatRowsFn sums over the copies) and repeat the rows for the per-shape AdaIN.
+            x1_one = self.EdgeConv1.forward_pm(feat[:N], 1, N, knn_mode=1, graph_cache=cache, count_rep=B)
+            if cache["idx_full"] is None:
+                off = (torch.arange(B, device=x.device, dtype=torch.int32) * N).view(B, 1, 1)
+                cache["idx_full"] = (cache["idx"].view(1, N, -1) + off).reshape(B * N, -1).contiguous()
+            self.EdgeConv1.last_idx = cache["idx_full"]
+            x1 = Fn.RepeatRowsFn.apply(x1_one, B)
+        else:
+            x1 = self.EdgeConv1.forward_pm(feat, B, N, knn_mode=0 if self.use_head else 1, graph_cache=cache)
         x1 = self.adain1.forward_pm(x1, style, N, slope)           # lrelu1 fused into the instance norm (Generator.py:175-176)
         self.last_x1 = x1.detach()                                 # [M,64] input of EdgeConv2's graph (diagnostics / parity tests)
         x2 = self.EdgeConv2.forward_pm(x1, B, N, knn_mode=0)

@@ -387,8 +387,11 @@ def conv_out_weight_grad_from_pm(g: Tensor, F_: int, k: int) -> Tensor:
     return g.view(F_, k, F_).permute(0, 2, 1).reshape(F_, F_, 1, k).contiguous()
 
 
-def edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int, training: bool = True, update_running: bool = True):
-    """x [M,C] (point-major), idx int32 [M,k] -> out [M,F] + ctx."""
+def edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int, training: bool = True, update_running: bool = True,
+                      count_rep: int = 1):
+    """x [M,C] (point-major), idx int32 [M,k] -> out [M,F] + ctx.
+    count_rep > 1: x stands for count_rep identical copies of these M rows (the tiled sphere prior): batch statistics are those
+    of one copy, only the unbiased-variance count of the running statistics is count_rep times larger."""
     M, C = x.shape
     k = idx.shape[1]
     Ww0 = P[pre + ".conv_w.0.weight"]; Wx = P[pre + ".conv_x.0.weight"]
@@ -399,13 +402,17 @@ def edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int,
     E = M * k
     if training:
         mean, var = ops.edge_stats(PQR, idx, b1, bx)
-        bn1 = _bn_train(mean[:H].contiguous(), var[:H].contiguous(), P, bufs, pre + ".conv_w.1", E, True, update_running)
-        bnx = _bn_train(mean[H:].contiguous(), var[H:].contiguous(), P, bufs, pre + ".conv_x.1", E, True, update_running)
+        bn1 = _bn_train(mean[:H].contiguous(), var[:H].contiguous(), P, bufs, pre + ".conv_w.1", E * count_rep, True, update_running)
+        bnx = _bn_train(mean[H:].contiguous(), var[H:].contiguous(), P, bufs, pre + ".conv_x.1", E * count_rep, True, update_running)
     else:
         bn1 = _bn_train(None, None, P, bufs, pre + ".conv_w.1", E, False, False)
         bnx = _bn_train(None, None, P, bufs, pre + ".conv_x.1", E, False, False)
     W2, b2 = _w2(P[pre + ".conv_w.3.weight"]), P[pre + ".conv_w.3.bias"]
-    h2pre, bn2 = _gemm_bn(PQR[:, :H], W2, b2, P, bufs, pre + ".conv_w.4", E, training, update_running, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1))
+    if training and count_rep > 1:
+        h2pre, m2, v2 = ops.gemm_nt(PQR[:, :H], W2, b2, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1), stats=True)
+        bn2 = _bn_train(m2, v2, P, bufs, pre + ".conv_w.4", E * count_rep, True, update_running)
+    else:
+        h2pre, bn2 = _gemm_bn(PQR[:, :H], W2, b2, P, bufs, pre + ".conv_w.4", E, training, update_running, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1))
     T = ops.edge_attend_fwd(h2pre, bn2[0], bn2[1], PQR, idx, bx, bnx[0], bnx[1], NEG)
     Wo = conv_out_weight_pm(P[pre + ".conv_out.weight"])
     out = ops.gemm_nt(T, Wo, P[pre + ".conv_out.bias"])

@@ -260,3 +260,31 @@ def test_eval_generation_and_interpolate_golden(sp, tag):
                 ref = orc.generator_interpolate(pg, xc, z1c, z2c, sel.cpu(), alpha, use_latent=(tag == "interp_style"), training=False,
                                                 buffers=bg, idx2=idx2)
         assert rel_l2(out.cpu().numpy(), ref.numpy()) <= 2e-4
+
+
+def test_shared_sphere_edgeconv1_equals_per_shape_evaluation(sp, monkeypatch):
+    """The tiled sphere prior lets EdgeConv1 run on ONE copy (Generator._body): outputs, parameter gradients and BatchNorm
+    buffers must equal the per-shape evaluation of all B copies (up to summation order)."""
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    z = fr.latent(B, N, seed=77).cuda()
+    dy = fr.normal("shared.dy", (B, 3, N)).cuda()
+    res = []
+    for shared in (True, False):
+        G = _load(sp.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=12)).train()
+        if not shared:
+            monkeypatch.setattr(torch, "equal", lambda a, b: False)
+        out = G(x.clone(), z)
+        monkeypatch.undo()
+        assert G._sphere_graph["shared"] == shared
+        (out * dy).sum().backward()
+        res.append((out.detach(), {n: p.grad.detach().clone() for n, p in G.named_parameters()},
+                    {n: b.detach().clone() for n, b in G.state_dict().items() if n in dict(G.named_buffers())},
+                    G.EdgeConv1.last_idx.clone()))
+    assert torch.equal(res[0][3], res[1][3])
+    assert rel_l2(res[0][0].cpu().numpy(), res[1][0].cpu().numpy()) <= 1e-5
+    for n in res[0][1]:
+        a, b = res[0][1][n].cpu(), res[1][1][n].cpu()
+        assert rel_l2(a.numpy(), b.numpy()) <= 2e-4 or (a - b).abs().max().item() <= _atol(n), n
+    for n in res[0][2]:
+        np.testing.assert_allclose(res[0][2][n].cpu().numpy(), res[1][2][n].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n)
