@@ -280,6 +280,19 @@ class Discriminator(nn.Module, _BNCounts):
         return Fn.DiscriminatorFn.apply(h, x.contiguous(), *params)
 
 
+def _discriminator_advance_running_stats(self, x):
+    """Train-mode D(x) reduced to its only lasting effect when the logits are not used: the BatchNorm running statistics and
+    call counts (TrainStep uses it for the reference's D(real) call inside the G step, Generation/model.py:272-273)."""
+    _require_gpu(x, "Discriminator")
+    if not self.training:
+        return
+    with torch.no_grad():
+        nets.d_advance_running_stats(dict(self.named_parameters()), _buffers(self), x.contiguous())
+
+
+Discriminator.advance_running_stats = _discriminator_advance_running_stats
+
+
 def get_edge_features(x, k, num=-1, idx=None, return_idx=False):
     """Generation/modules.py:683-725: x [B,C,N] -> ee [B,2C,N,k] (= cat[central, neighbour-central]); optional injected /
     returned idx is int64 [B, N*k] with per-shape local indices, like the reference.  Forward only (the Generator path

@@ -141,6 +141,29 @@ def d_forward(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], x_cm: Ten
     return hs[-1], ctx
 
 
+def d_advance_running_stats(P: Dict[str, Tensor], bufs: Dict[str, Tensor], x_cm: Tensor) -> None:
+    """The side effect of a train-mode D(x) whose logits nobody reads: the G-step of the reference loop calls D(real)
+    (model.py:272-273) although gen_loss ignores d_real -- only the four BatchNorm layers' running statistics (and call counts)
+    move.  Layers 1-3 run as usual; the statistics of the 1024-wide fc2.0 output follow from the 256 x 256 covariance of its
+    input, mean4 = mean(a3).W^T + b4, var4[c] = w_c^T Cov(a3) w_c, so that layer's GEMM (a quarter of a D forward), the pool
+    and the MLP head are skipped."""
+    B, _, N = x_cm.shape
+    M = B * N
+    a, pro = ops.cm_to_pm(x_cm), None
+    for conv, bn in D_LAYERS[:3]:
+        y, (sc, sh, inv, mu) = _gemm_bn(a, _w2(P[conv + ".weight"]), P[conv + ".bias"], P, bufs, bn, M, True, True, pro=pro)
+        a, pro = y, (sc, sh, NEG)
+    conv, bn = D_LAYERS[3]
+    W, b4 = _w2(P[conv + ".weight"]), P[conv + ".bias"]
+    a3 = ops.affine_act(a, pro[0], pro[1], NEG)
+    mu_a = ops.colsum(a3)[0] * (1.0 / M)
+    inv_m = torch.full_like(mu_a, 1.0 / M)
+    cov = ops.rowscale_outer(ops.gemm_tn(a3, a3), inv_m, torch.zeros_like(mu_a), -mu_a, mu_a)      # Gram/M - mu mu^T
+    mean4 = ops.gemm_nt(mu_a.view(1, -1), W, b4)[0]
+    var4 = ops.rowdot(W, ops.gemm_nt(W, cov))
+    _bn_train(mean4.contiguous(), var4, P, bufs, bn, M, True, True)
+
+
 def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for_double: bool = False):
     """First-order backward.  Returns (dx_cm | None, {name: grad} | None, saved-for-double-backward | None)."""
     B, N = ctx["B"], ctx["N"]

@@ -184,9 +184,11 @@ class TrainStep:
         requires_grad(G, True); requires_grad(D, False)
         self.optG.zero_grad()
         g_fake = G(x, z_g)
-        g_real_logit = D(real_t)
+        # model.py:272-274: d_real = D(real) is computed but gen_loss ignores it (loss_utils.py:727-802) -- what lasts of that call
+        # are D's BatchNorm running statistics, advanced here without the 1024-wide layer, the pool and the head
+        D.advance_running_stats(real_t)
         g_fake_logit = D(g_fake)
-        loss_g, _ = gen_loss(g_real_logit, g_fake_logit, gan=self.gan, noise_label=self.flip_g)
+        loss_g, _ = gen_loss(None, g_fake_logit, gan=self.gan, noise_label=self.flip_g)
         loss_g.backward()
         if keep_grads:
             info["fake_g"] = g_fake.detach()

@@ -288,3 +288,23 @@ def test_shared_sphere_edgeconv1_equals_per_shape_evaluation(sp, monkeypatch):
         assert rel_l2(a.numpy(), b.numpy()) <= 2e-4 or (a - b).abs().max().item() <= _atol(n), n
     for n in res[0][2]:
         np.testing.assert_allclose(res[0][2][n].cpu().numpy(), res[1][2][n].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n)
+
+
+def test_discriminator_advance_running_stats_equals_forward(sp):
+    """D.advance_running_stats(x) leaves exactly the buffers a train-mode D(x) leaves (fc2.1 statistics via the covariance of
+    its input instead of the 1024-wide GEMM)."""
+    B, N = 4, 512
+    x = fr.synthetic_real(B, N, seed=55).transpose(2, 1).contiguous().cuda()
+    bufs = []
+    for fast in (False, True):
+        D = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=14)).train()
+        with torch.no_grad():
+            D(x * 0.9)                                   # move the running statistics away from (0, 1) first
+            if fast:
+                D.advance_running_stats(x)
+            else:
+                D(x)
+        bufs.append({n: b.detach().clone().cpu() for n, b in D.state_dict().items() if n in dict(D.named_buffers())})
+    for n in bufs[0]:
+        np.testing.assert_allclose(bufs[1][n].numpy(), bufs[0][n].numpy(), rtol=2e-5, atol=1e-6, err_msg=n)
+    assert int(bufs[1]["fc2.1.num_batches_tracked"]) == 2
