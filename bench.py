@@ -70,7 +70,8 @@ def _pmc_traffic():
 
 # Dominant kernel of the step (profiles/r01_bench_*_kernel_stats.txt): gemm_nt_kernel<affine prologue, linear epilogue + column
 # statistics + max-pool partials, 128x64 tile> at the Discriminator's 256->1024 layer (Discriminator.py:74-81,104): M = B*N points,
-# N = 1024, K = 256; 5 launches per step (the 5 D forwards of the reference loop body).
+# N = 1024, K = 256; 4 launches per step (D(real), D(fake), D(interpolate) of the D step and D(fake) of the G step; the G step's
+# unused D(real) only advances running statistics, TrainStep._seg_g).
 DOMINANT = {"N": 1024, "K": 256, "a_mode": 1,
             "pmc_key": "gemm_nt D.fc2.0 M=65536 N=1024 K=256 (affine prologue + statistics + pooling partials, output not stored)"}
 
