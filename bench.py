@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--reference-schedule", action="store_true",
+                    help="also evaluate the two provably redundant pieces of the reference loop (EdgeConv1 on every copy of the tiled "
+                         "sphere, the G step's unused D(real) forward) -- for comparison; see DESIGN.md")
     args = ap.parse_args()
 
     import spgan
@@ -183,7 +186,7 @@ def main():
     use_graph = not args.no_graph and os.environ.get("SPGAN_GRAPH", "1") != "0"
     graph_warmup = 3
     tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=dist_on, graph=use_graph,
-                         graph_warmup=graph_warmup)
+                         graph_warmup=graph_warmup, reference_schedule=args.reference_schedule)
     x, real, zs, alpha = make_inputs(dev, rank, PER_GPU_BATCH)
 
     def one_step(i):
@@ -232,7 +235,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Chair-shaped synthetic clouds, 2048 pts, per-GPU batch 32, WGAN + gradient penalty (lambda 10), "
                                    "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10", "global_batch": PER_GPU_BATCH * world, "n_points": N_POINTS,
                        "parallelism": "dp%d" % world},
-            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3), "hipgraph_replay": bool(use_graph),
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3), "hipgraph_replay": bool(use_graph), "reference_schedule": bool(args.reference_schedule),
             "step_tflops_algorithmic": round(shapes_s * GF_PER_SHAPE_STEP / 1e3, 2),
             "step_frac_of_fp32_matrix_peak": round(shapes_s * GF_PER_SHAPE_STEP / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
         }

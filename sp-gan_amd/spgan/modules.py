@@ -211,7 +211,7 @@ class Generator(nn.Module, _BNCounts):
             if sg is None or sg["ref"]() is not x or sg["key"] != key:       # same tensor OBJECT (not just address), unmodified
                 # Does every shape of the batch carry the SAME prior (sphere_generator(static=True) tiles one template,
                 # model.py:169-171)?  Checked once per (tensor, version) -- one host sync when the cache entry is built.
-                shared = B > 1 and bool(torch.equal(x, x[:1].expand_as(x)))
+                shared = B > 1 and getattr(self, "dedup_sphere", True) and bool(torch.equal(x, x[:1].expand_as(x)))
                 sg = {"ref": weakref.ref(x), "key": key, "idx": None, "csr": None, "shared": shared, "idx_full": None}
                 self.__dict__["_sphere_graph"] = sg
             cache = sg

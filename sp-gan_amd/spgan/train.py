@@ -34,7 +34,8 @@ def requires_grad(model: nn.Module, flag: bool = True):
 class TrainStep:
     def __init__(self, G: nn.Module, D: nn.Module, gan: str = "ls", use_gp: bool = False, lambda_gp: float = 10.0,
                  lr_g: float = 1e-4, lr_d: float = 1e-4, betas=(0.5, 0.99), flip_d: bool = False, flip_g: bool = False,
-                 distributed: bool = False, process_group=None, graph: bool = False, graph_warmup: int = 3):
+                 distributed: bool = False, process_group=None, graph: bool = False, graph_warmup: int = 3,
+                 reference_schedule: bool = False):
         self.G, self.D = G, D
         self.gan, self.use_gp = gan, use_gp
         self.flip_d, self.flip_g = flip_d, flip_g
@@ -46,6 +47,12 @@ class TrainStep:
         self.optG = Adam(G, lr_g, betas, capturable=graph)
         self.optD = Adam(D, lr_d, betas, capturable=graph)
         G.train(); D.train()
+        # reference_schedule=True evaluates exactly the calls of model.py:239-279, including the two pieces of work this harness
+        # otherwise removes because they are provably redundant: EdgeConv1 on every copy of the tiled sphere prior
+        # (Generator.dedup_sphere) and the full D(real) forward of the G step whose logits gen_loss ignores.
+        self.reference_schedule = reference_schedule
+        if reference_schedule:
+            G.dedup_sphere = False
         self.use_graph, self.graph_warmup = graph, graph_warmup
         self._graph = None
         self._static = None          # [x, real, z_d, z_g, alpha]
@@ -186,9 +193,13 @@ class TrainStep:
         g_fake = G(x, z_g)
         # model.py:272-274: d_real = D(real) is computed but gen_loss ignores it (loss_utils.py:727-802) -- what lasts of that call
         # are D's BatchNorm running statistics, advanced here without the 1024-wide layer, the pool and the head
-        D.advance_running_stats(real_t)
+        g_real_logit = None
+        if self.reference_schedule:
+            g_real_logit = D(real_t)
+        else:
+            D.advance_running_stats(real_t)
         g_fake_logit = D(g_fake)
-        loss_g, _ = gen_loss(None, g_fake_logit, gan=self.gan, noise_label=self.flip_g)
+        loss_g, _ = gen_loss(g_real_logit, g_fake_logit, gan=self.gan, noise_label=self.flip_g)
         loss_g.backward()
         if keep_grads:
             info["fake_g"] = g_fake.detach()
