@@ -6,7 +6,7 @@
 Importing the package does not touch the GPU; the shared library is loaded on first use and its
 absence is a hard error (there is no CPU fallback).
 """
-from . import fixture_rng, metrics, ops, pointnet_util, sampling           # noqa: F401
+from . import dataset, fixture_rng, metrics, ops, pointnet_util, sampling  # noqa: F401
 from .losses import GradientPenalty, dis_loss, gen_loss                    # noqa: F401
 from .modules import AdaptivePointNorm, Discriminator, EdgeBlock, Generator, get_edge_features   # noqa: F401
 from .optim import Adam, flatten_module                                    # noqa: F401
