@@ -105,26 +105,44 @@ class TrainStep:
         if self._graph is None:
             before = self._bn_snapshot()
             tG, tD = self.optG.t, self.optD.t
-            if self.dpD is None:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._static_info = self._eager_step(*self._static)
-                graphs = [g]
-            else:
-                # data parallel: three graphs, the two flat all-reduces are issued eagerly between them (RCCL stays outside
-                # the capture); all three share one memory pool
-                sx, sreal, szd, szg, salpha = self._static
-                info: Dict[str, torch.Tensor] = {}
-                g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                w = 1.0 / self.dpD.world_size
-                with torch.cuda.graph(g1, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to call HIP
-                    real_t = self._seg_d(sx, sreal, szd, salpha, False, info)
-                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
-                    self._seg_g(sx, real_t, szg, w, False, info)
-                with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode="thread_local"):
-                    self._seg_opt_g(w, False, info)
-                self._static_info = info
-                graphs = [g1, g2, g3]
+            try:
+                if self.dpD is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._static_info = self._eager_step(*self._static)
+                    graphs = [g]
+                else:
+                    # data parallel: three graphs, the two flat all-reduces are issued eagerly between them (RCCL stays outside
+                    # the capture); all three share one memory pool
+                    sx, sreal, szd, szg, salpha = self._static
+                    info: Dict[str, torch.Tensor] = {}
+                    g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    w = 1.0 / self.dpD.world_size
+                    with torch.cuda.graph(g1, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to call HIP
+                        real_t = self._seg_d(sx, sreal, szd, salpha, False, info)
+                    with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                        self._seg_g(sx, real_t, szg, w, False, info)
+                    with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode="thread_local"):
+                        self._seg_opt_g(w, False, info)
+                    self._static_info = info
+                    graphs = [g1, g2, g3]
+            except Exception as e:                                   # noqa: BLE001
+                # a failed capture must not cost the run: undo the host-side bookkeeping of the aborted attempt and issue this and all
+                # later steps eagerly (data parallel: the collectives are eager in both modes, so ranks stay in lockstep)
+                import warnings
+                warnings.warn("hipGraph capture of the train step failed (%s: %s); falling back to eager issue" % (type(e).__name__, e))
+                after = self._bn_snapshot()
+                for m, b, a in zip(self._bn_modules(), before, after):
+                    store = m.__dict__.setdefault("_bn_pending", {})
+                    for pre, pend in a.items():
+                        for k, n in pend.items():
+                            store[pre][k] = b.get(pre, {}).get(k, 0)
+                self.optG.t, self.optD.t = tG, tD
+                if self.optG.capturable:
+                    self.optG.dev_state[:1].view(torch.int32).fill_(tG); self.optD.dev_state[:1].view(torch.int32).fill_(tD)
+                self.use_graph = False
+                torch.cuda.synchronize()
+                return self._eager_step(*self._static)
             after = self._bn_snapshot()
             # nothing ran during the capture: take the host-side bookkeeping of that step back, keep it as the per-replay delta
             self._bn_delta = []

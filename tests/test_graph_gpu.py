@@ -73,3 +73,22 @@ def test_graph_replay_data_parallel_segments(sp):
             assert torch.equal(a, b), n
     finally:
         dist.destroy_process_group()
+
+
+def test_graph_capture_failure_falls_back_to_eager(sp, monkeypatch):
+    """A capture that throws must not cost the run: the step falls back to eager issue with identical results."""
+    steps = 5
+    Ge, De, tre, le = _run(sp, False, steps)
+
+    class Boom:
+        def __init__(self, *a, **k):
+            raise RuntimeError("simulated capture failure")
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", Boom)
+    with pytest.warns(UserWarning, match="falling back to eager"):
+        Gg, Dg, trg, lg = _run(sp, True, steps)
+    assert trg.use_graph is False and trg._graph is None
+    assert le == lg
+    for (n, a), (_, b) in zip(list(Ge.state_dict().items()) + list(De.state_dict().items()),
+                              list(Gg.state_dict().items()) + list(Dg.state_dict().items())):
+        assert torch.equal(a, b), n
+    assert (trg.optG.t, trg.optD.t) == (steps, steps)
