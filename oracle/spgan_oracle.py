@@ -164,6 +164,9 @@ def generator_body(p, x: Tensor, style: Tensor, k: int = 10, training: bool = Tr
     feature, the tail."""
     B, N, _ = x.shape
     pc = x.transpose(2, 1).contiguous()
+    if "pc_head.0.weight" in p:                                 # --use_head, Generator.py:138-143,171-172 (LeakyReLU default slope)
+        pc = F.leaky_relu(_conv1x1(pc, p, "pc_head.0"), 0.01)
+        pc = F.leaky_relu(_conv1x1(pc, p, "pc_head.2"), 0.01)
     x1, i1 = edge_block(p, "EdgeConv1", pc, k, idx=idx1, training=training, buffers=buffers, return_idx=True)
     x1 = adaptive_point_norm(p, "adain1", F.leaky_relu(x1, NEG_2), style)
     x2, i2 = edge_block(p, "EdgeConv2", x1, k, idx=idx2, training=training, buffers=buffers, return_idx=True)
@@ -181,7 +184,7 @@ def generator_body(p, x: Tensor, style: Tensor, k: int = 10, training: bool = Tr
     out = torch.tanh(_conv1x1(t, p, "tail.4"))
     if stages is not None:
         stages.update(style=style, x1=x1, x2=x2, idx1=i1, idx2=i2, feat_global=g, out=out)
-    return pc + out if off else out
+    return x.transpose(2, 1) + out if off else out              # Generator.py:196 (pc is the coordinates when use_head is off)
 
 
 def generator_forward(p, x: Tensor, z: Tensor, k: int = 10, training: bool = True,
@@ -431,8 +434,8 @@ def sample_and_group(npoint, radius, nsample, xyz, points, start=None):
 # --------------------------------------------------------------------------- #
 # parameter containers                                                        #
 # --------------------------------------------------------------------------- #
-def generator_shapes(nz: int = 128, k: int = 10) -> Dict[str, Tuple[int, ...]]:
-    """state_dict parameter shapes of Generator(default flags), Generator.py:107-153."""
+def generator_shapes(nz: int = 128, k: int = 10, use_head: bool = False) -> Dict[str, Tuple[int, ...]]:
+    """state_dict parameter shapes of Generator (default flags, or --use_head: Generator.py:138-148), Generator.py:107-153."""
     d = 128
     s = {
         "head.0.weight": (d, 3 + nz, 1), "head.0.bias": (d,),
@@ -445,7 +448,9 @@ def generator_shapes(nz: int = 128, k: int = 10) -> Dict[str, Tuple[int, ...]]:
         "tail.2.weight": (64, 256, 1), "tail.2.bias": (64,),
         "tail.4.weight": (3, 64, 1), "tail.4.bias": (3,),
     }
-    for name, fin, fout in (("EdgeConv1", 3, 64), ("EdgeConv2", 64, d)):
+    if use_head:
+        s.update({"pc_head.0.weight": (d // 2, 3, 1), "pc_head.0.bias": (d // 2,), "pc_head.2.weight": (d, d // 2, 1), "pc_head.2.bias": (d,)})
+    for name, fin, fout in ((("EdgeConv1", d, d), ("EdgeConv2", d, d)) if use_head else (("EdgeConv1", 3, 64), ("EdgeConv2", 64, d))):
         s.update({
             name + ".conv_w.0.weight": (fout // 2, fin, 1, 1), name + ".conv_w.0.bias": (fout // 2,),
             name + ".conv_w.1.weight": (fout // 2,), name + ".conv_w.1.bias": (fout // 2,),
@@ -455,7 +460,7 @@ def generator_shapes(nz: int = 128, k: int = 10) -> Dict[str, Tuple[int, ...]]:
             name + ".conv_x.1.weight": (fout,), name + ".conv_x.1.bias": (fout,),
             name + ".conv_out.weight": (fout, fout, 1, k), name + ".conv_out.bias": (fout,),
         })
-    s.update({"adain1.style.weight": (128, d, 1), "adain1.style.bias": (128,),
+    s.update({"adain1.style.weight": (256 if use_head else 128, d, 1), "adain1.style.bias": (256 if use_head else 128,),
               "adain2.style.weight": (256, d, 1), "adain2.style.bias": (256,)})
     return s
 

@@ -428,8 +428,58 @@ def g11():
     save("g11_chamfer_metrics.npz", d)
 
 
+# ---------------------------------------------------------------- G12: non-default flags
+def g12():
+    """--use_head (pc_head + 128-wide EdgeConv1), --off + --z_norm, --small_d: train-mode forward, and gradients for an
+    injected upstream (as in G4)."""
+    B, N = 4, 256                    # 4 shapes: BatchNorm1d over the batch in global_conv is too ill-conditioned at 2 (SURVEY H1)
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    z = fr.latent(B, N, seed=120)
+    d = {}
+
+    class OH(Opts):
+        use_head = True
+    G = load_into(Generator(OH), fr.init_params(orc.generator_shapes(use_head=True), salt=20)).train()
+    stage = {}
+    hook = G.adain1.register_forward_hook(lambda m, i, o: stage.__setitem__("x1", o.detach().clone()))
+    hook0 = G.pc_head.register_forward_hook(lambda m, i, o: stage.__setitem__("feat", o.detach().clone()))
+    out = G(x, z)
+    hook.remove(); hook0.remove()
+    _, idx1 = get_edge_features(stage["feat"], 10, return_idx=True)
+    _, idx2 = get_edge_features(stage["x1"], 10, return_idx=True)
+    dy = fr.normal("g12.dy", out.shape)
+    grads = torch.autograd.grad(out, list(G.parameters()), dy)
+    put(d, "head|out", out, full_limit=1 << 20)
+    d["head|idx1"] = idx1.view(B, N, 10).numpy().astype(np.int32); d["head|idx2"] = idx2.view(B, N, 10).numpy().astype(np.int32)
+    for (n, _), g in zip(G.named_parameters(), grads):
+        put(d, "head|grad|" + n, g)
+
+    class OO(Opts):
+        off = True; z_norm = True
+    G = load_into(Generator(OO), fr.init_params(orc.generator_shapes(), salt=21)).train()
+    stage = {}
+    hook = G.adain1.register_forward_hook(lambda m, i, o: stage.__setitem__("x1", o.detach().clone()))
+    out = G(x, z)
+    hook.remove()
+    _, idx2 = get_edge_features(stage["x1"], 10, return_idx=True)
+    put(d, "off|out", out, full_limit=1 << 20)
+    d["off|idx2"] = idx2.view(B, N, 10).numpy().astype(np.int32)
+
+    class OS(Opts):
+        small_d = True
+    D = load_into(Discriminator(OS), fr.init_params(orc.discriminator_shapes(small_d=True), salt=22)).train()
+    real = fr.synthetic_real(4, N, seed=23).transpose(2, 1).contiguous().requires_grad_(True)
+    logit = D(real)
+    loss = ((logit - 1.0) ** 2).mean()
+    grads = torch.autograd.grad(loss, [real] + list(D.parameters()))
+    put(d, "small|logit", logit); put(d, "small|dx", grads[0], full_limit=1 << 20)
+    for (n, _), g in zip(D.named_parameters(), grads[1:]):
+        put(d, "small|grad|" + n, g)
+    save("g12_variants.npz", d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for name in which:
         globals()[name]()

@@ -299,3 +299,36 @@ def test_chamfer_metrics():
     # the direct-difference form (the CUDA kernel's) agrees with the expanded form up to rounding
     d1, d2, i1, i2 = orc.nn_distance(smp[:5], ref)
     np.testing.assert_allclose(d1.numpy(), dr.numpy(), atol=2e-6); np.testing.assert_allclose(d2.numpy(), dl.numpy(), atol=2e-6)
+
+
+# ---------------------------------------------------------------- G12: non-default flags
+def test_variant_flags():
+    d = golden("g12_variants.npz")
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    z = fr.latent(B, N, seed=120)
+    # --use_head: graphs of both EdgeConvs live in feature space -> inject the reference's (tie-aware protocol)
+    p = {k: v.clone().requires_grad_(True) for k, v in fr.init_params(orc.generator_shapes(use_head=True), salt=20).items()}
+    i1 = torch.from_numpy(d["head|idx1"].astype(np.int64)).view(B, N * 10)
+    i2 = torch.from_numpy(d["head|idx2"].astype(np.int64)).view(B, N * 10)
+    out = orc.generator_forward(p, x, z, training=True, buffers=orc.bn_buffers(orc.generator_shapes(use_head=True)), idx1=i1, idx2=i2)
+    check(d, "head|out", out, rtol=2e-5)
+    names = list(p.keys())
+    grads = torch.autograd.grad(out, [p[n] for n in names], fr.normal("g12.dy", out.shape))
+    for n, g in zip(names, grads):
+        check(d, "head|grad|" + n, g, rtol=3e-3, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-6)
+    # --off --z_norm
+    p = fr.init_params(orc.generator_shapes(), salt=21)
+    i2 = torch.from_numpy(d["off|idx2"].astype(np.int64)).view(B, N * 10)
+    out = orc.generator_forward(p, x, z, training=True, buffers=orc.bn_buffers(orc.generator_shapes()), idx2=i2, off=True, z_norm=True)
+    check(d, "off|out", out, rtol=2e-5)
+    # --small_d
+    p = {k: v.clone().requires_grad_(True) for k, v in fr.init_params(orc.discriminator_shapes(small_d=True), salt=22).items()}
+    real = fr.synthetic_real(4, N, seed=23).transpose(2, 1).contiguous().requires_grad_(True)
+    logit = orc.discriminator_forward(p, real, True, orc.bn_buffers(orc.discriminator_shapes(small_d=True)))
+    check(d, "small|logit", logit, rtol=2e-5)
+    names = list(p.keys())
+    grads = torch.autograd.grad(((logit - 1.0) ** 2).mean(), [real] + [p[n] for n in names])
+    check(d, "small|dx", grads[0], rtol=2e-3)
+    for n, g in zip(names, grads[1:]):
+        check(d, "small|grad|" + n, g, rtol=5e-3, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)

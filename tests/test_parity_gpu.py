@@ -308,3 +308,68 @@ def test_discriminator_advance_running_stats_equals_forward(sp):
     for n in bufs[0]:
         np.testing.assert_allclose(bufs[1][n].numpy(), bufs[0][n].numpy(), rtol=2e-5, atol=1e-6, err_msg=n)
     assert int(bufs[1]["fc2.1.num_batches_tracked"]) == 2
+
+
+# ---------------------------------------------------------------- non-default flags (G12)
+def _tie_aware_out(sp, G, d, tag, out, x, z, B, N, shapes_kw, salt, **fkw):
+    """Compare with the golden output when both feature-space graphs coincide with the reference's, otherwise with the oracle
+    run on OUR graphs (tie-aware protocol)."""
+    i1 = sp.ops.idx_to_local64(G.EdgeConv1.last_idx, B, N).view(B, N, 10).cpu()
+    i2 = sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).view(B, N, 10).cpu()
+    same = np.array_equal(i2.numpy(), d[tag + "|idx2"]) and ((tag + "|idx1") not in d or np.array_equal(i1.numpy(), d[tag + "|idx1"]))
+    if same:
+        check(d, tag + "|out", out, rtol=2e-4)
+    agree = (i2.numpy() == d[tag + "|idx2"]).all(axis=2).mean()
+    assert agree >= 0.99, agree
+    p = fr.init_params(orc.generator_shapes(**shapes_kw), salt=salt)
+    ref = orc.generator_forward(p, x.cpu(), z.cpu(), training=True, buffers=orc.bn_buffers(orc.generator_shapes(**shapes_kw)),
+                                idx1=i1.view(B, -1), idx2=i2.view(B, -1), **fkw)
+    assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) <= 2e-4
+    return same
+
+
+def test_generator_use_head_golden(sp):
+    d = golden("g12_variants.npz")
+    B, N = 4, 256
+
+    class OH(Opts):
+        use_head = True
+    G = _load(sp.Generator(OH), fr.init_params(orc.generator_shapes(use_head=True), salt=20)).train()
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    z = fr.latent(B, N, seed=120).cuda()
+    out = G(x, z)
+    same = _tie_aware_out(sp, G, d, "head", out, x, z, B, N, dict(use_head=True), 20)
+    dy = fr.normal("g12.dy", out.shape).cuda()
+    (out * dy).sum().backward()
+    if same:
+        for n, p in G.named_parameters():
+            check(d, "head|grad|" + n, p.grad, rtol=3e-2, atol=_atol(n))
+
+
+def test_generator_off_znorm_golden(sp):
+    d = golden("g12_variants.npz")
+    B, N = 4, 256
+
+    class OO(Opts):
+        off = True; z_norm = True
+    G = _load(sp.Generator(OO), fr.init_params(orc.generator_shapes(), salt=21)).train()
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    z = fr.latent(B, N, seed=120).cuda()
+    out = G(x, z)
+    _tie_aware_out(sp, G, d, "off", out, x, z, B, N, {}, 21, off=True, z_norm=True)
+
+
+def test_discriminator_small_d_golden(sp):
+    d = golden("g12_variants.npz")
+    N = 256
+
+    class OS(Opts):
+        small_d = True
+    D = _load(sp.Discriminator(OS), fr.init_params(orc.discriminator_shapes(small_d=True), salt=22)).train()
+    real = fr.synthetic_real(4, N, seed=23).transpose(2, 1).contiguous().cuda().requires_grad_(True)
+    logit = D(real)
+    check(d, "small|logit", logit, rtol=1e-4)
+    ((logit - 1.0) ** 2).mean().backward()
+    check(d, "small|dx", real.grad, rtol=3e-2)
+    for n, p in D.named_parameters():
+        check(d, "small|grad|" + n, p.grad, rtol=3e-2, atol=_atol(n))
