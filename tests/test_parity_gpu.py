@@ -373,3 +373,31 @@ def test_discriminator_small_d_golden(sp):
     check(d, "small|dx", real.grad, rtol=3e-2)
     for n, p in D.named_parameters():
         check(d, "small|grad|" + n, p.grad, rtol=3e-2, atol=_atol(n))
+
+
+@pytest.mark.parametrize("B,N,small", [(3, 300, False), (2, 200, True)])
+def test_discriminator_ragged_n_vs_oracle(sp, B, N, small):
+    """N % 128 != 0: the pooling partials cannot be used (tiles would straddle shapes), the output of fc2.0 is stored and
+    pooled by the stand-alone kernel -- forward, WGAN loss + gradient penalty gradients against the oracle's autograd."""
+    class O(Opts):
+        small_d = small
+    shapes = orc.discriminator_shapes(small_d=small)
+    p = fr.init_params(shapes, salt=15)
+    D = _load(sp.Discriminator(O), p).train()
+    real = fr.synthetic_real(B, N, seed=151).transpose(2, 1).contiguous()
+    fake = (0.8 * fr.synthetic_real(B, N, seed=152) + 0.05 * fr.normal("rag.n", (B, N, 3))).transpose(2, 1).contiguous()
+    alpha = fr.uniform("rag.alpha", (B, 1, 1), 0.0, 1.0)
+    loss = D(fake.cuda()).mean() - D(real.cuda()).mean() + sp.GradientPenalty(10.0, gamma=1)(D, real.cuda(), fake.cuda(), alpha=alpha.cuda())
+    loss.backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    f = lambda t: orc.discriminator_forward(po, t, True, None)
+    ref = f(fake).mean() - f(real).mean() + orc.gradient_penalty(f, real, fake, alpha, 10.0, 1.0)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-4)
+    names = list(po.keys())
+    gref = torch.autograd.grad(ref, [po[n] for n in names], allow_unused=True)
+    own = dict(D.named_parameters())
+    for n, g in zip(names, gref):
+        g = torch.zeros_like(po[n]) if g is None else g
+        mine = own[n].grad if own[n].grad is not None else torch.zeros_like(own[n])
+        e = rel_l2(mine.cpu().numpy(), g.numpy())
+        assert e <= 3e-3 or (mine.cpu() - g).abs().max().item() <= (2e-3 if n.endswith(ZERO_GRAD_BIASES) else 2e-6), "%s %.3e" % (n, e)
