@@ -977,7 +977,7 @@ inline void tn_plan(int M, int Na, int Nb, int* splits, int* rows) {
   const int tiles = cdiv(Na, TA) * cdiv(Nb, tn_tb(Nb));
   int want = cdiv(512, tiles);
   int r = cdiv(M, want);
-  if (r < 256) r = 256;
+  if (r < 64) r = 64;  // two staging steps: short reductions (M ~ 1000: the K x K products of the collapsed backward) are latency-bound, spread them
   r = cdiv(r, TKM) * TKM;
   *rows = r;
   *splits = cdiv(M, r);
