@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--mfma", choices=("f32", "f16"), default="f32",
+                    help="operand precision of the MFMA contractions: f32 (BASELINE configs[1], the headline) or f16 operands with fp32 "
+                         "accumulation (the per-GPU shape of BASELINE configs[4], 'fp16 MFMA MLPs')")
     ap.add_argument("--reference-schedule", action="store_true",
                     help="also evaluate the two provably redundant pieces of the reference loop (EdgeConv1 on every copy of the tiled "
                          "sphere, the G step's unused D(real) forward) -- for comparison; see DESIGN.md")
@@ -179,6 +182,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
 
+    spgan.ops.set_mfma_operands(args.mfma)
     G, D = build_models(dev)
     # The step is captured once into a hipGraph and replayed (TrainStep(graph=True)): issuing its ~580 launches from Python takes
     # as long as the GPU needs to run them.  Data-parallel runs capture the two RCCL all-reduces with it; SPGAN_GRAPH=0 / --no-graph
@@ -231,7 +235,8 @@ def main():
         line = {
             "metric": "G+D train-step shapes/sec @2048 pts, bs=32 per GPU (WGAN-GP)", "value": round(shapes_s, 2), "unit": "shapes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.mfma == "f32" else "f16 MFMA operands, f32 accumulate/epilogues/weight-gradients",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: Chair-shaped synthetic clouds, 2048 pts, per-GPU batch 32, WGAN + gradient penalty (lambda 10), "
                                    "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10", "global_batch": PER_GPU_BATCH * world, "n_points": N_POINTS,
                        "parallelism": "dp%d" % world},

@@ -116,6 +116,9 @@ typedef struct spgan_gemm_nt_args {
    * With them Y may be NULL (the output is not stored): adaptive_max_pool1d behind BatchNorm + LeakyReLU
    * (Discriminator.py:77-81,104) is finished by spgan_pool_finalize once the batch statistics are known. */
   float* pool_val; int32_t* pool_arg;
+  /* 1: round the operands to fp16 when staging them (after the prologue) and multiply with the fp16 MFMA, fp32 accumulation
+   * (BASELINE configs[4] "fp16 MFMA MLPs"); aligned operands and N > 32 only, otherwise the fp32 path is used.  Default 0. */
+  int mfma_f16;
 } spgan_gemm_nt_args;
 
 int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s);

@@ -25,6 +25,8 @@
 #include "common.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -97,6 +99,13 @@ __device__ __forceinline__ void sparse_add4(float4& v, const float* __restrict__
 
 // FAST (template flag below): every operand pointer is 16-byte aligned, leading dimensions and K are multiples of 4 ->
 // unconditional float4 loads (no divergent scalar tail path; the loads of a k-tile issue back to back).
+// 4 consecutive k-values as fp16 (round to nearest) into 2 LDS words
+__device__ __forceinline__ void st_row4h(float* p, float4 v) {
+  f32x4v f = {v.x, v.y, v.z, v.w};
+  const f16x4 h = __builtin_convertvector(f, f16x4);
+  *reinterpret_cast<f16x4*>(p) = h;
+}
+
 __device__ __forceinline__ void st_row4(float* p, float4 v) {  // rows are 8-byte aligned (LDT even)
   *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
   *reinterpret_cast<float2*>(p + 2) = make_float2(v.z, v.w);
@@ -132,17 +141,24 @@ __device__ __forceinline__ void col_reduce(float (&part)[Geo<CFG>::TJ], float* r
   __syncthreads();
 }
 
-template <int AMODE, int EPI, int CFG, int DB, int FAST>
+// F16 = 1: the operands are rounded to fp16 (round-to-nearest) when they are staged into LDS and multiplied with
+// v_mfma_f32_32x32x8_f16 (fp32 accumulate): BASELINE configs[4] "fp16 MFMA MLPs".  Global loads, prologues and epilogues stay
+// fp32; an LDS row holds the 32 k-values of the tile as 16 words + 2 words of padding (stride 18 == 2 mod 16: the 32 rows x
+// 8-byte fragment reads of a half-wave are conflict-free), a fragment read (4 halfs) feeds ONE MFMA of k = 8.
+template <int AMODE, int EPI, int CFG, int DB, int FAST, int F16 = 0>
 __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_args p) {  // <= 168 VGPRs: 3 waves/SIMD
   using G = Geo<CFG>;
   constexpr int TI = G::TI, TJ = G::TJ;
   constexpr int BN = G::WGN * TJ * 32;
   constexpr int NB = DB + 1;
   constexpr int BSLOT = BN / 32;  // float4 staging slots per thread for the weight tile
+  constexpr int LDX = F16 ? 18 : LDT;   // LDS row stride in 4-byte words
+  constexpr int KK = F16 ? BK / 8 : BK / 4;  // fragment reads per k-tile
+  static_assert(!(F16 && AMODE == A_AFFINE_SPARSE), "the LDS patch path of the sparse addend is fp32 only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                  // [NB][BM*LDT]
-  float* Bs = smem + NB * BM * LDT;  // [NB][BN*LDT]
-  float* red = Bs + NB * BN * LDT;   // [WGM][BN]
+  float* As = smem;                  // [NB][BM*LDX]
+  float* Bs = smem + NB * BM * LDX;  // [NB][BN*LDX]
+  float* red = Bs + NB * BN * LDX;   // [WGM][BN]
   float* pool = red + G::WGM * BN;   // [4][WGM][BN]: column max / arg-max / min / arg-min exchange of the pooling epilogue
 
   const int tilesN = (p.N + BN - 1) / BN;
@@ -248,8 +264,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
     for (int i = 0; i < BSLOT; ++i) rb[i] = kok ? ldrow(p.W, offW[i], k, vecW) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto sstore = [&](int buf, int k0) {
-    float* a = As + buf * BM * LDT;
-    float* b = Bs + buf * BN * LDT;
+    float* a = As + buf * BM * LDX;
+    float* b = Bs + buf * BN * LDX;
     const int k = k0 + lc4;
     const bool kok = k < p.K;
     if (AMODE != SPGAN_A_PLAIN) {
@@ -283,29 +299,48 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 #pragma unroll
       for (int i = 0; i < BSLOT; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (F16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st_row4(&a[(lrow + 32 * i) * LDT + lc4], ra[i]);
+      for (int i = 0; i < 4; ++i) st_row4h(&a[(lrow + 32 * i) * LDX + (lc4 >> 1)], ra[i]);
 #pragma unroll
-    for (int i = 0; i < BSLOT; ++i) st_row4(&b[(lrow + 32 * i) * LDT + lc4], rb[i]);
+      for (int i = 0; i < BSLOT; ++i) st_row4h(&b[(lrow + 32 * i) * LDX + (lc4 >> 1)], rb[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st_row4(&a[(lrow + 32 * i) * LDX + lc4], ra[i]);
+#pragma unroll
+      for (int i = 0; i < BSLOT; ++i) st_row4(&b[(lrow + 32 * i) * LDX + lc4], rb[i]);
+    }
   };
-  auto compute = [&](int buf, int kk0 = 0, int kk1 = BK / 4) {
-    const float* a = As + buf * BM * LDT + (wm * TI * 32 + l31) * LDT + 2 * lh;
-    const float* b = Bs + buf * BN * LDT + (wn * TJ * 32 + l31) * LDT + 2 * lh;
+  auto compute = [&](int buf, int kk0, int kk1) {
+    const float* a = As + buf * BM * LDX + (wm * TI * 32 + l31) * LDX + 2 * lh;
+    const float* b = Bs + buf * BN * LDX + (wn * TJ * 32 + l31) * LDX + 2 * lh;
 #pragma unroll
     for (int kk = kk0; kk < kk1; ++kk) {
-      float2 af[TI], bf[TJ];
+      if (F16) {
+        f16x4 ah[TI], bh[TJ];
 #pragma unroll
-      for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float2*>(a + i * 32 * LDT + kk * 4);
+        for (int i = 0; i < TI; ++i) ah[i] = *reinterpret_cast<const f16x4*>(a + i * 32 * LDX + kk * 4);
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float2*>(b + j * 32 * LDT + kk * 4);
+        for (int j = 0; j < TJ; ++j) bh[j] = *reinterpret_cast<const f16x4*>(b + j * 32 * LDX + kk * 4);
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      } else {
+        float2 af[TI], bf[TJ];
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float2*>(a + i * 32 * LDX + kk * 4);
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float2*>(b + j * 32 * LDX + kk * 4);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+      }
     }
   };
 
@@ -337,16 +372,16 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
     if (DB) {
       // the next tile's LDS stores go between the two halves of this tile's MFMAs (other buffer: its last readers passed the
       // previous barrier): they overlap with the second half instead of sitting between the last MFMA and the barrier
-      compute(kt & 1, 0, BK / 8);
+      compute(kt & 1, 0, KK / 2);
       if (kt + 1 < nk) sstore((kt + 1) & 1, (kt + 1) * BK);
-      compute(kt & 1, BK / 8, BK / 4);
+      compute(kt & 1, KK / 2, KK);
       __syncthreads();
       if (sp_lds && kt + 1 < nk) {
         sfix((kt + 1) & 1, (kt + 1) * BK);
         __syncthreads();
       }
     } else {
-      compute(0);
+      compute(0, 0, KK);
       __syncthreads();
       if (kt + 1 < nk) {
         sstore(0, (kt + 1) * BK);
@@ -542,22 +577,23 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 #undef ROW_OF
 }
 
-template <int CFG, int DB>
+template <int CFG, int DB, int F16 = 0>
 constexpr size_t nt_lds_bytes() {
-  return (size_t)((DB + 1) * (BM + Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * LDT + 5 * Geo<CFG>::WGM * Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * sizeof(float);
+  return (size_t)((DB + 1) * (BM + Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * (F16 ? 18 : LDT) + 5 * Geo<CFG>::WGM * Geo<CFG>::WGN * Geo<CFG>::TJ * 32) *
+         sizeof(float);
 }
 
-template <int AMODE, int EPI, int CFG, int DB, int FAST>
+template <int AMODE, int EPI, int CFG, int DB, int FAST, int F16 = 0>
 void launch_nt_cfg(const spgan_gemm_nt_args& a, hipStream_t s) {
   constexpr int BN = Geo<CFG>::WGN * Geo<CFG>::TJ * 32;
-  constexpr size_t lds = nt_lds_bytes<CFG, DB>();
+  constexpr size_t lds = nt_lds_bytes<CFG, DB, F16>();
   static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int tm8 = cdiv(cdiv(a.M, BM), 8) * 8;
-  hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST>), dim3(tm8 * cdiv(a.N, BN)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16>), dim3(tm8 * cdiv(a.N, BN)), dim3(256), lds, s, a);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -643,6 +679,13 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE_SPARSE && (EPI == SPGAN_EPI_LINEAR || EPI == SPGAN_EPI_MASK_OUT)) {
     if (a.M <= 64 && fast && !a.stats && !a.sp_val) {
       hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(cdiv(a.N, SC), cdiv(a.M, SR)), dim3(256), 0, s, a);
+      return spgan_launch_status();
+    }
+  }
+  if constexpr (AMODE != A_AFFINE_SPARSE) {
+    if (a.mfma_f16 && fast && a.N > 32) {  // fp16 operands (fp32 accumulate): same tiling rules
+      if (a.N > 64 && a.K >= 512) launch_nt_cfg<AMODE, EPI, 0, 1, 1, 1>(a, s);
+      else launch_nt_cfg<AMODE, EPI, 1, 0, 1, 1>(a, s);
       return spgan_launch_status();
     }
   }

@@ -35,6 +35,7 @@ class GemmNTArgs(C.Structure):
         ("e_bias2", c_f32p),
         ("sp_val", c_f32p), ("sp_arg", c_i32p), ("sp_rows", C.c_int),
         ("pool_val", c_f32p), ("pool_arg", c_i32p),
+        ("mfma_f16", C.c_int),
     ]
 
 

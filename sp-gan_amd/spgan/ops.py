@@ -77,6 +77,22 @@ def _ld(t: Tensor) -> int:
 # the launch was enqueued -- the bench brackets selected launches with HIP events on the launch stream.  None in normal use.
 launch_timer = None
 
+# Operand precision of the matrix-core contractions behind gemm_nt / gemm_nt_maskout / gemm_nt_bnbwd / gemm_bn_pool:
+# "f32" (default: exact fp32 products) or "f16" (operands rounded to fp16 at the LDS staging, fp32 accumulation: BASELINE
+# configs[4] "fp16 MFMA MLPs").  Weight gradients (gemm_tn), kNN distances, statistics and every epilogue stay fp32.
+_MFMA_F16 = [0]
+
+
+def set_mfma_operands(kind: str) -> None:
+    if kind not in ("f32", "f16"):
+        raise ValueError("mfma operands must be 'f32' or 'f16'")
+    _MFMA_F16[0] = 1 if kind == "f16" else 0
+
+
+def get_mfma_operands() -> str:
+    return "f16" if _MFMA_F16[0] else "f32"
+
+
 # Bumped by every optimiser step that rewrites parameters through a HIP kernel (invisible to torch's version counters);
 # host-side caches of weight-derived tensors (nets._t) key on it.
 WEIGHTS_EPOCH = [0]
@@ -177,7 +193,7 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
     stats=True additionally returns (mean[N], biased var[N]) of the pre-activation output over all M rows."""
     _rowmajor2d(A, "A"); _rowmajor2d(W, "W")
     N, K = W.shape
-    a = GemmNTArgs()
+    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]
     if edge is not None:
         idx, ebias = edge
         _i32(idx, "idx")
@@ -232,7 +248,7 @@ def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float) -> Tensor:
     N, K = W.shape
     M_ = A.shape[0]
     Y = torch.empty((M_, N), dtype=torch.float32, device=A.device)
-    a = GemmNTArgs()
+    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]
     a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W); a.Y = _p(Y); a.ldy = N
     a.M, a.N, a.K = M_, N, K
     a.a_mode = A_PLAIN; a.epi_mode = EPI_MASK_OUT
@@ -298,7 +314,7 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
     g = torch.empty((M_, N), dtype=torch.float32, device=A.device)
     tiles = (M_ + ROW_TILE - 1) // ROW_TILE
     part = torch.empty((tiles, N, 2), dtype=torch.float32, device=A.device)
-    a = GemmNTArgs()
+    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]
     a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W); a.Y = _p(g); a.ldy = N
     a.M, a.N, a.K = M_, N, K
     a.a_mode = A_PLAIN
@@ -534,7 +550,7 @@ def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, sl
     B = M_ // rows
     tiles = M_ // ROW_TILE
     dev = A.device
-    a = GemmNTArgs()
+    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]
     a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W)
     Y = torch.empty((M_, N), dtype=torch.float32, device=dev) if keep_y else None
     a.Y = _p(Y); a.ldy = N
