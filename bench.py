@@ -43,10 +43,14 @@ class Opts:
     use_head = False; eql = False; z_norm = False; small_d = False
 
 
-def build_models(dev):
+def build_models(dev, variant=()):
     import spgan
     torch.manual_seed(123)                      # Generation/model.py:38-41
-    G, D = spgan.Generator(Opts), spgan.Discriminator(Opts)
+    O = type("O", (Opts,), {f: True for f in variant})
+    G, D = spgan.Generator(O), spgan.Discriminator(O)
+    if "attn" in variant:
+        with torch.no_grad():
+            G.attn.gamma.fill_(0.1)             # the gate is 0 at initialisation (modules.py:546); timing is value-independent
     return G.to(dev), D.to(dev)
 
 
@@ -168,7 +172,10 @@ def main():
     ap.add_argument("--reference-schedule", action="store_true",
                     help="also evaluate the two provably redundant pieces of the reference loop (EdgeConv1 on every copy of the tiled "
                          "sphere, the G step's unused D(real) forward) -- for comparison; see DESIGN.md")
+    ap.add_argument("--variant", default="", help="comma-separated non-default generator flags (attn, eql, use_head, off, z_norm) or "
+                    "small_d: times that variant instead of the headline configuration (SURVEY 8(f) N4); the JSON line says so")
     args = ap.parse_args()
+    variant = tuple(v for v in args.variant.split(",") if v)
 
     import spgan
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,7 +191,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
 
     spgan.ops.set_mfma_operands(args.mfma)
-    G, D = build_models(dev)
+    G, D = build_models(dev, variant)
     # The step is captured once into a hipGraph and replayed (TrainStep(graph=True)): issuing its ~580 launches from Python takes
     # as long as the GPU needs to run them.  Data-parallel runs capture the two RCCL all-reduces with it; SPGAN_GRAPH=0 / --no-graph
     # fall back to eager issue.
@@ -245,6 +252,9 @@ def main():
             "step_tflops_algorithmic": round(shapes_s * GF_PER_SHAPE_STEP / 1e3, 2),
             "step_frac_of_fp32_matrix_peak": round(shapes_s * GF_PER_SHAPE_STEP / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
         }
+        if variant:
+            line["variant"] = list(variant)
+            line["config"]["workload"] += "; NON-HEADLINE variant flags: " + ",".join(variant)
         line["roofline"] = timer.roofline()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

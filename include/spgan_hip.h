@@ -119,6 +119,10 @@ typedef struct spgan_gemm_nt_args {
   /* 1: round the operands to fp16 when staging them (after the prologue) and multiply with the fp16 MFMA, fp32 accumulation
    * (BASELINE configs[4] "fp16 MFMA MLPs"); aligned operands and N > 32 only, otherwise the fp32 path is used.  Default 0. */
   int mfma_f16;
+  /* batch > 1 (A_PLAIN + EPI_LINEAR without stats / rowbias / pooling only): `batch` independent products in one launch,
+   * product z uses A + z*batch_stride_a, W + z*batch_stride_w, Y + z*batch_stride_y (strides in floats; bias is shared).
+   * The per-shape [N,N] contractions of the --attn variant (Generation/modules.py:554-556).  Default 0 / 1: a single product. */
+  int batch; long batch_stride_a, batch_stride_w, batch_stride_y;
 } spgan_gemm_nt_args;
 
 int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s);
@@ -370,6 +374,22 @@ int spgan_chamfer_bwd(const float* xa, const float* xb, int B, int Na, int Nb, c
 /* out[s,r] = mean_i min_j |A[s,i]-Bc[r,j]|^2 + mean_j min_i |A[s,i]-Bc[r,j]|^2 for every pair of clouds A[s] ([S,N,3]) and
  * Bc[r] ([R,M,3]): the all-pairs Chamfer matrix behind MMD-CD / COV-CD / 1-NNA-CD (metrics/evaluation_metrics.py:89-126). */
 int spgan_chamfer_pairs(const float* A, const float* Bc, int S, int R, int N, int M, float* out, spgan_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * --attn variant: `Attention(640)` between the concat and the tail (Generation/modules.py:534-558,
+ * Generator.py:116-117,191-192).  The projections and the per-shape [N,N] contractions are spgan_gemm_nt / spgan_gemm_tn
+ * calls; these are the HBM-bound pieces between them.
+ * ---------------------------------------------------------------------------------------- */
+/* S[r,:] = softmax(S[r,:]) in place, rows x cols contiguous (F.softmax(.,-1), modules.py:554) */
+int spgan_softmax_rows(float* S, long rows, int cols, spgan_stream_t s);
+/* dP[r,:] = P[r,:] * (dP[r,:] - sum_j dP[r,j]*P[r,j]) in place: the softmax Jacobian applied to the upstream gradient */
+int spgan_softmax_rows_bwd(const float* P, float* dP, long rows, int cols, spgan_stream_t s);
+/* y = gamma[0]*o + x (gamma: device scalar, the learnable gate of modules.py:546,558); n % 4 == 0 */
+int spgan_scale_residual(const float* o, const float* x, const float* gamma, float* y, size_t n, spgan_stream_t s);
+/* d_o = gamma[0]*dy, dgamma[0] = sum(dy*o) (two-stage, fixed order).  ws: spgan_scale_residual_bwd_ws_bytes(n) bytes. */
+size_t spgan_scale_residual_bwd_ws_bytes(size_t n);
+int spgan_scale_residual_bwd(const float* dy, const float* o, const float* gamma, float* d_o, float* dgamma, void* ws, size_t ws_bytes,
+                             size_t n, spgan_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -148,6 +148,40 @@ def adaptive_point_norm(p, prefix: str, x: Tensor, style: Tensor) -> Tensor:
     return gamma * xhat + beta
 
 
+def attention(p, prefix: str, x: Tensor) -> Tensor:
+    """Attention.forward, Generation/modules.py:549-558 (--attn, Generator.py:116-117,191-192): x [B,C,N] ->
+    gamma * o(g . softmax_j(theta^T phi)^T) + x; the four 1x1 convs carry no bias."""
+    def proj(name):
+        w = p[prefix + "." + name + ".weight"]
+        return torch.einsum("oc,bcn->bon", w.reshape(w.shape[0], w.shape[1]), x)
+    theta, phi, g = proj("theta"), proj("phi"), proj("g")
+    beta = F.softmax(torch.bmm(theta.transpose(1, 2), phi), -1)                 # [B,N,N]
+    o = torch.bmm(g, beta.transpose(1, 2))                                      # [B,C/2,N]
+    wo = p[prefix + ".o.weight"]
+    o = torch.einsum("oc,bcn->bon", wo.reshape(wo.shape[0], wo.shape[1]), o)
+    return p[prefix + ".gamma"] * o + x
+
+
+def eql_effective_params(p: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """--eql (Generator.py:103-104; EqualLR, Generation/modules.py:259-288): map the state_dict names of the equalised-LR
+    layers (`head.0.conv.weight_orig`, `global_conv.0.linear.bias`, ...) to the plain names used by this file, with the
+    run-time scaling weight = weight_orig * sqrt(2 / fan_in), fan_in = Cin * kernel size.  Differentiable."""
+    out = {}
+    for k, v in p.items():
+        for inner in (".conv.", ".linear."):
+            if inner in k:
+                base, leaf = k.split(inner)
+                if leaf == "weight_orig":
+                    fan_in = v.shape[1] * (v[0][0].numel() if v.dim() > 2 else 1)
+                    out[base + ".weight"] = v * math.sqrt(2.0 / fan_in)
+                else:
+                    out[base + "." + leaf] = v
+                break
+        else:
+            out[k] = v
+    return out
+
+
 def generator_style(p, x: Tensor, z: Tensor, z_norm: bool = False) -> Tensor:
     """The style branch: head MLP on cat[x, z] (Generator.py:163-169 / 203-215).  -> [B,128,N]"""
     if z_norm:                                                  # Generator.py:163-164
@@ -178,6 +212,8 @@ def generator_body(p, x: Tensor, style: Tensor, k: int = 10, training: bool = Tr
     g = F.linear(g, p["global_conv.3.weight"], p["global_conv.3.bias"])
     g = F.leaky_relu(_bn(g, p, "global_conv.4", training, buffers), NEG)
     feat = torch.cat([g.view(B, -1, 1).expand(B, g.shape[1], N), x2], dim=1)    # [B,640,N]
+    if "attn.gamma" in p:                                       # --attn, Generator.py:191-192
+        feat = attention(p, "attn", feat)
 
     t = F.leaky_relu(_conv1x1(feat, p, "tail.0"), NEG)
     t = F.leaky_relu(_conv1x1(t, p, "tail.2"), NEG)
@@ -434,8 +470,10 @@ def sample_and_group(npoint, radius, nsample, xyz, points, start=None):
 # --------------------------------------------------------------------------- #
 # parameter containers                                                        #
 # --------------------------------------------------------------------------- #
-def generator_shapes(nz: int = 128, k: int = 10, use_head: bool = False) -> Dict[str, Tuple[int, ...]]:
-    """state_dict parameter shapes of Generator (default flags, or --use_head: Generator.py:138-148), Generator.py:107-153."""
+def generator_shapes(nz: int = 128, k: int = 10, use_head: bool = False, attn: bool = False, eql: bool = False) -> Dict[str, Tuple[int, ...]]:
+    """state_dict parameter shapes of Generator, Generator.py:107-153 (default flags; --use_head: 138-148; --attn: 116-117 with
+    Generation/modules.py:541-546; --eql: the Conv/Linear of head, global_conv and pc_head become `<name>.conv.weight_orig` /
+    `<name>.linear.weight_orig` + bias, Generator.py:103-104)."""
     d = 128
     s = {
         "head.0.weight": (d, 3 + nz, 1), "head.0.bias": (d,),
@@ -462,6 +500,21 @@ def generator_shapes(nz: int = 128, k: int = 10, use_head: bool = False) -> Dict
         })
     s.update({"adain1.style.weight": (256 if use_head else 128, d, 1), "adain1.style.bias": (256 if use_head else 128,),
               "adain2.style.weight": (256, d, 1), "adain2.style.bias": (256,)})
+    if attn:
+        ch = d + 512
+        s.update({"attn.theta.weight": (ch // 8, ch, 1), "attn.phi.weight": (ch // 8, ch, 1), "attn.g.weight": (ch // 2, ch, 1),
+                  "attn.o.weight": (ch, ch // 2, 1), "attn.gamma": ()})
+    if eql:
+        ren = {}
+        for key, shp in s.items():
+            base, leaf = key.rsplit(".", 1)
+            if base in ("head.0", "head.2", "pc_head.0", "pc_head.2"):
+                ren[base + ".conv." + ("weight_orig" if leaf == "weight" else leaf)] = shp
+            elif base in ("global_conv.0", "global_conv.3"):
+                ren[base + ".linear." + ("weight_orig" if leaf == "weight" else leaf)] = shp
+            else:
+                ren[key] = shp
+        s = ren
     return s
 
 

@@ -146,7 +146,15 @@ __device__ __forceinline__ void col_reduce(float (&part)[Geo<CFG>::TJ], float* r
 // fp32; an LDS row holds the 32 k-values of the tile as 16 words + 2 words of padding (stride 18 == 2 mod 16: the 32 rows x
 // 8-byte fragment reads of a half-wave are conflict-free), a fragment read (4 halfs) feeds ONE MFMA of k = 8.
 template <int AMODE, int EPI, int CFG, int DB, int FAST, int F16 = 0>
-__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_args p) {  // <= 168 VGPRs: 3 waves/SIMD
+__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_args p_) {  // <= 168 VGPRs: 3 waves/SIMD
+  spgan_gemm_nt_args p = p_;
+  if constexpr (AMODE == SPGAN_A_PLAIN && EPI == SPGAN_EPI_LINEAR) {
+    if (blockIdx.y != 0) {  // batched product: blockIdx.y selects the (A, W, Y) triple (scalar pointer arithmetic)
+      p.A += (size_t)blockIdx.y * (size_t)p.batch_stride_a;
+      p.W += (size_t)blockIdx.y * (size_t)p.batch_stride_w;
+      p.Y += (size_t)blockIdx.y * (size_t)p.batch_stride_y;
+    }
+  }
   using G = Geo<CFG>;
   constexpr int TI = G::TI, TJ = G::TJ;
   constexpr int BN = G::WGN * TJ * 32;
@@ -593,7 +601,8 @@ void launch_nt_cfg(const spgan_gemm_nt_args& a, hipStream_t s) {
     attr_set = true;
   }
   const int tm8 = cdiv(cdiv(a.M, BM), 8) * 8;
-  hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16>), dim3(tm8 * cdiv(a.N, BN)), dim3(256), lds, s, a);
+  const int batch = (AMODE == SPGAN_A_PLAIN && EPI == SPGAN_EPI_LINEAR && a.batch > 1) ? a.batch : 1;
+  hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16>), dim3(tm8 * cdiv(a.N, BN), batch), dim3(256), lds, s, a);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -677,7 +686,7 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   if (AMODE == SPGAN_A_EDGE) fast = fast && al16(a.e_bias);
   if (AMODE == A_AFFINE_SPARSE) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
   if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE_SPARSE && (EPI == SPGAN_EPI_LINEAR || EPI == SPGAN_EPI_MASK_OUT)) {
-    if (a.M <= 64 && fast && !a.stats && !a.sp_val) {
+    if (a.M <= 64 && fast && !a.stats && !a.sp_val && a.batch <= 1) {
       hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(cdiv(a.N, SC), cdiv(a.M, SR)), dim3(256), 0, s, a);
       return spgan_launch_status();
     }
@@ -1063,6 +1072,9 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   if (a->a_mode == SPGAN_A_EDGE) SPGAN_CHECK_ARG(a->e_idx && a->e_bias && a->e_k > 0);
   if (a->rowbias) SPGAN_CHECK_ARG(a->rows_per_group > 0 && a->ld_rowbias >= a->N);
   if (a->sp_val) SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_AFFINE_LRELU && a->sp_arg && a->sp_rows > 0);
+  if (a->batch > 1)
+    SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->epi_mode == SPGAN_EPI_LINEAR && a->Y && !a->stats && !a->rowbias && !a->pool_val &&
+                    a->batch <= 65535 && a->batch_stride_a >= 0 && a->batch_stride_w >= 0 && a->batch_stride_y > 0);
   switch (a->epi_mode) {
     case SPGAN_EPI_LINEAR:
       if (a->a_mode == SPGAN_A_PLAIN) return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_LINEAR>(*a, s);

@@ -36,6 +36,7 @@ class GemmNTArgs(C.Structure):
         ("sp_val", c_f32p), ("sp_arg", c_i32p), ("sp_rows", C.c_int),
         ("pool_val", c_f32p), ("pool_arg", c_i32p),
         ("mfma_f16", C.c_int),
+        ("batch", C.c_int), ("batch_stride_a", C.c_long), ("batch_stride_w", C.c_long), ("batch_stride_y", C.c_long),
     ]
 
 
@@ -132,6 +133,11 @@ SIGNATURES = {
     "spgan_nn_distance": (I, [P, P, I, I, I, P, P, P]),
     "spgan_chamfer_bwd": (I, [P, P, I, I, I, P, P, P, P, P, P]),
     "spgan_chamfer_pairs": (I, [P, P, I, I, I, I, P, P]),
+    "spgan_softmax_rows": (I, [P, C.c_long, I, P]),
+    "spgan_softmax_rows_bwd": (I, [P, P, C.c_long, I, P]),
+    "spgan_scale_residual": (I, [P, P, P, P, SZ, P]),
+    "spgan_scale_residual_bwd_ws_bytes": (SZ, [SZ]),
+    "spgan_scale_residual_bwd": (I, [P, P, P, P, P, P, SZ, SZ, P]),
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
     "spgan_axpby": (I, [F, P, F, P, SZ, P]),
     "spgan_adam_step": (I, [P, P, P, P, SZ, F, F, F, F, I, F, P]),

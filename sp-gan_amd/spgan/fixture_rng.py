@@ -42,7 +42,11 @@ def init_params(shapes: Dict[str, Tuple[int, ...]], salt: int = 0, perturb_bn: b
     for name, shp in shapes.items():
         base, leaf = name.rsplit(".", 1)
         wshape = shapes.get(base + ".weight", shp)
-        if len(wshape) == 1:                                     # batch-norm affine
+        if leaf == "gamma":                                      # Attention's gate (0 at init in the reference: nothing to test)
+            t = torch.full(shp, 0.7)
+        elif leaf == "weight_orig":                              # equalised-LR layers: N(0,1), scaled at run time
+            t = normal(name, shp, 1.0, 0.0, salt)
+        elif len(wshape) == 1:                                   # batch-norm affine (and the biases of equalised-LR layers)
             if leaf == "weight":
                 t = uniform(name, shp, 0.5, 1.5, salt) if perturb_bn else torch.ones(shp)
             else:

@@ -36,25 +36,27 @@ FUSED_GRAD_ACCUMULATION = True
 
 
 def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool]):
-    """Hand parameter gradients back to autograd -- or, when every wanted parameter already owns a contiguous `.grad`
-    (the flat buffer of spgan.optim.flatten_module) and no graph is being recorded, add them into `.grad` with ONE
-    fused launch (spgan_multi_add) and return None for all of them: the same sums AccumulateGrad would form with one
-    elementwise launch per parameter tensor.  Exact-zero gradients (nets.ZERO_GRAD) cost nothing on that path."""
-    live = [(p, g) for p, g, need in zip(params, grads, needs) if need and g is not None]
-    if FUSED_GRAD_ACCUMULATION and not torch.is_grad_enabled() and live and all(
-            p.grad is not None and p.grad.is_contiguous() and (isinstance(g, int) or p.grad.numel() == g.numel()) for p, g in live):
-        pairs = [(p.grad, g.contiguous()) for p, g in live if not isinstance(g, int)]
-        if pairs:
-            ops.multi_add([d for d, _ in pairs], [s for _, s in pairs])
-        return (None,) * len(params)
-    out = []
-    for p, g, need in zip(params, grads, needs):
+    """Hand parameter gradients back to autograd -- or, for every wanted leaf parameter that already owns a contiguous `.grad`
+    (the flat buffer of spgan.optim.flatten_module) while no graph is being recorded, add them into `.grad` with ONE fused
+    launch (spgan_multi_add) and return None: the same sums AccumulateGrad would form with one elementwise launch per parameter
+    tensor (and on the launch stream, which keeps the step capturable as a hipGraph).  Non-leaf "parameters" (the scaled weights of
+    equalised-LR layers) get their gradient returned.  Exact-zero gradients (nets.ZERO_GRAD) cost nothing on the fused path."""
+    fused = FUSED_GRAD_ACCUMULATION and not torch.is_grad_enabled()
+    out: List[Optional[Tensor]] = [None] * len(params)
+    pairs = []
+    for i, (p, g, need) in enumerate(zip(params, grads, needs)):
         if not need or g is None:
-            out.append(None)
-        elif isinstance(g, int):
-            out.append(torch.zeros_like(p))
+            continue
+        zero = isinstance(g, int)
+        if fused and p.is_leaf and p.grad is not None and p.grad.is_contiguous() and (zero or p.grad.numel() == g.numel()):
+            if not zero:
+                pairs.append((p.grad, g.contiguous()))
+        elif zero:
+            out[i] = torch.zeros_like(p)
         else:
-            out.append(g.view_as(p) if g.shape != p.shape else g)
+            out[i] = g.view_as(p) if g.shape != p.shape else g
+    if pairs:
+        ops.multi_add([d for d, _ in pairs], [s_ for _, s_ in pairs])
     return tuple(out)
 
 
@@ -241,6 +243,69 @@ class MLPFn(Function):
             out.append(g.get(n + ".weight"))
             out.append(g.get(n + ".bias"))
         return (None, dx) + _deliver(params, out, ctx.needs_input_grad[2:])
+
+
+class ScaleFn(Function):
+    """c * w: the runtime weight scaling of equalised-LR layers (`EqualLR.compute_weight`, Generation/modules.py:264-268)."""
+
+    @staticmethod
+    def forward(ctx, w, c):
+        ctx.c = c
+        ctx.save_for_backward(w)
+        return ops.axpby(c, w.contiguous(), 0.0, torch.empty_like(w, memory_format=torch.contiguous_format))
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        gw = ops.axpby(ctx.c, g.contiguous(), 0.0, torch.empty_like(g, memory_format=torch.contiguous_format))
+        return _deliver((w,), [gw], ctx.needs_input_grad[:1]) + (None,)
+
+
+GF_NAMES = ("global_conv.0.weight", "global_conv.0.bias", "global_conv.1.weight", "global_conv.1.bias",
+            "global_conv.3.weight", "global_conv.3.bias", "global_conv.4.weight", "global_conv.4.bias")
+
+
+class GlobalFeatFn(Function):
+    """feat[M,640] = cat[global_conv(max_N a2) repeated over N, a2] as a tensor (Generator.py:183-189) -- the --attn variant
+    feeds it to `Attention`; the default path (GlobalTailFn) never builds it."""
+
+    @staticmethod
+    def forward(ctx, holder, a2, *params):
+        P = dict(zip(GF_NAMES, params))
+        feat, gctx = nets.global_feat_forward(P, holder.buffers, a2.contiguous(), holder.B, holder.N, holder.training, True)
+        ctx.gctx = gctx
+        ctx.save_for_backward(*params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        params = ctx.saved_tensors
+        P = dict(zip(GF_NAMES, [p.detach() for p in params]))
+        da2, g = nets.global_feat_backward(P, ctx.gctx, dfeat.contiguous())
+        return (None, da2 if ctx.needs_input_grad[1] else None) + _deliver(params, [g[n] for n in GF_NAMES], ctx.needs_input_grad[2:])
+
+
+ATTN_NAMES = ("attn.theta.weight", "attn.phi.weight", "attn.g.weight", "attn.o.weight", "attn.gamma")
+
+
+class AttentionFn(Function):
+    """`Attention(ch)` of Generation/modules.py:534-558 on point-major rows [M,ch]; inputs: holder(B, N), x, theta/phi/g/o weights,
+    gamma (module parameter order)."""
+
+    @staticmethod
+    def forward(ctx, holder, x, *params):
+        P = dict(zip(ATTN_NAMES, params))
+        y, actx = nets.attention_forward(P, "attn", x.contiguous(), holder.B, holder.N)
+        ctx.actx = actx
+        ctx.save_for_backward(*params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        params = ctx.saved_tensors
+        P = dict(zip(ATTN_NAMES, [p.detach() for p in params]))
+        dx, g = nets.attention_backward(P, "attn", ctx.actx, dy, ctx.needs_input_grad[1])
+        return (None, dx) + _deliver(params, [g[n] for n in ATTN_NAMES], ctx.needs_input_grad[2:])
 
 
 GT_NAMES = ("global_conv.0.weight", "global_conv.0.bias", "global_conv.1.weight", "global_conv.1.bias",

@@ -8,6 +8,7 @@ load both ways.  Their `forward` never calls those layers: it runs the HIP pipel
 """
 from __future__ import annotations
 
+import math
 import weakref
 from typing import List, Optional
 
@@ -21,12 +22,78 @@ from .functions import _Holder
 NEG = nets.NEG
 
 
-def _stack(spec):
-    """spec: list of ('conv1d'|'conv2d'|'linear', cin, cout[, ksize]) | ('bn1d'|'bn2d', c) | ('lrelu',) | ('tanh',)."""
+class _EqualLR(nn.Module):
+    """Equalised learning rate (`EqualLR` / `EqualConv1d` / `EqualLinear`, Generation/modules.py:202-239,259-288): the wrapped
+    layer keeps `weight_orig` ~ N(0,1) and a zero bias as parameters (state_dict keys `<name>.conv.weight_orig`,
+    `<name>.conv.bias` / `<name>.linear.*`), and every forward uses weight_orig * sqrt(2 / fan_in)."""
+    _inner = "conv"
+
+    def _wrap(self, layer: nn.Module):
+        with torch.no_grad():
+            layer.weight.normal_()
+            layer.bias.zero_()
+        w = layer.weight
+        del layer._parameters["weight"]
+        layer.register_parameter("weight_orig", nn.Parameter(w.data))
+        fan_in = w.shape[1] * (w[0][0].numel() if w.dim() > 2 else 1)
+        self.scale = math.sqrt(2.0 / fan_in)
+        setattr(self, self._inner, layer)
+
+    @property
+    def weight(self):
+        return Fn.ScaleFn.apply(getattr(self, self._inner).weight_orig, self.scale)
+
+    @property
+    def bias(self):
+        return getattr(self, self._inner).bias
+
+
+class EqualConv1d(_EqualLR):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self._wrap(nn.Conv1d(*args, **kwargs))
+
+
+class EqualLinear(_EqualLR):
+    _inner = "linear"
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self._wrap(nn.Linear(in_dim, out_dim))
+
+
+class Attention(nn.Module):
+    """Generation/modules.py:534-558: non-local block over the points of a shape.  forward(x [B,ch,N]) -> [B,ch,N]."""
+
+    def __init__(self, ch: int, name: str = "attention"):
+        super().__init__()
+        self.ch = ch
+        self.theta = nn.Conv1d(ch, ch // 8, 1, bias=False)
+        self.phi = nn.Conv1d(ch, ch // 8, 1, bias=False)
+        self.g = nn.Conv1d(ch, ch // 2, 1, bias=False)
+        self.o = nn.Conv1d(ch // 2, ch, 1, bias=False)
+        self.gamma = nn.Parameter(torch.tensor(0.), requires_grad=True)
+
+    def forward_pm(self, x_pm, B: int, N: int):
+        return Fn.AttentionFn.apply(_Holder(B=B, N=N), x_pm, self.theta.weight, self.phi.weight, self.g.weight, self.o.weight, self.gamma)
+
+    def forward(self, x, y=None):
+        _require_gpu(x, "Attention")
+        B, C, N = x.shape
+        return Fn.PmToCm.apply(self.forward_pm(Fn.CmToPm.apply(x), B, N), B, N)
+
+
+def _stack(spec, eql: bool = False):
+    """spec: list of ('conv1d'|'conv2d'|'linear', cin, cout[, ksize]) | ('bn1d'|'bn2d', c) | ('lrelu',) | ('tanh',).
+    eql: Conv1d / Linear become their equalised-LR wrappers."""
     layers = []
     for s in spec:
         kind = s[0]
-        if kind == "conv1d":
+        if kind == "conv1d" and eql:
+            layers.append(EqualConv1d(s[1], s[2], 1))
+        elif kind == "linear" and eql:
+            layers.append(EqualLinear(s[1], s[2]))
+        elif kind == "conv1d":
             layers.append(nn.Conv1d(s[1], s[2], 1))
         elif kind == "conv2d":
             layers.append(nn.Conv2d(s[1], s[2], s[3] if len(s) > 3 else 1))
@@ -164,14 +231,15 @@ class Generator(nn.Module, _BNCounts):
         self.off = opts.off
         self.use_attn = opts.attn
         self.use_head = opts.use_head
-        if getattr(opts, "eql", False) or self.use_attn:
-            raise NotImplementedError("--eql / --attn variants are not part of the accelerated path yet (SURVEY 8(f) N4)")
+        eql = bool(getattr(opts, "eql", False))      # Generator.py:103-104: head, global_conv's Linear and pc_head only
         dim = 128
-        self.head = _stack([("conv1d", 3 + self.nz, dim), ("lrelu",), ("conv1d", dim, dim), ("lrelu",)])
-        self.global_conv = _stack([("linear", dim, dim), ("bn1d", dim), ("lrelu",), ("linear", dim, 512), ("bn1d", 512), ("lrelu",)])
+        self.head = _stack([("conv1d", 3 + self.nz, dim), ("lrelu",), ("conv1d", dim, dim), ("lrelu",)], eql)
+        if self.use_attn:
+            self.attn = Attention(dim + 512)
+        self.global_conv = _stack([("linear", dim, dim), ("bn1d", dim), ("lrelu",), ("linear", dim, 512), ("bn1d", 512), ("lrelu",)], eql)
         self.tail = _stack([("conv1d", 512 + dim, 256), ("lrelu",), ("conv1d", 256, 64), ("lrelu",), ("conv1d", 64, 3), ("tanh",)])
         if self.use_head:
-            self.pc_head = _stack([("conv1d", 3, dim // 2), ("lrelu",), ("conv1d", dim // 2, dim), ("lrelu",)])
+            self.pc_head = _stack([("conv1d", 3, dim // 2), ("lrelu",), ("conv1d", dim // 2, dim), ("lrelu",)], eql)
             self.EdgeConv1 = EdgeBlock(dim, dim, self.nk)
             self.adain1 = AdaptivePointNorm(dim, dim)
             self.EdgeConv2 = EdgeBlock(dim, dim, self.nk)
@@ -184,6 +252,15 @@ class Generator(nn.Module, _BNCounts):
         self.lrelu1 = nn.LeakyReLU(nets.NEG_2)
         self.lrelu2 = nn.LeakyReLU(nets.NEG_2)
         self._install_count_hook()
+
+    def _params_of(self, names):
+        """The tensors behind reference-style names ('global_conv.0.weight'): parameters, or for equalised-LR layers the
+        scaled weight computed on the fly."""
+        out = []
+        for n in names:
+            mod, attr = n.rsplit(".", 1)
+            out.append(getattr(self.get_submodule(mod), attr))
+        return out
 
     def _mlp2(self, seq: nn.Sequential, x_pm):
         h = _Holder(names=["l0", "l2"], acts=[ops.ACT_LRELU, ops.ACT_LRELU], slope=NEG)
@@ -231,9 +308,14 @@ class Generator(nn.Module, _BNCounts):
         self.last_x1 = x1.detach()                                 # [M,64] input of EdgeConv2's graph (diagnostics / parity tests)
         x2 = self.EdgeConv2.forward_pm(x1, B, N, knn_mode=0)
         x2 = self.adain2.forward_pm(x2, style, N, slope)
-        gt_params = [dict(self.named_parameters())[n] for n in Fn.GT_NAMES]
         h = _Holder(buffers=_buffers(self), B=B, N=N, training=self.training)
-        out = Fn.GlobalTailFn.apply(h, x2, *gt_params)
+        if self.use_attn:
+            feat = Fn.GlobalFeatFn.apply(h, x2, *self._params_of(Fn.GF_NAMES))                    # [M,640], Generator.py:183-189
+            feat = self.attn.forward_pm(feat, B, N)                                              # Generator.py:191-192
+            th = _Holder(names=["tail.0", "tail.2", "tail.4"], acts=[ops.ACT_LRELU, ops.ACT_LRELU, ops.ACT_TANH], slope=NEG)
+            out = Fn.MLPFn.apply(th, feat, *self._params_of(Fn.GT_NAMES[len(Fn.GF_NAMES):]))
+        else:
+            out = Fn.GlobalTailFn.apply(h, x2, *self._params_of(Fn.GT_NAMES))
         out = Fn.PmToCm.apply(out, B, N)
         return x.transpose(2, 1) + out if self.off else out
 

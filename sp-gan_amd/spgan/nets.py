@@ -560,6 +560,74 @@ def mlp_backward(P, ctx, dout: Tensor, need_dx: bool = True, need_dparams: bool 
     return d, g, drb
 
 
+def global_feat_forward(P, bufs, a2: Tensor, B: int, N: int, training: bool = True, update_running: bool = True):
+    """cat[global feature repeated over N, a2] materialised, [M, 512+C] (Generator.py:183-189) -- only the --attn variant needs
+    it as a tensor; the default path folds the global half into a per-shape bias of tail.0."""
+    gctx = global_forward(P, bufs, a2, B, N, training, update_running)
+    gact = ops.affine_act(gctx["y3"], gctx["bn3"][0], gctx["bn3"][1], NEG)                       # [B,512]
+    Cg = gact.shape[1]
+    feat = torch.empty((B * N, Cg + a2.shape[1]), dtype=torch.float32, device=a2.device)
+    feat[:, :Cg].view(B, N, Cg).copy_(gact.view(B, 1, Cg).expand(B, N, Cg))
+    feat[:, Cg:].copy_(a2)
+    gctx["Cg"] = Cg
+    return feat, gctx
+
+
+def global_feat_backward(P, gctx, dfeat: Tensor):
+    """-> (da2, {name: grad}) for global_feat_forward."""
+    Cg, N = gctx["Cg"], gctx["N"]
+    da2 = dfeat[:, Cg:].contiguous()
+    dg = ops.colsum(dfeat[:, :Cg], N)                                                            # [B,512]: sum over the shape's points
+    return da2, global_backward(P, gctx, None, dg, da2)
+
+
+def attention_forward(P, pre: str, x: Tensor, B: int, N: int):
+    """`Attention.forward` (Generation/modules.py:549-558) on point-major rows: x [M,C] -> gamma * W_o(beta g) + x with
+    beta_b = softmax_rows(theta_b phi_b^T) per shape.  The [B,N,N] maps are materialised (537 MB at B=32, N=2048: they are kept
+    for the backward pass anyway); the per-shape products are ONE batched gemm_nt launch each (blockIdx.y = shape)."""
+    Wt, Wp, Wg, Wo = (_w2(P[pre + n + ".weight"]) for n in (".theta", ".phi", ".g", ".o"))
+    M = x.shape[0]
+    theta, phi, gv = ops.gemm_nt(x, Wt), ops.gemm_nt(x, Wp), ops.gemm_nt(x, Wg)                  # [M,C/8], [M,C/8], [M,C/2]
+    c8, c2 = theta.shape[1], gv.shape[1]
+    beta = ops.gemm_nt_batched(theta.view(B, N, c8), phi.view(B, N, c8))                         # [B,N,N] scores
+    ops.softmax_rows(beta)
+    o = ops.gemm_nt_batched(beta, ops.pm_to_cm(gv, B, N)).view(M, c2)                            # beta_b . g_b
+    oo = ops.gemm_nt(o, Wo)                                                                      # [M,C]
+    y = ops.scale_residual(oo, x, P[pre + ".gamma"])
+    return y, dict(x=x, theta=theta, phi=phi, g=gv, beta=beta, o=o, oo=oo, B=B, N=N)
+
+
+def attention_backward(P, pre: str, ctx, dy: Tensor, need_dx: bool = True):
+    """-> (dx | None, {name: grad}).  dS = softmax'(dP), d theta = dS phi, d phi = dS^T theta, d g = beta^T d_o per shape; the two
+    transposed products read explicitly transposed maps, so that all five are batched A.W^T launches."""
+    Wt, Wp, Wg, Wo = (_w2(P[pre + n + ".weight"]) for n in (".theta", ".phi", ".g", ".o"))
+    x, theta, phi, gv, beta, o, B, N = (ctx[k] for k in ("x", "theta", "phi", "g", "beta", "o", "B", "N"))
+    dy = dy.contiguous()
+    g: Dict[str, Tensor] = {}
+    d_oo, g[pre + ".gamma"] = ops.scale_residual_bwd(dy, ctx["oo"], P[pre + ".gamma"])
+    g[pre + ".o.weight"] = ops.gemm_tn(d_oo, o).view_as(P[pre + ".o.weight"])
+    d_o = ops.gemm_nt(d_oo, _t(Wo))                                                              # [M,C/2]
+    c8, c2 = theta.shape[1], gv.shape[1]
+    dcat = torch.empty((x.shape[0], 2 * c8 + c2), dtype=torch.float32, device=x.device)         # [d theta | d phi | d g]
+    dcat3 = dcat.view(B, N, 2 * c8 + c2)
+    dS = ops.gemm_nt_batched(d_o.view(B, N, c2), gv.view(B, N, c2))                              # dP [B,N,N]
+    ops.softmax_rows_bwd(beta, dS)
+    ops.gemm_nt_batched(dS, ops.pm_to_cm(phi, B, N), out=dcat3[:, :, :c8])
+    dST = ops.pm_to_cm(dS.view(B * N, N), B, N)
+    del dS
+    ops.gemm_nt_batched(dST, ops.pm_to_cm(theta, B, N), out=dcat3[:, :, c8:2 * c8])
+    del dST
+    ops.gemm_nt_batched(ops.pm_to_cm(beta.view(B * N, N), B, N), ops.pm_to_cm(d_o, B, N), out=dcat3[:, :, 2 * c8:])
+    dW = ops.gemm_tn(dcat, x)                                                                    # [C/8+C/8+C/2, C]
+    for n, lo, hi in ((".theta", 0, c8), (".phi", c8, 2 * c8), (".g", 2 * c8, 2 * c8 + c2)):
+        g[pre + n + ".weight"] = dW[lo:hi].reshape(P[pre + n + ".weight"].shape)
+    dx = None
+    if need_dx:
+        dx = ops.gemm_nt(dcat, _t(torch.cat([Wt, Wp, Wg], 0)))
+        ops.multi_add([dx], [dy])
+    return dx, g
+
+
 def global_forward(P, bufs, a2: Tensor, B: int, N: int, training: bool = True, update_running: bool = True):
     """max over N -> Linear+BN1d+LReLU -> Linear+BN1d+LReLU (Generator.py:119-126,183-186).  Returns the
     second pre-BN tensor and its BN affine (the activation is applied by the consumer's prologue)."""
@@ -571,16 +639,31 @@ def global_forward(P, bufs, a2: Tensor, B: int, N: int, training: bool = True, u
     return dict(gmax=gmax, garg=garg, y0=y0, bn0=bn0, y3=y3, bn3=bn3, B=B, N=N, training=training)
 
 
-def global_backward(P, gctx, W_g: Tensor, drb: Tensor, da2: Tensor):
+_EYE: Dict[Tuple[int, str], Tensor] = {}
+
+
+def _eye(n: int, device) -> Tensor:
+    key = (n, str(device))
+    if key not in _EYE:
+        _EYE[key] = torch.eye(n, dtype=torch.float32, device=device)
+    return _EYE[key]
+
+
+def global_backward(P, gctx, W_g: Optional[Tensor], drb: Tensor, da2: Tensor):
     """drb [B,256] = gradient w.r.t. the per-shape bias of tail.0 (= W_g . lrelu(bn(y3)) + b).
+    W_g None: drb [B,512] is the gradient w.r.t. the global feature lrelu(bn(y3)) itself (--attn: the concat is materialised).
     Adds the max-pool gradient into da2 in place.  -> {name: grad} incl. 'tail.0.weight.global' [256,512]."""
     B = gctx["B"]
     g: Dict[str, Tensor] = {}
     bn0, bn3, y0, y3 = gctx["bn0"], gctx["bn3"], gctx["y0"], gctx["y3"]
     tr = gctx["training"]
-    g["tail.0.weight.global"] = ops.gemm_tn(drb, y3, pro=(bn3[0], bn3[1], NEG))
-    g["tail.0.bias"] = ops.colsum(drb)[0]
-    g3, s0, s1 = ops.gemm_nt_bnbwd(drb, _t(W_g), y3, bn3[0], bn3[1], bn3[3], bn3[2], NEG)
+    if W_g is None:
+        Wg_t = _eye(y3.shape[1], y3.device)
+    else:
+        g["tail.0.weight.global"] = ops.gemm_tn(drb, y3, pro=(bn3[0], bn3[1], NEG))
+        g["tail.0.bias"] = ops.colsum(drb)[0]
+        Wg_t = _t(W_g)
+    g3, s0, s1 = ops.gemm_nt_bnbwd(drb, Wg_t, y3, bn3[0], bn3[1], bn3[3], bn3[2], NEG)
     g["global_conv.4.weight"] = s1; g["global_conv.4.bias"] = s0
     sums = _cat2(s0, s1) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
     dy3 = ops.bn_bwd_apply(g3, y3, bn3[3], bn3[2], P["global_conv.4.weight"], sums, B)

@@ -184,8 +184,10 @@ def _finalize(partials: Tensor, groups: int, tpg: int, Cn: int, G: int, mode: in
 
 
 def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, edge=None, rowbias: Optional[Tensor] = None,
-            rows_per_group: int = 0, act: int = ACT_NONE, slope: float = 0.0, stats: bool = False, M: Optional[int] = None, bn=None):
+            rows_per_group: int = 0, act: int = ACT_NONE, slope: float = 0.0, stats: bool = False, M: Optional[int] = None, bn=None,
+            out: Optional[Tensor] = None):
     """Y[M,N] = act( pro(A) @ W^T + bias + rowbias[m // rows_per_group] ).
+    out  = destination [M,N] (unit column stride; may be a column slice of a wider buffer) instead of a fresh tensor.
     bn = (gamma, beta, running_mean | None, running_var | None): train-mode BatchNorm of Y fused behind the GEMM: returns
          (Y, (scale, shift, invstd, mean)) and updates the running statistics (column statistics in the epilogue + one finalize launch).
     pro  = (scale[K], shift[K], slope): operand a = lrelu(A*scale+shift)            (A_AFFINE_LRELU)
@@ -209,8 +211,13 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
     if pro is not None:
         sc, sh, ps = pro
         a.p_scale = _p(_vec(sc, K, "pro.scale")); a.p_shift = _p(_vec(sh, K, "pro.shift")); a.p_slope = float(ps)
-    Y = torch.empty((M_, N), dtype=torch.float32, device=A.device)
-    a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W); a.Y = _p(Y); a.ldy = N
+    if out is None:
+        Y = torch.empty((M_, N), dtype=torch.float32, device=A.device)
+    else:
+        Y = _rowmajor2d(out, "out")
+        if tuple(Y.shape) != (M_, N):
+            raise ValueError("out must be [%d,%d], got %s" % (M_, N, tuple(Y.shape)))
+    a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W); a.Y = _p(Y); a.ldy = _ld(Y)
     a.M, a.N, a.K = M_, N, K
     a.epi_mode = EPI_LINEAR
     a.bias = _p(_vec(bias, N, "bias"))
@@ -240,6 +247,34 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
         mean, var = _finalize(part, 1, part.shape[0], N, M_, 0)
         return Y, mean[0], var[0]
     return Y
+
+
+def _batched3d(t: Tensor, name: str) -> Tensor:
+    _f32(t, name, 3)
+    if (t.shape[2] > 1 and t.stride(2) != 1) or t.stride(1) < t.shape[2]:
+        raise ValueError("%s must be [batch, rows, cols] with unit column stride, got strides %s" % (name, t.stride()))
+    return t
+
+
+def gemm_nt_batched(A: Tensor, W: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """Y[z] = A[z] @ W[z]^T for z < batch in ONE launch: A [Z,M,K], W [Z,N,K] -> [Z,M,N].  Row and batch strides are free
+    (column slices of wider buffers, or stride 0 to share an operand); `out` may be such a view too."""
+    _batched3d(A, "A"); _batched3d(W, "W")
+    Z, M_, K = A.shape
+    if W.shape[0] != Z or W.shape[2] != K:
+        raise ValueError("A %s and W %s do not form a batched A @ W^T" % (tuple(A.shape), tuple(W.shape)))
+    N = W.shape[1]
+    if out is None:
+        out = torch.empty((Z, M_, N), dtype=torch.float32, device=A.device)
+    elif tuple(_batched3d(out, "out").shape) != (Z, M_, N):
+        raise ValueError("out must be [%d,%d,%d], got %s" % (Z, M_, N, tuple(out.shape)))
+    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]
+    a.A = _p(A); a.lda = A.stride(1); a.W = _p(W); a.ldw = W.stride(1); a.Y = _p(out); a.ldy = out.stride(1)
+    a.M, a.N, a.K = M_, N, K
+    a.a_mode = A_PLAIN; a.epi_mode = EPI_LINEAR; a.act = ACT_NONE
+    a.batch = Z; a.batch_stride_a = A.stride(0); a.batch_stride_w = W.stride(0); a.batch_stride_y = out.stride(0)
+    check(_lib.load().spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_batched", Z=Z, M=M_, N=N, K=K)
+    return out
 
 
 def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float) -> Tensor:
@@ -875,6 +910,50 @@ def gp_penalty_bwd(g: Tensor, norms: Tensor, gamma: float, lam: float, upstream:
     up = None if upstream is None else upstream.reshape(1).contiguous()
     check(_lib.load().spgan_gp_penalty_bwd(_p(g), _p(norms), B, g.numel() // B, float(gamma), float(lam), _p(up), _p(v), _s()), "gp_penalty_bwd")
     return v
+
+
+def softmax_rows(S: Tensor) -> Tensor:
+    """softmax over the last dimension, in place (contiguous [..., cols])."""
+    _f32(S, "S")
+    if not S.is_contiguous():
+        raise ValueError("softmax_rows needs a contiguous tensor")
+    cols = S.shape[-1]
+    check(_lib.load().spgan_softmax_rows(_p(S), S.numel() // max(cols, 1), cols, _s()), "softmax_rows", shape=tuple(S.shape))
+    return S
+
+
+def softmax_rows_bwd(P: Tensor, dP: Tensor) -> Tensor:
+    """dP <- P * (dP - sum_j dP*P) in place: gradient w.r.t. the softmax input, given its output P."""
+    _f32(P, "P"); _f32(dP, "dP")
+    if not (P.is_contiguous() and dP.is_contiguous()) or P.shape != dP.shape:
+        raise ValueError("softmax_rows_bwd needs contiguous tensors of equal shape")
+    cols = P.shape[-1]
+    check(_lib.load().spgan_softmax_rows_bwd(_p(P), _p(dP), P.numel() // max(cols, 1), cols, _s()), "softmax_rows_bwd", shape=tuple(P.shape))
+    return dP
+
+
+def scale_residual(o: Tensor, x: Tensor, gamma: Tensor) -> Tensor:
+    """gamma*o + x with the scalar gamma read on the device."""
+    _f32(o, "o"); _f32(x, "x"); _f32(gamma, "gamma")
+    if not (o.is_contiguous() and x.is_contiguous()) or o.shape != x.shape or o.numel() % 4 or gamma.numel() != 1:
+        raise ValueError("scale_residual: o and x must be contiguous, equal in shape, with a multiple of 4 elements; gamma a scalar")
+    y = torch.empty_like(x)
+    check(_lib.load().spgan_scale_residual(_p(o), _p(x), _p(gamma), _p(y), o.numel(), _s()), "scale_residual", n=o.numel())
+    return y
+
+
+def scale_residual_bwd(dy: Tensor, o: Tensor, gamma: Tensor):
+    """-> (d_o = gamma*dy, dgamma = sum(dy*o) as a 0-d tensor)."""
+    _f32(dy, "dy"); _f32(o, "o"); _f32(gamma, "gamma")
+    if not (o.is_contiguous() and dy.is_contiguous()) or o.shape != dy.shape or o.numel() % 4 or gamma.numel() != 1:
+        raise ValueError("scale_residual_bwd: dy and o must be contiguous, equal in shape, with a multiple of 4 elements")
+    lib = _lib.load()
+    d_o = torch.empty_like(o)
+    dgamma = torch.empty((), dtype=torch.float32, device=o.device)
+    wsb = lib.spgan_scale_residual_bwd_ws_bytes(o.numel())
+    ws = torch.empty((max(wsb // 4, 1),), dtype=torch.float32, device=o.device)
+    check(lib.spgan_scale_residual_bwd(_p(dy), _p(o), _p(gamma), _p(d_o), _p(dgamma), _p(ws), wsb, o.numel(), _s()), "scale_residual_bwd", n=o.numel())
+    return d_o, dgamma
 
 
 def multi_add(dsts, srcs) -> None:

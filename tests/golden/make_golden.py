@@ -478,8 +478,41 @@ def g12():
     save("g12_variants.npz", d)
 
 
+def g13():
+    """--attn (Attention(640) between the concat and the tail) and --eql (equalised-LR head / global_conv): train-mode forward
+    and gradients for an injected upstream, as G12."""
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    z = fr.latent(B, N, seed=130)
+    d = {}
+    for tag, flags, salt in (("attn", dict(attn=True), 30), ("eql", dict(eql=True), 31), ("both", dict(attn=True, eql=True, use_head=True), 32)):
+        O = type("O_" + tag, (Opts,), flags)
+        G = Generator(O)
+        shapes = orc.generator_shapes(use_head=flags.get("use_head", False), attn=flags.get("attn", False), eql=flags.get("eql", False))
+        assert {k: tuple(v.shape) for k, v in G.named_parameters()} == {k: tuple(v) for k, v in shapes.items()}, tag
+        load_into(G, fr.init_params(shapes, salt=salt)).train()
+        stage = {}
+        hooks = [G.adain1.register_forward_hook(lambda m, i, o: stage.__setitem__("x1", o.detach().clone()))]
+        if flags.get("use_head"):
+            hooks.append(G.pc_head.register_forward_hook(lambda m, i, o: stage.__setitem__("feat", o.detach().clone())))
+        out = G(x, z)
+        for h in hooks:
+            h.remove()
+        if flags.get("use_head"):
+            _, idx1 = get_edge_features(stage["feat"], 10, return_idx=True)
+            d[tag + "|idx1"] = idx1.view(B, N, 10).numpy().astype(np.int32)
+        _, idx2 = get_edge_features(stage["x1"], 10, return_idx=True)
+        d[tag + "|idx2"] = idx2.view(B, N, 10).numpy().astype(np.int32)
+        dy = fr.normal("g13.dy." + tag, out.shape)
+        grads = torch.autograd.grad(out, list(G.parameters()), dy)
+        put(d, tag + "|out", out, full_limit=1 << 20)
+        for (n, _), g in zip(G.named_parameters(), grads):
+            put(d, tag + "|grad|" + n, g)
+    save("g13_attn_eql.npz", d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for name in which:
         globals()[name]()

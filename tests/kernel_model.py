@@ -96,7 +96,11 @@ def _operand(A, pro, edge, K):
     return a
 
 
-def gemm_nt(A, W, bias=None, *, pro=None, edge=None, rowbias=None, rows_per_group=0, act=ACT_NONE, slope=0.0, stats=False, M=None, bn=None):
+def gemm_nt(A, W, bias=None, *, pro=None, edge=None, rowbias=None, rows_per_group=0, act=ACT_NONE, slope=0.0, stats=False, M=None, bn=None,
+            out=None):
+    if out is not None:
+        out.copy_(gemm_nt(A, W, bias, pro=pro, edge=edge, rowbias=rowbias, rows_per_group=rows_per_group, act=act, slope=slope, M=M))
+        return out
     if bn is not None:
         y, mean, var = gemm_nt(A, W, bias, pro=pro, edge=edge, rowbias=rowbias, rows_per_group=rows_per_group, act=act, slope=slope, stats=True, M=M)
         gamma, beta, rm, rv = bn
@@ -118,6 +122,14 @@ def gemm_nt(A, W, bias=None, *, pro=None, edge=None, rowbias=None, rows_per_grou
     if stats:
         return y.contiguous(), pre.mean(0), pre.var(0, unbiased=False)
     return y.contiguous()
+
+
+def gemm_nt_batched(A, W, out=None):
+    y = torch.bmm(A, W.transpose(1, 2))
+    if out is None:
+        return y.contiguous()
+    out.copy_(y)
+    return out
 
 
 def gemm_nt_maskout(A, W, ref, slope):
@@ -222,6 +234,24 @@ def bn_dbl_pool(uarg, gval, yarg, pooled, U0, quad, bias, mean, invstd, gamma, S
     return t.contiguous(), spB.contiguous(), out4.contiguous()
 
 
+def softmax_rows(S):
+    S.copy_(torch.softmax(S, -1))
+    return S
+
+
+def softmax_rows_bwd(P, dP):
+    dP.copy_(P * (dP - (dP * P).sum(-1, keepdim=True)))
+    return dP
+
+
+def scale_residual(o, x, gamma):
+    return gamma * o + x
+
+
+def scale_residual_bwd(dy, o, gamma):
+    return gamma * dy, (dy * o).sum()
+
+
 def affine_act(X, scale, shift, slope):
     return _lrelu(X * scale + shift, slope).contiguous()
 
@@ -239,7 +269,7 @@ def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0):
     c = A.t() @ b
     if out is None:
         return c.contiguous()
-    out.copy_(beta * out + c)
+    out.copy_(beta * out + c if beta != 0 else c)          # beta == 0: the destination is not read (it may be uninitialised)
     return out
 
 

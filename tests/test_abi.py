@@ -53,6 +53,8 @@ def test_cpu_tensors_are_refused():
         D(torch.zeros(2, 3, 64))
     with pytest.raises(RuntimeError, match="GPU"):
         spgan.ops.knn(torch.zeros(32, 3), 1, 32, 4)
-    with pytest.raises(NotImplementedError):
-        O.attn = True
-        spgan.Generator(O)
+    O.attn = True; O.eql = True                           # non-default variants construct on the CPU, but run only on the GPU
+    G = spgan.Generator(O)
+    assert "attn.gamma" in G.state_dict() and "head.0.conv.weight_orig" in G.state_dict()
+    with pytest.raises(RuntimeError, match="no CPU"):
+        G(torch.zeros(2, 64, 3), torch.zeros(2, 64, 8))

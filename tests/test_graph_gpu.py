@@ -10,9 +10,10 @@ from test_parity_gpu import Opts, _load, sp  # noqa: F401  (sp is a fixture)
 pytestmark = pytest.mark.gpu
 
 
-def _run(sp, graph, steps, B=4, N=256):
-    o = Opts()
-    G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(), salt=8))
+def _run(sp, graph, steps, B=4, N=256, flags=None):
+    flags = flags or {}
+    o = type("O", (Opts,), flags)()
+    G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(**flags), salt=8))
     D = _load(sp.Discriminator(o), fr.init_params(orc.discriminator_shapes(), salt=8))
     tr = sp.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, graph=graph, graph_warmup=2)
     x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
@@ -39,6 +40,22 @@ def test_graph_replay_equals_eager(sp):
     assert (tre.optG.t, tre.optD.t) == (trg.optG.t, trg.optD.t) == (steps, steps)
     assert torch.equal(tre.optD.m, trg.optD.m) and torch.equal(tre.optG.v, trg.optG.v)
     assert int(trg.optD.dev_state[:1].view(torch.int32).item()) == steps
+
+
+def test_graph_replay_attn_eql_variant(sp):
+    """--attn --eql --use_head through the whole train step: the captured step equals the eager one bit for bit (ScaleFn, the
+    per-shape attention launches and the 0-d gate parameter all live inside the graph), and the gate actually trains."""
+    flags = dict(attn=True, eql=True, use_head=True)
+    steps = 5
+    Ge, De, tre, le = _run(sp, False, steps, flags=flags)
+    Gg, Dg, trg, lg = _run(sp, True, steps, flags=flags)
+    assert trg._graph is not None, "the step was never captured"
+    assert le == lg, (le, lg)
+    assert all(torch.isfinite(torch.tensor(l)).all() for l in le)
+    for (n, a), (_, b) in zip(list(Ge.state_dict().items()) + list(De.state_dict().items()),
+                              list(Gg.state_dict().items()) + list(Dg.state_dict().items())):
+        assert torch.equal(a, b), n
+    assert Gg.attn.gamma.item() != 0.7 and abs(Gg.attn.gamma.item() - 0.7) < 1e-2       # moved by <= steps * lr
 
 
 def test_graph_replay_data_parallel_segments(sp):

@@ -230,3 +230,31 @@ def test_generator_no_grad_and_eval(spgan_cpu):
     idx2 = spgan_cpu.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N)
     ref = orc.generator_forward(p, x, z, training=False, buffers=buf, idx1=idx1, idx2=idx2)
     _cmp("eval out", oe, ref, 1e-4)
+
+
+@pytest.mark.parametrize("flags", [dict(attn=True), dict(eql=True), dict(attn=True, eql=True, use_head=True)])
+def test_generator_attn_eql(spgan_cpu, flags):
+    """--attn / --eql host logic (parameter surface, EqualLR scaling, attention forward/backward composition) on the kernel models."""
+    B, N = 4, 64
+    O = type("O", (Opts,), flags)
+    shapes = orc.generator_shapes(**flags)
+    p = fr.init_params(shapes, salt=41)
+    G = spgan_cpu.modules.Generator(O)
+    assert {k: tuple(v.shape) for k, v in G.named_parameters()} == {k: tuple(v) for k, v in shapes.items()}
+    assert [k for k, _ in G.named_parameters()] == list(shapes.keys()) or set(dict(G.named_parameters())) == set(shapes)
+    _load(G, p).train()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    x = fr.sphere_template(256)[None, :N].repeat(B, 1, 1).contiguous()
+    z = fr.latent(B, N, seed=43)
+    out = G(x, z)
+    idx1 = spgan_cpu.ops.idx_to_local64(G.EdgeConv1.last_idx, B, N)
+    idx2 = spgan_cpu.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N)
+    ref = orc.generator_forward(orc.eql_effective_params(po), x, z, training=True, buffers=orc.bn_buffers(shapes), idx1=idx1, idx2=idx2)
+    _cmp("out", out, ref, 5e-4)
+    dy = fr.normal("hga.dy", out.shape)
+    (out * dy).sum().backward()
+    names = list(po.keys())
+    grads = torch.autograd.grad((ref * dy).sum(), [po[n] for n in names])
+    for n, g in zip(names, grads):
+        plain = n.replace(".linear.", ".").replace(".conv.", ".")
+        _cmp("grad " + n, dict(G.named_parameters())[n].grad, g, 3e-2, atol=2e-3 if plain.endswith(ZERO_GRAD_BIASES) else 1e-7)

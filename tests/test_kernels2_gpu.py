@@ -187,3 +187,56 @@ def test_adam_and_axpby(ops):
     y = rnd("am.y", (n,)); y2 = y.clone()
     ops.axpby(0.5, g, 2.0, y); km.axpby(0.5, g, 2.0, y2)
     close(y, y2, rtol=1e-6)
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 2048), (33, 4096), (17, 1000), (5, 37), (3, 8192)])
+def test_softmax_rows(ops, rows, cols):
+    S = rnd("sm.s.%d.%d" % (rows, cols), (rows, cols)) * 4.0
+    ref = torch.softmax(S.double(), -1)
+    P = ops.softmax_rows(S.clone())
+    assert (P.double() - ref).abs().max().item() <= 2e-7
+    assert (P.sum(-1) - 1).abs().max().item() <= 1e-5
+    dP = rnd("sm.d.%d.%d" % (rows, cols), (rows, cols))
+    want = km.softmax_rows_bwd(P.double(), dP.double().clone())
+    got = ops.softmax_rows_bwd(P, dP.clone())
+    close(got, want.float(), 1e-5)
+
+
+@pytest.mark.parametrize("n", [4, 640 * 256, 640 * 2048 * 3 + 8])
+def test_scale_residual(ops, n):
+    o, x, dy = rnd("sr.o%d" % n, (n,)), rnd("sr.x%d" % n, (n,)), rnd("sr.d%d" % n, (n,))
+    gamma = torch.tensor(0.37, device="cuda")
+    assert (ops.scale_residual(o, x, gamma) - (gamma * o + x)).abs().max().item() <= 1e-6
+    d_o, dg = ops.scale_residual_bwd(dy, o, gamma)
+    close(d_o, gamma * dy, 1e-6)
+    want = (dy.double() * o.double()).sum().item()
+    assert abs(dg.item() - want) <= 1e-5 * max(1.0, abs(want)) + 1e-3 * (n ** 0.5) * 1e-3
+
+
+def test_gemm_nt_into_column_slice(ops):
+    A, W = rnd("gs.a", (300, 96)), rnd("gs.w", (80, 96))
+    buf = torch.full((300, 480), 7.0, device="cuda")
+    ops.gemm_nt(A, W, out=buf[:, 160:240])
+    close(buf[:, 160:240], km.gemm_nt(A, W), 1e-5)
+    assert (buf[:, :160] == 7).all() and (buf[:, 240:] == 7).all()
+    big = rnd("gs.b", (2048, 2048)); th = rnd("gs.t", (2048, 80))
+    out = torch.full((2048, 480), 3.0, device="cuda")
+    ops.gemm_tn(big, th, out=out[:, 80:160])
+    close(out[:, 80:160], (big.double().t() @ th.double()).float(), 2e-5)
+    assert (out[:, :80] == 3).all() and (out[:, 160:] == 3).all()
+
+
+@pytest.mark.parametrize("Z,M,N,K", [(3, 256, 256, 80), (2, 300, 77, 50), (4, 2048, 80, 2048), (2, 40, 320, 64)])
+def test_gemm_nt_batched(ops, Z, M, N, K):
+    A, W = rnd("gb.a%d" % M, (Z, M, K)), rnd("gb.w%d" % M, (Z, N, K))
+    want = torch.bmm(A.double(), W.double().transpose(1, 2)).float()
+    close(ops.gemm_nt_batched(A, W), want, 2e-5)
+    # strided destination (column slice of a wider buffer) and strided operands
+    buf = torch.full((Z, M, N + 24), 5.0, device="cuda")
+    ops.gemm_nt_batched(A, W, out=buf[:, :, 8:8 + N])
+    close(buf[:, :, 8:8 + N], want, 2e-5)
+    assert (buf[:, :, :8] == 5).all() and (buf[:, :, 8 + N:] == 5).all()
+    wide = rnd("gb.wide%d" % M, (Z, M, K + 16))
+    close(ops.gemm_nt_batched(wide[:, :, 8:8 + K], W), torch.bmm(wide[:, :, 8:8 + K].double(), W.double().transpose(1, 2)).float(), 2e-5)
+    # one weight shared by all products (batch stride 0)
+    close(ops.gemm_nt_batched(A, W[:1].expand(Z, N, K)), torch.matmul(A.double(), W[0].double().t()).float(), 2e-5)

@@ -332,3 +332,25 @@ def test_variant_flags():
     check(d, "small|dx", grads[0], rtol=2e-3)
     for n, g in zip(names, grads[1:]):
         check(d, "small|grad|" + n, g, rtol=5e-3, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+
+
+# ---------------------------------------------------------------- G13: --attn / --eql
+@pytest.mark.parametrize("tag,flags,salt", [("attn", dict(attn=True), 30), ("eql", dict(eql=True), 31),
+                                            ("both", dict(attn=True, eql=True, use_head=True), 32)])
+def test_attn_eql_variants(tag, flags, salt):
+    d = golden("g13_attn_eql.npz")
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    z = fr.latent(B, N, seed=130)
+    shapes = orc.generator_shapes(**flags)
+    p = {k: v.clone().requires_grad_(True) for k, v in fr.init_params(shapes, salt=salt).items()}
+    i1 = torch.from_numpy(d[tag + "|idx1"].astype(np.int64)).view(B, N * 10) if flags.get("use_head") else None
+    i2 = torch.from_numpy(d[tag + "|idx2"].astype(np.int64)).view(B, N * 10)
+    out = orc.generator_forward(orc.eql_effective_params(p), x, z, training=True, buffers=orc.bn_buffers(shapes), idx1=i1, idx2=i2)
+    check(d, tag + "|out", out, rtol=2e-5)
+    names = list(p.keys())
+    grads = torch.autograd.grad(out, [p[n] for n in names], fr.normal("g13.dy." + tag, out.shape))
+    for n, g in zip(names, grads):
+        plain = n.replace(".linear.", ".").replace(".conv.", ".")
+        # "both": N(0,1) equalised weights in pc_head + BatchNorm over 4 shapes: the gradients are ill-conditioned
+        check(d, tag + "|grad|" + n, g, rtol=1e-2 if tag == "both" else 3e-3, atol=1e-3 if plain.endswith(ZERO_GRAD_BIASES) else 1e-6)

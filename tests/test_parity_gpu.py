@@ -322,8 +322,8 @@ def _tie_aware_out(sp, G, d, tag, out, x, z, B, N, shapes_kw, salt, **fkw):
     agree = (i2.numpy() == d[tag + "|idx2"]).all(axis=2).mean()
     assert agree >= 0.99, agree
     p = fr.init_params(orc.generator_shapes(**shapes_kw), salt=salt)
-    ref = orc.generator_forward(p, x.cpu(), z.cpu(), training=True, buffers=orc.bn_buffers(orc.generator_shapes(**shapes_kw)),
-                                idx1=i1.view(B, -1), idx2=i2.view(B, -1), **fkw)
+    ref = orc.generator_forward(orc.eql_effective_params(p), x.cpu(), z.cpu(), training=True,
+                                buffers=orc.bn_buffers(orc.generator_shapes(**shapes_kw)), idx1=i1.view(B, -1), idx2=i2.view(B, -1), **fkw)
     assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) <= 2e-4
     return same
 
@@ -401,3 +401,58 @@ def test_discriminator_ragged_n_vs_oracle(sp, B, N, small):
         mine = own[n].grad if own[n].grad is not None else torch.zeros_like(own[n])
         e = rel_l2(mine.cpu().numpy(), g.numpy())
         assert e <= 3e-3 or (mine.cpu() - g).abs().max().item() <= (2e-3 if n.endswith(ZERO_GRAD_BIASES) else 2e-6), "%s %.3e" % (n, e)
+
+
+# ---------------------------------------------------------------- --attn / --eql (G13)
+@pytest.mark.parametrize("tag,flags,salt", [("attn", dict(attn=True), 30), ("eql", dict(eql=True), 31),
+                                            ("both", dict(attn=True, eql=True, use_head=True), 32)])
+def test_generator_attn_eql_golden(sp, tag, flags, salt):
+    d = golden("g13_attn_eql.npz")
+    B, N = 4, 256
+    O = type("O_" + tag, (Opts,), flags)
+    shapes = orc.generator_shapes(**flags)
+    params = fr.init_params(shapes, salt=salt)
+    G = sp.Generator(O)
+    assert list(G.state_dict().keys()) and {k: tuple(v.shape) for k, v in G.named_parameters()} == {k: tuple(v) for k, v in shapes.items()}
+    _load(G, params).train()
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    z = fr.latent(B, N, seed=130).cuda()
+    out = G(x, z)
+    same = _tie_aware_out(sp, G, d, tag, out, x, z, B, N, flags, salt)
+    dy = fr.normal("g13.dy." + tag, out.shape)
+    (out * dy.cuda()).sum().backward()
+    # gradients against the oracle on OUR graphs (always), and against the reference's when the graphs coincide
+    i1 = sp.ops.idx_to_local64(G.EdgeConv1.last_idx, B, N).cpu(); i2 = sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).cpu()
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = orc.generator_forward(orc.eql_effective_params(po), x.cpu(), z.cpu(), training=True, buffers=orc.bn_buffers(shapes), idx1=i1, idx2=i2)
+    grads = dict(zip(po.keys(), torch.autograd.grad((ref * dy).sum(), list(po.values()))))
+    rtol = 6e-2 if tag == "both" else 3e-2
+    for n, p in G.named_parameters():
+        g = grads[n]
+        plain = n.replace(".linear.", ".").replace(".conv.", ".")
+        e = rel_l2(p.grad.cpu().numpy(), g.numpy())
+        assert e <= rtol or (p.grad.cpu() - g).abs().max().item() <= _atol(plain), (n, e)
+        if same:
+            check(d, tag + "|grad|" + n, p.grad, rtol=rtol, atol=_atol(plain))
+
+
+def test_attention_module_fullsize(sp):
+    """Attention(640) at the C2 shape count per shape (N=2048): against the oracle for two shapes, forward and backward."""
+    B, N, ch = 2, 2048, 640
+    A = sp.modules.Attention(ch).cuda()
+    names = ["theta.weight", "phi.weight", "g.weight", "o.weight", "gamma"]
+    params = fr.init_params({"attn." + n: tuple(dict(A.named_parameters())[n].shape) for n in names}, salt=33)
+    A.load_state_dict({n: params["attn." + n] for n in names})
+    x = fr.normal("attn.x", (B, ch, N), 0.5)
+    xg = x.cuda().requires_grad_(True)
+    y = A(xg)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = x.clone().requires_grad_(True)
+    ref = orc.attention(po, "attn", xo)
+    assert rel_l2(y.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-5
+    dy = fr.normal("attn.dy", y.shape)
+    (y * dy.cuda()).sum().backward()
+    grads = torch.autograd.grad((ref * dy).sum(), [xo] + list(po.values()))
+    assert rel_l2(xg.grad.cpu().numpy(), grads[0].numpy()) <= 1e-4
+    for n, g in zip(names, grads[1:]):
+        assert rel_l2(dict(A.named_parameters())[n].grad.cpu().numpy(), g.numpy()) <= 1e-4, n
