@@ -374,6 +374,10 @@ int spgan_chamfer_bwd(const float* xa, const float* xb, int B, int Na, int Nb, c
 /* out[s,r] = mean_i min_j |A[s,i]-Bc[r,j]|^2 + mean_j min_i |A[s,i]-Bc[r,j]|^2 for every pair of clouds A[s] ([S,N,3]) and
  * Bc[r] ([R,M,3]): the all-pairs Chamfer matrix behind MMD-CD / COV-CD / 1-NNA-CD (metrics/evaluation_metrics.py:89-126). */
 int spgan_chamfer_pairs(const float* A, const float* Bc, int S, int R, int N, int M, float* out, spgan_stream_t s);
+/* Occupancy-grid statistics of the JSD metric (metrics/evaluation_metrics.py:247-283, entropy_of_occupancy_grid): cell [S,N] holds
+ * the nearest grid cell of every point (spgan_nn_distance against the grid); counters[g] += points in cell g over all clouds,
+ * bernoulli[g] += clouds with at least one point in g.  Accumulates: the caller zeroes both int32 [G] arrays.  G <= 524288. */
+int spgan_occupancy_counts(const int32_t* cell, int S, int N, int G, int32_t* counters, int32_t* bernoulli, spgan_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * --attn variant: `Attention(640)` between the concat and the tail (Generation/modules.py:534-558,

@@ -602,3 +602,62 @@ def one_nn_accuracy(Mxx: Tensor, Mxy: Tensor, Myy: Tensor, k: int = 1) -> dict:
     tp, fp = (pred * label).sum(), (pred * (1 - label)).sum()
     fn, tn = ((1 - pred) * label).sum(), ((1 - pred) * (1 - label)).sum()
     return {"acc_t": tp / (tp + fn + 1e-10), "acc_f": tn / (tn + fp + 1e-10), "acc": (label == pred).float().mean()}
+
+
+# --------------------------------------------------------------------------- #
+# JSD between occupancy grids (metrics/evaluation_metrics.py:208-322)         #
+# --------------------------------------------------------------------------- #
+def unit_cube_grid_point_cloud(resolution: int, clip_sphere: bool = False):
+    """evaluation_metrics.py:210-229: float32 cell centres i*spacing - 0.5 (x slowest), optionally clipped to |g| <= 0.5."""
+    import numpy as np
+    spacing = 1.0 / float(resolution - 1)
+    ax = (np.arange(resolution, dtype=np.float64) * spacing - 0.5).astype(np.float32)
+    grid = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), axis=-1)
+    if clip_sphere:
+        grid = grid.reshape(-1, 3)
+        grid = grid[np.linalg.norm(grid, axis=1) <= 0.5]
+    return grid, spacing
+
+
+def _np_entropy(p, base=None):
+    import numpy as np
+    p = np.asarray(p, dtype=np.float64)
+    p = p / p.sum()
+    h = -np.sum(np.where(p > 0, p * np.log(np.where(p > 0, p, 1.0)), 0.0))
+    return h / np.log(base) if base else h
+
+
+def entropy_of_occupancy_grid(pclouds, grid_resolution: int, in_sphere: bool = False):
+    """evaluation_metrics.py:247-290 with the k-d tree replaced by an exhaustive float64 search (lowest index on ties).
+    pclouds: numpy [S,N,3].  -> (mean Bernoulli entropy over the cells, grid_counters [G])."""
+    import numpy as np
+    grid = unit_cube_grid_point_cloud(grid_resolution, in_sphere)[0].reshape(-1, 3).astype(np.float64)
+    counters = np.zeros(len(grid)); bern = np.zeros(len(grid))
+    for pc in np.asarray(pclouds, dtype=np.float64):
+        idx = np.empty(len(pc), dtype=np.int64)
+        for lo in range(0, len(pc), 512):
+            d = ((pc[lo:lo + 512, None, :] - grid[None, :, :]) ** 2).sum(-1)
+            idx[lo:lo + 512] = d.argmin(1)
+        np.add.at(counters, idx, 1)
+        bern[np.unique(idx)] += 1
+    n = float(len(pclouds))
+    acc = sum(_np_entropy([g / n, 1.0 - g / n]) for g in bern if g > 0)
+    return acc / len(counters), counters
+
+
+def jensen_shannon_divergence(P, Q):
+    """evaluation_metrics.py:293-312."""
+    import numpy as np
+    P = np.asarray(P, dtype=np.float64); Q = np.asarray(Q, dtype=np.float64)
+    if np.any(P < 0) or np.any(Q < 0):
+        raise ValueError("Negative values.")
+    if len(P) != len(Q):
+        raise ValueError("Non equal size.")
+    P_, Q_ = P / P.sum(), Q / Q.sum()
+    return _np_entropy((P_ + Q_) / 2.0, 2) - (_np_entropy(P_, 2) + _np_entropy(Q_, 2)) / 2.0
+
+
+def jsd_between_point_cloud_sets(sample_pcs, ref_pcs, resolution: int = 28):
+    """evaluation_metrics.py:232-244."""
+    return jensen_shannon_divergence(entropy_of_occupancy_grid(sample_pcs, resolution, True)[1],
+                                     entropy_of_occupancy_grid(ref_pcs, resolution, True)[1])

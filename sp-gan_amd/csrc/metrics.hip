@@ -146,6 +146,35 @@ __global__ __launch_bounds__(256) void chamfer_pairs_kernel(const float* __restr
   if (threadIdx.x == 0) out[(size_t)s * R + r] = total;
 }
 
+
+// Occupancy-grid statistics behind the JSD metric (metrics/evaluation_metrics.py:247-283): cell[s,n] = nearest grid cell of point n
+// of cloud s.  counters[g] += number of points in g, bernoulli[g] += number of clouds with at least one point in g.
+// One workgroup per cloud; the "seen" set is a bitmap in LDS.  Integer atomics only: the result does not depend on the order.
+__global__ __launch_bounds__(256) void occupancy_counts_kernel(const int32_t* __restrict__ cell, int N, int G, int32_t* __restrict__ counters,
+                                                                int32_t* __restrict__ bernoulli) {
+  extern __shared__ unsigned seen[];
+  const int words = (G + 31) >> 5;
+  for (int w = threadIdx.x; w < words; w += blockDim.x) seen[w] = 0u;
+  __syncthreads();
+  const int32_t* c = cell + (size_t)blockIdx.x * N;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const int g = c[n];
+    if (g >= 0 && g < G) {
+      atomicAdd(counters + g, 1);
+      atomicOr(seen + (g >> 5), 1u << (g & 31));
+    }
+  }
+  __syncthreads();
+  for (int w = threadIdx.x; w < words; w += blockDim.x) {
+    unsigned m = seen[w];
+    while (m) {
+      const int b = __ffs(m) - 1;
+      m &= m - 1;
+      atomicAdd(bernoulli + (w << 5) + b, 1);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int spgan_nn_distance(const float* xyz1, const float* xyz2, int B, int N, int M, float* dist, int32_t* idx, spgan_stream_t s_) {
@@ -170,5 +199,12 @@ extern "C" int spgan_chamfer_pairs(const float* A, const float* Bc, int S, int R
     attr_set = true;
   }
   hipLaunchKernelGGL(chamfer_pairs_kernel, dim3(S * R), dim3(256), lds, (hipStream_t)s_, A, Bc, N, M, R, out);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_occupancy_counts(const int32_t* cell, int S, int N, int G, int32_t* counters, int32_t* bernoulli, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(cell && counters && bernoulli && S > 0 && N > 0 && G > 0 && G <= 64 * 1024 * 8);
+  const size_t lds = (size_t)((G + 31) / 32) * sizeof(unsigned);
+  hipLaunchKernelGGL(occupancy_counts_kernel, dim3(S), dim3(256), lds, (hipStream_t)s_, cell, N, G, counters, bernoulli);
   return spgan_launch_status();
 }

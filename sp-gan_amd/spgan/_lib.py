@@ -133,6 +133,7 @@ SIGNATURES = {
     "spgan_nn_distance": (I, [P, P, I, I, I, P, P, P]),
     "spgan_chamfer_bwd": (I, [P, P, I, I, I, P, P, P, P, P, P]),
     "spgan_chamfer_pairs": (I, [P, P, I, I, I, I, P, P]),
+    "spgan_occupancy_counts": (I, [P, I, I, I, P, P, P]),
     "spgan_softmax_rows": (I, [P, C.c_long, I, P]),
     "spgan_softmax_rows_bwd": (I, [P, P, C.c_long, I, P]),
     "spgan_scale_residual": (I, [P, P, P, P, SZ, P]),

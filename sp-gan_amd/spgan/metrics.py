@@ -5,13 +5,18 @@
   pairwise_cd, lgan_mmd_cov, knn,       the CD half of metrics/evaluation_metrics.py:89-208
   compute_all_metrics_cd
 
-The distance searches and the all-pairs Chamfer matrix are HIP kernels (`csrc/metrics.hip`); what remains here are reductions
-over the [S,R] matrices (a few thousand numbers).  The EMD half needs the auction solver of metrics/emd (not built yet).
+  unit_cube_grid_point_cloud, entropy_of_occupancy_grid,     the JSD metric, metrics/evaluation_metrics.py:210-322
+  jensen_shannon_divergence, jsd_between_point_cloud_sets
+
+The distance searches, the all-pairs Chamfer matrix and the occupancy-grid statistics are HIP kernels (`csrc/metrics.hip`); what
+remains here are reductions over the [S,R] matrices and the grid histograms (a few thousand numbers).  The EMD half needs the
+auction solver of metrics/emd (not built yet).
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict
+import math
+from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
@@ -117,6 +122,63 @@ def knn(Mxx: Tensor, Mxy: Tensor, Myy: Tensor, k: int, sqrt: bool = False) -> Di
               "acc_t": s["tp"] / (s["tp"] + s["fn"] + 1e-10), "acc_f": s["tn"] / (s["tn"] + s["fp"] + 1e-10),
               "acc": torch.eq(label, pred).float().mean()})
     return s
+
+
+def unit_cube_grid_point_cloud(resolution: int, clip_sphere: bool = False, device="cuda"):
+    """evaluation_metrics.py:210-229: centres of the resolution^3 cells of the unit cube (float32, i*spacing - 0.5 per axis,
+    x slowest), optionally only those within the sphere of radius 0.5.  -> (grid, spacing); grid is [R,R,R,3] or, clipped, [G,3]."""
+    spacing = 1.0 / float(resolution - 1)
+    ax = (torch.arange(resolution, dtype=torch.float64) * spacing - 0.5).to(torch.float32)        # float64 product stored as float32, as there
+    grid = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1)
+    if clip_sphere:
+        grid = grid.reshape(-1, 3)
+        grid = grid[torch.linalg.norm(grid, dim=1) <= 0.5]
+    return grid.to(device), spacing
+
+
+def _entropy(p: Tensor, base: Optional[float] = None) -> Tensor:
+    """scipy.stats.entropy: normalises, sum(-p log p) with 0 log 0 = 0 (float64)."""
+    p = p.double()
+    p = p / p.sum()
+    h = -(torch.where(p > 0, p * torch.log(torch.where(p > 0, p, torch.ones_like(p))), torch.zeros_like(p))).sum()
+    return h / math.log(base) if base else h
+
+
+def entropy_of_occupancy_grid(pclouds: Tensor, grid_resolution: int, in_sphere: bool = False):
+    """evaluation_metrics.py:247-290: -> (mean Bernoulli entropy of the cell-activation variables, grid_counters [G]).  Every point
+    is assigned to its nearest grid centre by one brute-force search on the GPU (spgan_nn_distance; the reference fits a
+    k-d tree per call), the per-cell point and cloud counts come from spgan_occupancy_counts."""
+    pc = _cloud(pclouds, "pclouds")
+    S, N, _ = pc.shape
+    grid, _ = unit_cube_grid_point_cloud(grid_resolution, in_sphere, pc.device)
+    grid = grid.reshape(-1, 3).contiguous()
+    G = grid.shape[0]
+    _, cell = _nn(pc.view(1, S * N, 3), grid.view(1, G, 3))
+    counters = torch.zeros(G, dtype=torch.int32, device=pc.device)
+    bern = torch.zeros(G, dtype=torch.int32, device=pc.device)
+    check(_lib.load().spgan_occupancy_counts(_p(cell), S, N, G, _p(counters), _p(bern), _s()), "occupancy_counts", S=S, N=N, G=G)
+    p = bern.double() / float(S)
+    q = 1.0 - p
+    h = -(torch.where(p > 0, p * torch.log(p.clamp_min(1e-300)), torch.zeros_like(p)) + torch.where(q > 0, q * torch.log(q.clamp_min(1e-300)), torch.zeros_like(q)))
+    acc = torch.where(bern > 0, h, torch.zeros_like(h)).sum()
+    return acc / G, counters.double()
+
+
+def jensen_shannon_divergence(P: Tensor, Q: Tensor) -> Tensor:
+    """evaluation_metrics.py:293-312 (base-2 entropies)."""
+    if bool((P < 0).any()) or bool((Q < 0).any()):
+        raise ValueError("Negative values.")
+    if P.numel() != Q.numel():
+        raise ValueError("Non equal size.")
+    P_, Q_ = P.double() / P.double().sum(), Q.double() / Q.double().sum()
+    return _entropy((P_ + Q_) / 2.0, 2) - (_entropy(P_, 2) + _entropy(Q_, 2)) / 2.0
+
+
+def jsd_between_point_cloud_sets(sample_pcs: Tensor, ref_pcs: Tensor, resolution: int = 28) -> Tensor:
+    """evaluation_metrics.py:232-244: JSD between the occupancy histograms of two sets of clouds (in the unit sphere of radius 0.5)."""
+    sample_grid_var = entropy_of_occupancy_grid(sample_pcs, resolution, True)[1]
+    ref_grid_var = entropy_of_occupancy_grid(ref_pcs, resolution, True)[1]
+    return jensen_shannon_divergence(sample_grid_var, ref_grid_var)
 
 
 def compute_all_metrics_cd(sample_pcs: Tensor, ref_pcs: Tensor) -> Dict[str, Tensor]:

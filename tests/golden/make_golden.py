@@ -511,8 +511,34 @@ def g13():
     save("g13_attn_eql.npz", d)
 
 
+def g14():
+    """JSD between occupancy grids: the reference functions of metrics/evaluation_metrics.py:210-322 (compiled with `ast`, like
+    G11; they use sklearn's NearestNeighbors and scipy's entropy) on two small sets of clouds scaled into the radius-0.5 sphere."""
+    import warnings
+    from numpy.linalg import norm
+    from scipy.stats import entropy
+    from sklearn.neighbors import NearestNeighbors
+    EM = extract_functions(os.path.join(REF, "metrics/evaluation_metrics.py"),
+                           ["unit_cube_grid_point_cloud", "jsd_between_point_cloud_sets", "entropy_of_occupancy_grid",
+                            "jensen_shannon_divergence", "_jsdiv"],
+                           {"np": np, "norm": norm, "entropy": entropy, "NearestNeighbors": NearestNeighbors, "warnings": warnings})
+    S, R, N = 12, 10, 512
+    smp = np.stack([fr.synthetic_real(1, N, seed=500 + i)[0].numpy() * 0.5 for i in range(S)])
+    ref = np.stack([fr.synthetic_real(1, N, seed=600 + i)[0].numpy() * (0.35 + 0.015 * i) for i in range(R)])
+    d = {}
+    for res in (16, 28):
+        grid, spacing = EM.unit_cube_grid_point_cloud(res, True)
+        d["grid%d" % res] = grid.astype(np.float32); d["spacing%d" % res] = np.float64(spacing)
+        ent, cnt = EM.entropy_of_occupancy_grid(smp, res, True)
+        d["ent%d" % res] = np.float64(ent); d["cnt%d" % res] = cnt.astype(np.int32)
+        d["jsd%d" % res] = np.float64(EM.jsd_between_point_cloud_sets(smp, ref, res))
+    full, _ = EM.unit_cube_grid_point_cloud(6, False)
+    d["grid6_full"] = full.astype(np.float32)
+    save("g14_jsd.npz", d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for name in which:
         globals()[name]()

@@ -64,3 +64,30 @@ def test_pairwise_cd_full_size_properties():
     assert metrics.pairwise_cd(A, A).diagonal().abs().max().item() == 0.0
     d1, d2 = metrics.nn_distance(A[2:3].expand(5, -1, -1).contiguous(), Bc)
     np.testing.assert_allclose((d1.mean(1) + d2.mean(1)).cpu().numpy(), M[2].cpu().numpy(), rtol=1e-5)
+
+
+def test_jsd_occupancy_grid_golden():
+    """JSD metric (evaluation_metrics.py:210-322) on the GPU against the reference's numbers (golden G14) and the oracle."""
+    from test_oracle_golden import _jsd_sets
+    from spgan import metrics as M
+    d = golden("g14_jsd.npz")
+    smp, ref = _jsd_sets()
+    smp_g, ref_g = torch.from_numpy(smp).cuda(), torch.from_numpy(ref).cuda()
+    assert torch.equal(M.unit_cube_grid_point_cloud(6, False)[0].cpu(), torch.from_numpy(d["grid6_full"]))
+    for res in (16, 28):
+        grid, spacing = M.unit_cube_grid_point_cloud(res, True)
+        assert torch.equal(grid.cpu(), torch.from_numpy(d["grid%d" % res])) and spacing == float(d["spacing%d" % res])
+        ent, cnt = M.entropy_of_occupancy_grid(smp_g, res, True)
+        diff = np.abs(cnt.cpu().numpy() - d["cnt%d" % res])
+        assert diff.sum() <= 4, diff.sum()              # fp32 vs fp64 distance near a cell boundary may move single points
+        assert abs(ent.item() - float(d["ent%d" % res])) <= 1e-5
+        jsd = M.jsd_between_point_cloud_sets(smp_g, ref_g, res)
+        assert abs(jsd.item() - float(d["jsd%d" % res])) <= 1e-5, (jsd.item(), float(d["jsd%d" % res]))
+    # size-independent properties at evaluation scale: JSD(P,P) = 0, symmetry, 0 <= JSD <= 1 bit
+    big_a = torch.from_numpy(np.stack([fr.synthetic_real(1, 2048, seed=700 + i)[0].numpy() * 0.5 for i in range(64)])).cuda()
+    big_b = big_a * 0.8
+    assert abs(M.jsd_between_point_cloud_sets(big_a, big_a).item()) <= 1e-12
+    ab, ba = M.jsd_between_point_cloud_sets(big_a, big_b).item(), M.jsd_between_point_cloud_sets(big_b, big_a).item()
+    assert abs(ab - ba) <= 1e-12 and 0.0 < ab <= 1.0
+    _, cnt = M.entropy_of_occupancy_grid(big_a, 28, True)
+    assert int(cnt.sum().item()) == 64 * 2048

@@ -354,3 +354,24 @@ def test_attn_eql_variants(tag, flags, salt):
         plain = n.replace(".linear.", ".").replace(".conv.", ".")
         # "both": N(0,1) equalised weights in pc_head + BatchNorm over 4 shapes: the gradients are ill-conditioned
         check(d, tag + "|grad|" + n, g, rtol=1e-2 if tag == "both" else 3e-3, atol=1e-3 if plain.endswith(ZERO_GRAD_BIASES) else 1e-6)
+
+
+# ---------------------------------------------------------------- G14: JSD between occupancy grids
+def _jsd_sets():
+    S, R, N = 12, 10, 512
+    smp = np.stack([fr.synthetic_real(1, N, seed=500 + i)[0].numpy() * 0.5 for i in range(S)])
+    ref = np.stack([fr.synthetic_real(1, N, seed=600 + i)[0].numpy() * (0.35 + 0.015 * i) for i in range(R)])
+    return smp, ref
+
+
+def test_jsd_occupancy_grid():
+    d = golden("g14_jsd.npz")
+    smp, ref = _jsd_sets()
+    np.testing.assert_array_equal(orc.unit_cube_grid_point_cloud(6, False)[0], d["grid6_full"])
+    for res in (16, 28):
+        grid, spacing = orc.unit_cube_grid_point_cloud(res, True)
+        np.testing.assert_array_equal(grid, d["grid%d" % res]); assert spacing == float(d["spacing%d" % res])
+        ent, cnt = orc.entropy_of_occupancy_grid(smp, res, True)
+        np.testing.assert_array_equal(cnt.astype(np.int32), d["cnt%d" % res])
+        assert abs(ent - float(d["ent%d" % res])) <= 1e-12
+        assert abs(orc.jsd_between_point_cloud_sets(smp, ref, res) - float(d["jsd%d" % res])) <= 1e-12
