@@ -114,7 +114,7 @@ class DiscriminatorFn(Function):
             # create_graph=True and only the input gradient is wanted: differentiable backward
             dx = DiscriminatorBackwardFn.apply(ctx.holder, ctx.dctx, dout, x, *params)
             return (None, dx) + (None,) * len(params)
-        P = dict(zip(names, [p.detach() for p in params]))
+        P = dict(zip(names, [nets.owned(p) for p in params]))
         dx, grads, _ = nets.d_backward(P, ctx.dctx, dout.detach(), need_dx, need_dp, False)
         if grads is None:
             return (None, dx) + (None,) * len(params)
@@ -138,7 +138,7 @@ class DiscriminatorBackwardFn(Function):
         names = ctx.holder.names
         if not ctx.dctx["training"]:
             raise NotImplementedError("double backward through eval-mode BatchNorm is not implemented")
-        P = dict(zip(names, [p.detach() for p in params]))
+        P = dict(zip(names, [nets.owned(p) for p in params]))
         need_x = ctx.needs_input_grad[3]
         grads, dx2 = nets.d_double_backward(P, ctx.dctx, ctx.saved, v.detach(), need_dx=need_x)
         # (holder, dctx, dout, x, *params); the gradient w.r.t. dout is not provided (constant ones in WGAN-GP)
@@ -167,7 +167,7 @@ class EdgeBlockFn(Function):
     def backward(ctx, dout):
         params = ctx.saved_tensors
         h = ctx.holder
-        P = dict(zip(h.names, [p.detach() for p in params]))
+        P = dict(zip(h.names, [nets.owned(p) for p in params]))
         cache = getattr(h, "graph_cache", None)                      # static-sphere graph: CSR built once, reused every step
         if cache is not None and cache.get("csr") is not None:
             csr = cache["csr"]
@@ -210,7 +210,7 @@ class AdaINFn(Function):
     def backward(ctx, dout):
         w, b = ctx.saved_tensors
         pre = ctx.holder.prefix
-        P = {pre + ".style.weight": w.detach(), pre + ".style.bias": b.detach()}
+        P = {pre + ".style.weight": nets.owned(w), pre + ".style.bias": nets.owned(b)}
         need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         dx, ds, g = nets.adain_backward(P, pre, ctx.actx, dout, ctx.needs_input_grad[1], ctx.needs_input_grad[2], need_p)
         return (None, dx, ds) + _deliver((w, b), [g.get(pre + ".style.weight"), g.get(pre + ".style.bias")], ctx.needs_input_grad[3:])
@@ -235,7 +235,7 @@ class MLPFn(Function):
         h = ctx.holder
         P = {}
         for i, n in enumerate(h.names):
-            P[n + ".weight"], P[n + ".bias"] = params[2 * i].detach(), params[2 * i + 1].detach()
+            P[n + ".weight"], P[n + ".bias"] = nets.owned(params[2 * i]), nets.owned(params[2 * i + 1])
         need_p = any(ctx.needs_input_grad[2:])
         dx, g, _ = nets.mlp_backward(P, ctx.mctx, dout, ctx.needs_input_grad[1], need_p)
         out = []
@@ -280,7 +280,7 @@ class GlobalFeatFn(Function):
     @staticmethod
     def backward(ctx, dfeat):
         params = ctx.saved_tensors
-        P = dict(zip(GF_NAMES, [p.detach() for p in params]))
+        P = dict(zip(GF_NAMES, [nets.owned(p) for p in params]))
         da2, g = nets.global_feat_backward(P, ctx.gctx, dfeat.contiguous())
         return (None, da2 if ctx.needs_input_grad[1] else None) + _deliver(params, [g[n] for n in GF_NAMES], ctx.needs_input_grad[2:])
 
@@ -303,7 +303,7 @@ class AttentionFn(Function):
     @staticmethod
     def backward(ctx, dy):
         params = ctx.saved_tensors
-        P = dict(zip(ATTN_NAMES, [p.detach() for p in params]))
+        P = dict(zip(ATTN_NAMES, [nets.owned(p) for p in params]))
         dx, g = nets.attention_backward(P, "attn", ctx.actx, dy, ctx.needs_input_grad[1])
         return (None, dx) + _deliver(params, [g[n] for n in ATTN_NAMES], ctx.needs_input_grad[2:])
 
@@ -336,7 +336,7 @@ class GlobalTailFn(Function):
     @staticmethod
     def backward(ctx, dout):
         params = ctx.saved_tensors
-        P = dict(zip(GT_NAMES, [p.detach() for p in params]))
+        P = dict(zip(GT_NAMES, [nets.owned(p) for p in params]))
         Wt0 = P["tail.0.weight"].view(P["tail.0.weight"].shape[0], -1)
         ctx.mctx["first_weight"] = Wt0[:, ctx.Cg:]
         da2, g, drb = nets.mlp_backward(P, ctx.mctx, dout, True, True)

@@ -31,20 +31,38 @@ def _w2(w: Tensor) -> Tensor:
 _T_CACHE: Dict[Tuple[int, Tuple[int, ...]], tuple] = {}      # (data_ptr, shape) -> (stamp, w^T, weakref to the owning Parameter)
 
 
-def _t(w: Tensor) -> Tensor:
-    """w^T, contiguous.  For (views of) parameters the copy is cached until the weights change: the four backward passes of a
-    D-step transpose the same matrices.  "Changed" = an in-place torch op (version counter) or an optimiser step of
-    spgan.optim.Adam, whose HIP kernel updates the flat buffer behind torch's back and bumps ops.WEIGHTS_EPOCH instead."""
+def owned(p: Tensor) -> Tensor:
+    """p.detach() that remembers which Parameter it came from: the autograd Functions hand detached weights to the backward
+    pipelines, and the transpose cache below needs the owner to know when a cached copy is stale."""
+    d = p.detach()
+    if isinstance(p, torch.nn.Parameter):
+        d._spgan_owner = weakref.ref(p)
+    return d
+
+
+def _owner(w: Tensor):
     base = w._base if w._base is not None else w
-    if not isinstance(base, torch.nn.Parameter):
+    if isinstance(base, torch.nn.Parameter):
+        return base
+    ref = getattr(base, "_spgan_owner", None)
+    return ref() if ref is not None else None
+
+
+def _t(w: Tensor) -> Tensor:
+    """w^T, contiguous.  For (views of) parameters -- or of their `owned()` detached aliases -- the copy is cached until the
+    weights change: the backward passes of a D-step transpose the same matrices five times.  "Changed" = an in-place torch op
+    (version counter, shared by detached aliases) or an optimiser step of spgan.optim.Adam, whose HIP kernel updates the flat
+    buffer behind torch's back and bumps ops.WEIGHTS_EPOCH instead."""
+    owner = _owner(w)
+    if owner is None:
         return w.t().contiguous()
     key = (w.data_ptr(), tuple(w.shape))
-    stamp = (ops.WEIGHTS_EPOCH[0], base._version)
+    stamp = (ops.WEIGHTS_EPOCH[0], owner._version)
     hit = _T_CACHE.get(key)
-    if hit is not None and hit[0] == stamp and hit[2]() is base:     # same live Parameter object (not a new one at a recycled address)
+    if hit is not None and hit[0] == stamp and hit[2]() is owner:    # same live Parameter object (not a new one at a recycled address)
         return hit[1]
     t = w.t().contiguous()
-    _T_CACHE[key] = (stamp, t, weakref.ref(base))
+    _T_CACHE[key] = (stamp, t, weakref.ref(owner))
     return t
 
 

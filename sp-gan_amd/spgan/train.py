@@ -163,6 +163,7 @@ class TrainStep:
             self._graph[1].replay()
             self.dpG.allreduce_grads()
             self._graph[2].replay()
+        ops.WEIGHTS_EPOCH[0] += 2                  # both networks were updated by the replayed Adam kernels: host-side weight caches are stale
         for m, d in zip(self._bn_modules(), self._bn_delta):
             store = m.__dict__.setdefault("_bn_pending", {})
             for pre, pend in d.items():
