@@ -148,6 +148,9 @@ typedef struct spgan_gemm_tn_args {
   /* Optional prologue on A (per column of A): a = A*a_scale[c] + a_shift[c] + (a_sp_arg[b,c]==m ? a_sp_val[b,c] : 0), b = m / a_sp_rows.
    * a_scale == NULL: A is used as is. */
   const float* a_scale; const float* a_shift; const float* a_sp_val; const int32_t* a_sp_arg; int a_sp_rows;
+  /* 1: only write the split partials into ws; the caller finishes C = beta*C + sum(partials) later with
+   * spgan_splitk_reduce_multi (one launch for all the weight gradients of a backward pass).  Not with a_sp_val.  Default 0. */
+  int defer_reduce;
 } spgan_gemm_tn_args;
 
 size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb);
@@ -351,6 +354,18 @@ typedef struct spgan_multi_add_args {
   int n[SPGAN_MULTI_MAX];
 } spgan_multi_add_args;
 int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s);
+/* Finish up to SPGAN_MULTI_MAX deferred spgan_gemm_tn products in one launch: C[e] = beta[e]*C[e] + fixed-order sum of the
+ * splits[e] = spgan_gemm_tn_splits(M,Na,Nb) partials [splits, Na, Nb] in ws[e].  block_start[e] = sum_{f<e} ceil(Na[f]*Nb[f]/64). */
+typedef struct spgan_splitk_multi_args {
+  int count;
+  const float* ws[SPGAN_MULTI_MAX];
+  float* C[SPGAN_MULTI_MAX];
+  int splits[SPGAN_MULTI_MAX], Na[SPGAN_MULTI_MAX], Nb[SPGAN_MULTI_MAX], ldc[SPGAN_MULTI_MAX];
+  float beta[SPGAN_MULTI_MAX];
+  int block_start[SPGAN_MULTI_MAX + 1];
+} spgan_splitk_multi_args;
+int spgan_gemm_tn_splits(int M, int Na, int Nb);
+int spgan_splitk_reduce_multi(const spgan_splitk_multi_args* a, spgan_stream_t s);
 /* y = a*x + b*y */
 int spgan_axpby(float a, const float* x, float b, float* y, size_t n, spgan_stream_t s);
 /* torch.optim.Adam step on a flat buffer (Generation/model.py:94-97: lr 1e-4, betas (0.5,0.99)); g is scaled by grad_scale first */

@@ -1022,6 +1022,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// The same reduction for up to SPGAN_MULTI_MAX pending products in one launch (spgan_splitk_reduce_multi): block b serves
+// entry e with start[e] <= b < start[e+1].
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const spgan_splitk_multi_args a) {
+  __shared__ float red[4][64];
+  int e = 0;
+  while (e + 1 < a.count && (int)blockIdx.x >= a.block_start[e + 1]) ++e;
+  const float* __restrict__ ws = a.ws[e];
+  const int splits = a.splits[e], Na = a.Na[e], Nb = a.Nb[e], ldc = a.ldc[e];
+  const float beta = a.beta[e];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = ((int)blockIdx.x - a.block_start[e]) * 64 + lane;
+  const size_t stride = (size_t)Na * Nb;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < Na * Nb) {
+    int k = sl;
+    for (; k + 4 < splits; k += 8) {
+      s0 += ws[(size_t)k * stride + i];
+      s1 += ws[(size_t)(k + 4) * stride + i];
+    }
+    if (k < splits) s0 += ws[(size_t)k * stride + i];
+  }
+  red[sl][lane] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && i < Na * Nb) {
+    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int r = i / Nb, c = i % Nb;
+    float* o = a.C[e] + (size_t)r * ldc + c;
+    *o = (beta == 0.f) ? s : fmaf(beta, *o, s);
+  }
+}
+
 inline int tn_tb(int Nb) { return Nb > 64 ? 128 : (Nb > 32 ? 64 : 32); }
 
 // Split choice: about two workgroups per CU in total, at least 256 m-rows each.
@@ -1052,7 +1083,8 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 2, 0>), grid, dim3(256), 0, s, a, rows);
   }
   const int n = a.Na * a.Nb;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
+  if (!a.defer_reduce)  // deferred: the caller sums the partials later, batched with others (spgan_splitk_reduce_multi)
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
   if constexpr (BMODE != SPGAN_A_EDGE) {
     if (a.a_sp_val) hipLaunchKernelGGL((tn_sparse_rows_kernel<BMODE>), dim3(a.Na), dim3(256), 0, s, a);
   }
@@ -1131,8 +1163,26 @@ extern "C" size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb) {
   return (size_t)splits * Na * Nb * sizeof(float);
 }
 
+extern "C" int spgan_gemm_tn_splits(int M, int Na, int Nb) {
+  if (M <= 0 || Na <= 0 || Nb <= 0) return 0;
+  int splits, rows;
+  tn_plan(M, Na, Nb, &splits, &rows);
+  return splits;
+}
+
+extern "C" int spgan_splitk_reduce_multi(const spgan_splitk_multi_args* a, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && a->count > 0 && a->count <= SPGAN_MULTI_MAX && a->block_start[0] == 0);
+  for (int e = 0; e < a->count; ++e) {
+    SPGAN_CHECK_ARG(a->ws[e] && a->C[e] && a->splits[e] > 0 && a->Na[e] > 0 && a->Nb[e] > 0 && a->ldc[e] >= a->Nb[e]);
+    SPGAN_CHECK_ARG(a->block_start[e + 1] - a->block_start[e] == cdiv((long)a->Na[e] * a->Nb[e], 64));
+  }
+  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(a->block_start[a->count]), dim3(256), 0, (hipStream_t)s_, *a);
+  return spgan_launch_status();
+}
+
 extern "C" int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
+  SPGAN_CHECK_ARG(a && !(a->defer_reduce && a->a_sp_val));
   SPGAN_CHECK_ARG(a && a->A && a->B && a->C && a->ws && a->M > 0 && a->Na > 0 && a->Nb > 0);
   SPGAN_CHECK_ARG(a->lda >= a->Na && a->ldb >= a->Nb && a->ldc >= a->Nb);
   SPGAN_CHECK_ARG(a->ws_bytes >= spgan_gemm_tn_ws_bytes(a->M, a->Na, a->Nb));

@@ -52,6 +52,7 @@ class GemmTNArgs(C.Structure):
         ("beta", C.c_float),
         ("ws", c_f32p), ("ws_bytes", C.c_size_t),
         ("a_scale", c_f32p), ("a_shift", c_f32p), ("a_sp_val", c_f32p), ("a_sp_arg", c_i32p), ("a_sp_rows", C.c_int),
+        ("defer_reduce", C.c_int),
     ]
 
 
@@ -60,6 +61,12 @@ MULTI_MAX = 64
 
 class MultiAddArgs(C.Structure):
     _fields_ = [("count", C.c_int), ("dst", C.c_void_p * MULTI_MAX), ("src", C.c_void_p * MULTI_MAX), ("n", C.c_int * MULTI_MAX)]
+
+
+class SplitKMultiArgs(C.Structure):
+    _fields_ = [("count", C.c_int), ("ws", C.c_void_p * MULTI_MAX), ("C", C.c_void_p * MULTI_MAX),
+                ("splits", C.c_int * MULTI_MAX), ("Na", C.c_int * MULTI_MAX), ("Nb", C.c_int * MULTI_MAX), ("ldc", C.c_int * MULTI_MAX),
+                ("beta", C.c_float * MULTI_MAX), ("block_start", C.c_int * (MULTI_MAX + 1))]
 
 
 I, F, P, SZ = C.c_int, C.c_float, C.c_void_p, C.c_size_t
@@ -140,6 +147,8 @@ SIGNATURES = {
     "spgan_scale_residual_bwd_ws_bytes": (SZ, [SZ]),
     "spgan_scale_residual_bwd": (I, [P, P, P, P, P, P, SZ, SZ, P]),
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
+    "spgan_gemm_tn_splits": (I, [I, I, I]),
+    "spgan_splitk_reduce_multi": (I, [C.POINTER(SplitKMultiArgs), P]),
     "spgan_axpby": (I, [F, P, F, P, SZ, P]),
     "spgan_adam_step": (I, [P, P, P, P, SZ, F, F, F, F, I, F, P]),
     "spgan_adam_step_dev": (I, [P, P, P, P, SZ, F, F, F, F, P, F, P]),

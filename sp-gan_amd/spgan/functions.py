@@ -41,6 +41,7 @@ def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool]):
     launch (spgan_multi_add) and return None: the same sums AccumulateGrad would form with one elementwise launch per parameter
     tensor (and on the launch stream, which keeps the step capturable as a hipGraph).  Non-leaf "parameters" (the scaled weights of
     equalised-LR layers) get their gradient returned.  Exact-zero gradients (nets.ZERO_GRAD) cost nothing on the fused path."""
+    ops.flush_tn()                     # weight gradients whose split-K sums were deferred (ops.gemm_tn(defer=True)) become valid here
     fused = FUSED_GRAD_ACCUMULATION and not torch.is_grad_enabled()
     out: List[Optional[Tensor]] = [None] * len(params)
     pairs = []
@@ -342,5 +343,6 @@ class GlobalTailFn(Function):
         da2, g, drb = nets.mlp_backward(P, ctx.mctx, dout, True, True)
         gg = nets.global_backward(P, ctx.gctx, Wt0[:, :ctx.Cg], drb, da2)
         g.update({k: v for k, v in gg.items() if k != "tail.0.weight.global"})
+        ops.flush_tn()                 # the per-point half of tail.0's weight gradient was deferred
         g["tail.0.weight"] = torch.cat([gg["tail.0.weight.global"], g.pop("tail.0.weight.part")], dim=1).view_as(P["tail.0.weight"])
         return (None, da2 if ctx.needs_input_grad[1] else None) + _deliver(params, [g[n] for n in GT_NAMES], ctx.needs_input_grad[2:])

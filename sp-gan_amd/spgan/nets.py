@@ -196,7 +196,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
     for li in (3, 2, 1, 0):
         name = D_MLP[li]
         if need_dparams:
-            grads[name + ".weight"] = ops.gemm_tn(d, acts[li])
+            grads[name + ".weight"] = ops.gemm_tn(d, acts[li], defer=True)
             grads[name + ".bias"] = ops.colsum(d)[0]
         Wt = _t(P[name + ".weight"])
         if li > 0:
@@ -249,9 +249,9 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             continue
         if need_dparams:
             if li > 0:
-                grads[conv + ".weight"] = ops.gemm_tn(dy, ys[li - 1], pro=(bns[li - 1][0], bns[li - 1][1], NEG)).view_as(P[conv + ".weight"])
+                grads[conv + ".weight"] = ops.gemm_tn(dy, ys[li - 1], pro=(bns[li - 1][0], bns[li - 1][1], NEG), defer=True).view_as(P[conv + ".weight"])
             else:
-                grads[conv + ".weight"] = ops.gemm_tn(dy, ctx["x_pm"]).view_as(P[conv + ".weight"])
+                grads[conv + ".weight"] = ops.gemm_tn(dy, ctx["x_pm"], defer=True).view_as(P[conv + ".weight"])
             grads[conv + ".bias"] = ZERO_GRAD     # bias before a train-mode BN: exactly zero gradient
             if not ctx["training"]:
                 grads[conv + ".bias"] = ops.colsum(dy)[0]
@@ -376,7 +376,7 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
     acts = [pooled, hs[0], hs[1], hs[2]]
     for li in (0, 1, 2, 3):
         name = D_MLP[li]
-        grads[name + ".weight"] = ops.gemm_tn(dhs[li], t)                        # (grad wrt pre-act of layer li)^T . adjoint
+        grads[name + ".weight"] = ops.gemm_tn(dhs[li], t, defer=True)                        # (grad wrt pre-act of layer li)^T . adjoint
         grads[name + ".bias"] = ZERO_GRAD
         if li < 3:
             t = ops.gemm_nt_maskout(t, P[name + ".weight"], hs[li], NEG)
@@ -483,7 +483,7 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     # conv_w.4 BN backward -> conv_w.3
     dh2 = ops.bn_bwd_apply(g2, ctx["h2pre"], bn2[3], bn2[2], P[pre + ".conv_w.4.weight"], sums2, E)
     W2 = _w2(P[pre + ".conv_w.3.weight"])
-    g[pre + ".conv_w.3.weight"] = ops.gemm_tn(dh2, PQR[:, :H], pro=(bn1[0], bn1[1], NEG), edge=(idx, b1)).view_as(P[pre + ".conv_w.3.weight"])
+    g[pre + ".conv_w.3.weight"] = ops.gemm_tn(dh2, PQR[:, :H], pro=(bn1[0], bn1[1], NEG), edge=(idx, b1), defer=True).view_as(P[pre + ".conv_w.3.weight"])
     g[pre + ".conv_w.3.bias"] = ZERO_GRAD if ctx["training"] else ops.colsum(dh2)[0]
     g1, s10, s11 = ops.gemm_nt_bnbwd(dh2, _t(W2), PQR[:, :H], bn1[0], bn1[1], bn1[3], bn1[2], NEG, edge=(idx, b1))
     g[pre + ".conv_w.1.weight"] = s11; g[pre + ".conv_w.1.bias"] = s10
@@ -518,7 +518,7 @@ def adain_backward(P, pre: str, ctx, dout: Tensor, need_dx: bool = True, need_ds
     dx, dgb = ops.adain_bwd(dout.contiguous(), ctx["x"], ctx["N"], ctx["slope"], ctx["imean"], ctx["ivar"], ctx["gb"])
     g = {}
     if need_dparams:
-        g[pre + ".style.weight"] = ops.gemm_tn(dgb, ctx["style"]).view_as(P[pre + ".style.weight"])
+        g[pre + ".style.weight"] = ops.gemm_tn(dgb, ctx["style"], defer=True).view_as(P[pre + ".style.weight"])
         g[pre + ".style.bias"] = ops.colsum(dgb)[0]
     dstyle = ops.gemm_nt(dgb, _t(_w2(P[pre + ".style.weight"]))) if need_dstyle else None
     return (dx if need_dx else None), dstyle, g
@@ -555,7 +555,7 @@ def mlp_backward(P, ctx, dout: Tensor, need_dx: bool = True, need_dparams: bool 
         first_part = i == 0 and ctx["first_weight"] is not None
         W = ctx["first_weight"] if first_part else _w2(P[names[i] + ".weight"])
         if need_dparams:
-            gw = ops.gemm_tn(d, inp)
+            gw = ops.gemm_tn(d, inp, defer=True)
             if first_part:
                 g[names[i] + ".weight.part"] = gw
             else:
@@ -623,7 +623,7 @@ def attention_backward(P, pre: str, ctx, dy: Tensor, need_dx: bool = True):
     dy = dy.contiguous()
     g: Dict[str, Tensor] = {}
     d_oo, g[pre + ".gamma"] = ops.scale_residual_bwd(dy, ctx["oo"], P[pre + ".gamma"])
-    g[pre + ".o.weight"] = ops.gemm_tn(d_oo, o).view_as(P[pre + ".o.weight"])
+    g[pre + ".o.weight"] = ops.gemm_tn(d_oo, o, defer=True).view_as(P[pre + ".o.weight"])
     d_o = ops.gemm_nt(d_oo, _t(Wo))                                                              # [M,C/2]
     c8, c2 = theta.shape[1], gv.shape[1]
     dcat = torch.empty((x.shape[0], 2 * c8 + c2), dtype=torch.float32, device=x.device)         # [d theta | d phi | d g]
@@ -636,7 +636,7 @@ def attention_backward(P, pre: str, ctx, dy: Tensor, need_dx: bool = True):
     ops.gemm_nt_batched(dST, ops.pm_to_cm(theta, B, N), out=dcat3[:, :, c8:2 * c8])
     del dST
     ops.gemm_nt_batched(ops.pm_to_cm(beta.view(B * N, N), B, N), ops.pm_to_cm(d_o, B, N), out=dcat3[:, :, 2 * c8:])
-    dW = ops.gemm_tn(dcat, x)                                                                    # [C/8+C/8+C/2, C]
+    dW = ops.gemm_tn(dcat, x, defer=True)                                                                    # [C/8+C/8+C/2, C]
     for n, lo, hi in ((".theta", 0, c8), (".phi", c8, 2 * c8), (".g", 2 * c8, 2 * c8 + c2)):
         g[pre + n + ".weight"] = dW[lo:hi].reshape(P[pre + n + ".weight"].shape)
     dx = None
@@ -685,13 +685,13 @@ def global_backward(P, gctx, W_g: Optional[Tensor], drb: Tensor, da2: Tensor):
     g["global_conv.4.weight"] = s1; g["global_conv.4.bias"] = s0
     sums = _cat2(s0, s1) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
     dy3 = ops.bn_bwd_apply(g3, y3, bn3[3], bn3[2], P["global_conv.4.weight"], sums, B)
-    g["global_conv.3.weight"] = ops.gemm_tn(dy3, y0, pro=(bn0[0], bn0[1], NEG))
+    g["global_conv.3.weight"] = ops.gemm_tn(dy3, y0, pro=(bn0[0], bn0[1], NEG), defer=True)
     g["global_conv.3.bias"] = ZERO_GRAD if tr else ops.colsum(dy3)[0]
     g0, s0, s1 = ops.gemm_nt_bnbwd(dy3, _t(P["global_conv.3.weight"]), y0, bn0[0], bn0[1], bn0[3], bn0[2], NEG)
     g["global_conv.1.weight"] = s1; g["global_conv.1.bias"] = s0
     sums = _cat2(s0, s1) if tr else torch.zeros(2 * s0.numel(), device=s0.device)
     dy0 = ops.bn_bwd_apply(g0, y0, bn0[3], bn0[2], P["global_conv.1.weight"], sums, B)
-    g["global_conv.0.weight"] = ops.gemm_tn(dy0, gctx["gmax"])
+    g["global_conv.0.weight"] = ops.gemm_tn(dy0, gctx["gmax"], defer=True)
     g["global_conv.0.bias"] = ZERO_GRAD if tr else ops.colsum(dy0)[0]
     dgmax = ops.gemm_nt(dy0, _t(P["global_conv.0.weight"]))
     ops.maxpool_bwd_add(dgmax, gctx["garg"], da2)

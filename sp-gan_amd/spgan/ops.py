@@ -382,9 +382,35 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
     return g, s0[0], s1[0]
 
 
-def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor] = None, beta: float = 0.0) -> Tensor:
+_PENDING_TN: list = []      # deferred split-K reductions: (ws, out, splits, Na, Nb, ldc, beta); see gemm_tn(defer=True) / flush_tn()
+
+
+def flush_tn() -> None:
+    """Finish every gemm_tn(defer=True) product issued so far: one launch per 64 pending products."""
+    if not _PENDING_TN:
+        return
+    from ._lib import MULTI_MAX, SplitKMultiArgs
+    lib = _lib.load()
+    pend = list(_PENDING_TN)
+    _PENDING_TN.clear()
+    for i0 in range(0, len(pend), MULTI_MAX):
+        chunk = pend[i0:i0 + MULTI_MAX]
+        a = SplitKMultiArgs()
+        a.count = len(chunk)
+        start = 0
+        for e, (ws, out, splits, Na, Nb, ldc, beta) in enumerate(chunk):
+            a.ws[e] = ws.data_ptr(); a.C[e] = out.data_ptr(); a.splits[e] = splits; a.Na[e] = Na; a.Nb[e] = Nb; a.ldc[e] = ldc; a.beta[e] = beta
+            a.block_start[e] = start
+            start += (Na * Nb + 63) // 64
+        a.block_start[len(chunk)] = start
+        check(lib.spgan_splitk_reduce_multi(C.byref(a), _s()), "splitk_reduce_multi", count=len(chunk))
+
+
+def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor] = None, beta: float = 0.0, defer: bool = False) -> Tensor:
     """C[Na,Nb] = beta*C + A^T @ pro(Bm): weight gradient, reduction over the M rows (points or edges).
-    A may be a SparseAffine operand (evaluated on load)."""
+    A may be a SparseAffine operand (evaluated on load).
+    defer=True: the returned tensor is NOT valid until flush_tn() ran -- the split-K partial sums of all the weight gradients of a
+    backward pass are then finished by one launch (functions._deliver flushes before it hands gradients on)."""
     sa = A if isinstance(A, SparseAffine) else None
     if sa is not None:
         A = sa.y
@@ -419,7 +445,11 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     a.A = _p(A); a.lda = _ld(A); a.B = _p(Bm); a.ldb = _ld(Bm); a.C = _p(out); a.ldc = _ld(out)
     a.M, a.Na, a.Nb = M_, Na, Nb
     a.beta = float(beta); a.ws = _p(ws); a.ws_bytes = wsb
+    defer = bool(defer) and sa is None
+    a.defer_reduce = 1 if defer else 0
     check(lib.spgan_gemm_tn(C.byref(a), _s()), "gemm_tn", M=M_, Na=Na, Nb=Nb)
+    if defer:
+        _PENDING_TN.append((ws, out, lib.spgan_gemm_tn_splits(M_, Na, Nb), Na, Nb, _ld(out), float(beta)))
     return out
 
 

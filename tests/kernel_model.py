@@ -263,7 +263,11 @@ def rowscale_outer(X, a, b=None, d=None, v=None):
     return out.contiguous()
 
 
-def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0):
+def flush_tn():
+    pass
+
+
+def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0, defer=False):
     A = _dense(A)
     b = _operand(Bm, pro, edge, Bm.shape[1])
     c = A.t() @ b

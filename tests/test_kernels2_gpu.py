@@ -240,3 +240,22 @@ def test_gemm_nt_batched(ops, Z, M, N, K):
     close(ops.gemm_nt_batched(wide[:, :, 8:8 + K], W), torch.bmm(wide[:, :, 8:8 + K].double(), W.double().transpose(1, 2)).float(), 2e-5)
     # one weight shared by all products (batch stride 0)
     close(ops.gemm_nt_batched(A, W[:1].expand(Z, N, K)), torch.matmul(A.double(), W[0].double().t()).float(), 2e-5)
+
+
+def test_gemm_tn_deferred_reduce(ops):
+    """gemm_tn(defer=True) + flush_tn(): one batched launch finishes several weight gradients bit-identically to the immediate path."""
+    shapes = [(65536, 256, 128), (4096, 64, 3), (1000, 100, 36), (32, 512, 1024), (20480, 128, 640)]
+    now, later = [], []
+    for i, (M, Na, Nb) in enumerate(shapes):
+        A, B = rnd("dt.a%d" % i, (M, Na)), rnd("dt.b%d" % i, (M, Nb))
+        now.append(ops.gemm_tn(A, B))
+        later.append(ops.gemm_tn(A, B, defer=True))
+    acc0 = rnd("dt.acc", (256, 128)); acc1 = acc0.clone()
+    A, B = rnd("dt.a0", (65536, 256)), rnd("dt.b0", (65536, 128))
+    ops.gemm_tn(A, B, out=acc0, beta=1.0)
+    ops.gemm_tn(A, B, out=acc1, beta=1.0, defer=True)
+    ops.flush_tn()
+    ops.flush_tn()                                                   # idempotent
+    for a, b in zip(now, later):
+        assert torch.equal(a, b)
+    assert torch.equal(acc0, acc1)
