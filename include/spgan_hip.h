@@ -394,6 +394,19 @@ int spgan_chamfer_pairs(const float* A, const float* Bc, int S, int R, int N, in
  * bernoulli[g] += clouds with at least one point in g.  Accumulates: the caller zeroes both int32 [G] arrays.  G <= 524288. */
 int spgan_occupancy_counts(const int32_t* cell, int S, int N, int G, int32_t* counters, int32_t* bernoulli, spgan_stream_t s);
 
+/* Approximate earth mover's distance by a synchronous auction: the algorithm of the reference's emd module
+ * (metrics/emd/emd_cuda.cu:93-236 behind metrics/CD_EMD/emd_/emd_module.py:33-75: `emd.forward(xyz1, xyz2, dist, assignment, price,
+ * assignment_inv, bid, bid_increments, max_increments, ..., eps, iters)`), with the scratch arrays folded into one workspace and a
+ * timing-independent winner rule (highest increment, lowest bidder index).  xyz1/xyz2 [B,n,3] (coordinates normalised to [0,1] as
+ * there); dist [B,n] = squared distance of every point of xyz1 to its assigned point, assignment [B,n] = that point's index in
+ * xyz2[b] (not guaranteed to be a bijection when `iters` ends before the auction does).  Any n (the reference: n % 1024 == 0). */
+size_t spgan_emd_ws_bytes(int B, int n);
+int spgan_emd_forward(const float* xyz1, const float* xyz2, int B, int n, float eps, int iters, float* dist, int32_t* assignment,
+                      void* ws, size_t ws_bytes, spgan_stream_t s);
+/* grad_xyz1[b,i] = 2*grad_dist[b,i]*(xyz1[b,i] - xyz2[b,assignment[b,i]]) (emd_cuda.cu:279-313; xyz2 receives no gradient there) */
+int spgan_emd_backward(const float* xyz1, const float* xyz2, int B, int n, const float* grad_dist, const int32_t* assignment,
+                       float* grad_xyz1, spgan_stream_t s);
+
 /* ------------------------------------------------------------------------------------------
  * --attn variant: `Attention(640)` between the concat and the tail (Generation/modules.py:534-558,
  * Generator.py:116-117,191-192).  The projections and the per-shape [N,N] contractions are spgan_gemm_nt / spgan_gemm_tn

@@ -141,6 +141,9 @@ SIGNATURES = {
     "spgan_chamfer_bwd": (I, [P, P, I, I, I, P, P, P, P, P, P]),
     "spgan_chamfer_pairs": (I, [P, P, I, I, I, I, P, P]),
     "spgan_occupancy_counts": (I, [P, I, I, I, P, P, P]),
+    "spgan_emd_ws_bytes": (SZ, [I, I]),
+    "spgan_emd_forward": (I, [P, P, I, I, F, I, P, P, P, SZ, P]),
+    "spgan_emd_backward": (I, [P, P, I, I, P, P, P, P]),
     "spgan_softmax_rows": (I, [P, C.c_long, I, P]),
     "spgan_softmax_rows_bwd": (I, [P, P, C.c_long, I, P]),
     "spgan_scale_residual": (I, [P, P, P, P, SZ, P]),

@@ -8,9 +8,14 @@
   unit_cube_grid_point_cloud, entropy_of_occupancy_grid,     the JSD metric, metrics/evaluation_metrics.py:210-322
   jensen_shannon_divergence, jsd_between_point_cloud_sets
 
-The distance searches, the all-pairs Chamfer matrix and the occupancy-grid statistics are HIP kernels (`csrc/metrics.hip`); what
-remains here are reductions over the [S,R] matrices and the grid histograms (a few thousand numbers).  The EMD half needs the
-auction solver of metrics/emd (not built yet).
+  emdFunction / emdModule                the auction EMD of metrics/CD_EMD/emd_/emd_module.py:33-85 (over emd_cuda.cu)
+  emd_approx, pairwise_emd, EMD_CD,      the EMD half of metrics/evaluation_metrics.py:26-35,52-126,176-207.  There `emd_approx`
+  compute_all_metrics                    calls StructuralLosses.match_cost, an extension that is NOT part of the reference tree;
+                                         here it is the tree's own auction module: mean over the points of sqrt(dist).
+
+The distance searches, the all-pairs Chamfer matrix, the occupancy-grid statistics and the auction are HIP kernels
+(`csrc/metrics.hip`, `csrc/emd.hip`); what remains here are reductions over the [S,R] matrices and the grid histograms (a few
+thousand numbers).
 """
 from __future__ import annotations
 
@@ -96,6 +101,70 @@ def pairwise_cd(sample_pcs: Tensor, ref_pcs: Tensor) -> Tensor:
     return out
 
 
+class emdFunction(Function):
+    """emd_module.py:33-75: forward(xyz1 [B,n,3], xyz2 [B,n,3], eps=0.005, iters=50) -> (dist [B,n] squared distances to the assigned
+    points, assignment [B,n] int32).  Gradient for xyz1 only, as there."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, eps=0.005, iters=50):
+        xyz1, xyz2 = _cloud(xyz1, "xyz1"), _cloud(xyz2, "xyz2")
+        if xyz1.shape != xyz2.shape:
+            raise ValueError("the two clouds must have the same batch size and point count, got %s and %s" % (tuple(xyz1.shape), tuple(xyz2.shape)))
+        B, n, _ = xyz1.shape
+        lib = _lib.load()
+        dist = torch.empty((B, n), dtype=torch.float32, device=xyz1.device)
+        assignment = torch.empty((B, n), dtype=torch.int32, device=xyz1.device)
+        wsb = lib.spgan_emd_ws_bytes(B, n)
+        ws = torch.empty((wsb // 8,), dtype=torch.int64, device=xyz1.device)
+        check(lib.spgan_emd_forward(_p(xyz1), _p(xyz2), B, n, float(eps), int(iters), _p(dist), _p(assignment), _p(ws), wsb, _s()),
+              "emd_forward", B=B, n=n, iters=iters)
+        ctx.save_for_backward(xyz1, xyz2, assignment)
+        ctx.mark_non_differentiable(assignment)
+        return dist, assignment
+
+    @staticmethod
+    def backward(ctx, graddist, _gradidx):
+        xyz1, xyz2, assignment = ctx.saved_tensors
+        B, n, _ = xyz1.shape
+        g1 = torch.empty_like(xyz1)
+        check(_lib.load().spgan_emd_backward(_p(xyz1), _p(xyz2), B, n, _p(graddist.contiguous()), _p(assignment), _p(g1), _s()), "emd_backward")
+        return g1, torch.zeros_like(xyz2), None, None
+
+
+class emdModule(nn.Module):
+    """emd_module.py:78-85: forward(input1, input2, eps, iters) -> (dist, assignment)."""
+
+    def forward(self, input1, input2, eps=0.005, iters=50):
+        return emdFunction.apply(input1, input2, eps, iters)
+
+
+def emd_approx(sample: Tensor, ref: Tensor, eps: float = 0.005, iters: int = 50) -> Tensor:
+    """Per-pair EMD / N (evaluation_metrics.py:26-35), [B]: mean over the points of the distance to the assigned point."""
+    dist, _ = emdFunction.apply(sample, ref, eps, iters)
+    return dist.sqrt().mean(dim=1)
+
+
+def pairwise_emd(sample_pcs: Tensor, ref_pcs: Tensor, batch_size: int = 512, eps: float = 0.005, iters: int = 50) -> Tensor:
+    """[S,R] matrix of emd_approx over all pairs (the EMD half of _pairwise_EMD_CD_, evaluation_metrics.py:89-126), `batch_size`
+    pairs per auction launch sequence."""
+    a, b = _cloud(sample_pcs, "sample_pcs"), _cloud(ref_pcs, "ref_pcs")
+    S, R = a.shape[0], b.shape[0]
+    out = torch.empty((S * R,), dtype=torch.float32, device=a.device)
+    si = torch.arange(S, device=a.device).repeat_interleave(R)
+    ri = torch.arange(R, device=a.device).repeat(S)
+    for lo in range(0, S * R, batch_size):
+        out[lo:lo + batch_size] = emd_approx(a[si[lo:lo + batch_size]], b[ri[lo:lo + batch_size]], eps, iters)
+    return out.view(S, R)
+
+
+def EMD_CD(sample_pcs: Tensor, ref_pcs: Tensor, batch_size: int = 512, reduced: bool = True) -> Dict[str, Tensor]:
+    """evaluation_metrics.py:52-86: Chamfer and EMD between corresponding clouds."""
+    dl, dr = nn_distance(sample_pcs, ref_pcs)
+    cd = dl.mean(dim=1) + dr.mean(dim=1)
+    emd = torch.cat([emd_approx(sample_pcs[lo:lo + batch_size], ref_pcs[lo:lo + batch_size]) for lo in range(0, sample_pcs.shape[0], batch_size)])
+    return {"MMD-CD": cd.mean() if reduced else cd, "MMD-EMD": emd.mean() if reduced else emd}
+
+
 def lgan_mmd_cov(all_dist: Tensor) -> Dict[str, Tensor]:
     """evaluation_metrics.py:161-173; all_dist [N_sample, N_ref]."""
     n_ref = all_dist.shape[1]
@@ -179,6 +248,16 @@ def jsd_between_point_cloud_sets(sample_pcs: Tensor, ref_pcs: Tensor, resolution
     sample_grid_var = entropy_of_occupancy_grid(sample_pcs, resolution, True)[1]
     ref_grid_var = entropy_of_occupancy_grid(ref_pcs, resolution, True)[1]
     return jensen_shannon_divergence(sample_grid_var, ref_grid_var)
+
+
+def compute_all_metrics(sample_pcs: Tensor, ref_pcs: Tensor, batch_size: int = 512) -> Dict[str, Tensor]:
+    """evaluation_metrics.py:176-207: MMD / COV / 1-NNA for both Chamfer and EMD."""
+    res = compute_all_metrics_cd(sample_pcs, ref_pcs)
+    M_rs = pairwise_emd(ref_pcs, sample_pcs, batch_size)
+    res.update({"%s-EMD" % k: v for k, v in lgan_mmd_cov(M_rs.t()).items()})
+    M_rr, M_ss = pairwise_emd(ref_pcs, ref_pcs, batch_size), pairwise_emd(sample_pcs, sample_pcs, batch_size)
+    res.update({"1-NN-EMD-%s" % k: v for k, v in knn(M_rr, M_rs, M_ss, 1, sqrt=False).items() if "acc" in k})
+    return res
 
 
 def compute_all_metrics_cd(sample_pcs: Tensor, ref_pcs: Tensor) -> Dict[str, Tensor]:

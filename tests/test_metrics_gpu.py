@@ -91,3 +91,55 @@ def test_jsd_occupancy_grid_golden():
     assert abs(ab - ba) <= 1e-12 and 0.0 < ab <= 1.0
     _, cnt = M.entropy_of_occupancy_grid(big_a, 28, True)
     assert int(cnt.sum().item()) == 64 * 2048
+
+
+def test_emd_auction_matches_oracle_and_optimum():
+    """The auction on the GPU: identical assignments and distances to the numpy restatement (same float32 arithmetic, same tie
+    rules), optimal within n*eps once complete, the reference module's surface (emdModule(x, y, eps, iters) -> dist, assignment)."""
+    from scipy.optimize import linear_sum_assignment
+    from test_oracle_golden import _emd_sets
+    from spgan import metrics as M
+    a, b = _emd_sets(B=3, n=128)
+    ag, bg = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    for eps, iters in ((0.005, 50), (0.005, 7), (0.002, 3000)):
+        dist, assign = M.emdModule()(ag, bg, eps, iters)
+        od, oa = orc.emd_auction(a, b, eps, iters)
+        assert np.array_equal(assign.cpu().numpy(), oa), (eps, iters, (assign.cpu().numpy() != oa).sum())
+        np.testing.assert_array_equal(dist.cpu().numpy(), od)
+    n = a.shape[1]
+    for i in range(3):
+        cost = np.linalg.norm(a[i][:, None, :] - b[i][None, :, :], axis=-1).astype(np.float64)
+        r, c = linear_sum_assignment(cost)
+        got = dist[i].double().sqrt().sum().item()
+        assert cost[r, c].sum() - 1e-4 <= got <= cost[r, c].sum() + n * 0.002 + 1e-4
+    # ragged n (the reference insists on multiples of 1024), larger clouds: a bijection once the auction has finished
+    big_a = (fr.synthetic_real(4, 2048, seed=950) * 0.5 + 0.5).cuda(); big_b = (fr.synthetic_real(4, 2048, seed=960) * 0.4 + 0.5).cuda()
+    dist, assign = M.emdFunction.apply(big_a, big_b, 0.005, 3000)
+    assert all(torch.equal(torch.sort(assign[i].long())[0].cpu(), torch.arange(2048)) for i in range(4))
+    rag_a, rag_b = big_a[:, :777].contiguous(), big_b[:, :777].contiguous()
+    dist, assign = M.emdFunction.apply(rag_a, rag_b, 0.005, 3000)
+    assert all(torch.equal(torch.sort(assign[i].long())[0].cpu(), torch.arange(777)) for i in range(4))
+    ref = (rag_a - torch.gather(rag_b, 1, assign.long()[..., None].expand(-1, -1, 3))).pow(2).sum(-1)
+    assert (dist - ref).abs().max().item() <= 1e-6
+    # gradient: d/dx1 sum(w * dist) = 2 w (x1 - x2[assignment]); nothing for x2 (emd_cuda.cu:279-296)
+    x1 = rag_a.clone().requires_grad_(True); x2 = rag_b.clone().requires_grad_(True)
+    w = torch.rand(4, 777, device="cuda")
+    d, asg = M.emdFunction.apply(x1, x2, 0.005, 50)
+    (d * w).sum().backward()
+    want = 2 * w[..., None] * (rag_a - torch.gather(rag_b, 1, asg.long()[..., None].expand(-1, -1, 3)))
+    assert (x1.grad - want).abs().max().item() <= 1e-6 and x2.grad.abs().max().item() == 0
+
+
+def test_emd_metric_drivers():
+    from spgan import metrics as M
+    smp, ref = _metric_sets()
+    smp_g, ref_g = (smp * 0.5 + 0.5).cuda(), (ref * 0.5 + 0.5).cuda()
+    pe = M.pairwise_emd(smp_g, ref_g, batch_size=7)                  # chunked launches
+    want = np.stack([orc.emd_approx(np.repeat(smp_g[i:i + 1].cpu().numpy(), ref_g.shape[0], 0), ref_g.cpu().numpy()) for i in range(smp_g.shape[0])])
+    np.testing.assert_allclose(pe.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+    R = min(smp_g.shape[0], ref_g.shape[0])
+    res = M.EMD_CD(smp_g[:R], ref_g[:R])
+    assert abs(res["MMD-EMD"].item() - np.diag(want)[:R].mean()) <= 1e-6
+    allm = M.compute_all_metrics(smp_g, ref_g)
+    for key in ("lgan_mmd-CD", "lgan_cov-CD", "lgan_mmd_smp-CD", "lgan_mmd-EMD", "lgan_cov-EMD", "lgan_mmd_smp-EMD", "1-NN-CD-acc", "1-NN-EMD-acc"):
+        assert key in allm and np.isfinite(allm[key].item()), key

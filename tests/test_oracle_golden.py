@@ -375,3 +375,32 @@ def test_jsd_occupancy_grid():
         np.testing.assert_array_equal(cnt.astype(np.int32), d["cnt%d" % res])
         assert abs(ent - float(d["ent%d" % res])) <= 1e-12
         assert abs(orc.jsd_between_point_cloud_sets(smp, ref, res) - float(d["jsd%d" % res])) <= 1e-12
+
+
+# ---------------------------------------------------------------- auction EMD (unpinned by reference outputs)
+def _emd_sets(B=3, n=128):
+    a = np.stack([(fr.synthetic_real(1, n, seed=800 + i)[0].numpy() * 0.5 + 0.5) for i in range(B)]).astype(np.float32)
+    b = np.stack([(fr.synthetic_real(1, n, seed=900 + i)[0].numpy() * 0.45 + 0.5) for i in range(B)]).astype(np.float32)
+    return a, b
+
+
+def test_emd_auction_against_optimal_assignment():
+    """The auction restatement against the exact optimum (Hungarian method): once every point is assigned the matching is a
+    permutation whose cost is within n*eps of the optimal cost (Bertsekas' eps-complementary-slackness bound)."""
+    from scipy.optimize import linear_sum_assignment
+    a, b = _emd_sets()
+    eps, n = 0.002, a.shape[1]
+    dist, assign = orc.emd_auction(a, b, eps=eps, iters=3000)
+    for i in range(a.shape[0]):
+        assert sorted(assign[i].tolist()) == list(range(n))                  # a bijection
+        cost = np.linalg.norm(a[i][:, None, :] - b[i][None, :, :], axis=-1).astype(np.float64)
+        r, c = linear_sum_assignment(cost)
+        opt = cost[r, c].sum()
+        got = np.sqrt(dist[i].astype(np.float64)).sum()
+        assert opt - 1e-4 <= got <= opt + n * eps + 1e-4, (got, opt)
+    # identical clouds: every point keeps itself, distance 0
+    dist, assign = orc.emd_auction(a, a, eps=0.005, iters=50)
+    assert (assign == np.arange(n)[None]).all() and (dist == 0).all()
+    # short runs (the module's default 50 iterations) leave a valid, possibly non-bijective assignment
+    dist, assign = orc.emd_auction(a, b, eps=0.005, iters=5)
+    assert assign.min() >= 0 and assign.max() < n
