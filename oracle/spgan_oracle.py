@@ -324,6 +324,26 @@ def gradient_penalty(d_fn, real: Tensor, fake: Tensor, alpha: Tensor,
     return (((g.norm(2, dim=1) - gamma) / gamma) ** 2).mean() * lambda_gp
 
 
+def gradient_penalty_loss_utils(d_fn, real: Tensor, fake: Tensor, alpha: Tensor, lambda_gp: float = 10.0, gamma: float = 1.0,
+                                mapping: bool = False) -> Tensor:
+    """The second GradientPenalty, Common/loss_utils.py:1087-1131: x_hat = alpha*real + (1-alpha)*fake (:1108); with
+    mapping=True (:1110-1118) every fake point is first paired with a real point by the auction EMD (`emd_auction(fake, real,
+    0.005, 300)` above) and x_hat = alpha*fake + (1-alpha)*real[assignment].  real/fake [B,3,N]."""
+    B = real.shape[0]
+    fake = fake[:B]
+    if mapping:
+        f, r = fake.transpose(1, 2).contiguous(), real.transpose(1, 2).contiguous()
+        _, ass = emd_auction(f.detach().numpy(), r.detach().numpy(), 0.005, 300)
+        paired = torch.stack([r[i][torch.from_numpy(ass[i])] for i in range(B)])
+        xhat = (alpha * f + (1.0 - alpha) * paired).transpose(1, 2).contiguous()
+    else:
+        xhat = alpha * real + (1 - alpha) * fake
+    xhat = xhat.detach().requires_grad_(True)
+    out = d_fn(xhat)
+    g = torch.autograd.grad(out, xhat, grad_outputs=torch.ones_like(out), create_graph=True, retain_graph=True, only_inputs=True)[0]
+    return (((g.contiguous().view(B, -1).norm(2, dim=1) - gamma) / gamma) ** 2).mean() * lambda_gp
+
+
 # --------------------------------------------------------------------------- #
 # optimiser + one train step (Generation/model.py:239-279)                    #
 # --------------------------------------------------------------------------- #

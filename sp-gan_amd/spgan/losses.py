@@ -103,20 +103,44 @@ class GradientPenalty:
     """WGAN-GP penalty, Common/gradient_penalty.py:4-37:
         alpha ~ U[0,1] per sample; x_hat = real + alpha*(fake-real); g = d netD(x_hat)/d x_hat (create_graph);
         penalty = lambdaGP * mean(((||g_b||_2 - gamma)/gamma)^2).
-    `netD` must be an spgan.Discriminator (its input-gradient node is differentiable once more)."""
+    `netD` must be an spgan.Discriminator (its input-gradient node is differentiable once more).
 
-    def __init__(self, lambdaGP, gamma=1, vertex_num=2500, device=None):
+    The second GradientPenalty of the reference (Common/loss_utils.py:1087-1131) differs in two ways, both available here:
+    `mix="loss_utils"` interpolates alpha*real + (1-alpha)*fake (:1108), and `mapping=True` (:1110-1118) first pairs every fake point
+    with a real point by the auction EMD (`emdModule()(fake, real, 0.005, 300)`, spgan.metrics) and interpolates along those pairs:
+    alpha*fake + (1-alpha)*real[assignment]."""
+
+    def __init__(self, lambdaGP, gamma=1, vertex_num=2500, device=None, mix: str = "common"):
+        if mix not in ("common", "loss_utils"):
+            raise ValueError("mix must be 'common' (gradient_penalty.py) or 'loss_utils'")
         self.lambdaGP = lambdaGP
         self.gamma = gamma
         self.vertex_num = vertex_num
         self.device = device
+        self.mix = mix
 
-    def __call__(self, netD, real_data, fake_data, alpha: Optional[torch.Tensor] = None):
+    def _mapped(self, real_data, fake_data, alpha):
+        from . import metrics
+        B, C, N = real_data.shape
+        fake_pm, real_pm = ops.cm_to_pm(fake_data), ops.cm_to_pm(real_data)                   # [B*N,3]
+        _, ass = metrics.emdFunction.apply(fake_pm.view(B, N, C), real_pm.view(B, N, C), 0.005, 300)
+        rows = (ass + (torch.arange(B, device=ass.device, dtype=torch.int32) * N).view(B, 1)).reshape(B * N, 1)
+        paired = ops.gather_rows(real_pm, rows.expand(B * N, C).contiguous())                   # real[b][assignment[b]] (same row for x, y, z)
+        mixed = ops.lerp_rows(paired.view(B, N * C), fake_pm.view(B, N * C), alpha.reshape(B))  # paired + alpha*(fake - paired)
+        return ops.pm_to_cm(mixed.view(B * N, C), B, N)
+
+    def __call__(self, netD, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False):
         B = real_data.size(0)
         fake_data = fake_data[:B]
         if alpha is None:
             alpha = torch.rand(B, 1, 1, device=real_data.device)
-        interpolates = ops.lerp_rows(real_data.detach(), fake_data.detach(), alpha.reshape(B)).requires_grad_(True)
+        real_d, fake_d = real_data.detach().contiguous(), fake_data.detach().contiguous()
+        if mapping:
+            interpolates = self._mapped(real_d, fake_d, alpha).requires_grad_(True)
+        elif self.mix == "loss_utils":
+            interpolates = ops.lerp_rows(fake_d, real_d, alpha.reshape(B)).requires_grad_(True)   # fake + alpha*(real - fake)
+        else:
+            interpolates = ops.lerp_rows(real_d, fake_d, alpha.reshape(B)).requires_grad_(True)
         disc = netD(interpolates)
         grads = torch.autograd.grad(outputs=disc, inputs=interpolates, grad_outputs=torch.ones_like(disc),
                                     create_graph=True, retain_graph=True, only_inputs=True)[0]

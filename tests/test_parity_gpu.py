@@ -456,3 +456,26 @@ def test_attention_module_fullsize(sp):
     assert rel_l2(xg.grad.cpu().numpy(), grads[0].numpy()) <= 1e-4
     for n, g in zip(names, grads[1:]):
         assert rel_l2(dict(A.named_parameters())[n].grad.cpu().numpy(), g.numpy()) <= 1e-4, n
+
+
+# ---------------------------------------------------------------- the second GradientPenalty (Common/loss_utils.py:1087-1131)
+@pytest.mark.parametrize("mapping", [False, True])
+def test_gradient_penalty_loss_utils_variant(sp, mapping):
+    B, N = 3, 256
+    params = fr.init_params(orc.discriminator_shapes(), salt=7)
+    D = _load(sp.Discriminator(Opts), params).train()
+    real = (fr.synthetic_real(B, N, seed=71) * 0.5 + 0.5).transpose(2, 1).contiguous()
+    fake = (0.4 * fr.synthetic_real(B, N, seed=72) + 0.5 + 0.02 * fr.normal("g7.n", (B, N, 3))).transpose(2, 1).contiguous()
+    alpha = fr.uniform("gpv.alpha", (B, 1, 1), 0.0, 1.0)
+    gp = sp.GradientPenalty(10.0, gamma=1, mix="loss_utils")(D, real.cuda(), fake.cuda(), alpha=alpha.cuda(), mapping=mapping)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    bufs = orc.bn_buffers(orc.discriminator_shapes())
+    ref = orc.gradient_penalty_loss_utils(lambda x: orc.discriminator_forward(po, x, True, bufs), real, fake, alpha, 10.0, 1.0, mapping=mapping)
+    np.testing.assert_allclose(gp.item(), ref.item(), rtol=2e-4)
+    gp.backward()
+    grads = torch.autograd.grad(ref, list(po.values()), allow_unused=True)
+    for (n, p), g in zip(D.named_parameters(), grads):
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        want = g if g is not None else torch.zeros(p.shape)
+        e = rel_l2(got.cpu().numpy(), want.numpy())
+        assert e <= 5e-3 or (got.cpu() - want).abs().max().item() <= (2e-3 if n.endswith(ZERO_GRAD_BIASES) else 2e-6), (n, e)
