@@ -141,6 +141,35 @@ __device__ __forceinline__ void col_reduce(float (&part)[Geo<CFG>::TJ], float* r
   __syncthreads();
 }
 
+// Two sets of column partials in ONE exchange (one barrier, none behind it: for the end of a kernel, `buf` = [2][WGM][BN] floats
+// that nobody touches afterwards).
+template <int CFG>
+__device__ __forceinline__ void col_reduce2(float (&pa)[Geo<CFG>::TJ], float (&pb)[Geo<CFG>::TJ], float* buf, int wm, int wn, int lane) {
+  using G = Geo<CFG>;
+  constexpr int BN = G::WGN * G::TJ * 32;
+#pragma unroll
+  for (int j = 0; j < G::TJ; ++j) {
+    const float va = pa[j] + __shfl_xor(pa[j], 32), vb = pb[j] + __shfl_xor(pb[j], 32);
+    if (lane < 32) {
+      buf[wm * BN + (wn * G::TJ + j) * 32 + lane] = va;
+      buf[(G::WGM + wm) * BN + (wn * G::TJ + j) * 32 + lane] = vb;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < G::TJ; ++j) {
+    const int c = (wn * G::TJ + j) * 32 + (lane & 31);
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < G::WGM; ++w) {
+      sa += buf[w * BN + c];
+      sb += buf[(G::WGM + w) * BN + c];
+    }
+    pa[j] = sa;
+    pb[j] = sb;
+  }
+}
+
 // F16 = 1: the operands are rounded to fp16 (round-to-nearest) when they are staged into LDS and multiplied with
 // v_mfma_f32_32x32x8_f16 (fp32 accumulate): BASELINE configs[4] "fp16 MFMA MLPs".  Global loads, prologues and epilogues stay
 // fp32; an LDS row holds the 32 k-values of the tile as 16 words + 2 words of padding (stride 18 == 2 mod 16: the 32 rows x
@@ -369,7 +398,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 
   const int nk = (p.K + BK - 1) / BK;
 #ifdef SPGAN_TRACE
-  unsigned long long* trc = (AMODE == SPGAN_A_PLAIN && EPI == SPGAN_EPI_LINEAR && p.e_bias2) ? ((unsigned long long*)p.e_bias2) + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long* trc = (AMODE != SPGAN_A_EDGE && EPI == SPGAN_EPI_LINEAR && p.e_bias2) ? ((unsigned long long*)p.e_bias2) + (size_t)blockIdx.x * 8 : nullptr;
 #define TRC(i) do { if (trc && threadIdx.x == 0) trc[i] = __builtin_amdgcn_s_memtime(); } while (0)
   TRC(0);
 #else
@@ -487,6 +516,88 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
         }
     }
     }
+    if (full && (p.stats || p.pool_val)) {
+      // One LDS exchange for everything (the operand tiles are dead: every wave passed the k-loop's last barrier).  Statistics:
+      // every lane holds NL = 16*TI rows of a column; (sum, M2 about the lane's own mean) pairs are merged with Chan's formula --
+      // lane halves by shuffle, the WGM waves through LDS in ascending order -- which gives the tile's (sum, centred M2) without
+      // a second pass that needs the tile mean first (that cost two more exchanges).
+      constexpr int WGM = G::WGM;
+      constexpr float NL = (float)(16 * TI);
+      float* xs = As;
+      float* xm = As + WGM * BN;
+      float* xvx = As + 2 * WGM * BN;
+      int* xax = reinterpret_cast<int*>(As + 3 * WGM * BN);
+      float* xvn = As + 4 * WGM * BN;
+      int* xan = reinterpret_cast<int*>(As + 5 * WGM * BN);
+      const bool do_pool = p.pool_val != nullptr;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const float sl = csum[j], mean = sl * (1.f / NL);
+        float m2 = 0.f;
+        float vx = -INFINITY, vn = INFINITY;
+        int ax = 0x7fffffff, an = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            const float d = v - mean;
+            m2 = fmaf(d, d, m2);
+            if (do_pool) {  // rows ascend with (i, r): strict compares keep the first
+              const int row = ROW_OF(i, r);
+              if (v > vx) { vx = v; ax = row; }
+              if (v < vn) { vn = v; an = row; }
+            }
+          }
+        const float so = __shfl_xor(sl, 32), m2o = __shfl_xor(m2, 32);
+        const float dl = (so - sl) * (1.f / NL);
+        const float S = sl + so, M2 = (m2 + m2o) + dl * dl * (0.5f * NL);
+        if (do_pool) {
+          const float ovx = __shfl_xor(vx, 32), ovn = __shfl_xor(vn, 32);
+          const int oax = __shfl_xor(ax, 32), oan = __shfl_xor(an, 32);
+          if (ovx > vx || (ovx == vx && oax < ax)) { vx = ovx; ax = oax; }
+          if (ovn < vn || (ovn == vn && oan < an)) { vn = ovn; an = oan; }
+        }
+        if (lh == 0) {
+          const int c = wm * BN + (wn * TJ + j) * 32 + l31;
+          xs[c] = S; xm[c] = M2;
+          if (do_pool) { xvx[c] = vx; xax[c] = ax; xvn[c] = vn; xan[c] = an; }
+        }
+      }
+      __syncthreads();
+      if (wm == 0 && lh == 0) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int c = (wn * TJ + j) * 32 + l31, col = cbase + j * 32;
+          float S = xs[c], M2 = xm[c], n = 2.f * NL;
+#pragma unroll
+          for (int w = 1; w < WGM; ++w) {
+            const float Sb = xs[w * BN + c], nb = 2.f * NL;
+            const float dl = Sb / nb - S / n;
+            M2 = (M2 + xm[w * BN + c]) + dl * dl * (n * nb / (n + nb));
+            S += Sb;
+            n += nb;
+          }
+          if (p.stats) {
+            float* o = p.stats + ((size_t)t.tm * p.N + col) * 2;
+            o[0] = S;
+            o[1] = M2;
+          }
+          if (do_pool) {
+            float vx = xvx[c], vn = xvn[c];
+            int ax = xax[c], an = xan[c];
+#pragma unroll
+            for (int w = 1; w < WGM; ++w) {  // wave w holds higher rows than wave w-1: strict compares keep the first
+              if (xvx[w * BN + c] > vx) { vx = xvx[w * BN + c]; ax = xax[w * BN + c]; }
+              if (xvn[w * BN + c] < vn) { vn = xvn[w * BN + c]; an = xan[w * BN + c]; }
+            }
+            const size_t o = ((size_t)t.tm * p.N + col) * 2;
+            p.pool_val[o] = vx; p.pool_val[o + 1] = vn;
+            p.pool_arg[o] = ax; p.pool_arg[o + 1] = an;
+          }
+        }
+      }
+    } else {
     if (p.pool_val) {
       // Per-tile column max / min of the pre-activation output with their rows (first row on ties): a global max-pool behind a
       // per-channel monotone map (BatchNorm affine of either sign + LeakyReLU) is finished from these by spgan_pool_finalize
@@ -567,6 +678,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           }
         }
       }
+    }
     }
   } else if (EPI == SPGAN_EPI_MASK_OUT) {
     if (full) {
@@ -666,8 +778,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
         }
     }
     if (p.stats) {
-      col_reduce<CFG>(s0, red, wm, wn, lane);
-      col_reduce<CFG>(s1, red, wm, wn, lane);
+      col_reduce2<CFG>(s0, s1, As, wm, wn, lane);  // the operand tiles are dead: every wave passed the k-loop's last barrier
       if (wm == 0 && lh == 0) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
