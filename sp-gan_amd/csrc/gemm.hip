@@ -1358,8 +1358,8 @@ extern "C" int spgan_sparse_rows_nt(const float* val, const int32_t* arg, int B,
                                     int lde, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(val && arg && W && E && B > 0 && rows > 0 && Cs > 0 && N > 0 && ldw >= N && lde >= N && Cs <= 8192);
   const int words = cdiv(Cs, 64);
-  int RB = (32 * 1024) / (words * 8);  // 32 KB of row masks per workgroup
-  if (RB > 256) RB = 256;
+  int RB = (32 * 1024) / (words * 8);  // at most 32 KB of row masks per workgroup
+  if (RB > 32) RB = 32;               // 8 rows per wave: B*rows/32 workgroups (2048 at C2) -- with 256 rows a launch had one workgroup per CU and was latency-bound (61 us for 67 MB)
   if (RB > rows) RB = rows;
   const size_t lds = (size_t)RB * words * 8 + (size_t)Cs * 4;
   hipLaunchKernelGGL(sparse_rows_nt_kernel, dim3(cdiv(rows, RB), B), dim3(256), lds, (hipStream_t)s_, val, arg, rows, Cs, W, ldw, N, E, lde, RB);

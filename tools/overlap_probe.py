@@ -44,5 +44,14 @@ for (Cout, Cin) in ((256, 256), (256, 128), (128, 64), (1024, 256)):
     def only_tn():
         for _ in range(n):
             ops.gemm_tn(dy, x)
+    def eager(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
+    print("   eager (no graph): serial %.1f us  forked %.1f us" % (eager(serial) / n * 1e3, eager(forked) / n * 1e3))
     a, b, c, d = bench(serial), bench(forked), bench(only_nt), bench(only_tn)
     print("Cout %4d Cin %4d: nt %.1f us  tn %.1f us  serial %.1f us  forked %.1f us  (saves %.0f%%)" % (Cout, Cin, c / n * 1e3, d / n * 1e3, a / n * 1e3, b / n * 1e3, 100 * (1 - b / a)))
