@@ -72,22 +72,35 @@ __global__ void adain_bwd2_kernel(const float* __restrict__ dout, const float* _
 }
 
 // gval = gpool * lrelu'(pooled);  sums[c] = sum_b gval, sums[C+c] = sum_b gval * xhat(argmax row)
-__global__ void pool_bwd_stats_kernel(const float* __restrict__ gpool, const float* __restrict__ pooled, const int32_t* __restrict__ argmax,
-                                      const float* __restrict__ y, int ld, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                      float slope, int B, int C, float* __restrict__ gval, float* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// 64 channels x 4 shape-lanes per workgroup: the B gathers of a channel are independent loads spread over four threads
+// (one thread per channel walked the shapes one dependent-latency at a time: 25 us for 32 x 1024 values); the four partial
+// sums are combined in a fixed order.
+__global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __restrict__ gpool, const float* __restrict__ pooled,
+                                                             const int32_t* __restrict__ argmax, const float* __restrict__ y, int ld,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, float slope, int B,
+                                                             int C, float* __restrict__ gval, float* __restrict__ sums) {
+  __shared__ float r0[4][64], r1[4][64];
+  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s0 = 0.f, s1 = 0.f;
-  const float mu = mean[c], iv = invstd[c];
-  for (int b = 0; b < B; ++b) {
-    const float g = gpool[(size_t)b * C + c] * lrelu_mask(pooled[(size_t)b * C + c], slope);
-    gval[(size_t)b * C + c] = g;
-    const float xh = (y[(size_t)argmax[(size_t)b * C + c] * ld + c] - mu) * iv;
-    s0 += g;
-    s1 = fmaf(g, xh, s1);
+  if (c < C) {
+    const float mu = mean[c], iv = invstd[c];
+#pragma unroll 4
+    for (int b = bl; b < B; b += 4) {
+      const float g = gpool[(size_t)b * C + c] * lrelu_mask(pooled[(size_t)b * C + c], slope);
+      gval[(size_t)b * C + c] = g;
+      const float xh = (y[(size_t)argmax[(size_t)b * C + c] * ld + c] - mu) * iv;
+      s0 += g;
+      s1 = fmaf(g, xh, s1);
+    }
   }
-  sums[c] = s0;
-  sums[C + c] = s1;
+  r0[bl][cl] = s0;
+  r1[bl][cl] = s1;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    sums[c] = (r0[0][cl] + r0[1][cl]) + (r0[2][cl] + r0[3][cl]);
+    sums[C + c] = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
+  }
 }
 
 // dy[m,c] = gamma*invstd*( (argmax[b,c]==m ? gval[b,c] : 0) - sums[c]/count - xhat*sums[C+c]/count )
@@ -250,28 +263,40 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
 //   phase A coefficients as bn_dbl_coeffs; top adjoint t[b,c] = gamma*inv*(uarg - U0/M - xhat_arg*U1/M)*lrelu'(pooled)
 //   phase B: ybar = c1*u + c2*y + c3 + scatter(spB)  with sum0 = xsum0, sum1 = xsum1 + inv*sbarA:
 //     c1 = -gamma*inv^2*S1/M,  c2 = -inv^2*sum1/M,  c3 = -inv*sum0/M + inv^2*mean*sum1/M,  spB = -(gamma*inv^2/M)*U1*gval
-__global__ void bn_dbl_pool_kernel(const float* __restrict__ uarg, const float* __restrict__ gval, const float* __restrict__ yarg,
-                                   const float* __restrict__ pooled, const float* __restrict__ U0, const float* __restrict__ quad,
-                                   const float* __restrict__ bias, const float* __restrict__ mean, const float* __restrict__ inv,
-                                   const float* __restrict__ gamma, const float* __restrict__ S0, const float* __restrict__ S1, int B, int C,
-                                   float rM, float slope, float* __restrict__ t, float* __restrict__ spB, float* __restrict__ out4) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_dbl_pool_kernel(const float* __restrict__ uarg, const float* __restrict__ gval,
+                                                          const float* __restrict__ yarg, const float* __restrict__ pooled,
+                                                          const float* __restrict__ U0, const float* __restrict__ quad,
+                                                          const float* __restrict__ bias, const float* __restrict__ mean,
+                                                          const float* __restrict__ inv, const float* __restrict__ gamma,
+                                                          const float* __restrict__ S0, const float* __restrict__ S1, int B, int C, float rM,
+                                                          float slope, float* __restrict__ t, float* __restrict__ spB, float* __restrict__ out4) {
+  // 64 channels x 4 shape-lanes per workgroup (see pool_bwd_stats_kernel)
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool ok = c < C;
+  float part = 0.f;
+  if (ok)
+    for (int b = bl; b < B; b += 4) part = fmaf(gval[(size_t)b * C + c], uarg[(size_t)b * C + c], part);
+  red[bl][cl] = part;
+  __syncthreads();
+  if (!ok) return;
+  const float ugz = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
   const float iv = inv[c], ga = gamma[c], mu = mean[c], u0 = U0[c];
   const float u1 = iv * (quad[c] + (bias[c] - mu) * u0);
-  float ugz = 0.f;
-  for (int b = 0; b < B; ++b) ugz = fmaf(gval[(size_t)b * C + c], uarg[(size_t)b * C + c], ugz);
   const float core = ugz - (u0 * S0[c] + u1 * S1[c]) * rM;
   const float gsM = ga * iv * rM;
   const float sbarA = ga * core;
   const float sum0 = -gsM * (u0 * S1[c] + S0[c] * u1);
   const float sum1 = -2.0f * gsM * (u1 * S1[c]) + iv * sbarA;
-  out4[c] = iv * core;                                       // dgamma
-  out4[C + c] = -gsM * iv * S1[c];                           // c1
-  out4[2 * C + c] = -iv * iv * sum1 * rM;                    // c2
-  out4[3 * C + c] = -iv * sum0 * rM + iv * iv * mu * sum1 * rM;  // c3
+  if (bl == 0) {
+    out4[c] = iv * core;                                       // dgamma
+    out4[C + c] = -gsM * iv * S1[c];                           // c1
+    out4[2 * C + c] = -iv * iv * sum1 * rM;                    // c2
+    out4[3 * C + c] = -iv * sum0 * rM + iv * iv * mu * sum1 * rM;  // c3
+  }
   const float gs = ga * iv, spc = -gsM * iv * u1;
-  for (int b = 0; b < B; ++b) {
+  for (int b = bl; b < B; b += 4) {
     const size_t i = (size_t)b * C + c;
     const float xh = (yarg[i] - mu) * iv;
     t[i] = gs * (uarg[i] - u0 * rM - xh * (u1 * rM)) * lrelu_mask(pooled[i], slope);
@@ -281,15 +306,17 @@ __global__ void bn_dbl_pool_kernel(const float* __restrict__ uarg, const float* 
 
 // BatchNorm backward behind the max-pool as a lazy operand: alpha = -(gamma*inv)*inv*S1/M, beta = -(gamma*inv)*S0/M - alpha*mean,
 // cg[b,c] = gamma*inv*gval[b,c]
-__global__ void sparse_bn_prep_kernel(const float* gval, const float* mean, const float* inv, const float* gamma, const float* sums, int B,
-                                      int C, float rM, float* alpha, float* beta, float* cg) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void sparse_bn_prep_kernel(const float* gval, const float* mean, const float* inv, const float* gamma,
+                                                             const float* sums, int B, int C, float rM, float* alpha, float* beta, float* cg) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), bl = threadIdx.x >> 6;
   if (c >= C) return;
   const float coef = gamma[c] * inv[c];
-  const float al = -(coef * inv[c]) * (sums[C + c] * rM);
-  alpha[c] = al;
-  beta[c] = -(coef * (sums[c] * rM)) - al * mean[c];
-  for (int b = 0; b < B; ++b) cg[(size_t)b * C + c] = gval[(size_t)b * C + c] * coef;
+  if (bl == 0) {
+    const float al = -(coef * inv[c]) * (sums[C + c] * rM);
+    alpha[c] = al;
+    beta[c] = -(coef * (sums[c] * rM)) - al * mean[c];
+  }
+  for (int b = bl; b < B; b += 4) cg[(size_t)b * C + c] = gval[(size_t)b * C + c] * coef;
 }
 
 // out = a + gamma[c]*b
@@ -407,7 +434,7 @@ extern "C" int spgan_adain_bwd2(const float* dout, const float* x, int M, int C,
 extern "C" int spgan_pool_bwd_stats(const float* gpool, const float* pooled, const int32_t* argmax, const float* y, int ld, const float* mean,
                                     const float* invstd, float slope, int B, int C, float* gval, float* sums, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(gpool && pooled && argmax && y && mean && invstd && gval && sums && B > 0 && C > 0 && ld >= C);
-  hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)s_, gpool, pooled, argmax, y, ld, mean, invstd, slope, B,
+  hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)s_, gpool, pooled, argmax, y, ld, mean, invstd, slope, B,
                      C, gval, sums);
   return spgan_launch_status();
 }
@@ -497,14 +524,14 @@ extern "C" int spgan_bn_dbl_pool(const float* uarg, const float* gval, const flo
                                  int B, int C, int count, float slope, float* t, float* spB, float* out4C, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(uarg && gval && yarg && pooled && U0 && quad && bias && mean && invstd && gamma && S0 && S1 && t && spB && out4C);
   SPGAN_CHECK_ARG(B > 0 && C > 0 && count > 0);
-  hipLaunchKernelGGL(bn_dbl_pool_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)s_, uarg, gval, yarg, pooled, U0, quad, bias, mean, invstd,
+  hipLaunchKernelGGL(bn_dbl_pool_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)s_, uarg, gval, yarg, pooled, U0, quad, bias, mean, invstd,
                      gamma, S0, S1, B, C, 1.0f / (float)count, slope, t, spB, out4C);
   return spgan_launch_status();
 }
 extern "C" int spgan_sparse_bn_prep(const float* gval, const float* mean, const float* invstd, const float* gamma, const float* sums, int B,
                                     int C, int count, float* alpha, float* beta, float* cg, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(gval && mean && invstd && gamma && sums && alpha && beta && cg && B > 0 && C > 0 && count > 0);
-  hipLaunchKernelGGL(sparse_bn_prep_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s_, gval, mean, invstd, gamma, sums, B, C,
+  hipLaunchKernelGGL(sparse_bn_prep_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)s_, gval, mean, invstd, gamma, sums, B, C,
                      1.0f / (float)count, alpha, beta, cg);
   return spgan_launch_status();
 }
