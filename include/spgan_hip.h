@@ -364,6 +364,17 @@ typedef struct spgan_splitk_multi_args {
   float beta[SPGAN_MULTI_MAX];
   int block_start[SPGAN_MULTI_MAX + 1];
 } spgan_splitk_multi_args;
+/* dst[e] (cols x rows, contiguous) = src[e]^T (rows x cols, row stride ld) for count <= SPGAN_MULTI_MAX matrices in ONE launch: the
+ * transposed weights read by the input-gradient GEMMs, refreshed once per optimiser step.  tile_start[e] = sum_{f<e} of
+ * ceil(rows/32)*ceil(cols/32). */
+typedef struct spgan_multi_transpose_args {
+  int count;
+  const float* src[SPGAN_MULTI_MAX];
+  float* dst[SPGAN_MULTI_MAX];
+  int rows[SPGAN_MULTI_MAX], cols[SPGAN_MULTI_MAX], ld[SPGAN_MULTI_MAX];
+  int tile_start[SPGAN_MULTI_MAX + 1];
+} spgan_multi_transpose_args;
+int spgan_multi_transpose(const spgan_multi_transpose_args* a, spgan_stream_t s);
 int spgan_gemm_tn_splits(int M, int Na, int Nb);
 int spgan_splitk_reduce_multi(const spgan_splitk_multi_args* a, spgan_stream_t s);
 /* y = a*x + b*y */

@@ -491,6 +491,30 @@ __global__ void pm_to_cm_kernel(const float* __restrict__ x, int C, int N, float
   }
 }
 
+// dst[e] = src[e]^T for up to SPGAN_MULTI_MAX row-major matrices in one launch (the transposed weights the input-gradient GEMMs
+// read, refreshed once per optimiser step): 32x32 tiles through LDS, block b serves entry e with tile_start[e] <= b < tile_start[e+1].
+__global__ __launch_bounds__(256) void multi_transpose_kernel(const spgan_multi_transpose_args a) {
+  __shared__ float tile[32][33];
+  int e = 0;
+  while (e + 1 < a.count && (int)blockIdx.x >= a.tile_start[e + 1]) ++e;
+  const int rows = a.rows[e], cols = a.cols[e], ld = a.ld[e];
+  const int tcols = (cols + 31) >> 5;
+  const int t = (int)blockIdx.x - a.tile_start[e];
+  const int r0 = (t / tcols) * 32, c0 = (t % tcols) * 32;
+  const float* __restrict__ src = a.src[e];
+  float* __restrict__ dst = a.dst[e];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[tx][i];
+  }
+}
+
 __global__ void concat2_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb, size_t M,
                                float* __restrict__ out) {
   const int Ct = Ca + Cb;
@@ -554,6 +578,15 @@ extern "C" int spgan_pm_to_cm(const float* x, int B, int C, int N, float* y, spg
   hipStream_t s = (hipStream_t)s_;
   SPGAN_CHECK_ARG(x && y && B > 0 && C > 0 && N > 0);
   hipLaunchKernelGGL(pm_to_cm_kernel, dim3(cdiv(N, 32), cdiv(C, 32), B), dim3(256), 0, s, x, C, N, y);
+  return spgan_launch_status();
+}
+extern "C" int spgan_multi_transpose(const spgan_multi_transpose_args* a, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && a->count > 0 && a->count <= SPGAN_MULTI_MAX && a->tile_start[0] == 0);
+  for (int e = 0; e < a->count; ++e) {
+    SPGAN_CHECK_ARG(a->src[e] && a->dst[e] && a->rows[e] > 0 && a->cols[e] > 0 && a->ld[e] >= a->cols[e]);
+    SPGAN_CHECK_ARG(a->tile_start[e + 1] - a->tile_start[e] == cdiv(a->rows[e], 32) * cdiv(a->cols[e], 32));
+  }
+  hipLaunchKernelGGL(multi_transpose_kernel, dim3(a->tile_start[a->count]), dim3(256), 0, (hipStream_t)s_, *a);
   return spgan_launch_status();
 }
 extern "C" int spgan_concat2(const float* a, int Ca, const float* b, int Cb, int M, float* out, spgan_stream_t s_) {

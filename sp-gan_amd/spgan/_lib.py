@@ -63,6 +63,12 @@ class MultiAddArgs(C.Structure):
     _fields_ = [("count", C.c_int), ("dst", C.c_void_p * MULTI_MAX), ("src", C.c_void_p * MULTI_MAX), ("n", C.c_int * MULTI_MAX)]
 
 
+class MultiTransposeArgs(C.Structure):
+    _fields_ = [("count", C.c_int), ("src", C.c_void_p * MULTI_MAX), ("dst", C.c_void_p * MULTI_MAX),
+                ("rows", C.c_int * MULTI_MAX), ("cols", C.c_int * MULTI_MAX), ("ld", C.c_int * MULTI_MAX),
+                ("tile_start", C.c_int * (MULTI_MAX + 1))]
+
+
 class SplitKMultiArgs(C.Structure):
     _fields_ = [("count", C.c_int), ("ws", C.c_void_p * MULTI_MAX), ("C", C.c_void_p * MULTI_MAX),
                 ("splits", C.c_int * MULTI_MAX), ("Na", C.c_int * MULTI_MAX), ("Nb", C.c_int * MULTI_MAX), ("ldc", C.c_int * MULTI_MAX),
@@ -150,6 +156,7 @@ SIGNATURES = {
     "spgan_scale_residual_bwd_ws_bytes": (SZ, [SZ]),
     "spgan_scale_residual_bwd": (I, [P, P, P, P, P, P, SZ, SZ, P]),
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
+    "spgan_multi_transpose": (I, [C.POINTER(MultiTransposeArgs), P]),
     "spgan_gemm_tn_splits": (I, [I, I, I]),
     "spgan_splitk_reduce_multi": (I, [C.POINTER(SplitKMultiArgs), P]),
     "spgan_axpby": (I, [F, P, F, P, SZ, P]),

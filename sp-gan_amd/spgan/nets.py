@@ -52,18 +52,56 @@ def _t(w: Tensor) -> Tensor:
     """w^T, contiguous.  For (views of) parameters -- or of their `owned()` detached aliases -- the copy is cached until the
     weights change: the backward passes of a D-step transpose the same matrices five times.  "Changed" = an in-place torch op
     (version counter, shared by detached aliases) or an optimiser step of spgan.optim.Adam, whose HIP kernel updates the flat
-    buffer behind torch's back and bumps ops.WEIGHTS_EPOCH instead."""
+    buffer behind torch's back and bumps ops.WEIGHTS_EPOCH instead.  The first stale hit after such a change re-transposes ALL
+    stale cached matrices in one launch (ops.multi_transpose) instead of one copy kernel per weight."""
     owner = _owner(w)
     if owner is None:
         return w.t().contiguous()
     key = (w.data_ptr(), tuple(w.shape))
     stamp = (ops.WEIGHTS_EPOCH[0], owner._version)
     hit = _T_CACHE.get(key)
-    if hit is not None and hit[0] == stamp and hit[2]() is owner:    # same live Parameter object (not a new one at a recycled address)
-        return hit[1]
+    if hit is not None and hit[2]() is owner:                        # same live Parameter object (not a new one at a recycled address)
+        if hit[0] == stamp:
+            return hit[1]
+        _refresh_transposes()
+        hit = _T_CACHE.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
     t = w.t().contiguous()
-    _T_CACHE[key] = (stamp, t, weakref.ref(owner))
+    _T_CACHE[key] = (stamp, t, weakref.ref(owner), (tuple(w.shape), tuple(w.stride()), w.storage_offset()))
     return t
+
+
+def _refresh_transposes() -> None:
+    epoch = ops.WEIGHTS_EPOCH[0]
+    todo, srcs = [], []
+    for key, (stamp, _t_old, oref, view) in list(_T_CACHE.items()):
+        o = oref()
+        if o is None:
+            del _T_CACHE[key]                                        # the model is gone
+            continue
+        cur = (epoch, o._version)
+        if stamp == cur:
+            continue
+        shape, stride, offset = view
+        try:
+            src = torch.as_strided(o.detach(), shape, stride, offset)
+        except RuntimeError:
+            del _T_CACHE[key]
+            continue
+        if src.data_ptr() != key[0] or (shape[1] > 1 and stride[1] != 1):
+            del _T_CACHE[key]                                        # storage moved / unusual view: rebuilt on its next use
+            continue
+        todo.append((key, cur, oref, view))
+        srcs.append(src)
+    by_dev: Dict[str, list] = {}
+    for i, src in enumerate(srcs):
+        by_dev.setdefault(str(src.device), []).append(i)
+    for ids in by_dev.values():
+        outs = ops.multi_transpose([srcs[i] for i in ids])
+        for i, t in zip(ids, outs):
+            key, cur, oref, view = todo[i]
+            _T_CACHE[key] = (cur, t, oref, view)
 
 
 def _cat2(s0: Tensor, s1: Tensor) -> Tensor:

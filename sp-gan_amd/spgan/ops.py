@@ -942,6 +942,29 @@ def gp_penalty_bwd(g: Tensor, norms: Tensor, gamma: float, lam: float, upstream:
     return v
 
 
+def multi_transpose(srcs) -> list:
+    """[w^T contiguous for w in srcs] (2-D fp32, unit column stride) in one launch per 64 matrices."""
+    from ._lib import MULTI_MAX, MultiTransposeArgs
+    lib = _lib.load()
+    outs = []
+    for i0 in range(0, len(srcs), MULTI_MAX):
+        chunk = srcs[i0:i0 + MULTI_MAX]
+        a = MultiTransposeArgs()
+        a.count = len(chunk)
+        start = 0
+        for e, w in enumerate(chunk):
+            _rowmajor2d(w, "srcs[%d]" % (i0 + e))
+            r, c = w.shape
+            t = torch.empty((c, r), dtype=torch.float32, device=w.device)
+            outs.append(t)
+            a.src[e] = w.data_ptr(); a.dst[e] = t.data_ptr(); a.rows[e] = r; a.cols[e] = c; a.ld[e] = _ld(w)
+            a.tile_start[e] = start
+            start += ((r + 31) // 32) * ((c + 31) // 32)
+        a.tile_start[len(chunk)] = start
+        check(lib.spgan_multi_transpose(C.byref(a), _s()), "multi_transpose", count=len(chunk))
+    return outs
+
+
 def softmax_rows(S: Tensor) -> Tensor:
     """softmax over the last dimension, in place (contiguous [..., cols])."""
     _f32(S, "S")

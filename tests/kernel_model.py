@@ -234,6 +234,10 @@ def bn_dbl_pool(uarg, gval, yarg, pooled, U0, quad, bias, mean, invstd, gamma, S
     return t.contiguous(), spB.contiguous(), out4.contiguous()
 
 
+def multi_transpose(srcs):
+    return [w.t().contiguous() for w in srcs]
+
+
 def softmax_rows(S):
     S.copy_(torch.softmax(S, -1))
     return S

@@ -259,3 +259,16 @@ def test_gemm_tn_deferred_reduce(ops):
     for a, b in zip(now, later):
         assert torch.equal(a, b)
     assert torch.equal(acc0, acc1)
+
+
+def test_multi_transpose(ops):
+    shapes = [(64, 3), (128, 64), (1024, 256), (257, 33), (1, 7), (512, 1024)]
+    srcs = [rnd("mt.%d" % i, s) for i, s in enumerate(shapes)]
+    wide = rnd("mt.wide", (256, 640))
+    srcs.append(wide[:, 512:])                               # column slice: row stride 640
+    outs = ops.multi_transpose(srcs)
+    for w, t in zip(srcs, outs):
+        assert t.is_contiguous() and torch.equal(t, w.t().contiguous())
+    many = [rnd("mt.m%d" % i, (8 + i, 5 + (i % 7))) for i in range(70)]      # more than one launch (64 per launch)
+    for w, t in zip(many, ops.multi_transpose(many)):
+        assert torch.equal(t, w.t().contiguous())
