@@ -63,7 +63,7 @@ def _t(w: Tensor) -> Tensor:
     if hit is not None and hit[2]() is owner:                        # same live Parameter object (not a new one at a recycled address)
         if hit[0] == stamp:
             return hit[1]
-        _refresh_transposes()
+        _refresh_transposes(owner)
         hit = _T_CACHE.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -72,13 +72,19 @@ def _t(w: Tensor) -> Tensor:
     return t
 
 
-def _refresh_transposes() -> None:
+def _refresh_transposes(trigger: Tensor) -> None:
+    """Re-transpose the stale cached matrices of the network `trigger` belongs to (= the parameters that live in the same flat
+    buffer, spgan.optim.flatten_module; an unflattened parameter is its own group) -- never another model's: a captured train
+    step must not read the parameters of a model that may be freed while the graph lives."""
     epoch = ops.WEIGHTS_EPOCH[0]
+    group = trigger.untyped_storage().data_ptr()
     todo, srcs = [], []
     for key, (stamp, _t_old, oref, view) in list(_T_CACHE.items()):
         o = oref()
         if o is None:
             del _T_CACHE[key]                                        # the model is gone
+            continue
+        if o.untyped_storage().data_ptr() != group:
             continue
         cur = (epoch, o._version)
         if stamp == cur:
@@ -94,13 +100,8 @@ def _refresh_transposes() -> None:
             continue
         todo.append((key, cur, oref, view))
         srcs.append(src)
-    by_dev: Dict[str, list] = {}
-    for i, src in enumerate(srcs):
-        by_dev.setdefault(str(src.device), []).append(i)
-    for ids in by_dev.values():
-        outs = ops.multi_transpose([srcs[i] for i in ids])
-        for i, t in zip(ids, outs):
-            key, cur, oref, view = todo[i]
+    if srcs:
+        for (key, cur, oref, view), t in zip(todo, ops.multi_transpose(srcs)):
             _T_CACHE[key] = (cur, t, oref, view)
 
 
