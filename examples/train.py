@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--augment", action="store_true"); ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--out", default="runs/spgan"); ap.add_argument("--choice", default="chair")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lr_decay", action="store_true", help="StepLR on both optimisers, stepped once per epoch (Generation/model.py:99-110,309-312)")
+    ap.add_argument("--lr_decay_feq", type=int, default=40); ap.add_argument("--lr_decay_rate", type=float, default=0.7)
     a = ap.parse_args()
 
     class Opts:                                                # the fields of Generation/config.py the modules read
@@ -49,6 +51,7 @@ def main():
     x = smp.sphere_generator(a.bs)                             # model.py:231
     os.makedirs(a.out, exist_ok=True)
     it = 0
+    scheds = [spgan.optim.StepLR(o, a.lr_decay_feq, a.lr_decay_rate) for o in (step.optG, step.optD)] if a.lr_decay else []
     for epoch in range(a.epochs):
         t0 = time.time()
         for real in data:
@@ -59,6 +62,8 @@ def main():
             epoch, data.num_batches, data.num_batches * a.bs / (time.time() - t0), info["loss_d"].item(), info["loss_g"].item(),
             info["real_acc"].item(), info["fake_acc"].item()))
         tag = os.path.join(a.out, "%d_%s" % (epoch, a.choice))
+        for sch in scheds:
+            sch.step()
         torch.save({"G_model": G.state_dict(), "G_optimizer": step.optG.state_dict(), "G_epoch": epoch}, tag + "_G.pth")
         torch.save({"D_model": D.state_dict(), "D_optimizer": step.optD.state_dict(), "D_epoch": epoch}, tag + "_D.pth")
     G.eval()

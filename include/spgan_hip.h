@@ -382,10 +382,11 @@ int spgan_axpby(float a, const float* x, float b, float* y, size_t n, spgan_stre
 /* torch.optim.Adam step on a flat buffer (Generation/model.py:94-97: lr 1e-4, betas (0.5,0.99)); g is scaled by grad_scale first */
 int spgan_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
                     float grad_scale, spgan_stream_t s);
-/* The same update with the step count in device memory (state3[0] holds the int step count, advanced by this call; state3[1..2]
- * its bias corrections): no host value changes from one step to the next, so a captured hipGraph of the train step replays it. */
+/* The same update with its step-dependent state in device memory: state[0] = int step count (advanced by this call), state[1..2] = its
+ * bias corrections, state[3] = a multiplier on `lr` (1 = lr as passed; the StepLR schedule of Generation/model.py:99-110,309-312 writes
+ * it): no host value changes from one step to the next, so a captured hipGraph of the train step replays it.  state: 4 floats. */
 int spgan_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
-                        float* state3, float grad_scale, spgan_stream_t s);
+                        float* state, float grad_scale, spgan_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * Evaluation metrics: Chamfer distance.

@@ -394,6 +394,7 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const float bc1 = state[1], rsqrt_bc2 = state[2];
+  lr *= state[3];  // learning-rate multiplier in device memory: a schedule changes it without re-capturing the step
   const float gr = g[t] * gscale;
   const float mm = b1 * m[t] + (1.f - b1) * gr;
   const float vv = b2 * v[t] + (1.f - b2) * gr * gr;
@@ -590,7 +591,7 @@ extern "C" int spgan_axpby(float a, const float* x, float b, float* y, size_t n,
 }
 
 extern "C" int spgan_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
-                                   float* state3, float grad_scale, spgan_stream_t s_) {
+                                   float* state3, float grad_scale, spgan_stream_t s_) {  // state3: 4 floats, see spgan_hip.h
   SPGAN_CHECK_ARG(p && g && m && v && state3 && n > 0);
   hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)s_, beta1, beta2, state3);
   hipLaunchKernelGGL(adam_dev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, p, g, m, v, n, lr, beta1, beta2, eps, state3, grad_scale);

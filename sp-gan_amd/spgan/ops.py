@@ -1046,13 +1046,14 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float =
 
 def adam_step_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, state: Tensor, lr: float = 1e-4, beta1: float = 0.5, beta2: float = 0.99,
                   eps: float = 1e-8, grad_scale: float = 1.0) -> None:
-    """adam_step with the step count kept in `state` (3 floats on the device: int step bits, 1-beta1^t, 1/sqrt(1-beta2^t));
-    every call advances it.  Nothing host-side changes between steps: capturable in a hipGraph."""
+    """adam_step with the step count kept in `state` (4 floats on the device: int step bits, 1-beta1^t, 1/sqrt(1-beta2^t), and a
+    multiplier on lr that schedules write); every call advances it.  Nothing host-side changes between steps: capturable in a
+    hipGraph."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _f32(t, n)
         if not t.is_contiguous() or t.numel() != p.numel():
             raise ValueError("adam_step_dev: %s must be contiguous with %d elements" % (n, p.numel()))
     _f32(state, "state")
-    if state.numel() != 3 or not state.is_contiguous():
-        raise ValueError("adam_step_dev: state must be 3 contiguous floats")
+    if state.numel() != 4 or not state.is_contiguous():
+        raise ValueError("adam_step_dev: state must be 4 contiguous floats (step bits, two bias corrections, lr multiplier)")
     check(_lib.load().spgan_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(state), grad_scale, _s()), "adam_step_dev")

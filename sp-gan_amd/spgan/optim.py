@@ -70,7 +70,8 @@ class Adam:
         # capturable: the step count (and its bias corrections) live on the device, so that a hipGraph of the train step can
         # be replayed; `t` stays the host-side mirror (state_dict)
         self.capturable = capturable
-        self.dev_state = torch.zeros(3, dtype=torch.float32, device=self.fp.flat.device) if capturable else None
+        self.dev_state = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=torch.float32, device=self.fp.flat.device) if capturable else None
+        self.base_lr = lr
 
     def zero_grad(self, set_to_none: bool = False):
         self.fp.zero_grad()
@@ -83,11 +84,41 @@ class Adam:
         else:
             ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps, grad_scale)
 
+    def set_lr(self, lr: float) -> None:
+        """Change the learning rate (lr schedules).  In capturable mode the captured kernels keep the lr they were recorded with;
+        the new value enters through the multiplier in the device state, so replayed graphs follow it."""
+        if self.capturable:
+            self.dev_state[3:4].fill_(float(lr) / self.base_lr)
+            self._lr_now = float(lr)
+        else:
+            self.lr = float(lr)
+
+    def get_lr(self) -> float:
+        return getattr(self, "_lr_now", self.lr) if self.capturable else self.lr
+
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr, "betas": self.betas, "eps": self.eps}
+        return {"m": self.m, "v": self.v, "t": self.t, "lr": self.get_lr(), "betas": self.betas, "eps": self.eps}
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = int(sd["t"])
-        self.lr, self.betas, self.eps = sd["lr"], tuple(sd["betas"]), sd["eps"]
+        self.betas, self.eps = tuple(sd["betas"]), sd["eps"]
+        self.set_lr(sd["lr"])
         if self.capturable:
             self.dev_state[:1].view(torch.int32).fill_(self.t)
+
+
+class StepLR:
+    """torch.optim.lr_scheduler.StepLR for spgan.optim.Adam (Generation/model.py:99-110: step_size = lr_decay_feq, gamma =
+    lr_decay_rate, stepped once per epoch at model.py:309-312): lr = base_lr * gamma ** (epoch // step_size)."""
+
+    def __init__(self, optimizer: Adam, step_size: int, gamma: float = 0.1):
+        self.opt, self.step_size, self.gamma = optimizer, int(step_size), float(gamma)
+        self.base_lr = optimizer.get_lr()
+        self.last_epoch = 0
+
+    def step(self) -> None:
+        self.last_epoch += 1
+        self.opt.set_lr(self.base_lr * self.gamma ** (self.last_epoch // self.step_size))
+
+    def get_last_lr(self):
+        return [self.opt.get_lr()]

@@ -494,7 +494,7 @@ def adam_step_dev(p, g, m, v, state, lr=1e-4, beta1=0.5, beta2=0.99, eps=1e-8, g
     state[:1].view(torch.int32).fill_(step)
     state[1] = 1.0 - beta1 ** step
     state[2] = 1.0 / math.sqrt(1.0 - beta2 ** step)
-    adam_step(p, g, m, v, step, lr, beta1, beta2, eps, grad_scale)
+    adam_step(p, g, m, v, step, lr * float(state[3]), beta1, beta2, eps, grad_scale)
 
 
 def act_bwd(dy, y, act, slope=0.0):

@@ -10,7 +10,7 @@ from test_parity_gpu import Opts, _load, sp  # noqa: F401  (sp is a fixture)
 pytestmark = pytest.mark.gpu
 
 
-def _run(sp, graph, steps, B=4, N=256, flags=None):
+def _run(sp, graph, steps, B=4, N=256, flags=None, lr_change_at=None):
     flags = flags or {}
     o = type("O", (Opts,), flags)()
     G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(**flags), salt=8))
@@ -22,6 +22,8 @@ def _run(sp, graph, steps, B=4, N=256, flags=None):
     alpha = fr.uniform("graph.alpha", (B, 1, 1), 0.0, 1.0).cuda()
     losses = []
     for i in range(steps):
+        if lr_change_at is not None and i == lr_change_at:
+            tr.optD.set_lr(5e-5); tr.optG.set_lr(2.5e-5)      # a schedule step (model.py:309-312) after the graph was captured
         info = tr.step(x, real[i % 2], zs[i % 3], zs[(i + 1) % 3], alpha=alpha)
         losses.append((info["loss_d"].item(), info["loss_g"].item()))
     torch.cuda.synchronize()
@@ -40,6 +42,24 @@ def test_graph_replay_equals_eager(sp):
     assert (tre.optG.t, tre.optD.t) == (trg.optG.t, trg.optD.t) == (steps, steps)
     assert torch.equal(tre.optD.m, trg.optD.m) and torch.equal(tre.optG.v, trg.optG.v)
     assert int(trg.optD.dev_state[:1].view(torch.int32).item()) == steps
+
+
+def test_graph_replay_follows_lr_schedule(sp):
+    """A learning-rate change after capture reaches the replayed Adam kernels (device-side multiplier) bit-exactly."""
+    steps = 7
+    Ge, De, tre, le = _run(sp, False, steps, lr_change_at=4)
+    Gg, Dg, trg, lg = _run(sp, True, steps, lr_change_at=4)
+    Gn, Dn, trn, ln = _run(sp, True, steps)
+    assert trg._graph is not None and le == lg and le != ln
+    for (n, a), (_, b) in zip(list(Ge.state_dict().items()) + list(De.state_dict().items()),
+                              list(Gg.state_dict().items()) + list(Dg.state_dict().items())):
+        assert torch.equal(a, b), n
+    assert trg.optD.get_lr() == 5e-5 and trg.optG.state_dict()["lr"] == 2.5e-5
+    from spgan.optim import StepLR
+    sch = StepLR(trg.optD, step_size=2, gamma=0.5)
+    for _ in range(4):
+        sch.step()
+    assert abs(sch.get_last_lr()[0] - 5e-5 * 0.25) < 1e-12
 
 
 def test_graph_replay_attn_eql_variant(sp):
