@@ -244,3 +244,41 @@ def test_bn_and_pool(ops):
     out, arg = ops.maxpool(y, B, N)
     out2, arg2 = km.maxpool(y, B, N)
     assert torch.equal(out, out2) and torch.equal(arg, arg2)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 64, 32), (129, 65, 36), (1024, 256, 256), (1000, 192, 132), (4096, 1024, 256), (640, 320, 64), (2048, 64, 640),
+                                   (257, 128, 1280), (65, 33, 8)])
+def test_gemm_nt_full_and_partial_tiles(ops, M, N, K):
+    """Every epilogue on shapes whose output tiles are all inside, all ragged, or mixed (the straight-line path serves the inside
+    tiles, the generic path the rest -- both must agree with the model on the same launch), operands as column slices."""
+    wideA, wideW = rnd("ft.A%d%d" % (M, K), (M, K + 8)), rnd("ft.W%d%d" % (N, K), (N, K + 4), 0.1)
+    A, W = wideA[:, 4:4 + K], wideW[:, :K]
+    b = rnd("ft.b%d" % N, (N,))
+    for act in (0, 1, 2):
+        close(ops.gemm_nt(A, W, b, act=act, slope=0.2), km.gemm_nt(A, W, b, act=act, slope=0.2), rtol=5e-5, what="act%d" % act)
+    sc, sh = rnd("ft.sc%d" % K, (K,)).abs() + 0.5, rnd("ft.sh%d" % K, (K,), 0.3)
+    y, m, v = ops.gemm_nt(A, W, b, pro=(sc, sh, 0.01), stats=True)
+    y2, m2, v2 = km.gemm_nt(A, W, b, pro=(sc, sh, 0.01), stats=True)
+    close(y, y2, rtol=5e-5, what="affine"); close(m, m2, atol=2e-5, what="mean"); close(v, v2, rtol=1e-4, what="var")
+    out = torch.full((M, N + 12), 9.0, device="cuda")
+    ops.gemm_nt(A, W, b, out=out[:, 4:4 + N])
+    close(out[:, 4:4 + N], km.gemm_nt(A, W, b), rtol=5e-5, what="strided out")
+    assert (out[:, :4] == 9).all() and (out[:, 4 + N:] == 9).all()
+    ref = rnd("ft.ref%d%d" % (M, N), (M, N + 4))[:, :N]
+    close(ops.gemm_nt_maskout(A, W, ref, 0.01), km.gemm_nt_maskout(A, W, ref, 0.01), rtol=5e-5, what="maskout")
+    bsc, bsh = rnd("ft.bsc%d" % N, (N,)), rnd("ft.bsh%d" % N, (N,), 0.3)
+    mean, inv = rnd("ft.mu%d" % N, (N,), 0.2), rnd("ft.inv%d" % N, (N,)).abs() + 0.5
+    for name, a_, b_ in zip(("g", "s0", "s1"), ops.gemm_nt_bnbwd(A, W, ref, bsc, bsh, mean, inv, 0.01, bias=b),
+                            km.gemm_nt_bnbwd(A, W, ref, bsc, bsh, mean, inv, 0.01, bias=b)):
+        close(a_, b_, rtol=1e-4, atol=5e-4, what="bnbwd " + name)
+    if M % 128 == 0 and M > 64:
+        gamma, beta = rnd("ft.ga%d" % N, (N,)).abs() + 0.5, rnd("ft.be%d" % N, (N,), 0.1)
+        rows = 128 if M % 256 else 256
+        got = ops.gemm_bn_pool(A, W, b, (gamma, beta, None, None), rows, 0.01, pro=(sc, sh, 0.01), keep_y=True)
+        want = km.gemm_bn_pool(A, W, b, (gamma, beta, None, None), rows, 0.01, pro=(sc, sh, 0.01), keep_y=True)
+        close(got[0], want[0], rtol=5e-5, what="pool y")
+        for g_, w_ in zip(got[1], want[1]):
+            close(g_, w_, rtol=1e-4, atol=2e-5, what="pool bn")
+        close(got[2], want[2], rtol=1e-4, atol=2e-5, what="pooled")
+    A2, B2 = rnd("ft.ta%d" % M, (M, N)), rnd("ft.tb%d" % M, (M, K))
+    close(ops.gemm_tn(A2, B2), A2.double().t().matmul(B2.double()).float(), rtol=5e-5, atol=1e-4, what="tn")
