@@ -355,7 +355,8 @@ typedef struct spgan_multi_add_args {
 } spgan_multi_add_args;
 int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s);
 /* Finish up to SPGAN_MULTI_MAX deferred spgan_gemm_tn products in one launch: C[e] = beta[e]*C[e] + fixed-order sum of the
- * splits[e] = spgan_gemm_tn_splits(M,Na,Nb) partials [splits, Na, Nb] in ws[e].  block_start[e] = sum_{f<e} ceil(Na[f]*Nb[f]/64). */
+ * splits[e] = spgan_gemm_tn_splits(M,Na,Nb) partials [splits, Na, Nb] in ws[e].  block_start[e] = sum_{f<e}
+ * spgan_splitk_reduce_blocks(splits[f], Na[f], Nb[f]) (64 outputs per workgroup, or 4 -- one wave each -- for many partials of few outputs). */
 typedef struct spgan_splitk_multi_args {
   int count;
   const float* ws[SPGAN_MULTI_MAX];
@@ -376,6 +377,7 @@ typedef struct spgan_multi_transpose_args {
 } spgan_multi_transpose_args;
 int spgan_multi_transpose(const spgan_multi_transpose_args* a, spgan_stream_t s);
 int spgan_gemm_tn_splits(int M, int Na, int Nb);
+int spgan_splitk_reduce_blocks(int splits, int Na, int Nb);
 int spgan_splitk_reduce_multi(const spgan_splitk_multi_args* a, spgan_stream_t s);
 /* y = a*x + b*y */
 int spgan_axpby(float a, const float* x, float b, float* y, size_t n, spgan_stream_t s);

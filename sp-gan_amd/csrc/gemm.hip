@@ -1245,6 +1245,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// Many partials of few outputs (the skinny products: 512 x [64,3]): 64 outputs x 4
+// slices per workgroup would leave three workgroups walking 128 partials per thread -- here one WAVE owns an output, its lanes
+// take the partials k = lane, lane+64, ... and a fixed butterfly adds them up.
+inline bool reduce_by_wave(int splits, long n) { return splits >= 32 && n <= 1024; }  // beyond ~1k outputs the k-strided lane reads thrash (15 us for 8192 outputs)
+inline int reduce_blocks(int splits, long n) { return reduce_by_wave(splits, n) ? cdiv(n, 4) : cdiv(n, 64); }
+
+__device__ __forceinline__ void splitk_reduce_wave(const float* __restrict__ ws, int splits, int Na, int Nb, float* __restrict__ C, int ldc,
+                                                   float beta, int block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = block * 4 + wave;
+  if (i >= Na * Nb) return;
+  const size_t stride = (size_t)Na * Nb;
+  float s = 0.f;
+  for (int k = lane; k < splits; k += 64) s += ws[(size_t)k * stride + i];
+  s = wave_sum(s);
+  if (lane == 0) {
+    float* o = C + (size_t)(i / Nb) * ldc + (i % Nb);
+    *o = (beta == 0.f) ? s : fmaf(beta, *o, s);
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_wave_kernel(const float* __restrict__ ws, int splits, int Na, int Nb, float* __restrict__ C,
+                                                                 int ldc, float beta) {
+  splitk_reduce_wave(ws, splits, Na, Nb, C, ldc, beta, blockIdx.x);
+}
+
 // The same reduction for up to SPGAN_MULTI_MAX pending products in one launch (spgan_splitk_reduce_multi): block b serves
 // entry e with start[e] <= b < start[e+1].
 __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const spgan_splitk_multi_args a) {
@@ -1254,6 +1280,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const spgan_sp
   const float* __restrict__ ws = a.ws[e];
   const int splits = a.splits[e], Na = a.Na[e], Nb = a.Nb[e], ldc = a.ldc[e];
   const float beta = a.beta[e];
+  if (splits >= 32 && (long)Na * Nb <= 1024) {  // reduce_by_wave (uniform per workgroup; no barrier on this path)
+    splitk_reduce_wave(ws, splits, Na, Nb, a.C[e], ldc, beta, (int)blockIdx.x - a.block_start[e]);
+    return;
+  }
   const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int i = ((int)blockIdx.x - a.block_start[e]) * 64 + lane;
   const size_t stride = (size_t)Na * Nb;
@@ -1279,7 +1309,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const spgan_sp
 inline int tn_tb(int Nb) { return Nb > 64 ? 128 : (Nb > 32 ? 64 : 32); }
 
 // Split choice: about two workgroups per CU in total, at least 256 m-rows each.
+// One side of the product has <= 4 columns (the weight gradients of the 3-channel layers: D's first conv, the generator's tail.4
+// and pc inputs): nothing for the matrix cores to do -- gemm_tn_skinny_kernel streams the wide operand once.
+inline bool tn_skinny(int Na, int Nb) { return (Na <= 4 || Nb <= 4) && Na <= 2048 && Nb <= 2048; }
+
 inline void tn_plan(int M, int Na, int Nb, int* splits, int* rows) {
+  if (tn_skinny(Na, Nb)) {
+    int r = cdiv(cdiv(M, 1024), TKM) * TKM;  // <= 1024 partials, each over a multiple of TKM rows (the MFMA kernel may have to serve the plan)
+    if (r < 128) r = 128;
+    *rows = r;
+    *splits = cdiv(M, r);
+    return;
+  }
   const int tiles = cdiv(Na, TA) * cdiv(Nb, tn_tb(Nb));
   int want = cdiv(512, tiles);
   int r = cdiv(M, want);
@@ -1289,10 +1330,79 @@ inline void tn_plan(int M, int Na, int Nb, int* splits, int* rows) {
   *splits = cdiv(M, r);
 }
 
+// out[split][Na][Nb] partials of A^T B when A or B has <= 4 columns: 64 columns of the wide operand x 4 row-lanes per workgroup,
+// the narrow operand's row is a broadcast load; the four row-lanes are summed in a fixed order.
+template <bool NARROW_B>
+__global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(const spgan_gemm_tn_args p, int rows_per_split) {
+  __shared__ float red[4][4][64];
+  const int split = blockIdx.y;
+  const int mbeg = split * rows_per_split, mend = min(p.M, mbeg + rows_per_split);
+  const float* __restrict__ Lm = NARROW_B ? p.A : p.B;
+  const float* __restrict__ Sm = NARROW_B ? p.B : p.A;
+  const int ldl = NARROW_B ? p.lda : p.ldb, lds_ = NARROW_B ? p.ldb : p.lda;
+  const int Ln = NARROW_B ? p.Na : p.Nb, Sn = NARROW_B ? p.Nb : p.Na;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int l = blockIdx.x * 64 + cl;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (l < Ln) {
+    int m = mbeg + rl;
+    for (; m + 28 < mend; m += 32) {  // 8 rows in flight per thread
+      float v[8], sv[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = Lm[(size_t)(m + 4 * u) * ldl + l];
+        const float* srow = Sm + (size_t)(m + 4 * u) * lds_;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv[u][q] = (q < Sn) ? srow[q] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fmaf(v[u], sv[u][q], acc[q]);
+    }
+    for (; m < mend; m += 4) {
+      const float v = Lm[(size_t)m * ldl + l];
+      const float* srow = Sm + (size_t)m * lds_;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < Sn) acc[q] = fmaf(v, srow[q], acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[rl][q][cl] = acc[q];
+  __syncthreads();
+  if (rl == 0 && l < Ln) {
+    float* out = p.ws + (size_t)split * p.Na * p.Nb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < Sn) {
+        const float v = (red[0][q][cl] + red[1][q][cl]) + (red[2][q][cl] + red[3][q][cl]);
+        if (NARROW_B) out[(size_t)l * p.Nb + q] = v;
+        else out[(size_t)q * p.Nb + l] = v;
+      }
+  }
+}
+
+inline void launch_reduce(const spgan_gemm_tn_args& a, int splits, hipStream_t s) {
+  const long n = (long)a.Na * a.Nb;
+  if (reduce_by_wave(splits, n))
+    hipLaunchKernelGGL(splitk_reduce_wave_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
+}
+
 template <int BMODE>
 int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
   int splits, rows;
   tn_plan(a.M, a.Na, a.Nb, &splits, &rows);
+  if (BMODE == SPGAN_A_PLAIN && !a.a_scale && tn_skinny(a.Na, a.Nb)) {
+    const bool narrow_b = a.Nb <= 4;
+    const dim3 g(cdiv(narrow_b ? a.Na : a.Nb, 64), splits);
+    if (narrow_b) hipLaunchKernelGGL((gemm_tn_skinny_kernel<true>), g, dim3(256), 0, s, a, rows);
+    else hipLaunchKernelGGL((gemm_tn_skinny_kernel<false>), g, dim3(256), 0, s, a, rows);
+    if (!a.defer_reduce) launch_reduce(a, splits, s);
+    return spgan_launch_status();
+  }
   const int TB = tn_tb(a.Nb);
   const dim3 grid(cdiv(a.Na, TA) * cdiv(a.Nb, TB), splits);
   const bool fast = (a.Na % 4 == 0) && (a.Nb % 4 == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && al16(a.A) && al16(a.B);
@@ -1305,9 +1415,7 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
     else if (TB == 64) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 1, 0>), grid, dim3(256), 0, s, a, rows);
     else hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 2, 0>), grid, dim3(256), 0, s, a, rows);
   }
-  const int n = a.Na * a.Nb;
-  if (!a.defer_reduce)  // deferred: the caller sums the partials later, batched with others (spgan_splitk_reduce_multi)
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
+  if (!a.defer_reduce) launch_reduce(a, splits, s);  // deferred: the caller sums the partials later, batched with others (spgan_splitk_reduce_multi)
   if constexpr (BMODE != SPGAN_A_EDGE) {
     if (a.a_sp_val) hipLaunchKernelGGL((tn_sparse_rows_kernel<BMODE>), dim3(a.Na), dim3(256), 0, s, a);
   }
@@ -1393,11 +1501,16 @@ extern "C" int spgan_gemm_tn_splits(int M, int Na, int Nb) {
   return splits;
 }
 
+extern "C" int spgan_splitk_reduce_blocks(int splits, int Na, int Nb) {
+  if (splits <= 0 || Na <= 0 || Nb <= 0) return 0;
+  return reduce_blocks(splits, (long)Na * Nb);
+}
+
 extern "C" int spgan_splitk_reduce_multi(const spgan_splitk_multi_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a && a->count > 0 && a->count <= SPGAN_MULTI_MAX && a->block_start[0] == 0);
   for (int e = 0; e < a->count; ++e) {
     SPGAN_CHECK_ARG(a->ws[e] && a->C[e] && a->splits[e] > 0 && a->Na[e] > 0 && a->Nb[e] > 0 && a->ldc[e] >= a->Nb[e]);
-    SPGAN_CHECK_ARG(a->block_start[e + 1] - a->block_start[e] == cdiv((long)a->Na[e] * a->Nb[e], 64));
+    SPGAN_CHECK_ARG(a->block_start[e + 1] - a->block_start[e] == reduce_blocks(a->splits[e], (long)a->Na[e] * a->Nb[e]));
   }
   hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(a->block_start[a->count]), dim3(256), 0, (hipStream_t)s_, *a);
   return spgan_launch_status();

@@ -158,6 +158,7 @@ SIGNATURES = {
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
     "spgan_multi_transpose": (I, [C.POINTER(MultiTransposeArgs), P]),
     "spgan_gemm_tn_splits": (I, [I, I, I]),
+    "spgan_splitk_reduce_blocks": (I, [I, I, I]),
     "spgan_splitk_reduce_multi": (I, [C.POINTER(SplitKMultiArgs), P]),
     "spgan_axpby": (I, [F, P, F, P, SZ, P]),
     "spgan_adam_step": (I, [P, P, P, P, SZ, F, F, F, F, I, F, P]),

@@ -401,7 +401,7 @@ def flush_tn() -> None:
         for e, (ws, out, splits, Na, Nb, ldc, beta) in enumerate(chunk):
             a.ws[e] = ws.data_ptr(); a.C[e] = out.data_ptr(); a.splits[e] = splits; a.Na[e] = Na; a.Nb[e] = Nb; a.ldc[e] = ldc; a.beta[e] = beta
             a.block_start[e] = start
-            start += (Na * Nb + 63) // 64
+            start += lib.spgan_splitk_reduce_blocks(splits, Na, Nb)
         a.block_start[len(chunk)] = start
         check(lib.spgan_splitk_reduce_multi(C.byref(a), _s()), "splitk_reduce_multi", count=len(chunk))
 

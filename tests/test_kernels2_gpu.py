@@ -272,3 +272,18 @@ def test_multi_transpose(ops):
     many = [rnd("mt.m%d" % i, (8 + i, 5 + (i % 7))) for i in range(70)]      # more than one launch (64 per launch)
     for w, t in zip(many, ops.multi_transpose(many)):
         assert torch.equal(t, w.t().contiguous())
+
+
+@pytest.mark.parametrize("M,Na,Nb", [(65536, 64, 3), (65536, 3, 64), (2048, 160, 3), (1000, 1, 37), (777, 129, 4), (300, 4, 4), (65536, 3, 256)])
+def test_gemm_tn_skinny(ops, M, Na, Nb):
+    """Weight gradients of the 3-channel layers (one operand with <= 4 columns): the streaming kernel instead of MFMA tiles."""
+    A, B = rnd("sk.a%d%d" % (M, Na), (M, Na + 4))[:, :Na], rnd("sk.b%d%d" % (M, Nb), (M, Nb + 5))[:, 2:2 + Nb]
+    want = A.double().t().matmul(B.double()).float()
+    close(ops.gemm_tn(A, B), want, rtol=3e-5, atol=2e-4, what="skinny")
+    acc = rnd("sk.c%d%d" % (Na, Nb), (Na, Nb)); acc2 = acc.clone()
+    ops.gemm_tn(A, B, out=acc, beta=1.0)
+    close(acc, acc2 + want, rtol=3e-5, atol=2e-4, what="skinny beta")
+    d = ops.gemm_tn(A, B, defer=True); ops.flush_tn()
+    assert torch.equal(d, ops.gemm_tn(A, B))
+    sc, sh = rnd("sk.sc%d" % Nb, (Nb,)).abs() + 0.5, rnd("sk.sh%d" % Nb, (Nb,), 0.3)       # a prologue keeps the MFMA kernel on the skinny plan
+    close(ops.gemm_tn(A, B, pro=(sc, sh, 0.01)), km.gemm_tn(A, B, pro=(sc, sh, 0.01)), rtol=5e-5, atol=3e-4, what="skinny plan, mfma kernel")
