@@ -1229,6 +1229,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   float s0 = 0.f, s1 = 0.f;
   if (i < Na * Nb) {
     int k = sl;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (; k + 28 < splits; k += 32) {  // eight partials in flight per thread (a long split list is latency-bound otherwise)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += ws[(size_t)(k + 4 * u) * stride + i];
+    }
+    s0 = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     for (; k + 4 < splits; k += 8) {
       s0 += ws[(size_t)k * stride + i];
       s1 += ws[(size_t)(k + 4) * stride + i];
@@ -1290,6 +1296,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const spgan_sp
   float s0 = 0.f, s1 = 0.f;
   if (i < Na * Nb) {
     int k = sl;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (; k + 28 < splits; k += 32) {  // eight partials in flight per thread (a long split list is latency-bound otherwise)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += ws[(size_t)(k + 4 * u) * stride + i];
+    }
+    s0 = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     for (; k + 4 < splits; k += 8) {
       s0 += ws[(size_t)k * stride + i];
       s1 += ws[(size_t)(k + 4) * stride + i];
