@@ -80,6 +80,21 @@ __global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restric
   if (cok) {
     const float2* base = reinterpret_cast<const float2*>(part) + (size_t)g * tiles_per_group * C + c;
     int t = sl;
+    for (; t + 7 * FS < tiles_per_group; t += 8 * FS) {  // eight independent loads in flight (512 tiles: two rounds per thread)
+      float2 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = base[(size_t)(t + u * FS) * C];
+      if (mode == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float nb = (float)min(tile_rows, G - (t + u * FS) * tile_rows);
+          chan_merge(n, a, b, nb, q[u].x / nb, q[u].y);
+        }
+      } else {
+        a += ((q[0].x + q[1].x) + (q[2].x + q[3].x)) + ((q[4].x + q[5].x) + (q[6].x + q[7].x));
+        b += ((q[0].y + q[1].y) + (q[2].y + q[3].y)) + ((q[4].y + q[5].y) + (q[6].y + q[7].y));
+      }
+    }
     for (; t + 3 * FS < tiles_per_group; t += 4 * FS) {  // four independent loads in flight
       const float2 p0 = base[(size_t)t * C], p1 = base[(size_t)(t + FS) * C], p2 = base[(size_t)(t + 2 * FS) * C],
                    p3 = base[(size_t)(t + 3 * FS) * C];
