@@ -21,8 +21,16 @@ __global__ __launch_bounds__(256) void colpartials_kernel(const float* __restric
   const float* base = X + ((size_t)g * G + r0) * ldx;
   const bool cok = c < C;
   float s = 0.f;
-  if (cok)
-    for (int r = sl; r < cnt; r += 4) s += lrelu_f(base[(size_t)r * ldx + c], slope);
+  if (cok) {
+    int r = sl;
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (; r + 28 < cnt; r += 32) {  // eight rows in flight per thread
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += lrelu_f(base[(size_t)(r + 4 * u) * ldx + c], slope);
+    }
+    s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    for (; r < cnt; r += 4) s += lrelu_f(base[(size_t)r * ldx + c], slope);
+  }
   red[sl][threadIdx.x & 63] = s;
   __syncthreads();
   const float tot = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63]) + (red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]);
