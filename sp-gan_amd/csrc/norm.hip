@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void colpartials_kernel(const float* __restric
     __syncthreads();
     float m2 = 0.f;
     if (cok)
-      for (int r = sl; r < cnt; r += 4) {
+  #pragma unroll 8
+    for (int r = sl; r < cnt; r += 4) {
         const float d = lrelu_f(base[(size_t)r * ldx + c], slope) - mean;
         m2 = fmaf(d, d, m2);
       }
@@ -277,16 +278,25 @@ __global__ __launch_bounds__(256) void maxpool_v4_kernel(const float* __restrict
   const float* base = y + (size_t)b * N * ld + c;
   float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   int bi[4] = {0, 0, 0, 0};
-  if (cok)
-    for (int n = sl; n < N; n += 16) {
-      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)n * ld);
+  if (cok) {
+    auto take = [&](const float4 v, int n) {
       const float t0 = lrelu_f(fmaf(v.x, sc.x, sh.x), slope), t1 = lrelu_f(fmaf(v.y, sc.y, sh.y), slope);
       const float t2 = lrelu_f(fmaf(v.z, sc.z, sh.z), slope), t3 = lrelu_f(fmaf(v.w, sc.w, sh.w), slope);
       if (t0 > best[0]) { best[0] = t0; bi[0] = n; }
       if (t1 > best[1]) { best[1] = t1; bi[1] = n; }
       if (t2 > best[2]) { best[2] = t2; bi[2] = n; }
       if (t3 > best[3]) { best[3] = t3; bi[3] = n; }
+    };
+    int n = sl;
+    for (; n + 7 * 16 < N; n += 8 * 16) {  // eight rows in flight, consumed in row order (strict '>' keeps the first maximum)
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (size_t)(n + 16 * u) * ld);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) take(v[u], n + 16 * u);
     }
+    for (; n < N; n += 16) take(*reinterpret_cast<const float4*>(base + (size_t)n * ld), n);
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { rv[sl][q * 4 + j] = best[j]; ri[sl][q * 4 + j] = bi[j]; }
   __syncthreads();

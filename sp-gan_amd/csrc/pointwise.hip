@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void adain_bwd1_kernel(const float* __restrict
   float s0 = 0.f, s1 = 0.f;
   if (ok) {
     const float mu = imean[(size_t)b * C + c], iv = rsqrtf(ivar[(size_t)b * C + c] + eps);
+#pragma unroll 8
     for (int r = sl; r < cnt; r += 4) {
       const size_t m = (size_t)b * N + n0 + r;
       const float d = dout[m * C + c];
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256) void bn_dbl_stats_kernel(const float* __restri
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (ok) {
     const float mu = mean[c], iv = invstd[c];
+#pragma unroll 8
     for (int r = sl; r < cnt; r += 4) {
       const size_t o = (size_t)(m0 + r) * C + c;
       const float uv = u[o];
