@@ -34,8 +34,7 @@ __global__ __launch_bounds__(256) void adain_bwd1_kernel(const float* __restrict
   float s0 = 0.f, s1 = 0.f;
   if (ok) {
     const float mu = imean[(size_t)b * C + c], iv = rsqrtf(ivar[(size_t)b * C + c] + eps);
-#pragma unroll 8
-    for (int r = sl; r < cnt; r += 4) {
+    for (int r = sl; r < cnt; r += 4) {  // (two stores per row: unrolling this one by 8 made it slower, 30 -> 46 us)
       const size_t m = (size_t)b * N + n0 + r;
       const float d = dout[m * C + c];
       const float xh = (lrelu_f(x[m * C + c], slope) - mu) * iv;
