@@ -58,7 +58,9 @@ def make_inputs(dev, rank, b):
     from spgan import fixture_rng as fr
     x = fr.sphere_template(N_POINTS)[None].repeat(b, 1, 1).to(dev)
     real = fr.synthetic_real(b, N_POINTS, seed=1234 + rank).to(dev)
-    zs = [fr.latent(b, N_POINTS, NZ, seed=4321 + rank + i).to(dev) for i in range(4)]
+    # one latent per shape (the reference's default noise_generator, model.py:128-131); passed un-tiled [b,1,nz] -- spgan.Generator
+    # evaluates the latent half of head.0 per shape instead of tiling it over the 2048 points first
+    zs = [fr.latent(b, N_POINTS, NZ, seed=4321 + rank + i)[:, :1, :].contiguous().to(dev) for i in range(4)]
     alpha = fr.uniform("bench.alpha.%d" % rank, (b, 1, 1), 0.0, 1.0).to(dev)
     return x, real, zs, alpha
 

@@ -55,7 +55,7 @@ def main():
     for epoch in range(a.epochs):
         t0 = time.time()
         for real in data:
-            info = step.step(x, real, smp.noise_generator(a.bs), smp.noise_generator(a.bs))
+            info = step.step(x, real, smp.noise_generator(a.bs, compact=True), smp.noise_generator(a.bs, compact=True))
             it += 1
         torch.cuda.synchronize()
         print("epoch %d: %d steps, %.1f shapes/s, lossD %.4f lossG %.4f real_acc %.2f fake_acc %.2f" % (

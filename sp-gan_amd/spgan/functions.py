@@ -262,6 +262,42 @@ class ScaleFn(Function):
         return _deliver((w,), [gw], ctx.needs_input_grad[:1]) + (None,)
 
 
+class HeadFn(Function):
+    """The style branch for a latent that is constant over the points of a shape (the default `noise_generator`, model.py:128-131:
+    one vector per shape tiled over N): head.0([x, z]) = Wx.x + (Wz.z + b) -- the 128-wide latent half is a per-shape bias
+    ([B,128], one small GEMM) and only the three coordinate channels are contracted per point, instead of a 131-wide GEMM over all
+    B*N rows of a materialised cat[x, z] (Generator.py:166-169).  inputs: holder(N), x_pm [M,3], zb [B,nz], head.0 w/b, head.2 w/b."""
+
+    @staticmethod
+    def forward(ctx, holder, x_pm, zb, w0, b0, w2, b2):
+        W0 = nets._w2(w0)
+        c = x_pm.shape[1]
+        rb = ops.gemm_nt(zb.contiguous(), W0[:, c:], b0)                               # [B,128]
+        P = {"head.0.weight": w0, "head.0.bias": b0, "head.2.weight": w2, "head.2.bias": b2}
+        out, mctx = nets.mlp_forward(P, ["head.0", "head.2"], [ops.ACT_LRELU, ops.ACT_LRELU], x_pm.contiguous(), nets.NEG,
+                                     rowbias=rb, N=holder.N, first_weight=W0[:, :c])
+        ctx.mctx, ctx.c = mctx, c
+        ctx.save_for_backward(zb, w0, b0, w2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        zb, w0, b0, w2, b2 = ctx.saved_tensors
+        params = (w0, b0, w2, b2)
+        P = {"head.0.weight": nets.owned(w0), "head.0.bias": nets.owned(b0), "head.2.weight": nets.owned(w2), "head.2.bias": nets.owned(b2)}
+        W0 = nets._w2(P["head.0.weight"])
+        ctx.mctx["first_weight"] = W0[:, :ctx.c]
+        need_p = any(ctx.needs_input_grad[3:])
+        dx, g, drb = nets.mlp_backward(P, ctx.mctx, dout, ctx.needs_input_grad[1], need_p)
+        dz = ops.gemm_nt(drb, nets._t(W0[:, ctx.c:])) if ctx.needs_input_grad[2] else None
+        grads = [None] * 4
+        if need_p:
+            gz = ops.gemm_tn(drb, zb.contiguous())                                       # [128, nz]
+            ops.flush_tn()
+            grads = [torch.cat([g["head.0.weight.part"], gz], dim=1).view_as(w0), ops.colsum(drb)[0], g["head.2.weight"], g["head.2.bias"]]
+        return (None, dx, dz) + _deliver(params, grads, ctx.needs_input_grad[3:])
+
+
 GF_NAMES = ("global_conv.0.weight", "global_conv.0.bias", "global_conv.1.weight", "global_conv.1.bias",
             "global_conv.3.weight", "global_conv.3.bias", "global_conv.4.weight", "global_conv.4.bias")
 

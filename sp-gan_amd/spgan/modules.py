@@ -267,9 +267,14 @@ class Generator(nn.Module, _BNCounts):
         return Fn.MLPFn.apply(h, x_pm, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias)
 
     def _style(self, x, z):
+        """head(cat[x, z]) (Generator.py:163-169).  z [B,N,nz] as in the reference, or [B,1,nz]: one latent per shape, i.e. what the
+        default noise_generator tiles over the points -- then the latent half of head.0 is evaluated once per shape (HeadFn)."""
         B, N, _ = x.shape
         if self.opts.z_norm:
             z = z / (z.norm(p=2, dim=-1, keepdim=True) + 1e-8)
+        if z.dim() == 3 and z.shape[1] == 1 and N > 1:
+            h0, h2 = self.head[0], self.head[2]
+            return Fn.HeadFn.apply(_Holder(N=N), x.reshape(B * N, 3), z.reshape(B, -1), h0.weight, h0.bias, h2.weight, h2.bias)
         hz = ops.concat2(x.reshape(B * N, 3), z.reshape(B * N, -1))
         return self._mlp2(self.head, hz)
 

@@ -58,8 +58,9 @@ class InputSampler:
         return torch.argsort(d, dim=1, stable=True)
 
     # ------------------------------------------------------------------ latent noise
-    def noise_generator(self, bs: int = 1, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """model.py:122-154 -> [bs, np, nz].
+    def noise_generator(self, bs: int = 1, masks: Optional[torch.Tensor] = None, compact: bool = False) -> torch.Tensor:
+        """model.py:122-154 -> [bs, np, nz]; compact=True (default mode only: one latent per shape, no n_rand / n_mix / masks)
+        returns the un-tiled [bs, 1, nz], which spgan.Generator accepts as is and evaluates per shape instead of per point.
         default: one N(0, nv^2) vector per shape, tiled over the points; n_rand: independent per point; n_mix: with
         probability 1/2 a random region (the `num` points closest to a random centre in ball_dist order, num =
         max(U,0.1)*np) of every shape gets a second vector.  masks [bs,np] (part labels): one N(0, 0.2^2) vector per part
@@ -76,7 +77,10 @@ class InputSampler:
         if o.n_rand:
             noise = torch.randn((bs, o.np, o.nz), generator=g, device=dev) * o.nv
         else:
-            noise = (torch.randn((bs, 1, o.nz), generator=g, device=dev) * o.nv).repeat(1, o.np, 1)
+            noise = torch.randn((bs, 1, o.nz), generator=g, device=dev) * o.nv
+            if compact and not getattr(o, "n_mix", False):
+                return noise
+            noise = noise.repeat(1, o.np, 1)
         if getattr(o, "n_mix", False) and torch.rand((), generator=g, device=dev).item() < 0.5:
             noise2 = torch.randn((bs, o.nz), generator=g, device=dev) * o.nv
             centre = torch.randint(0, o.np, (bs,), generator=g, device=dev)

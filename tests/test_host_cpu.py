@@ -258,3 +258,22 @@ def test_generator_attn_eql(spgan_cpu, flags):
     for n, g in zip(names, grads):
         plain = n.replace(".linear.", ".").replace(".conv.", ".")
         _cmp("grad " + n, dict(G.named_parameters())[n].grad, g, 3e-2, atol=2e-3 if plain.endswith(ZERO_GRAD_BIASES) else 1e-7)
+
+
+def test_generator_per_shape_latent(spgan_cpu):
+    """z [B,1,nz] (one latent per shape, what noise_generator tiles over N) == the tiled [B,N,nz] input: forward and all gradients."""
+    B, N = 3, 64
+    p = fr.init_params(orc.generator_shapes(), salt=51)
+    x = fr.sphere_template(256)[None, :N].repeat(B, 1, 1).contiguous()
+    z1 = fr.latent(B, N, seed=53)[:, :1, :].contiguous()
+    dy = None
+    res = []
+    for z in (z1, z1.expand(B, N, -1).contiguous()):
+        G = _load(spgan_cpu.modules.Generator(Opts), p).train()
+        out = G(x, z)
+        dy = fr.normal("hps.dy", out.shape) if dy is None else dy
+        (out * dy).sum().backward()
+        res.append((out.detach(), {n: q.grad.clone() for n, q in G.named_parameters()}))
+    _cmp("out", res[0][0], res[1][0], 1e-5)
+    for n in res[0][1]:
+        _cmp("grad " + n, res[0][1][n], res[1][1][n], 2e-3, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-6)
