@@ -209,6 +209,10 @@ int spgan_bn_prepare(const float* mean, const float* var, const float* gamma, co
 /* dy[m,c] = gamma[c]*invstd[c]*( g[m,c] - sums[c]/count - xhat[m,c]*sums[C+c]/count ),  xhat=(y-mean)*invstd */
 int spgan_bn_bwd_apply(const float* g, const float* y, int ld, int M, int C, const float* mean, const float* invstd,
                        const float* gamma, const float* sums, int count, float* dy, spgan_stream_t s);
+/* The same with g := g + g2scale[c]*g2 formed on the fly (contiguous [M,C], C % 4 == 0, 16-byte aligned): the double backward's
+ * xbarA + gamma*g (BatchNorm backward of the gradient-penalty graph) without a separate elementwise pass. */
+int spgan_bn_bwd_apply2(const float* g, const float* g2, const float* g2scale, const float* y, int M, int C, const float* mean,
+                        const float* invstd, const float* gamma, const float* sums, int count, float* dy, spgan_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * Global max over the N points of each shape (Generator.py:183; Discriminator.py:104) fused with

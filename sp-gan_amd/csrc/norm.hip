@@ -204,14 +204,20 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
 __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ g, const float* __restrict__ y, int ld, unsigned total4,
                                                               int C, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ sums, float rcount,
-                                                              float* __restrict__ dy) {
+                                                              float* __restrict__ dy, const float* __restrict__ g2,
+                                                              const float* __restrict__ g2scale) {
   const unsigned t = blockIdx.x * 256u + threadIdx.x;
   if (t >= total4) return;
   const unsigned c4n = (unsigned)C >> 2;
   const unsigned m = t / c4n;
   const int c = (int)(t - m * c4n) * 4;
   const size_t o = (size_t)m * ld + c;
-  const float4 gv = *reinterpret_cast<const float4*>(g + o), yv = *reinterpret_cast<const float4*>(y + o);
+  float4 gv = *reinterpret_cast<const float4*>(g + o);
+  const float4 yv = *reinterpret_cast<const float4*>(y + o);
+  if (g2) {  // g + g2scale[c]*g2 formed on the fly (the double-backward's xbarA + gamma*g without a pass of its own)
+    const float4 hv = *reinterpret_cast<const float4*>(g2 + (size_t)m * C + c), hs = *reinterpret_cast<const float4*>(g2scale + c);
+    gv.x = fmaf(hs.x, hv.x, gv.x); gv.y = fmaf(hs.y, hv.y, gv.y); gv.z = fmaf(hs.z, hv.z, gv.z); gv.w = fmaf(hs.w, hv.w, gv.w);
+  }
   const float4 mu = *reinterpret_cast<const float4*>(mean + c), iv = *reinterpret_cast<const float4*>(invstd + c);
   const float4 s0 = *reinterpret_cast<const float4*>(sums + c), s1 = *reinterpret_cast<const float4*>(sums + C + c);
   float4 ga = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -416,6 +422,18 @@ extern "C" int spgan_bn_prepare(const float* mean, const float* var, const float
   return spgan_launch_status();
 }
 
+extern "C" int spgan_bn_bwd_apply2(const float* g, const float* g2, const float* g2scale, const float* y, int M, int C, const float* mean,
+                                   const float* invstd, const float* gamma, const float* sums, int count, float* dy, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(g && g2 && g2scale && y && dy && mean && invstd && sums && M > 0 && C > 0 && C % 4 == 0 && count > 0);
+  const size_t total = (size_t)M * C;
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  SPGAN_CHECK_ARG(al(g) && al(g2) && al(g2scale) && al(y) && al(dy) && al(mean) && al(invstd) && al(sums) && (!gamma || al(gamma)) &&
+                  total / 4 < (1ull << 32));
+  hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)s_, g, y, C, (unsigned)(total / 4), C, mean,
+                     invstd, gamma, sums, 1.0f / (float)count, dy, g2, g2scale);
+  return spgan_launch_status();
+}
+
 extern "C" int spgan_bn_bwd_apply(const float* g, const float* y, int ld, int M, int C, const float* mean, const float* invstd,
                                   const float* gamma, const float* sums, int count, float* dy, spgan_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
@@ -426,7 +444,7 @@ extern "C" int spgan_bn_bwd_apply(const float* g, const float* y, int ld, int M,
                   total / 4 < (1ull << 32);
   if (v4)
     hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, s, g, y, ld, (unsigned)(total / 4), C, mean, invstd, gamma,
-                       sums, 1.0f / (float)count, dy);
+                       sums, 1.0f / (float)count, dy, (const float*)nullptr, (const float*)nullptr);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, g, y, ld, (size_t)M, C, mean, invstd, gamma, sums,
                        1.0f / (float)count, dy);

@@ -105,6 +105,7 @@ SIGNATURES = {
     "spgan_colsum": (I, [P, I, I, I, I, P, P, SZ, P]),
     "spgan_bn_prepare": (I, [P, P, P, P, I, I, F, F, I, P, P, P, P, P, P, P]),
     "spgan_bn_bwd_apply": (I, [P, P, I, I, I, P, P, P, P, I, P, P]),
+    "spgan_bn_bwd_apply2": (I, [P, P, P, P, I, I, P, P, P, P, I, P, P]),
     "spgan_maxpool": (I, [P, I, I, I, I, P, P, F, P, P, P]),
     "spgan_edge_wcat": (I, [P, P, I, I, I, P, P]),
     "spgan_edge_wcat_bwd": (I, [P, I, I, I, P, P, P]),

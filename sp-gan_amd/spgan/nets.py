@@ -431,16 +431,16 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         if li == 3 and top is not None:
             abar_g = _d_double_top_phase_b(P, ctx, top, grads)
             continue
+        add = None
         if abar_g is None:
-            X = xbarA[li]
             sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, None, None)
             grads[bn + ".bias"] = ZERO_GRAD
         else:
             g, s0, s1 = abar_g
-            X = ops.col_scale_add(xbarA[li], g, gamma)                           # xbarA + gamma*g
+            add = (g, gamma)                                                     # X = xbarA + gamma*g, formed inside bn_bwd_apply
             sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, s0, s1)
             grads[bn + ".bias"] = s0
-        ybar = ops.bn_bwd_apply(X, ys[li], mu, inv, None, sums, M)
+        ybar = ops.bn_bwd_apply(xbarA[li], ys[li], mu, inv, None, sums, M, add=add)
         if li > 0:
             psc, psh, pinv, pmu = bns[li - 1]
             gw = ops.gemm_tn(ybar, ys[li - 1], pro=(psc, psh, NEG))

@@ -580,13 +580,22 @@ def bn_prepare(mean: Optional[Tensor], var: Optional[Tensor], gamma: Optional[Te
     return out[0], out[1], out[2], out[3]
 
 
-def bn_bwd_apply(g: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Optional[Tensor], sums: Tensor, count: int) -> Tensor:
-    """dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count);  sums = [sum_g | sum_gx] (2C)."""
+def bn_bwd_apply(g: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Optional[Tensor], sums: Tensor, count: int,
+                 add: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
+    """dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count);  sums = [sum_g | sum_gx] (2C).
+    add = (g2 [M,C], scale [C]): g is replaced by g + scale[c]*g2, formed on the fly."""
     _f32(g, "g", 2); _f32(y, "y", 2)
     if not (g.is_contiguous() and y.is_contiguous()) or g.shape != y.shape:
         raise ValueError("g and y must be contiguous with equal shapes")
     M_, Cn = g.shape
     dy = torch.empty_like(g)
+    if add is not None:
+        g2, sc = add
+        if Cn % 4 == 0 and g2.is_contiguous() and g2.shape == g.shape:
+            check(_lib.load().spgan_bn_bwd_apply2(_p(g), _p(_f32(g2, "g2", 2)), _p(_vec(sc, Cn, "scale")), _p(y), M_, Cn, _p(mean), _p(invstd),
+                                                  _p(gamma), _p(_vec(sums, 2 * Cn, "sums")), count, _p(dy), _s()), "bn_bwd_apply2", M=M_, C=Cn)
+            return dy
+        g = col_scale_add(g, g2, sc)
     check(_lib.load().spgan_bn_bwd_apply(_p(g), _p(y), Cn, M_, Cn, _p(mean), _p(invstd), _p(gamma), _p(_vec(sums, 2 * Cn, "sums")),
                                          count, _p(dy), _s()), "bn_bwd_apply", M=M_, C=Cn)
     return dy

@@ -310,7 +310,9 @@ def bn_prepare(mean, var, gamma, beta, count, training=True, running_mean=None, 
     return sc, b - m * sc, inv, m.clone()
 
 
-def bn_bwd_apply(g, y, mean, invstd, gamma, sums, count):
+def bn_bwd_apply(g, y, mean, invstd, gamma, sums, count, add=None):
+    if add is not None:
+        g = g + add[1] * add[0]
     C = g.shape[1]
     xh = (y - mean) * invstd
     ga = gamma if gamma is not None else torch.ones_like(mean)
