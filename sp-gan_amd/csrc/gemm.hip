@@ -713,11 +713,14 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
     }
   } else {  // BNBWD / EDGE_BNBWD
     float s0[TJ], s1[TJ];
-    if (EPI == SPGAN_EPI_BNBWD && full && !p.rowbias) {
+    if (EPI == SPGAN_EPI_BNBWD && full && (!p.rowbias || p.rows_per_group == 1)) {
       const float* rb = p.ref + (size_t)rbase * p.ld_ref + cbase;
       float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
       const unsigned ldr = (unsigned)p.ld_ref, ldy = (unsigned)p.ldy;
       const float sl = p.b_slope;
+      // dense [M,N] addend (rows_per_group == 1: the S.W rows of the collapsed 256->1024 backward): one more straight-line load
+      const float* ab = p.rowbias ? p.rowbias + (size_t)rbase * p.ld_rowbias + cbase : nullptr;
+      const unsigned lda2 = (unsigned)p.ld_rowbias;
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
         const int col = cbase + j * 32;
@@ -730,6 +733,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           float yv[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) yv[r] = rb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldr + (unsigned)(j * 32))];
+          if (ab) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += ab[(size_t)((unsigned)(i * 32 + ROFF(r)) * lda2 + (unsigned)(j * 32))];
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float y = yv[r];

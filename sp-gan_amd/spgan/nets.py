@@ -269,7 +269,9 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             # -- a quarter of the FLOPs, and y4 is not read at all.
             sc, sh, inv, mu = bns[2]
             alpha, beta, b4 = dy.alpha, dy.beta, P[conv + ".bias"]
-            a3 = ops.affine_act(ys[2], sc, sh, NEG)
+            # a3 = lrelu(bn3(y3)) is materialised only where the weight gradients need it as a plain operand (Gram matrix, column
+            # sums, the sparse rows); the input-gradient GEMM below applies the same affine + LeakyReLU in its operand prologue
+            a3 = ops.affine_act(ys[2], sc, sh, NEG) if need_dparams else None
             if need_dparams:
                 gram = ops.gemm_tn(a3, a3)                                        # [256,256]
                 dW = ops.rowscale_outer(ops.gemm_nt(W, gram), alpha, b4, beta, ops.colsum(a3)[0])
@@ -279,7 +281,10 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             G4 = ops.gemm_tn(W, ops.rowscale_outer(W, alpha))                     # W^T diag(alpha) W
             cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(alpha, beta, 1.0))[0]  # (alpha*b4 + beta).W
             E = ops.sparse_rows_nt(dy.sp_val, dy.sp_arg, N, W)                    # S.W, dense rows
-            g, s0, s1 = ops.gemm_nt_bnbwd(a3, G4, ys[2], sc, sh, mu, inv, NEG, bias=cvec, rowadd=E)
+            if a3 is not None:
+                g, s0, s1 = ops.gemm_nt_bnbwd(a3, G4, ys[2], sc, sh, mu, inv, NEG, bias=cvec, rowadd=E)
+            else:
+                g, s0, s1 = ops.gemm_nt_bnbwd(ys[2], G4, ys[2], sc, sh, mu, inv, NEG, pro=(sc, sh, NEG), bias=cvec, rowadd=E)
             if need_dparams:
                 grads[D_LAYERS[2][1] + ".weight"] = s1; grads[D_LAYERS[2][1] + ".bias"] = s0
             sums = _cat2(s0, s1)
