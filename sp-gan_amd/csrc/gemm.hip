@@ -457,19 +457,32 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 
   if (EPI == SPGAN_EPI_LINEAR) {
     float csum[TJ];
-    if (full && !p.rowbias) {
+    // per-group bias rows: usable on the straight-line path when the whole tile lies in one group (per-shape bias, N % 128 == 0) or
+    // when the "group" is a single row (a dense [M,N] addend)
+    const int rb_g0 = p.rowbias ? fast_div(m0, p.rows_per_group) : 0;
+    const bool rb_uniform = p.rowbias && p.rows_per_group > 1 && fast_div(m0 + BM - 1, p.rows_per_group) == rb_g0;
+    const bool rb_dense = p.rowbias && p.rows_per_group == 1;
+    if (full && (!p.rowbias || rb_uniform || rb_dense)) {
+      const float* ab = rb_dense ? p.rowbias + (size_t)rbase * p.ld_rowbias + cbase : nullptr;
+      const unsigned lda2 = (unsigned)p.ld_rowbias;
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
-        const float b = p.bias ? p.bias[cbase + j * 32] : 0.f;
+        float b = p.bias ? p.bias[cbase + j * 32] : 0.f;
+        if (rb_uniform) b += p.rowbias[(size_t)rb_g0 * p.ld_rowbias + cbase + j * 32];
         csum[j] = 0.f;
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i) {
+          if (ab) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += ab[(size_t)((unsigned)(i * 32 + ROFF(r)) * lda2 + (unsigned)(j * 32))];
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float v = acc[i][j][r] + b;
             acc[i][j][r] = v;  // keep the pre-activation value for the statistics / pooling passes
             csum[j] += v;
           }
+        }
       }
       if (p.Y) {
         float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
