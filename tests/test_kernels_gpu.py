@@ -260,6 +260,15 @@ def test_gemm_nt_full_and_partial_tiles(ops, M, N, K):
     y, m, v = ops.gemm_nt(A, W, b, pro=(sc, sh, 0.01), stats=True)
     y2, m2, v2 = km.gemm_nt(A, W, b, pro=(sc, sh, 0.01), stats=True)
     close(y, y2, rtol=5e-5, what="affine"); close(m, m2, atol=2e-5, what="mean"); close(v, v2, rtol=1e-4, what="var")
+    for G_ in (1, 64, 128, 256):                       # dense addend / two groups per tile / one group per tile / per two tiles
+        rb = rnd("ft.rb%d.%d.%d" % (M, N, G_), ((M + G_ - 1) // G_, N + 4))[:, :N]
+        close(ops.gemm_nt(A, W, b, rowbias=rb, rows_per_group=G_, act=1, slope=0.1), km.gemm_nt(A, W, b, rowbias=rb, rows_per_group=G_, act=1, slope=0.1),
+              rtol=5e-5, what="rowbias G=%d" % G_)
+        for name, a_, b_ in zip(("g", "s0", "s1"), ops.gemm_nt_bnbwd(A, W, rnd("ft.ref2%d%d" % (M, N), (M, N)), rnd("ft.q%d" % N, (N,)), rnd("ft.r%d" % N, (N,), 0.3),
+                                                                      rnd("ft.s%d" % N, (N,), 0.2), rnd("ft.t%d" % N, (N,)).abs() + 0.5, 0.01, rowadd=rb.contiguous() if G_ == 1 else None),
+                                km.gemm_nt_bnbwd(A, W, rnd("ft.ref2%d%d" % (M, N), (M, N)), rnd("ft.q%d" % N, (N,)), rnd("ft.r%d" % N, (N,), 0.3),
+                                                 rnd("ft.s%d" % N, (N,), 0.2), rnd("ft.t%d" % N, (N,)).abs() + 0.5, 0.01, rowadd=rb.contiguous() if G_ == 1 else None)):
+            close(a_, b_, rtol=1e-4, atol=5e-4, what="bnbwd rowadd " + name)
     out = torch.full((M, N + 12), 9.0, device="cuda")
     ops.gemm_nt(A, W, b, out=out[:, 4:4 + N])
     close(out[:, 4:4 + N], km.gemm_nt(A, W, b), rtol=5e-5, what="strided out")
