@@ -762,6 +762,41 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           }
         }
       }
+    } else if (EPI == SPGAN_EPI_EDGE_BNBWD && full && !p.rowbias) {
+      // rows are edges e = (i, r): ref[e,n] = (P[idx[e],n] - P[i,n]) + e_bias2[n]; the two row offsets of an accumulator row are
+      // uniform over the 32 lanes of a half-wave, the gathers of a 16-row block issue together
+      float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
+      const unsigned ldr = (unsigned)p.ld_ref, ldy = (unsigned)p.ldy;
+      const float sl = p.b_slope;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = cbase + j * 32;
+        const float sc = p.b_scale[col], sh = p.b_shift[col], mu = p.b_mean[col], inv = p.b_invstd[col], eb = p.e_bias2[col];
+        const float bia = p.bias ? p.bias[col] : 0.f;
+        const float* pc = p.ref + col;
+        s0[j] = 0.f;
+        s1[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          float yv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + i * 32 + ROFF(r);
+            const unsigned oj = (unsigned)p.e_idx[row] * ldr, oi = (unsigned)fast_div(row, p.e_k) * ldr;
+            yv[r] = (pc[oj] - pc[oi]) + eb;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float y = yv[r];
+            const float z = fmaf(y, sc, sh);
+            const float g = (acc[i][j][r] + bia) * lrelu_mask(z, sl);
+            const float xh = (y - mu) * inv;
+            yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = g;
+            s0[j] += g;
+            s1[j] = fmaf(g, xh, s1[j]);
+          }
+        }
+      }
     } else
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
