@@ -885,10 +885,15 @@ constexpr int SR = 16, SC = 4;
 template <int AMODE, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_args p) {
   __shared__ float red[4][SR * SC];
+  __shared__ float colv[2][64][SC];  // per (row, column) values of the statistics epilogues (M <= 64)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * SC;
-  {
-    const int mc = blockIdx.y * SR;  // one SR-row chunk per workgroup
+  // gridDim.y == 1 with more than SR rows: this workgroup walks all row chunks of its SC columns (column statistics: LINEAR + stats,
+  // BNBWD); otherwise one SR-row chunk per workgroup.
+  const bool whole = gridDim.y == 1;
+  const int chunks = whole ? (p.M + SR - 1) / SR : 1;
+  for (int ch = 0; ch < chunks; ++ch) {
+    const int mc = (whole ? ch : (int)blockIdx.y) * SR;
     float v[SR * SC];
 #pragma unroll
     for (int i = 0; i < SR * SC; ++i) v[i] = 0.f;
@@ -925,23 +930,57 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_
         v[i] = keep + __shfl_xor(send, half);
       }
     }
+    __syncthreads();  // red is reused from chunk to chunk
     red[wave][lane] = v[0];
     __syncthreads();
     if (tid < SR * SC) {
       const float acc = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
       const int row = mc + tid / SC, col = n0 + tid % SC;
+      float c0 = 0.f, c1 = 0.f;
       if (row < p.M && col < p.N) {
         float o;
         if (EPI == SPGAN_EPI_LINEAR) {
           o = acc + (p.bias ? p.bias[col] : 0.f);
           if (p.rowbias) o += p.rowbias[(size_t)(row / p.rows_per_group) * p.ld_rowbias + col];
+          c0 = o;  // pre-activation value for the statistics
           if (p.act == SPGAN_ACT_LRELU) o = lrelu_f(o, p.act_slope);
           else if (p.act == SPGAN_ACT_TANH) o = tanhf(o);
-        } else {
+        } else if (EPI == SPGAN_EPI_MASK_OUT) {
           o = acc * lrelu_mask(p.ref[(size_t)row * p.ld_ref + col], p.b_slope);
+        } else {  // BNBWD
+          const float y = p.ref[(size_t)row * p.ld_ref + col];
+          const float z = fmaf(y, p.b_scale[col], p.b_shift[col]);
+          float a = acc + (p.bias ? p.bias[col] : 0.f);
+          if (p.rowbias) a += p.rowbias[(size_t)(row / p.rows_per_group) * p.ld_rowbias + col];
+          o = a * lrelu_mask(z, p.b_slope);
+          c0 = o;
+          c1 = o * ((y - p.b_mean[col]) * p.b_invstd[col]);
         }
-        p.Y[(size_t)row * p.ldy + col] = o;
+        if (p.Y) p.Y[(size_t)row * p.ldy + col] = o;
       }
+      if (whole && row < 64) {
+        colv[0][row][tid % SC] = c0;
+        colv[1][row][tid % SC] = c1;
+      }
+    }
+  }
+  if (whole && p.stats) {
+    __syncthreads();
+    if (tid < SC && n0 + tid < p.N) {  // one thread per column, rows in ascending order
+      float s0 = 0.f, s1 = 0.f;
+      for (int r = 0; r < p.M; ++r) s0 += colv[0][r][tid];
+      if (EPI == SPGAN_EPI_LINEAR) {
+        const float mean = s0 / (float)p.M;
+        for (int r = 0; r < p.M; ++r) {
+          const float d = colv[0][r][tid] - mean;
+          s1 = fmaf(d, d, s1);
+        }
+      } else {
+        for (int r = 0; r < p.M; ++r) s1 += colv[1][r][tid];
+      }
+      float* o = p.stats + (size_t)(n0 + tid) * 2;  // a single 128-row tile: partials [1, N, 2]
+      o[0] = s0;
+      o[1] = s1;
     }
   }
 }
@@ -952,9 +991,10 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   if (AMODE != SPGAN_A_PLAIN) fast = fast && al16(a.p_scale) && al16(a.p_shift);
   if (AMODE == SPGAN_A_EDGE) fast = fast && al16(a.e_bias);
   if (AMODE == A_AFFINE_SPARSE) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
-  if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE_SPARSE && (EPI == SPGAN_EPI_LINEAR || EPI == SPGAN_EPI_MASK_OUT)) {
-    if (a.M <= 64 && fast && !a.stats && !a.sp_val && a.batch <= 1) {
-      hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(cdiv(a.N, SC), cdiv(a.M, SR)), dim3(256), 0, s, a);
+  if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE_SPARSE && EPI != SPGAN_EPI_EDGE_BNBWD) {
+    if (a.M <= 64 && fast && !a.sp_val && a.batch <= 1 && !a.pool_val) {
+      const bool whole = a.stats != nullptr || EPI == SPGAN_EPI_BNBWD;  // column statistics: one workgroup walks all rows of its columns
+      hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(cdiv(a.N, SC), (whole || a.M <= SR) ? 1 : cdiv(a.M, SR)), dim3(256), 0, s, a);
       return spgan_launch_status();
     }
   }

@@ -41,3 +41,24 @@ def test_small_m_deterministic(ops):
     y0 = ops.gemm_nt(A, W)
     for _ in range(3):
         assert torch.equal(ops.gemm_nt(A, W), y0)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 128, 128), (32, 512, 128), (32, 128, 512), (4, 64, 256), (64, 20, 64), (17, 7, 36)])
+def test_small_m_statistics_epilogues(M, N, K):
+    """M <= 64 with column statistics (LINEAR + stats, BatchNorm-backward epilogue): served by the small-M kernel (one workgroup walks
+    all rows of its columns) instead of a single 128-row MFMA tile."""
+    import kernel_model as km
+    from spgan import ops
+    from test_kernels_gpu import close, rnd
+    A, W, b = rnd("sm.A%d%d" % (M, K), (M, K)), rnd("sm.W%d%d" % (N, K), (N, K), 0.2), rnd("sm.b%d" % N, (N,))
+    sc, sh = rnd("sm.sc%d" % K, (K,)).abs() + 0.5, rnd("sm.sh%d" % K, (K,), 0.3)
+    for pro in (None, (sc, sh, 0.01)):
+        y, m, v = ops.gemm_nt(A, W, b, pro=pro, stats=True, act=1, slope=0.2)
+        y2, m2, v2 = km.gemm_nt(A, W, b, pro=pro, stats=True, act=1, slope=0.2)
+        close(y, y2, rtol=5e-5, what="y"); close(m, m2, atol=2e-5, what="mean"); close(v, v2, rtol=1e-4, atol=1e-6, what="var")
+        ref = rnd("sm.ref%d%d" % (M, N), (M, N))
+        bsc, bsh = rnd("sm.bsc%d" % N, (N,)), rnd("sm.bsh%d" % N, (N,), 0.3)
+        mean, inv = rnd("sm.mu%d" % N, (N,), 0.2), rnd("sm.inv%d" % N, (N,)).abs() + 0.5
+        for name, a_, b_ in zip(("g", "s0", "s1"), ops.gemm_nt_bnbwd(A, W, ref, bsc, bsh, mean, inv, 0.01, pro=pro, bias=b),
+                                km.gemm_nt_bnbwd(A, W, ref, bsc, bsh, mean, inv, 0.01, pro=pro, bias=b)):
+            close(a_, b_, rtol=1e-4, atol=5e-4, what="bnbwd " + name)
