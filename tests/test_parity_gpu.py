@@ -504,3 +504,24 @@ def test_generator_per_shape_latent_matches_tiled_and_oracle(sp):
     i1 = sp.ops.idx_to_local64(last.EdgeConv1.last_idx, B, N).cpu(); i2 = sp.ops.idx_to_local64(last.EdgeConv2.last_idx, B, N).cpu()
     ref = orc.generator_forward(params, x.cpu(), zt, training=True, buffers=orc.bn_buffers(orc.generator_shapes()), idx1=i1, idx2=i2)
     assert rel_l2(outs[0].cpu().numpy(), ref.numpy()) <= 2e-4
+
+
+def test_per_shape_latent_with_eql_and_znorm(sp):
+    """The un-tiled latent path under --eql (scaled, non-leaf head weights) and --z_norm: same output and gradients as the tiled input."""
+    B, N = 4, 256
+    flags = dict(eql=True, z_norm=True)
+    O = type("O_pe", (Opts,), flags)
+    params = fr.init_params(orc.generator_shapes(eql=True), salt=61)
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    zt = fr.latent(B, N, seed=62)
+    dy = fr.normal("pe.dy", (B, 3, N)).cuda()
+    res = []
+    for z in (zt[:, :1, :].contiguous().cuda(), zt.cuda()):
+        G = _load(sp.Generator(O), params).train()
+        out = G(x, z)
+        (out * dy).sum().backward()
+        res.append((out.detach(), {n: p.grad.clone() for n, p in G.named_parameters()}))
+    assert rel_l2(res[0][0].cpu().numpy(), res[1][0].cpu().numpy()) <= 2e-5
+    for n in ("head.0.conv.weight_orig", "head.0.conv.bias", "head.2.conv.weight_orig", "head.2.conv.bias"):
+        e = rel_l2(res[0][1][n].cpu().numpy(), res[1][1][n].cpu().numpy())
+        assert e <= 6e-2, (n, e)
