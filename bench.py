@@ -194,9 +194,9 @@ def main():
 
     spgan.ops.set_mfma_operands(args.mfma)
     G, D = build_models(dev, variant)
-    # The step is captured once into a hipGraph and replayed (TrainStep(graph=True)): issuing its ~580 launches from Python takes
-    # as long as the GPU needs to run them.  Data-parallel runs capture the two RCCL all-reduces with it; SPGAN_GRAPH=0 / --no-graph
-    # fall back to eager issue.
+    # The step is captured once into a hipGraph and replayed (TrainStep(graph=True)): issuing its ~570 launches from Python takes
+    # as long as the GPU needs to run them.  Data-parallel runs capture three graphs (D step | Adam(D) + G step | Adam(G)) and issue
+    # the two RCCL all-reduces eagerly between them; SPGAN_GRAPH=0 / --no-graph fall back to eager issue.
     use_graph = not args.no_graph and os.environ.get("SPGAN_GRAPH", "1") != "0"
     graph_warmup = 3
     tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=dist_on, graph=use_graph,
