@@ -2,7 +2,10 @@
 """G+D train-step throughput of the MI355X-native SP-GAN hot path (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`--gpus N` with N > 1 launches its own N ranks (one process per GPU, re-executing this file under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`); started under torchrun
+(RANK/WORLD_SIZE in the environment) it is a rank of that job.  Rank 0 prints ONE JSON line.
 
 A "step" is one iteration of the reference loop body (Generation/model.py:239-279): D-step + G-step
 with both Adam updates (and, for N>1, both flat gradient all-reduces), on BASELINE config 2:
@@ -10,14 +13,20 @@ Chair-shaped synthetic clouds, 2048 points, per-GPU batch 32, WGAN loss + gradie
 fp32.  Weak scaling: the per-GPU batch is fixed, global batch = 32*N.  Inputs are resident in HBM.
 
 The JSON line also carries
-  roofline     : the dominant kernel (the fp32-MFMA gemm_nt), its algorithmic FLOPs per launch / average
-                 launch time measured with HIP events on the launch stream, against the 157.3 TFLOP/s fp32 matrix peak;
-  cpu_baseline : the CPU oracle (a PyTorch restatement of the reference, kind "port") timed on this box's host
-                 cores on a bounded sample of the same workload.
+  roofline      : the dominant kernel (the fp32-MFMA gemm_nt), its algorithmic FLOPs per launch / average
+                  launch time measured with HIP events on the launch stream, against the 157.3 TFLOP/s fp32 matrix peak;
+  mfma          : FLOPs the step actually issues on the matrix cores (our formulation, padded tiles), the summed duration of
+                  those kernels (HIP events around every launch, GPU kept ahead of the host) -> time-weighted MFMA utilisation;
+  drop_in_caller: the same step the way an unmodified reference loop would drive it (latent tiled to [B,N,nz], the unused
+                  D(real) forward of the G step evaluated, EdgeConv1 on every copy of the tiled sphere);
+  cpu_baseline  : the CPU oracle (a PyTorch restatement of the reference, kind "port") timed on this box's host
+                  cores on a bounded sample of the same workload (batch 32 = the metric's own batch, and batch 4).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,14 +37,19 @@ for p in (ROOT, os.path.join(ROOT, "sp-gan_amd")):
 
 import torch   # noqa: E402
 
-N_POINTS = 2048
-PER_GPU_BATCH = int(os.environ.get("SPGAN_BENCH_BATCH", "32"))   # 32 = BASELINE configs[1]; the override is for experiments only
+# SPGAN_BENCH_SELFTEST=1: plumbing self-test on the CPU (tests/test_bench_cpu.py): tiny shapes, gloo, spgan.ops replaced by the
+# test doubles of tests/kernel_model.py.  Exercises argument handling, the self-launch, the rendezvous, the data-parallel step and
+# the JSON line; its numbers are meaningless and the line says so.
+SELFTEST = os.environ.get("SPGAN_BENCH_SELFTEST", "0") == "1"
+N_POINTS = 128 if SELFTEST else 2048
+PER_GPU_BATCH = 2 if SELFTEST else int(os.environ.get("SPGAN_BENCH_BATCH", "32"))   # 32 = BASELINE configs[1]; the override is for experiments only
 NZ = 128
 K_NN = 10
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 FP16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (never the 2:1-sparsity figure)
 # algorithmic FLOPs per shape per step, reference formulation: WGAN-GP at N=2048
 GF_PER_SHAPE_STEP = 32.6
+PMC_FILES = ("r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json")
 
 
 class Opts:
@@ -54,13 +68,16 @@ def build_models(dev, variant=()):
     return G.to(dev), D.to(dev)
 
 
-def make_inputs(dev, rank, b):
+def make_inputs(dev, rank, b, tiled_z=False):
     from spgan import fixture_rng as fr
-    x = fr.sphere_template(N_POINTS)[None].repeat(b, 1, 1).to(dev)
+    n_t = N_POINTS if N_POINTS in (512, 1024, 2048, 4096) else 256
+    x = fr.sphere_template(n_t)[:N_POINTS][None].repeat(b, 1, 1).to(dev)
     real = fr.synthetic_real(b, N_POINTS, seed=1234 + rank).to(dev)
     # one latent per shape (the reference's default noise_generator, model.py:128-131); passed un-tiled [b,1,nz] -- spgan.Generator
-    # evaluates the latent half of head.0 per shape instead of tiling it over the 2048 points first
-    zs = [fr.latent(b, N_POINTS, NZ, seed=4321 + rank + i)[:, :1, :].contiguous().to(dev) for i in range(4)]
+    # evaluates the latent half of head.0 per shape instead of tiling it over the 2048 points first.  tiled_z: [b,N,nz] as the
+    # reference's loop hands it over.
+    zs = [fr.latent(b, N_POINTS, NZ, seed=4321 + rank + i) for i in range(2 if tiled_z else 4)]
+    zs = [(z if tiled_z else z[:, :1, :]).contiguous().to(dev) for z in zs]
     alpha = fr.uniform("bench.alpha.%d" % rank, (b, 1, 1), 0.0, 1.0).to(dev)
     return x, real, zs, alpha
 
@@ -68,14 +85,16 @@ def make_inputs(dev, rank, b):
 def _pmc_traffic():
     """HBM bytes per launch of the same kernel/shape from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 correction, + WRITE_SIZE); PMC counters cannot be sampled from inside this process."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_nt.json")) as f:
-            return json.load(f)["kernels"][DOMINANT["pmc_key"]]["hbm_bytes_per_launch_corrected"]
-    except Exception:
-        return None
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"][DOMINANT["pmc_key"]]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            continue
+    return None
 
 
-# Dominant kernel of the step (profiles/r01_bench_*_kernel_stats.txt): gemm_nt_kernel<affine prologue, linear epilogue + column
+# Dominant kernel of the step (profiles/r0*_bench_*_kernel_stats.txt): gemm_nt_kernel<affine prologue, linear epilogue + column
 # statistics + max-pool partials, 128x64 tile> at the Discriminator's 256->1024 layer (Discriminator.py:74-81,104): M = B*N points,
 # N = 1024, K = 256; 4 launches per step (D(real), D(fake), D(interpolate) of the D step and D(fake) of the G step; the G step's
 # unused D(real) only advances running statistics, TrainStep._seg_g).
@@ -83,37 +102,108 @@ DOMINANT = {"N": 1024, "K": 256, "a_mode": 1,
             "pmc_key": "gemm_nt D.fc2.0 M=65536 N=1024 K=256 (affine prologue + statistics + pooling partials, output not stored)"}
 
 
-class DominantKernelTimer:
-    """Brackets every launch of the dominant kernel inside the timed region with HIP events recorded on the launch stream
-    (spgan.ops.launch_timer hook) -- the live per-launch duration behind `roofline.achieved`."""
+def _cdiv(a, b):
+    return (a + b - 1) // b
 
-    def __init__(self, M, peak=FP32_MATRIX_PEAK_TFLOPS):
-        self.M, self.events, self.peak = M, [], peak
+
+class MfmaAccounting:
+    """HIP events (on the launch stream) around EVERY launch that runs on the matrix cores during a few eagerly issued steps:
+    the dominant kernel's launches give `roofline`, all of them give the step's issued MFMA FLOPs and the summed duration of
+    the kernels that issue them -> a time-weighted MFMA utilisation.  Which launches use MFMA, and their tile padding, follow the
+    dispatch rules of csrc/gemm.hip (launch_nt / launch_tn) and csrc/graph.hip (knn_mfma for feature-space kNN)."""
+
+    def __init__(self, M, peak, f16):
+        self.M, self.peak, self.f16 = M, peak, f16
+        self.rec = []          # (kind, useful flops, issued flops, e0, e1, dominant?)
+
+    def _classify(self, kind, a):
+        if kind == "gemm_nt":
+            batch = max(int(a.batch), 1)
+            small = a.M <= 64 and a.a_mode != 2 and a.epi_mode != 3 and not a.sp_val and batch == 1 and not a.pool_val
+            if small:
+                return None
+            if self.f16 and a.N > 32:
+                bn = 128 if (a.N > 64 and a.K >= 512) else 64
+            else:
+                bn = 128 if (a.N > 64 and a.K >= 512) else (64 if a.N > 32 else 32)
+            useful = 2.0 * a.M * a.N * a.K * batch
+            issued = 2.0 * _cdiv(a.M, 128) * 128 * _cdiv(a.N, bn) * bn * _cdiv(a.K, 32) * 32 * batch
+            dom = (a.M == self.M and a.N == DOMINANT["N"] and a.K == DOMINANT["K"] and a.a_mode == DOMINANT["a_mode"] and bool(a.stats))
+            return useful, issued, dom
+        if kind == "gemm_tn":
+            skinny = (a.Na <= 4 or a.Nb <= 4) and a.Na <= 2048 and a.Nb <= 2048
+            if skinny and a.b_mode == 0 and not a.a_scale:
+                return None
+            tb = 128 if a.Nb > 64 else (64 if a.Nb > 32 else 32)
+            useful = 2.0 * a.M * a.Na * a.Nb
+            return useful, 2.0 * _cdiv(a.M, 32) * 32 * _cdiv(a.Na, 128) * 128 * _cdiv(a.Nb, tb) * tb, False
+        if kind == "knn":
+            if a.mode != 0 or a.C < 16:
+                return None                                   # coordinate-space kNN: fp64 VALU kernel
+            f = 2.0 * a.B * a.N * a.N * a.C
+            return f, f, False
+        return None
 
     def __call__(self, kind, a):
-        if kind != "gemm_nt" or a.M != self.M or a.N != DOMINANT["N"] or a.K != DOMINANT["K"] or a.a_mode != DOMINANT["a_mode"] or not a.stats:
+        c = self._classify(kind, a)
+        if c is None:
             return None
         stream = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        self.events.append((e0, e1))
+        self.rec.append((kind, c[0], c[1], e0, e1, c[2]))
         return lambda: e1.record(stream)
 
     def roofline(self):
-        if not self.events:
+        dom = [(r[3], r[4]) for r in self.rec if r[5]]
+        if not dom:
             return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1 in self.events) / len(self.events)
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in dom) / len(dom)
         flops = 2.0 * self.M * DOMINANT["N"] * DOMINANT["K"]          # SURVEY 8(d): 2*N*256*1024 per shape x the shapes of one launch
         achieved = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": "gemm_nt_kernel<1,0,1,0,1> at D.fc2.0 (M=%d N=%d K=%d, BN+LeakyReLU prologue, column-statistics + max-pool epilogue, output not stored)"
                                            % (self.M, DOMINANT["N"], DOMINANT["K"]),
                 "achieved": round(achieved, 2), "peak": self.peak, "unit": "TFLOP/s", "frac": round(achieved / self.peak, 4),
-                "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches_timed": len(self.events), "traffic": _pmc_traffic()}
+                "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches_timed": len(dom), "traffic": _pmc_traffic(),
+                "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/); algorithmic = A 67.1 MB + W 1.0 MB read once "
+                                "(68.2 MB) + this kernel's own statistics/pooling partials 12.6 MB written"}
+
+    def summary(self, steps, step_ms):
+        if not self.rec:
+            return None
+        t_ms = sum(r[3].elapsed_time(r[4]) for r in self.rec) / steps
+        useful = sum(r[1] for r in self.rec) / steps
+        issued = sum(r[2] for r in self.rec) / steps
+        by = {}
+        for r in self.rec:
+            d = by.setdefault(r[0], [0, 0.0, 0.0])
+            d[0] += 1; d[1] += r[1]; d[2] += r[3].elapsed_time(r[4])
+        return {"mfma_flops_issued_per_step": issued, "mfma_flops_useful_per_step": useful, "mfma_kernel_ms_per_step": round(t_ms, 3),
+                "mfma_launches_per_step": len(self.rec) // steps,
+                "mfma_util_issued": round(issued / (t_ms * 1e-3) / 1e12 / self.peak, 4),
+                "mfma_util_useful": round(useful / (t_ms * 1e-3) / 1e12 / self.peak, 4),
+                "mfma_time_share_of_step": round(t_ms / step_ms, 4),
+                "by_kind": {k: {"launches_per_step": v[0] // steps, "tflops_useful": round(v[1] / (v[2] * 1e-3) / 1e12, 2), "ms_per_step": round(v[2] / steps, 3)}
+                            for k, v in by.items()},
+                "note": "HIP events around every matrix-core launch over %d eagerly issued steps (GPU kept behind a spin kernel so the events do not see host "
+                        "issue gaps); issued = 2*M*N*K with M, N, K padded to the kernel's tiles; util = FLOPs / (summed duration of these kernels x %.1f TFLOP/s); "
+                        "gemm_tn durations include the split-K reduction the same entry point launches when it is not deferred" % (steps, self.peak)}
 
 
-def cpu_baseline(budget_s=25.0):
-    """The oracle's train step (same loss composition) on the host cores, bounded sample: C2 shape at a reduced
-    batch (the [B,N,N] sort of the reference formulation needs ~64 MB per shape per EdgeConv)."""
+def _spin_ahead(ms):
+    """Keep the GPU busy for ~ms so that the host gets ahead with issuing (HIP events then bracket kernels, not issue gaps)."""
+    if not hasattr(_spin_ahead, "cycles_per_ms"):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(); torch.cuda._sleep(20_000_000); e1.record()
+        torch.cuda.synchronize()
+        _spin_ahead.cycles_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
+    torch.cuda._sleep(int(ms * _spin_ahead.cycles_per_ms))
+
+
+def cpu_baseline(budget_s=45.0):
+    """The oracle's train step (same loss composition) on the host cores, bounded sample: the metric's own shape (C2: N=2048,
+    batch 32; >= 1 warm-up + up to 3 timed steps inside the budget) and, for continuity with round 1, batch 4."""
     from oracle import spgan_oracle as orc
     from spgan import fixture_rng as fr
     ncpu = os.cpu_count() or 1
@@ -134,10 +224,10 @@ def cpu_baseline(budget_s=25.0):
         return time.time() - t
 
     # PyTorch CPU oversubscribes badly on many-core hosts (256 threads: 143 s/step measured vs 1.5 s/step on 8):
-    # pick the fastest thread count on a tiny probe first, then time the bounded sample with it.
-    probe = setup(2, 512)
+    # pick the fastest thread count on a small probe first, then time the bounded samples with it.
+    probe = setup(4, 1024)
     best, best_t = 1, None
-    for th in [t for t in (4, 8, 16, 32, 64) if t <= ncpu] or [ncpu]:
+    for th in [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]:
         torch.set_num_threads(th)
         run(probe)
         dt = min(run(probe), run(probe))
@@ -146,19 +236,60 @@ def cpu_baseline(budget_s=25.0):
         if dt > 5.0:
             break
     torch.set_num_threads(best)
-    b = 4
-    st = setup(b, N_POINTS)
-    run(st)                                                          # warm-up
-    t0 = time.time(); n = 0
-    while True:
-        run(st)
-        n += 1
-        if time.time() - t0 > budget_s or n >= 8:
-            break
-    dt = (time.time() - t0) / n
-    return {"value": round(b / dt, 3), "unit": "shapes/s", "cores": best, "kind": "port", "host_cpus": ncpu,
-            "sample": "%d oracle train steps (WGAN-GP, N=%d, batch %d; PyTorch CPU fp32, %d threads = fastest of a probe over 4..64 "
-                      "on a %d-CPU host), %.2f s/step" % (n, N_POINTS, b, best, ncpu, dt)}
+
+    def sample(b, budget, max_steps):
+        st = setup(b, N_POINTS)
+        run(st)                                                          # warm-up
+        t0 = time.time(); n = 0
+        while True:
+            run(st)
+            n += 1
+            if time.time() - t0 > budget or n >= max_steps:
+                break
+        return (time.time() - t0) / n, n
+
+    dt4, n4 = sample(4, 6.0, 4)
+    dt32, n32 = sample(PER_GPU_BATCH, budget_s - 15.0, 3)
+    return {"value": round(PER_GPU_BATCH / dt32, 3), "unit": "shapes/s", "cores": best, "kind": "port", "host_cpus": ncpu,
+            "value_batch4": round(4 / dt4, 3),
+            "sample": "oracle train steps (WGAN-GP, N=%d; PyTorch CPU fp32, %d threads = fastest of a probe over 8..64 on a %d-CPU host): "
+                      "batch %d (the metric's batch): 1 warm-up + %d timed, %.2f s/step; batch 4: 1 warm-up + %d timed, %.2f s/step"
+                      % (N_POINTS, best, ncpu, PER_GPU_BATCH, n32, dt32, n4, dt4)}
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without torchrun: re-execute under torch.distributed.run with one rank per GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL / device-memory sharing across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def time_steps(tr, step_fn, steps, dist_on, dev):
+    if dist_on:
+        torch.distributed.barrier()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(i)
+    t_issue = time.perf_counter() - t0        # host time to enqueue the K steps (the GPU may still be running)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    return dt, t_issue
 
 
 def main():
@@ -167,37 +298,53 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the drop-in-caller and MFMA-accounting legs (they run after the timed region)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--mfma", choices=("f32", "f16"), default="f32",
                     help="operand precision of the MFMA contractions: f32 (BASELINE configs[1], the headline) or f16 operands with fp32 "
                          "accumulation (the per-GPU shape of BASELINE configs[4], 'fp16 MFMA MLPs')")
     ap.add_argument("--reference-schedule", action="store_true",
                     help="also evaluate the two provably redundant pieces of the reference loop (EdgeConv1 on every copy of the tiled "
-                         "sphere, the G step's unused D(real) forward) -- for comparison; see DESIGN.md")
+                         "sphere, the G step's unused D(real) forward) in the HEADLINE timing -- for comparison; see DESIGN.md")
     ap.add_argument("--variant", default="", help="comma-separated non-default generator flags (attn, eql, use_head, off, z_norm) or "
                     "small_d: times that variant instead of the headline configuration (SURVEY 8(f) N4); the JSON line says so")
     args = ap.parse_args()
     variant = tuple(v for v in args.variant.split(",") if v)
 
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))                     # the ranks print the JSON line; this process only waits for them
+    if args.gpus != world_env:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start `python bench.py --gpus N` directly or under torch.distributed.run with "
+                         "--nproc-per-node N" % (args.gpus, world_env))
+
     import spgan
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = spgan.init_process_group_from_env("nccl")        # no-op for a plain single-process launch
+    if SELFTEST:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import install_kernel_models
+        install_kernel_models()
+        torch.set_num_threads(2)
+    world = world_env
+    rank = spgan.init_process_group_from_env("gloo" if SELFTEST else "nccl")        # no-op for a plain single-process launch
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if SELFTEST:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    world_seen = torch.distributed.get_world_size() if dist_on else 1
+    if world_seen != args.gpus:
+        raise SystemExit("process group has %d ranks, --gpus asked for %d" % (world_seen, args.gpus))
 
     spgan.ops.set_mfma_operands(args.mfma)
     G, D = build_models(dev, variant)
-    # The step is captured once into a hipGraph and replayed (TrainStep(graph=True)): issuing its ~570 launches from Python takes
+    # The step is captured once into a hipGraph and replayed (TrainStep(graph=True)): issuing its launches from Python takes
     # as long as the GPU needs to run them.  Data-parallel runs capture three graphs (D step | Adam(D) + G step | Adam(G)) and issue
     # the two RCCL all-reduces eagerly between them; SPGAN_GRAPH=0 / --no-graph fall back to eager issue.
-    use_graph = not args.no_graph and os.environ.get("SPGAN_GRAPH", "1") != "0"
+    use_graph = not args.no_graph and os.environ.get("SPGAN_GRAPH", "1") != "0" and not SELFTEST
     graph_warmup = 3
     tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=dist_on, graph=use_graph,
                          graph_warmup=graph_warmup, reference_schedule=args.reference_schedule)
@@ -211,33 +358,40 @@ def main():
             one_step(i)
     for i in range(args.warmup):
         one_step(i)
-    timer = DominantKernelTimer(PER_GPU_BATCH * N_POINTS, FP32_MATRIX_PEAK_TFLOPS if args.mfma == "f32" else FP16_MATRIX_PEAK_TFLOPS) if rank == 0 else None
-    if not use_graph:
-        spgan.ops.launch_timer = timer
-    if dist_on:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    t_issue = time.perf_counter() - t0        # host time to enqueue the K steps (the GPU may still be running)
-    torch.cuda.synchronize()
-    if dist_on:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = t.item()
-    spgan.ops.launch_timer = None
-    if use_graph and rank == 0:
-        # a replayed graph offers no per-launch hook: the dominant kernel's launches are bracketed with HIP events over a few
-        # eager steps of the same TrainStep right after the timed region (same process, same tensors; not part of `value`)
-        spgan.ops.launch_timer = timer
-        for i in range(4):
+    peak = FP32_MATRIX_PEAK_TFLOPS if args.mfma == "f32" else FP16_MATRIX_PEAK_TFLOPS
+    acct = MfmaAccounting(PER_GPU_BATCH * N_POINTS, peak, args.mfma == "f16") if (rank == 0 and not SELFTEST) else None
+    dt, t_issue = time_steps(tr, one_step, args.steps, dist_on, dev)
+
+    ACCT_STEPS = 4
+    if not SELFTEST:
+        # a replayed graph offers no per-launch hook: the matrix-core launches are bracketed with HIP events over a few eager steps
+        # of the same TrainStep right after the timed region (same process, same tensors; not part of `value`).  Data-parallel:
+        # every rank runs them (the all-reduces inside must match up); only rank 0 records.
+        spgan.ops.launch_timer = acct
+        for i in range(ACCT_STEPS):
+            _spin_ahead(25.0)
             tr._eager_step(x, real, zs[(2 * i) % 4], zs[(2 * i + 1) % 4], alpha=alpha)
         torch.cuda.synchronize()
         spgan.ops.launch_timer = None
+
+    drop_in = None
+    if not SELFTEST and not args.no_extra_legs and not variant:
+        # The same step as an unmodified reference loop would drive it (model.py:246-248,272-273): z tiled to [B,N,nz], the G step's
+        # unused D(real) forward evaluated, EdgeConv1 on every copy of the tiled sphere.  Fresh models (same initialisation), its own
+        # captured graph; every rank takes part.
+        G2, D2 = build_models(dev, variant)
+        tr2 = spgan.TrainStep(G2, D2, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=dist_on, graph=use_graph,
+                              graph_warmup=graph_warmup, reference_schedule=True)
+        x2, real2, zt, alpha2 = make_inputs(dev, rank, PER_GPU_BATCH, tiled_z=True)
+        step2 = lambda i: tr2.step(x2, real2, zt[0], zt[1], alpha=alpha2)
+        for i in range((graph_warmup + 1 if use_graph else 0) + 2):
+            step2(i)
+        dt2, _ = time_steps(tr2, step2, 10, dist_on, dev)
+        drop_in = {"ms_per_step_reference_schedule_tiled_z": round(dt2 / 10 * 1e3, 3),
+                   "shapes_per_s": round(PER_GPU_BATCH * world * 10 / dt2, 2),
+                   "note": "z handed over tiled [B,N,128] (33.5 MB), reference_schedule=True: EdgeConv1 on all B copies of the sphere, full D(real) "
+                           "forward in the G step; 10 steps after priming"}
+        del tr2, G2, D2, zt
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -250,19 +404,29 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Chair-shaped synthetic clouds, 2048 pts, per-GPU batch 32, WGAN + gradient penalty (lambda 10), "
                                    "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10; one latent per shape (default noise_generator) handed over un-tiled [b,1,128]", "global_batch": PER_GPU_BATCH * world, "n_points": N_POINTS,
                        "parallelism": "dp%d" % world},
+            "world_size_observed": world_seen, "collective_backend": (torch.distributed.get_backend() if dist_on else None),
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3), "hipgraph_replay": bool(use_graph), "reference_schedule": bool(args.reference_schedule),
             "step_tflops_algorithmic": round(shapes_s * GF_PER_SHAPE_STEP / 1e3, 2),
-            "step_frac_of_fp32_matrix_peak": round(shapes_s * GF_PER_SHAPE_STEP / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
+            "step_frac_of_fp32_matrix_peak_reference_flops": round(shapes_s * GF_PER_SHAPE_STEP / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
         }
+        if SELFTEST:
+            line["selftest"] = True
+            line["data"] = "selftest: CPU test doubles, tiny shapes -- NOT a measurement"
+            line["config"]["workload"] = "SELFTEST (N=%d, per-rank batch %d, gloo, kernel-model doubles): plumbing only" % (N_POINTS, PER_GPU_BATCH)
         if variant:
             line["variant"] = list(variant)
             line["config"]["workload"] += "; NON-HEADLINE variant flags: " + ",".join(variant)
-        line["roofline"] = timer.roofline()
-        if world == 1 and not args.no_cpu_baseline:
+        if acct is not None:
+            line["roofline"] = acct.roofline()
+            line["mfma"] = acct.summary(ACCT_STEPS, ms)
+        if drop_in is not None:
+            line["drop_in_caller"] = drop_in
+        if world == 1 and not args.no_cpu_baseline and not SELFTEST:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(shapes_s / line["cpu_baseline"]["value"], 1)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist_on:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

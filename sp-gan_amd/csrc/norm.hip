@@ -168,7 +168,7 @@ __global__ void bn_prepare_kernel(const float* mean, const float* var, const flo
   float m, v;
   if (training) {
     m = mean[c];
-    v = var[c];
+    v = fmaxf(var[c], 0.f);  // a variance obtained as a difference (d_advance_running_stats) may round below zero
     if (rmean) {
       const float unb = count > 1 ? v * ((float)count / (float)(count - 1)) : v;
       rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;

@@ -68,9 +68,8 @@ def init_params(shapes: Dict[str, Tuple[int, ...]], salt: int = 0, perturb_bn: b
 _BALLS = None
 
 
-def sphere_template(n: int) -> torch.Tensor:
-    """Unit-sphere template with N points, centred and scaled to unit max radius the way
-    the reference does (Generation/model.py:46-52,159-160): float64 maths, then fp32."""
+def sphere_template64(n: int) -> np.ndarray:
+    """The normalised template in float64, as the reference holds `self.ball` (Generation/model.py:46-52,159-160)."""
     global _BALLS
     if _BALLS is None:
         _BALLS = np.load(os.path.join(os.path.dirname(__file__), "data", "balls.npz"))
@@ -80,7 +79,13 @@ def sphere_template(n: int) -> torch.Tensor:
     pc = _BALLS[key].astype(np.float64)
     pc = pc - np.mean(pc, axis=0)
     pc = pc / np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
-    return torch.Tensor(pc)                                   # float64 -> float32 like torch.Tensor(ndarray)
+    return pc
+
+
+def sphere_template(n: int) -> torch.Tensor:
+    """Unit-sphere template with N points, centred and scaled to unit max radius the way
+    the reference does (Generation/model.py:46-52,159-160): float64 maths, then fp32."""
+    return torch.Tensor(sphere_template64(n))                 # float64 -> float32 like torch.Tensor(ndarray)
 
 
 def synthetic_real(b: int, n: int, seed: int = 1234) -> torch.Tensor:

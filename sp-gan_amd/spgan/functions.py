@@ -17,32 +17,67 @@ from . import nets, ops
 Tensor = torch.Tensor
 
 
+_HAS_ENGINE_QUERY = hasattr(torch._C, "_will_engine_execute_node")     # private API (present in torch 1.13 .. 2.10); guarded, see below
+_INPUT_GRAD_ONLY = [0]       # > 0 while spgan.losses.GradientPenalty runs its autograd.grad(D(x_hat), x_hat, create_graph=True)
+
+
+class input_grad_only:
+    """Context: the backward passes started inside it want input gradients only (no parameter gradients).  spgan's own
+    GradientPenalty says so explicitly, which makes the WGAN-GP route independent of the private engine query below."""
+
+    def __enter__(self):
+        _INPUT_GRAD_ONLY[0] += 1
+
+    def __exit__(self, *exc):
+        _INPUT_GRAD_ONLY[0] -= 1
+
+
 def _engine_needs(ctx, pos: int, tpos: int) -> bool:
     """True if the running autograd task will actually consume the gradient of input `pos`
     (autograd.grad(inputs=[x]) does not need parameter gradients although they require grad).
-    `tpos` is the input's index among the *tensor* arguments (next_functions skips non-tensors)."""
+    `tpos` is the input's index among the *tensor* arguments (next_functions skips non-tensors).
+    Uses torch._C._will_engine_execute_node where this torch has it (so that the REFERENCE's GradientPenalty works unchanged on
+    our Discriminator); without it every gradient autograd marks as needed is computed, and only `input_grad_only()` callers get
+    the differentiable input-gradient route."""
     if not ctx.needs_input_grad[pos]:
         return False
+    if not _HAS_ENGINE_QUERY:
+        return True
     try:
         fn = ctx.next_functions[tpos][0]
         if fn is None:
             return False
         return bool(torch._C._will_engine_execute_node(fn))
-    except Exception:
+    except RuntimeError:
         return True
 
 
-FUSED_GRAD_ACCUMULATION = True
+# Parameter gradients are handed back to autograd (AccumulateGrad, hooks, torch.autograd.grad all behave as usual) unless the
+# caller opted into the fused route with `fused_grad_accumulation()` -- spgan.TrainStep does, around its two backward() calls.
+_FUSED = [0]
+
+
+class fused_grad_accumulation:
+    """Context: backward passes started inside add parameter gradients straight into the pre-bound flat `.grad` buffers
+    (spgan.optim.flatten_module) with one fused launch per Function and return None to autograd.  Only for callers that read
+    gradients from `.grad` afterwards and use no parameter hooks (TrainStep); everything else gets normal autograd semantics."""
+
+    def __enter__(self):
+        _FUSED[0] += 1
+
+    def __exit__(self, *exc):
+        _FUSED[0] -= 1
 
 
 def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool]):
-    """Hand parameter gradients back to autograd -- or, for every wanted leaf parameter that already owns a contiguous `.grad`
-    (the flat buffer of spgan.optim.flatten_module) while no graph is being recorded, add them into `.grad` with ONE fused
-    launch (spgan_multi_add) and return None: the same sums AccumulateGrad would form with one elementwise launch per parameter
-    tensor (and on the launch stream, which keeps the step capturable as a hipGraph).  Non-leaf "parameters" (the scaled weights of
-    equalised-LR layers) get their gradient returned.  Exact-zero gradients (nets.ZERO_GRAD) cost nothing on the fused path."""
+    """Hand parameter gradients back to autograd -- or, inside `fused_grad_accumulation()`, for every wanted leaf parameter that
+    already owns a contiguous `.grad` (the flat buffer of spgan.optim.flatten_module) while no graph is being recorded, add them
+    into `.grad` with ONE fused launch (spgan_multi_add) and return None: the same sums AccumulateGrad would form with one
+    elementwise launch per parameter tensor (and on the launch stream, which keeps the step capturable as a hipGraph).  Non-leaf
+    "parameters" (the scaled weights of equalised-LR layers) get their gradient returned.  Exact-zero gradients (nets.ZERO_GRAD)
+    cost nothing on the fused path."""
     ops.flush_tn()                     # weight gradients whose split-K sums were deferred (ops.gemm_tn(defer=True)) become valid here
-    fused = FUSED_GRAD_ACCUMULATION and not torch.is_grad_enabled()
+    fused = _FUSED[0] > 0 and not torch.is_grad_enabled()
     out: List[Optional[Tensor]] = [None] * len(params)
     pairs = []
     for i, (p, g, need) in enumerate(zip(params, grads, needs)):
@@ -109,8 +144,11 @@ class DiscriminatorFn(Function):
     def backward(ctx, dout):
         x, *params = ctx.saved_tensors
         names = ctx.holder.names
-        need_dx = _engine_needs(ctx, 1, 0)
-        need_dp = any(_engine_needs(ctx, 2 + i, 1 + i) for i in range(len(params)))
+        if _INPUT_GRAD_ONLY[0] > 0:
+            need_dx, need_dp = bool(ctx.needs_input_grad[1]), False
+        else:
+            need_dx = _engine_needs(ctx, 1, 0)
+            need_dp = any(_engine_needs(ctx, 2 + i, 1 + i) for i in range(len(params)))
         if torch.is_grad_enabled() and need_dx and not need_dp:
             # create_graph=True and only the input gradient is wanted: differentiable backward
             dx = DiscriminatorBackwardFn.apply(ctx.holder, ctx.dctx, dout, x, *params)

@@ -11,11 +11,11 @@ from __future__ import annotations
 
 from typing import Optional
 
-import numpy as np
 import torch
 from torch.autograd import Function
 
 from . import ops
+from .functions import input_grad_only
 
 
 class _GanLossFn(Function):
@@ -35,15 +35,19 @@ class _GanLossFn(Function):
         return None, None, gr, gf, None, None
 
 
-def _smooth_labels(B, ran=(0.9, 1.0)):
-    return (ran[1] - ran[0]) * np.random.random(B) + ran[0]          # loss_utils.py:698-700
+def _smooth_labels(B, device, ran=(0.9, 1.0)):
+    """loss_utils.py:698-700: labels drawn uniformly from `ran` -- on the device (torch's generator; capturable in a hipGraph,
+    every replay draws fresh values), where the reference draws with host numpy."""
+    return (ran[1] - ran[0]) * torch.rand(B, device=device) + ran[0]
 
 
 def _noisy_labels(y, p_flip=0.05):
-    n = int(p_flip * y.shape[0])                                      # loss_utils.py:718-725
-    ix = np.random.choice([i for i in range(y.shape[0])], size=n)
-    y[ix] = 1 - y[ix]
-    return y
+    """loss_utils.py:718-725: int(p_flip*B) positions drawn with replacement, y[ix] = 1 - y[ix] (a position drawn twice flips once)."""
+    n = int(p_flip * y.shape[0])
+    if n == 0:
+        return y
+    ix = torch.randint(0, y.shape[0], (n,), device=y.device)
+    return y.index_put((ix,), 1 - y[ix])
 
 
 def _mode(gan: str) -> int:
@@ -55,18 +59,21 @@ def _mode(gan: str) -> int:
 
 def dis_loss(d_real, d_fake, gan="wgan", weight=1., d_real_p=None, d_fake_p=None, noise_label=False,
              real_label: Optional[torch.Tensor] = None, fake_label: Optional[torch.Tensor] = None):
-    """Discriminator loss; `noise_label` draws smoothed/flipped real labels with numpy like the reference
-    (loss_utils.py:897-901).  Explicit label tensors [B] may be passed instead (tests)."""
+    """Discriminator loss; `noise_label` draws smoothed/flipped real labels (loss_utils.py:897-901) on the device, so a captured
+    train step draws new ones on every replay.  Explicit label tensors [B] may be passed instead (tests); the labels used are
+    returned in the info dict."""
     if d_real_p is not None or d_fake_p is not None:
         raise NotImplementedError("patch logits (d_real_p/d_fake_p) are not produced by this Discriminator")
     mode = _mode(gan)
     B = d_fake.shape[0]
     if mode == 0 and noise_label and real_label is None:
-        real_label = torch.from_numpy(_noisy_labels(_smooth_labels(B)).astype(np.float32)).to(d_fake.device)
+        real_label = _noisy_labels(_smooth_labels(B, d_fake.device))
     loss, out5 = _GanLossFn.apply(mode, 0, d_real, d_fake, real_label, fake_label)
     if weight != 1.:
         loss = loss * weight
     info = {"loss": loss.detach(), "loss_fake": out5[1], "loss_real": out5[2], "real_acc": out5[3], "fake_acc": out5[4]}
+    if real_label is not None:
+        info["real_label"] = real_label
     return loss, info
 
 
@@ -78,11 +85,14 @@ def gen_loss(d_real, d_fake, gan="wgan", weight=1., d_real_p=None, d_fake_p=None
     mode = _mode(gan)
     B = d_fake.shape[0]
     if mode == 0 and noise_label and fake_label is None:
-        fake_label = torch.from_numpy(_noisy_labels(np.ones((B,))).astype(np.float32)).to(d_fake.device)   # loss_utils.py:753-755
+        fake_label = _noisy_labels(torch.ones(B, device=d_fake.device))                                  # loss_utils.py:753-755
     loss, out5 = _GanLossFn.apply(mode, 1, d_real, d_fake, None, fake_label)
     if weight != 1.:
         loss = loss * weight
-    return loss, {"loss": loss.detach(), "g_loss": out5[1]}
+    info = {"loss": loss.detach(), "g_loss": out5[1]}
+    if fake_label is not None:
+        info["fake_label"] = fake_label
+    return loss, info
 
 
 class _GPPenaltyFn(Function):
@@ -142,6 +152,7 @@ class GradientPenalty:
         else:
             interpolates = ops.lerp_rows(real_d, fake_d, alpha.reshape(B)).requires_grad_(True)
         disc = netD(interpolates)
-        grads = torch.autograd.grad(outputs=disc, inputs=interpolates, grad_outputs=torch.ones_like(disc),
-                                    create_graph=True, retain_graph=True, only_inputs=True)[0]
+        with input_grad_only():          # explicit: this backward wants d disc / d x_hat only, as a differentiable node
+            grads = torch.autograd.grad(outputs=disc, inputs=interpolates, grad_outputs=torch.ones_like(disc),
+                                        create_graph=True, retain_graph=True, only_inputs=True)[0]
         return _GPPenaltyFn.apply(grads.contiguous().view(B, -1), float(self.gamma), float(self.lambdaGP))

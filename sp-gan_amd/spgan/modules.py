@@ -153,8 +153,14 @@ class _BNCounts:
             if isinstance(m, _BNCounts):
                 m._flush_own()
 
+    def _discard_own(self, *args):
+        """load_state_dict replaces `num_batches_tracked`: counts of forwards that ran before the load must not be added later."""
+        for pend in self.__dict__.get("_bn_pending", {}).values():
+            pend.clear()
+
     def _install_count_hook(self):
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_own())
+        self._register_load_state_dict_pre_hook(self._discard_own)
 
 
 class AdaptivePointNorm(nn.Module):

@@ -215,7 +215,10 @@ def d_advance_running_stats(P: Dict[str, Tensor], bufs: Dict[str, Tensor], x_cm:
     a3 = ops.affine_act(a, pro[0], pro[1], NEG)
     mu_a = ops.colsum(a3)[0] * (1.0 / M)
     inv_m = torch.full_like(mu_a, 1.0 / M)
-    cov = ops.rowscale_outer(ops.gemm_tn(a3, a3), inv_m, torch.zeros_like(mu_a), -mu_a, mu_a)      # Gram/M - mu mu^T
+    # Cov(a3) = a3^T (a3 - 1 mu^T) / M: the second operand is centred on load (gemm_tn's affine prologue with slope 1), so no
+    # Gram/M - mu mu^T difference of two large numbers is formed (a3 is a LeakyReLU output: its means are not small); what
+    # rounding leaves of a negative variance is clamped by bn_prepare.
+    cov = ops.rowscale_outer(ops.gemm_tn(a3, a3, pro=(torch.ones_like(mu_a), -mu_a, 1.0)), inv_m)
     mean4 = ops.gemm_nt(mu_a.view(1, -1), W, b4)[0]
     var4 = ops.rowdot(W, ops.gemm_nt(W, cov))
     _bn_train(mean4.contiguous(), var4, P, bufs, bn, M, True, True)

@@ -73,8 +73,9 @@ def _ld(t: Tensor) -> int:
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
 
 
-# Measurement hook (bench.py's roofline leg): launch_timer(kind, args_struct) may return a callable that is invoked right after
-# the launch was enqueued -- the bench brackets selected launches with HIP events on the launch stream.  None in normal use.
+# Measurement hook (bench.py's roofline / MFMA-accounting legs): launch_timer(kind, args) may return a callable that is invoked
+# right after the launch was enqueued -- the bench brackets launches with HIP events on the launch stream.  kind is "gemm_nt"
+# (args: GemmNTArgs -- every gemm_nt flavour), "gemm_tn" (GemmTNArgs) or "knn" (_KnnInfo).  None in normal use.
 launch_timer = None
 
 # Operand precision of the matrix-core contractions behind gemm_nt / gemm_nt_maskout / gemm_nt_bnbwd / gemm_bn_pool:
@@ -98,6 +99,11 @@ def get_mfma_operands() -> str:
 WEIGHTS_EPOCH = [0]
 
 
+class _KnnInfo:
+    def __init__(self, B, N, C, k, mode):
+        self.B, self.N, self.C, self.k, self.mode = B, N, C, k, mode
+
+
 # ----------------------------------------------------------------------------- graph
 def knn(x_pm: Tensor, B: int, N: int, k: int, mode: int = 0) -> Tensor:
     """x_pm [B*N, C] -> idx int32 [B*N, k] (global rows), sorted ascending, rank 0 dropped.
@@ -106,7 +112,10 @@ def knn(x_pm: Tensor, B: int, N: int, k: int, mode: int = 0) -> Tensor:
     if not x_pm.is_contiguous() or x_pm.shape[0] != B * N:
         raise ValueError("x_pm must be contiguous [B*N, C]")
     idx = torch.empty((B * N, k), dtype=torch.int32, device=x_pm.device)
+    done = launch_timer("knn", _KnnInfo(B, N, x_pm.shape[1], k, mode)) if launch_timer is not None else None
     check(_lib.load().spgan_knn(_p(x_pm), B, N, x_pm.shape[1], k, mode, _p(idx), _s()), "knn", B=B, N=N, C=x_pm.shape[1], k=k)
+    if done is not None:
+        done()
     return idx
 
 
@@ -273,7 +282,10 @@ def gemm_nt_batched(A: Tensor, W: Tensor, out: Optional[Tensor] = None) -> Tenso
     a.M, a.N, a.K = M_, N, K
     a.a_mode = A_PLAIN; a.epi_mode = EPI_LINEAR; a.act = ACT_NONE
     a.batch = Z; a.batch_stride_a = A.stride(0); a.batch_stride_w = W.stride(0); a.batch_stride_y = out.stride(0)
+    done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(_lib.load().spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_batched", Z=Z, M=M_, N=N, K=K)
+    if done is not None:
+        done()
     return out
 
 
@@ -288,7 +300,10 @@ def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float) -> Tensor:
     a.M, a.N, a.K = M_, N, K
     a.a_mode = A_PLAIN; a.epi_mode = EPI_MASK_OUT
     a.ref = _p(ref); a.ld_ref = _ld(ref); a.b_slope = float(slope)
+    done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(_lib.load().spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_maskout", M=M_, N=N, K=K)
+    if done is not None:
+        done()
     return Y
 
 
@@ -377,7 +392,10 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
         idx, ebias = edge
         _i32(idx, "idx")
         a.epi_mode = EPI_EDGE_BNBWD; a.e_idx = _p(idx); a.e_k = idx.shape[1]; a.e_bias2 = _p(_vec(ebias, N, "ebias"))
+    done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(_lib.load().spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_bnbwd", M=M_, N=N, K=K)
+    if done is not None:
+        done()
     s0, s1 = _finalize(part, 1, tiles, N, M_, 1)
     return g, s0[0], s1[0]
 
@@ -447,7 +465,10 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     a.beta = float(beta); a.ws = _p(ws); a.ws_bytes = wsb
     defer = bool(defer) and sa is None
     a.defer_reduce = 1 if defer else 0
+    done = launch_timer("gemm_tn", a) if launch_timer is not None else None
     check(lib.spgan_gemm_tn(C.byref(a), _s()), "gemm_tn", M=M_, Na=Na, Nb=Nb)
+    if done is not None:
+        done()
     if defer:
         _PENDING_TN.append((ws, out, lib.spgan_gemm_tn_splits(M_, Na, Nb), Na, Nb, _ld(out), float(beta)))
     return out

@@ -17,9 +17,10 @@ from . import fixture_rng
 
 
 def pc_normalize(pc: torch.Tensor) -> torch.Tensor:
-    """model.py:46-52: centre on the centroid, scale the farthest point to radius 1.  pc [N,3]."""
+    """model.py:46-52: centre on the centroid, scale the farthest point to radius 1.  pc [N,3]; computed in the input's dtype
+    (the reference's numpy version runs in float64: pass a float64 tensor for its exact arithmetic)."""
     pc = pc - pc.mean(dim=0, keepdim=True)
-    return pc / pc.norm(dim=1).max()
+    return pc / pc.pow(2).sum(dim=1).sqrt().max()
 
 
 class InputSampler:
@@ -51,11 +52,29 @@ class InputSampler:
     def _region_order(self, centre: torch.Tensor) -> torch.Tensor:
         """Rows of argsort(ball_dist) for the given centre points.  ball_dist is the reference's expression
         -2*|x|^2|y|^2 + |x|^2 + |y|^2 (model.py:164-167: it multiplies the squared norms instead of taking the inner
-        product) -- kept, since it defines which points a 'region' contains."""
+        product) -- kept, since it defines which points a 'region' contains.  Evaluated the way the reference does -- float64
+        numpy on the host, np.argsort's default sort -- so that the ordering (ties included) is the reference's own; the rows are
+        computed once per centre and cached on the device (pinned by tests/golden/g15_samplers.npz)."""
         self._load_ball()
-        xx = (self.ball ** 2).sum(dim=1)                                              # [np]
-        d = -2.0 * xx[centre][:, None] * xx[None, :] + xx[centre][:, None] + xx[None, :]
-        return torch.argsort(d, dim=1, stable=True)
+        n = self.opts.np
+        if self.ball_order is None:
+            ball = fixture_rng.sphere_template64(n)
+            xx = np.sum(ball ** 2, axis=1).reshape(n, 1)
+            self._ball_dist = -2 * xx @ xx.T + xx + xx.T                              # model.py:164-167
+            self.ball_order = torch.full((n, n), -1, dtype=torch.int64, device=self.device)
+            self._order_known = np.zeros(n, dtype=bool)
+        ids = centre.detach().cpu().numpy().astype(np.int64).reshape(-1)
+        for i in np.unique(ids[~self._order_known[ids]]):
+            self.ball_order[i] = torch.from_numpy(np.argsort(self._ball_dist[i])[::1].copy()).to(self.device)
+            self._order_known[i] = True
+        return self.ball_order[centre.to(self.device).long()]
+
+    def region_mask(self, centre: torch.Tensor, num: torch.Tensor) -> torch.Tensor:
+        """[bs, np] bool: the `num[b]` points closest to `centre[b]` in ball_dist order (model.py:138-143: idx[:num])."""
+        order = self._region_order(centre)
+        n = self.opts.np
+        inside = torch.arange(n, device=self.device)[None, :] < num.to(self.device)[:, None]
+        return torch.zeros((order.shape[0], n), dtype=torch.bool, device=self.device).scatter_(1, order, inside)
 
     # ------------------------------------------------------------------ latent noise
     def noise_generator(self, bs: int = 1, masks: Optional[torch.Tensor] = None, compact: bool = False) -> torch.Tensor:
@@ -84,10 +103,8 @@ class InputSampler:
         if getattr(o, "n_mix", False) and torch.rand((), generator=g, device=dev).item() < 0.5:
             noise2 = torch.randn((bs, o.nz), generator=g, device=dev) * o.nv
             centre = torch.randint(0, o.np, (bs,), generator=g, device=dev)
-            order = self._region_order(centre)                                        # [bs, np]
             num = (torch.rand((bs,), generator=g, device=dev).clamp_min(0.1) * o.np).long()
-            inside = torch.arange(o.np, device=dev)[None, :] < num[:, None]           # first `num` entries of each order row
-            sel = torch.zeros((bs, o.np), dtype=torch.bool, device=dev).scatter_(1, order, inside)
+            sel = self.region_mask(centre, num)                                       # first `num` entries of each order row
             noise = torch.where(sel[:, :, None], noise2[:, None, :], noise)
         return noise
 

@@ -10,7 +10,9 @@ No host<->device synchronisation happens inside step(); losses are returned as d
 `graph=True`: after `graph_warmup` eager steps the whole iteration (2 G forwards, 5 D forwards, all backwards, the gradient
 penalty's double backward, both Adam updates and, data-parallel, both all-reduces: ~580 kernel launches) is captured once into
 a hipGraph and replayed.  The Python/launch cost of a step (~14 ms, as long as the GPU work itself) drops to one graph launch;
-inputs are copied into static buffers (or adopted, when the caller keeps passing the same tensors).
+inputs are copied into static buffers every step; only the sphere prior x is adopted without a copy while the caller keeps
+passing the same unmodified tensor object.  x must be constant in graph mode: the capture depends on its kNN graph, so a changed
+x costs an eager step and a re-capture (and after a few changes the harness stays eager).
 """
 from __future__ import annotations
 
@@ -20,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .functions import fused_grad_accumulation
 from .losses import GradientPenalty, dis_loss, gen_loss
 from .optim import Adam
 from .parallel import DataParallel
@@ -56,7 +59,8 @@ class TrainStep:
         self.use_graph, self.graph_warmup = graph, graph_warmup
         self._graph = None
         self._static = None          # [x, real, z_d, z_g, alpha]
-        self._last_src = None
+        self._x_src = None
+        self._recaptures = 0
         self._static_info = None
         self._eager_calls = 0
         self._bn_delta = None        # host-side BatchNorm call counts of one step (replayed on the host)
@@ -71,27 +75,56 @@ class TrainStep:
         return [{pre: dict(pend) for pre, pend in m.__dict__.get("_bn_pending", {}).items()} for m in self._bn_modules()]
 
     def _bind(self, tensors):
-        """Copy the step's inputs into the static buffers the graph reads.  An input that is the same tensor (storage and
-        version) as on the previous step is not copied again -- the constant sphere template keeps its cached kNN graph."""
+        """Copy the step's inputs into the static buffers the graph reads.  real, z_d, z_g and alpha are copied on EVERY step
+        (16 KB .. 0.8 MB device copies): equal address and version do not prove equal content -- a fresh temporary routinely
+        lands on the block the previous step's temporary just freed.  Only the sphere prior x may be adopted without a copy, and
+        only when it is the same tensor OBJECT at the same version as on the previous step (the constant template: its cached
+        kNN graph stays valid).  Returns True when x changed."""
+        import weakref
         if self._static is None:
             self._static = [None if t is None else t.detach().clone() for t in tensors]
-            self._last_src = [None if t is None else (t.data_ptr(), t._version) for t in tensors]
-            return
+            self._x_src = (weakref.ref(tensors[0]), tensors[0]._version)
+            return False
+        x_changed = False
         for i, t in enumerate(tensors):
             st = self._static[i]
             if t is None or st is None:
                 if (t is None) != (st is None):
                     raise ValueError("graph mode: alpha must be given on every step or on none")
                 continue
-            key = (t.data_ptr(), t._version)
-            if key != self._last_src[i]:
-                if t.shape != st.shape:
-                    raise ValueError("graph mode needs static shapes: got %s, captured %s" % (tuple(t.shape), tuple(st.shape)))
-                st.copy_(t)
-                self._last_src[i] = key
+            if t.shape != st.shape:
+                raise ValueError("graph mode needs static shapes: got %s, captured %s" % (tuple(t.shape), tuple(st.shape)))
+            if i == 0:
+                ref, ver = self._x_src
+                if ref() is t and ver == t._version:
+                    continue
+                # a different prior tensor (or the same one modified in place): the content may or may not differ -- compare on
+                # the device only when a captured graph depends on it (one host sync, off the steady-state path)
+                if self._graph is not None and not bool(torch.equal(st, t)):
+                    x_changed = True
+                self._x_src = (weakref.ref(t), t._version)
+                if self._graph is None or x_changed:
+                    st.copy_(t)
+                continue
+            st.copy_(t)
+        return x_changed
 
     def _graph_step(self, x, real, z_d, z_g, alpha):
-        self._bind((x, real, z_d, z_g, alpha))
+        if self._bind((x, real, z_d, z_g, alpha)):
+            # The sphere prior changed after the capture.  The captured kernels hold the kNN graph, its CSR and the
+            # "every shape carries the same prior" decision of the OLD x (Generator caches them per tensor and version, so the
+            # capture contains no kNN launch): replaying would silently use stale neighbours.  Drop the graph, run this step
+            # eagerly (rebuilds the caches for the new x) and capture again on the next one; a caller whose prior changes every
+            # step (sphere_generator(static=False)) gets eager issue for good after a few re-captures.
+            self._graph = None
+            self._recaptures += 1
+            if self._recaptures > 3:
+                import warnings
+                warnings.warn("TrainStep(graph=True): the sphere prior x keeps changing between steps; the captured graph depends on "
+                              "its kNN graph, so steps are issued eagerly from now on")
+                self.use_graph = False
+                return self._eager_step(x, real, z_d, z_g, alpha)
+            self._eager_calls = max(self.graph_warmup - 1, 0)
         if self._graph is None and self._eager_calls < self.graph_warmup:
             # eager warm-up on a side stream (allocator / autograd state as the capture will see it)
             if self._side is None:
@@ -195,7 +228,8 @@ class TrainStep:
         loss_d, dinfo = dis_loss(d_real, d_fake, gan=self.gan, noise_label=self.flip_d)
         if self.use_gp:
             loss_d = loss_d + self.gp(D, real_t, fake, alpha=alpha)
-        loss_d.backward()
+        with fused_grad_accumulation():
+            loss_d.backward()
         if keep_grads:
             info["fake_d"] = fake
         info.update(loss_d=loss_d.detach(), real_acc=dinfo["real_acc"], fake_acc=dinfo["fake_acc"])
@@ -219,7 +253,8 @@ class TrainStep:
             D.advance_running_stats(real_t)
         g_fake_logit = D(g_fake)
         loss_g, _ = gen_loss(g_real_logit, g_fake_logit, gan=self.gan, noise_label=self.flip_g)
-        loss_g.backward()
+        with fused_grad_accumulation():
+            loss_g.backward()
         if keep_grads:
             info["fake_g"] = g_fake.detach()
         info["loss_g"] = loss_g.detach()

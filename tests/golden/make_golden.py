@@ -245,6 +245,29 @@ def g6():
     d["dis|ls_noisy|loss"] = l.detach().numpy()
     gr, gf = torch.autograd.grad(l, [dr, df])
     d["dis|ls_noisy|g_real"] = gr.numpy(); d["dis|ls_noisy|g_fake"] = gf.numpy()
+    # batch 40: int(0.05*40) = 2 labels really flip (loss_utils.py:718-725), on both sides (D: :897-901, G: :753-755)
+    B2 = 40
+    dr2 = fr.normal("g6.dreal40", (B2, 1)).requires_grad_(True)
+    df2 = fr.normal("g6.dfake40", (B2, 1)).requires_grad_(True)
+    d["b40|d_real"] = dr2.detach().numpy(); d["b40|d_fake"] = df2.detach().numpy()
+    np.random.seed(11)
+    l, _ = LU.dis_loss(dr2, df2, gan="ls", noise_label=True)
+    np.random.seed(11)
+    rl = LU.noisy_labels(LU.smooth_labels(B2, ran=[0.9, 1.0]), 0.05)
+    assert (rl < 0.5).sum() >= 1, "no label flipped"
+    d["b40|dis|ls_noisy|real_label"] = rl.astype(np.float32)
+    d["b40|dis|ls_noisy|loss"] = l.detach().numpy()
+    gr, gf = torch.autograd.grad(l, [dr2, df2])
+    d["b40|dis|ls_noisy|g_real"] = gr.numpy(); d["b40|dis|ls_noisy|g_fake"] = gf.numpy()
+    np.random.seed(12)
+    l, _ = LU.gen_loss(dr2, df2, gan="ls", noise_label=True)
+    np.random.seed(12)
+    fl = LU.noisy_labels(np.ones((B2,)), 0.05)
+    assert (fl < 0.5).sum() >= 1
+    d["b40|gen|ls_noisy|fake_label"] = fl.astype(np.float32)
+    d["b40|gen|ls_noisy|loss"] = l.detach().numpy()
+    gf, = torch.autograd.grad(l, [df2])
+    d["b40|gen|ls_noisy|g_fake"] = gf.numpy()
     save("g6_losses.npz", d)
 
 
@@ -537,8 +560,77 @@ def g14():
     save("g14_jsd.npz", d)
 
 
+def extract_methods(path, cls, names, extra_globals):
+    """Compile selected methods of a reference class into a bare stand-in class (the class body around them -- trainer set-up,
+    CUDA calls -- does not run here)."""
+    tree = ast.parse(open(path).read())
+    cdef = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls][0]
+    body = [n for n in cdef.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    mod = ast.Module(body=[ast.ClassDef(name=cls, bases=[], keywords=[], body=body, decorator_list=[])], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    ns = dict(extra_globals)
+    exec(compile(mod, path, "exec"), ns)
+    return ns[cls]
+
+
+def g15():
+    """The deterministic halves of the input samplers (Generation/model.py:46-52, 122-180): pc_normalize, the normalised sphere
+    prior, the `ball_dist` region ordering, and which points a region-mixed latent covers for a given (centre, size)."""
+    import random
+    MP = os.path.join(REF, "Generation/model.py")
+    PN = extract_functions(MP, ["pc_normalize"], dict(np=np))
+    d = {}
+    pc = (fr.normal("g15.pc", (300, 3)) * 2.5 + 4.0).double().numpy()
+    d["pc_normalize|in"] = pc
+    d["pc_normalize|out"] = PN.pc_normalize(pc.copy())
+    Model = extract_methods(MP, "Model", ["noise_generator", "sphere_generator"],
+                            dict(np=np, random=random, torch=torch, Variable=Variable, pc_normalize=PN.pc_normalize))
+    cwd = os.getcwd()
+    os.chdir(REF)                                                   # 'template/balls/%d.xyz' is a relative path (model.py:159)
+    try:
+        for n_pts in (256, 2048):
+            m = Model()
+            m.opts = types.SimpleNamespace(np=n_pts, nz=128, nv=0.2, n_rand=False, n_mix=True)
+            m.ball = None
+            ball = m.sphere_generator(bs=2, static=True)
+            assert torch.equal(ball[0], ball[1])
+            d["N%d|ball" % n_pts] = ball[0].numpy()                  # fp32, as the Generator receives it
+            ids = [0, 17, n_pts // 2, n_pts - 1]
+            d["N%d|order_ids" % n_pts] = np.array(ids)
+            d["N%d|order" % n_pts] = np.stack([np.argsort(m.ball_dist[i])[::1] for i in ids]).astype(np.int32)
+            # region mixing: record the (centre, size) the reference draws and the points that received the second latent
+            bs = 6
+            rec = {"ids": [], "u": []}
+            real_randint, real_random = np.random.randint, random.random
+
+            def randint(*a, **k):
+                v = real_randint(*a, **k); rec["ids"].append(int(v)); return v
+
+            def rnd():
+                v = real_random(); rec["u"].append(v); return v
+            np.random.seed(100 + n_pts); random.seed(3)                # seed 3: the coin flip (first random.random()) is < 0.5
+            np.random.randint, random.random = randint, rnd
+            try:
+                noise = m.noise_generator(bs=bs)
+            finally:
+                np.random.randint, random.random = real_randint, real_random
+            assert rec["u"][0] < 0.5 and len(rec["ids"]) == bs and len(rec["u"]) == bs + 1
+            noise = noise.numpy()                                      # [bs, np, nz]
+            masks = np.zeros((bs, n_pts), dtype=np.uint8)
+            for i in range(bs):
+                first = noise[i, np.argsort(m.ball_dist[rec["ids"][i]])[0]]      # the region's latent (its closest point is always inside)
+                masks[i] = (noise[i] == first).all(axis=1)
+            nums = np.array([int(max(u, 0.1) * n_pts) for u in rec["u"][1:]])
+            assert (masks.sum(1) == nums).all(), (masks.sum(1), nums)
+            d["N%d|mix_ids" % n_pts] = np.array(rec["ids"]); d["N%d|mix_num" % n_pts] = nums
+            d["N%d|mix_mask" % n_pts] = np.packbits(masks, axis=1)
+    finally:
+        os.chdir(cwd)
+    save("g15_samplers.npz", d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for name in which:
         globals()[name]()

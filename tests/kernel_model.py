@@ -296,7 +296,7 @@ def colsum(X, G=None):
 
 def bn_prepare(mean, var, gamma, beta, count, training=True, running_mean=None, running_var=None, momentum=BN_MOMENTUM, eps=BN_EPS):
     if training:
-        m, v = mean, var
+        m, v = mean, var.clamp(min=0)
         if running_mean is not None:
             unb = v * (count / (count - 1)) if count > 1 else v
             running_mean.mul_(1 - momentum).add_(momentum * m)

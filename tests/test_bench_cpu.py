@@ -1,0 +1,43 @@
+"""bench.py's plumbing on the CPU (SPGAN_BENCH_SELFTEST=1: tiny shapes, gloo, kernel-model doubles): `python bench.py --gpus 2`
+started WITHOUT torchrun -- exactly how the driver starts it -- must launch its own two ranks, run the data-parallel step,
+print ONE JSON line from rank 0 with n_gpus = the world size it observed, and exit 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = dict(os.environ, SPGAN_BENCH_SELFTEST="1", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=600)
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_bench_self_launches_its_ranks(n):
+    r = _run(["--gpus", str(n), "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["selftest"] is True and line["n_gpus"] == n and line["world_size_observed"] == n
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["unit"] == "shapes/s"
+    assert line["config"]["global_batch"] == 2 * n and line["config"]["parallelism"] == "dp%d" % n
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+    if n > 1:
+        assert line["collective_backend"] == "gloo"
+
+
+def test_bench_refuses_a_mismatched_world():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

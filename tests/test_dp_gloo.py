@@ -1,7 +1,10 @@
-"""CPU, world_size 2 over gloo: the data-parallel path (spgan.parallel + TrainStep(distributed=True)).
-Two ranks each take half of the batch; after one step both ranks hold identical parameters, and the
-all-reduced gradient equals the mean of the per-rank gradients (what nn.DataParallel's reduce-add of
-replica gradients of the full-batch-mean loss gives, Generation/model.py:79-84; BN stays per replica)."""
+"""CPU, world_size 2 and 4 over gloo: the data-parallel path (spgan.parallel + TrainStep(distributed=True)) against its
+contract (Generation/model.py:79-84): an N-rank step equals the single-process step on the concatenated batch with
+per-replica BatchNorm -- the shards evaluated one after the other from the same weights, their gradients averaged (what
+nn.DataParallel's reduce-add of the replica gradients of the full-batch-mean loss gives), one Adam update.
+
+The single-process side runs the SAME harness segments (TrainStep._seg_d / _seg_g / _seg_opt_g) on W model copies and sums
+their flat gradient buffers by hand where the distributed run calls dist.all_reduce."""
 import os
 import socket
 import sys
@@ -12,59 +15,139 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BG, N = 8, 128            # global batch, points
+
+
+class O:
+    np = N; nk = 20; nz = 128; softmax = True; off = False; attn = False; use_head = False; eql = False; z_norm = False; small_d = False
 
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out):
+def _setup_paths():
     for p in (ROOT, os.path.join(ROOT, "sp-gan_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    import inspect
-    import kernel_model as km
+
+
+def _models(salt):
     import spgan
-    import spgan.modules as modules
-    import spgan.ops as ops
-    for name, fn in inspect.getmembers(km, inspect.isfunction):
-        if not name.startswith("_"):
-            setattr(ops, name, fn)
-    ops.SparseAffine = km.SparseAffine
-    modules._require_gpu = lambda t, what: None
     from oracle import spgan_oracle as orc
     from spgan import fixture_rng as fr
+    G, D = spgan.Generator(O), spgan.Discriminator(O)
+    G.load_state_dict({**G.state_dict(), **fr.init_params(orc.generator_shapes(), salt=salt)})
+    D.load_state_dict({**D.state_dict(), **fr.init_params(orc.discriminator_shapes(), salt=salt)})
+    return G, D
+
+
+def _inputs():
+    from spgan import fixture_rng as fr
+    x = fr.sphere_template(256)[:N][None].repeat(BG, 1, 1)
+    return x, fr.synthetic_real(BG, N, seed=7), fr.latent(BG, N, seed=8), fr.latent(BG, N, seed=9), fr.uniform("dp.alpha", (BG, 1, 1), 0.0, 1.0)
+
+
+def _flat(module):
+    return torch.cat([p.detach().reshape(-1) for p in module.parameters()])
+
+
+def _worker(rank, world, port, out, gan, use_gp):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from helpers import install_kernel_models
+    import spgan
+    install_kernel_models()
     torch.set_num_threads(2)
     assert spgan.init_process_group_from_env("gloo") == rank
-
-    class O:
-        np = 128; nk = 20; nz = 128; softmax = True; off = False; attn = False; use_head = False; eql = False; z_norm = False; small_d = False
-    G, D = spgan.Generator(O), spgan.Discriminator(O)
     # different initial weights per rank on purpose: sync_params() must make them rank 0's
-    sd = G.state_dict(); G.load_state_dict({**sd, **fr.init_params(orc.generator_shapes(), salt=100 + rank)})
-    sd = D.state_dict(); D.load_state_dict({**sd, **fr.init_params(orc.discriminator_shapes(), salt=100 + rank)})
-    tr = spgan.TrainStep(G, D, gan="ls", distributed=True)
-    Bg, N = 4, 128
-    x = fr.sphere_template(256)[:N][None].repeat(Bg, 1, 1)
-    real = fr.synthetic_real(Bg, N, seed=7)
-    z_d, z_g = fr.latent(Bg, N, seed=8), fr.latent(Bg, N, seed=9)
+    G, D = _models(100 + rank)
+    tr = spgan.TrainStep(G, D, gan=gan, use_gp=use_gp, distributed=True)
     sh = lambda t: spgan.shard_batch(t, rank, world).contiguous()
-    info = tr.step(sh(x), sh(real), sh(z_d), sh(z_g), keep_grads=True)
-    flatD = torch.cat([p.detach().reshape(-1) for p in D.parameters()])
-    flatG = torch.cat([p.detach().reshape(-1) for p in G.parameters()])
+    info = tr.step(*[sh(t) for t in _inputs()], keep_grads=True)
     gD = torch.cat([g.reshape(-1) for g in info["d_grads"].values()])
-    torch.save(dict(flatD=flatD, flatG=flatG, gD=gD, local_gD=None), os.path.join(out, "r%d.pt" % rank))
+    gG = torch.cat([g.reshape(-1) for g in info["g_grads"].values()])
+    torch.save(dict(flatD=_flat(D), flatG=_flat(G), gD=gD, gG=gG, loss_d=info["loss_d"], loss_g=info["loss_g"],
+                    bufD={k: v.clone() for k, v in D.state_dict().items() if "running" in k}), os.path.join(out, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_step(tmp_path):
-    world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    assert torch.equal(a["flatD"], b["flatD"]) and torch.equal(a["flatG"], b["flatG"]), "ranks diverged after one step"
-    assert torch.equal(a["gD"], b["gD"])
+def _single_process_reference(world, gan, use_gp):
+    """The same step on the concatenated batch in ONE process: W replicas from rank 0's weights, shard r on replica r (per-replica
+    BatchNorm statistics), gradient buffers summed by hand, every replica's Adam applies sum/W."""
+    import spgan
+    from helpers import install_kernel_models
+    install_kernel_models()
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(2)                                    # same CPU reduction orders as the workers
+    reps = []
+    for r in range(world):
+        G, D = _models(100)                                     # rank 0's weights (what sync_params broadcasts)
+        reps.append((G, D, spgan.TrainStep(G, D, gan=gan, use_gp=use_gp, distributed=False)))
+    ins = _inputs()
+    sh = lambda t, r: spgan.shard_batch(t, r, world).contiguous()
+    infos = [dict() for _ in range(world)]
+    real_ts = []
+    for r, (G, D, tr) in enumerate(reps):
+        x, real, z_d, z_g, alpha = [sh(t, r) for t in ins]
+        real_ts.append(tr._seg_d(x, real, z_d, alpha, False, infos[r]))
+    gD_sum = sum(tr.optD.fp.grad for _, _, tr in reps)
+    for _, _, tr in reps:
+        tr.optD.fp.grad.copy_(gD_sum)
+    for r, (G, D, tr) in enumerate(reps):
+        x, real, z_d, z_g, alpha = [sh(t, r) for t in ins]
+        tr._seg_g(x, real_ts[r], z_g, 1.0 / world, True, infos[r])
+    gG_sum = sum(tr.optG.fp.grad for _, _, tr in reps)
+    for r, (G, D, tr) in enumerate(reps):
+        tr.optG.fp.grad.copy_(gG_sum)
+        tr._seg_opt_g(1.0 / world, True, infos[r])
+    torch.set_num_threads(nthreads)
+    G0, D0, _ = reps[0]
+    gD = torch.cat([g.reshape(-1) for g in infos[0]["d_grads"].values()])
+    gG = torch.cat([g.reshape(-1) for g in infos[0]["g_grads"].values()])
+    return dict(flatD=_flat(D0), flatG=_flat(G0), gD=gD, gG=gG, loss_d=[i["loss_d"] for i in infos], loss_g=[i["loss_g"] for i in infos],
+                bufD=[{k: v.clone() for k, v in D.state_dict().items() if "running" in k} for _, D, _ in reps])
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("world,gan,use_gp", [(2, "ls", False), (2, "wgan", True), (4, "wgan", True)])
+def test_n_rank_step_equals_single_process_on_concatenated_batch(tmp_path, world, gan, use_gp):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), gan, use_gp), nprocs=world, join=True)
+    ranks = [torch.load(tmp_path / ("r%d.pt" % r)) for r in range(world)]
+    for r in ranks[1:]:
+        assert torch.equal(ranks[0]["flatD"], r["flatD"]) and torch.equal(ranks[0]["flatG"], r["flatG"]), "ranks diverged after one step"
+        assert torch.equal(ranks[0]["gD"], r["gD"]) and torch.equal(ranks[0]["gG"], r["gG"])
+    _setup_paths()
+    ref = _single_process_reference(world, gan, use_gp)
+    a = ranks[0]
+    # the all-reduced gradient is the mean of the per-shard gradients (sum order of gloo's reduction may differ for W > 2)
+    assert _rel(a["gD"], ref["gD"]) <= 1e-6, _rel(a["gD"], ref["gD"])
+    assert _rel(a["gG"], ref["gG"]) <= 1e-6, _rel(a["gG"], ref["gG"])
+    if world == 2:
+        assert torch.equal(a["gD"], ref["gD"]) and torch.equal(a["gG"], ref["gG"])          # a + b in both runs: bit-identical
+        assert torch.equal(a["flatD"], ref["flatD"]) and torch.equal(a["flatG"], ref["flatG"])
+    # parameters after Adam: an element moves by <= lr = 1e-4; equal up to the rounding of the gradient sum
+    # (W = 2: bit-identical, asserted above).  Adam divides by sqrt(v) = |g| on the first step, so where a gradient element is
+    # itself rounding noise (|g| within a few ulp of the sum's rounding error) a different summation order can flip the sign of a
+    # +-lr step: such elements are compared through the gradient (above), the rest element-wise.
+    for fa, fr_, g in ((a["flatD"], ref["flatD"], ref["gD"]), (a["flatG"], ref["flatG"], ref["gG"])):
+        diff = (fa - fr_).abs()
+        solid = g.abs() > 1e-6 * g.abs().max()
+        assert diff[solid].max().item() <= 1e-6, diff[solid].max().item()
+        assert diff.max().item() <= 2.01e-4 and (diff > 1e-6).float().mean().item() < 1e-3
+    # per-replica losses and BatchNorm running statistics (each rank keeps the statistics of its own shard)
+    for r in range(world):
+        assert torch.allclose(ranks[r]["loss_d"], ref["loss_d"][r], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(ranks[r]["loss_g"], ref["loss_g"][r], rtol=1e-5, atol=1e-7)
+        for k, v in ranks[r]["bufD"].items():
+            assert torch.allclose(v, ref["bufD"][r][k], rtol=1e-6, atol=1e-7), k
+    # and the shards really differ: the mean is not any single rank's gradient
+    assert (ranks[0]["bufD"]["mlps.1.running_mean"] - ranks[1]["bufD"]["mlps.1.running_mean"]).abs().max().item() > 1e-6
 
 
 def test_shard_batch_and_flat_allreduce_single_process():

@@ -69,3 +69,121 @@ def test_networks_f16_close_to_f32(sp):
     assert (a[1] == b[1]).all(dim=1).float().mean().item() > 0.9                    # EdgeConv2 kNN rows
     assert ((a[3] - b[3]).abs().max() / a[3].abs().max()).item() < 2e-2             # D logits
     assert abs(a[2].std().item() - b[2].std().item()) / a[2].std().item() < 0.1     # generated cloud: same scale
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fp16-operand mode against the REFERENCE (golden vectors) and the oracle -- not against our own fp32 path.
+# Stated tolerances: operands are rounded to fp16 (relative 2^-11 = 4.9e-4 each) once per contraction, products and sums are
+# exact/fp32, everything between contractions is fp32.  A K-term dot product of rounded operands has a relative error of about
+# 4.9e-4 * sqrt(2/K) * (|a||w| / |a.w|); through 3-6 chained layers with BatchNorm re-normalising in between that leaves
+# ~1e-3 on activations and ~1e-2 on gradients.  Measured values are in profiles/r02_parity.json; bounds are <= 3x those.
+from helpers import check, golden, rel_l2   # noqa: E402
+
+
+@pytest.fixture()
+def f16sp(sp):
+    sp.ops.set_mfma_operands("f16")
+    yield sp
+    sp.ops.set_mfma_operands("f32")
+
+
+def test_f16_generator_stage_vs_reference_golden(f16sp):
+    """G4 (captured from the reference): the sphere graph stays bit-exact (fp64 kNN, not an MFMA product), the stage in front of
+    EdgeConv2's graph is within fp16-operand accuracy of the REFERENCE's fp32 values."""
+    sp = f16sp
+    d = golden("g4_generator.npz")
+    B, N = 4, 256
+    G = _load(sp.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=4)).train()
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    z = fr.latent(B, N, seed=44).cuda()
+    out = G(x, z)
+    i1 = sp.ops.idx_to_local64(G.EdgeConv1.last_idx, B, N).view(B, N, 10).cpu().numpy()
+    assert np.array_equal(i1, d["idx1"]), "sphere graph must be bit-exact in fp16-operand mode too"
+    check(d, "stage|x1", sp.ops.pm_to_cm(G.last_x1, B, N), rtol=3e-3, what="f16")
+    i2 = sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).view(B, N, 10).cpu().numpy()
+    assert (i2 == d["idx2"]).all(axis=2).mean() >= 0.9
+    assert torch.isfinite(out).all()
+
+
+def test_f16_generator_vs_oracle_with_injected_graph(f16sp):
+    """The fp32 CPU oracle evaluated on the kNN graphs the fp16-operand run chose (tie-aware protocol): output and parameter
+    gradients within fp16-operand accuracy."""
+    sp = f16sp
+    B, N = 4, 256
+    p = fr.init_params(orc.generator_shapes(), salt=31)
+    G = _load(sp.Generator(Opts), p).train()
+    x = fr.synthetic_real(B, N, seed=32); z = fr.latent(B, N, seed=33)
+    out = G(x.cuda(), z.cuda())
+    idx1 = sp.ops.idx_to_local64(G.EdgeConv1.last_idx, B, N).cpu()
+    idx2 = sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).cpu()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = orc.generator_forward(po, x, z, training=True, buffers=orc.bn_buffers(orc.generator_shapes()), idx1=idx1, idx2=idx2)
+    assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy(), "f16|G out vs oracle (injected graphs)") <= 1e-2
+    dy = fr.normal("pg.dy", out.shape)
+    (out * dy.cuda()).sum().backward()
+    names = [n for n in po if not n.endswith(("conv_w.0.bias", "conv_w.3.bias", "conv_x.0.bias", "global_conv.0.bias", "global_conv.3.bias"))]
+    grads = torch.autograd.grad((ref * dy).sum(), [po[n] for n in names])
+    gsd = dict(G.named_parameters())
+    fa = torch.cat([gsd[n].grad.cpu().reshape(-1) for n in names]); fb = torch.cat([g.reshape(-1) for g in grads])
+    cos = (torch.dot(fa, fb) / (fa.norm() * fb.norm())).item()
+    assert cos >= 0.999, cos
+    assert rel_l2(fa.numpy(), fb.numpy(), "f16|G all parameter gradients vs oracle") <= 5e-2
+
+
+def test_f16_discriminator_vs_reference_golden(f16sp):
+    """G5 (captured from the reference): logits, the input gradient (the WGAN-GP route) and the parameter gradients."""
+    sp = f16sp
+    d = golden("g5_discriminator.npz")
+    B, N = 4, 256
+    D = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=4)).train()
+    real = fr.synthetic_real(B, N, seed=5).transpose(2, 1).contiguous().cuda().requires_grad_(True)
+    logit = D(real)
+    check(d, "logit", logit, rtol=5e-3, what="f16")
+    ((logit - 1.0) ** 2).mean().backward()
+    check(d, "dx", real.grad, rtol=3e-2, what="f16")
+    for n, p in D.named_parameters():
+        if not n.endswith(("mlps.0.bias", "mlps.3.bias", "mlps.6.bias", "fc2.0.bias")):
+            check(d, "grad|" + n, p.grad, rtol=5e-2, atol=1e-6, what="f16")
+    # the gradient penalty against golden G7 (double backward through fp16-operand contractions)
+    d7 = golden("g7_gradient_penalty.npz")
+    D7 = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=7)).train()
+    B7 = 3
+    real7 = fr.synthetic_real(B7, N, seed=71).transpose(2, 1).contiguous().cuda()
+    fake7 = (0.8 * fr.synthetic_real(B7, N, seed=72) + 0.05 * fr.normal("g7.n", (B7, N, 3))).transpose(2, 1).contiguous().cuda()
+    gp = sp.GradientPenalty(10.0, gamma=1)(D7, real7, fake7, alpha=torch.from_numpy(d7["alpha"]).cuda())
+    np.testing.assert_allclose(gp.item(), float(d7["gp"]), rtol=2e-2)
+
+
+def test_f16_full_size_config_properties(f16sp):
+    """The per-GPU shape of BASELINE configs[4] / [1] -- batch 32, N = 2048, WGAN-GP -- in fp16-operand mode: size-independent
+    properties.  The sphere graph is bit-exact against the oracle's sort, two runs are bit-identical (no atomics, fixed-order
+    reductions), everything stays finite, the generated cloud is inside tanh's range and one Adam step moves a parameter by
+    at most lr."""
+    sp = f16sp
+    B, N = 32, 2048
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    real = fr.synthetic_real(B, N, seed=1).cuda()
+    zd, zg = fr.latent(B, N, seed=2)[:, :1].contiguous().cuda(), fr.latent(B, N, seed=3)[:, :1].contiguous().cuda()
+    alpha = fr.uniform("f16.full.alpha", (B, 1, 1), 0.0, 1.0).cuda()
+
+    class O2048(Opts):
+        np = 2048
+    runs = []
+    for r in range(2):
+        G = _load(sp.Generator(O2048), fr.init_params(orc.generator_shapes(), salt=8))
+        D = _load(sp.Discriminator(O2048), fr.init_params(orc.discriminator_shapes(), salt=8))
+        p0 = torch.cat([p.detach().reshape(-1).clone() for p in list(G.parameters()) + list(D.parameters())])
+        tr = sp.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4)
+        info = tr.step(x, real, zd, zg, alpha=alpha, keep_grads=True)
+        torch.cuda.synchronize()
+        p1 = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
+        runs.append((info["loss_d"].item(), info["loss_g"].item(), p1.clone(), info["fake_g"].clone()))
+        assert torch.isfinite(p1).all() and np.isfinite(runs[-1][0]) and np.isfinite(runs[-1][1])
+        assert (p1 - p0).abs().max().item() <= 1.0001e-4
+        assert info["fake_g"].abs().max().item() <= 1.0
+        if r == 0:
+            own = orc.knn_sorted(fr.sphere_template(N)[None].transpose(2, 1).contiguous(), 10).reshape(1, -1)
+            got = sp.ops.idx_to_local64(G.EdgeConv1.last_idx[:N].contiguous(), 1, N).cpu()
+            assert torch.equal(own, got), "sphere graph differs from the oracle at N=2048"
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3]), "fp16-operand step is not deterministic"

@@ -129,3 +129,91 @@ def test_graph_capture_failure_falls_back_to_eager(sp, monkeypatch):
                               list(Gg.state_dict().items()) + list(Dg.state_dict().items())):
         assert torch.equal(a, b), n
     assert (trg.optG.t, trg.optD.t) == (steps, steps)
+
+
+def _state(G, D):
+    return list(G.state_dict().items()) + list(D.state_dict().items())
+
+
+def test_graph_replay_with_fresh_temporaries_every_step(sp):
+    """The caller hands over freshly allocated tensors on every step and frees them afterwards (examples/train.py does): the
+    caching allocator returns the just-freed blocks, so the new tensors recur at old addresses with version 0.  The graph's
+    static buffers must nevertheless hold the NEW content on every replay."""
+    steps, B, N = 8, 4, 256
+
+    def run(graph):
+        G = _load(sp.Generator(Opts()), fr.init_params(orc.generator_shapes(), salt=8))
+        D = _load(sp.Discriminator(Opts()), fr.init_params(orc.discriminator_shapes(), salt=8))
+        tr = sp.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, graph=graph, graph_warmup=2)
+        x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+        losses, ptrs = [], []
+        for i in range(steps):
+            real = fr.synthetic_real(B, N, seed=300 + i).cuda() * 1.0          # temporaries: products of an op, freed after the step
+            z_d = fr.latent(B, N, seed=400 + i).cuda() * 1.0
+            z_g = fr.latent(B, N, seed=500 + i).cuda() * 1.0
+            alpha = fr.uniform("tmp.alpha.%d" % i, (B, 1, 1), 0.0, 1.0).cuda() * 1.0
+            ptrs.append((real.data_ptr(), z_d.data_ptr(), z_g.data_ptr(), real._version))
+            info = tr.step(x, real, z_d, z_g, alpha=alpha)
+            losses.append((info["loss_d"].item(), info["loss_g"].item()))
+            del real, z_d, z_g, alpha
+        torch.cuda.synchronize()
+        return G, D, tr, losses, ptrs
+
+    Ge, De, _, le, _ = run(False)
+    Gg, Dg, trg, lg, ptrs = run(True)
+    assert trg._graph is not None
+    assert len({p[:3] for p in ptrs[3:]}) < len(ptrs[3:]), "the scenario needs recurring addresses to mean anything"
+    assert le == lg, (le, lg)
+    for (n, a), (_, b) in zip(_state(Ge, De), _state(Gg, Dg)):
+        assert torch.equal(a, b), n
+
+
+def test_graph_mode_survives_a_changed_sphere_prior(sp):
+    """The capture depends on the kNN graph of x (cached per tensor and version, so no kNN launch is inside the graph).  A new x
+    after the capture must not replay stale neighbours: the harness steps eagerly once, re-captures, and stays equal to eager."""
+    steps, B, N = 9, 4, 256
+
+    def run(graph):
+        G = _load(sp.Generator(Opts()), fr.init_params(orc.generator_shapes(), salt=8))
+        D = _load(sp.Discriminator(Opts()), fr.init_params(orc.discriminator_shapes(), salt=8))
+        tr = sp.TrainStep(G, D, gan="ls", graph=graph, graph_warmup=2)
+        xa = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+        perm = torch.randperm(N, generator=torch.Generator().manual_seed(1))
+        xb = (fr.sphere_template(N)[perm] * 0.9)[None].repeat(B, 1, 1).cuda()            # a different prior (other points, other graph)
+        real = fr.synthetic_real(B, N, seed=90).cuda()
+        zs = [fr.latent(B, N, seed=70 + i).cuda() for i in range(2)]
+        losses = []
+        for i in range(steps):
+            x = xa if i < 5 else xb
+            if i == 7:
+                xb.mul_(1.05)                                                             # ... and an in-place change of the same tensor
+            info = tr.step(x, real, zs[0], zs[1])
+            losses.append((info["loss_d"].item(), info["loss_g"].item()))
+        torch.cuda.synchronize()
+        return G, D, tr, losses
+
+    Ge, De, _, le = run(False)
+    Gg, Dg, trg, lg = run(True)
+    assert trg._recaptures == 2 and trg._graph is not None and trg.use_graph
+    assert le == lg, (le, lg)
+    for (n, a), (_, b) in zip(_state(Ge, De), _state(Gg, Dg)):
+        assert torch.equal(a, b), n
+
+
+def test_graph_mode_with_noisy_labels(sp):
+    """flip_d / flip_g (noise_label=True in dis_loss / gen_loss): the labels are drawn on the device inside the captured step, so the
+    capture succeeds and every replay draws new ones (the loss of identical inputs differs from replay to replay)."""
+    B, N = 4, 256
+    G = _load(sp.Generator(Opts()), fr.init_params(orc.generator_shapes(), salt=8))
+    D = _load(sp.Discriminator(Opts()), fr.init_params(orc.discriminator_shapes(), salt=8))
+    tr = sp.TrainStep(G, D, gan="ls", flip_d=True, flip_g=True, lr_g=0.0, lr_d=0.0, graph=True, graph_warmup=2)
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    real = fr.synthetic_real(B, N, seed=90).cuda()
+    z = fr.latent(B, N, seed=70).cuda()
+    vals = []
+    for i in range(7):
+        info = tr.step(x, real, z, z)
+        vals.append(info["loss_d"].item())
+    assert tr._graph is not None and tr.use_graph, "capture must succeed with device-side label draws"
+    # lr = 0: parameters never move, BatchNorm is in train mode -> the only thing that changes between replays is the label draw
+    assert len(set(vals[3:])) == len(vals[3:]), vals

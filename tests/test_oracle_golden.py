@@ -161,6 +161,18 @@ def test_losses():
     np.testing.assert_allclose(l.item(), float(d["dis|ls_noisy|loss"]), rtol=1e-6)
     np.testing.assert_allclose(gr.numpy(), d["dis|ls_noisy|g_real"], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(gf.numpy(), d["dis|ls_noisy|g_fake"], rtol=1e-5, atol=1e-8)
+    # batch 40: labels that really flipped, on the D side (:897-901) and on the G side (:753-755)
+    dr = torch.from_numpy(d["b40|d_real"]).requires_grad_(True)
+    df = torch.from_numpy(d["b40|d_fake"]).requires_grad_(True)
+    l = orc.dis_loss(dr, df, "ls", real_label=torch.from_numpy(d["b40|dis|ls_noisy|real_label"]))
+    gr, gf = torch.autograd.grad(l, [dr, df])
+    np.testing.assert_allclose(l.item(), float(d["b40|dis|ls_noisy|loss"]), rtol=1e-6)
+    np.testing.assert_allclose(gr.numpy(), d["b40|dis|ls_noisy|g_real"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(gf.numpy(), d["b40|dis|ls_noisy|g_fake"], rtol=1e-5, atol=1e-8)
+    l = orc.gen_loss(dr, df, "ls", fake_label=torch.from_numpy(d["b40|gen|ls_noisy|fake_label"]))
+    gf, = torch.autograd.grad(l, [df])
+    np.testing.assert_allclose(l.item(), float(d["b40|gen|ls_noisy|loss"]), rtol=1e-6)
+    np.testing.assert_allclose(gf.numpy(), d["b40|gen|ls_noisy|g_fake"], rtol=1e-5, atol=1e-8)
 
 
 # ---------------------------------------------------------------- G7

@@ -290,14 +290,21 @@ def test_shared_sphere_edgeconv1_equals_per_shape_evaluation(sp, monkeypatch):
         np.testing.assert_allclose(res[0][2][n].cpu().numpy(), res[1][2][n].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n)
 
 
-def test_discriminator_advance_running_stats_equals_forward(sp):
+@pytest.mark.parametrize("shifted", [False, True])
+def test_discriminator_advance_running_stats_equals_forward(sp, shifted):
     """D.advance_running_stats(x) leaves exactly the buffers a train-mode D(x) leaves (fc2.1 statistics via the covariance of
-    its input instead of the 1024-wide GEMM)."""
+    its input instead of the 1024-wide GEMM).  shifted: BatchNorm 3 with a large offset and a small scale, i.e. activations whose
+    mean^2 is ~10^4 times their variance -- the regime in which a Gram/M - mu mu^T covariance would lose its digits; the operand
+    is centred on load instead, and the running variance must stay accurate (and non-negative)."""
     B, N = 4, 512
     x = fr.synthetic_real(B, N, seed=55).transpose(2, 1).contiguous().cuda()
+    params = fr.init_params(orc.discriminator_shapes(), salt=14)
+    if shifted:
+        params["mlps.7.bias"] = params["mlps.7.bias"] + 4.0
+        params["mlps.7.weight"] = params["mlps.7.weight"] * 0.04
     bufs = []
     for fast in (False, True):
-        D = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=14)).train()
+        D = _load(sp.Discriminator(Opts), params).train()
         with torch.no_grad():
             D(x * 0.9)                                   # move the running statistics away from (0, 1) first
             if fast:
@@ -306,8 +313,10 @@ def test_discriminator_advance_running_stats_equals_forward(sp):
                 D(x)
         bufs.append({n: b.detach().clone().cpu() for n, b in D.state_dict().items() if n in dict(D.named_buffers())})
     for n in bufs[0]:
-        np.testing.assert_allclose(bufs[1][n].numpy(), bufs[0][n].numpy(), rtol=2e-5, atol=1e-6, err_msg=n)
+        rel_l2(bufs[1][n].float().numpy(), bufs[0][n].float().numpy(), "advance_running_stats%s|%s" % ("|shifted" if shifted else "", n))
+        np.testing.assert_allclose(bufs[1][n].numpy(), bufs[0][n].numpy(), rtol=1e-4 if shifted else 2e-5, atol=1e-6, err_msg=n)
     assert int(bufs[1]["fc2.1.num_batches_tracked"]) == 2
+    assert float(bufs[1]["fc2.1.running_var"].min()) >= 0.0
 
 
 # ---------------------------------------------------------------- non-default flags (G12)

@@ -80,3 +80,27 @@ def test_noise_generator_masks_and_xyz(tmp_path):
     sampling.save_xyz(str(p), pts)
     back = np.loadtxt(str(p))
     assert back.shape == (50, 3) and np.allclose(back, pts.t().numpy(), atol=1e-6)
+
+
+def test_deterministic_sampler_parts_match_reference_golden():
+    """G15 (tests/golden/make_golden.py::g15, produced by the reference's own pc_normalize / sphere_generator / noise_generator
+    compiled from Generation/model.py): normalisation, the sphere prior as the Generator receives it, the ball_dist region
+    ordering and the point set a region-mixed latent covers for the (centre, size) the reference drew."""
+    from helpers import golden
+    d = golden("g15_samplers.npz")
+    out = sampling.pc_normalize(torch.from_numpy(d["pc_normalize|in"]))                # float64 in -> the reference's arithmetic
+    np.testing.assert_allclose(out.numpy(), d["pc_normalize|out"], rtol=1e-13, atol=1e-15)
+    out32 = sampling.pc_normalize(torch.from_numpy(d["pc_normalize|in"]).float())
+    np.testing.assert_allclose(out32.numpy(), d["pc_normalize|out"], rtol=0, atol=2e-6)
+    for n_pts in (256, 2048):
+        class On(O):
+            np = n_pts; n_mix = True
+        s = sampling.InputSampler(On, device="cpu", seed=1)
+        ball = s.sphere_generator(2)
+        assert np.array_equal(ball[0].numpy(), d["N%d|ball" % n_pts]) and torch.equal(ball[0], ball[1])   # bit-exact prior
+        ids = torch.from_numpy(d["N%d|order_ids" % n_pts])
+        assert np.array_equal(s._region_order(ids).numpy(), d["N%d|order" % n_pts])   # the reference's own argsort rows
+        mask = s.region_mask(torch.from_numpy(d["N%d|mix_ids" % n_pts]), torch.from_numpy(d["N%d|mix_num" % n_pts]))
+        ref = np.unpackbits(d["N%d|mix_mask" % n_pts], axis=1)[:, :n_pts].astype(bool)
+        assert np.array_equal(mask.numpy(), ref)
+        assert np.array_equal(mask.sum(1).numpy(), d["N%d|mix_num" % n_pts])

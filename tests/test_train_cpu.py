@@ -34,6 +34,19 @@ def test_losses_golden(spgan_cpu):
     np.testing.assert_allclose(dr.grad.numpy(), d["dis|ls_noisy|g_real"], rtol=1e-4, atol=1e-7)
     with pytest.raises(NotImplementedError):
         spgan.dis_loss(dr, df, gan="nope")
+    # batch 40: labels that really flipped, D side and G side
+    dr = torch.from_numpy(d["b40|d_real"]).requires_grad_(True)
+    df = torch.from_numpy(d["b40|d_fake"]).requires_grad_(True)
+    l, _ = spgan.dis_loss(dr, df, gan="ls", real_label=torch.from_numpy(d["b40|dis|ls_noisy|real_label"]))
+    l.backward()
+    np.testing.assert_allclose(l.item(), float(d["b40|dis|ls_noisy|loss"]), rtol=1e-5)
+    np.testing.assert_allclose(dr.grad.numpy(), d["b40|dis|ls_noisy|g_real"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(df.grad.numpy(), d["b40|dis|ls_noisy|g_fake"], rtol=1e-4, atol=1e-7)
+    df2 = torch.from_numpy(d["b40|d_fake"]).requires_grad_(True)
+    l, _ = spgan.gen_loss(None, df2, gan="ls", fake_label=torch.from_numpy(d["b40|gen|ls_noisy|fake_label"]))
+    l.backward()
+    np.testing.assert_allclose(l.item(), float(d["b40|gen|ls_noisy|loss"]), rtol=1e-5)
+    np.testing.assert_allclose(df2.grad.numpy(), d["b40|gen|ls_noisy|g_fake"], rtol=1e-4, atol=1e-7)
 
 
 @pytest.mark.parametrize("tag,gan,use_gp,B,N", [("ls", "ls", False, 4, 512), ("wgangp", "wgan", True, 4, 256)])
@@ -80,3 +93,60 @@ def test_checkpoint_interchange(spgan_cpu):
     G2.load_state_dict(sd)
     for (n, a), (_, b) in zip(G.named_parameters(), G2.named_parameters()):
         assert torch.equal(a, b), n
+
+
+def test_autograd_contract_outside_trainstep(spgan_cpu):
+    """Outside TrainStep parameter gradients travel through autograd as usual: torch.autograd.grad returns them and leaves
+    `.grad` alone even when the module was flattened (p.grad pre-bound), tensor hooks fire; only inside
+    `fused_grad_accumulation()` are they added straight into the flat buffer."""
+    import spgan
+    from spgan.functions import fused_grad_accumulation
+    D = _load(spgan.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=21)).train()
+    spgan.flatten_module(D)
+    x = fr.synthetic_real(2, 128, seed=22).transpose(2, 1).contiguous()
+    params = list(D.parameters())
+    before = [p.grad.clone() for p in params]
+    seen = []
+    h = params[0].register_hook(lambda g: seen.append(g.clone()))
+    grads = torch.autograd.grad(D(x).sum(), params)
+    assert all(g is not None for g in grads) and len(seen) == 1
+    assert all(torch.equal(p.grad, b) for p, b in zip(params, before)), "autograd.grad must not touch .grad"
+    h.remove()
+    D(x).sum().backward()                                             # plain backward: AccumulateGrad adds into the bound slices
+    flat = D._spgan_flat
+    assert all(p.grad.data_ptr() == flat.grad.data_ptr() + 4 * off for p, off in zip(flat.params, flat.offsets))
+    for p, g in zip(params, grads):
+        assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-8)
+    flat.zero_grad()
+    with fused_grad_accumulation():
+        D(x).sum().backward()
+    for p, g in zip(params, grads):
+        assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-8)
+
+
+def test_load_state_dict_discards_pending_bn_counts(spgan_cpu):
+    import spgan
+    D = spgan.Discriminator(Opts).train()
+    x = fr.synthetic_real(2, 128, seed=23).transpose(2, 1).contiguous()
+    D(x); D(x)
+    sd = {k: v.clone() for k, v in D.state_dict().items()}            # flushes: 2 calls recorded
+    assert int(sd["mlps.1.num_batches_tracked"]) == 2
+    D(x)                                                              # one more, pending on the host
+    sd["mlps.1.num_batches_tracked"] = torch.tensor(7)
+    D.load_state_dict(sd)
+    assert int(D.state_dict()["mlps.1.num_batches_tracked"]) == 7    # not 8: the pre-load call is not added afterwards
+    D(x)
+    assert int(D.state_dict()["mlps.1.num_batches_tracked"]) == 8
+
+
+def test_noisy_labels_semantics(spgan_cpu):
+    """loss_utils.py:698-725: smooth labels in [0.9,1), int(0.05*B) positions flipped to 1-y; drawn with torch's generator."""
+    from spgan import losses
+    torch.manual_seed(5)
+    y = losses._smooth_labels(64, torch.device("cpu"))
+    assert y.shape == (64,) and float(y.min()) >= 0.9 and float(y.max()) < 1.0
+    y2 = losses._noisy_labels(y.clone())
+    changed = (y2 != y).nonzero().flatten()
+    assert 1 <= changed.numel() <= 3                                   # int(0.05*64) = 3 draws with replacement
+    assert torch.allclose(y2[changed], 1 - y[changed])
+    assert torch.equal(losses._noisy_labels(torch.ones(8)), torch.ones(8))   # int(0.05*8) = 0: nothing flips
