@@ -185,20 +185,38 @@ class MfmaAccounting:
                 "mfma_time_share_of_step": round(t_ms / step_ms, 4),
                 "by_kind": {k: {"launches_per_step": v[0] // steps, "tflops_useful": round(v[1] / (v[2] * 1e-3) / 1e12, 2), "ms_per_step": round(v[2] / steps, 3)}
                             for k, v in by.items()},
-                "note": "HIP events around every matrix-core launch over %d eagerly issued steps (GPU kept behind a spin kernel so the events do not see host "
+                "note": "HIP events around every matrix-core launch over %d eagerly issued steps (GPU kept busy ahead of the host so the events do not see host "
                         "issue gaps); issued = 2*M*N*K with M, N, K padded to the kernel's tiles; util = FLOPs / (summed duration of these kernels x %.1f TFLOP/s); "
                         "gemm_tn durations include the split-K reduction the same entry point launches when it is not deferred" % (steps, self.peak)}
 
 
-def _spin_ahead(ms):
-    """Keep the GPU busy for ~ms so that the host gets ahead with issuing (HIP events then bracket kernels, not issue gaps)."""
-    if not hasattr(_spin_ahead, "cycles_per_ms"):
+class _KeepBusy:
+    """Puts ~ms of heavy work (launches of the dominant GEMM shape on scratch operands) in front of an eagerly issued step, so that
+    the host gets ahead with issuing and the HIP events bracket kernels, not issue gaps -- and the chip is at the clocks of a
+    continuously busy GPU (a graph-replayed step), not at the boost clocks it reaches between sparse eager launches or the idle
+    clocks a sleeping spin kernel would leave it at."""
+
+    def __init__(self, dev, ms=25.0):
+        import spgan
+        self.ops = spgan.ops
+        self.A = torch.randn(PER_GPU_BATCH * N_POINTS, DOMINANT["K"], device=dev)
+        self.W = torch.randn(DOMINANT["N"], DOMINANT["K"], device=dev) * 0.05
+        self.out = torch.empty(PER_GPU_BATCH * N_POINTS, DOMINANT["N"], device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self._run(3)
         torch.cuda.synchronize()
-        e0.record(); torch.cuda._sleep(20_000_000); e1.record()
+        e0.record(); self._run(10); e1.record()
         torch.cuda.synchronize()
-        _spin_ahead.cycles_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
-    torch.cuda._sleep(int(ms * _spin_ahead.cycles_per_ms))
+        self.n = max(int(ms / (e0.elapsed_time(e1) / 10.0)), 1)
+
+    def _run(self, n):
+        timer, self.ops.launch_timer = self.ops.launch_timer, None
+        for _ in range(n):
+            self.ops.gemm_nt(self.A, self.W, out=self.out)
+        self.ops.launch_timer = timer
+
+    def __call__(self):
+        self._run(self.n)
 
 
 def cpu_baseline(budget_s=45.0):
@@ -367,9 +385,10 @@ def main():
         # a replayed graph offers no per-launch hook: the matrix-core launches are bracketed with HIP events over a few eager steps
         # of the same TrainStep right after the timed region (same process, same tensors; not part of `value`).  Data-parallel:
         # every rank runs them (the all-reduces inside must match up); only rank 0 records.
+        busy = _KeepBusy(dev)
         spgan.ops.launch_timer = acct
         for i in range(ACCT_STEPS):
-            _spin_ahead(25.0)
+            busy()
             tr._eager_step(x, real, zs[(2 * i) % 4], zs[(2 * i + 1) % 4], alpha=alpha)
         torch.cuda.synchronize()
         spgan.ops.launch_timer = None

@@ -411,6 +411,17 @@ int spgan_chamfer_pairs(const float* A, const float* Bc, int S, int R, int N, in
  * the nearest grid cell of every point (spgan_nn_distance against the grid); counters[g] += points in cell g over all clouds,
  * bernoulli[g] += clouds with at least one point in g.  Accumulates: the caller zeroes both int32 [G] arrays.  G <= 524288. */
 int spgan_occupancy_counts(const int32_t* cell, int S, int N, int G, int32_t* counters, int32_t* bernoulli, spgan_stream_t s);
+/* Minimum matching distance / coverage over a distance matrix dist [S,R] between S sample clouds and R reference clouds
+ * (metrics/evaluation_metrics.py:161-173, lgan_mmd_cov): out3 = [mean over references of their closest sample's distance,
+ * fraction of references that are the closest reference of some sample (first one on ties), mean over samples of their closest
+ * reference's distance].  ws: (S + 2R) floats of scratch.  Fixed-order sums. */
+int spgan_mmd_cov(const float* dist, int S, int R, float* out3, float* ws, spgan_stream_t s);
+/* Leave-one-out k-nearest-neighbour two-sample test (metrics/evaluation_metrics.py:129-158, knn): Mxx [n0,n0], Mxy [n0,n1],
+ * Myy [n1,n1] are the blocks of the joint distance matrix (never concatenated); every cloud is classified by the majority label of
+ * its k nearest OTHER clouds (votes >= k/2 -> first set; lower index on distance ties); take_sqrt compares sqrt(|d|).
+ * out9 = [tp, fp, fn, tn, precision, recall, acc_t, acc_f, acc]; pred: int32 [n0+n1] scratch (the per-cloud predictions). */
+int spgan_two_sample_knn(const float* Mxx, const float* Mxy, const float* Myy, int n0, int n1, int k, int take_sqrt, float* out9,
+                         int32_t* pred, spgan_stream_t s);
 
 /* Approximate earth mover's distance by a synchronous auction: the algorithm of the reference's emd module
  * (metrics/emd/emd_cuda.cu:93-236 behind metrics/CD_EMD/emd_/emd_module.py:33-75: `emd.forward(xyz1, xyz2, dist, assignment, price,

@@ -175,6 +175,143 @@ __global__ __launch_bounds__(256) void occupancy_counts_kernel(const int32_t* __
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Set-level statistics over a distance matrix between two sets of clouds (metrics/evaluation_metrics.py:129-173): the
+// minimum-matching-distance / coverage numbers and the leave-one-out k-NN two-sample test.  Small matrices (a few hundred to
+// a few thousand clouds per side); what matters is that no value leaves the device and every sum has a fixed order.
+
+// one workgroup per sample row: its smallest distance, and the reference cloud attaining it (first one on ties) is marked covered
+__global__ __launch_bounds__(256) void mmd_rows_kernel(const float* __restrict__ dist, int R, float* __restrict__ rowmin, int32_t* __restrict__ hit) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const float* row = dist + (size_t)blockIdx.x * R;
+  float best = INFINITY;
+  int bi = 0x7fffffff;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float v = row[r];
+    if (v < best) { best = v; bi = r; }  // ascending r per thread: first occurrence
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const float v = sv[threadIdx.x + o];
+      const int i = si[threadIdx.x + o];
+      if (v < sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    rowmin[blockIdx.x] = sv[0];
+    if (si[0] < R) hit[si[0]] = 1;  // every writer stores the same value
+  }
+}
+
+// one thread per reference column (coalesced over the columns)
+__global__ __launch_bounds__(256) void mmd_cols_kernel(const float* __restrict__ dist, int S, int R, float* __restrict__ colmin) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  float best = INFINITY;
+  for (int s = 0; s < S; ++s) best = fminf(best, dist[(size_t)s * R + r]);
+  colmin[r] = best;
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {  // fixed-order tree over 256 threads
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double t = red[0];
+  __syncthreads();
+  return t;
+}
+
+// out3 = [mean_r colmin, |{covered r}| / R, mean_s rowmin]
+__global__ __launch_bounds__(256) void mmd_final_kernel(const float* __restrict__ rowmin, const float* __restrict__ colmin, const int32_t* __restrict__ hit,
+                                                        int S, int R, float* __restrict__ out3) {
+  __shared__ double red[256];
+  double a = 0., b = 0., c = 0.;
+  for (int r = threadIdx.x; r < R; r += 256) { a += colmin[r]; c += hit[r] ? 1. : 0.; }
+  for (int s = threadIdx.x; s < S; s += 256) b += rowmin[s];
+  a = block_sum_d(a, red);
+  b = block_sum_d(b, red);
+  c = block_sum_d(c, red);
+  if (threadIdx.x == 0) {
+    out3[0] = (float)(a / R);
+    out3[1] = (float)(c / R);
+    out3[2] = (float)(b / S);
+  }
+}
+
+// Joint matrix of the two-sample test, never materialised: M = [[Mxx, Mxy], [Mxy^T, Myy]] over n = n0 + n1 clouds.
+__device__ __forceinline__ float joint_at(const float* Mxx, const float* Mxy, const float* Myy, int n0, int n1, int i, int j, int take_sqrt) {
+  float v;
+  if (i < n0) v = j < n0 ? Mxx[(size_t)i * n0 + j] : Mxy[(size_t)i * n1 + (j - n0)];
+  else v = j < n0 ? Mxy[(size_t)j * n1 + (i - n0)] : Myy[(size_t)(i - n0) * n1 + (j - n0)];
+  return take_sqrt ? sqrtf(fabsf(v)) : v;
+}
+
+// one workgroup per cloud j: its k nearest OTHER clouds (column j of M, smallest first, lower index on ties), the vote of their
+// labels (label 1 = first set), pred[j] = votes >= k/2
+__global__ __launch_bounds__(256) void two_sample_vote_kernel(const float* __restrict__ Mxx, const float* __restrict__ Mxy, const float* __restrict__ Myy,
+                                                              int n0, int n1, int k, int take_sqrt, int32_t* __restrict__ pred) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const int n = n0 + n1, j = blockIdx.x;
+  float pv = -INFINITY;  // the pair selected in the previous round: candidates must be lexicographically greater
+  int pi = -1, votes = 0;
+  for (int round = 0; round < k; ++round) {
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      if (i == j) continue;
+      const float v = joint_at(Mxx, Mxy, Myy, n0, n1, i, j, take_sqrt);
+      const bool after = v > pv || (v == pv && i > pi);
+      if (after && (v < best || (v == best && i < bi))) { best = v; bi = i; }
+    }
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) {
+        const float v = sv[threadIdx.x + o];
+        const int i = si[threadIdx.x + o];
+        if (v < sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
+      }
+      __syncthreads();
+    }
+    pv = sv[0];
+    pi = si[0];
+    __syncthreads();
+    if (pi < n0) ++votes;
+  }
+  if (threadIdx.x == 0) pred[j] = (2 * votes >= k) ? 1 : 0;
+}
+
+// out9 = [tp, fp, fn, tn, precision, recall, acc_t, acc_f, acc] (evaluation_metrics.py:144-158)
+__global__ __launch_bounds__(256) void two_sample_final_kernel(const int32_t* __restrict__ pred, int n0, int n1, float* __restrict__ out9) {
+  __shared__ double red[256];
+  double tp = 0., fp = 0.;
+  for (int j = threadIdx.x; j < n0 + n1; j += 256) {
+    if (pred[j]) { if (j < n0) tp += 1.; else fp += 1.; }
+  }
+  tp = block_sum_d(tp, red);
+  fp = block_sum_d(fp, red);
+  if (threadIdx.x == 0) {
+    const float ftp = (float)tp, ffp = (float)fp, ffn = (float)(n0 - tp), ftn = (float)(n1 - fp);
+    out9[0] = ftp; out9[1] = ffp; out9[2] = ffn; out9[3] = ftn;
+    out9[4] = ftp / (ftp + ffp + 1e-10f);
+    out9[5] = ftp / (ftp + ffn + 1e-10f);
+    out9[6] = ftp / (ftp + ffn + 1e-10f);
+    out9[7] = ftn / (ftn + ffp + 1e-10f);
+    out9[8] = (ftp + ftn) / (float)(n0 + n1);
+  }
+}
+
 }  // namespace
 
 extern "C" int spgan_nn_distance(const float* xyz1, const float* xyz2, int B, int N, int M, float* dist, int32_t* idx, spgan_stream_t s_) {
@@ -206,5 +343,27 @@ extern "C" int spgan_occupancy_counts(const int32_t* cell, int S, int N, int G, 
   SPGAN_CHECK_ARG(cell && counters && bernoulli && S > 0 && N > 0 && G > 0 && G <= 64 * 1024 * 8);
   const size_t lds = (size_t)((G + 31) / 32) * sizeof(unsigned);
   hipLaunchKernelGGL(occupancy_counts_kernel, dim3(S), dim3(256), lds, (hipStream_t)s_, cell, N, G, counters, bernoulli);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_mmd_cov(const float* dist, int S, int R, float* out3, float* ws, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dist && out3 && ws && S > 0 && R > 0);
+  hipStream_t s = (hipStream_t)s_;
+  float* rowmin = ws;                // [S]
+  float* colmin = ws + S;            // [R]
+  int32_t* hit = reinterpret_cast<int32_t*>(ws + S + R);  // [R]
+  (void)hipMemsetAsync(hit, 0, (size_t)R * sizeof(int32_t), s);
+  hipLaunchKernelGGL(mmd_rows_kernel, dim3(S), dim3(256), 0, s, dist, R, rowmin, hit);
+  hipLaunchKernelGGL(mmd_cols_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, dist, S, R, colmin);
+  hipLaunchKernelGGL(mmd_final_kernel, dim3(1), dim3(256), 0, s, rowmin, colmin, hit, S, R, out3);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_two_sample_knn(const float* Mxx, const float* Mxy, const float* Myy, int n0, int n1, int k, int take_sqrt, float* out9,
+                                    int32_t* pred, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(Mxx && Mxy && Myy && out9 && pred && n0 > 0 && n1 > 0 && k > 0 && k < n0 + n1);
+  hipStream_t s = (hipStream_t)s_;
+  hipLaunchKernelGGL(two_sample_vote_kernel, dim3(n0 + n1), dim3(256), 0, s, Mxx, Mxy, Myy, n0, n1, k, take_sqrt, pred);
+  hipLaunchKernelGGL(two_sample_final_kernel, dim3(1), dim3(256), 0, s, pred, n0, n1, out9);
   return spgan_launch_status();
 }

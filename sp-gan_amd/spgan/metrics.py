@@ -165,32 +165,40 @@ def EMD_CD(sample_pcs: Tensor, ref_pcs: Tensor, batch_size: int = 512, reduced: 
     return {"MMD-CD": cd.mean() if reduced else cd, "MMD-EMD": emd.mean() if reduced else emd}
 
 
+def _matrix(t: Tensor, name: str) -> Tensor:
+    _f32(t, name, 2)
+    return t.contiguous()
+
+
 def lgan_mmd_cov(all_dist: Tensor) -> Dict[str, Tensor]:
-    """evaluation_metrics.py:161-173; all_dist [N_sample, N_ref]."""
-    n_ref = all_dist.shape[1]
-    min_val_fromsmp, min_idx = torch.min(all_dist, dim=1)
-    min_val, _ = torch.min(all_dist, dim=0)
-    cov = torch.tensor(float(min_idx.unique().numel()) / float(n_ref)).to(all_dist)
-    return {"lgan_mmd": min_val.mean(), "lgan_cov": cov, "lgan_mmd_smp": min_val_fromsmp.mean()}
+    """Minimum matching distance and coverage of a [samples, references] distance matrix -- the quantities (and dictionary keys)
+    of evaluation_metrics.py:161-173.  One HIP launch sequence (spgan_mmd_cov: a row pass, a column pass, a fixed-order
+    finish); results stay on the device as 0-d tensors."""
+    d = _matrix(all_dist, "all_dist")
+    S, R = d.shape
+    out = torch.empty((3,), dtype=torch.float32, device=d.device)
+    ws = torch.empty((S + 2 * R,), dtype=torch.float32, device=d.device)
+    check(_lib.load().spgan_mmd_cov(_p(d), S, R, _p(out), _p(ws), _s()), "mmd_cov", S=S, R=R)
+    return {"lgan_mmd": out[0], "lgan_cov": out[1], "lgan_mmd_smp": out[2]}
+
+
+_TWO_SAMPLE_KEYS = ("tp", "fp", "fn", "tn", "precision", "recall", "acc_t", "acc_f", "acc")
 
 
 def knn(Mxx: Tensor, Mxy: Tensor, Myy: Tensor, k: int, sqrt: bool = False) -> Dict[str, Tensor]:
-    """Leave-one-out k-NN two-sample test, evaluation_metrics.py:129-158."""
-    n0, n1 = Mxx.size(0), Myy.size(0)
-    label = torch.cat((torch.ones(n0), torch.zeros(n1))).to(Mxx)
-    M = torch.cat((torch.cat((Mxx, Mxy), 1), torch.cat((Mxy.transpose(0, 1), Myy), 1)), 0)
-    if sqrt:
-        M = M.abs().sqrt()
-    _, idx = (M + torch.diag(float("inf") * torch.ones(n0 + n1).to(Mxx))).topk(k, 0, False)
-    count = torch.zeros(n0 + n1).to(Mxx)
-    for i in range(k):
-        count = count + label.index_select(0, idx[i])
-    pred = torch.ge(count, (float(k) / 2) * torch.ones(n0 + n1).to(Mxx)).float()
-    s = {"tp": (pred * label).sum(), "fp": (pred * (1 - label)).sum(), "fn": ((1 - pred) * label).sum(), "tn": ((1 - pred) * (1 - label)).sum()}
-    s.update({"precision": s["tp"] / (s["tp"] + s["fp"] + 1e-10), "recall": s["tp"] / (s["tp"] + s["fn"] + 1e-10),
-              "acc_t": s["tp"] / (s["tp"] + s["fn"] + 1e-10), "acc_f": s["tn"] / (s["tn"] + s["fp"] + 1e-10),
-              "acc": torch.eq(label, pred).float().mean()})
-    return s
+    """1-NNA-style two-sample test (evaluation_metrics.py:129-158 semantics and result keys): each of the n0 + n1 clouds is
+    labelled by the vote of its k nearest other clouds in the joint distance matrix [[Mxx, Mxy], [Mxy^T, Myy]]; the confusion
+    counts of those leave-one-out predictions and the ratios derived from them are returned.  The joint matrix is read block-wise
+    by spgan_two_sample_knn, not assembled."""
+    xx, xy, yy = _matrix(Mxx, "Mxx"), _matrix(Mxy, "Mxy"), _matrix(Myy, "Myy")
+    n0, n1 = xx.shape[0], yy.shape[0]
+    if xx.shape != (n0, n0) or yy.shape != (n1, n1) or xy.shape != (n0, n1):
+        raise ValueError("expected Mxx [n0,n0], Mxy [n0,n1], Myy [n1,n1]; got %s %s %s" % (tuple(xx.shape), tuple(xy.shape), tuple(yy.shape)))
+    out = torch.empty((9,), dtype=torch.float32, device=xx.device)
+    pred = torch.empty((n0 + n1,), dtype=torch.int32, device=xx.device)
+    check(_lib.load().spgan_two_sample_knn(_p(xx), _p(xy), _p(yy), n0, n1, int(k), 1 if sqrt else 0, _p(out), _p(pred), _s()),
+          "two_sample_knn", n0=n0, n1=n1, k=k)
+    return {name: out[i] for i, name in enumerate(_TWO_SAMPLE_KEYS)}
 
 
 def unit_cube_grid_point_cloud(resolution: int, clip_sphere: bool = False, device="cuda"):

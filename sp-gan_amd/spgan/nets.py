@@ -219,8 +219,8 @@ def d_advance_running_stats(P: Dict[str, Tensor], bufs: Dict[str, Tensor], x_cm:
     # Gram/M - mu mu^T difference of two large numbers is formed (a3 is a LeakyReLU output: its means are not small); what
     # rounding leaves of a negative variance is clamped by bn_prepare.
     cov = ops.rowscale_outer(ops.gemm_tn(a3, a3, pro=(torch.ones_like(mu_a), -mu_a, 1.0)), inv_m)
-    mean4 = ops.gemm_nt(mu_a.view(1, -1), W, b4)[0]
-    var4 = ops.rowdot(W, ops.gemm_nt(W, cov))
+    mean4 = ops.gemm_nt(mu_a.view(1, -1), W, b4, exact=True)[0]
+    var4 = ops.rowdot(W, ops.gemm_nt(W, cov, exact=True))
     _bn_train(mean4.contiguous(), var4, P, bufs, bn, M, True, True)
 
 
@@ -277,12 +277,12 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             a3 = ops.affine_act(ys[2], sc, sh, NEG) if need_dparams else None
             if need_dparams:
                 gram = ops.gemm_tn(a3, a3)                                        # [256,256]
-                dW = ops.rowscale_outer(ops.gemm_nt(W, gram), alpha, b4, beta, ops.colsum(a3)[0])
+                dW = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), alpha, b4, beta, ops.colsum(a3)[0])   # gram: a sum over B*N points
                 ops.sparse_rows_tn(dy.sp_val, dy.sp_arg, N, a3, dW)
                 grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
                 grads[conv + ".bias"] = ZERO_GRAD
             G4 = ops.gemm_tn(W, ops.rowscale_outer(W, alpha))                     # W^T diag(alpha) W
-            cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(alpha, beta, 1.0))[0]  # (alpha*b4 + beta).W
+            cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(alpha, beta, 1.0), exact=True)[0]  # (alpha*b4 + beta).W
             E = ops.sparse_rows_nt(dy.sp_val, dy.sp_arg, N, W)                    # S.W, dense rows
             if a3 is not None:
                 g, s0, s1 = ops.gemm_nt_bnbwd(a3, G4, ys[2], sc, sh, mu, inv, NEG, bias=cvec, rowadd=E)
@@ -339,11 +339,11 @@ def _d_double_top_phase_a(P, ctx, saved, q3: Tensor, grads) -> dict:
     a3 = ops.affine_act(ys[2], bns[2][0], bns[2][1], NEG)
     Qqa = ops.gemm_tn(q3, a3)                                                    # q3^T a3 [256,256]
     cq = ops.colsum(q3)[0]
-    T = ops.gemm_nt(W, Qqa)                                                      # W.(a3^T q3) [1024,256]
+    T = ops.gemm_nt(W, Qqa, exact=True)                                          # W.(a3^T q3) [1024,256]; Qqa: a sum over B*N points
     dW = ops.rowscale_outer(T, dz.alpha, b4, dz.beta, cq)
     ops.sparse_rows_tn(dz.sp_val, dz.sp_arg, N, q3, dW)
     grads[conv + ".weight"] = dW
-    U0 = ops.gemm_nt(cq.view(1, -1), W)[0]
+    U0 = ops.gemm_nt(cq.view(1, -1), W, exact=True)[0]
     quad = ops.rowdot(W, T)                                                      # w_c^T (q3^T a3) w_c
     uarg = ops.gather_rowdot(q3, argmax, W)                                      # u at the arg-max rows [B,1024]
     yarg = ctx["yarg"] if ctx.get("yarg") is not None else ops.gather_rows(ys[3], argmax)
@@ -365,13 +365,13 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
     grads[bn + ".bias"] = ZERO_GRAD
     Wc1, Wc2 = ops.rowscale_outer(W, c1), ops.rowscale_outer(W, c2)
     gram = ops.gemm_tn(a3, a3)
-    gw = ops.rowscale_outer(ops.gemm_nt(W, gram), c2, b4, c3, ops.colsum(a3)[0])
-    gw = ops.axpby(1.0, ops.gemm_nt(Wc1, _t(top["Qqa"])), 1.0, gw)             # + diag(c1).W.(q3^T a3)
+    gw = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), c2, b4, c3, ops.colsum(a3)[0])
+    gw = ops.axpby(1.0, ops.gemm_nt(Wc1, _t(top["Qqa"]), exact=True), 1.0, gw)             # + diag(c1).W.(q3^T a3)
     ops.sparse_rows_tn(spB, argmax, N, a3, gw)
     grads[conv + ".weight"] = ops.axpby(1.0, gw, 1.0, grads[conv + ".weight"]).view_as(P[conv + ".weight"])
     grads[conv + ".bias"] = ZERO_GRAD
     G1, G2 = ops.gemm_tn(W, Wc1), ops.gemm_tn(W, Wc2)
-    cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(c2, c3, 1.0))[0]
+    cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(c2, c3, 1.0), exact=True)[0]
     part = ops.gemm_nt(q3, G1, rowbias=ops.sparse_rows_nt(spB, argmax, N, W), rows_per_group=1)
     psc, psh, pinv, pmu = bns[2]
     return ops.gemm_nt_bnbwd(a3, G2, ys[2], psc, psh, pmu, pinv, NEG, bias=cvec, rowadd=part)

@@ -194,17 +194,19 @@ def _finalize(partials: Tensor, groups: int, tpg: int, Cn: int, G: int, mode: in
 
 def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, edge=None, rowbias: Optional[Tensor] = None,
             rows_per_group: int = 0, act: int = ACT_NONE, slope: float = 0.0, stats: bool = False, M: Optional[int] = None, bn=None,
-            out: Optional[Tensor] = None):
+            out: Optional[Tensor] = None, exact: bool = False):
     """Y[M,N] = act( pro(A) @ W^T + bias + rowbias[m // rows_per_group] ).
     out  = destination [M,N] (unit column stride; may be a column slice of a wider buffer) instead of a fresh tensor.
     bn = (gamma, beta, running_mean | None, running_var | None): train-mode BatchNorm of Y fused behind the GEMM: returns
          (Y, (scale, shift, invstd, mean)) and updates the running statistics (column statistics in the epilogue + one finalize launch).
     pro  = (scale[K], shift[K], slope): operand a = lrelu(A*scale+shift)            (A_AFFINE_LRELU)
     edge = (idx[M,k], ebias[K]) with pro: rows are edges, a = lrelu((A[j]-A[i]+ebias)*scale+shift)  (A_EDGE)
-    stats=True additionally returns (mean[N], biased var[N]) of the pre-activation output over all M rows."""
+    stats=True additionally returns (mean[N], biased var[N]) of the pre-activation output over all M rows.
+    exact=True keeps fp32 operands even in fp16-operand mode: for products whose operands are sums over all points (Gram matrices,
+    column sums: they grow with B*N and leave fp16's range at full size) rather than per-point activations."""
     _rowmajor2d(A, "A"); _rowmajor2d(W, "W")
     N, K = W.shape
-    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]
+    a = GemmNTArgs(); a.mfma_f16 = 0 if exact else _MFMA_F16[0]
     if edge is not None:
         idx, ebias = edge
         _i32(idx, "idx")

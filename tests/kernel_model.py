@@ -97,7 +97,7 @@ def _operand(A, pro, edge, K):
 
 
 def gemm_nt(A, W, bias=None, *, pro=None, edge=None, rowbias=None, rows_per_group=0, act=ACT_NONE, slope=0.0, stats=False, M=None, bn=None,
-            out=None):
+            out=None, exact=False):
     if out is not None:
         out.copy_(gemm_nt(A, W, bias, pro=pro, edge=edge, rowbias=rowbias, rows_per_group=rows_per_group, act=act, slope=slope, M=M))
         return out
