@@ -81,6 +81,29 @@ enum { SPGAN_A_PLAIN = 0, SPGAN_A_AFFINE_LRELU = 1, SPGAN_A_EDGE = 2 };
 enum { SPGAN_EPI_LINEAR = 0, SPGAN_EPI_MASK_OUT = 1, SPGAN_EPI_BNBWD = 2, SPGAN_EPI_EDGE_BNBWD = 3 };
 enum { SPGAN_ACT_NONE = 0, SPGAN_ACT_LRELU = 1, SPGAN_ACT_TANH = 2 };
 
+/* In-launch finish of per-tile column records by the last-arriving workgroup (csrc/fanin.hpp): instead of leaving the merge
+ * over the row tiles to a follow-up launch (spgan_colstats_finalize*), the producer's workgroups count their arrivals and the last
+ * one merges -- in tile order, so the result does not depend on the arrival order -- and runs the tail:
+ *   mode 0: records are (sum, centred M2) -> out0 = mean, out1 = biased variance (either may be NULL) and, when scale != NULL,
+ *           the train-mode BatchNorm bookkeeping of spgan_bn_prepare (scale, shift, invstd, mean_out; running statistics
+ *           updated with momentum when rmean != NULL; count_rep multiplies the row count of the unbiased-variance factor);
+ *   mode 1: records are plain sums -> out0 = sum of x, out1 = sum of y.
+ * counters: int32 [col_blocks * (spgan_fanin_groups(tiles) + 1)], zero before the first use; the kernels leave them zero.
+ * group_part: float scratch [spgan_fanin_groups(tiles), C, 2] (unused when there is a single group).  enabled = 0: off. */
+typedef struct spgan_fanin {
+  int enabled;
+  int32_t* counters;
+  float* group_part;
+  int mode;
+  float* out0; float* out1;
+  const float* gamma; const float* beta; float* rmean; float* rvar;
+  float* scale; float* shift; float* invstd; float* mean_out;
+  float eps, momentum;
+  int count_rep;
+} spgan_fanin;
+/* number of first-level groups the row tiles of a launch are cut into (1 for <= 48 tiles) */
+int spgan_fanin_groups(int tiles);
+
 typedef struct spgan_gemm_nt_args {
   /* Y[M,N] = epilogue( prologue(A)[M,K] . W[N,K]^T ) */
   const float* A; int lda;
@@ -123,7 +146,12 @@ typedef struct spgan_gemm_nt_args {
    * product z uses A + z*batch_stride_a, W + z*batch_stride_w, Y + z*batch_stride_y (strides in floats; bias is shared).
    * The per-shape [N,N] contractions of the --attn variant (Generation/modules.py:554-556).  Default 0 / 1: a single product. */
   int batch; long batch_stride_a, batch_stride_w, batch_stride_y;
+  /* fin.enabled (needs `stats`): the column records are merged in this launch -- column blocks = the kernel's N-tiles
+   * (spgan_gemm_nt_col_blocks), row tiles of 128 rows.  Not with pooling-only launches (stats == NULL). */
+  spgan_fanin fin;
 } spgan_gemm_nt_args;
+/* number of column blocks (N-tiles) spgan_gemm_nt uses for this problem: sizes the fan-in counters */
+int spgan_gemm_nt_col_blocks(const spgan_gemm_nt_args* a);
 
 int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s);
 /* pooled[b,c] = max_n lrelu(scale[c]*y[b*rows+n, c] + shift[c], slope) from the tile partials above (rows % 128 == 0, so
@@ -188,6 +216,13 @@ int spgan_colstats_finalize(const float* partials, int groups, int tiles_per_gro
 int spgan_colstats_finalize_bn(const float* partials, int tiles, int C, int G, int tile_rows, const float* gamma, const float* beta,
                                float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                                float* invstd, float* mean_out, spgan_stream_t s);
+/* The same for TWO BatchNorm layers whose channels lie side by side in one record set (columns [0,split) -> layer A, [split,C) ->
+ * layer B, each with its own gamma/beta/running buffers): the two per-edge BatchNorms of an EdgeBlock (Generator.py:57-58,66-67) from
+ * spgan_edge_stats' records in one launch.  out4 [4,C] = scale | shift | invstd | mean.  count_rep: the rows stand for count_rep
+ * identical copies (only the unbiased-variance count of the running statistics changes). */
+int spgan_colstats_finalize_bn2(const float* partials, int tiles, int C, int G, int tile_rows, int split, const float* gammaA,
+                                const float* betaA, float* rmeanA, float* rvarA, const float* gammaB, const float* betaB, float* rmeanB,
+                                float* rvarB, float eps, float momentum, int count_rep, float* out4, spgan_stream_t s);
 /* mean / biased variance over each group of lrelu(X, slope) (slope = 1: plain).  InstanceNorm1d statistics of
  * AdaptivePointNorm (Generator.py:29,42) with G = N; BatchNorm statistics with G = M.  ws >= spgan_colreduce_ws_bytes. */
 int spgan_colstats(const float* X, int ldx, int M, int C, int G, float slope, float* out_mean, float* out_var,

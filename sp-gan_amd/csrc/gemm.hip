@@ -23,6 +23,7 @@
 // for the following train-mode BatchNorm, and the LeakyReLU/BatchNorm backward masks with their
 // column sums.
 #include "common.hpp"
+#include "fanin.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -176,12 +177,17 @@ __device__ __forceinline__ void col_reduce2(float (&pa)[Geo<CFG>::TJ], float (&p
 // 8-byte fragment reads of a half-wave are conflict-free), a fragment read (4 halfs) feeds ONE MFMA of k = 8.
 template <int AMODE, int EPI, int CFG, int DB, int FAST, int F16 = 0>
 __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_args p_) {  // <= 168 VGPRs: 3 waves/SIMD
-  spgan_gemm_nt_args p = p_;
+  // The argument block stays in the kernarg segment (scalar loads): it is never copied or modified -- a modified copy of a
+  // struct this size lands in scratch.  Only the three operand pointers of a batched product are adjusted, as locals.
+  const spgan_gemm_nt_args& p = p_;
+  const float* pA = p_.A;
+  const float* pW = p_.W;
+  float* pY = p_.Y;
   if constexpr (AMODE == SPGAN_A_PLAIN && EPI == SPGAN_EPI_LINEAR) {
     if (blockIdx.y != 0) {  // batched product: blockIdx.y selects the (A, W, Y) triple (scalar pointer arithmetic)
-      p.A += (size_t)blockIdx.y * (size_t)p.batch_stride_a;
-      p.W += (size_t)blockIdx.y * (size_t)p.batch_stride_w;
-      p.Y += (size_t)blockIdx.y * (size_t)p.batch_stride_y;
+      pA += (size_t)blockIdx.y * (size_t)p.batch_stride_a;
+      pW += (size_t)blockIdx.y * (size_t)p.batch_stride_w;
+      pY += (size_t)blockIdx.y * (size_t)p.batch_stride_y;
     }
   }
   using G = Geo<CFG>;
@@ -209,8 +215,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   const int wm = wave / G::WGN, wn = wave % G::WGN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
-  const bool vecW = ((p.ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.W) & 15) == 0);
+  const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(pA) & 15) == 0);
+  const bool vecW = ((p.ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(pW) & 15) == 0);
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -266,8 +272,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       const int kc = kok ? k : 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ra[i] = ldrow(p.A, offA[i], kc, true);
-        if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(p.A, offC[i], kc, true);
+        ra[i] = ldrow(pA, offA[i], kc, true);
+        if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(pA, offC[i], kc, true);
       }
       if (AMODE != SPGAN_A_PLAIN) {
         psc = ldpar(p.p_scale, kc);
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
         spv = *reinterpret_cast<const float4*>(p.sp_val + off);
       }
 #pragma unroll
-      for (int i = 0; i < BSLOT; ++i) rb[i] = ldrow(p.W, offW[i], kc, true);
+      for (int i = 0; i < BSLOT; ++i) rb[i] = ldrow(pW, offW[i], kc, true);
       return;
     }
 #pragma unroll
@@ -288,8 +294,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (AMODE == SPGAN_A_EDGE) ra2[i] = ra[i];
       if (kok) {
-        ra[i] = ldrow(p.A, offA[i], k, vecA);
-        if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(p.A, offC[i], k, vecA);
+        ra[i] = ldrow(pA, offA[i], k, vecA);
+        if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(pA, offC[i], k, vecA);
       }
     }
     if (AMODE != SPGAN_A_PLAIN && kok) {
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       if (AMODE == SPGAN_A_EDGE) peb = ldpar(p.e_bias, k);
     }
 #pragma unroll
-    for (int i = 0; i < BSLOT; ++i) rb[i] = kok ? ldrow(p.W, offW[i], k, vecW) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < BSLOT; ++i) rb[i] = kok ? ldrow(pW, offW[i], k, vecW) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto sstore = [&](int buf, int k0) {
     float* a = As + buf * BM * LDX;
@@ -484,8 +490,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           }
         }
       }
-      if (p.Y) {
-        float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
+      if (pY) {
+        float* yb = pY + (size_t)rbase * p.ldy + cbase;
         const unsigned ldy = (unsigned)p.ldy;
         auto store_all = [&](auto actf) {
 #pragma unroll
@@ -520,11 +526,11 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           if (p.rowbias && cok && row < p.M) v += p.rowbias[(size_t)fast_div(row, p.rows_per_group) * p.ld_rowbias + col];
           acc[i][j][r] = v;  // keep the pre-activation value for the statistics pass
           if (row < p.M) csum[j] += v;
-          if (cok && row < p.M && p.Y) {
+          if (cok && row < p.M && pY) {
             float o = v;
             if (p.act == SPGAN_ACT_LRELU) o = lrelu_f(v, p.act_slope);
             else if (p.act == SPGAN_ACT_TANH) o = tanhf(v);
-            p.Y[(size_t)row * p.ldy + col] = o;
+            pY[(size_t)row * p.ldy + col] = o;
           }
         }
     }
@@ -593,8 +599,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           }
           if (p.stats) {
             float* o = p.stats + ((size_t)t.tm * p.N + col) * 2;
-            o[0] = S;
-            o[1] = M2;
+            if (p.fin.enabled) fanin::st_record(o, S, M2);
+            else { o[0] = S; o[1] = M2; }
           }
           if (do_pool) {
             float vx = xvx[c], vn = xvn[c];
@@ -686,8 +692,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           const int col = cbase + j * 32;
           if (col < p.N) {
             float* o = p.stats + ((size_t)t.tm * p.N + col) * 2;
-            o[0] = csum[j];
-            o[1] = m2[j];
+            if (p.fin.enabled) fanin::st_record(o, csum[j], m2[j]);
+            else { o[0] = csum[j]; o[1] = m2[j]; }
           }
         }
       }
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   } else if (EPI == SPGAN_EPI_MASK_OUT) {
     if (full) {
       const float* rb = p.ref + (size_t)rbase * p.ld_ref + cbase;
-      float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
+      float* yb = pY + (size_t)rbase * p.ldy + cbase;
       const unsigned ldr = (unsigned)p.ld_ref, ldy = (unsigned)p.ldy;
       const float sl = p.b_slope;
 #pragma unroll
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           const int row = ROW_OF(i, r);
           if (col < p.N && row < p.M) {
             const float ref = p.ref[(size_t)row * p.ld_ref + col];
-            p.Y[(size_t)row * p.ldy + col] = acc[i][j][r] * lrelu_mask(ref, p.b_slope);
+            pY[(size_t)row * p.ldy + col] = acc[i][j][r] * lrelu_mask(ref, p.b_slope);
           }
         }
     }
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
     float s0[TJ], s1[TJ];
     if (EPI == SPGAN_EPI_BNBWD && full && (!p.rowbias || p.rows_per_group == 1)) {
       const float* rb = p.ref + (size_t)rbase * p.ld_ref + cbase;
-      float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
+      float* yb = pY + (size_t)rbase * p.ldy + cbase;
       const unsigned ldr = (unsigned)p.ld_ref, ldy = (unsigned)p.ldy;
       const float sl = p.b_slope;
       // dense [M,N] addend (rows_per_group == 1: the S.W rows of the collapsed 256->1024 backward): one more straight-line load
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
     } else if (EPI == SPGAN_EPI_EDGE_BNBWD && full && !p.rowbias) {
       // rows are edges e = (i, r): ref[e,n] = (P[idx[e],n] - P[i,n]) + e_bias2[n]; the two row offsets of an accumulator row are
       // uniform over the 32 lanes of a half-wave, the gathers of a 16-row block issue together
-      float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
+      float* yb = pY + (size_t)rbase * p.ldy + cbase;
       const unsigned ldr = (unsigned)p.ld_ref, ldy = (unsigned)p.ldy;
       const float sl = p.b_slope;
 #pragma unroll
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
             if (p.rowbias) a += p.rowbias[(size_t)fast_div(row, p.rows_per_group) * p.ld_rowbias + col];
             const float g = a * lrelu_mask(z, p.b_slope);
             const float xh = (y - mu) * inv;
-            p.Y[(size_t)row * p.ldy + col] = g;
+            pY[(size_t)row * p.ldy + col] = g;
             s0[j] += g;
             s1[j] = fmaf(g, xh, s1[j]);
           }
@@ -840,8 +846,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           const int col = cbase + j * 32;
           if (col < p.N) {
             float* o = p.stats + ((size_t)t.tm * p.N + col) * 2;
-            o[0] = s0[j];
-            o[1] = s1[j];
+            if (p.fin.enabled) fanin::st_record(o, s0[j], s1[j]);
+            else { o[0] = s0[j]; o[1] = s1[j]; }
           }
         }
       }
@@ -849,6 +855,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   }
 #undef ROW_OF
 #undef ROFF
+  if constexpr (EPI != SPGAN_EPI_MASK_OUT) {
+    // column records of all row tiles are merged by the last-arriving workgroup of this column block (fanin.hpp)
+    if (p.stats && p.fin.enabled) fanin::finalize(p.fin, p.stats, t.tm, tilesM, p.N, n0, min(BN, p.N - n0), t.tn, p.M, BM, As);
+  }
   TRC(4);
 }
 
@@ -981,6 +991,33 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_
       float* o = p.stats + (size_t)(n0 + tid) * 2;  // a single 128-row tile: partials [1, N, 2]
       o[0] = s0;
       o[1] = s1;
+      if (p.fin.enabled) {  // this workgroup owns its columns entirely: finish them here (the tail of fanin::finalize)
+        const spgan_fanin& f = p.fin;
+        const int c = n0 + tid;
+        if (f.mode != 0) {
+          f.out0[c] = s0;
+          f.out1[c] = s1;
+        } else {
+          const float mean = s0 / (float)p.M, var = s1 / (float)p.M;
+          if (f.out0) f.out0[c] = mean;
+          if (f.out1) f.out1[c] = var;
+          if (f.scale) {
+            if (f.rmean) {
+              const float cnt = (float)p.M * (float)max(f.count_rep, 1);
+              const float unb = cnt > 1.f ? var * (cnt / (cnt - 1.f)) : var;
+              f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * mean;
+              f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * unb;
+            }
+            const float inv = 1.0f / sqrtf(var + f.eps);
+            const float ga = f.gamma ? f.gamma[c] : 1.f, be = f.beta ? f.beta[c] : 0.f;
+            const float sc = ga * inv;
+            f.scale[c] = sc;
+            f.shift[c] = be - mean * sc;
+            f.invstd[c] = inv;
+            f.mean_out[c] = mean;
+          }
+        }
+      }
     }
   }
 }
@@ -1531,6 +1568,21 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int spgan_fanin_groups(int tiles) { return tiles > 0 ? fanin::group_count(tiles) : 0; }
+
+// N-tile width launch_nt picks for this problem (must mirror launch_nt)
+static int nt_tile_n(const spgan_gemm_nt_args& a) {
+  const bool fast = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A) && al16(a.W);
+  if (a.mfma_f16 && fast && a.N > 32 && !a.sp_val) return (a.N > 64 && a.K >= 512) ? 128 : 64;
+  if (a.N > 64 && a.K >= 512) return 128;
+  return a.N > 32 ? 64 : 32;
+}
+
+extern "C" int spgan_gemm_nt_col_blocks(const spgan_gemm_nt_args* a) {
+  if (!a || a->N <= 0) return 0;
+  return cdiv(a->N, nt_tile_n(*a));
+}
+
 extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   SPGAN_CHECK_ARG(a && a->A && a->W && a->M > 0 && a->N > 0 && a->K > 0);
@@ -1545,6 +1597,13 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   if (a->batch > 1)
     SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->epi_mode == SPGAN_EPI_LINEAR && a->Y && !a->stats && !a->rowbias && !a->pool_val &&
                     a->batch <= 65535 && a->batch_stride_a >= 0 && a->batch_stride_w >= 0 && a->batch_stride_y > 0);
+  if (a->fin.enabled) {
+    const spgan_fanin& f = a->fin;
+    SPGAN_CHECK_ARG(a->stats && a->epi_mode != SPGAN_EPI_MASK_OUT && (f.mode == 0 || f.mode == 1));
+    if (f.mode == 1) SPGAN_CHECK_ARG(f.out0 && f.out1);
+    if (f.scale) SPGAN_CHECK_ARG(f.mode == 0 && f.shift && f.invstd && f.mean_out && (!f.rmean || f.rvar));
+    SPGAN_CHECK_ARG(f.counters && (fanin::group_count(cdiv(a->M, BM)) == 1 || f.group_part));  // the M <= 64 kernel does not use them
+  }
   switch (a->epi_mode) {
     case SPGAN_EPI_LINEAR:
       if (a->a_mode == SPGAN_A_PLAIN) return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_LINEAR>(*a, s);

@@ -9,9 +9,12 @@ constexpr int RT = 128;  // rows per partial tile (== gemm_nt's BM, so fused and
 
 // partials layout: [groups * tiles_per_group][C][2]
 // MODE 0: (sum, centred M2) of f(x);  MODE 1: (sum f(x), 0)
+// direct0 != NULL (only with tiles_per_group == 1: a group is a single tile): the tile's result IS the group's -- written as
+// out[g][c] = sum (MODE 1) or (mean, biased var) (MODE 0) right here, no finalize launch.
 template <int MODE>
 __global__ __launch_bounds__(256) void colpartials_kernel(const float* __restrict__ X, int ldx, int C, int G, int tiles_per_group,
-                                                          float slope, float* __restrict__ part) {
+                                                          float slope, float* __restrict__ part, float* __restrict__ direct0 = nullptr,
+                                                          float* __restrict__ direct1 = nullptr) {
   __shared__ float red[4][64];
   const int tile = blockIdx.x;
   const int g = tile / tiles_per_group, q = tile % tiles_per_group;
@@ -50,6 +53,11 @@ __global__ __launch_bounds__(256) void colpartials_kernel(const float* __restric
     m2tot = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63]) + (red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]);
   }
   if (sl == 0 && cok) {
+    if (direct0) {
+      direct0[(size_t)tile * C + c] = MODE == 0 ? tot / (float)cnt : tot;
+      if (MODE == 0 && direct1) direct1[(size_t)tile * C + c] = m2tot / (float)cnt;
+      return;
+    }
     float* o = part + ((size_t)tile * C + c) * 2;
     o[0] = tot;
     o[1] = m2tot;
@@ -76,6 +84,11 @@ struct BnTail {
   float* rmean; float* rvar;            // running stats (may be NULL)
   float* scale; float* shift; float* invstd; float* mean_out;   // NULL scale: no tail
   float eps, momentum;
+  // Columns >= split belong to a SECOND BatchNorm layer (its own gamma/beta/running buffers, indexed from 0): the two per-edge
+  // BatchNorms of an EdgeBlock (conv_w.1 over H channels, conv_x.1 over F) get their statistics from one record set.  split <= 0: off.
+  int split;
+  const float* gamma2; const float* beta2; float* rmean2; float* rvar2;
+  int count_rep;                        // the rows stand for count_rep identical copies (unbiased-variance count of the running statistics)
 };
 
 __global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restrict__ part, int tiles_per_group, int C, int G, int mode,
@@ -144,13 +157,20 @@ __global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restric
     if (out0) out0[(size_t)g * C + c] = a;
     if (out1) out1[(size_t)g * C + c] = var;
     if (bn.scale) {  // single group, mode 0: same arithmetic as bn_prepare_kernel
-      if (bn.rmean) {
-        const float unb = G > 1 ? var * ((float)G / (float)(G - 1)) : var;
-        bn.rmean[c] = (1.f - bn.momentum) * bn.rmean[c] + bn.momentum * a;
-        bn.rvar[c] = (1.f - bn.momentum) * bn.rvar[c] + bn.momentum * unb;
+      const bool second = bn.split > 0 && c >= bn.split;
+      const int cc = second ? c - bn.split : c;
+      float* rm = second ? bn.rmean2 : bn.rmean;
+      float* rv = second ? bn.rvar2 : bn.rvar;
+      const float* gam = second ? bn.gamma2 : bn.gamma;
+      const float* bet = second ? bn.beta2 : bn.beta;
+      if (rm) {
+        const float cnt = (float)G * (float)(bn.count_rep > 1 ? bn.count_rep : 1);
+        const float unb = cnt > 1.f ? var * (cnt / (cnt - 1.f)) : var;
+        rm[cc] = (1.f - bn.momentum) * rm[cc] + bn.momentum * a;
+        rv[cc] = (1.f - bn.momentum) * rv[cc] + bn.momentum * unb;
       }
       const float inv = 1.0f / sqrtf(var + bn.eps);
-      const float ga = bn.gamma ? bn.gamma[c] : 1.f, be = bn.beta ? bn.beta[c] : 0.f;
+      const float ga = gam ? gam[cc] : 1.f, be = bet ? bet[cc] : 0.f;
       const float sc = ga * inv;
       bn.scale[c] = sc;
       bn.shift[c] = be - a * sc;
@@ -381,7 +401,24 @@ extern "C" int spgan_colstats_finalize_bn(const float* partials, int tiles, int 
   if (tile_rows <= 0) tile_rows = RT;
   SPGAN_CHECK_ARG(partials && scale && shift && invstd && mean_out && tiles > 0 && C > 0 && G > 0 && tiles == cdiv(G, tile_rows));
   SPGAN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
-  BnTail bn{gamma, beta, running_mean, running_var, scale, shift, invstd, mean_out, eps, momentum};
+  BnTail bn{gamma, beta, running_mean, running_var, scale, shift, invstd, mean_out, eps, momentum, 0, nullptr, nullptr, nullptr, nullptr, 1};
+  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), 1), dim3(256), 0, s, partials, tiles, C, G, 0, tile_rows, (float*)nullptr,
+                     (float*)nullptr, bn);
+  return spgan_launch_status();
+}
+
+// The same for TWO BatchNorm layers whose channels sit side by side in one record set (columns [0,split) and [split,C)):
+// out4 [4,C] = scale | shift | invstd | mean over all C columns.  count_rep as in spgan_gemm_nt's fan-in descriptor.
+extern "C" int spgan_colstats_finalize_bn2(const float* partials, int tiles, int C, int G, int tile_rows, int split, const float* gammaA,
+                                           const float* betaA, float* rmeanA, float* rvarA, const float* gammaB, const float* betaB,
+                                           float* rmeanB, float* rvarB, float eps, float momentum, int count_rep, float* out4,
+                                           spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (tile_rows <= 0) tile_rows = RT;
+  SPGAN_CHECK_ARG(partials && out4 && tiles > 0 && C > 0 && G > 0 && tiles == cdiv(G, tile_rows) && split > 0 && split < C && count_rep >= 1);
+  SPGAN_CHECK_ARG((rmeanA == nullptr) == (rvarA == nullptr) && (rmeanB == nullptr) == (rvarB == nullptr));
+  BnTail bn{gammaA, betaA, rmeanA, rvarA, out4, out4 + C, out4 + 2 * (size_t)C, out4 + 3 * (size_t)C, eps, momentum,
+            split, gammaB, betaB, rmeanB, rvarB, count_rep};
   hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), 1), dim3(256), 0, s, partials, tiles, C, G, 0, tile_rows, (float*)nullptr,
                      (float*)nullptr, bn);
   return spgan_launch_status();
@@ -393,7 +430,11 @@ extern "C" int spgan_colstats(const float* X, int ldx, int M, int C, int G, floa
   SPGAN_CHECK_ARG(X && out_mean && out_var && ws && M > 0 && C > 0 && G > 0 && M % G == 0 && ldx >= C);
   SPGAN_CHECK_ARG(ws_bytes >= spgan_colreduce_ws_bytes(M, C, G));
   const int groups = M / G, tpg = cdiv(G, RT);
-  hipLaunchKernelGGL((colpartials_kernel<0>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, slope, ws);
+  if (tpg == 1) {  // groups of <= 128 rows: one launch
+    hipLaunchKernelGGL((colpartials_kernel<0>), dim3(groups, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, 1, slope, ws, out_mean, out_var);
+    return spgan_launch_status();
+  }
+  hipLaunchKernelGGL((colpartials_kernel<0>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, slope, ws, (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, ws, tpg, C, G, 0, RT, out_mean, out_var, BnTail{});
   return spgan_launch_status();
 }
@@ -405,7 +446,11 @@ extern "C" int spgan_colsum(const float* X, int ldx, int M, int C, int G, float*
   // ws: partials + a scratch row block for the unused second output
   SPGAN_CHECK_ARG(ws_bytes >= spgan_colreduce_ws_bytes(M, C, G) + (size_t)groups * C * sizeof(float));
   float* scratch = ws + (size_t)groups * tpg * C * 2;
-  hipLaunchKernelGGL((colpartials_kernel<1>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, 1.0f, ws);
+  if (tpg == 1) {  // groups of <= 128 rows (per-shape linears: M = batch): one launch
+    hipLaunchKernelGGL((colpartials_kernel<1>), dim3(groups, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, 1, 1.0f, ws, out, (float*)nullptr);
+    return spgan_launch_status();
+  }
+  hipLaunchKernelGGL((colpartials_kernel<1>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, 1.0f, ws, (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, ws, tpg, C, G, 1, RT, out, scratch, BnTail{});
   return spgan_launch_status();
 }

@@ -17,6 +17,14 @@ c_i64p = C.c_void_p
 stream_t = C.c_void_p
 
 
+class FanIn(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("counters", c_i32p), ("group_part", c_f32p), ("mode", C.c_int),
+                ("out0", c_f32p), ("out1", c_f32p),
+                ("gamma", c_f32p), ("beta", c_f32p), ("rmean", c_f32p), ("rvar", c_f32p),
+                ("scale", c_f32p), ("shift", c_f32p), ("invstd", c_f32p), ("mean_out", c_f32p),
+                ("eps", C.c_float), ("momentum", C.c_float), ("count_rep", C.c_int)]
+
+
 class GemmNTArgs(C.Structure):
     _fields_ = [
         ("A", c_f32p), ("lda", C.c_int),
@@ -37,6 +45,7 @@ class GemmNTArgs(C.Structure):
         ("pool_val", c_f32p), ("pool_arg", c_i32p),
         ("mfma_f16", C.c_int),
         ("batch", C.c_int), ("batch_stride_a", C.c_long), ("batch_stride_w", C.c_long), ("batch_stride_y", C.c_long),
+        ("fin", FanIn),
     ]
 
 
@@ -91,6 +100,8 @@ SIGNATURES = {
     "spgan_pm_to_cm": (I, [P, I, I, I, P, P]),
     "spgan_concat2": (I, [P, I, P, I, I, P, P]),
     "spgan_gemm_nt": (I, [C.POINTER(GemmNTArgs), P]),
+    "spgan_gemm_nt_col_blocks": (I, [C.POINTER(GemmNTArgs)]),
+    "spgan_fanin_groups": (I, [I]),
     "spgan_pool_finalize": (I, [P, P, I, I, I, P, P, F, P, P, P, P]),
     "spgan_gemm_tn_ws_bytes": (SZ, [I, I, I]),
     "spgan_gemm_tn": (I, [C.POINTER(GemmTNArgs), P]),
@@ -101,6 +112,7 @@ SIGNATURES = {
     "spgan_colreduce_ws_bytes": (SZ, [I, I, I]),
     "spgan_colstats_finalize": (I, [P, I, I, I, I, I, I, P, P, P]),
     "spgan_colstats_finalize_bn": (I, [P, I, I, I, I, P, P, F, F, P, P, P, P, P, P, P]),
+    "spgan_colstats_finalize_bn2": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, P, F, F, I, P, P]),
     "spgan_colstats": (I, [P, I, I, I, I, F, P, P, P, SZ, P]),
     "spgan_colsum": (I, [P, I, I, I, I, P, P, SZ, P]),
     "spgan_bn_prepare": (I, [P, P, P, P, I, I, F, F, I, P, P, P, P, P, P, P]),

@@ -465,10 +465,23 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
 # =============================================================================================
 # EdgeBlock (Generation/Generator.py:47-88), point-major, restructured per point
 # =============================================================================================
+_WO_CACHE: Dict[int, tuple] = {}      # data_ptr -> (stamp, permuted weight, weakref to the owning Parameter)
+
+
 def conv_out_weight_pm(w: Tensor) -> Tensor:
-    """conv_out.weight [F,F,1,k] -> [F, k*F] with K index r*F + c (matches T's layout)."""
+    """conv_out.weight [F,F,1,k] -> [F, k*F] with K index r*F + c (matches T's layout).  For a Parameter the copy is kept until the
+    weights change (both generator forwards of a train step see the same weights: nets._t's staleness rule)."""
     F_, _, _, k = w.shape
-    return w[:, :, 0, :].permute(0, 2, 1).reshape(F_, k * F_).contiguous()
+    owner = _owner(w)
+    if owner is None:
+        return w[:, :, 0, :].permute(0, 2, 1).reshape(F_, k * F_).contiguous()
+    stamp = (ops.WEIGHTS_EPOCH[0], owner._version)
+    hit = _WO_CACHE.get(w.data_ptr())
+    if hit is not None and hit[0] == stamp and hit[2]() is owner:
+        return hit[1]
+    out = w.detach()[:, :, 0, :].permute(0, 2, 1).reshape(F_, k * F_).contiguous()
+    _WO_CACHE[w.data_ptr()] = (stamp, out, weakref.ref(owner))
+    return out
 
 
 def conv_out_weight_grad_from_pm(g: Tensor, F_: int, k: int) -> Tensor:
@@ -489,18 +502,18 @@ def edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int,
     PQR = ops.gemm_nt(x, Wcat)                                                   # [M, H+2F]
     E = M * k
     if training:
-        mean, var = ops.edge_stats(PQR, idx, b1, bx)
-        bn1 = _bn_train(mean[:H].contiguous(), var[:H].contiguous(), P, bufs, pre + ".conv_w.1", E * count_rep, True, update_running)
-        bnx = _bn_train(mean[H:].contiguous(), var[H:].contiguous(), P, bufs, pre + ".conv_x.1", E * count_rep, True, update_running)
+        run = lambda n: (bufs[n + ".running_mean"], bufs[n + ".running_var"]) if (bufs is not None and update_running) else (None, None)
+        bn1, bnx = ops.edge_stats_bn(PQR, idx, b1, bx,
+                                     (P[pre + ".conv_w.1.weight"], P[pre + ".conv_w.1.bias"]) + run(pre + ".conv_w.1"),
+                                     (P[pre + ".conv_x.1.weight"], P[pre + ".conv_x.1.bias"]) + run(pre + ".conv_x.1"), count_rep)
+        if bufs is not None and update_running:
+            _count_bn_call(bufs, pre + ".conv_w.1"); _count_bn_call(bufs, pre + ".conv_x.1")
     else:
         bn1 = _bn_train(None, None, P, bufs, pre + ".conv_w.1", E, False, False)
         bnx = _bn_train(None, None, P, bufs, pre + ".conv_x.1", E, False, False)
     W2, b2 = _w2(P[pre + ".conv_w.3.weight"]), P[pre + ".conv_w.3.bias"]
-    if training and count_rep > 1:
-        h2pre, m2, v2 = ops.gemm_nt(PQR[:, :H], W2, b2, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1), stats=True)
-        bn2 = _bn_train(m2, v2, P, bufs, pre + ".conv_w.4", E * count_rep, True, update_running)
-    else:
-        h2pre, bn2 = _gemm_bn(PQR[:, :H], W2, b2, P, bufs, pre + ".conv_w.4", E, training, update_running, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1))
+    h2pre, bn2 = _gemm_bn(PQR[:, :H], W2, b2, P, bufs, pre + ".conv_w.4", E, training, update_running, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1),
+                          **({"count_rep": count_rep} if training and count_rep > 1 else {}))
     T = ops.edge_attend_fwd(h2pre, bn2[0], bn2[1], PQR, idx, bx, bnx[0], bnx[1], NEG)
     Wo = conv_out_weight_pm(P[pre + ".conv_out.weight"])
     out = ops.gemm_nt(T, Wo, P[pre + ".conv_out.bias"])

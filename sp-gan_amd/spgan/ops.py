@@ -185,6 +185,54 @@ def concat2(a: Tensor, b: Tensor) -> Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------- in-launch finish of column records (csrc/fanin.hpp)
+# Kernels that produce per-tile column records (GEMM statistics epilogues) can merge them in the same launch instead of leaving
+# that to a finalize launch:
+#   * M <= 64 (gemm_nt_small_kernel, one workgroup owns its columns): always -- the tail costs nothing;
+#   * MFMA grids (M > 64): by the last-arriving workgroup (two-level fan-in).  MEASURED SLOWER than the separate launch on every
+#     shape of the train step (profiles/r02_fanin_ab.txt: +5..+27 us per GEMM against ~6 us per finalize launch; the chain
+#     store-drain -> device-scope atomic -> L2/L1 invalidate -> dependent loads is ~6 us per level on MI355X), so it is OFF by
+#     default; SPGAN_FANIN=1 / ops.FANIN[0] = True switch it on (tests/test_fanin_gpu.py keeps it correct).
+import os as _os
+FANIN = [_os.environ.get("SPGAN_FANIN", "0") == "1"]
+_FANIN_RING = {}        # device -> [int32 counters (zero; the kernels leave them zero), cursor]
+_FANIN_RING_SIZE = 1 << 16
+
+
+def _fanin_counters(device, n: int) -> int:
+    st = _FANIN_RING.get(device)
+    if st is None:
+        st = [torch.zeros(_FANIN_RING_SIZE, dtype=torch.int32, device=device), 0]
+        _FANIN_RING[device] = st
+    if n > _FANIN_RING_SIZE:
+        raise ValueError("fan-in counter request too large: %d" % n)
+    if st[1] + n > _FANIN_RING_SIZE:
+        st[1] = 0
+    off = st[1]
+    st[1] += n
+    return st[0].data_ptr() + 4 * off
+
+
+def _fanin_setup(fin, lib, device, tiles: int, col_blocks: int, Cn: int, need_counters: bool = True):
+    """Counters and group scratch of one fan-in launch; returns the scratch tensor (keep it alive until the launch was issued)."""
+    fin.enabled = 1
+    gp = None
+    if need_counters:
+        ng = lib.spgan_fanin_groups(tiles)
+        fin.counters = _fanin_counters(device, col_blocks * (ng + 1))
+        if ng > 1:
+            gp = torch.empty((ng, Cn, 2), dtype=torch.float32, device=device)
+            fin.group_part = gp.data_ptr()
+    return gp
+
+
+def _fanin_bn(fin, gamma, beta, rm, rv, out4, count_rep: int = 1):
+    fin.mode = 0
+    fin.gamma, fin.beta, fin.rmean, fin.rvar = _p(gamma), _p(beta), _p(rm), _p(rv)
+    fin.scale, fin.shift, fin.invstd, fin.mean_out = _p(out4[0]), _p(out4[1]), _p(out4[2]), _p(out4[3])
+    fin.eps, fin.momentum, fin.count_rep = BN_EPS, BN_MOMENTUM, int(count_rep)
+
+
 # ----------------------------------------------------------------------------- contractions
 def _finalize(partials: Tensor, groups: int, tpg: int, Cn: int, G: int, mode: int, tile_rows: int = 0) -> Tuple[Tensor, Tensor]:
     out = torch.empty((2, groups, Cn), dtype=torch.float32, device=partials.device)
@@ -194,11 +242,13 @@ def _finalize(partials: Tensor, groups: int, tpg: int, Cn: int, G: int, mode: in
 
 def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, edge=None, rowbias: Optional[Tensor] = None,
             rows_per_group: int = 0, act: int = ACT_NONE, slope: float = 0.0, stats: bool = False, M: Optional[int] = None, bn=None,
-            out: Optional[Tensor] = None, exact: bool = False):
+            out: Optional[Tensor] = None, exact: bool = False, count_rep: int = 1):
     """Y[M,N] = act( pro(A) @ W^T + bias + rowbias[m // rows_per_group] ).
     out  = destination [M,N] (unit column stride; may be a column slice of a wider buffer) instead of a fresh tensor.
     bn = (gamma, beta, running_mean | None, running_var | None): train-mode BatchNorm of Y fused behind the GEMM: returns
-         (Y, (scale, shift, invstd, mean)) and updates the running statistics (column statistics in the epilogue + one finalize launch).
+         (Y, (scale, shift, invstd, mean)) and updates the running statistics -- column statistics in the epilogue, merged and
+         finished by the last-arriving workgroup of the same launch (csrc/fanin.hpp).  count_rep: the rows stand for count_rep
+         identical copies (only the unbiased-variance count of the running statistics changes).
     pro  = (scale[K], shift[K], slope): operand a = lrelu(A*scale+shift)            (A_AFFINE_LRELU)
     edge = (idx[M,k], ebias[K]) with pro: rows are edges, a = lrelu((A[j]-A[i]+ebias)*scale+shift)  (A_EDGE)
     stats=True additionally returns (mean[N], biased var[N]) of the pre-activation output over all M rows.
@@ -244,17 +294,35 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
         part = torch.empty((tiles, N, 2), dtype=torch.float32, device=A.device)
         a.stats = _p(part)
     lib = _lib.load()
+    fused = part is not None and (FANIN[0] or M_ <= 64)
+    res = keep = None
+    if fused:
+        keep = _fanin_setup(a.fin, lib, A.device, part.shape[0], lib.spgan_gemm_nt_col_blocks(C.byref(a)), N)
+        if bn is not None:
+            res = torch.empty((4, N), dtype=torch.float32, device=A.device)
+            _fanin_bn(a.fin, bn[0], bn[1], bn[2], bn[3], res, count_rep)
+        else:
+            res = torch.empty((2, N), dtype=torch.float32, device=A.device)
+            a.fin.mode = 0; a.fin.out0 = _p(res[0]); a.fin.out1 = _p(res[1])
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt", M=M_, N=N, K=K, a_mode=a.a_mode)
     if done is not None:
         done()
+    del keep
     if bn is not None:
+        if fused:
+            return Y, (res[0], res[1], res[2], res[3])
         gamma, beta, rm, rv = bn
+        if count_rep != 1:
+            mean, var = _finalize(part, 1, part.shape[0], N, M_, 0)
+            return Y, bn_prepare(mean[0].contiguous(), var[0].contiguous(), gamma, beta, M_ * count_rep, True, rm, rv)
         out = torch.empty((4, N), dtype=torch.float32, device=A.device)
         check(lib.spgan_colstats_finalize_bn(_p(part), part.shape[0], N, M_, 0, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM, _p(rm), _p(rv),
                                              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _s()), "colstats_finalize_bn", N=N, M=M_)
         return Y, (out[0], out[1], out[2], out[3])
     if stats:
+        if fused:
+            return Y, res[0], res[1]
         mean, var = _finalize(part, 1, part.shape[0], N, M_, 0)
         return Y, mean[0], var[0]
     return Y
@@ -394,10 +462,19 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
         idx, ebias = edge
         _i32(idx, "idx")
         a.epi_mode = EPI_EDGE_BNBWD; a.e_idx = _p(idx); a.e_k = idx.shape[1]; a.e_bias2 = _p(_vec(ebias, N, "ebias"))
+    lib = _lib.load()
+    res = keep = None
+    if FANIN[0] or M_ <= 64:
+        res = torch.empty((2, N), dtype=torch.float32, device=A.device)          # [sum g | sum g*xhat], contiguous (nets._cat2)
+        keep = _fanin_setup(a.fin, lib, A.device, tiles, lib.spgan_gemm_nt_col_blocks(C.byref(a)), N)
+        a.fin.mode = 1; a.fin.out0 = _p(res[0]); a.fin.out1 = _p(res[1])
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
-    check(_lib.load().spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_bnbwd", M=M_, N=N, K=K)
+    check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_bnbwd", M=M_, N=N, K=K)
     if done is not None:
         done()
+    del keep
+    if res is not None:
+        return g, res[0], res[1]
     s0, s1 = _finalize(part, 1, tiles, N, M_, 1)
     return g, s0[0], s1[0]
 
@@ -663,14 +740,20 @@ def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, sl
     parg = torch.empty((tiles, N, 2), dtype=torch.int32, device=dev)
     a.stats = _p(part); a.pool_val = _p(pval); a.pool_arg = _p(parg)
     lib = _lib.load()
+    gamma, beta, rm, rv = bn
+    st = torch.empty((4, N), dtype=torch.float32, device=dev)
+    keep = None
+    if FANIN[0]:
+        keep = _fanin_setup(a.fin, lib, dev, tiles, lib.spgan_gemm_nt_col_blocks(C.byref(a)), N)
+        _fanin_bn(a.fin, gamma, beta, rm, rv, st)
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_bn_pool", M=M_, N=N, K=K)
     if done is not None:
         done()
-    gamma, beta, rm, rv = bn
-    st = torch.empty((4, N), dtype=torch.float32, device=dev)
-    check(lib.spgan_colstats_finalize_bn(_p(part), tiles, N, M_, 0, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM, _p(rm), _p(rv),
-                                         _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _s()), "colstats_finalize_bn", N=N, M=M_)
+    del keep
+    if not FANIN[0]:
+        check(lib.spgan_colstats_finalize_bn(_p(part), tiles, N, M_, 0, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM, _p(rm), _p(rv),
+                                             _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _s()), "colstats_finalize_bn", N=N, M=M_)
     pooled = torch.empty((B, N), dtype=torch.float32, device=dev)
     yarg = torch.empty((B, N), dtype=torch.float32, device=dev)
     arg = torch.empty((B, N), dtype=torch.int32, device=dev)
@@ -723,6 +806,30 @@ def edge_stats(PQR: Tensor, idx: Tensor, b1: Tensor, bx: Tensor) -> Tuple[Tensor
           "edge_stats", M=M_, k=k, H=H, F=F_)
     mean, var = _finalize(part, 1, tiles, H + F_, M_ * k, 0, tr)
     return mean[0], var[0]
+
+
+def edge_stats_bn(PQR: Tensor, idx: Tensor, b1: Tensor, bx: Tensor, bn_w, bn_x, count_rep: int = 1):
+    """edge_stats followed by the train-mode bookkeeping of BOTH per-edge BatchNorm layers (conv_w.1 over the H channels, conv_x.1
+    over the F channels; bn_* = (gamma, beta, running_mean | None, running_var | None)) in ONE finalize launch
+    (spgan_colstats_finalize_bn2) instead of a finalize and two bn_prepare launches.
+    -> ((scale, shift, invstd, mean) of conv_w.1 [H], the same of conv_x.1 [F])."""
+    H, F_ = b1.numel(), bx.numel()
+    _pqr(PQR, H, F_); _i32(idx, "idx")
+    M_, k = idx.shape
+    lib = _lib.load()
+    tr = lib.spgan_edge_stats_tile_rows(k)
+    tiles = (M_ * k + tr - 1) // tr
+    Cn = H + F_
+    part = torch.empty((tiles, Cn, 2), dtype=torch.float32, device=PQR.device)
+    check(lib.spgan_edge_stats(_p(PQR), PQR.shape[1], _p(idx), M_, k, H, F_, _p(_vec(b1, H, "b1")), _p(_vec(bx, F_, "bx")), _p(part), _s()),
+          "edge_stats", M=M_, k=k, H=H, F=F_)
+    out = torch.empty((4, Cn), dtype=torch.float32, device=PQR.device)
+    gw, bw, rmw, rvw = bn_w
+    gx, bx_, rmx, rvx = bn_x
+    check(lib.spgan_colstats_finalize_bn2(_p(part), tiles, Cn, M_ * k, tr, H, _p(_vec(gw, H, "gamma_w")), _p(_vec(bw, H, "beta_w")), _p(rmw), _p(rvw),
+                                          _p(_vec(gx, F_, "gamma_x")), _p(_vec(bx_, F_, "beta_x")), _p(rmx), _p(rvx), BN_EPS, BN_MOMENTUM, int(count_rep),
+                                          _p(out), _s()), "colstats_finalize_bn2", C=Cn, G=M_ * k)
+    return tuple(out[i, :H] for i in range(4)), tuple(out[i, H:] for i in range(4))
 
 
 def edge_attend_fwd(h2pre: Tensor, sc2: Tensor, sh2: Tensor, PQR: Tensor, idx: Tensor, bx: Tensor, scx: Tensor, shx: Tensor,

@@ -97,14 +97,14 @@ def _operand(A, pro, edge, K):
 
 
 def gemm_nt(A, W, bias=None, *, pro=None, edge=None, rowbias=None, rows_per_group=0, act=ACT_NONE, slope=0.0, stats=False, M=None, bn=None,
-            out=None, exact=False):
+            out=None, exact=False, count_rep=1):
     if out is not None:
         out.copy_(gemm_nt(A, W, bias, pro=pro, edge=edge, rowbias=rowbias, rows_per_group=rows_per_group, act=act, slope=slope, M=M))
         return out
     if bn is not None:
         y, mean, var = gemm_nt(A, W, bias, pro=pro, edge=edge, rowbias=rowbias, rows_per_group=rows_per_group, act=act, slope=slope, stats=True, M=M)
         gamma, beta, rm, rv = bn
-        return y, bn_prepare(mean, var, gamma, beta, y.shape[0], True, rm, rv)
+        return y, bn_prepare(mean, var, gamma, beta, y.shape[0] * count_rep, True, rm, rv)
     N, K = W.shape
     a = _operand(A, pro, edge, K)
     if M is not None:
@@ -370,6 +370,14 @@ def _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope):
     zy = (yp * scx + shx).view(M, k, F_)
     w = torch.softmax(_lrelu(z2, slope), dim=1)
     return z2, zy, w, _lrelu(zy, slope), yp.view(M, k, F_)
+
+
+def edge_stats_bn(PQR, idx, b1, bx, bn_w, bn_x, count_rep=1):
+    H = b1.numel()
+    mean, var = edge_stats(PQR, idx, b1, bx)
+    E = idx.shape[0] * idx.shape[1]
+    return (bn_prepare(mean[:H].contiguous(), var[:H].contiguous(), bn_w[0], bn_w[1], E * count_rep, True, bn_w[2], bn_w[3]),
+            bn_prepare(mean[H:].contiguous(), var[H:].contiguous(), bn_x[0], bn_x[1], E * count_rep, True, bn_x[2], bn_x[3]))
 
 
 def edge_attend_fwd(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope):
