@@ -122,7 +122,9 @@ class MfmaAccounting:
             small = a.M <= 64 and a.a_mode != 2 and a.epi_mode != 3 and not a.sp_val and batch == 1 and not a.pool_val
             if small:
                 return None
-            if self.f16 and a.N > 32:
+            if self.f16 == "bf16x3" and a.N > 32 and a.mfma_f16:
+                bn = 64
+            elif self.f16 == "f16" and a.N > 32 and a.mfma_f16:
                 bn = 128 if (a.N > 64 and a.K >= 512) else 64
             else:
                 bn = 128 if (a.N > 64 and a.K >= 512) else (64 if a.N > 32 else 32)
@@ -318,7 +320,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the drop-in-caller and MFMA-accounting legs (they run after the timed region)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying the captured hipGraph")
-    ap.add_argument("--mfma", choices=("f32", "f16"), default="f32",
+    ap.add_argument("--mfma", choices=("f32", "f16", "bf16x3"), default="f32",
                     help="operand precision of the MFMA contractions: f32 (BASELINE configs[1], the headline) or f16 operands with fp32 "
                          "accumulation (the per-GPU shape of BASELINE configs[4], 'fp16 MFMA MLPs')")
     ap.add_argument("--reference-schedule", action="store_true",
@@ -377,7 +379,7 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     peak = FP32_MATRIX_PEAK_TFLOPS if args.mfma == "f32" else FP16_MATRIX_PEAK_TFLOPS
-    acct = MfmaAccounting(PER_GPU_BATCH * N_POINTS, peak, args.mfma == "f16") if (rank == 0 and not SELFTEST) else None
+    acct = MfmaAccounting(PER_GPU_BATCH * N_POINTS, peak, args.mfma) if (rank == 0 and not SELFTEST) else None
     dt, t_issue = time_steps(tr, one_step, args.steps, dist_on, dev)
 
     ACCT_STEPS = 4
@@ -418,7 +420,8 @@ def main():
         line = {
             "metric": "G+D train-step shapes/sec @2048 pts, bs=32 per GPU (WGAN-GP)", "value": round(shapes_s, 2), "unit": "shapes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.mfma == "f32" else "f16 MFMA operands, f32 accumulate/epilogues/weight-gradients",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate/epilogues/weight-gradients",
+                                                                                  "bf16x3": "f32 operands split into 3 bf16 terms (6 bf16 MFMA cross products, f32 accumulate); weight gradients f32 MFMA"}[args.mfma],
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: Chair-shaped synthetic clouds, 2048 pts, per-GPU batch 32, WGAN + gradient penalty (lambda 10), "
                                    "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10; one latent per shape (default noise_generator) handed over un-tiled [b,1,128]", "global_batch": PER_GPU_BATCH * world, "n_points": N_POINTS,

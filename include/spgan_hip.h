@@ -140,7 +140,9 @@ typedef struct spgan_gemm_nt_args {
    * (Discriminator.py:77-81,104) is finished by spgan_pool_finalize once the batch statistics are known. */
   float* pool_val; int32_t* pool_arg;
   /* 1: round the operands to fp16 when staging them (after the prologue) and multiply with the fp16 MFMA, fp32 accumulation
-   * (BASELINE configs[4] "fp16 MFMA MLPs"); aligned operands and N > 32 only, otherwise the fp32 path is used.  Default 0. */
+   * (BASELINE configs[4] "fp16 MFMA MLPs"); aligned operands and N > 32 only, otherwise the fp32 path is used.  Default 0.
+   * 2: split every fp32 operand value exactly into three bfloat16 terms and evaluate the six leading cross products on the bf16 matrix
+   * pipe with fp32 accumulation: fp32-equivalent products (dropped terms <= 3*2^-24 relative) at 6/16 of the fp32-MFMA time. */
   int mfma_f16;
   /* batch > 1 (A_PLAIN + EPI_LINEAR without stats / rowbias / pooling only): `batch` independent products in one launch,
    * product z uses A + z*batch_stride_a, W + z*batch_stride_w, Y + z*batch_stride_y (strides in floats; bias is shared).

@@ -107,6 +107,28 @@ __device__ __forceinline__ void st_row4h(float* p, float4 v) {
   *reinterpret_cast<f16x4*>(p) = h;
 }
 
+// F16 = 2 ("bf16x3"): every fp32 operand value v is split EXACTLY into three bfloat16 terms v = hi + mid + lo (8 significand bits
+// each: 24 together = fp32's significand; each residual is exactly representable in fp32, so the subtractions are exact) and the
+// product a*b is evaluated as the six leading cross terms on the bf16 matrix pipe (16x the fp32 MFMA rate), accumulated in fp32:
+//   a*b ~ ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm),  dropped terms <= 3 * 2^-24 |a*b|  (one fp32 ulp is 2^-23 |a*b|)
+// -- fp32-equivalent products (each bf16 x bf16 partial product is exact in fp32) at 6/16 of the fp32-MFMA time.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDX3 = 52;  // LDS row: three planes of 32 bf16 (16 words each) + 4 words of padding; 52 = 4*13 keeps the 16-byte
+                          // fragment reads of 16 consecutive rows on disjoint 4-bank groups (conflict-free ds_read_b128)
+
+__device__ __forceinline__ void st_row4b3(float* p, float4 v) {  // p: word address of this k-quad inside the hi plane
+  f32x4v f = {v.x, v.y, v.z, v.w};
+  const bf16x4 hi = __builtin_convertvector(f, bf16x4);
+  const f32x4v r1 = f - __builtin_convertvector(hi, f32x4v);
+  const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
+  const f32x4v r2 = r1 - __builtin_convertvector(mid, f32x4v);
+  const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
+  *reinterpret_cast<bf16x4*>(p) = hi;
+  *reinterpret_cast<bf16x4*>(p + 16) = mid;
+  *reinterpret_cast<bf16x4*>(p + 32) = lo;
+}
+
 __device__ __forceinline__ void st_row4(float* p, float4 v) {  // rows are 8-byte aligned (LDT even)
   *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
   *reinterpret_cast<float2*>(p + 2) = make_float2(v.z, v.w);
@@ -195,8 +217,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   constexpr int BN = G::WGN * TJ * 32;
   constexpr int NB = DB + 1;
   constexpr int BSLOT = BN / 32;  // float4 staging slots per thread for the weight tile
-  constexpr int LDX = F16 ? 18 : LDT;   // LDS row stride in 4-byte words
-  constexpr int KK = F16 ? BK / 8 : BK / 4;  // fragment reads per k-tile
+  constexpr int LDX = F16 == 2 ? LDX3 : (F16 ? 18 : LDT);   // LDS row stride in 4-byte words
+  constexpr int KK = F16 == 2 ? BK / 16 : (F16 ? BK / 8 : BK / 4);  // fragment reads per k-tile
   static_assert(!(F16 && AMODE == A_AFFINE_SPARSE), "the LDS patch path of the sparse addend is fp32 only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [NB][BM*LDX]
@@ -342,7 +364,12 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 #pragma unroll
       for (int i = 0; i < BSLOT; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (F16) {
+    if (F16 == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st_row4b3(&a[(lrow + 32 * i) * LDX + (lc4 >> 1)], ra[i]);
+#pragma unroll
+      for (int i = 0; i < BSLOT; ++i) st_row4b3(&b[(lrow + 32 * i) * LDX + (lc4 >> 1)], rb[i]);
+    } else if (F16) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) st_row4h(&a[(lrow + 32 * i) * LDX + (lc4 >> 1)], ra[i]);
 #pragma unroll
@@ -355,11 +382,34 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
     }
   };
   auto compute = [&](int buf, int kk0, int kk1) {
-    const float* a = As + buf * BM * LDX + (wm * TI * 32 + l31) * LDX + 2 * lh;
-    const float* b = Bs + buf * BN * LDX + (wn * TJ * 32 + l31) * LDX + 2 * lh;
+    const float* a = As + buf * BM * LDX + (wm * TI * 32 + l31) * LDX + (F16 == 2 ? 4 : 2) * lh;
+    const float* b = Bs + buf * BN * LDX + (wn * TJ * 32 + l31) * LDX + (F16 == 2 ? 4 : 2) * lh;
 #pragma unroll
     for (int kk = kk0; kk < kk1; ++kk) {
-      if (F16) {
+      if (F16 == 2) {
+        // k-step of 16: lane half lh holds k = 8*lh .. 8*lh+7 of each plane (16 bytes); six cross terms, small ones first
+        bf16x8 ap[3][TI], bp[3][TJ];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) ap[q][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LDX + q * 16 + kk * 8);
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) bp[q][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LDX + q * 16 + kk * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) {
+            f32x16 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2][i], bp[0][j], c, 0, 0, 0);  // lo * hi
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bp[2][j], c, 0, 0, 0);  // hi * lo
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][i], bp[1][j], c, 0, 0, 0);  // mid * mid
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][i], bp[0][j], c, 0, 0, 0);  // mid * hi
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bp[1][j], c, 0, 0, 0);  // hi * mid
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bp[0][j], c, 0, 0, 0);  // hi * hi
+            acc[i][j] = c;
+          }
+      } else if (F16) {
         f16x4 ah[TI], bh[TJ];
 #pragma unroll
         for (int i = 0; i < TI; ++i) ah[i] = *reinterpret_cast<const f16x4*>(a + i * 32 * LDX + kk * 4);
@@ -864,7 +914,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 
 template <int CFG, int DB, int F16 = 0>
 constexpr size_t nt_lds_bytes() {
-  return (size_t)((DB + 1) * (BM + Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * (F16 ? 18 : LDT) + 5 * Geo<CFG>::WGM * Geo<CFG>::WGN * Geo<CFG>::TJ * 32) *
+  return (size_t)((DB + 1) * (BM + Geo<CFG>::WGN * Geo<CFG>::TJ * 32) * (F16 == 2 ? LDX3 : (F16 ? 18 : LDT)) + 5 * Geo<CFG>::WGM * Geo<CFG>::WGN * Geo<CFG>::TJ * 32) *
          sizeof(float);
 }
 
@@ -1036,7 +1086,11 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
     }
   }
   if constexpr (AMODE != A_AFFINE_SPARSE) {
-    if (a.mfma_f16 && fast && a.N > 32) {  // fp16 operands (fp32 accumulate): same tiling rules
+    if (a.mfma_f16 == 2 && fast && a.N > 32) {  // fp32 operands split into three bf16 terms: 128x64 tiles (three operand planes in LDS)
+      launch_nt_cfg<AMODE, EPI, 1, 0, 1, 2>(a, s);
+      return spgan_launch_status();
+    }
+    if (a.mfma_f16 == 1 && fast && a.N > 32) {  // fp16 operands (fp32 accumulate): same tiling rules
       if (a.N > 64 && a.K >= 512) launch_nt_cfg<AMODE, EPI, 0, 1, 1, 1>(a, s);
       else launch_nt_cfg<AMODE, EPI, 1, 0, 1, 1>(a, s);
       return spgan_launch_status();
@@ -1573,7 +1627,8 @@ extern "C" int spgan_fanin_groups(int tiles) { return tiles > 0 ? fanin::group_c
 // N-tile width launch_nt picks for this problem (must mirror launch_nt)
 static int nt_tile_n(const spgan_gemm_nt_args& a) {
   const bool fast = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A) && al16(a.W);
-  if (a.mfma_f16 && fast && a.N > 32 && !a.sp_val) return (a.N > 64 && a.K >= 512) ? 128 : 64;
+  if (a.mfma_f16 == 2 && fast && a.N > 32 && !a.sp_val) return 64;
+  if (a.mfma_f16 == 1 && fast && a.N > 32 && !a.sp_val) return (a.N > 64 && a.K >= 512) ? 128 : 64;
   if (a.N > 64 && a.K >= 512) return 128;
   return a.N > 32 ? 64 : 32;
 }

@@ -84,14 +84,21 @@ launch_timer = None
 _MFMA_F16 = [0]
 
 
+_MFMA_KINDS = {"f32": 0, "f16": 1, "bf16x3": 2}
+
+
 def set_mfma_operands(kind: str) -> None:
-    if kind not in ("f32", "f16"):
-        raise ValueError("mfma operands must be 'f32' or 'f16'")
-    _MFMA_F16[0] = 1 if kind == "f16" else 0
+    """"f32": fp32 MFMA (exact fp32 products, the default);
+    "f16": operands rounded to fp16 at the LDS staging, fp32 accumulation (BASELINE configs[4] "fp16 MFMA MLPs");
+    "bf16x3": each fp32 operand split exactly into three bf16 terms, six cross products on the bf16 matrix pipe, fp32
+              accumulation -- fp32-equivalent products (|error| <= 3*2^-24 relative per product) at 6/16 of the fp32-MFMA time."""
+    if kind not in _MFMA_KINDS:
+        raise ValueError("mfma operands must be one of %s" % sorted(_MFMA_KINDS))
+    _MFMA_F16[0] = _MFMA_KINDS[kind]
 
 
 def get_mfma_operands() -> str:
-    return "f16" if _MFMA_F16[0] else "f32"
+    return {v: k for k, v in _MFMA_KINDS.items()}[_MFMA_F16[0]]
 
 
 # Bumped by every optimiser step that rewrites parameters through a HIP kernel (invisible to torch's version counters);

@@ -194,3 +194,66 @@ def test_f16_full_size_config_properties(f16sp):
             assert torch.equal(own, got), "sphere graph differs from the oracle at N=2048"
     assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
     assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3]), "fp16-operand step is not deterministic"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# "bf16x3": fp32 operands split exactly into three bf16 terms, six cross products on the bf16 matrix pipe, fp32 accumulation
+@pytest.fixture()
+def b3(ops):
+    ops.set_mfma_operands("bf16x3")
+    yield ops
+    ops.set_mfma_operands("f32")
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 256, 128), (4096, 128, 1280), (1024, 1024, 256), (700, 64, 64), (8192, 256, 3 * 32 + 8)])
+def test_gemm_nt_bf16x3_is_fp32_equivalent(b3, M, N, K):
+    """Against the float64 product of the SAME fp32 operands: the split-bf16 result is as close as the exact-fp32-MFMA result
+    (both are limited by fp32 accumulation), i.e. the dropped cross terms (<= 3*2^-24 per product) do not show."""
+    ops = b3
+    A, W, b = rnd("b3.A%d" % K, (M, K)), rnd("b3.W%d.%d" % (N, K), (N, K), 0.1), rnd("b3.b%d" % N, (N,))
+    ref = (A.double() @ W.double().t() + b.double())
+    got = ops.gemm_nt(A, W, b)
+    ops.set_mfma_operands("f32")
+    f32 = ops.gemm_nt(A, W, b)
+    ops.set_mfma_operands("bf16x3")
+    e3 = ((got.double() - ref).norm() / ref.norm()).item()
+    e32 = ((f32.double() - ref).norm() / ref.norm()).item()
+    m3 = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert e3 <= max(3.0 * e32, 3e-7), (e3, e32)
+    assert e3 <= 1e-6 and m3 <= 3e-6, (e3, m3)               # fp32 accumulation over K terms: ~sqrt(K) * 2^-24
+    # the fused prologue / epilogues run unchanged in front of / behind the split
+    sc, sh = rnd("b3.sc%d" % K, (K,)).abs() + 0.5, rnd("b3.sh%d" % K, (K,), 0.3)
+    y, m, v = ops.gemm_nt(A, W, b, pro=(sc, sh, 0.01), stats=True)
+    y2, m2, v2 = km.gemm_nt(A, W, b, pro=(sc, sh, 0.01), stats=True)
+    close(y, y2, rtol=2e-6, atol=2e-6, what="affine"); close(m, m2, rtol=1e-5, atol=1e-6); close(v, v2, rtol=2e-5)
+    refm = rnd("b3.ref%d.%d" % (M, N), (M, N))
+    close(ops.gemm_nt_maskout(A, W, refm, 0.01), km.gemm_nt_maskout(A, W, refm, 0.01), rtol=2e-6, atol=2e-6, what="maskout")
+    # extreme magnitudes: the split keeps fp32's range (bf16 has fp32's exponent)
+    big = ops.gemm_nt(A * 1e18, W * 1e15)
+    assert torch.isfinite(big).all()
+    close(big, (A.double() * 1e18) @ (W.double() * 1e15).t(), rtol=1e-6, what="large magnitudes")
+    tiny = ops.gemm_nt(A * 1e-18, W * 1e-15)
+    close(tiny, (A.double() * 1e-18) @ (W.double() * 1e-15).t(), rtol=1e-6, atol=0.0, what="small magnitudes")
+
+
+def test_networks_bf16x3_match_reference_goldens_at_fp32_tolerances(sp):
+    """The split mode against the REFERENCE goldens at the SAME tolerances as the exact-fp32 path (test_parity_gpu.py): G4 stage,
+    G5 discriminator forward/backward, G7 gradient penalty."""
+    sp.ops.set_mfma_operands("bf16x3")
+    try:
+        d = golden("g4_generator.npz")
+        B, N = 4, 256
+        G = _load(sp.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=4)).train()
+        G(fr.sphere_template(N)[None].repeat(B, 1, 1).cuda(), fr.latent(B, N, seed=44).cuda())
+        check(d, "stage|x1", sp.ops.pm_to_cm(G.last_x1, B, N), rtol=2e-5, what="bf16x3")
+        d = golden("g5_discriminator.npz")
+        D = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=4)).train()
+        real = fr.synthetic_real(B, N, seed=5).transpose(2, 1).contiguous().cuda().requires_grad_(True)
+        logit = D(real)
+        check(d, "logit", logit, rtol=1e-5, what="bf16x3")
+        ((logit - 1.0) ** 2).mean().backward()
+        check(d, "dx", real.grad, rtol=2e-4, what="bf16x3")
+        for n, p in D.named_parameters():
+            check(d, "grad|" + n, p.grad, rtol=3e-4, atol=2e-3 if n.endswith(("mlps.0.bias", "mlps.3.bias", "mlps.6.bias", "fc2.0.bias")) else 1e-7, what="bf16x3")
+    finally:
+        sp.ops.set_mfma_operands("f32")
