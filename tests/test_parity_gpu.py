@@ -1,7 +1,8 @@
 """GPU parity: the HIP-backed modules against (a) the golden vectors captured from the real
-reference and (b) the CPU oracle on the same seeded inputs.  Tolerances follow SURVEY H1/H1b:
-fp32 stages <= 1e-5 rel before EdgeConv2's kNN, <= 1e-3 after, kNN judged tie-aware, and
-whole-network gradients are kink-limited (rel-L2 <= 3e-2 there; block gradients are tight)."""
+reference and (b) the CPU oracle on the same seeded inputs.  Tolerances are set to <= ~3x the errors MEASURED
+on MI355X (profiles/r02_parity.json lists every comparison: rel-L2 and max-abs): block tests with injected upstream land at 5e-7 ..
+1.4e-6 rel-L2 (fp32 rounding class; SURVEY H1b planned ~1e-5), the generated cloud at 8e-6, kNN is judged tie-aware, and only the
+end-to-end gradients of a whole train step are kink-limited (1e-3 .. 8e-3 measured: a LeakyReLU / arg-max flip moves them discretely)."""
 import numpy as np
 import pytest
 import torch
@@ -68,12 +69,12 @@ def test_edgeblock_golden(sp, tag, fin, fout):
     x = x.cuda().requires_grad_(True)
     idx = torch.from_numpy(d[tag + "|idx"].astype(np.int64)).view(B, N * 10).cuda()
     y = blk(x, idx=idx)                                                          # reference graph injected (tie-aware protocol)
-    check(d, tag + "|y", y, rtol=1e-5)
+    check(d, tag + "|y", y, rtol=3e-6)                                          # measured 5.9e-7 / 7.3e-7
     dy = fr.normal("g2.dy.%s" % tag, y.shape).cuda()
     (y * dy).sum().backward()
-    check(d, tag + "|dx", x.grad, rtol=1e-4)
+    check(d, tag + "|dx", x.grad, rtol=3e-6)                                    # measured 6.8e-7
     for n, p in blk.named_parameters():
-        check(d, tag + "|grad|" + n, p.grad, rtol=2e-4, atol=_atol(n))
+        check(d, tag + "|grad|" + n, p.grad, rtol=5e-6, atol=_atol(n))             # measured <= 1.3e-6
     for n, b in [(k, v) for k, v in blk.state_dict().items() if k in dict(blk.named_buffers())]:
         np.testing.assert_allclose(b.cpu().numpy(), d[tag + "|buf|" + n], rtol=1e-5, atol=1e-6)
     # own graph: the block's kNN agrees with the reference's except at near-ties
@@ -93,7 +94,7 @@ def test_adain_golden(sp):
     y = m(x, s)
     (y * fr.normal("g3.dy", y.shape).cuda()).sum().backward()
     for n, t in (("y", y), ("dx", x.grad), ("dstyle", s.grad), ("dw", m.style.weight.grad), ("db", m.style.bias.grad)):
-        check(d, n, t, rtol=2e-5)
+        check(d, n, t, rtol=1.5e-6)                                              # measured <= 4.0e-7
 
 
 # ---------------------------------------------------------------- Discriminator (G5, G7)
@@ -103,11 +104,11 @@ def test_discriminator_golden(sp):
     D = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=4)).train()
     real = fr.synthetic_real(B, N, seed=5).transpose(2, 1).contiguous().cuda().requires_grad_(True)
     logit = D(real)
-    check(d, "logit", logit, rtol=1e-5)
+    check(d, "logit", logit, rtol=2e-6)                                         # measured 4.4e-7
     ((logit - 1.0) ** 2).mean().backward()
-    check(d, "dx", real.grad, rtol=2e-4)
+    check(d, "dx", real.grad, rtol=3e-6)                                         # measured 7.6e-7
     for n, p in D.named_parameters():
-        check(d, "grad|" + n, p.grad, rtol=3e-4, atol=_atol(n))
+        check(d, "grad|" + n, p.grad, rtol=5e-6, atol=_atol(n))                  # measured <= 1.4e-6
     for n, b in [(k, v) for k, v in D.state_dict().items() if k in dict(D.named_buffers())]:
         np.testing.assert_allclose(b.cpu().numpy(), d["buf|" + n], rtol=1e-5, atol=1e-6)
 
@@ -120,15 +121,15 @@ def test_gradient_penalty_golden(sp):
     fake = (0.8 * fr.synthetic_real(B, N, seed=72) + 0.05 * fr.normal("g7.n", (B, N, 3))).transpose(2, 1).contiguous().cuda()
     alpha = torch.from_numpy(d["alpha"]).cuda()
     gp = sp.GradientPenalty(10.0, gamma=1)(D, real, fake, alpha=alpha)
-    np.testing.assert_allclose(gp.item(), float(d["gp"]), rtol=1e-4)
+    np.testing.assert_allclose(gp.item(), float(d["gp"]), rtol=1e-5)
     gp.backward()
     for n, p in D.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)
-        check(d, "grad|" + n, g, rtol=2e-3, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 2e-6)
+        check(d, "grad|" + n, g, rtol=5e-6, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)    # double backward: measured <= 1.1e-6
     xh = (real + alpha * (fake - real)).requires_grad_(True)
     D2 = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=7)).train()
     gin, = torch.autograd.grad(D2(xh).sum(), xh)
-    check(d, "input_grad", gin, rtol=2e-4)
+    check(d, "input_grad", gin, rtol=3e-6)                                      # measured 6.9e-7
 
 
 # ---------------------------------------------------------------- Generator (G4)
@@ -154,11 +155,11 @@ def test_generator_golden(sp):
     # (measured on the reference against itself), so the raw output is only comparable when the
     # graphs coincide; otherwise test_generator_vs_oracle_with_injected_graph carries the comparison.
     if rows2 == 1.0:
-        check(d, "out", out, rtol=2e-4)
+        check(d, "out", out, rtol=3e-5)                                          # measured 7.6e-6
         for n, b in [(k, v) for k, v in G.state_dict().items() if k in dict(G.named_buffers())]:
             np.testing.assert_allclose(b.cpu().numpy(), d["buf|" + n], rtol=2e-3, atol=1e-4)
     # the stage feeding EdgeConv2's graph is tie-independent and must be tight (<= 1e-5 class)
-    check(d, "stage|x1", sp.ops.pm_to_cm(G.last_x1, B, N), rtol=2e-5)
+    check(d, "stage|x1", sp.ops.pm_to_cm(G.last_x1, B, N), rtol=3e-6)           # measured 9.7e-7
 
 
 def test_generator_vs_oracle_with_injected_graph(sp):
@@ -173,7 +174,7 @@ def test_generator_vs_oracle_with_injected_graph(sp):
     po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     buf = orc.bn_buffers(orc.generator_shapes())
     ref = orc.generator_forward(po, x, z, training=True, buffers=buf, idx1=idx1, idx2=idx2)
-    assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) <= 2e-4
+    assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) <= 2e-5         # measured 4.8e-6
     dy = fr.normal("pg.dy", out.shape)
     (out * dy.cuda()).sum().backward()
     names = list(po.keys())
@@ -182,11 +183,11 @@ def test_generator_vs_oracle_with_injected_graph(sp):
     for n, g in zip(names, grads):
         e = rel_l2(gsd[n].grad.cpu().numpy(), g.numpy())
         mx = (gsd[n].grad.cpu() - g).abs().max().item()
-        assert e <= 3e-2 or mx <= _atol(n), "%s: rel-L2 %.3e max-abs %.3e" % (n, e, mx)
+        assert e <= 1.5e-3 or mx <= _atol(n), "%s: rel-L2 %.3e max-abs %.3e" % (n, e, mx)      # kink-limited: measured <= 3.9e-4
     flat_a = torch.cat([gsd[n].grad.cpu().reshape(-1) for n in names if not n.endswith(ZERO_GRAD_BIASES)])
     flat_b = torch.cat([g.reshape(-1) for n, g in zip(names, grads) if not n.endswith(ZERO_GRAD_BIASES)])
     cos = torch.dot(flat_a, flat_b) / (flat_a.norm() * flat_b.norm())
-    assert cos.item() >= 0.9995, cos.item()
+    assert cos.item() >= 0.99999, cos.item()
 
 
 # ---------------------------------------------------------------- one full train step (G8)
@@ -204,11 +205,11 @@ def test_train_step_golden(sp, tag, gan, use_gp, B, N):
     info = tr.step(x, real, z_d, z_g, alpha=alpha, keep_grads=True)
     np.testing.assert_allclose(info["loss_d"].item(), float(d["lossD"]), rtol=3e-3)
     np.testing.assert_allclose(info["loss_g"].item(), float(d["lossG"]), rtol=5e-3)
-    check(d, "fake_d", info["fake_d"], rtol=1e-3)
+    check(d, "fake_d", info["fake_d"], rtol=6e-5)                               # measured 1.8e-5 / 5.9e-6
     for n, g in info["d_grads"].items():
-        check(d, "dgrad|" + n, g, rtol=3e-2, atol=_atol(n))
+        check(d, "dgrad|" + n, g, rtol=4e-3, atol=_atol(n))                     # kink-limited end-to-end gradients: measured <= 1.2e-3
     for n, g in info["g_grads"].items():
-        check(d, "ggrad|" + n, g, rtol=1.5e-1, atol=_atol(n))   # after D's Adam step and through D's kinks
+        check(d, "ggrad|" + n, g, rtol=2.5e-2, atol=_atol(n))   # after D's Adam step and through D's kinks: measured <= 7.8e-3
     for n, p in D.named_parameters():
         if not n.endswith(ZERO_GRAD_BIASES):
             check(d, "dparam|" + n, p, rtol=1e-3, atol=2.5e-4)      # one Adam step moves an element by <= lr; sign noise => 2*lr
@@ -240,7 +241,7 @@ def test_eval_generation_and_interpolate_golden(sp, tag):
         else:
             out = G.interpolate(x, z1.clone(), z2.clone(), sel, alpha, use_latent=(tag == "interp_style"))
         logit = D(out)
-    check(d, tag + "|x1", sp.ops.pm_to_cm(G.last_x1, B, N), rtol=2e-5)          # tie-independent stage: tight
+    check(d, tag + "|x1", sp.ops.pm_to_cm(G.last_x1, B, N), rtol=3e-6)          # tie-independent stage: measured 8.0e-7
     i2 = sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).view(B, N, 10).cpu().numpy()
     same = (i2 == d[tag + "|idx2"]).all(axis=2)
     assert same.mean() >= 0.995, "EdgeConv2 kNN row agreement %.4f" % same.mean()
@@ -329,13 +330,13 @@ def _tie_aware_out(sp, G, d, tag, out, x, z, B, N, shapes_kw, salt, **fkw):
     i2 = sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).view(B, N, 10).cpu()
     same = np.array_equal(i2.numpy(), d[tag + "|idx2"]) and ((tag + "|idx1") not in d or np.array_equal(i1.numpy(), d[tag + "|idx1"]))
     if same:
-        check(d, tag + "|out", out, rtol=2e-4)
+        check(d, tag + "|out", out, rtol=6e-5)                                     # measured 2.4e-6 .. 1.9e-5
     agree = (i2.numpy() == d[tag + "|idx2"]).all(axis=2).mean()
     assert agree >= 0.99, agree
     p = fr.init_params(orc.generator_shapes(**shapes_kw), salt=salt)
     ref = orc.generator_forward(orc.eql_effective_params(p), x.cpu(), z.cpu(), training=True,
                                 buffers=orc.bn_buffers(orc.generator_shapes(**shapes_kw)), idx1=i1.view(B, -1), idx2=i2.view(B, -1), **fkw)
-    assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) <= 2e-4
+    assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) <= 6e-5     # measured <= 1.6e-5
     return same
 
 
@@ -354,7 +355,7 @@ def test_generator_use_head_golden(sp):
     (out * dy).sum().backward()
     if same:
         for n, p in G.named_parameters():
-            check(d, "head|grad|" + n, p.grad, rtol=3e-2, atol=_atol(n))
+            check(d, "head|grad|" + n, p.grad, rtol=1.5e-2, atol=_atol(n))            # whole-G gradients (kink-limited): measured <= 4.9e-3
 
 
 def test_generator_off_znorm_golden(sp):
@@ -379,11 +380,11 @@ def test_discriminator_small_d_golden(sp):
     D = _load(sp.Discriminator(OS), fr.init_params(orc.discriminator_shapes(small_d=True), salt=22)).train()
     real = fr.synthetic_real(4, N, seed=23).transpose(2, 1).contiguous().cuda().requires_grad_(True)
     logit = D(real)
-    check(d, "small|logit", logit, rtol=1e-4)
+    check(d, "small|logit", logit, rtol=3e-6)
     ((logit - 1.0) ** 2).mean().backward()
-    check(d, "small|dx", real.grad, rtol=3e-2)
+    check(d, "small|dx", real.grad, rtol=5e-6)
     for n, p in D.named_parameters():
-        check(d, "small|grad|" + n, p.grad, rtol=3e-2, atol=_atol(n))
+        check(d, "small|grad|" + n, p.grad, rtol=5e-6, atol=_atol(n))                # measured <= 7.3e-7
 
 
 @pytest.mark.parametrize("B,N,small", [(3, 300, False), (2, 200, True)])
@@ -411,7 +412,7 @@ def test_discriminator_ragged_n_vs_oracle(sp, B, N, small):
         g = torch.zeros_like(po[n]) if g is None else g
         mine = own[n].grad if own[n].grad is not None else torch.zeros_like(own[n])
         e = rel_l2(mine.cpu().numpy(), g.numpy())
-        assert e <= 3e-3 or (mine.cpu() - g).abs().max().item() <= (2e-3 if n.endswith(ZERO_GRAD_BIASES) else 2e-6), "%s %.3e" % (n, e)
+        assert e <= 6e-6 or (mine.cpu() - g).abs().max().item() <= (2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7), "%s %.3e" % (n, e)    # measured <= 1.5e-6
 
 
 # ---------------------------------------------------------------- --attn / --eql (G13)
@@ -437,7 +438,7 @@ def test_generator_attn_eql_golden(sp, tag, flags, salt):
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     ref = orc.generator_forward(orc.eql_effective_params(po), x.cpu(), z.cpu(), training=True, buffers=orc.bn_buffers(shapes), idx1=i1, idx2=i2)
     grads = dict(zip(po.keys(), torch.autograd.grad((ref * dy).sum(), list(po.values()))))
-    rtol = 6e-2 if tag == "both" else 3e-2
+    rtol = {"attn": 1e-4, "eql": 1.5e-3, "both": 1e-2}[tag]     # whole-G gradients, kink-limited: measured 2.4e-5 / 4.3e-4 / 3.0e-3
     for n, p in G.named_parameters():
         g = grads[n]
         plain = n.replace(".linear.", ".").replace(".conv.", ".")
