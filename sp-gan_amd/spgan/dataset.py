@@ -53,6 +53,23 @@ def load_points(source: Union[str, np.ndarray, Tensor], num_points: int) -> Tens
     raise ValueError("unsupported point source: %s" % source)
 
 
+def item_transform(points: Tensor, perm: Tensor, angle_y: Optional[Tensor] = None, scale: Optional[Tensor] = None) -> Tensor:
+    """The deterministic part of `H5DataLoader.__getitem__` (H5DataLoader.py:113-118) for a batch, given the random draws:
+    rows permuted (np.random.shuffle), then `pc @ Ry(angle)` (point_operation.py:215-230, y_rotated) and `pc * scale`
+    (point_operation.py:300-301).  points [B,P,3], perm int64 [B,P], angle_y / scale [B] or None (no augmentation).
+    Pinned by tests/golden/g16_data_path.npz (captured from the reference functions)."""
+    B = points.shape[0]
+    out = points[torch.arange(B, device=points.device)[:, None], perm]
+    if angle_y is not None:
+        c, s = torch.cos(angle_y), torch.sin(angle_y)
+        R = torch.zeros((B, 3, 3), device=points.device, dtype=points.dtype)
+        R[:, 0, 0] = c; R[:, 0, 2] = s; R[:, 1, 1] = 1.0; R[:, 2, 0] = -s; R[:, 2, 2] = c
+        out = torch.bmm(out, R)                                                # pc @ rotation_matrix
+    if scale is not None:
+        out = out * scale.view(B, 1, 1).to(points.dtype)
+    return out
+
+
 class DeviceDataset:
     """All shapes of a category in HBM, normalised as H5DataLoader.py:107 (`opts.scale * normalize_point_cloud(data)`).
     Iterating yields `len(self) // bs` batches [bs, np, 3] per epoch in a fresh random order (shuffle=True, drop_last=True),
@@ -82,17 +99,84 @@ class DeviceDataset:
         dev, g = self.device, self.gen
         B, P = index.numel(), self.num_points
         perm = torch.rand((B, P), generator=g, device=dev).argsort(dim=1)      # np.random.shuffle(point_set), per cloud
-        batch = self.data[index][torch.arange(B, device=dev)[:, None], perm]
+        angle = scale = None
         if self.augment:
-            ang = torch.rand((B,), generator=g, device=dev) * (2 * math.pi)    # rotate_point_cloud_and_gt: y_rotated=True -> Ry
-            c, s = torch.cos(ang), torch.sin(ang)
-            R = torch.zeros((B, 3, 3), device=dev)
-            R[:, 0, 0] = c; R[:, 0, 2] = s; R[:, 1, 1] = 1.0; R[:, 2, 0] = -s; R[:, 2, 2] = c
-            batch = torch.bmm(batch, R)                                        # pc @ rotation_matrix
-            batch = batch * (0.8 + 0.45 * torch.rand((B, 1, 1), generator=g, device=dev))   # random_scale_point_cloud_and_gt
-        return batch
+            angle = torch.rand((B,), generator=g, device=dev) * (2 * math.pi)  # rotate_point_cloud_and_gt: y_rotated=True -> Ry
+            scale = 0.8 + 0.45 * torch.rand((B,), generator=g, device=dev)     # random_scale_point_cloud_and_gt: U[0.8, 1.25]
+        return item_transform(self.data[index], perm, angle, scale)
 
     def __iter__(self) -> Iterator[Tensor]:
         order = torch.randperm(len(self), generator=self.gen, device=self.device)
         for b in range(self.num_batches):
             yield self.get_batch(order[b * self.batch_size:(b + 1) * self.batch_size])
+
+
+class HostStagedLoader:
+    """The classic staging path for a point set that shall NOT live in HBM ("pinned host buffers -> async H2D"):
+    the normalised set stays in pinned host memory; a batch is gathered / shuffled / augmented on the host (numpy, as the reference's
+    DataLoader workers do, H5DataLoader.py:113-118) straight into one of two pinned staging buffers and copied to the device on a
+    side stream while the previous batch is being consumed; the consumer's stream waits on the copy's event, never the host.
+    Same iteration contract as DeviceDataset (shuffle=True, drop_last=True); yields [bs, np, 3] device tensors that stay valid
+    until the batch after next is requested."""
+
+    def __init__(self, source, num_points: int = 2048, batch_size: int = 32, scale: float = 1.0, augment: bool = False,
+                 device="cuda", seed: Optional[int] = None):
+        pts = load_points(source, num_points)[:, :num_points, :3]
+        if pts.dim() != 3 or pts.shape[1] < num_points:
+            raise ValueError("need [S, >=%d, >=3] points, got %s" % (num_points, tuple(pts.shape)))
+        self.device = torch.device(device)
+        self.data = (scale * normalize_point_cloud(pts)).contiguous().numpy()
+        self.num_points, self.batch_size, self.augment = num_points, batch_size, augment
+        self.rng = np.random.default_rng(seed)
+        cuda = self.device.type == "cuda"
+        self._host = [torch.empty((batch_size, num_points, 3), dtype=torch.float32, pin_memory=cuda) for _ in range(2)]
+        self._dev = [torch.empty((batch_size, num_points, 3), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._copy = torch.cuda.Stream(device=self.device) if cuda else None
+        self._done = [None, None]         # event: H2D copy into slot i finished
+        self._free = [None, None]         # event: the consumer no longer reads _dev[i]
+
+    def __len__(self) -> int:
+        return self.data.shape[0]
+
+    @property
+    def num_batches(self) -> int:
+        return len(self) // self.batch_size
+
+    def _stage(self, slot: int, index: np.ndarray) -> None:
+        B, P = self.batch_size, self.num_points
+        perm = self.rng.random((B, P)).argsort(axis=1)
+        angle = scale = None
+        if self.augment:
+            angle = torch.from_numpy(self.rng.random(B) * (2 * math.pi))
+            scale = torch.from_numpy(0.8 + 0.45 * self.rng.random(B))
+        out = item_transform(torch.from_numpy(self.data[index]), torch.from_numpy(perm),
+                             None if angle is None else angle.float(), None if scale is None else scale.float())
+        self._host[slot].copy_(out)
+        if self._copy is None:
+            self._dev[slot].copy_(self._host[slot])
+            return
+        if self._free[slot] is not None:
+            self._copy.wait_event(self._free[slot])                            # the batch last handed out from this slot was consumed
+        with torch.cuda.stream(self._copy):
+            self._dev[slot].copy_(self._host[slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy)
+        self._done[slot] = ev
+
+    def __iter__(self) -> Iterator[Tensor]:
+        order = self.rng.permutation(len(self))
+        nb, bs = self.num_batches, self.batch_size
+        if nb == 0:
+            return
+        self._stage(0, order[:bs])
+        for b in range(nb):
+            slot = b & 1
+            if b + 1 < nb:
+                self._stage(slot ^ 1, order[(b + 1) * bs:(b + 2) * bs])        # next batch: host work + H2D overlap the consumer
+            if self._copy is not None:
+                torch.cuda.current_stream().wait_event(self._done[slot])
+            yield self._dev[slot]
+            if self._copy is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._free[slot] = ev

@@ -629,8 +629,41 @@ def g15():
     save("g15_samplers.npz", d)
 
 
+def g16():
+    """The per-item data path of Generation/H5DataLoader.py:107,113-118 over Generation/point_operation.py:144-163,207-235,292-307:
+    set normalisation, row shuffle, rotation about the up axis, random scale -- run with numpy's global RNG seeded, with the
+    random draws it consumed recorded next to the outputs (the draws are inputs of the deterministic transforms)."""
+    PO = extract_functions(os.path.join(REF, "Generation/point_operation.py"),
+                           ["normalize_point_cloud", "rotate_point_cloud_and_gt", "random_scale_point_cloud_and_gt"], dict(np=np))
+    d = {}
+    raw = (fr.normal("g16.raw", (5, 300, 3)) * fr.uniform("g16.s", (5, 1, 3), 0.5, 3.0) + fr.normal("g16.c", (5, 1, 3)) * 2.0).numpy().astype(np.float32)
+    d["raw"] = raw
+    data = 0.9 * PO.normalize_point_cloud(raw)                         # H5DataLoader.py:107 with opts.scale = 0.9
+    d["normalized"] = data.astype(np.float32)
+    raw6 = np.concatenate([raw[:2], fr.normal("g16.nor", (2, 300, 3)).numpy()], axis=-1)
+    d["raw6"] = raw6; d["normalized6"] = PO.normalize_point_cloud(raw6).astype(np.float32)
+    num_points = 256
+    items, perms, angles, scales = [], [], [], []
+    for index in range(5):
+        np.random.seed(1000 + index)
+        point_set = data[index][:num_points, :3].copy()               # __getitem__, augment=True
+        np.random.shuffle(point_set)
+        point_set = PO.rotate_point_cloud_and_gt(point_set)
+        point_set = PO.random_scale_point_cloud_and_gt(point_set)
+        items.append(point_set.astype(np.float32))
+        np.random.seed(1000 + index)                                  # replay the same stream to learn the draws
+        perm = np.arange(num_points); np.random.shuffle(perm)
+        ang = np.random.uniform(size=(3)) * 2 * np.pi
+        sc = np.random.uniform(0.8, 1.25, 1)
+        perms.append(perm); angles.append(ang[1]); scales.append(sc[0])
+        assert np.array_equal(data[index][:num_points][perm], (lambda a: (np.random.seed(1000 + index), np.random.shuffle(a), a)[2])(data[index][:num_points].copy()))
+    d["items"] = np.stack(items); d["perm"] = np.stack(perms).astype(np.int64)
+    d["angle_y"] = np.array(angles, dtype=np.float64); d["scale"] = np.array(scales, dtype=np.float64)
+    save("g16_data_path.npz", d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for name in which:
         globals()[name]()

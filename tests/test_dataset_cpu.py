@@ -52,3 +52,43 @@ def test_augment_is_rotation_about_y_and_scale():
     assert torch.allclose(r_aug, r_plain * scale[:, None], rtol=1e-4)                   # one scale per cloud ...
     assert (scale > 0.8 - 1e-4).all() and (scale < 1.25 + 1e-4).all() and scale.std() > 0.01
     assert torch.allclose(aug[..., 1], plain[..., 1] * scale[:, None], rtol=1e-4, atol=1e-6)   # ... and y only scaled: rotation about y
+
+
+def test_data_path_matches_reference_golden():
+    """G16 (tests/golden/make_golden.py::g16: the reference's normalize_point_cloud / rotate_point_cloud_and_gt /
+    random_scale_point_cloud_and_gt and H5DataLoader.__getitem__'s call order, numpy RNG seeded, its draws recorded): the set
+    normalisation and the per-item transform given the same draws."""
+    from helpers import golden
+    d = golden("g16_data_path.npz")
+    norm = 0.9 * dataset.normalize_point_cloud(torch.from_numpy(d["raw"]))
+    np.testing.assert_allclose(norm.numpy(), d["normalized"], rtol=0, atol=3e-7)
+    n6 = dataset.normalize_point_cloud(torch.from_numpy(d["raw6"]))
+    np.testing.assert_allclose(n6.numpy(), d["normalized6"], rtol=0, atol=3e-7)     # extra channels pass through
+    assert np.array_equal(n6.numpy()[..., 3:], d["raw6"][..., 3:])
+    pts = torch.from_numpy(d["normalized"])[:, :256]
+    out = dataset.item_transform(pts, torch.from_numpy(d["perm"]), torch.from_numpy(d["angle_y"]).float(), torch.from_numpy(d["scale"]).float())
+    np.testing.assert_allclose(out.numpy(), d["items"], rtol=0, atol=5e-7)           # float32 here, float64 rotation in the reference
+    out64 = dataset.item_transform(pts.double(), torch.from_numpy(d["perm"]), torch.from_numpy(d["angle_y"]), torch.from_numpy(d["scale"]))
+    np.testing.assert_allclose(out64.numpy(), d["items"], rtol=0, atol=1.2e-7)       # float64 maths: only the final float32 rounding differs
+    plain = dataset.item_transform(pts, torch.from_numpy(d["perm"]))
+    assert torch.equal(plain[2], pts[2][torch.from_numpy(d["perm"][2])])
+
+
+def test_host_staged_loader_semantics():
+    """HostStagedLoader (pinned staging + side-stream H2D on the GPU; here on the CPU device): same epoch contract as DeviceDataset."""
+    raw = _raw()
+    ld = dataset.HostStagedLoader(raw, num_points=64, batch_size=8, device="cpu", seed=5)
+    assert len(ld) == 37 and ld.num_batches == 4
+    norm = dataset.normalize_point_cloud(torch.from_numpy(raw)[:, :64])
+    seen = []
+    for b in ld:
+        assert b.shape == (8, 64, 3)
+        for cloud in b.clone():
+            hit = [i for i in range(37) if torch.allclose(torch.sort(cloud[:, 0])[0], torch.sort(norm[i][:, 0])[0], atol=1e-6)]
+            assert len(hit) == 1
+            seen.append(hit[0])
+    assert len(set(seen)) == 32                                                       # 4 batches x 8 distinct shapes, drop_last
+    aug = dataset.HostStagedLoader(raw, num_points=64, batch_size=8, augment=True, device="cpu", seed=6)
+    b = next(iter(aug))
+    r = b.norm(dim=-1).amax(dim=1)
+    assert float(r.min()) >= 0.8 - 1e-5 and float(r.max()) <= 1.25 + 1e-5             # unit-radius clouds scaled by U[0.8, 1.25]

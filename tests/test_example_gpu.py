@@ -29,3 +29,27 @@ def test_train_example(tmp_path):
     assert int(G.global_conv[1].num_batches_tracked) == 2 * 16 + 0      # two G forwards per step, 16 steps
     pts = open(os.path.join(out, "sample", "0.xyz")).read().split("\n")
     assert len([l for l in pts if l.strip()]) == 256
+
+
+def test_host_staged_loader_on_gpu():
+    """Pinned staging buffers + H2D on a side stream: every batch arrives intact although the next one is being staged and copied
+    while it is consumed (two slots, event hand-over in both directions)."""
+    import numpy as np
+    import torch
+    from spgan import dataset, fixture_rng as fr
+    raw = fr.synthetic_real(70, 512, seed=9).numpy() * 2.0 + 1.0
+    ld = dataset.HostStagedLoader(raw, num_points=512, batch_size=16, device="cuda", seed=1)
+    ref = dataset.normalize_point_cloud(torch.from_numpy(raw)).cuda()
+    keys = torch.sort(ref[:, :, 0], dim=1)[0]                                   # [S,P] fingerprint of every source cloud
+    count = 0
+    acc = torch.zeros((), device="cuda")
+    for ep in range(2):
+        for b in ld:
+            assert b.is_cuda and b.shape == (16, 512, 3)
+            acc = acc + (b @ torch.randn(3, 64, device="cuda")).sum() * 0          # consumer work on the current stream
+            fp = torch.sort(b[:, :, 0], dim=1)[0]
+            dist = torch.cdist(fp, keys)
+            assert float(dist.min(dim=1)[0].max()) < 1e-5, "a batch does not consist of (permuted) source clouds"
+            count += 1
+    torch.cuda.synchronize()
+    assert count == 2 * (70 // 16)
