@@ -6,8 +6,8 @@ an epoch is a device-side permutation, a batch is a gather, and the per-item wor
 rotation about the up axis and random scale: H5DataLoader.py:113-118, point_operation.py:207-308) runs on the device for the
 whole batch.  No worker processes, no pinned staging, no PCIe traffic per step.
 
-Sources: a numpy array / torch tensor [S, P, >=3], an `.npy` / `.npz` file, or (when h5py is importable -- it is not in this
-image) the reference's `<data_root>/<np>/<choice>.h5` with its `poisson_<np>` dataset.
+Sources: a numpy array / torch tensor [S, P, >=3], an `.npy` / `.npz` file, or the reference's `<data_root>/<np>/<choice>.h5` with
+its `poisson_<np>` dataset -- through h5py when it is importable, otherwise through the built-in reader spgan.h5lite.
 """
 from __future__ import annotations
 
@@ -44,12 +44,14 @@ def load_points(source: Union[str, np.ndarray, Tensor], num_points: int) -> Tens
         key = "poisson_%d" % num_points if "poisson_%d" % num_points in z.files else z.files[0]
         return torch.from_numpy(z[key].astype(np.float32))
     if ext in (".h5", ".hdf5"):
+        key = "poisson_%d" % num_points                                      # H5DataLoader.py:14-17: f['poisson_%d' % num_points][:]
         try:
             import h5py
-        except ImportError as e:                                            # pragma: no cover (h5py is absent in the build image)
-            raise RuntimeError("reading %s needs h5py (H5DataLoader.py:14-17); convert it to .npy/.npz or install h5py" % source) from e
+        except ImportError:                                                  # h5py is absent in the build image: the built-in reader
+            from . import h5lite
+            return torch.from_numpy(np.ascontiguousarray(h5lite.read(source, key), dtype=np.float32))
         with h5py.File(source, "r") as f:
-            return torch.from_numpy(f["poisson_%d" % num_points][:].astype(np.float32))
+            return torch.from_numpy(f[key][:].astype(np.float32))
     raise ValueError("unsupported point source: %s" % source)
 
 
