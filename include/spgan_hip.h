@@ -395,6 +395,8 @@ typedef struct spgan_multi_add_args {
   int n[SPGAN_MULTI_MAX];
 } spgan_multi_add_args;
 int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s);
+/* dst[t][i] = src[t][i] for the same argument block: up to SPGAN_MULTI_MAX device-to-device copies in ONE launch. */
+int spgan_multi_copy(const spgan_multi_add_args* a, spgan_stream_t s);
 /* Finish up to SPGAN_MULTI_MAX deferred spgan_gemm_tn products in one launch: C[e] = beta[e]*C[e] + fixed-order sum of the
  * splits[e] = spgan_gemm_tn_splits(M,Na,Nb) partials [splits, Na, Nb] in ws[e].  block_start[e] = sum_{f<e}
  * spgan_splitk_reduce_blocks(splits[f], Na[f], Nb[f]) (64 outputs per workgroup, or 4 -- one wave each -- for many partials of few outputs). */

@@ -555,6 +555,29 @@ __global__ void multi_add_kernel(const spgan_multi_add_args a) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] += s[i];
 }
 
+// dst[t][i] = src[t][i]: the same argument block, assignment instead of accumulation (a train step's input tensors copied into the
+// static buffers of its captured graph with one launch instead of one memcpy per tensor)
+__global__ void multi_copy_kernel(const spgan_multi_add_args a) {
+  const int t = blockIdx.y;
+  const int n = a.n[t];
+  float* __restrict__ d = a.dst[t];
+  const float* __restrict__ s = a.src[t];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+extern "C" int spgan_multi_copy(const spgan_multi_add_args* a, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && a->count > 0 && a->count <= SPGAN_MULTI_MAX);
+  int nmax = 0;
+  for (int t = 0; t < a->count; ++t) {
+    SPGAN_CHECK_ARG(a->dst[t] && a->src[t] && a->n[t] > 0);
+    nmax = a->n[t] > nmax ? a->n[t] : nmax;
+  }
+  int bx = cdiv(nmax, 256 * 4);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, a->count), dim3(256), 0, (hipStream_t)s_, *a);
+  return spgan_launch_status();
+}
+
 extern "C" int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a && a->count > 0 && a->count <= SPGAN_MULTI_MAX);
   int nmax = 0;

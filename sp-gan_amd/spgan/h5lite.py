@@ -15,9 +15,8 @@ The layout follows "HDF5 File Format Specification Version 3.0".  Checked in tes
 real HDF5 library (tests/golden/make_h5_fixtures.py drives libhdf5 1.10.6 through ctypes)."""
 from __future__ import annotations
 
-import struct
 import zlib
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Tuple
 
 import numpy as np
 
@@ -29,7 +28,7 @@ class H5Error(RuntimeError):
 
 
 class File:
-    """`File(path)[name]` -> numpy array; `keys()` lists the root group; `File(path).visit()` yields every dataset path."""
+    """`File(path)[name]` -> numpy array (name may be a path "group/dataset"); `keys(group="/")` lists a group; `name in file`."""
 
     def __init__(self, path: str):
         with open(path, "rb") as f:

@@ -1173,6 +1173,24 @@ def multi_add(dsts, srcs) -> None:
         check(lib.spgan_multi_add(C.byref(a), _s()), "multi_add", count=len(chunk))
 
 
+def multi_copy(dsts, srcs) -> None:
+    """dst[t].copy_(src[t]) for a list of contiguous fp32 GPU tensor pairs of equal size in ceil(T/64) launches."""
+    from ._lib import MULTI_MAX, MultiAddArgs
+    lib = _lib.load()
+    pairs = [(d, s) for d, s in zip(dsts, srcs)]
+    for i0 in range(0, len(pairs), MULTI_MAX):
+        chunk = pairs[i0:i0 + MULTI_MAX]
+        a = MultiAddArgs()
+        a.count = len(chunk)
+        for t, (d, s) in enumerate(chunk):
+            if not (d.is_contiguous() and s.is_contiguous()) or d.numel() != s.numel() or d.dtype != torch.float32 or s.dtype != torch.float32:
+                raise ValueError("multi_copy: pair %d is not a contiguous fp32 pair of equal size" % (i0 + t))
+            if not (d.is_cuda and s.is_cuda):
+                raise RuntimeError("multi_copy needs GPU tensors")
+            a.dst[t] = d.data_ptr(); a.src[t] = s.data_ptr(); a.n[t] = d.numel()
+        check(lib.spgan_multi_copy(C.byref(a), _s()), "multi_copy", count=len(chunk))
+
+
 def axpby(a: float, x: Tensor, b: float, y: Tensor) -> Tensor:
     """y = a*x + b*y in place (contiguous fp32)."""
     if not (x.is_contiguous() and y.is_contiguous()) or x.numel() != y.numel():

@@ -86,6 +86,7 @@ class TrainStep:
             self._x_src = (weakref.ref(tensors[0]), tensors[0]._version)
             return False
         x_changed = False
+        pend_d, pend_s = [], []
         for i, t in enumerate(tensors):
             st = self._static[i]
             if t is None or st is None:
@@ -106,7 +107,12 @@ class TrainStep:
                 if self._graph is None or x_changed:
                     st.copy_(t)
                 continue
-            st.copy_(t)
+            if t.is_cuda and t.is_contiguous() and t.dtype == torch.float32:
+                pend_d.append(st); pend_s.append(t)                              # one launch for all of them (below)
+            else:
+                st.copy_(t)
+        if pend_d:
+            ops.multi_copy(pend_d, pend_s)
         return x_changed
 
     def _graph_step(self, x, real, z_d, z_g, alpha):

@@ -485,6 +485,11 @@ def tanh_bwd(dy, y):
     return (dy * (1 - y * y)).contiguous()
 
 
+def multi_copy(dsts, srcs):
+    for d, s in zip(dsts, srcs):
+        d.copy_(s)
+
+
 def axpby(a, x, b, y):
     y.copy_(a * x + (b * y if b != 0 else 0))
     return y

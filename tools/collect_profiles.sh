@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the measurement artefacts of a round on the GPU box into gpurun_out/ (copy what shall be judged to profiles/).
+# usage (through gpurun): bash tools/collect_profiles.sh r02
+set -u
+TAG=${1:-rXX}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+python $R/bench.py --mfma f16 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_f16_operands.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --mfma bf16x3 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_bf16x3.json 2>> $O/${TAG}_bench.err
+rm -rf /tmp/prof_s; rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/bench_s.log 2>&1
+DB=$(find /tmp/prof_s -name "*.db" | head -1)
+python $R/tools/rocprof_summary.py $DB 32 > $O/${TAG}_bench_kernel_stats.txt      # 4 priming + 3 warm-up + 20 timed + 4 eager accounting steps + the keep-busy launches
+python $R/tools/gap_analysis.py $DB 0.35 0.7 > $O/${TAG}_bench_graph_replay_window.txt
+python $R/tools/step_sequence.py $DB -8 > $O/${TAG}_step_sequence.txt
+for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do rm -rf /tmp/p_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/p_$c -o r -- python $R/tools/pmc_step.py > /tmp/log_$c 2>&1; done
+python $R/tools/pmc_step_total.py $(find /tmp/p_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/p_WRITE_SIZE -name "*.db" | head -1) $(find /tmp/p_MfmaUtil -name "*.db" | head -1) > $O/${TAG}_pmc_step.json
+for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/g_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/g_$c -o r -- python $R/tools/pmc_gemm.py > /tmp/glog_$c 2>&1; python $R/tools/pmc_summary.py $(find /tmp/g_$c -name "*.db" | head -1) gemm_nt > $O/${TAG}_pmc_gemm_$c.txt; done
+python $R/tools/mfma_shapes.py > $O/${TAG}_mfma_shapes.txt 2>/dev/null
+echo collected; ls -la $O | tail -20
