@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void colpartials_kernel(const float* __restric
 
 // Combine per-tile partials over the tiles of each group.  block = 32 slices x 8 columns (one 64-byte
 // segment of the partial row per slice); slices are merged through LDS in a fixed tree order.
-constexpr int FS = 32, FC = 8;
+// <FS, FC> = <32, 8> by default; <128, 2> when a group has thousands of tiles (the per-edge GEMMs: 5120 records per column): four
+// times the workgroups and a quarter of the serial record loop per thread (27 -> ~10 us at 5120 x 128).
+// (the geometry is a template parameter of colfinalize_t_kernel; launch_colfinalize picks it)
 
 __device__ __forceinline__ void chan_merge(float& n, float& a, float& b, float n2, float a2, float b2) {
   const float nn = n + n2;
@@ -91,8 +93,10 @@ struct BnTail {
   int count_rep;                        // the rows stand for count_rep identical copies (unbiased-variance count of the running statistics)
 };
 
-__global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restrict__ part, int tiles_per_group, int C, int G, int mode,
-                                                          int tile_rows, float* __restrict__ out0, float* __restrict__ out1, const BnTail bn) {
+template <int FS, int FC>
+__global__ __launch_bounds__(256) void colfinalize_t_kernel(const float* __restrict__ part, int tiles_per_group, int C, int G, int mode,
+                                                            int tile_rows, float* __restrict__ out0, float* __restrict__ out1, const BnTail bn) {
+  static_assert(FS * FC == 256, "one thread per (slice, column)");
   __shared__ float sn[FS][FC], sa[FS][FC], sb[FS][FC];
   const int g = blockIdx.y;
   const int cl = threadIdx.x & (FC - 1), sl = threadIdx.x / FC;
@@ -178,6 +182,14 @@ __global__ __launch_bounds__(256) void colfinalize_kernel(const float* __restric
       bn.mean_out[c] = a;
     }
   }
+}
+
+inline void launch_colfinalize(hipStream_t s, const float* part, int groups, int tiles_per_group, int C, int G, int mode, int tile_rows,
+                               float* out0, float* out1, const BnTail& bn) {
+  if (tiles_per_group >= 2048)
+    hipLaunchKernelGGL((colfinalize_t_kernel<128, 2>), dim3(cdiv(C, 2), groups), dim3(256), 0, s, part, tiles_per_group, C, G, mode, tile_rows, out0, out1, bn);
+  else
+    hipLaunchKernelGGL((colfinalize_t_kernel<32, 8>), dim3(cdiv(C, 8), groups), dim3(256), 0, s, part, tiles_per_group, C, G, mode, tile_rows, out0, out1, bn);
 }
 
 __global__ void bn_prepare_kernel(const float* mean, const float* var, const float* gamma, const float* beta, int C, int count,
@@ -289,15 +301,19 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
   }
 }
 
-// float4 variant: 16 lanes x 16 B cover 64 channels of a row, 16 row-slices per workgroup.
+// float4 variant: LQ lanes x 16 B cover LQ*4 channels of a row, 256/LQ row-slices per workgroup.  LQ = 16 (64 channels per workgroup)
+// when shapes x channel blocks already fill the chip; LQ = 4 (16 channels, 64 row-slices: 4x the workgroups, a quarter of the serial
+// row loop) for the generator's global feature (B x 128 channels: 64 workgroups of 2048 rows each were latency-bound at 33 us).
+template <int LQ>
 __global__ __launch_bounds__(256) void maxpool_v4_kernel(const float* __restrict__ y, int ld, int N, int C, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float slope, float* __restrict__ out,
                                                          int32_t* __restrict__ argmax) {
-  __shared__ float rv[16][64];
-  __shared__ int ri[16][64];
+  constexpr int SLN = 256 / LQ, CW = LQ * 4;
+  __shared__ float rv[SLN][CW];
+  __shared__ int ri[SLN][CW];
   const int b = blockIdx.x;
-  const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.y * 64 + q * 4;
+  const int q = threadIdx.x % LQ, sl = threadIdx.x / LQ;
+  const int c = blockIdx.y * CW + q * 4;
   const bool cok = c < C;  // C % 4 == 0
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cok && scale) { sc = *reinterpret_cast<const float4*>(scale + c); sh = *reinterpret_cast<const float4*>(shift + c); }
@@ -314,24 +330,24 @@ __global__ __launch_bounds__(256) void maxpool_v4_kernel(const float* __restrict
       if (t3 > best[3]) { best[3] = t3; bi[3] = n; }
     };
     int n = sl;
-    for (; n + 7 * 16 < N; n += 8 * 16) {  // eight rows in flight, consumed in row order (strict '>' keeps the first maximum)
+    for (; n + 7 * SLN < N; n += 8 * SLN) {  // eight rows in flight, consumed in row order (strict '>' keeps the first maximum)
       float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (size_t)(n + 16 * u) * ld);
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (size_t)(n + SLN * u) * ld);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) take(v[u], n + 16 * u);
+      for (int u = 0; u < 8; ++u) take(v[u], n + SLN * u);
     }
-    for (; n < N; n += 16) take(*reinterpret_cast<const float4*>(base + (size_t)n * ld), n);
+    for (; n < N; n += SLN) take(*reinterpret_cast<const float4*>(base + (size_t)n * ld), n);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { rv[sl][q * 4 + j] = best[j]; ri[sl][q * 4 + j] = bi[j]; }
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const int cc = blockIdx.y * 64 + threadIdx.x;
+  if (threadIdx.x < CW) {
+    const int cc = blockIdx.y * CW + threadIdx.x;
     if (cc < C) {
       float bv = rv[0][threadIdx.x];
       int bn = ri[0][threadIdx.x];
-      for (int s2 = 1; s2 < 16; ++s2) {
+      for (int s2 = 1; s2 < SLN; ++s2) {
         const float v = rv[s2][threadIdx.x];
         const int i2 = ri[s2][threadIdx.x];
         if (v > bv || (v == bv && i2 < bn)) { bv = v; bn = i2; }
@@ -371,7 +387,7 @@ __global__ void pool_finalize_kernel(const float* __restrict__ pv, const int32_t
 extern "C" int spgan_pool_finalize(const float* pool_val, const int32_t* pool_arg, int B, int rows, int C, const float* scale, const float* shift,
                                    float slope, float* pooled, int32_t* argmax, float* yarg, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(pool_val && pool_arg && scale && shift && pooled && argmax && B > 0 && rows > 0 && C > 0 && rows % 128 == 0 && slope > 0.f);
-  hipLaunchKernelGGL(pool_finalize_kernel, dim3(cdiv(C, 128), B), dim3(128), 0, (hipStream_t)s_, pool_val, pool_arg, B, rows / 128, C, scale, shift,
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3(cdiv(C, 64), B), dim3(64), 0, (hipStream_t)s_, pool_val, pool_arg, B, rows / 128, C, scale, shift,
                      slope, rows, pooled, argmax, yarg);
   return spgan_launch_status();
 }
@@ -388,7 +404,7 @@ extern "C" int spgan_colstats_finalize(const float* partials, int groups, int ti
   if (tile_rows <= 0) tile_rows = RT;
   SPGAN_CHECK_ARG(partials && out0 && out1 && groups > 0 && tiles_per_group > 0 && C > 0 && G > 0 && (mode == 0 || mode == 1));
   SPGAN_CHECK_ARG(tiles_per_group == cdiv(G, tile_rows));
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, partials, tiles_per_group, C, G, mode, tile_rows, out0, out1, BnTail{});
+  launch_colfinalize(s, partials, groups, tiles_per_group, C, G, mode, tile_rows, out0, out1, BnTail{});
   return spgan_launch_status();
 }
 
@@ -402,7 +418,7 @@ extern "C" int spgan_colstats_finalize_bn(const float* partials, int tiles, int 
   SPGAN_CHECK_ARG(partials && scale && shift && invstd && mean_out && tiles > 0 && C > 0 && G > 0 && tiles == cdiv(G, tile_rows));
   SPGAN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   BnTail bn{gamma, beta, running_mean, running_var, scale, shift, invstd, mean_out, eps, momentum, 0, nullptr, nullptr, nullptr, nullptr, 1};
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), 1), dim3(256), 0, s, partials, tiles, C, G, 0, tile_rows, (float*)nullptr,
+  launch_colfinalize(s, partials, 1, tiles, C, G, 0, tile_rows, (float*)nullptr,
                      (float*)nullptr, bn);
   return spgan_launch_status();
 }
@@ -419,7 +435,7 @@ extern "C" int spgan_colstats_finalize_bn2(const float* partials, int tiles, int
   SPGAN_CHECK_ARG((rmeanA == nullptr) == (rvarA == nullptr) && (rmeanB == nullptr) == (rvarB == nullptr));
   BnTail bn{gammaA, betaA, rmeanA, rvarA, out4, out4 + C, out4 + 2 * (size_t)C, out4 + 3 * (size_t)C, eps, momentum,
             split, gammaB, betaB, rmeanB, rvarB, count_rep};
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), 1), dim3(256), 0, s, partials, tiles, C, G, 0, tile_rows, (float*)nullptr,
+  launch_colfinalize(s, partials, 1, tiles, C, G, 0, tile_rows, (float*)nullptr,
                      (float*)nullptr, bn);
   return spgan_launch_status();
 }
@@ -435,7 +451,7 @@ extern "C" int spgan_colstats(const float* X, int ldx, int M, int C, int G, floa
     return spgan_launch_status();
   }
   hipLaunchKernelGGL((colpartials_kernel<0>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, slope, ws, (float*)nullptr, (float*)nullptr);
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, ws, tpg, C, G, 0, RT, out_mean, out_var, BnTail{});
+  launch_colfinalize(s, ws, groups, tpg, C, G, 0, RT, out_mean, out_var, BnTail{});
   return spgan_launch_status();
 }
 
@@ -451,7 +467,7 @@ extern "C" int spgan_colsum(const float* X, int ldx, int M, int C, int G, float*
     return spgan_launch_status();
   }
   hipLaunchKernelGGL((colpartials_kernel<1>), dim3(groups * tpg, cdiv(C, 64)), dim3(256), 0, s, X, ldx, C, G, tpg, 1.0f, ws, (float*)nullptr, (float*)nullptr);
-  hipLaunchKernelGGL(colfinalize_kernel, dim3(cdiv(C, FC), groups), dim3(256), 0, s, ws, tpg, C, G, 1, RT, out, scratch, BnTail{});
+  launch_colfinalize(s, ws, groups, tpg, C, G, 1, RT, out, scratch, BnTail{});
   return spgan_launch_status();
 }
 
@@ -502,7 +518,9 @@ extern "C" int spgan_maxpool(const float* y, int ld, int B, int N, int C, const 
   SPGAN_CHECK_ARG(y && out && B > 0 && N > 0 && C > 0 && ld >= C);
   const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
                   (!scale || (((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0));
-  if (v4) hipLaunchKernelGGL(maxpool_v4_kernel, dim3(B, cdiv(C, 64)), dim3(256), 0, s, y, ld, N, C, scale, shift, slope, out, argmax);
+  if (v4 && (long)B * cdiv(C, 64) < 512 && N >= 512)
+    hipLaunchKernelGGL(maxpool_v4_kernel<4>, dim3(B, cdiv(C, 16)), dim3(256), 0, s, y, ld, N, C, scale, shift, slope, out, argmax);
+  else if (v4) hipLaunchKernelGGL(maxpool_v4_kernel<16>, dim3(B, cdiv(C, 64)), dim3(256), 0, s, y, ld, N, C, scale, shift, slope, out, argmax);
   else hipLaunchKernelGGL(maxpool_kernel, dim3(B, cdiv(C, 64)), dim3(256), 0, s, y, ld, N, C, scale, shift, slope, out, argmax);
   return spgan_launch_status();
 }

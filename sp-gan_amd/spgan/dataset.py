@@ -153,6 +153,8 @@ class HostStagedLoader:
             scale = torch.from_numpy(0.8 + 0.45 * self.rng.random(B))
         out = item_transform(torch.from_numpy(self.data[index]), torch.from_numpy(perm),
                              None if angle is None else angle.float(), None if scale is None else scale.float())
+        if self._done[slot] is not None:
+            self._done[slot].synchronize()                                     # the DMA that last read this pinned buffer has finished (host-side wait; two batches old)
         self._host[slot].copy_(out)
         if self._copy is None:
             self._dev[slot].copy_(self._host[slot])
