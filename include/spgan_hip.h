@@ -307,6 +307,11 @@ int spgan_adain_bwd2(const float* dout, const float* x, int M, int C, int N, flo
  * ---------------------------------------------------------------------------------------- */
 int spgan_pool_bwd_stats(const float* gpool, const float* pooled, const int32_t* argmax, const float* y, int ld, const float* mean,
                          const float* invstd, float slope, int B, int C, float* gval, float* sums /*[2C]*/, spgan_stream_t s);
+/* spgan_pool_bwd_stats followed by spgan_sparse_bn_prep (the coefficients alpha, beta [C] and cg [B,C] of the lazily evaluated BatchNorm
+ * backward behind the max-pool) in ONE launch: both are per-channel work on the same [B,C] values. */
+int spgan_pool_bwd_stats_prep(const float* gpool, const float* pooled, const int32_t* argmax, const float* y, int ld, const float* mean,
+                              const float* invstd, float slope, int B, int C, const float* gamma, int count, float* gval, float* sums /*[2C]*/,
+                              float* alpha, float* beta, float* cg, spgan_stream_t s);
 int spgan_bn_bwd_apply_sparse(const float* gval, const int32_t* argmax, const float* y, int ld, int M, int C, int N,
                               const float* mean, const float* invstd, const float* gamma, const float* sums, int count, float* dy,
                               spgan_stream_t s);

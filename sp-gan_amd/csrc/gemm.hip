@@ -1007,6 +1007,7 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_
           else if (p.act == SPGAN_ACT_TANH) o = tanhf(o);
         } else if (EPI == SPGAN_EPI_MASK_OUT) {
           o = acc * lrelu_mask(p.ref[(size_t)row * p.ld_ref + col], p.b_slope);
+          c0 = o;  // column sums of the masked product (the bias gradient of the layer below), when statistics are asked for
         } else {  // BNBWD
           const float y = p.ref[(size_t)row * p.ld_ref + col];
           const float z = fmaf(y, p.b_scale[col], p.b_shift[col]);
@@ -1654,7 +1655,8 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
                     a->batch <= 65535 && a->batch_stride_a >= 0 && a->batch_stride_w >= 0 && a->batch_stride_y > 0);
   if (a->fin.enabled) {
     const spgan_fanin& f = a->fin;
-    SPGAN_CHECK_ARG(a->stats && a->epi_mode != SPGAN_EPI_MASK_OUT && (f.mode == 0 || f.mode == 1));
+    SPGAN_CHECK_ARG(a->stats && (f.mode == 0 || f.mode == 1));
+    if (a->epi_mode == SPGAN_EPI_MASK_OUT) SPGAN_CHECK_ARG(a->M <= 64 && f.mode == 1);  // column sums of a masked product: the per-shape linears only
     if (f.mode == 1) SPGAN_CHECK_ARG(f.out0 && f.out1);
     if (f.scale) SPGAN_CHECK_ARG(f.mode == 0 && f.shift && f.invstd && f.mean_out && (!f.rmean || f.rvar));
     SPGAN_CHECK_ARG(f.counters && (fanin::group_count(cdiv(a->M, BM)) == 1 || f.group_part));  // the M <= 64 kernel does not use them

@@ -78,7 +78,9 @@ __global__ void adain_bwd2_kernel(const float* __restrict__ dout, const float* _
 __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __restrict__ gpool, const float* __restrict__ pooled,
                                                              const int32_t* __restrict__ argmax, const float* __restrict__ y, int ld,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd, float slope, int B,
-                                                             int C, float* __restrict__ gval, float* __restrict__ sums) {
+                                                             int C, float* __restrict__ gval, float* __restrict__ sums,
+                                                             const float* __restrict__ gamma = nullptr, float rM = 0.f, float* __restrict__ alpha = nullptr,
+                                                             float* __restrict__ beta = nullptr, float* __restrict__ cg = nullptr) {
   __shared__ float r0[4][64], r1[4][64];
   const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -97,9 +99,21 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __rest
   r0[bl][cl] = s0;
   r1[bl][cl] = s1;
   __syncthreads();
-  if (bl == 0 && c < C) {
-    sums[c] = (r0[0][cl] + r0[1][cl]) + (r0[2][cl] + r0[3][cl]);
-    sums[C + c] = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
+  if (c >= C) return;
+  const float t0 = (r0[0][cl] + r0[1][cl]) + (r0[2][cl] + r0[3][cl]);
+  const float t1 = (r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]);
+  if (bl == 0) {
+    sums[c] = t0;
+    sums[C + c] = t1;
+  }
+  if (alpha) {  // the coefficients of the lazily evaluated BatchNorm backward (sparse_bn_prep_kernel's arithmetic) in the same launch
+    const float iv = invstd[c], coef = gamma[c] * iv;
+    if (bl == 0) {
+      const float al = -(coef * iv) * (t1 * rM);
+      alpha[c] = al;
+      beta[c] = -(coef * (t0 * rM)) - al * mean[c];
+    }
+    for (int b = bl; b < B; b += 4) cg[(size_t)b * C + c] = gval[(size_t)b * C + c] * coef;   // this thread wrote gval[b,c] itself
   }
 }
 
@@ -437,7 +451,17 @@ extern "C" int spgan_pool_bwd_stats(const float* gpool, const float* pooled, con
                                     const float* invstd, float slope, int B, int C, float* gval, float* sums, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(gpool && pooled && argmax && y && mean && invstd && gval && sums && B > 0 && C > 0 && ld >= C);
   hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)s_, gpool, pooled, argmax, y, ld, mean, invstd, slope, B,
-                     C, gval, sums);
+                     C, gval, sums, (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_pool_bwd_stats_prep(const float* gpool, const float* pooled, const int32_t* argmax, const float* y, int ld, const float* mean,
+                                         const float* invstd, float slope, int B, int C, const float* gamma, int count, float* gval, float* sums,
+                                         float* alpha, float* beta, float* cg, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(gpool && pooled && argmax && y && mean && invstd && gval && sums && gamma && alpha && beta && cg && B > 0 && C > 0 && ld >= C &&
+                  count > 0);
+  hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)s_, gpool, pooled, argmax, y, ld, mean, invstd, slope, B,
+                     C, gval, sums, gamma, 1.0f / (float)count, alpha, beta, cg);
   return spgan_launch_status();
 }
 

@@ -131,6 +131,7 @@ SIGNATURES = {
     "spgan_adain_bwd1": (I, [P, P, I, I, I, F, P, P, F, P, P, P, P]),
     "spgan_adain_bwd2": (I, [P, P, I, I, I, F, P, P, F, P, P, P, P, P]),
     "spgan_pool_bwd_stats": (I, [P, P, P, P, I, P, P, F, I, I, P, P, P]),
+    "spgan_pool_bwd_stats_prep": (I, [P, P, P, P, I, P, P, F, I, I, P, I, P, P, P, P, P, P]),
     "spgan_bn_bwd_apply_sparse": (I, [P, P, P, I, I, I, I, P, P, P, P, I, P, P]),
     "spgan_maxpool_bwd_add": (I, [P, P, I, I, P, I, P]),
     "spgan_tanh_bwd": (I, [P, P, SZ, P, P]),

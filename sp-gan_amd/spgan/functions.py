@@ -160,6 +160,55 @@ class DiscriminatorFn(Function):
         return (None, dx) + _deliver(params, [grads[n] for n in names], ctx.needs_input_grad[2:])
 
 
+class DStackFn(Function):
+    """pooled [B,C4] = max_N lrelu(bn(conv stack(x))): the Discriminator without its per-shape MLP head (first-order only).
+    inputs: holder(names of the conv-stack parameters, buffers, training), x [B,3,N], *conv-stack params."""
+
+    @staticmethod
+    def forward(ctx, holder, x, *params):
+        P = dict(zip(holder.names, params))
+        pooled, dctx = nets.d_forward(P, holder.buffers, x, holder.training, True, head=False)
+        ctx.holder, ctx.dctx = holder, dctx
+        ctx.save_for_backward(*params)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gpool):
+        params = ctx.saved_tensors
+        names = ctx.holder.names
+        need_dp = any(ctx.needs_input_grad[2:])
+        P = dict(zip(names, [nets.owned(p) for p in params]))
+        dx, grads, _ = nets.d_backward(P, ctx.dctx, None, ctx.needs_input_grad[1], need_dp, False, gpool=gpool.detach())
+        if grads is None:
+            return (None, dx) + (None,) * len(params)
+        return (None, dx) + _deliver(params, [grads.get(n) for n in names], ctx.needs_input_grad[2:])
+
+
+class DHeadFn(Function):
+    """logits [B',1] = mlp(pooled [B',C4]) -- the head of one or several stacked passes as one batch.  inputs: holder(names), pooled, *params."""
+
+    @staticmethod
+    def forward(ctx, holder, pooled, *params):
+        P = dict(zip(holder.names, params))
+        pooled = pooled.contiguous()
+        logits, hs = nets.d_head_forward(P, pooled)
+        ctx.holder, ctx.hs = holder, hs
+        ctx.save_for_backward(pooled, *params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dout):
+        pooled, *params = ctx.saved_tensors
+        names = ctx.holder.names
+        need_dp = any(ctx.needs_input_grad[2:])
+        P = dict(zip(names, [nets.owned(p) for p in params]))
+        gpool, grads, _ = nets.d_head_backward(P, pooled, ctx.hs, dout.detach().contiguous(), need_dp)
+        gp = gpool if ctx.needs_input_grad[1] else None
+        if not need_dp:
+            return (None, gp) + (None,) * len(params)
+        return (None, gp) + _deliver(params, [grads.get(n) for n in names], ctx.needs_input_grad[2:])
+
+
 class DiscriminatorBackwardFn(Function):
     """dx = dD(x)/dx contracted with dout, as a differentiable node (its backward is the double backward)."""
 

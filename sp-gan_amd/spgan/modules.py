@@ -373,6 +373,31 @@ class Discriminator(nn.Module, _BNCounts):
         return Fn.DiscriminatorFn.apply(h, x.contiguous(), *params)
 
 
+def _discriminator_forward_many(self, *xs):
+    """[D(x) for x in xs] with the per-shape MLP head of all passes evaluated as ONE batch: the conv stacks run one after the other
+    (each with its own train-mode BatchNorm statistics and running-statistics update, in call order -- exactly what separate calls
+    do), the head has no BatchNorm, so its rows are independent and cat[pooled...] goes through it once (4 launches forward and 16
+    backward once instead of once per pass).  First-order only: the WGAN-GP route uses forward()."""
+    for x in xs:
+        _require_gpu(x, "Discriminator")
+    sn, sp = _named(self.mlps, "mlps.")
+    fn, fp = _named(self.fc2, "fc2.")
+    hn, hp = _named(self.mlp, "mlp.")
+    pooled = []
+    for x in xs:
+        h = _Holder(names=sn + fn, buffers=_buffers(self), training=self.training)
+        pooled.append(Fn.DStackFn.apply(h, x.contiguous(), *(sp + fp)))
+    logits = Fn.DHeadFn.apply(_Holder(names=hn), torch.cat(pooled, dim=0), *hp)
+    out, lo = [], 0
+    for x in xs:
+        out.append(logits[lo:lo + x.shape[0]])
+        lo += x.shape[0]
+    return out
+
+
+Discriminator.forward_many = _discriminator_forward_many
+
+
 def _discriminator_advance_running_stats(self, x):
     """Train-mode D(x) reduced to its only lasting effect when the logits are not used: the BatchNorm running statistics and
     call counts (TrainStep uses it for the reference's D(real) call inside the G step, Generation/model.py:272-273)."""

@@ -162,9 +162,46 @@ D_LAYERS = (("mlps.0", "mlps.1"), ("mlps.3", "mlps.4"), ("mlps.6", "mlps.7"), ("
 D_MLP = ("mlp.0", "mlp.2", "mlp.4", "mlp.6")
 
 
+def d_head_forward(P: Dict[str, Tensor], pooled: Tensor):
+    """The per-shape MLP head (Discriminator.py:83-95,110-113): pooled [B,C4] -> (logits [B,1], [h0, h1, h2, logits])."""
+    h, hs = pooled, []
+    for i, name in enumerate(D_MLP):
+        last = i == len(D_MLP) - 1
+        h = ops.gemm_nt(h, P[name + ".weight"], P[name + ".bias"], act=ops.ACT_NONE if last else ops.ACT_LRELU, slope=NEG)
+        hs.append(h)
+    return hs[-1], hs
+
+
+def d_head_backward(P, pooled: Tensor, hs, dout: Tensor, need_dparams: bool):
+    """-> (gpool [B,C4], {name: grad} of the head, dhs = gradients w.r.t. the pre-activation output of each head layer)."""
+    grads: Dict[str, Tensor] = {}
+    acts = [pooled, hs[0], hs[1], hs[2]]          # input of mlp.0/2/4/6
+    d = dout
+    dsum = None                                   # column sums of d (= the bias gradient), when the producing launch had them
+    dhs = [None, None, None, dout]
+    gpool = None
+    for li in (3, 2, 1, 0):
+        name = D_MLP[li]
+        if need_dparams:
+            grads[name + ".weight"] = ops.gemm_tn(d, acts[li], defer=True)
+            grads[name + ".bias"] = dsum if dsum is not None else ops.colsum(d)[0]
+        Wt = _t(P[name + ".weight"])
+        if li > 0:
+            # through the (in-place) LeakyReLU of the layer below; the bias gradient of that layer rides along
+            if need_dparams:
+                d, dsum = ops.gemm_nt_maskout(d, Wt, acts[li], NEG, colsum=True)
+            else:
+                d = ops.gemm_nt_maskout(d, Wt, acts[li], NEG)
+            dhs[li - 1] = d
+        else:
+            gpool = ops.gemm_nt(d, Wt)
+    return gpool, grads, dhs
+
+
 def d_forward(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], x_cm: Tensor, training: bool = True,
-              update_running: bool = True):
-    """x [B,3,N] -> logits [B,1] plus the saved context for backward."""
+              update_running: bool = True, head: bool = True):
+    """x [B,3,N] -> logits [B,1] plus the saved context for backward.  head=False: stop behind the max-pool and return
+    (pooled [B,C4], ctx) -- the head of several passes can then run as ONE batch (it has no BatchNorm: rows are independent)."""
     B, _, N = x_cm.shape
     M = B * N
     x_pm = ops.cm_to_pm(x_cm)
@@ -189,13 +226,11 @@ def d_forward(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], x_cm: Ten
         a, pro = y, (sc, sh, NEG)
     if yarg is None:
         pooled, argmax = ops.maxpool(ys[3], B, N, bns[3][0], bns[3][1], NEG)    # BN + LeakyReLU + max over N fused
-    h, hs = pooled, []
-    for i, name in enumerate(D_MLP):
-        last = i == len(D_MLP) - 1
-        h = ops.gemm_nt(h, P[name + ".weight"], P[name + ".bias"], act=ops.ACT_NONE if last else ops.ACT_LRELU, slope=NEG)
-        hs.append(h)
-    ctx = dict(B=B, N=N, x_pm=x_pm, ys=ys, bns=bns, pooled=pooled, argmax=argmax, yarg=yarg, hs=hs, training=training)
-    return hs[-1], ctx
+    ctx = dict(B=B, N=N, x_pm=x_pm, ys=ys, bns=bns, pooled=pooled, argmax=argmax, yarg=yarg, hs=None, training=training)
+    if not head:
+        return pooled, ctx
+    logits, ctx["hs"] = d_head_forward(P, pooled)
+    return logits, ctx
 
 
 def d_advance_running_stats(P: Dict[str, Tensor], bufs: Dict[str, Tensor], x_cm: Tensor) -> None:
@@ -224,38 +259,34 @@ def d_advance_running_stats(P: Dict[str, Tensor], bufs: Dict[str, Tensor], x_cm:
     _bn_train(mean4.contiguous(), var4, P, bufs, bn, M, True, True)
 
 
-def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for_double: bool = False):
-    """First-order backward.  Returns (dx_cm | None, {name: grad} | None, saved-for-double-backward | None)."""
+def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for_double: bool = False, gpool: Optional[Tensor] = None):
+    """First-order backward.  Returns (dx_cm | None, {name: grad} | None, saved-for-double-backward | None).
+    gpool given (the context came from d_forward(head=False)): `dout` is ignored, the backward starts at the max-pool with the
+    gradient w.r.t. the pooled features, and no head gradients are produced."""
     B, N = ctx["B"], ctx["N"]
     M = B * N
     ys, bns, hs, pooled, argmax = ctx["ys"], ctx["bns"], ctx["hs"], ctx["pooled"], ctx["argmax"]
     grads: Dict[str, Tensor] = {}
-    dout = dout.contiguous()
-    # ---- MLP head (mlp.6 <- mlp.4 <- mlp.2 <- mlp.0)
-    acts = [pooled, hs[0], hs[1], hs[2]]          # input of mlp.0/2/4/6
-    d = dout
-    dhs = [None, None, None, dout]               # gradient w.r.t. the *pre-activation* output of each MLP layer
-    for li in (3, 2, 1, 0):
-        name = D_MLP[li]
-        if need_dparams:
-            grads[name + ".weight"] = ops.gemm_tn(d, acts[li], defer=True)
-            grads[name + ".bias"] = ops.colsum(d)[0]
-        Wt = _t(P[name + ".weight"])
-        if li > 0:
-            d = ops.gemm_nt_maskout(d, Wt, acts[li], NEG)     # through the (in-place) LeakyReLU of the layer below
-            dhs[li - 1] = d
-        else:
-            gpool = ops.gemm_nt(d, Wt)
+    dhs = None
+    if gpool is None:
+        dout = dout.contiguous()
+        # ---- MLP head (mlp.6 <- mlp.4 <- mlp.2 <- mlp.0)
+        gpool, grads, dhs = d_head_backward(P, pooled, hs, dout, need_dparams)
+    else:
+        gpool = gpool.contiguous()
     # ---- max-pool + BN4 (sparse incoming gradient)
     sc4, sh4, inv4, mu4 = bns[3]
-    gval, sums4 = ops.pool_bwd_stats(gpool, pooled, argmax, ys[3] if ys[3] is not None else ctx["yarg"], mu4, inv4, NEG)
+    y4ref = ys[3] if ys[3] is not None else ctx["yarg"]
+    if ctx["training"]:
+        # dense [M,1024] BatchNorm backward of a sparse gradient: never materialised, evaluated on the GEMM operand loads; its
+        # per-channel coefficients come out of the same launch as the statistics
+        gval, sums4, dy = ops.pool_bwd_stats(gpool, pooled, argmax, y4ref, mu4, inv4, NEG, prep=(P["fc2.1.weight"], M, ys[3], N))
+    else:
+        gval, sums4 = ops.pool_bwd_stats(gpool, pooled, argmax, y4ref, mu4, inv4, NEG)
     C4 = gval.shape[1]
     if need_dparams:
         grads["fc2.1.weight"] = sums4[C4:]; grads["fc2.1.bias"] = sums4[:C4]
-    if ctx["training"]:
-        # dense [M,1024] BatchNorm backward of a sparse gradient: never materialised, evaluated on the GEMM operand loads
-        dy = ops.sparse_bn_bwd_operand(gval, argmax, ys[3], N, mu4, inv4, P["fc2.1.weight"], sums4, M)
-    else:
+    if not ctx["training"]:
         sums4 = torch.zeros_like(sums4)
         dy = ops.bn_bwd_apply_sparse(gval, argmax, ys[3], N, mu4, inv4, P["fc2.1.weight"], sums4, M)
     dys = [None, None, None, dy]

@@ -366,8 +366,10 @@ def gemm_nt_batched(A: Tensor, W: Tensor, out: Optional[Tensor] = None) -> Tenso
     return out
 
 
-def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float) -> Tensor:
-    """Y = (A @ W^T) * (ref > 0 ? 1 : slope): input-gradient through an (in-place) LeakyReLU whose output `ref` was saved."""
+def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float, colsum: bool = False):
+    """Y = (A @ W^T) * (ref > 0 ? 1 : slope): input-gradient through an (in-place) LeakyReLU whose output `ref` was saved.
+    colsum=True: returns (Y, column sums of Y [N]) -- the bias gradient of the layer below; for the per-shape linears (M <= 64,
+    aligned operands) they come out of the same launch, otherwise from a column-sum launch."""
     _rowmajor2d(A, "A"); _rowmajor2d(W, "W"); _rowmajor2d(ref, "ref")
     N, K = W.shape
     M_ = A.shape[0]
@@ -377,11 +379,22 @@ def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float) -> Tensor:
     a.M, a.N, a.K = M_, N, K
     a.a_mode = A_PLAIN; a.epi_mode = EPI_MASK_OUT
     a.ref = _p(ref); a.ld_ref = _ld(ref); a.b_slope = float(slope)
+    lib = _lib.load()
+    res = part = None
+    # the M <= 64 kernel (the only one with this epilogue's column sums) is taken for 16-byte aligned operands with K % 4 == 0
+    if colsum and M_ <= 64 and K % 4 == 0 and a.lda % 4 == 0 and a.ldw % 4 == 0 and A.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0:
+        part = torch.empty((1, N, 2), dtype=torch.float32, device=A.device)
+        res = torch.empty((2, N), dtype=torch.float32, device=A.device)
+        a.stats = _p(part)
+        _fanin_setup(a.fin, lib, A.device, 1, lib.spgan_gemm_nt_col_blocks(C.byref(a)), N)
+        a.fin.mode = 1; a.fin.out0 = _p(res[0]); a.fin.out1 = _p(res[1])
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
-    check(_lib.load().spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_maskout", M=M_, N=N, K=K)
+    check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_maskout", M=M_, N=N, K=K)
     if done is not None:
         done()
-    return Y
+    if not colsum:
+        return Y
+    return Y, (res[0] if res is not None else globals()["colsum"](Y)[0])
 
 
 class SparseAffine:
@@ -940,19 +953,30 @@ def _rowids(B: int, Cn: int, device) -> Tensor:
     return _ROWIDS[key]
 
 
-def pool_bwd_stats(gpool: Tensor, pooled: Tensor, argmax: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, slope: float):
+def pool_bwd_stats(gpool: Tensor, pooled: Tensor, argmax: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, slope: float, prep=None):
     """gval = gpool*lrelu'(pooled); sums [2C] = [sum_b gval | sum_b gval*xhat(argmax row)].
-    y is either the full [M,C] pre-BN tensor or, when that was never stored, its values at the arg-max rows [B,C]."""
+    y is either the full [M,C] pre-BN tensor or, when that was never stored, its values at the arg-max rows [B,C].
+    prep = (gamma, count, y_full | None, rows): additionally returns the lazily evaluated BatchNorm backward operand that
+    sparse_bn_bwd_operand(gval, argmax, y_full, rows, mean, invstd, gamma, sums, count) would build -- from the same launch."""
     _f32(gpool, "gpool", 2); _rowmajor2d(y, "y")
     B, Cn = gpool.shape
+    real_arg = argmax
     if y.shape[0] == B:                     # yarg [B,C]: "row b" of it is the arg-max row of shape b
         argmax = _rowids(B, Cn, y.device)
     gpool = gpool.contiguous()
     gval = torch.empty_like(gpool)
     sums = torch.empty((2 * Cn,), dtype=torch.float32, device=y.device)
-    check(_lib.load().spgan_pool_bwd_stats(_p(gpool), _p(pooled), _p(_i32(argmax, "argmax")), _p(y), _ld(y), _p(mean), _p(invstd), float(slope), B, Cn,
-                                           _p(gval), _p(sums), _s()), "pool_bwd_stats")
-    return gval, sums
+    if prep is None:
+        check(_lib.load().spgan_pool_bwd_stats(_p(gpool), _p(pooled), _p(_i32(argmax, "argmax")), _p(y), _ld(y), _p(mean), _p(invstd), float(slope), B, Cn,
+                                               _p(gval), _p(sums), _s()), "pool_bwd_stats")
+        return gval, sums
+    gamma, count, y_full, rows = prep
+    ab = torch.empty((2, Cn), dtype=torch.float32, device=y.device)
+    cg = torch.empty_like(gval)
+    check(_lib.load().spgan_pool_bwd_stats_prep(_p(gpool), _p(pooled), _p(_i32(argmax, "argmax")), _p(y), _ld(y), _p(_vec(mean, Cn, "mean")),
+                                                _p(_vec(invstd, Cn, "invstd")), float(slope), B, Cn, _p(_vec(gamma, Cn, "gamma")), int(count), _p(gval),
+                                                _p(sums), _p(ab[0]), _p(ab[1]), _p(cg), _s()), "pool_bwd_stats_prep")
+    return gval, sums, SparseAffine(y_full, ab[0], ab[1], cg, real_arg, rows)
 
 
 def bn_bwd_apply_sparse(gval: Tensor, argmax: Tensor, y: Tensor, N: int, mean, invstd, gamma, sums, count: int) -> Tensor:

@@ -229,8 +229,11 @@ class TrainStep:
         self.optD.zero_grad()
         fake = G(x, z_d).detach()
         real_t = ops.pm_to_cm(real.reshape(B * N, 3), B, N)                      # real_points.transpose(2,1)
-        d_real = D(real_t)
-        d_fake = D(fake)
+        if self.reference_schedule or not hasattr(D, "forward_many"):
+            d_real = D(real_t)
+            d_fake = D(fake)
+        else:
+            d_real, d_fake = D.forward_many(real_t, fake)        # same two passes, the BatchNorm-free head of both as one batch
         loss_d, dinfo = dis_loss(d_real, d_fake, gan=self.gan, noise_label=self.flip_d)
         if self.use_gp:
             loss_d = loss_d + self.gp(D, real_t, fake, alpha=alpha)

@@ -132,8 +132,9 @@ def gemm_nt_batched(A, W, out=None):
     return out
 
 
-def gemm_nt_maskout(A, W, ref, slope):
-    return ((A @ W.t()) * torch.where(ref > 0, 1.0, slope)).contiguous()
+def gemm_nt_maskout(A, W, ref, slope, colsum=False):
+    y = ((A @ W.t()) * torch.where(ref > 0, 1.0, slope)).contiguous()
+    return (y, y.sum(0)) if colsum else y
 
 
 class SparseAffine:
@@ -454,14 +455,19 @@ def gemm_bn_pool(A, W, bias, bn, rows, slope, pro=None, keep_y=False):
     return (y if keep_y else None), st, pooled, arg, y[arg.long(), cols].contiguous()
 
 
-def pool_bwd_stats(gpool, pooled, argmax, y, mean, invstd, slope):
+def pool_bwd_stats(gpool, pooled, argmax, y, mean, invstd, slope, prep=None):
     B, C = gpool.shape
     gval = gpool * torch.where(pooled > 0, 1.0, slope)
     cols = torch.arange(C, device=y.device).view(1, C).expand(B, C)
+    real_arg = argmax
     if y.shape[0] == B:
         argmax = torch.arange(B, device=y.device).view(B, 1).expand(B, C)
     xh = (y[argmax.long(), cols] - mean) * invstd
-    return gval.contiguous(), torch.cat([gval.sum(0), (gval * xh).sum(0)])
+    sums = torch.cat([gval.sum(0), (gval * xh).sum(0)])
+    if prep is None:
+        return gval.contiguous(), sums
+    gamma, count, y_full, rows = prep
+    return gval.contiguous(), sums, sparse_bn_bwd_operand(gval.contiguous(), real_arg, y_full, rows, mean, invstd, gamma, sums, count)
 
 
 def bn_bwd_apply_sparse(gval, argmax, y, N, mean, invstd, gamma, sums, count):

@@ -130,3 +130,29 @@ def test_colsum_of_short_groups_is_one_launch(ops, M, C, G):
     m, v = ops.colstats(X, G, 0.2)
     m2, v2 = km.colstats(X, G, 0.2)
     close(m, m2, rtol=2e-6, atol=1e-6); close(v, v2, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 256, 64), (64, 512, 256), (32, 64, 1), (100, 128, 64)])
+def test_maskout_with_column_sums(ops, M, N, K):
+    """gemm_nt_maskout(colsum=True): the bias gradient of the layer below from the same launch (M <= 64, aligned) or a follow-up."""
+    A, W, ref = rnd("mo.A%d.%d" % (M, K), (M, K)), rnd("mo.W%d.%d" % (N, K), (N, K), 0.2), rnd("mo.r%d.%d" % (M, N), (M, N))
+    y, cs = ops.gemm_nt_maskout(A, W, ref, 0.01, colsum=True)
+    y2, cs2 = km.gemm_nt_maskout(A, W, ref, 0.01, colsum=True)
+    close(y, y2, rtol=2e-5, atol=2e-5, what="maskout"); close(cs, cs2, rtol=2e-5, atol=1e-4, what="column sums")
+    assert torch.equal(y, ops.gemm_nt_maskout(A, W, ref, 0.01))
+
+
+def test_pool_bwd_stats_with_prep(ops):
+    B, C, N = 8, 1024, 256
+    M = B * N
+    gpool, pooled, y = rnd("pp.g", (B, C)), rnd("pp.p", (B, C)), rnd("pp.y", (M, C))
+    g = torch.Generator().manual_seed(2)
+    arg = (torch.randint(0, N, (B, C), generator=g) + torch.arange(B)[:, None] * N).int().cuda()
+    mu, inv, gamma = rnd("pp.mu", (C,), 0.2), rnd("pp.inv", (C,)).abs() + 0.5, rnd("pp.ga", (C,)).abs() + 0.5
+    gval, sums, sa = ops.pool_bwd_stats(gpool, pooled, arg, y, mu, inv, 0.01, prep=(gamma, M, y, N))
+    gval2, sums2 = ops.pool_bwd_stats(gpool, pooled, arg, y, mu, inv, 0.01)
+    sb = ops.sparse_bn_bwd_operand(gval2, arg, y, N, mu, inv, gamma, sums2, M)
+    assert torch.equal(gval, gval2) and torch.equal(sums, sums2)
+    for a, b in ((sa.alpha, sb.alpha), (sa.beta, sb.beta), (sa.sp_val, sb.sp_val)):
+        assert torch.equal(a, b)
+    assert sa.rows == sb.rows and torch.equal(sa.sp_arg, sb.sp_arg)

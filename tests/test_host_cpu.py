@@ -277,3 +277,27 @@ def test_generator_per_shape_latent(spgan_cpu):
     _cmp("out", res[0][0], res[1][0], 1e-5)
     for n in res[0][1]:
         _cmp("grad " + n, res[0][1][n], res[1][1][n], 2e-3, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-6)
+
+
+def test_discriminator_forward_many_equals_separate_calls(spgan_cpu):
+    """D.forward_many(a, b): the conv stacks run separately (own BatchNorm statistics, running statistics in call order), the
+    BatchNorm-free head once on the stacked pooled features -- same logits, gradients and buffers as D(a), D(b)."""
+    B, N = 3, 128
+    p = fr.init_params(orc.discriminator_shapes(), salt=41)
+    xa = fr.synthetic_real(B, N, seed=42).transpose(2, 1).contiguous()
+    xb = (0.7 * fr.synthetic_real(B, N, seed=43)).transpose(2, 1).contiguous()
+    w = fr.normal("fm.w", (2 * B, 1))
+    res = []
+    for many in (False, True):
+        D = _load(spgan_cpu.modules.Discriminator(Opts), p).train()
+        a, b = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+        la, lb = D.forward_many(a, b) if many else (D(a), D(b))
+        (torch.cat([la, lb]) * w).sum().backward()
+        res.append((la.detach(), lb.detach(), a.grad, b.grad, {n: q.grad.clone() for n, q in D.named_parameters()},
+                    {k: v.clone() for k, v in D.state_dict().items() if k not in dict(D.named_parameters())}))
+    for i in range(4):
+        _cmp("forward_many tensor %d" % i, res[1][i], res[0][i], 1e-6)
+    for n in res[0][4]:
+        _cmp("forward_many grad " + n, res[1][4][n], res[0][4][n], 2e-6, atol=1e-7)
+    for k in res[0][5]:
+        assert torch.allclose(res[1][5][k].float(), res[0][5][k].float(), rtol=1e-6, atol=1e-7), k

@@ -537,3 +537,28 @@ def test_per_shape_latent_with_eql_and_znorm(sp):
     for n in ("head.0.conv.weight_orig", "head.0.conv.bias", "head.2.conv.weight_orig", "head.2.conv.bias"):
         e = rel_l2(res[0][1][n].cpu().numpy(), res[1][1][n].cpu().numpy())
         assert e <= 6e-2, (n, e)
+
+
+def test_discriminator_forward_many_equals_separate_calls_gpu(sp):
+    """D.forward_many(real, fake) (what TrainStep uses for the D step): the BatchNorm-free head of both passes as one batch; logits,
+    input gradients, parameter gradients and buffers equal those of two separate calls."""
+    B, N = 4, 512
+    p = fr.init_params(orc.discriminator_shapes(), salt=41)
+    xa = fr.synthetic_real(B, N, seed=42).transpose(2, 1).contiguous().cuda()
+    xb = (0.7 * fr.synthetic_real(B, N, seed=43)).transpose(2, 1).contiguous().cuda()
+    w = fr.normal("fm.w", (2 * B, 1)).cuda()
+    res = []
+    for many in (False, True):
+        D = _load(sp.Discriminator(Opts), p).train()
+        a, b = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+        la, lb = D.forward_many(a, b) if many else (D(a), D(b))
+        (torch.cat([la, lb]) * w).sum().backward()
+        res.append(([la.detach(), lb.detach(), a.grad, b.grad], {n: q.grad.clone() for n, q in D.named_parameters()},
+                    {k: v.clone() for k, v in D.state_dict().items() if k not in dict(D.named_parameters())}))
+    for i in range(4):
+        assert rel_l2(res[1][0][i].cpu().numpy(), res[0][0][i].cpu().numpy(), "forward_many|tensor%d" % i) <= 1e-6
+    for n in res[0][1]:
+        a_, b_ = res[1][1][n].cpu(), res[0][1][n].cpu()
+        assert rel_l2(a_.numpy(), b_.numpy(), "forward_many|grad|" + n) <= 3e-6 or (a_ - b_).abs().max().item() <= 1e-7, n
+    for k in res[0][2]:
+        assert torch.equal(res[1][2][k], res[0][2][k]), k
