@@ -50,6 +50,19 @@ def _noisy_labels(y, p_flip=0.05):
     return y.index_put((ix,), 1 - y[ix])
 
 
+_ONES = {}
+
+
+def _ones_like(t: torch.Tensor) -> torch.Tensor:
+    """A cached all-ones seed of t's shape (constant: created once per shape and device)."""
+    key = (tuple(t.shape), str(t.device))
+    o = _ONES.get(key)
+    if o is None:
+        o = torch.ones_like(t)
+        _ONES[key] = o
+    return o
+
+
 def _mode(gan: str) -> int:
     g = gan.lower()
     if g not in ops.GAN_MODES:
@@ -93,6 +106,27 @@ def gen_loss(d_real, d_fake, gan="wgan", weight=1., d_real_p=None, d_fake_p=None
     if fake_label is not None:
         info["fake_label"] = fake_label
     return loss, info
+
+
+def dis_loss_with_grads(d_real, d_fake, gan="wgan", noise_label=False):
+    """dis_loss evaluated once with its gradients w.r.t. the two logit tensors: -> (out5 [loss, fake term, real term, real_acc,
+    fake_acc], g_real, g_fake).  For callers that seed the backward pass themselves (spgan.TrainStep: torch.autograd.backward(
+    [d_real, d_fake], [g_real, g_fake]) -- no loss clone, no multiplication of the gradients by the implicit seed 1)."""
+    mode = _mode(gan)
+    real_label = None
+    if mode == 0 and noise_label:
+        real_label = _noisy_labels(_smooth_labels(d_fake.shape[0], d_fake.device))
+    return ops.gan_loss(mode, 0, d_real.detach(), d_fake.detach(), real_label, None)
+
+
+def gen_loss_with_grads(d_fake, gan="wgan", noise_label=False):
+    """gen_loss the same way: -> (out5 [loss, g_loss, ...], g_fake)."""
+    mode = _mode(gan)
+    fake_label = None
+    if mode == 0 and noise_label:
+        fake_label = _noisy_labels(torch.ones(d_fake.shape[0], device=d_fake.device))
+    out5, _, g_fake = ops.gan_loss(mode, 1, None, d_fake.detach(), None, fake_label)
+    return out5, g_fake
 
 
 class _GPPenaltyFn(Function):
@@ -140,6 +174,20 @@ class GradientPenalty:
         return ops.pm_to_cm(mixed.view(B * N, C), B, N)
 
     def __call__(self, netD, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False):
+        grads = self.input_gradient(netD, real_data, fake_data, alpha, mapping)
+        return _GPPenaltyFn.apply(grads.contiguous().view(grads.shape[0], -1), float(self.gamma), float(self.lambdaGP))
+
+    def with_grads(self, netD, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False):
+        """-> (penalty [1], grads, v): the penalty's value, the differentiable input gradient it is a function of, and
+        d penalty / d grads -- for a caller that seeds torch.autograd.backward([grads], [v]) itself."""
+        grads = self.input_gradient(netD, real_data, fake_data, alpha, mapping)
+        g = grads.detach().contiguous().view(grads.shape[0], -1)
+        loss, norms = ops.gp_penalty_fwd(g, float(self.gamma), float(self.lambdaGP))
+        v = ops.gp_penalty_bwd(g, norms, float(self.gamma), float(self.lambdaGP), None)
+        return loss, grads, v.view_as(grads)
+
+    def input_gradient(self, netD, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False):
+        """d netD(x_hat) / d x_hat on the interpolates, as a differentiable tensor (create_graph)."""
         B = real_data.size(0)
         fake_data = fake_data[:B]
         if alpha is None:
@@ -153,6 +201,6 @@ class GradientPenalty:
             interpolates = ops.lerp_rows(real_d, fake_d, alpha.reshape(B)).requires_grad_(True)
         disc = netD(interpolates)
         with input_grad_only():          # explicit: this backward wants d disc / d x_hat only, as a differentiable node
-            grads = torch.autograd.grad(outputs=disc, inputs=interpolates, grad_outputs=torch.ones_like(disc),
+            grads = torch.autograd.grad(outputs=disc, inputs=interpolates, grad_outputs=_ones_like(disc),
                                         create_graph=True, retain_graph=True, only_inputs=True)[0]
-        return _GPPenaltyFn.apply(grads.contiguous().view(B, -1), float(self.gamma), float(self.lambdaGP))
+        return grads

@@ -105,6 +105,19 @@ def _refresh_transposes(trigger: Tensor) -> None:
             _T_CACHE[key] = (cur, t, oref, view)
 
 
+_CONST_VEC: Dict[Tuple[int, float, str], Tensor] = {}
+
+
+def _const_vec(n: int, value: float, device) -> Tensor:
+    """A cached constant vector (created once, outside any later graph capture's allocations)."""
+    key = (n, float(value), str(device))
+    v = _CONST_VEC.get(key)
+    if v is None:
+        v = torch.full((n,), float(value), dtype=torch.float32, device=device)
+        _CONST_VEC[key] = v
+    return v
+
+
 def _cat2(s0: Tensor, s1: Tensor) -> Tensor:
     """[s0 | s1] without a copy when the two vectors already sit back to back in one allocation (the finalize kernels
     write (sum0, sum1) into one [2,C] buffer)."""
@@ -249,11 +262,12 @@ def d_advance_running_stats(P: Dict[str, Tensor], bufs: Dict[str, Tensor], x_cm:
     W, b4 = _w2(P[conv + ".weight"]), P[conv + ".bias"]
     a3 = ops.affine_act(a, pro[0], pro[1], NEG)
     mu_a = ops.colsum(a3)[0] * (1.0 / M)
-    inv_m = torch.full_like(mu_a, 1.0 / M)
+    neg_ones, neg_inv_m = _const_vec(mu_a.numel(), -1.0, mu_a.device), _const_vec(mu_a.numel(), -1.0 / M, mu_a.device)
     # Cov(a3) = a3^T (a3 - 1 mu^T) / M: the second operand is centred on load (gemm_tn's affine prologue with slope 1), so no
     # Gram/M - mu mu^T difference of two large numbers is formed (a3 is a LeakyReLU output: its means are not small); what
-    # rounding leaves of a negative variance is clamped by bn_prepare.
-    cov = ops.rowscale_outer(ops.gemm_tn(a3, a3, pro=(torch.ones_like(mu_a), -mu_a, 1.0)), inv_m)
+    # rounding leaves of a negative variance is clamped by bn_prepare.  Written with constant vectors only: the prologue forms
+    # -(a3 - mu) = a3*(-1) + mu and the row scaling multiplies by -1/M.
+    cov = ops.rowscale_outer(ops.gemm_tn(a3, a3, pro=(neg_ones, mu_a, 1.0)), neg_inv_m)
     mean4 = ops.gemm_nt(mu_a.view(1, -1), W, b4, exact=True)[0]
     var4 = ops.rowdot(W, ops.gemm_nt(W, cov, exact=True))
     _bn_train(mean4.contiguous(), var4, P, bufs, bn, M, True, True)
@@ -506,7 +520,7 @@ def conv_out_weight_pm(w: Tensor) -> Tensor:
     owner = _owner(w)
     if owner is None:
         return w[:, :, 0, :].permute(0, 2, 1).reshape(F_, k * F_).contiguous()
-    stamp = (ops.WEIGHTS_EPOCH[0], owner._version)
+    stamp = (ops.weights_epoch_of(owner), owner._version)          # this network's own optimiser steps, not the other's
     hit = _WO_CACHE.get(w.data_ptr())
     if hit is not None and hit[0] == stamp and hit[2]() is owner:
         return hit[1]

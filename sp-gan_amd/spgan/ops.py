@@ -104,6 +104,19 @@ def get_mfma_operands() -> str:
 # Bumped by every optimiser step that rewrites parameters through a HIP kernel (invisible to torch's version counters);
 # host-side caches of weight-derived tensors (nets._t) key on it.
 WEIGHTS_EPOCH = [0]
+# The same per flat parameter buffer (keyed by its storage address): a cache of something derived from the GENERATOR's weights
+# need not be refreshed because the discriminator's optimiser stepped in between (and vice versa).
+WEIGHTS_EPOCH_OF = {}
+
+
+def bump_weights_epoch(flat: Tensor) -> None:
+    WEIGHTS_EPOCH[0] += 1
+    key = flat.untyped_storage().data_ptr()
+    WEIGHTS_EPOCH_OF[key] = WEIGHTS_EPOCH_OF.get(key, 0) + 1
+
+
+def weights_epoch_of(p: Tensor) -> int:
+    return WEIGHTS_EPOCH_OF.get(p.untyped_storage().data_ptr(), 0)
 
 
 class _KnnInfo:

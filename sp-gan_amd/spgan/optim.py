@@ -78,7 +78,7 @@ class Adam:
 
     def step(self, grad_scale: float = 1.0):
         self.t += 1
-        ops.WEIGHTS_EPOCH[0] += 1
+        ops.bump_weights_epoch(self.fp.flat)
         if self.capturable:
             ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.dev_state, self.lr, self.betas[0], self.betas[1], self.eps, grad_scale)
         else:

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from . import ops
 from .functions import fused_grad_accumulation
-from .losses import GradientPenalty, dis_loss, gen_loss
+from .losses import GradientPenalty, dis_loss_with_grads, gen_loss_with_grads
 from .optim import Adam
 from .parallel import DataParallel
 
@@ -202,7 +202,7 @@ class TrainStep:
             self._graph[1].replay()
             self.dpG.allreduce_grads()
             self._graph[2].replay()
-        ops.WEIGHTS_EPOCH[0] += 2                  # both networks were updated by the replayed Adam kernels: host-side weight caches are stale
+        ops.bump_weights_epoch(self.optD.fp.flat); ops.bump_weights_epoch(self.optG.fp.flat)   # both networks were updated by the replayed Adam kernels: host-side weight caches are stale
         for m, d in zip(self._bn_modules(), self._bn_delta):
             store = m.__dict__.setdefault("_bn_pending", {})
             for pre, pend in d.items():
@@ -234,14 +234,20 @@ class TrainStep:
             d_fake = D(fake)
         else:
             d_real, d_fake = D.forward_many(real_t, fake)        # same two passes, the BatchNorm-free head of both as one batch
-        loss_d, dinfo = dis_loss(d_real, d_fake, gan=self.gan, noise_label=self.flip_d)
+        # lossD.backward() with the seeds written out: the loss kernel returns d loss / d logits, the penalty kernel d penalty / d
+        # (input gradient); one backward pass from those three roots (no loss clones, no sum node, no multiplication by the seed 1)
+        out5, g_real, g_fake = dis_loss_with_grads(d_real, d_fake, self.gan, self.flip_d)
+        roots, seeds = [d_real, d_fake], [g_real, g_fake]
+        loss_d = out5[0]
         if self.use_gp:
-            loss_d = loss_d + self.gp(D, real_t, fake, alpha=alpha)
+            pen, gx, v = self.gp.with_grads(D, real_t, fake, alpha=alpha)
+            roots.append(gx); seeds.append(v)
+            loss_d = loss_d + pen[0]
         with fused_grad_accumulation():
-            loss_d.backward()
+            torch.autograd.backward(roots, seeds)
         if keep_grads:
             info["fake_d"] = fake
-        info.update(loss_d=loss_d.detach(), real_acc=dinfo["real_acc"], fake_acc=dinfo["fake_acc"])
+        info.update(loss_d=loss_d.detach(), real_acc=out5[3], fake_acc=out5[4])
         return real_t
 
     def _seg_g(self, x, real_t, z_g, scale_d, keep_grads, info):
@@ -261,12 +267,12 @@ class TrainStep:
         else:
             D.advance_running_stats(real_t)
         g_fake_logit = D(g_fake)
-        loss_g, _ = gen_loss(g_real_logit, g_fake_logit, gan=self.gan, noise_label=self.flip_g)
+        out5, seed = gen_loss_with_grads(g_fake_logit, self.gan, self.flip_g)      # gen_loss ignores d_real (loss_utils.py:727-802)
         with fused_grad_accumulation():
-            loss_g.backward()
+            torch.autograd.backward([g_fake_logit], [seed])
         if keep_grads:
             info["fake_g"] = g_fake.detach()
-        info["loss_g"] = loss_g.detach()
+        info["loss_g"] = out5[0]
 
     def _seg_opt_g(self, scale_g, keep_grads, info):
         if keep_grads:
