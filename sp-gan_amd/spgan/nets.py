@@ -202,7 +202,7 @@ def d_head_backward(P, pooled: Tensor, hs, dout: Tensor, need_dparams: bool):
         if li > 0:
             # through the (in-place) LeakyReLU of the layer below; the bias gradient of that layer rides along
             if need_dparams:
-                d, dsum = ops.gemm_nt_maskout(d, Wt, acts[li], NEG, colsum=True)
+                d, dsum = ops.gemm_nt_maskout(d, Wt, acts[li], NEG, with_colsum=True)
             else:
                 d = ops.gemm_nt_maskout(d, Wt, acts[li], NEG)
             dhs[li - 1] = d

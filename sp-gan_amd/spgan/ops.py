@@ -379,9 +379,9 @@ def gemm_nt_batched(A: Tensor, W: Tensor, out: Optional[Tensor] = None) -> Tenso
     return out
 
 
-def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float, colsum: bool = False):
+def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float, with_colsum: bool = False):
     """Y = (A @ W^T) * (ref > 0 ? 1 : slope): input-gradient through an (in-place) LeakyReLU whose output `ref` was saved.
-    colsum=True: returns (Y, column sums of Y [N]) -- the bias gradient of the layer below; for the per-shape linears (M <= 64,
+    with_colsum=True: returns (Y, column sums of Y [N]) -- the bias gradient of the layer below; for the per-shape linears (M <= 64,
     aligned operands) they come out of the same launch, otherwise from a column-sum launch."""
     _rowmajor2d(A, "A"); _rowmajor2d(W, "W"); _rowmajor2d(ref, "ref")
     N, K = W.shape
@@ -395,7 +395,7 @@ def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float, colsum: boo
     lib = _lib.load()
     res = part = None
     # the M <= 64 kernel (the only one with this epilogue's column sums) is taken for 16-byte aligned operands with K % 4 == 0
-    if colsum and M_ <= 64 and K % 4 == 0 and a.lda % 4 == 0 and a.ldw % 4 == 0 and A.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0:
+    if with_colsum and M_ <= 64 and K % 4 == 0 and a.lda % 4 == 0 and a.ldw % 4 == 0 and A.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0:
         part = torch.empty((1, N, 2), dtype=torch.float32, device=A.device)
         res = torch.empty((2, N), dtype=torch.float32, device=A.device)
         a.stats = _p(part)
@@ -405,9 +405,9 @@ def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float, colsum: boo
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_maskout", M=M_, N=N, K=K)
     if done is not None:
         done()
-    if not colsum:
+    if not with_colsum:
         return Y
-    return Y, (res[0] if res is not None else globals()["colsum"](Y)[0])
+    return Y, (res[0] if res is not None else colsum(Y)[0])
 
 
 class SparseAffine:

@@ -132,9 +132,9 @@ def gemm_nt_batched(A, W, out=None):
     return out
 
 
-def gemm_nt_maskout(A, W, ref, slope, colsum=False):
+def gemm_nt_maskout(A, W, ref, slope, with_colsum=False):
     y = ((A @ W.t()) * torch.where(ref > 0, 1.0, slope)).contiguous()
-    return (y, y.sum(0)) if colsum else y
+    return (y, y.sum(0)) if with_colsum else y
 
 
 class SparseAffine:

@@ -134,10 +134,10 @@ def test_colsum_of_short_groups_is_one_launch(ops, M, C, G):
 
 @pytest.mark.parametrize("M,N,K", [(32, 256, 64), (64, 512, 256), (32, 64, 1), (100, 128, 64)])
 def test_maskout_with_column_sums(ops, M, N, K):
-    """gemm_nt_maskout(colsum=True): the bias gradient of the layer below from the same launch (M <= 64, aligned) or a follow-up."""
+    """gemm_nt_maskout(with_colsum=True): the bias gradient of the layer below from the same launch (M <= 64, aligned) or a follow-up."""
     A, W, ref = rnd("mo.A%d.%d" % (M, K), (M, K)), rnd("mo.W%d.%d" % (N, K), (N, K), 0.2), rnd("mo.r%d.%d" % (M, N), (M, N))
-    y, cs = ops.gemm_nt_maskout(A, W, ref, 0.01, colsum=True)
-    y2, cs2 = km.gemm_nt_maskout(A, W, ref, 0.01, colsum=True)
+    y, cs = ops.gemm_nt_maskout(A, W, ref, 0.01, with_colsum=True)
+    y2, cs2 = km.gemm_nt_maskout(A, W, ref, 0.01, with_colsum=True)
     close(y, y2, rtol=2e-5, atol=2e-5, what="maskout"); close(cs, cs2, rtol=2e-5, atol=1e-4, what="column sums")
     assert torch.equal(y, ops.gemm_nt_maskout(A, W, ref, 0.01))
 
