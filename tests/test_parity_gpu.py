@@ -495,27 +495,52 @@ def test_gradient_penalty_loss_utils_variant(sp, mapping):
 
 # ---------------------------------------------------------------- one latent per shape, passed un-tiled
 def test_generator_per_shape_latent_matches_tiled_and_oracle(sp):
+    """z handed over un-tiled [B,1,nz] (HeadFn: latent half of head.0 once per shape, coordinate half as a K = 3 product) against
+    the tiled [B,N,nz] input (one K = 131 MFMA product).  The two evaluations round differently in the last bits, so each run may
+    build its own EdgeConv2 graph at near-ties (tie-aware protocol): every run is checked against the oracle on ITS OWN
+    graphs, the runs against each other only when their graphs coincide."""
     B, N = 4, 256
     params = fr.init_params(orc.generator_shapes(), salt=4)
     x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
     zt = fr.latent(B, N, seed=44)                                            # tiled, as the reference builds it
-    outs, grads = [], []
+    outs, grads, graphs, x1s = [], [], [], []
     dy = fr.normal("psl.dy", (B, 3, N)).cuda()
     for z in (zt[:, :1, :].contiguous().cuda(), zt.cuda()):
         G = _load(sp.Generator(Opts), params).train()
         out = G(x, z)
         (out * dy).sum().backward()
         outs.append(out.detach()); grads.append({n: p.grad.clone() for n, p in G.named_parameters()})
-        last = G
-    assert rel_l2(outs[0].cpu().numpy(), outs[1].cpu().numpy()) <= 2e-5
+        graphs.append((sp.ops.idx_to_local64(G.EdgeConv1.last_idx, B, N).cpu(), sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).cpu()))
+        x1s.append(G.last_x1.clone())
+    assert rel_l2(x1s[0].cpu().numpy(), x1s[1].cpu().numpy(), "per-shape vs tiled latent|x1") <= 3e-6   # the stage in front of the graph: tie-independent
+    assert torch.equal(graphs[0][0], graphs[1][0])
+    # This configuration is ill-conditioned (train-mode BatchNorm of the global feature over 4 shapes): the reference arithmetic
+    # in fp32 is itself ~3e-2 away from its fp64 evaluation on the same graphs, and a 1e-7 relative change of z moves the fp32
+    # gradients by 3e-4.  So the yardstick is the fp64 oracle, and the HIP path has to be no further from it than a small multiple
+    # of the fp32 oracle's own distance.
+    for r in range(2):
+        og = {}
+        for dt in (torch.float32, torch.float64):
+            po = {k: v.clone().to(dt).requires_grad_(True) for k, v in params.items()}
+            bufs = {k: v.to(dt) for k, v in orc.bn_buffers(orc.generator_shapes()).items()}
+            ref = orc.generator_forward(po, x.cpu().to(dt), zt.to(dt), training=True, buffers=bufs, idx1=graphs[r][0], idx2=graphs[r][1])
+            og[dt] = dict(zip(po.keys(), torch.autograd.grad((ref * dy.cpu().to(dt)).sum(), list(po.values()))))
+            if dt == torch.float32:
+                assert rel_l2(outs[r].cpu().numpy(), ref.detach().numpy(), "latent run %d|out vs oracle on its own graphs" % r) <= 2e-5
+        for n in grads[r]:
+            want = og[torch.float64][n].numpy()
+            own = rel_l2(og[torch.float32][n].numpy(), want)                 # the reference arithmetic's own fp32 error
+            e = rel_l2(grads[r][n].cpu().double().numpy(), want, "latent run %d|grad|%s vs fp64 oracle on its own graphs" % (r, n))
+            assert e <= 3.0 * own + 1e-4 or (grads[r][n].cpu().double() - og[torch.float64][n]).abs().max().item() <= _atol(n), (r, n, e, own)
+    same = torch.equal(graphs[0][1], graphs[1][1])
+    agree = (graphs[0][1].view(B * N, -1) == graphs[1][1].view(B * N, -1)).all(dim=1).float().mean().item()
+    assert agree >= 0.995, agree
+    if same:
+        assert rel_l2(outs[0].cpu().numpy(), outs[1].cpu().numpy()) <= 2e-5
     for n in grads[0]:
-        # the two runs build their own EdgeConv2 graphs from features that differ in the last bits: near-tie neighbours may flip,
-        # which moves the gradients at the percent level (the tie-aware protocol of the other generator tests)
+        # the two evaluations round differently; with this conditioning (see above) that alone moves the gradients by percents
         e = rel_l2(grads[0][n].cpu().numpy(), grads[1][n].cpu().numpy())
-        assert e <= 6e-2 or (grads[0][n] - grads[1][n]).abs().max().item() <= _atol(n), (n, e)
-    i1 = sp.ops.idx_to_local64(last.EdgeConv1.last_idx, B, N).cpu(); i2 = sp.ops.idx_to_local64(last.EdgeConv2.last_idx, B, N).cpu()
-    ref = orc.generator_forward(params, x.cpu(), zt, training=True, buffers=orc.bn_buffers(orc.generator_shapes()), idx1=i1, idx2=i2)
-    assert rel_l2(outs[0].cpu().numpy(), ref.numpy()) <= 2e-4
+        assert e <= 1e-1 or (grads[0][n] - grads[1][n]).abs().max().item() <= _atol(n), (n, e)
 
 
 def test_per_shape_latent_with_eql_and_znorm(sp):
