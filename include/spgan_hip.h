@@ -151,6 +151,10 @@ typedef struct spgan_gemm_nt_args {
   /* fin.enabled (needs `stats`): the column records are merged in this launch -- column blocks = the kernel's N-tiles
    * (spgan_gemm_nt_col_blocks), row tiles of 128 rows.  Not with pooling-only launches (stats == NULL). */
   spgan_fanin fin;
+  /* Tile geometry.  0: automatic -- 256 x 256 tiles (csrc/gemm_wide.hip) for large aligned products whose tiles fill the chip, the
+   * 128-row kernels otherwise; 1: 128-row kernels only; 2: 256 x 256 tiles whenever the problem is eligible (M % 256 == 0,
+   * N % 256 == 0, K % 32 == 0, 16-byte aligned rows, fp32 operands, no per-edge mode / fan-in / batching): for tests and A/B runs. */
+  int tile_hint;
 } spgan_gemm_nt_args;
 /* number of column blocks (N-tiles) spgan_gemm_nt uses for this problem: sizes the fan-in counters */
 int spgan_gemm_nt_col_blocks(const spgan_gemm_nt_args* a);

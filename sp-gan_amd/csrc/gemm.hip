@@ -24,6 +24,7 @@
 // column sums.
 #include "common.hpp"
 #include "fanin.hpp"
+#include "gemm_wide.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -1079,6 +1080,9 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   if (AMODE != SPGAN_A_PLAIN) fast = fast && al16(a.p_scale) && al16(a.p_shift);
   if (AMODE == SPGAN_A_EDGE) fast = fast && al16(a.e_bias);
   if (AMODE == A_AFFINE_SPARSE) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
+  if constexpr (AMODE != SPGAN_A_EDGE && EPI != SPGAN_EPI_EDGE_BNBWD) {
+    if (spgan_nt_wide_selected(a)) return spgan_launch_nt_wide(a, s);  // large aligned products: 256 x 256 tiles (gemm_wide.hip)
+  }
   if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE_SPARSE && EPI != SPGAN_EPI_EDGE_BNBWD) {
     if (a.M <= 64 && fast && !a.sp_val && a.batch <= 1 && !a.pool_val) {
       const bool whole = a.stats != nullptr || EPI == SPGAN_EPI_BNBWD;  // column statistics: one workgroup walks all rows of its columns
@@ -1627,6 +1631,7 @@ extern "C" int spgan_fanin_groups(int tiles) { return tiles > 0 ? fanin::group_c
 
 // N-tile width launch_nt picks for this problem (must mirror launch_nt)
 static int nt_tile_n(const spgan_gemm_nt_args& a) {
+  if (spgan_nt_wide_selected(a)) return 256;
   const bool fast = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A) && al16(a.W);
   if (a.mfma_f16 == 2 && fast && a.N > 32 && !a.sp_val) return 64;
   if (a.mfma_f16 == 1 && fast && a.N > 32 && !a.sp_val) return (a.N > 64 && a.K >= 512) ? 128 : 64;

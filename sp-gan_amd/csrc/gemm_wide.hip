@@ -1,0 +1,375 @@
+// gemm_nt for the large aligned products of the train step (M % 256 == 0, N % 256 == 0, K % 32 == 0, 16-byte aligned rows):
+// 256 x 256 output tiles, 512 threads.
+//
+// Why a second geometry.  The 128-row kernels of gemm.hip run at a clock the chip's power limit sets (~1.8 GHz instead of 2.4 under
+// fp32 MFMA load), so what a product costs is decided by the energy spent per MFMA besides the MFMA itself: LDS
+// fragment reads, LDS stores and L2 -> LDS operand traffic.  Here
+//   * 8 waves as 2 (rows) x 4 (columns), each owning 128 x 64 of the tile (4 x 2 MFMA tiles of 32x32, 128 accumulator registers):
+//     6 fragment reads feed 16 MFMAs (0.375 LDS reads per MFMA, 0.5-0.75 in the 128-row kernels);
+//   * every operand element is fetched once per 256 columns/rows of the other operand (128 or 64 before): half the L2 and
+//     LDS-store traffic per FLOP;
+//   * a wave's 128 rows are exactly one statistics / pooling record tile (the [M/128, N, 2] records of spgan_hip.h): the epilogue
+//     needs no exchange between waves -- lane halves merge by one shuffle, nothing goes through LDS, no barrier after the k-loop.
+// One workgroup per CU (139 KB of double-buffered LDS tiles, k-tiles of 32, one barrier per k-tile), two waves per SIMD (<= 256 VGPRs).
+// Measured against the 128-row kernels on MI355X (tools/exp/run_gemm_v3.py, same launch loop): D.fc2.0 (65536 x 1024 x 256 with
+// BatchNorm+LeakyReLU prologue, statistics + pooling epilogue, output not stored) 370 -> 280 us; 65536 x 256 x 256: 97 -> 73 us.
+//
+// Only straight-line code: shapes that do not tile exactly, reduced-precision operand modes, the per-edge prologue/epilogue and the
+// in-launch fan-in stay with gemm.hip (launch_nt falls through).
+#include "gemm_wide.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int WM = 256, WN = 256, WK = 32, WLD = WK + 2;  // row stride 34 words == 2 (mod 32): conflict-free 8-byte fragment reads
+constexpr int WTHREADS = 512;
+constexpr int WGN = 4;           // waves along N (x 2 along M)
+constexpr int TI = 4, TJ = 2;    // MFMA tiles per wave
+constexpr int SLOTS = 4;         // float4 staging slots per thread and operand: 256 rows x 8 float4 / 512 threads
+constexpr int RPP = 64;          // rows staged by one pass of the workgroup
+constexpr size_t WIDE_LDS = (size_t)2 * (WM + WN) * WLD * sizeof(float);
+
+#define ROFF(r) (((r) & 3) + 8 * ((r) >> 2))
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_gemm_nt_args p_) {
+  const spgan_gemm_nt_args& p = p_;  // stays in the kernarg segment (scalar loads)
+  constexpr bool affine = AMODE != SPGAN_A_PLAIN;
+  constexpr bool sparse = AMODE == SPGAN_WIDE_A_SPARSE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][WM*WLD]
+  float* Bs = smem + 2 * WM * WLD;  // [2][WN*WLD]
+
+  const int tilesN = p.N / WN, tilesM = p.M / WM;
+  const int id = blockIdx.x, xcd = id & 7, t = id >> 3;  // XCD-aware: all N-tiles of one M-tile share an L2
+  const int tn = t % tilesN, tm = xcd + 8 * (t / tilesN);
+  if (tm >= tilesM) return;
+  const int m0 = tm * WM, n0 = tn * WN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[SLOTS], rb[SLOTS];
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  int4 spa = make_int4(-1, -1, -1, -1);
+  float4 spv = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+  // 32-bit element offsets (host: M*lda, N*ldw < 2^32): scalar base + 32-bit offset addressing
+  const unsigned oa = (unsigned)(m0 + lrow) * (unsigned)p.lda + (unsigned)lc4, sa = (unsigned)RPP * (unsigned)p.lda;
+  const unsigned ow = (unsigned)(n0 + lrow) * (unsigned)p.ldw + (unsigned)lc4, sw = (unsigned)RPP * (unsigned)p.ldw;
+  const int sp_b = sparse ? m0 / p.sp_rows : 0;  // the whole tile lies in one shape (host: sp_rows % 256 == 0)
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) ra[i] = *reinterpret_cast<const float4*>(p.A + (oa + (unsigned)i * sa + (unsigned)k0));
+    if (affine) {
+      psc = *reinterpret_cast<const float4*>(p.p_scale + k0 + lc4);
+      psh = *reinterpret_cast<const float4*>(p.p_shift + k0 + lc4);
+    }
+    if (sparse) {
+      const size_t off = (size_t)sp_b * p.K + k0 + lc4;
+      spa = *reinterpret_cast<const int4*>(p.sp_arg + off);
+      spv = *reinterpret_cast<const float4*>(p.sp_val + off);
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) rb[i] = *reinterpret_cast<const float4*>(p.W + (ow + (unsigned)i * sw + (unsigned)k0));
+  };
+  // The prologue transform runs here, after the current tile's first MFMAs were issued: transforming at load time would put a
+  // vmcnt wait in front of them.
+  auto sstore = [&](int buf) {
+    float* a = As + buf * WM * WLD + lrow * WLD + lc4;
+    float* b = Bs + buf * WN * WLD + lrow * WLD + lc4;
+    if (affine) {
+      const float sl = p.p_slope;
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        ra[i].x = lrelu_f(fmaf(ra[i].x, psc.x, psh.x), sl);
+        ra[i].y = lrelu_f(fmaf(ra[i].y, psc.y, psh.y), sl);
+        ra[i].z = lrelu_f(fmaf(ra[i].z, psc.z, psh.z), sl);
+        ra[i].w = lrelu_f(fmaf(ra[i].w, psc.w, psh.w), sl);
+      }
+    }
+    if (sparse) {
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        const int m = m0 + lrow + RPP * i;
+        ra[i].x += (spa.x == m) ? spv.x : 0.f;
+        ra[i].y += (spa.y == m) ? spv.y : 0.f;
+        ra[i].z += (spa.z == m) ? spv.z : 0.f;
+        ra[i].w += (spa.w == m) ? spv.w : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      *reinterpret_cast<float2*>(a + i * RPP * WLD) = make_float2(ra[i].x, ra[i].y);
+      *reinterpret_cast<float2*>(a + i * RPP * WLD + 2) = make_float2(ra[i].z, ra[i].w);
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      *reinterpret_cast<float2*>(b + i * RPP * WLD) = make_float2(rb[i].x, rb[i].y);
+      *reinterpret_cast<float2*>(b + i * RPP * WLD + 2) = make_float2(rb[i].z, rb[i].w);
+    }
+  };
+  // One lane's 8-byte read feeds the k-operands of two consecutive MFMAs (any permutation of k inside a tile is legal as long as
+  // both operands agree).
+  auto compute = [&](int buf, int kk0, int kk1) {
+    const float* a = As + buf * WM * WLD + (wm * TI * 32 + l31) * WLD + 2 * lh;
+    const float* b = Bs + buf * WN * WLD + (wn * TJ * 32 + l31) * WLD + 2 * lh;
+#pragma unroll
+    for (int kk = kk0; kk < kk1; ++kk) {
+      float2 af[TI], bf[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float2*>(a + i * 32 * WLD + kk * 4);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float2*>(b + j * 32 * WLD + kk * 4);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+    }
+  };
+
+  constexpr int KK = WK / 4;
+  const int nk = p.K / WK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * WK);  // next tile's loads fly under this tile's MFMAs
+    compute(kt & 1, 0, KK / 2);
+    if (kt + 1 < nk) sstore((kt + 1) & 1);  // into the other buffer: its last readers passed the previous barrier
+    compute(kt & 1, KK / 2, KK);
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue (C/D layout: col = lane&31, row = ROFF(r) + 4*(lane>>5))
+  const int rbase = m0 + wm * (TI * 32) + 4 * lh;
+  const int cbase = n0 + wn * (TJ * 32) + l31;
+  const int rec = (m0 >> 7) + wm;      // the 128-row record tile this wave's rows form
+  constexpr float NL = (float)(16 * TI);  // rows a lane holds per column
+
+  if constexpr (EPI == SPGAN_EPI_LINEAR) {
+    const bool rb_dense = p.rowbias && p.rows_per_group == 1;
+    const bool rb_group = p.rowbias && p.rows_per_group > 1;  // host: rows_per_group % 256 == 0 -> one group per tile
+    const int g0 = rb_group ? m0 / p.rows_per_group : 0;
+    float csum[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      float b = p.bias ? p.bias[cbase + j * 32] : 0.f;
+      if (rb_group) b += p.rowbias[(size_t)g0 * p.ld_rowbias + cbase + j * 32];
+      csum[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        if (rb_dense) {
+          const float* ab = p.rowbias + (size_t)(rbase + i * 32) * p.ld_rowbias + cbase + j * 32;
+          const unsigned ld2 = (unsigned)p.ld_rowbias;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += ab[(unsigned)ROFF(r) * ld2];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r] + b;
+          acc[i][j][r] = v;  // pre-activation value: what the statistics and the pooling see
+          csum[j] += v;
+        }
+      }
+    }
+    if (p.Y) {
+      float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
+      const unsigned ldy = (unsigned)p.ldy;
+      auto store_all = [&](auto actf) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = actf(acc[i][j][r]);
+      };
+      if (p.act == SPGAN_ACT_LRELU) {
+        const float sl = p.act_slope;
+        store_all([sl](float v) { return lrelu_f(v, sl); });
+      } else if (p.act == SPGAN_ACT_TANH) {
+        store_all([](float v) { return tanhf(v); });
+      } else {
+        store_all([](float v) { return v; });
+      }
+    }
+    if (p.stats || p.pool_val) {
+      // every lane holds NL rows of a column: (sum, M2 about the lane's own mean), merged with the other lane half by Chan's formula
+      const bool do_pool = p.pool_val != nullptr;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const float sl = csum[j], mean = sl * (1.f / NL);
+        float m2 = 0.f, vx = -INFINITY, vn = INFINITY;
+        int ax = 0x7fffffff, an = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            const float d = v - mean;
+            m2 = fmaf(d, d, m2);
+            if (do_pool) {  // rows ascend with (i, r): strict compares keep the first
+              const int row = rbase + i * 32 + ROFF(r);
+              if (v > vx) { vx = v; ax = row; }
+              if (v < vn) { vn = v; an = row; }
+            }
+          }
+        const float so = __shfl_xor(sl, 32), m2o = __shfl_xor(m2, 32);
+        const float dl = (so - sl) * (1.f / NL);
+        const float S = sl + so, M2 = (m2 + m2o) + dl * dl * (0.5f * NL);
+        if (do_pool) {
+          const float ovx = __shfl_xor(vx, 32), ovn = __shfl_xor(vn, 32);
+          const int oax = __shfl_xor(ax, 32), oan = __shfl_xor(an, 32);
+          if (ovx > vx || (ovx == vx && oax < ax)) { vx = ovx; ax = oax; }
+          if (ovn < vn || (ovn == vn && oan < an)) { vn = ovn; an = oan; }
+        }
+        if (lh == 0) {
+          const size_t o = ((size_t)rec * p.N + cbase + j * 32) * 2;
+          if (p.stats) { p.stats[o] = S; p.stats[o + 1] = M2; }
+          if (do_pool) {
+            p.pool_val[o] = vx; p.pool_val[o + 1] = vn;
+            p.pool_arg[o] = ax; p.pool_arg[o + 1] = an;
+          }
+        }
+      }
+    }
+  } else if constexpr (EPI == SPGAN_EPI_MASK_OUT) {
+    const float* rb = p.ref + (size_t)rbase * p.ld_ref + cbase;
+    float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
+    const unsigned ldr = (unsigned)p.ld_ref, ldy = (unsigned)p.ldy;
+    const float sl = p.b_slope;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = rb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldr + (unsigned)(j * 32))];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = acc[i][j][r] * lrelu_mask(rv[r], sl);
+      }
+  } else {  // SPGAN_EPI_BNBWD
+    const float* rb = p.ref + (size_t)rbase * p.ld_ref + cbase;
+    float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
+    const unsigned ldr = (unsigned)p.ld_ref, ldy = (unsigned)p.ldy;
+    const float sl = p.b_slope;
+    const float* ab = p.rowbias ? p.rowbias + (size_t)rbase * p.ld_rowbias + cbase : nullptr;  // host: rows_per_group == 1 (dense addend)
+    const unsigned ld2 = (unsigned)p.ld_rowbias;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = cbase + j * 32;
+      const float sc = p.b_scale[col], sh = p.b_shift[col], mu = p.b_mean[col], inv = p.b_invstd[col];
+      const float bia = p.bias ? p.bias[col] : 0.f;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        float yv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[r] = rb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldr + (unsigned)(j * 32))];
+        if (ab) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += ab[(size_t)((unsigned)(i * 32 + ROFF(r)) * ld2 + (unsigned)(j * 32))];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float y = yv[r];
+          const float z = fmaf(y, sc, sh);
+          const float g = (acc[i][j][r] + bia) * lrelu_mask(z, sl);
+          const float xh = (y - mu) * inv;
+          yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = g;
+          s0 += g;
+          s1 = fmaf(g, xh, s1);
+        }
+      }
+      if (p.stats) {
+        s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 32);
+        if (lh == 0) {
+          float* o = p.stats + ((size_t)rec * p.N + col) * 2;
+          o[0] = s0; o[1] = s1;
+        }
+      }
+    }
+  }
+}
+
+template <int AMODE, int EPI>
+int launch(const spgan_gemm_nt_args& a, hipStream_t s) {
+  static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_wide_kernel<AMODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS);
+    attr_set = true;
+  }
+  const int tm8 = cdiv(a.M / WM, 8) * 8;
+  hipLaunchKernelGGL((gemm_nt_wide_kernel<AMODE, EPI>), dim3(tm8 * (a.N / WN)), dim3(WTHREADS), WIDE_LDS, s, a);
+  return spgan_launch_status();
+}
+
+template <int AMODE>
+int launch_epi(const spgan_gemm_nt_args& a, hipStream_t s) {
+  switch (a.epi_mode) {
+    case SPGAN_EPI_LINEAR: return launch<AMODE, SPGAN_EPI_LINEAR>(a, s);
+    case SPGAN_EPI_MASK_OUT: return AMODE == SPGAN_A_PLAIN ? launch<SPGAN_A_PLAIN, SPGAN_EPI_MASK_OUT>(a, s) : SPGAN_EINVAL;
+    case SPGAN_EPI_BNBWD: return launch<AMODE, SPGAN_EPI_BNBWD>(a, s);
+  }
+  return SPGAN_EINVAL;
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+bool spgan_nt_wide_eligible(const spgan_gemm_nt_args& a) {
+  if (a.M < WM || a.M % WM || a.N % WN || a.K % WK || a.K < WK) return false;
+  if (a.mfma_f16 != 0 || a.fin.enabled || a.batch > 1) return false;
+  if (a.a_mode == SPGAN_A_EDGE || a.epi_mode == SPGAN_EPI_EDGE_BNBWD) return false;
+  if (a.lda % 4 || a.ldw % 4 || !al16(a.A) || !al16(a.W)) return false;
+  if (a.a_mode != SPGAN_A_PLAIN && (!al16(a.p_scale) || !al16(a.p_shift))) return false;
+  if (a.sp_val) {
+    if (a.a_mode != SPGAN_A_AFFINE_LRELU || a.sp_rows % WM || !al16(a.sp_val) || !al16(a.sp_arg)) return false;
+  }
+  if (a.epi_mode == SPGAN_EPI_LINEAR) {
+    if (a.rowbias && a.rows_per_group != 1 && a.rows_per_group % WM) return false;
+    if (!a.Y && !a.stats && !a.pool_val) return false;
+  } else {
+    if (a.epi_mode == SPGAN_EPI_MASK_OUT && a.a_mode != SPGAN_A_PLAIN) return false;
+    if (a.epi_mode == SPGAN_EPI_BNBWD && a.rowbias && a.rows_per_group != 1) return false;
+    if (a.epi_mode == SPGAN_EPI_MASK_OUT && (a.bias || a.rowbias)) return false;
+  }
+  return true;
+}
+
+// Measured inside the train step (tools/mfma_shapes.py, MI355X): one workgroup per CU means a launch whose tiles make a single round
+// runs its load / MFMA / epilogue phases in lockstep on all CUs -- with a heavy epilogue (the BatchNorm-backward one reads and writes
+// [M,N]) that costs what the leaner main loop gains (65536 x 256 x 256: 103 -> 107 us), and k-loops of two tiles are all ramp
+// (K = 64: 40 -> 45 us).  Wins: 65536 x 1024 x 256 + statistics/pooling 327 -> 300 us, 65536 x 256 x 128: 57 -> 54, 65536 x 1280 x 128: 224 -> 214.
+bool spgan_nt_wide_pays(const spgan_gemm_nt_args& a) {
+  const long tiles = (long)(a.M / WM) * (a.N / WN);
+  if (tiles < 256 || a.K < 128) return false;
+  return a.epi_mode == SPGAN_EPI_LINEAR || tiles >= 512;
+}
+
+bool spgan_nt_wide_selected(const spgan_gemm_nt_args& a) {
+  static const bool off = getenv("SPGAN_NT_WIDE") && atoi(getenv("SPGAN_NT_WIDE")) == 0;
+  if (off || a.tile_hint == 1 || !spgan_nt_wide_eligible(a)) return false;
+  return a.tile_hint == 2 || spgan_nt_wide_pays(a);
+}
+
+int spgan_launch_nt_wide(const spgan_gemm_nt_args& a, hipStream_t s) {
+  if (a.a_mode == SPGAN_A_PLAIN) return launch_epi<SPGAN_A_PLAIN>(a, s);
+  if (a.sp_val) return launch_epi<SPGAN_WIDE_A_SPARSE>(a, s);
+  return launch_epi<SPGAN_A_AFFINE_LRELU>(a, s);
+}

@@ -1,0 +1,12 @@
+// 256 x 256-tile gemm_nt for large aligned products (gemm_wide.hip); launch_nt (gemm.hip) routes eligible problems here.
+#pragma once
+#include "common.hpp"
+
+constexpr int SPGAN_WIDE_A_SPARSE = 3;  // internal operand mode: A_AFFINE_LRELU with the sparse addend (sp_val != NULL)
+
+bool spgan_nt_wide_eligible(const spgan_gemm_nt_args& a);  // the kernel can run this problem
+bool spgan_nt_wide_pays(const spgan_gemm_nt_args& a);      // ... and is expected to be faster than the 128-row kernels (tile_hint 0)
+// what launch_nt does: tile_hint 1 -> never, 2 -> when eligible, 0 -> when eligible and expected to pay; the environment variable
+// SPGAN_NT_WIDE=0 (read once) turns the kernel off altogether (A/B measurements of whole programs)
+bool spgan_nt_wide_selected(const spgan_gemm_nt_args& a);
+int spgan_launch_nt_wide(const spgan_gemm_nt_args& a, hipStream_t s);

@@ -46,6 +46,7 @@ class GemmNTArgs(C.Structure):
         ("mfma_f16", C.c_int),
         ("batch", C.c_int), ("batch_stride_a", C.c_long), ("batch_stride_w", C.c_long), ("batch_stride_y", C.c_long),
         ("fin", FanIn),
+        ("tile_hint", C.c_int),
     ]
 
 

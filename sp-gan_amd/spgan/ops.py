@@ -101,6 +101,27 @@ def get_mfma_operands() -> str:
     return {v: k for k, v in _MFMA_KINDS.items()}[_MFMA_F16[0]]
 
 
+# gemm_nt tile geometry (spgan_gemm_nt_args.tile_hint): 0 automatic, 1 the 128-row kernels only, 2 the 256 x 256-tile kernel
+# (csrc/gemm_wide.hip) whenever the problem is eligible.  1 / 2 are for tests and A/B measurements.
+_NT_TILE_HINT = [0]
+
+
+class nt_tile_hint:
+    """with ops.nt_tile_hint(2): ...   -- every gemm_nt launch inside uses the given tile_hint."""
+
+    def __init__(self, hint: int):
+        if hint not in (0, 1, 2):
+            raise ValueError("tile_hint must be 0, 1 or 2")
+        self.hint = hint
+
+    def __enter__(self):
+        self.prev = _NT_TILE_HINT[0]
+        _NT_TILE_HINT[0] = self.hint
+
+    def __exit__(self, *exc):
+        _NT_TILE_HINT[0] = self.prev
+
+
 # Bumped by every optimiser step that rewrites parameters through a HIP kernel (invisible to torch's version counters);
 # host-side caches of weight-derived tensors (nets._t) key on it.
 WEIGHTS_EPOCH = [0]
@@ -276,7 +297,7 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
     column sums: they grow with B*N and leave fp16's range at full size) rather than per-point activations."""
     _rowmajor2d(A, "A"); _rowmajor2d(W, "W")
     N, K = W.shape
-    a = GemmNTArgs(); a.mfma_f16 = 0 if exact else _MFMA_F16[0]
+    a = GemmNTArgs(); a.mfma_f16 = 0 if exact else _MFMA_F16[0]; a.tile_hint = _NT_TILE_HINT[0]
     if edge is not None:
         idx, ebias = edge
         _i32(idx, "idx")
@@ -367,7 +388,7 @@ def gemm_nt_batched(A: Tensor, W: Tensor, out: Optional[Tensor] = None) -> Tenso
         out = torch.empty((Z, M_, N), dtype=torch.float32, device=A.device)
     elif tuple(_batched3d(out, "out").shape) != (Z, M_, N):
         raise ValueError("out must be [%d,%d,%d], got %s" % (Z, M_, N, tuple(out.shape)))
-    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]
+    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]; a.tile_hint = _NT_TILE_HINT[0]
     a.A = _p(A); a.lda = A.stride(1); a.W = _p(W); a.ldw = W.stride(1); a.Y = _p(out); a.ldy = out.stride(1)
     a.M, a.N, a.K = M_, N, K
     a.a_mode = A_PLAIN; a.epi_mode = EPI_LINEAR; a.act = ACT_NONE
@@ -387,7 +408,7 @@ def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float, with_colsum
     N, K = W.shape
     M_ = A.shape[0]
     Y = torch.empty((M_, N), dtype=torch.float32, device=A.device)
-    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]
+    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]; a.tile_hint = _NT_TILE_HINT[0]
     a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W); a.Y = _p(Y); a.ldy = N
     a.M, a.N, a.K = M_, N, K
     a.a_mode = A_PLAIN; a.epi_mode = EPI_MASK_OUT
@@ -467,7 +488,7 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
     g = torch.empty((M_, N), dtype=torch.float32, device=A.device)
     tiles = (M_ + ROW_TILE - 1) // ROW_TILE
     part = torch.empty((tiles, N, 2), dtype=torch.float32, device=A.device)
-    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]
+    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]; a.tile_hint = _NT_TILE_HINT[0]
     a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W); a.Y = _p(g); a.ldy = N
     a.M, a.N, a.K = M_, N, K
     a.a_mode = A_PLAIN
@@ -757,7 +778,7 @@ def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, sl
     B = M_ // rows
     tiles = M_ // ROW_TILE
     dev = A.device
-    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]
+    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]; a.tile_hint = _NT_TILE_HINT[0]
     a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W)
     Y = torch.empty((M_, N), dtype=torch.float32, device=dev) if keep_y else None
     a.Y = _p(Y); a.ldy = N

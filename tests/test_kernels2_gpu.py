@@ -123,6 +123,29 @@ def test_sparse_affine_operand(ops):
     close(ops.gemm_tn(sa2, Bm), km.gemm_tn(d2, Bm), rtol=5e-5, what="tn.sparse_affine.unaligned")
 
 
+def test_sparse_affine_operand_wide_tiles(ops):
+    """The same lazily evaluated operand through the 256 x 256-tile kernel (tile_hint 2; shapes = whole tiles, 256-row shapes)."""
+    B, N, C, Cp = 3, 256, 256, 256
+    M = B * N
+    y = rnd("saw.y", (M, C)) * 2
+    mean, var = km.colstats(y, M)
+    gamma, beta = rnd("saw.g", (C,)).abs() + 0.5, rnd("saw.b", (C,), 0.2)
+    sc, sh, inv, mu = km.bn_prepare(mean[0], var[0], gamma, beta, M)
+    pooled, arg = km.maxpool(y, B, N, sc, sh, 0.01)
+    gval, sums = km.pool_bwd_stats(rnd("saw.gp", (B, C)), pooled, arg, y, mu, inv, 0.01)
+    dense = km.bn_bwd_apply_sparse(gval, arg, y, N, mu, inv, gamma, sums, M)
+    sa = ops.sparse_bn_bwd_operand(gval, arg, y, N, mu, inv, gamma, sums, M)
+    W = rnd("saw.W", (Cp, C), 0.2)
+    yref = rnd("saw.yref", (M, Cp))
+    psc, psh = rnd("saw.psc", (Cp,)).abs() + 0.5, rnd("saw.psh", (Cp,), 0.3)
+    m2, i2 = rnd("saw.m2", (Cp,), 0.2), rnd("saw.i2", (Cp,)).abs() + 0.5
+    want = km.gemm_nt_bnbwd(dense, W, yref, psc, psh, m2, i2, 0.01)
+    for hint in (1, 2):
+        with ops.nt_tile_hint(hint):
+            for a, b in zip(ops.gemm_nt_bnbwd(sa, W, yref, psc, psh, m2, i2, 0.01), want):
+                close(a, b, rtol=5e-5, atol=2e-4, what="nt_bnbwd.sparse_affine hint %d" % hint)
+
+
 def test_double_backward_helpers(ops):
     M, C = 700, 96
     u, y, gz = rnd("db.u", (M, C)), rnd("db.y", (M, C)) * 2, rnd("db.gz", (M, C))

@@ -246,11 +246,34 @@ def test_bn_and_pool(ops):
     assert torch.equal(out, out2) and torch.equal(arg, arg2)
 
 
+def _col_blocks(ops, A, W, hint):
+    """N-tiles spgan_gemm_nt would use for a plain product of these operands under the given tile_hint"""
+    from spgan import _lib
+    import ctypes as C
+    a = _lib.GemmNTArgs()
+    a.A = A.data_ptr(); a.lda = A.stride(0); a.W = W.data_ptr(); a.ldw = W.stride(0); a.M, a.N, a.K = A.shape[0], W.shape[0], A.shape[1]
+    a.Y = A.data_ptr(); a.ldy = W.shape[0]; a.tile_hint = hint
+    return _lib.load().spgan_gemm_nt_col_blocks(C.byref(a))
+
+
+@pytest.mark.parametrize("hint", [0, 2])
 @pytest.mark.parametrize("M,N,K", [(128, 64, 32), (129, 65, 36), (1024, 256, 256), (1000, 192, 132), (4096, 1024, 256), (640, 320, 64), (2048, 64, 640),
-                                   (257, 128, 1280), (65, 33, 8)])
-def test_gemm_nt_full_and_partial_tiles(ops, M, N, K):
+                                   (257, 128, 1280), (65, 33, 8), (512, 256, 128), (768, 512, 64), (2304, 256, 32)])
+def test_gemm_nt_full_and_partial_tiles(ops, M, N, K, hint):
     """Every epilogue on shapes whose output tiles are all inside, all ragged, or mixed (the straight-line path serves the inside
-    tiles, the generic path the rest -- both must agree with the model on the same launch), operands as column slices."""
+    tiles, the generic path the rest -- both must agree with the model on the same launch), operands as column slices.
+    hint = 2: the 256 x 256-tile kernel (csrc/gemm_wide.hip) wherever the shape is eligible -- the same checks against the same models."""
+    wide = M % 256 == 0 and N % 256 == 0 and K % 32 == 0
+    if hint == 2 and not wide:
+        pytest.skip("not a 256 x 256-tile shape")
+    with ops.nt_tile_hint(hint):
+        if hint == 2:
+            wA, wW = rnd("ft.A%d%d" % (M, K), (M, K + 8)), rnd("ft.W%d%d" % (N, K), (N, K + 4), 0.1)
+            assert _col_blocks(ops, wA[:, 4:4 + K], wW[:, :K], 2) == N // 256 and _col_blocks(ops, wA[:, 4:4 + K], wW[:, :K], 1) > N // 256
+        _full_and_partial_tiles(ops, M, N, K)
+
+
+def _full_and_partial_tiles(ops, M, N, K):
     wideA, wideW = rnd("ft.A%d%d" % (M, K), (M, K + 8)), rnd("ft.W%d%d" % (N, K), (N, K + 4), 0.1)
     A, W = wideA[:, 4:4 + K], wideW[:, :K]
     b = rnd("ft.b%d" % N, (N,))

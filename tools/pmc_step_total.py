@@ -51,7 +51,7 @@ def main():
     mu = defaultdict(lambda: [0.0, 0.0, 0])
     for n, v, g, ns in mfma:
         k = short(n)
-        if any(t in k for t in ("gemm_nt_kernel", "gemm_tn_kernel", "knn_mfma")):
+        if any(t in k for t in ("gemm_nt_kernel", "gemm_nt_wide_kernel", "gemm_tn_kernel", "knn_mfma")):
             mu[k][0] += v * ns; mu[k][1] += ns; mu[k][2] += 1
     tw_num = sum(v[0] for v in mu.values()); tw_den = sum(v[1] for v in mu.values())
     mlist = [{"kernel": k, "MfmaUtil_pct_time_weighted": round(v[0] / max(v[1], 1), 1), "ms_per_step": round(v[1] / steps / 1e6, 3),
