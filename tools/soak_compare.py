@@ -9,6 +9,7 @@ import torch
 import bench, spgan
 steps = int(sys.argv[1]); out = sys.argv[2]
 dev = torch.device("cuda", 0)
+spgan.ops.set_mfma_operands(os.environ.get("SPGAN_MFMA", "f32"))        # "bf16x3": fp32-equivalent products in another summation order
 G, D = bench.build_models(dev)
 tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, graph=True)
 from spgan import fixture_rng as fr
