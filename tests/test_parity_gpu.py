@@ -98,14 +98,18 @@ def test_adain_golden(sp):
 
 
 # ---------------------------------------------------------------- Discriminator (G5, G7)
-def test_discriminator_golden(sp):
+@pytest.mark.parametrize("hint", [0, 2])
+def test_discriminator_golden(sp, hint):
+    """hint 2: every eligible product (the 128->256 and the fused 256->1024 layer, their input gradients) through the 256 x 256-tile
+    kernel of csrc/gemm_wide.hip -- at this size the automatic rule would not pick it; same golden, same tolerances."""
     d = golden("g5_discriminator.npz")
     B, N = 4, 256
     D = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=4)).train()
     real = fr.synthetic_real(B, N, seed=5).transpose(2, 1).contiguous().cuda().requires_grad_(True)
-    logit = D(real)
-    check(d, "logit", logit, rtol=2e-6)                                         # measured 4.4e-7
-    ((logit - 1.0) ** 2).mean().backward()
+    with sp.ops.nt_tile_hint(hint):
+        logit = D(real)
+        check(d, "logit", logit, rtol=2e-6)                                     # measured 4.4e-7
+        ((logit - 1.0) ** 2).mean().backward()
     check(d, "dx", real.grad, rtol=3e-6)                                         # measured 7.6e-7
     for n, p in D.named_parameters():
         check(d, "grad|" + n, p.grad, rtol=5e-6, atol=_atol(n))                  # measured <= 1.4e-6
@@ -113,16 +117,19 @@ def test_discriminator_golden(sp):
         np.testing.assert_allclose(b.cpu().numpy(), d["buf|" + n], rtol=1e-5, atol=1e-6)
 
 
-def test_gradient_penalty_golden(sp):
+@pytest.mark.parametrize("hint", [0, 2])
+def test_gradient_penalty_golden(sp, hint):
+    """hint 2: the double backward with the 256 x 256-tile kernel wherever a product is eligible (M = 768 = three row tiles)."""
     d = golden("g7_gradient_penalty.npz")
     B, N = 3, 256
     D = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=7)).train()
     real = fr.synthetic_real(B, N, seed=71).transpose(2, 1).contiguous().cuda()
     fake = (0.8 * fr.synthetic_real(B, N, seed=72) + 0.05 * fr.normal("g7.n", (B, N, 3))).transpose(2, 1).contiguous().cuda()
     alpha = torch.from_numpy(d["alpha"]).cuda()
-    gp = sp.GradientPenalty(10.0, gamma=1)(D, real, fake, alpha=alpha)
-    np.testing.assert_allclose(gp.item(), float(d["gp"]), rtol=1e-5)
-    gp.backward()
+    with sp.ops.nt_tile_hint(hint):
+        gp = sp.GradientPenalty(10.0, gamma=1)(D, real, fake, alpha=alpha)
+        np.testing.assert_allclose(gp.item(), float(d["gp"]), rtol=1e-5)
+        gp.backward()
     for n, p in D.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         check(d, "grad|" + n, g, rtol=5e-6, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)    # double backward: measured <= 1.1e-6
