@@ -11,8 +11,8 @@
 //   * a wave's 128 rows are exactly one statistics / pooling record tile (the [M/128, N, 2] records of spgan_hip.h): the epilogue
 //     needs no exchange between waves -- lane halves merge by one shuffle, nothing goes through LDS, no barrier after the k-loop.
 // One workgroup per CU (139 KB of double-buffered LDS tiles, k-tiles of 32, one barrier per k-tile), two waves per SIMD (<= 256 VGPRs).
-// Measured against the 128-row kernels on MI355X (tools/exp/run_gemm_v3.py, same launch loop): D.fc2.0 (65536 x 1024 x 256 with
-// BatchNorm+LeakyReLU prologue, statistics + pooling epilogue, output not stored) 370 -> 280 us; 65536 x 256 x 256: 97 -> 73 us.
+// Measured on MI355X inside the train step (tools/mfma_shapes.py, same box): D.fc2.0 (65536 x 1024 x 256 with BatchNorm+LeakyReLU
+// prologue, statistics + pooling epilogue, output not stored) 327 -> 300 us = 73 % of the fp32 MFMA peak.
 //
 // Only straight-line code: shapes that do not tile exactly, reduced-precision operand modes, the per-edge prologue/epilogue and the
 // in-launch fan-in stay with gemm.hip (launch_nt falls through).
