@@ -14,11 +14,13 @@
 // Measured on MI355X inside the train step (tools/mfma_shapes.py, same box): D.fc2.0 (65536 x 1024 x 256 with BatchNorm+LeakyReLU
 // prologue, statistics + pooling epilogue, output not stored) 327 -> 300 us = 73 % of the fp32 MFMA peak.
 //
-// Only straight-line code: shapes that do not tile exactly, reduced-precision operand modes, the per-edge prologue/epilogue and the
-// in-launch fan-in stay with gemm.hip (launch_nt falls through).
+// Only straight-line code: shapes that do not tile exactly, the split-bf16 operand mode, the per-edge prologue/epilogue and the
+// in-launch fan-in stay with gemm.hip (launch_nt falls through).  fp16 operands (mfma_f16 == 1) are served here: D.fc2.0 114 -> 99 us.
 #include "gemm_wide.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -28,18 +30,28 @@ constexpr int WGN = 4;           // waves along N (x 2 along M)
 constexpr int TI = 4, TJ = 2;    // MFMA tiles per wave
 constexpr int SLOTS = 4;         // float4 staging slots per thread and operand: 256 rows x 8 float4 / 512 threads
 constexpr int RPP = 64;          // rows staged by one pass of the workgroup
-constexpr size_t WIDE_LDS = (size_t)2 * (WM + WN) * WLD * sizeof(float);
+constexpr int WLDH = WK / 2 + 2;  // fp16 operands: a row holds the 32 k-values as 16 words + 2 of padding (18 == 2 mod 16: conflict-free 8-byte reads)
+template <int F16> constexpr size_t wide_lds() { return (size_t)2 * (WM + WN) * (F16 ? WLDH : WLD) * sizeof(float); }
+
+// 4 consecutive k-values rounded to fp16 (round to nearest) into 2 LDS words
+__device__ __forceinline__ void st_row4h(float* p, float4 v) {
+  f32x4v f = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<f16x4*>(p) = __builtin_convertvector(f, f16x4);
+}
 
 #define ROFF(r) (((r) & 3) + 8 * ((r) >> 2))
 
-template <int AMODE, int EPI>
+// F16 = 1: the operands are rounded to fp16 when they are staged into LDS (after the fp32 prologue) and multiplied with
+// v_mfma_f32_32x32x8_f16, fp32 accumulation (spgan_gemm_nt_args.mfma_f16 == 1, BASELINE configs[4]); loads, prologues, epilogues fp32.
+template <int AMODE, int EPI, int F16>
 __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_gemm_nt_args p_) {
   const spgan_gemm_nt_args& p = p_;  // stays in the kernarg segment (scalar loads)
   constexpr bool affine = AMODE != SPGAN_A_PLAIN;
   constexpr bool sparse = AMODE == SPGAN_WIDE_A_SPARSE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                 // [2][WM*WLD]
-  float* Bs = smem + 2 * WM * WLD;  // [2][WN*WLD]
+  constexpr int LDX = F16 ? WLDH : WLD;  // LDS row stride in 4-byte words
+  float* As = smem;                 // [2][WM*LDX]
+  float* Bs = smem + 2 * WM * LDX;  // [2][WN*LDX]
 
   const int tilesN = p.N / WN, tilesM = p.M / WM;
   const int id = blockIdx.x, xcd = id & 7, t = id >> 3;  // XCD-aware: all N-tiles of one M-tile share an L2
@@ -85,8 +97,8 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_g
   // The prologue transform runs here, after the current tile's first MFMAs were issued: transforming at load time would put a
   // vmcnt wait in front of them.
   auto sstore = [&](int buf) {
-    float* a = As + buf * WM * WLD + lrow * WLD + lc4;
-    float* b = Bs + buf * WN * WLD + lrow * WLD + lc4;
+    float* a = As + buf * WM * LDX + lrow * LDX + (F16 ? (lc4 >> 1) : lc4);
+    float* b = Bs + buf * WN * LDX + lrow * LDX + (F16 ? (lc4 >> 1) : lc4);
     if (affine) {
       const float sl = p.p_slope;
 #pragma unroll
@@ -107,29 +119,48 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_g
         ra[i].w += (spa.w == m) ? spv.w : 0.f;
       }
     }
+    if (F16) {
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) {
-      *reinterpret_cast<float2*>(a + i * RPP * WLD) = make_float2(ra[i].x, ra[i].y);
-      *reinterpret_cast<float2*>(a + i * RPP * WLD + 2) = make_float2(ra[i].z, ra[i].w);
+      for (int i = 0; i < SLOTS; ++i) st_row4h(a + i * RPP * LDX, ra[i]);
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) st_row4h(b + i * RPP * LDX, rb[i]);
+      return;
     }
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
-      *reinterpret_cast<float2*>(b + i * RPP * WLD) = make_float2(rb[i].x, rb[i].y);
-      *reinterpret_cast<float2*>(b + i * RPP * WLD + 2) = make_float2(rb[i].z, rb[i].w);
+      *reinterpret_cast<float2*>(a + i * RPP * LDX) = make_float2(ra[i].x, ra[i].y);
+      *reinterpret_cast<float2*>(a + i * RPP * LDX + 2) = make_float2(ra[i].z, ra[i].w);
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      *reinterpret_cast<float2*>(b + i * RPP * LDX) = make_float2(rb[i].x, rb[i].y);
+      *reinterpret_cast<float2*>(b + i * RPP * LDX + 2) = make_float2(rb[i].z, rb[i].w);
     }
   };
   // One lane's 8-byte read feeds the k-operands of two consecutive MFMAs (any permutation of k inside a tile is legal as long as
   // both operands agree).
   auto compute = [&](int buf, int kk0, int kk1) {
-    const float* a = As + buf * WM * WLD + (wm * TI * 32 + l31) * WLD + 2 * lh;
-    const float* b = Bs + buf * WN * WLD + (wn * TJ * 32 + l31) * WLD + 2 * lh;
+    const float* a = As + buf * WM * LDX + (wm * TI * 32 + l31) * LDX + 2 * lh;
+    const float* b = Bs + buf * WN * LDX + (wn * TJ * 32 + l31) * LDX + 2 * lh;
 #pragma unroll
     for (int kk = kk0; kk < kk1; ++kk) {
+      if (F16) {  // one 8-byte read = 4 halfs = the lane's k-operands of ONE k = 8 MFMA
+        f16x4 ah[TI], bh[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) ah[i] = *reinterpret_cast<const f16x4*>(a + i * 32 * LDX + kk * 4);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bh[j] = *reinterpret_cast<const f16x4*>(b + j * 32 * LDX + kk * 4);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        continue;
+      }
       float2 af[TI], bf[TJ];
 #pragma unroll
-      for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float2*>(a + i * 32 * WLD + kk * 4);
+      for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float2*>(a + i * 32 * LDX + kk * 4);
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float2*>(b + j * 32 * WLD + kk * 4);
+      for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float2*>(b + j * 32 * LDX + kk * 4);
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -141,7 +172,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_g
     }
   };
 
-  constexpr int KK = WK / 4;
+  constexpr int KK = F16 ? WK / 8 : WK / 4;  // fragment reads per k-tile
   const int nk = p.K / WK;
   gload(0);
   sstore(0);
@@ -306,16 +337,22 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_g
   }
 }
 
-template <int AMODE, int EPI>
-int launch(const spgan_gemm_nt_args& a, hipStream_t s) {
+template <int AMODE, int EPI, int F16>
+int launch_op(const spgan_gemm_nt_args& a, hipStream_t s) {
+  constexpr size_t lds = wide_lds<F16>();
   static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_wide_kernel<AMODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_wide_kernel<AMODE, EPI, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int tm8 = cdiv(a.M / WM, 8) * 8;
-  hipLaunchKernelGGL((gemm_nt_wide_kernel<AMODE, EPI>), dim3(tm8 * (a.N / WN)), dim3(WTHREADS), WIDE_LDS, s, a);
+  hipLaunchKernelGGL((gemm_nt_wide_kernel<AMODE, EPI, F16>), dim3(tm8 * (a.N / WN)), dim3(WTHREADS), lds, s, a);
   return spgan_launch_status();
+}
+
+template <int AMODE, int EPI>
+int launch(const spgan_gemm_nt_args& a, hipStream_t s) {
+  return a.mfma_f16 == 1 ? launch_op<AMODE, EPI, 1>(a, s) : launch_op<AMODE, EPI, 0>(a, s);
 }
 
 template <int AMODE>
@@ -334,7 +371,8 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 bool spgan_nt_wide_eligible(const spgan_gemm_nt_args& a) {
   if (a.M < WM || a.M % WM || a.N % WN || a.K % WK || a.K < WK) return false;
-  if (a.mfma_f16 != 0 || a.fin.enabled || a.batch > 1) return false;
+  if ((a.mfma_f16 != 0 && a.mfma_f16 != 1) || a.fin.enabled || a.batch > 1) return false;  // fp32 or fp16 operands (not the split-bf16 mode)
+  if (a.mfma_f16 == 1 && a.sp_val) return false;                                              // the sparse addend is an fp32-operand path (gemm.hip: same rule)
   if (a.a_mode == SPGAN_A_EDGE || a.epi_mode == SPGAN_EPI_EDGE_BNBWD) return false;
   if (a.lda % 4 || a.ldw % 4 || !al16(a.A) || !al16(a.W)) return false;
   if (a.a_mode != SPGAN_A_PLAIN && (!al16(a.p_scale) || !al16(a.p_shift))) return false;

@@ -20,9 +20,17 @@ def f16(ops):
     ops.set_mfma_operands("f32")
 
 
+@pytest.mark.parametrize("hint", [0, 2])
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 128), (4096, 128, 1280), (1024, 1024, 256), (700, 64, 64), (512, 40, 36)])
-def test_gemm_nt_f16(f16, M, N, K):
-    ops = f16
+def test_gemm_nt_f16(f16, M, N, K, hint):
+    """hint 2: the same checks through the 256 x 256-tile kernel (csrc/gemm_wide.hip, fp16-operand instantiation) where the shape is eligible"""
+    if hint == 2 and (M % 256 or N % 256 or K % 32):
+        pytest.skip("not a 256 x 256-tile shape")
+    with f16.nt_tile_hint(hint):
+        _gemm_nt_f16(f16, M, N, K)
+
+
+def _gemm_nt_f16(ops, M, N, K):
     A, W, b = rnd("h.A%d" % K, (M, K)), rnd("h.W%d.%d" % (N, K), (N, K), 0.1), rnd("h.b%d" % N, (N,))
     ref = km.gemm_nt(A, W, b)
     close(ops.gemm_nt(A, W, b), ref, rtol=1e-3, what="plain")
