@@ -404,6 +404,13 @@ typedef struct spgan_multi_add_args {
   int n[SPGAN_MULTI_MAX];
 } spgan_multi_add_args;
 int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s);
+/* The local step of a ONE-HOP all-reduce of a flat gradient buffer over W ranks (on a fully connected xGMI node an
+ * all-to-all is one hop per pair, so reduce-scatter = all-to-all + this sum, all-gather = one more hop; 2 hops instead of a ring's
+ * 2(W-1) steps for the 2.3 / 3.9 MB latency-bound messages).  recv [parts, n] holds this rank's chunk as received from every rank
+ * (row j from rank j); out[i] = sum_j recv[j, i] in ascending j -- every chunk is summed exactly once, on one rank, in a fixed order, so
+ * all ranks end up with bit-identical sums.  recv and out 16-byte aligned.  The exchanges themselves are torch.distributed / RCCL
+ * (spgan.parallel.DataParallel(collective="one_hop")). */
+int spgan_reduce_chunks(const float* recv, int parts, size_t n, float* out, spgan_stream_t s);
 /* dst[t][i] = src[t][i] for the same argument block: up to SPGAN_MULTI_MAX device-to-device copies in ONE launch. */
 int spgan_multi_copy(const spgan_multi_add_args* a, spgan_stream_t s);
 /* Finish up to SPGAN_MULTI_MAX deferred spgan_gemm_tn products in one launch: C[e] = beta[e]*C[e] + fixed-order sum of the

@@ -632,6 +632,34 @@ extern "C" int spgan_rowscale_outer(const float* X, int ldx, int R, int C, const
   return spgan_launch_status();
 }
 
+// out[i] = sum_{j < parts} recv[j*n + i], j ascending: the local step of a one-hop all-reduce (every rank owns one chunk and has
+// received that chunk from all ranks).  Streaming: each thread sums `parts` float4 values with up to eight loads in flight.
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restrict__ recv, int parts, size_t n, float* __restrict__ out) {
+  const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 3 < n && (n & 3) == 0) {
+    float4 s = *reinterpret_cast<const float4*>(recv + i4);
+    for (int j = 1; j < parts; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(recv + (size_t)j * n + i4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i4) = s;
+  } else {
+    for (size_t i = i4; i < n && i < i4 + 4; ++i) {
+      float s = recv[i];
+      for (int j = 1; j < parts; ++j) s += recv[(size_t)j * n + i];
+      out[i] = s;
+    }
+  }
+}
+
+extern "C" int spgan_reduce_chunks(const float* recv, int parts, size_t n, float* out, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(recv && out && parts > 0 && n > 0);
+  SPGAN_CHECK_ARG((reinterpret_cast<uintptr_t>(recv) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)s_, recv, parts, n, out);
+  return spgan_launch_status();
+}
+
 extern "C" int spgan_axpby(float a, const float* x, float b, float* y, size_t n, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(x && y && n > 0);
   hipLaunchKernelGGL(axpby_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, a, x, b, y, n);

@@ -173,6 +173,7 @@ SIGNATURES = {
     "spgan_scale_residual_bwd_ws_bytes": (SZ, [SZ]),
     "spgan_scale_residual_bwd": (I, [P, P, P, P, P, P, SZ, SZ, P]),
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
+    "spgan_reduce_chunks": (I, [P, I, C.c_size_t, P, P]),
     "spgan_multi_copy": (I, [C.POINTER(MultiAddArgs), P]),
     "spgan_multi_transpose": (I, [C.POINTER(MultiTransposeArgs), P]),
     "spgan_gemm_tn_splits": (I, [I, I, I]),

@@ -1231,6 +1231,20 @@ def multi_add(dsts, srcs) -> None:
         check(lib.spgan_multi_add(C.byref(a), _s()), "multi_add", count=len(chunk))
 
 
+def reduce_chunks(recv: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """recv [parts, n] (contiguous) -> out[n] = sum over parts in ascending order (the local step of a one-hop all-reduce)."""
+    _f32(recv, "recv", 2)
+    if not recv.is_contiguous():
+        raise ValueError("recv must be contiguous [parts, n]")
+    parts, n = recv.shape
+    if out is None:
+        out = torch.empty((n,), dtype=torch.float32, device=recv.device)
+    elif out.numel() != n or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("out must be a contiguous fp32 tensor of %d elements" % n)
+    check(_lib.load().spgan_reduce_chunks(_p(recv), parts, n, _p(out), _s()), "reduce_chunks", parts=parts, n=n)
+    return out
+
+
 def multi_copy(dsts, srcs) -> None:
     """dst[t].copy_(src[t]) for a list of contiguous fp32 GPU tensor pairs of equal size in ceil(T/64) launches."""
     from ._lib import MULTI_MAX, MultiAddArgs

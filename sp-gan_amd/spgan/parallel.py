@@ -40,11 +40,21 @@ class DataParallel(nn.Module):
     forward() runs the local replica on the local shard; `allreduce_grads()` sums the flat gradient
     buffer over ranks; `sync_params()` broadcasts rank 0's parameters and buffers once at start."""
 
-    def __init__(self, module: nn.Module, process_group=None):
+    def __init__(self, module: nn.Module, process_group=None, collective: Optional[str] = None):
+        """collective: "all_reduce" (default: one dist.all_reduce of the flat buffer, RCCL picks the algorithm) or "one_hop": reduce-scatter as
+        ONE all-to-all (on a fully connected xGMI node every pair is one hop apart) + a local sum of the received chunks in rank order
+        (spgan_reduce_chunks) + one all-gather -- two hops for the 2.3 / 3.9 MB latency-bound gradient messages instead of a ring's
+        2(W-1) steps.  Both give every rank the same sums (one_hop: bit-identical on all ranks by construction).
+        Which is faster on an 8-GPU MI355X node is NOT measured (no multi-GPU box in this build's loop); the environment variable
+        SPGAN_DP_COLLECTIVE overrides the default for such a measurement."""
         super().__init__()
         self.module = module
         self.pg = process_group
         self.flat = flatten_module(module)
+        self.collective = collective or os.environ.get("SPGAN_DP_COLLECTIVE", "all_reduce")
+        if self.collective not in ("all_reduce", "one_hop"):
+            raise ValueError("collective must be 'all_reduce' or 'one_hop'")
+        self._hop = None             # (send [W, chunk], recv [W, chunk], mine [chunk], full [W*chunk]) staging buffers of the one-hop path
 
     @property
     def world_size(self) -> int:
@@ -63,8 +73,27 @@ class DataParallel(nn.Module):
         """Sum gradients over ranks in place; returns the scale (1/world) the optimiser must apply."""
         w = self.world_size
         if w > 1:
-            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.collective == "one_hop":
+                self._allreduce_one_hop(w)
+            else:
+                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg)
         return 1.0 / w
+
+    def _allreduce_one_hop(self, w: int) -> None:
+        from . import ops
+        g = self.flat.grad
+        n = g.numel()
+        chunk = (n + w - 1) // w
+        chunk = (chunk + 3) // 4 * 4                      # 16-byte aligned chunks
+        if self._hop is None or self._hop[0].shape != (w, chunk) or self._hop[0].device != g.device:
+            mk = lambda *s: torch.zeros(*s, dtype=torch.float32, device=g.device)
+            self._hop = (mk(w, chunk), mk(w, chunk), mk(chunk), mk(w * chunk))
+        send, recv, mine, full = self._hop
+        send.view(-1)[:n].copy_(g)                          # the padding stays zero
+        dist.all_to_all_single(recv, send, group=self.pg)   # row j of recv: my chunk as rank j computed it
+        ops.reduce_chunks(recv, mine)                       # fixed order j = 0 .. W-1
+        dist.all_gather_into_tensor(full, mine, group=self.pg)
+        g.copy_(full[:n])
 
 
 def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:

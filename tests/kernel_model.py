@@ -625,6 +625,16 @@ def gp_penalty_bwd(g, norms, gamma, lam, upstream):
     return (c.reshape(B, *([1] * (g.dim() - 1))) * g).contiguous()
 
 
+def reduce_chunks(recv, out=None):
+    s = recv[0].clone()
+    for j in range(1, recv.shape[0]):
+        s = s + recv[j]
+    if out is None:
+        return s
+    out.copy_(s.reshape(out.shape))
+    return out
+
+
 def multi_add(dsts, srcs):
     for d, s in zip(dsts, srcs):
         d.add_(s.reshape(d.shape))

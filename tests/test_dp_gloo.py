@@ -52,9 +52,10 @@ def _flat(module):
     return torch.cat([p.detach().reshape(-1) for p in module.parameters()])
 
 
-def _worker(rank, world, port, out, gan, use_gp):
+def _worker(rank, world, port, out, gan, use_gp, collective="all_reduce"):
     _setup_paths()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      SPGAN_DP_COLLECTIVE=collective)
     from helpers import install_kernel_models
     import spgan
     install_kernel_models()
@@ -114,10 +115,11 @@ def _rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("world,gan,use_gp", [(2, "ls", False), (2, "wgan", True), (4, "wgan", True)])
-def test_n_rank_step_equals_single_process_on_concatenated_batch(tmp_path, world, gan, use_gp):
+@pytest.mark.parametrize("world,gan,use_gp,collective", [(2, "ls", False, "all_reduce"), (2, "wgan", True, "all_reduce"), (4, "wgan", True, "all_reduce"),
+                                                         (2, "wgan", True, "one_hop")])
+def test_n_rank_step_equals_single_process_on_concatenated_batch(tmp_path, world, gan, use_gp, collective):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), gan, use_gp), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), gan, use_gp, collective), nprocs=world, join=True)
     ranks = [torch.load(tmp_path / ("r%d.pt" % r)) for r in range(world)]
     for r in ranks[1:]:
         assert torch.equal(ranks[0]["flatD"], r["flatD"]) and torch.equal(ranks[0]["flatG"], r["flatG"]), "ranks diverged after one step"
@@ -160,3 +162,47 @@ def test_shard_batch_and_flat_allreduce_single_process():
     dp = spgan.DataParallel(lin)
     assert dp.module is lin and dp.world_size == 1 and dp.allreduce_grads() == 1.0
     assert lin.weight.grad is not None and lin.weight.grad.data_ptr() == dp.flat.grad.data_ptr()
+
+
+def _hop_worker(rank, world, port, out):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from helpers import install_kernel_models
+    import spgan
+    install_kernel_models()
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = {}
+        for n_out in (5, 64, 1001):                         # flat sizes that do and do not divide by the world size
+            sums = {}
+            for kind in ("all_reduce", "one_hop"):
+                lin = torch.nn.Linear(7, n_out, bias=False)
+                tail = torch.nn.Parameter(torch.zeros(3))
+                mod = torch.nn.Module(); mod.lin = lin; mod.tail = tail
+                dp = spgan.DataParallel(mod, collective=kind)
+                grads = torch.randn(dp.flat.grad.numel(), generator=torch.Generator().manual_seed(100 + rank))   # the flat buffer pads its members
+                dp.flat.grad.copy_(grads)
+                scale = dp.allreduce_grads()
+                assert scale == 1.0 / world
+                sums[kind] = dp.flat.grad.clone()
+            sums["input"] = grads
+            res[n_out] = sums
+        torch.save(res, os.path.join(out, "hop%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_hop_collective_equals_all_reduce(world, tmp_path):
+    """DataParallel(collective="one_hop") -- all-to-all + local sum in rank order (ops.reduce_chunks) + all-gather -- gives every rank
+    the sums of dist.all_reduce: bit-identical across ranks, and equal to the all-reduce result up to its summation order."""
+    port = _free_port()
+    mp.spawn(_hop_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(os.path.join(str(tmp_path), "hop%d.pt" % r)) for r in range(world)]
+    for n_out in (5, 64, 1001):
+        want = sum(ranks[r][n_out]["input"].double() for r in range(world))
+        for r in range(world):
+            assert torch.equal(ranks[r][n_out]["one_hop"], ranks[0][n_out]["one_hop"])          # every rank holds the same bits
+            assert torch.allclose(ranks[r][n_out]["one_hop"].double(), want, rtol=0, atol=1e-5)
+            assert torch.allclose(ranks[r][n_out]["one_hop"], ranks[r][n_out]["all_reduce"], rtol=0, atol=1e-5)

@@ -310,3 +310,24 @@ def test_gemm_tn_skinny(ops, M, Na, Nb):
     assert torch.equal(d, ops.gemm_tn(A, B))
     sc, sh = rnd("sk.sc%d" % Nb, (Nb,)).abs() + 0.5, rnd("sk.sh%d" % Nb, (Nb,), 0.3)       # a prologue keeps the MFMA kernel on the skinny plan
     close(ops.gemm_tn(A, B, pro=(sc, sh, 0.01)), km.gemm_tn(A, B, pro=(sc, sh, 0.01)), rtol=5e-5, atol=3e-4, what="skinny plan, mfma kernel")
+
+
+@pytest.mark.parametrize("parts,n", [(2, 8), (4, 1000), (8, 245088), (8, 146289), (3, 7)])
+def test_reduce_chunks(ops, parts, n):
+    """The local sum of a one-hop all-reduce: rows added in ascending order (bit-identical to that fixed-order sum)."""
+    n4 = (n + 3) // 4 * 4
+    recv = rnd("rc.%d.%d" % (parts, n), (parts, n4))
+    got = ops.reduce_chunks(recv)
+    want = recv[0].clone()
+    for j in range(1, parts):
+        want = want + recv[j]
+    assert torch.equal(got, want)
+    out = torch.empty(n4, device="cuda")
+    assert ops.reduce_chunks(recv, out) is out and torch.equal(out, want)
+    if n != n4:                                             # a row length that is not a multiple of 4: the scalar tail path
+        r2 = rnd("rc2.%d.%d" % (parts, n), (parts, n))
+        if r2.data_ptr() % 16 == 0:
+            w2 = r2[0].clone()
+            for j in range(1, parts):
+                w2 = w2 + r2[j]
+            assert torch.equal(ops.reduce_chunks(r2), w2)
