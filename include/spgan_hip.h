@@ -155,6 +155,11 @@ typedef struct spgan_gemm_nt_args {
    * 128-row kernels otherwise; 1: 128-row kernels only; 2: 256 x 256 tiles whenever the problem is eligible (M % 256 == 0,
    * N % 256 == 0, K % 32 == 0, 16-byte aligned rows, fp32 operands, no per-edge mode / fan-in / batching): for tests and A/B runs. */
   int tile_hint;
+  /* p_group_rows > 0: the rows form M / p_group_rows groups of p_group_rows consecutive rows, and p_scale / p_shift hold one vector per
+   * group ([groups, K], row g for the rows of group g) -- several passes of a network with their own train-mode BatchNorm statistics
+   * evaluated as ONE product (D(real), D(fake) and D(x_hat) of a D step).  A multiple of 128 (of 256 for the 256 x 256-tile kernel),
+   * M a multiple of it, M > 64.  0: one vector for all rows. */
+  int p_group_rows;
 } spgan_gemm_nt_args;
 /* number of column blocks (N-tiles) spgan_gemm_nt uses for this problem: sizes the fan-in counters */
 int spgan_gemm_nt_col_blocks(const spgan_gemm_nt_args* a);
@@ -166,6 +171,12 @@ int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s);
  * argmax = the first row like torch.max, yarg = the column maximum (y at the first row is not available without Y). */
 int spgan_pool_finalize(const float* pool_val, const int32_t* pool_arg, int B, int rows, int C, const float* scale, const float* shift,
                         float slope, float* pooled, int32_t* argmax, float* yarg, spgan_stream_t s);
+/* The same for B = groups * shapes_per_group shapes that belong to `groups` passes with their own BatchNorm: scale / shift are
+ * [groups, group_stride >= C] (vector g for the shapes of group g).  relative_rows != 0: argmax counts rows from the first row of the
+ * shape's own group (what a per-group view of the batched tensors needs). */
+int spgan_pool_finalize_groups(const float* pool_val, const int32_t* pool_arg, int B, int rows, int C, const float* scale, const float* shift,
+                               int group_stride, int shapes_per_group, float slope, float* pooled, int32_t* argmax, float* yarg,
+                               int relative_rows, spgan_stream_t s);
 
 typedef struct spgan_gemm_tn_args {
   /* C[Na,Nb] = beta*C + sum_m A[m,Na]^T . prologue(B)[m,Nb]  -- weight gradients (reduction over points/edges).
@@ -222,6 +233,13 @@ int spgan_colstats_finalize(const float* partials, int groups, int tiles_per_gro
 int spgan_colstats_finalize_bn(const float* partials, int tiles, int C, int G, int tile_rows, const float* gamma, const float* beta,
                                float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                                float* invstd, float* mean_out, spgan_stream_t s);
+/* spgan_colstats_finalize_bn for `groups` consecutive row groups of G rows each (records [groups * tiles_per_group, C, 2]) that go
+ * through the SAME BatchNorm layer one after the other: out [4, groups, C] = scale | shift | invstd | mean, each a contiguous [groups, C]
+ * block (what spgan_gemm_nt_args.p_group_rows and spgan_pool_finalize_groups read); the running statistics are updated group after
+ * group (group 0 first) exactly as `groups` separate calls would. */
+int spgan_colstats_finalize_bn_groups(const float* partials, int groups, int tiles_per_group, int C, int G, int tile_rows, const float* gamma,
+                                      const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* out,
+                                      spgan_stream_t s);
 /* The same for TWO BatchNorm layers whose channels lie side by side in one record set (columns [0,split) -> layer A, [split,C) ->
  * layer B, each with its own gamma/beta/running buffers): the two per-edge BatchNorms of an EdgeBlock (Generator.py:57-58,66-67) from
  * spgan_edge_stats' records in one launch.  out4 [4,C] = scale | shift | invstd | mean.  count_rep: the rows stand for count_rep

@@ -232,6 +232,16 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   const Tile t = map_tile(tilesN);
   if (t.tm >= tilesM) return;
   const int m0 = t.tm * BM, n0 = t.tn * BN;
+  // prologue vectors: one pair for all rows, or one pair per group of p_group_rows rows (a tile never straddles two groups)
+  const float* pPsc = AMODE != SPGAN_A_PLAIN ? p_.p_scale : nullptr;
+  const float* pPsh = AMODE != SPGAN_A_PLAIN ? p_.p_shift : nullptr;
+  if (AMODE != SPGAN_A_PLAIN && p.p_group_rows > 0) {
+    // a handful of groups: walked with scalar subtractions (a division would cost vector registers right where the kernel is tightest)
+    for (int r = m0 - p.p_group_rows; r >= 0; r -= p.p_group_rows) {
+      pPsc += p.K;
+      pPsh += p.K;
+    }
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -299,8 +309,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
         if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(pA, offC[i], kc, true);
       }
       if (AMODE != SPGAN_A_PLAIN) {
-        psc = ldpar(p.p_scale, kc);
-        psh = ldpar(p.p_shift, kc);
+        psc = ldpar(pPsc, kc);
+        psh = ldpar(pPsh, kc);
         if (AMODE == SPGAN_A_EDGE) peb = ldpar(p.e_bias, kc);
       }
       if (sp_reg) {
@@ -322,8 +332,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       }
     }
     if (AMODE != SPGAN_A_PLAIN && kok) {
-      psc = ldpar(p.p_scale, k);
-      psh = ldpar(p.p_shift, k);
+      psc = ldpar(pPsc, k);
+      psh = ldpar(pPsh, k);
       if (AMODE == SPGAN_A_EDGE) peb = ldpar(p.e_bias, k);
     }
 #pragma unroll
@@ -1652,6 +1662,8 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a->lda >= a->K && a->ldw >= a->K && a->ldy >= a->N);
   SPGAN_CHECK_ARG((uint64_t)a->M * (uint64_t)a->lda < (1ull << 32) && (uint64_t)a->N * (uint64_t)a->ldw < (1ull << 32));  // 32-bit operand offsets
   if (a->a_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
+  if (a->p_group_rows != 0)  // per-group prologue vectors: whole 128-row tiles per group, not for the M <= 64 kernel
+    SPGAN_CHECK_ARG(a->a_mode != SPGAN_A_PLAIN && a->p_group_rows > 0 && a->p_group_rows % BM == 0 && a->M % a->p_group_rows == 0 && a->M > 64);
   if (a->a_mode == SPGAN_A_EDGE) SPGAN_CHECK_ARG(a->e_idx && a->e_bias && a->e_k > 0);
   if (a->rowbias) SPGAN_CHECK_ARG(a->rows_per_group > 0 && a->ld_rowbias >= a->N);
   if (a->sp_val) SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_AFFINE_LRELU && a->sp_arg && a->sp_rows > 0);

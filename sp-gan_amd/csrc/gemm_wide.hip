@@ -78,13 +78,22 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_g
   const unsigned oa = (unsigned)(m0 + lrow) * (unsigned)p.lda + (unsigned)lc4, sa = (unsigned)RPP * (unsigned)p.lda;
   const unsigned ow = (unsigned)(n0 + lrow) * (unsigned)p.ldw + (unsigned)lc4, sw = (unsigned)RPP * (unsigned)p.ldw;
   const int sp_b = sparse ? m0 / p.sp_rows : 0;  // the whole tile lies in one shape (host: sp_rows % 256 == 0)
+  // prologue vectors: one pair for all rows, or one pair per group of p_group_rows rows (host: p_group_rows % 256 == 0)
+  const float* pPsc = p_.p_scale;
+  const float* pPsh = p_.p_shift;
+  if (affine && p.p_group_rows > 0) {
+    for (int r = m0 - p.p_group_rows; r >= 0; r -= p.p_group_rows) {  // a handful of groups: scalar subtractions instead of a division
+      pPsc += p.K;
+      pPsh += p.K;
+    }
+  }
 
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) ra[i] = *reinterpret_cast<const float4*>(p.A + (oa + (unsigned)i * sa + (unsigned)k0));
     if (affine) {
-      psc = *reinterpret_cast<const float4*>(p.p_scale + k0 + lc4);
-      psh = *reinterpret_cast<const float4*>(p.p_shift + k0 + lc4);
+      psc = *reinterpret_cast<const float4*>(pPsc + k0 + lc4);
+      psh = *reinterpret_cast<const float4*>(pPsh + k0 + lc4);
     }
     if (sparse) {
       const size_t off = (size_t)sp_b * p.K + k0 + lc4;
@@ -376,6 +385,7 @@ bool spgan_nt_wide_eligible(const spgan_gemm_nt_args& a) {
   if (a.a_mode == SPGAN_A_EDGE || a.epi_mode == SPGAN_EPI_EDGE_BNBWD) return false;
   if (a.lda % 4 || a.ldw % 4 || !al16(a.A) || !al16(a.W)) return false;
   if (a.a_mode != SPGAN_A_PLAIN && (!al16(a.p_scale) || !al16(a.p_shift))) return false;
+  if (a.p_group_rows > 0 && a.p_group_rows % WM) return false;
   if (a.sp_val) {
     if (a.a_mode != SPGAN_A_AFFINE_LRELU || a.sp_rows % WM || !al16(a.sp_val) || !al16(a.sp_arg)) return false;
   }

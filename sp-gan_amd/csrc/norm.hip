@@ -91,6 +91,9 @@ struct BnTail {
   int split;
   const float* gamma2; const float* beta2; float* rmean2; float* rvar2;
   int count_rep;                        // the rows stand for count_rep identical copies (unbiased-variance count of the running statistics)
+  // seq_groups > 1 (grid.y == 1): the workgroup walks seq_groups row groups one after the other -- the same BatchNorm layer applied to
+  // several passes: outputs of group g at offset g * group_stride, running statistics updated in group order by the same thread.
+  int seq_groups; size_t group_stride;
 };
 
 template <int FS, int FC>
@@ -98,10 +101,13 @@ __global__ __launch_bounds__(256) void colfinalize_t_kernel(const float* __restr
                                                             int tile_rows, float* __restrict__ out0, float* __restrict__ out1, const BnTail bn) {
   static_assert(FS * FC == 256, "one thread per (slice, column)");
   __shared__ float sn[FS][FC], sa[FS][FC], sb[FS][FC];
-  const int g = blockIdx.y;
   const int cl = threadIdx.x & (FC - 1), sl = threadIdx.x / FC;
   const int c = blockIdx.x * FC + cl;
   const bool cok = c < C;
+  const int g_end = bn.seq_groups > 1 ? bn.seq_groups : (int)blockIdx.y + 1;
+  for (int g = bn.seq_groups > 1 ? 0 : (int)blockIdx.y; g < g_end; ++g) {
+  const size_t goff = bn.seq_groups > 1 ? (size_t)g * bn.group_stride : 0;
+  if (g > 0 && bn.seq_groups > 1) __syncthreads();  // the LDS exchange of the previous group is done
   float n = 0.f, a = 0.f, b = 0.f;  // mode 0: (count, mean, M2); mode 1: (-, s0, s1)
   if (cok) {
     const float2* base = reinterpret_cast<const float2*>(part) + (size_t)g * tiles_per_group * C + c;
@@ -176,11 +182,12 @@ __global__ __launch_bounds__(256) void colfinalize_t_kernel(const float* __restr
       const float inv = 1.0f / sqrtf(var + bn.eps);
       const float ga = gam ? gam[cc] : 1.f, be = bet ? bet[cc] : 0.f;
       const float sc = ga * inv;
-      bn.scale[c] = sc;
-      bn.shift[c] = be - a * sc;
-      bn.invstd[c] = inv;
-      bn.mean_out[c] = a;
+      bn.scale[goff + c] = sc;
+      bn.shift[goff + c] = be - a * sc;
+      bn.invstd[goff + c] = inv;
+      bn.mean_out[goff + c] = a;
     }
+  }
   }
 }
 
@@ -364,10 +371,12 @@ __global__ __launch_bounds__(256) void maxpool_v4_kernel(const float* __restrict
 // first row wins (like torch.max).  Tiles are visited in ascending row order with strict compares: first row on ties.
 __global__ void pool_finalize_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pa, int B, int tiles, int C,
                                      const float* __restrict__ scale, const float* __restrict__ shift, float slope, int rows,
-                                     float* __restrict__ pooled, int32_t* __restrict__ argmax, float* __restrict__ yarg) {
+                                     float* __restrict__ pooled, int32_t* __restrict__ argmax, float* __restrict__ yarg,
+                                     int group_stride, int shapes_per_group, int relative_rows) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (c >= C) return;
-  const float sc = scale[c], sh = shift[c];
+  const int grp = shapes_per_group > 0 ? b / shapes_per_group : 0;   // the pass this shape belongs to (its own BatchNorm vectors)
+  const float sc = scale[(size_t)grp * group_stride + c], sh = shift[(size_t)grp * group_stride + c];
   const int pick = sc >= 0.f ? 0 : 1;
   float best = 0.f;
   int arg = -1;
@@ -377,6 +386,7 @@ __global__ void pool_finalize_kernel(const float* __restrict__ pv, const int32_t
     if (arg < 0 || (pick == 0 ? v > best : v < best)) { best = v; arg = pa[o]; }
   }
   if (sc == 0.f) arg = b * rows;
+  if (relative_rows) arg -= grp * shapes_per_group * rows;
   pooled[(size_t)b * C + c] = lrelu_f(fmaf(best, sc, sh), slope);
   argmax[(size_t)b * C + c] = arg;
   if (yarg) yarg[(size_t)b * C + c] = best;
@@ -388,7 +398,17 @@ extern "C" int spgan_pool_finalize(const float* pool_val, const int32_t* pool_ar
                                    float slope, float* pooled, int32_t* argmax, float* yarg, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(pool_val && pool_arg && scale && shift && pooled && argmax && B > 0 && rows > 0 && C > 0 && rows % 128 == 0 && slope > 0.f);
   hipLaunchKernelGGL(pool_finalize_kernel, dim3(cdiv(C, 64), B), dim3(64), 0, (hipStream_t)s_, pool_val, pool_arg, B, rows / 128, C, scale, shift,
-                     slope, rows, pooled, argmax, yarg);
+                     slope, rows, pooled, argmax, yarg, 0, 0, 0);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_pool_finalize_groups(const float* pool_val, const int32_t* pool_arg, int B, int rows, int C, const float* scale,
+                                          const float* shift, int group_stride, int shapes_per_group, float slope, float* pooled,
+                                          int32_t* argmax, float* yarg, int relative_rows, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(pool_val && pool_arg && scale && shift && pooled && argmax && B > 0 && rows > 0 && C > 0 && rows % 128 == 0 && slope > 0.f);
+  SPGAN_CHECK_ARG(shapes_per_group > 0 && B % shapes_per_group == 0 && group_stride >= C);
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3(cdiv(C, 64), B), dim3(64), 0, (hipStream_t)s_, pool_val, pool_arg, B, rows / 128, C, scale, shift,
+                     slope, rows, pooled, argmax, yarg, group_stride, shapes_per_group, relative_rows);
   return spgan_launch_status();
 }
 
@@ -417,9 +437,24 @@ extern "C" int spgan_colstats_finalize_bn(const float* partials, int tiles, int 
   if (tile_rows <= 0) tile_rows = RT;
   SPGAN_CHECK_ARG(partials && scale && shift && invstd && mean_out && tiles > 0 && C > 0 && G > 0 && tiles == cdiv(G, tile_rows));
   SPGAN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
-  BnTail bn{gamma, beta, running_mean, running_var, scale, shift, invstd, mean_out, eps, momentum, 0, nullptr, nullptr, nullptr, nullptr, 1};
+  BnTail bn{gamma, beta, running_mean, running_var, scale, shift, invstd, mean_out, eps, momentum, 0, nullptr, nullptr, nullptr, nullptr, 1, 0, 0};
   launch_colfinalize(s, partials, 1, tiles, C, G, 0, tile_rows, (float*)nullptr,
                      (float*)nullptr, bn);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_colstats_finalize_bn_groups(const float* partials, int groups, int tiles_per_group, int C, int G, int tile_rows,
+                                                 const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                                 float* running_var, float* out, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (tile_rows <= 0) tile_rows = RT;
+  SPGAN_CHECK_ARG(partials && out && groups > 0 && tiles_per_group > 0 && C > 0 && G > 0 && tiles_per_group == cdiv(G, tile_rows));
+  SPGAN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  // one workgroup row (grid.y == 1) walks the groups in order; with a single group this is spgan_colstats_finalize_bn
+  const size_t gc = (size_t)groups * C;  // out [4, groups, C]: the scale (shift, ...) vectors of all groups are one contiguous [groups, C] block
+  BnTail bn{gamma, beta, running_mean, running_var, out, out + gc, out + 2 * gc, out + 3 * gc, eps, momentum,
+            0, nullptr, nullptr, nullptr, nullptr, 1, groups > 1 ? groups : 0, (size_t)C};
+  launch_colfinalize(s, partials, 1, tiles_per_group, C, G, 0, tile_rows, (float*)nullptr, (float*)nullptr, bn);
   return spgan_launch_status();
 }
 
@@ -434,7 +469,7 @@ extern "C" int spgan_colstats_finalize_bn2(const float* partials, int tiles, int
   SPGAN_CHECK_ARG(partials && out4 && tiles > 0 && C > 0 && G > 0 && tiles == cdiv(G, tile_rows) && split > 0 && split < C && count_rep >= 1);
   SPGAN_CHECK_ARG((rmeanA == nullptr) == (rvarA == nullptr) && (rmeanB == nullptr) == (rvarB == nullptr));
   BnTail bn{gammaA, betaA, rmeanA, rvarA, out4, out4 + C, out4 + 2 * (size_t)C, out4 + 3 * (size_t)C, eps, momentum,
-            split, gammaB, betaB, rmeanB, rvarB, count_rep};
+            split, gammaB, betaB, rmeanB, rvarB, count_rep, 0, 0};
   launch_colfinalize(s, partials, 1, tiles, C, G, 0, tile_rows, (float*)nullptr,
                      (float*)nullptr, bn);
   return spgan_launch_status();

@@ -47,6 +47,7 @@ class GemmNTArgs(C.Structure):
         ("batch", C.c_int), ("batch_stride_a", C.c_long), ("batch_stride_w", C.c_long), ("batch_stride_y", C.c_long),
         ("fin", FanIn),
         ("tile_hint", C.c_int),
+        ("p_group_rows", C.c_int),
     ]
 
 
@@ -104,6 +105,7 @@ SIGNATURES = {
     "spgan_gemm_nt_col_blocks": (I, [C.POINTER(GemmNTArgs)]),
     "spgan_fanin_groups": (I, [I]),
     "spgan_pool_finalize": (I, [P, P, I, I, I, P, P, F, P, P, P, P]),
+    "spgan_pool_finalize_groups": (I, [P, P, I, I, I, P, P, I, I, F, P, P, P, I, P]),
     "spgan_gemm_tn_ws_bytes": (SZ, [I, I, I]),
     "spgan_gemm_tn": (I, [C.POINTER(GemmTNArgs), P]),
     "spgan_sparse_rows_nt": (I, [P, P, I, I, I, P, I, I, P, I, P]),
@@ -113,6 +115,7 @@ SIGNATURES = {
     "spgan_colreduce_ws_bytes": (SZ, [I, I, I]),
     "spgan_colstats_finalize": (I, [P, I, I, I, I, I, I, P, P, P]),
     "spgan_colstats_finalize_bn": (I, [P, I, I, I, I, P, P, F, F, P, P, P, P, P, P, P]),
+    "spgan_colstats_finalize_bn_groups": (I, [P, I, I, I, I, I, P, P, F, F, P, P, P, P]),
     "spgan_colstats_finalize_bn2": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, P, F, F, I, P, P]),
     "spgan_colstats": (I, [P, I, I, I, I, F, P, P, P, SZ, P]),
     "spgan_colsum": (I, [P, I, I, I, I, P, P, SZ, P]),

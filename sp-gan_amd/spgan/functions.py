@@ -135,7 +135,13 @@ class DiscriminatorFn(Function):
     @staticmethod
     def forward(ctx, holder, x, *params):
         P = dict(zip(holder.names, params))
-        out, dctx = nets.d_forward(P, holder.buffers, x, holder.training, True)
+        pre = getattr(holder, "pre", None)
+        if pre is not None:
+            # the conv stack of this pass was already evaluated (batched with other passes, nets.d_forward_groups): only the head is left
+            pooled, dctx = pre
+            out, dctx["hs"] = nets.d_head_forward(P, pooled)
+        else:
+            out, dctx = nets.d_forward(P, holder.buffers, x, holder.training, True)
         ctx.holder, ctx.dctx = holder, dctx
         ctx.save_for_backward(x, *params)
         return out
@@ -167,7 +173,11 @@ class DStackFn(Function):
     @staticmethod
     def forward(ctx, holder, x, *params):
         P = dict(zip(holder.names, params))
-        pooled, dctx = nets.d_forward(P, holder.buffers, x, holder.training, True, head=False)
+        pre = getattr(holder, "pre", None)
+        if pre is not None:
+            pooled, dctx = pre          # evaluated as one of several batched passes (nets.d_forward_groups)
+        else:
+            pooled, dctx = nets.d_forward(P, holder.buffers, x, holder.training, True, head=False)
         ctx.holder, ctx.dctx = holder, dctx
         ctx.save_for_backward(*params)
         return pooled

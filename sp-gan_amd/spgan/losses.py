@@ -177,29 +177,36 @@ class GradientPenalty:
         grads = self.input_gradient(netD, real_data, fake_data, alpha, mapping)
         return _GPPenaltyFn.apply(grads.contiguous().view(grads.shape[0], -1), float(self.gamma), float(self.lambdaGP))
 
-    def with_grads(self, netD, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False):
+    def with_grads(self, netD, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False, interpolates=None, pre=None):
         """-> (penalty [1], grads, v): the penalty's value, the differentiable input gradient it is a function of, and
-        d penalty / d grads -- for a caller that seeds torch.autograd.backward([grads], [v]) itself."""
-        grads = self.input_gradient(netD, real_data, fake_data, alpha, mapping)
+        d penalty / d grads -- for a caller that seeds torch.autograd.backward([grads], [v]) itself.
+        interpolates / pre: the x_hat of `interpolate(...)` and its entry of netD.forward_stacks_grouped([..., x_hat]) when the caller
+        evaluated D's conv stack on x_hat together with other passes."""
+        grads = self.input_gradient(netD, real_data, fake_data, alpha, mapping, interpolates=interpolates, pre=pre)
         g = grads.detach().contiguous().view(grads.shape[0], -1)
         loss, norms = ops.gp_penalty_fwd(g, float(self.gamma), float(self.lambdaGP))
         v = ops.gp_penalty_bwd(g, norms, float(self.gamma), float(self.lambdaGP), None)
         return loss, grads, v.view_as(grads)
 
-    def input_gradient(self, netD, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False):
-        """d netD(x_hat) / d x_hat on the interpolates, as a differentiable tensor (create_graph)."""
+    def interpolate(self, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False):
+        """x_hat [B,3,N] (detached): the points the penalty is evaluated at."""
         B = real_data.size(0)
         fake_data = fake_data[:B]
         if alpha is None:
             alpha = torch.rand(B, 1, 1, device=real_data.device)
         real_d, fake_d = real_data.detach().contiguous(), fake_data.detach().contiguous()
         if mapping:
-            interpolates = self._mapped(real_d, fake_d, alpha).requires_grad_(True)
-        elif self.mix == "loss_utils":
-            interpolates = ops.lerp_rows(fake_d, real_d, alpha.reshape(B)).requires_grad_(True)   # fake + alpha*(real - fake)
-        else:
-            interpolates = ops.lerp_rows(real_d, fake_d, alpha.reshape(B)).requires_grad_(True)
-        disc = netD(interpolates)
+            return self._mapped(real_d, fake_d, alpha)
+        if self.mix == "loss_utils":
+            return ops.lerp_rows(fake_d, real_d, alpha.reshape(B))                               # fake + alpha*(real - fake)
+        return ops.lerp_rows(real_d, fake_d, alpha.reshape(B))
+
+    def input_gradient(self, netD, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False, interpolates=None, pre=None):
+        """d netD(x_hat) / d x_hat on the interpolates, as a differentiable tensor (create_graph)."""
+        if interpolates is None:
+            interpolates = self.interpolate(real_data, fake_data, alpha, mapping)
+        interpolates = interpolates.requires_grad_(True)
+        disc = netD(interpolates) if pre is None else netD(interpolates, pre=pre)
         with input_grad_only():          # explicit: this backward wants d disc / d x_hat only, as a differentiable node
             grads = torch.autograd.grad(outputs=disc, inputs=interpolates, grad_outputs=_ones_like(disc),
                                         create_graph=True, retain_graph=True, only_inputs=True)[0]

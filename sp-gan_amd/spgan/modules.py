@@ -366,11 +366,26 @@ class Discriminator(nn.Module, _BNCounts):
         self.mlp = _stack([("linear", dim, 512), ("lrelu",), ("linear", 512, 256), ("lrelu",), ("linear", 256, 64), ("lrelu",), ("linear", 64, 1)])
         self._install_count_hook()
 
-    def forward(self, x):
+    def forward(self, x, pre=None):
+        """pre: this input's entry of `forward_stacks_grouped(...)` -- its conv stack was evaluated there, only the head runs here."""
         _require_gpu(x, "Discriminator")
         names, params = _named(self)
-        h = _Holder(names=names, buffers=_buffers(self), training=self.training)
+        h = _Holder(names=names, buffers=_buffers(self), training=self.training, pre=pre)
         return Fn.DiscriminatorFn.apply(h, x.contiguous(), *params)
+
+    def forward_stacks_grouped(self, xs):
+        """The conv stacks of several train-mode passes as ONE batch (nets.d_forward_groups): one GEMM and one finalize launch per layer
+        for all of them, per-pass BatchNorm statistics, running statistics advanced in list order -- bit-identical to separate calls.
+        Returns one opaque entry per input, to be handed to `forward(x, pre=...)` or `forward_stack(x, pre=...)` of the same input."""
+        for x in xs:
+            _require_gpu(x, "Discriminator")
+        if not self.training:
+            raise RuntimeError("forward_stacks_grouped is a train-mode path (batch statistics)")
+        from . import nets
+        names, params = _named(self)
+        with torch.no_grad():
+            P = dict(zip(names, [nets.owned(p) for p in params]))
+            return nets.d_forward_groups(P, _buffers(self), [x.detach() for x in xs])
 
 
 def _discriminator_forward_many(self, *xs):
@@ -378,24 +393,33 @@ def _discriminator_forward_many(self, *xs):
     (each with its own train-mode BatchNorm statistics and running-statistics update, in call order -- exactly what separate calls
     do), the head has no BatchNorm, so its rows are independent and cat[pooled...] goes through it once (4 launches forward and 16
     backward once instead of once per pass).  First-order only: the WGAN-GP route uses forward()."""
-    for x in xs:
-        _require_gpu(x, "Discriminator")
+    return self.forward_heads([self.forward_stack(x) for x in xs])
+
+
+def _discriminator_forward_stack(self, x, pre=None):
+    """The conv stack up to the max-pool: x [B,3,N] -> pooled [B,C4] (train-mode BatchNorm statistics and running-statistics update
+    of this pass).  pre: this input's entry of forward_stacks_grouped(...) (already evaluated there)."""
+    _require_gpu(x, "Discriminator")
     sn, sp = _named(self.mlps, "mlps.")
     fn, fp = _named(self.fc2, "fc2.")
+    h = _Holder(names=sn + fn, buffers=_buffers(self), training=self.training, pre=pre)
+    return Fn.DStackFn.apply(h, x.contiguous(), *(sp + fp))
+
+
+def _discriminator_forward_heads(self, pooled):
+    """The per-shape MLP head of several forward_stack() results as one batch -> one logits tensor per pass."""
     hn, hp = _named(self.mlp, "mlp.")
-    pooled = []
-    for x in xs:
-        h = _Holder(names=sn + fn, buffers=_buffers(self), training=self.training)
-        pooled.append(Fn.DStackFn.apply(h, x.contiguous(), *(sp + fp)))
-    logits = Fn.DHeadFn.apply(_Holder(names=hn), torch.cat(pooled, dim=0), *hp)
+    logits = Fn.DHeadFn.apply(_Holder(names=hn), torch.cat(list(pooled), dim=0), *hp)
     out, lo = [], 0
-    for x in xs:
-        out.append(logits[lo:lo + x.shape[0]])
-        lo += x.shape[0]
+    for p in pooled:
+        out.append(logits[lo:lo + p.shape[0]])
+        lo += p.shape[0]
     return out
 
 
 Discriminator.forward_many = _discriminator_forward_many
+Discriminator.forward_stack = _discriminator_forward_stack
+Discriminator.forward_heads = _discriminator_forward_heads
 
 
 def _discriminator_advance_running_stats(self, x):

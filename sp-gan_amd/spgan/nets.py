@@ -246,6 +246,48 @@ def d_forward(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], x_cm: Ten
     return logits, ctx
 
 
+def d_forward_groups(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], xs_cm, update_running: bool = True):
+    """The conv stacks of several train-mode passes D(x_0), D(x_1), ... as ONE batch: every layer is a single GEMM over the rows of all
+    passes (ops.gemm_bn_groups), every pass keeps its own BatchNorm batch statistics, and the running statistics (and call counts)
+    advance pass after pass in list order -- the activations, statistics and buffers are those of separate d_forward(head=False) calls
+    bit for bit (tests/test_kernels2_gpu.py::test_gemm_bn_groups, test_parity_gpu.py::test_discriminator_grouped_forward...).
+    Returns [(pooled_g [B,C4], ctx_g)]: the contexts are VIEWS of the batched tensors, laid out exactly like d_forward's, so d_backward /
+    d_double_backward run per pass unchanged.  Needs equal shapes and N % 128 == 0."""
+    G = len(xs_cm)
+    B, _, N = xs_cm[0].shape
+    M = B * N
+    if any(tuple(x.shape) != (B, 3, N) for x in xs_cm) or N % ops.ROW_TILE:
+        raise ValueError("d_forward_groups needs equally shaped inputs [B,3,N] with N %% %d == 0" % ops.ROW_TILE)
+    x_pm = ops.cm_to_pm(torch.cat([x.contiguous() for x in xs_cm], dim=0))            # [G*M, 3]
+    ys_all, outs = [], []
+    a, pro = x_pm, None
+    for li, (conv, bn) in enumerate(D_LAYERS):
+        W, b = _w2(P[conv + ".weight"]), P[conv + ".bias"]
+        rm = rv = None
+        if bufs is not None and update_running:
+            rm, rv = bufs[bn + ".running_mean"], bufs[bn + ".running_var"]
+        bnp = (P[bn + ".weight"], P[bn + ".bias"], rm, rv)
+        if li == 3:
+            out, pooled, argmax, yarg = ops.gemm_bn_groups(a, W, b, bnp, G, pro=pro, rows=N, slope=NEG)
+            ys_all.append(None)
+        else:
+            y, out = ops.gemm_bn_groups(a, W, b, bnp, G, pro=pro)
+            ys_all.append(y)
+            a, pro = y, (out[0], out[1], NEG)
+        outs.append(out)
+        if rm is not None:
+            for _ in range(G):
+                _count_bn_call(bufs, bn)
+    res = []
+    for g in range(G):
+        ys = [None if y is None else y[g * M:(g + 1) * M] for y in ys_all]
+        bns = [(o[0, g], o[1, g], o[2, g], o[3, g]) for o in outs]
+        sl = slice(g * B, (g + 1) * B)
+        ctx = dict(B=B, N=N, x_pm=x_pm[g * M:(g + 1) * M], ys=ys, bns=bns, pooled=pooled[sl], argmax=argmax[sl], yarg=yarg[sl], hs=None, training=True)
+        res.append((pooled[sl], ctx))
+    return res
+
+
 def d_advance_running_stats(P: Dict[str, Tensor], bufs: Dict[str, Tensor], x_cm: Tensor) -> None:
     """The side effect of a train-mode D(x) whose logits nobody reads: the G-step of the reference loop calls D(real)
     (model.py:272-273) although gen_loss ignores d_real -- only the four BatchNorm layers' running statistics (and call counts)

@@ -816,6 +816,71 @@ def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, sl
     return Y, (st[0], st[1], st[2], st[3]), pooled, arg, yarg
 
 
+def gemm_bn_groups(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, groups: int, pro=None, rows: int = 0, slope: float = 0.0):
+    """Several passes through the same layer as ONE product: A [groups*Mg, K] holds the rows of `groups` passes one after the other,
+    every pass has its own train-mode BatchNorm statistics -- of its input (pro = (scale [groups,K], shift [groups,K], slope):
+    operand a = lrelu(A*scale[g]+shift[g]) for the rows of pass g) and of this layer's output (bn = (gamma, beta, running_mean | None,
+    running_var | None): out [4, groups, N] = scale | shift | invstd | mean per pass, the running statistics updated pass after pass
+    exactly as `groups` separate calls would).  One GEMM launch + one finalize launch.
+    rows = 0: returns (Y [groups*Mg, N], out).
+    rows > 0 (the Discriminator's last conv layer, gemm_bn_pool for several passes): Y is not stored; returns
+    (out, pooled [B,N], argmax int32 [B,N] -- rows counted from the first row of the shape's OWN pass --, yarg [B,N]) with B = groups*Mg/rows."""
+    _rowmajor2d(A, "A"); _rowmajor2d(W, "W")
+    N, K = W.shape
+    M_ = A.shape[0]
+    if groups <= 0 or M_ % groups or (M_ // groups) % ROW_TILE:
+        raise ValueError("gemm_bn_groups needs groups | M and whole %d-row tiles per group" % ROW_TILE)
+    Mg = M_ // groups
+    dev = A.device
+    a = GemmNTArgs(); a.mfma_f16 = _MFMA_F16[0]; a.tile_hint = _NT_TILE_HINT[0]
+    a.A = _p(A); a.lda = _ld(A); a.W = _p(W); a.ldw = _ld(W)
+    a.M, a.N, a.K = M_, N, K
+    a.a_mode = A_PLAIN
+    if pro is not None:
+        sc, sh, ps = pro
+        for t, nm in ((sc, "pro.scale"), (sh, "pro.shift")):
+            _f32(t, nm, 2)
+            if tuple(t.shape) != (groups, K) or not t.is_contiguous():
+                raise ValueError("%s must be contiguous [groups, K]" % nm)
+        a.a_mode = A_AFFINE_LRELU
+        a.p_scale = _p(sc); a.p_shift = _p(sh); a.p_slope = float(ps)
+        a.p_group_rows = Mg if groups > 1 else 0
+    a.epi_mode = EPI_LINEAR
+    a.bias = _p(_vec(bias, N, "bias"))
+    tiles = M_ // ROW_TILE
+    part = torch.empty((tiles, N, 2), dtype=torch.float32, device=dev)
+    a.stats = _p(part)
+    Y = pval = parg = None
+    if rows > 0:
+        if rows % ROW_TILE or Mg % rows:
+            raise ValueError("rows must be a multiple of %d and divide the rows of a group" % ROW_TILE)
+        pval = torch.empty((tiles, N, 2), dtype=torch.float32, device=dev)
+        parg = torch.empty((tiles, N, 2), dtype=torch.int32, device=dev)
+        a.pool_val = _p(pval); a.pool_arg = _p(parg)
+        a.Y = None; a.ldy = N
+    else:
+        Y = torch.empty((M_, N), dtype=torch.float32, device=dev)
+        a.Y = _p(Y); a.ldy = N
+    lib = _lib.load()
+    gamma, beta, rm, rv = bn
+    out = torch.empty((4, groups, N), dtype=torch.float32, device=dev)
+    done = launch_timer("gemm_nt", a) if launch_timer is not None else None
+    check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_bn_groups", M=M_, N=N, K=K, groups=groups)
+    if done is not None:
+        done()
+    check(lib.spgan_colstats_finalize_bn_groups(_p(part), groups, tiles // groups, N, Mg, 0, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM, _p(rm), _p(rv),
+                                                _p(out), _s()), "colstats_finalize_bn_groups", N=N, groups=groups)
+    if rows == 0:
+        return Y, out
+    B = M_ // rows
+    pooled = torch.empty((B, N), dtype=torch.float32, device=dev)
+    yarg = torch.empty((B, N), dtype=torch.float32, device=dev)
+    arg = torch.empty((B, N), dtype=torch.int32, device=dev)
+    check(lib.spgan_pool_finalize_groups(_p(pval), _p(parg), B, rows, N, _p(out[0]), _p(out[1]), N, Mg // rows, float(slope),
+                                         _p(pooled), _p(arg), _p(yarg), 1, _s()), "pool_finalize_groups", B=B, rows=rows, C=N)
+    return out, pooled, arg, yarg
+
+
 # ----------------------------------------------------------------------------- EdgeBlock gather-side ops
 def edge_wcat(Ww0: Tensor, Wx: Tensor) -> Tensor:
     """[W1; Wd; Wc-Wd] from conv_w.0.weight [H,C] and conv_x.0.weight [F,2C] = [Wc|Wd] -> [H+2F, C]."""

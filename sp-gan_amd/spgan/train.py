@@ -16,6 +16,7 @@ x costs an eager step and a re-capture (and after a few changes the harness stay
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -65,6 +66,11 @@ class TrainStep:
         self._eager_calls = 0
         self._bn_delta = None        # host-side BatchNorm call counts of one step (replayed on the host)
         self._side = None
+        # The D step's three passes through D's conv stack -- D(real), D(fake), D(x_hat) of the penalty -- as ONE batch: one GEMM and one
+        # finalize launch per layer for all three, per-pass BatchNorm statistics (Discriminator.forward_stacks_grouped; bit-identical to
+        # the separate calls, running statistics advanced in the reference's order real, fake, x_hat).  The backward passes run per
+        # pass as before, on views of the batched activations.
+        self.batch_d_forwards = not reference_schedule and hasattr(D, "forward_stacks_grouped") and os.environ.get("SPGAN_BATCH_D", "1") != "0"
 
     # ------------------------------------------------------------------ hipGraph replay
     def _bn_modules(self):
@@ -229,7 +235,17 @@ class TrainStep:
         self.optD.zero_grad()
         fake = G(x, z_d).detach()
         real_t = ops.pm_to_cm(real.reshape(B * N, 3), B, N)                      # real_points.transpose(2,1)
-        if self.reference_schedule or not hasattr(D, "forward_many"):
+        pre_hat = x_hat = None
+        if self.batch_d_forwards and D.training and N % ops.ROW_TILE == 0 and tuple(fake.shape) == tuple(real_t.shape):
+            ins = [real_t, fake]
+            if self.use_gp:
+                x_hat = self.gp.interpolate(real_t, fake, alpha)
+                ins.append(x_hat)
+            pre = D.forward_stacks_grouped(ins)
+            d_real, d_fake = D.forward_heads([D.forward_stack(real_t, pre=pre[0]), D.forward_stack(fake, pre=pre[1])])
+            if self.use_gp:
+                pre_hat = pre[2]
+        elif self.reference_schedule or not hasattr(D, "forward_many"):
             d_real = D(real_t)
             d_fake = D(fake)
         else:
@@ -240,7 +256,7 @@ class TrainStep:
         roots, seeds = [d_real, d_fake], [g_real, g_fake]
         loss_d = out5[0]
         if self.use_gp:
-            pen, gx, v = self.gp.with_grads(D, real_t, fake, alpha=alpha)
+            pen, gx, v = self.gp.with_grads(D, real_t, fake, alpha=alpha, interpolates=x_hat, pre=pre_hat)
             roots.append(gx); seeds.append(v)
             loss_d = loss_d + pen[0]
         with fused_grad_accumulation():

@@ -447,6 +447,26 @@ def adain_bwd(dout, x, N, slope, imean, ivar, gb):
 
 
 # ----------------------------------------------------------------------------- pooled BN backward, misc
+def gemm_bn_groups(A, W, bias, bn, groups, pro=None, rows=0, slope=0.0):
+    """`groups` separate calls of the single-pass models, in order (running statistics included), results stacked."""
+    Mg = A.shape[0] // groups
+    ys, outs, pooled, args, yargs = [], [], [], [], []
+    for g in range(groups):
+        pg = None if pro is None else (pro[0][g], pro[1][g], pro[2])
+        Ag = A[g * Mg:(g + 1) * Mg]
+        if rows == 0:
+            y, st = gemm_nt(Ag, W, bias, pro=pg, bn=bn)
+            ys.append(y)
+        else:
+            _, st, p, a, ya = gemm_bn_pool(Ag, W, bias, bn, rows, slope, pro=pg)
+            pooled.append(p); args.append(a); yargs.append(ya)          # argmax already relative to the pass's own rows
+        outs.append(torch.stack(list(st)))
+    out = torch.stack(outs).permute(1, 0, 2).contiguous()          # [4, groups, N]
+    if rows == 0:
+        return torch.cat(ys).contiguous(), out
+    return out, torch.cat(pooled).contiguous(), torch.cat(args).contiguous(), torch.cat(yargs).contiguous()
+
+
 def gemm_bn_pool(A, W, bias, bn, rows, slope, pro=None, keep_y=False):
     y, st = gemm_nt(A, W, bias, pro=pro, bn=bn)
     B = y.shape[0] // rows

@@ -331,3 +331,41 @@ def test_reduce_chunks(ops, parts, n):
             for j in range(1, parts):
                 w2 = w2 + r2[j]
             assert torch.equal(ops.reduce_chunks(r2), w2)
+
+
+@pytest.mark.parametrize("hint", [0, 2])
+@pytest.mark.parametrize("groups,Mg,N,K", [(3, 512, 256, 128), (2, 768, 128, 64), (3, 256, 1024, 256), (1, 512, 256, 32)])
+def test_gemm_bn_groups(ops, groups, Mg, N, K, hint):
+    """Several passes through one layer as ONE product (per-pass BatchNorm of the operand and of the output, running statistics
+    updated pass after pass): against `groups` separate calls of the single-pass ops -- the activations bit for bit."""
+    M = groups * Mg
+    A, W, b = rnd("gg.A%d.%d" % (M, K), (M, K)), rnd("gg.W%d.%d" % (N, K), (N, K), 0.1), rnd("gg.b%d" % N, (N,))
+    A = A + torch.arange(groups, device="cuda").repeat_interleave(Mg).view(M, 1) * 0.5          # the passes have different statistics
+    sc, sh = rnd("gg.sc%d%d" % (groups, K), (groups, K)).abs() + 0.5, rnd("gg.sh%d%d" % (groups, K), (groups, K), 0.3)
+    gamma, beta = rnd("gg.ga%d" % N, (N,)).abs() + 0.5, rnd("gg.be%d" % N, (N,), 0.1)
+    with ops.nt_tile_hint(hint):
+        for pro in (None, (sc, sh, 0.01)):
+            rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+            Y, out = ops.gemm_bn_groups(A, W, b, (gamma, beta, rm, rv), groups, pro=pro)
+            rm2, rv2 = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+            for g in range(groups):
+                pg = None if pro is None else (pro[0][g].contiguous(), pro[1][g].contiguous(), pro[2])
+                y1, st1 = ops.gemm_nt(A[g * Mg:(g + 1) * Mg], W, b, pro=pg, bn=(gamma, beta, rm2, rv2))
+                assert torch.equal(Y[g * Mg:(g + 1) * Mg], y1), "pass %d: activations differ" % g
+                for q in range(4):
+                    assert torch.equal(out[q, g], st1[q]), (g, q)
+            assert torch.equal(rm, rm2) and torch.equal(rv, rv2)
+            Ym, outm = km.gemm_bn_groups(A, W, b, (gamma, beta, torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")), groups, pro=pro)
+            close(Y, Ym, rtol=5e-5, what="Y vs model"); close(out, outm, rtol=2e-4, atol=2e-5, what="bn vs model")
+        rows = 256
+        rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+        out, pooled, arg, yarg = ops.gemm_bn_groups(A, W, b, (gamma, beta, rm, rv), groups, pro=(sc, sh, 0.01), rows=rows, slope=0.01)
+        rm2, rv2 = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+        Bg = Mg // rows
+        for g in range(groups):
+            _, st1, p1, a1, ya1 = ops.gemm_bn_pool(A[g * Mg:(g + 1) * Mg], W, b, (gamma, beta, rm2, rv2), rows, 0.01,
+                                                   pro=(sc[g].contiguous(), sh[g].contiguous(), 0.01))
+            assert torch.equal(pooled[g * Bg:(g + 1) * Bg], p1) and torch.equal(arg[g * Bg:(g + 1) * Bg], a1) and torch.equal(yarg[g * Bg:(g + 1) * Bg], ya1)
+            for q in range(4):
+                assert torch.equal(out[q, g], st1[q]), (g, q)
+        assert torch.equal(rm, rm2) and torch.equal(rv, rv2)
