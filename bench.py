@@ -96,9 +96,11 @@ def _pmc_traffic():
 
 # Dominant kernel of the step (profiles/r0*_bench_*_kernel_stats.txt): gemm_nt_wide_kernel<affine prologue, linear epilogue + column
 # statistics + max-pool partials>, 256x256 tiles (csrc/gemm_wide.hip; round 1 and the first half of round 2 ran it as gemm_nt_kernel<1,0,1,0,1,0>
-# with 128x64 tiles), at the Discriminator's 256->1024 layer (Discriminator.py:74-81,104): M = B*N points,
-# N = 1024, K = 256; 4 launches per step (D(real), D(fake), D(interpolate) of the D step and D(fake) of the G step; the G step's
-# unused D(real) only advances running statistics, TrainStep._seg_g).
+# with 128x64 tiles), at the Discriminator's 256->1024 layer (Discriminator.py:74-81,104): N = 1024, K = 256, M = B*N points per pass.
+# Per step: ONE launch over the rows of three passes (D(real), D(fake), D(interpolate) of the D step, batched with per-pass BatchNorm:
+# M = 3*B*N, 103 GF) and ONE launch for D(fake) of the G step (M = B*N, 34.4 GF) -- the roofline entry times the latter, the launch
+# whose shape is the per-pass figure of SURVEY 8(d); the batched launch runs at the same rate (profiles/r02_mfma_shapes.txt: 891 us = 115.6 TF).
+# (The G step's unused D(real) only advances running statistics, TrainStep._seg_g.)
 DOMINANT = {"N": 1024, "K": 256, "a_mode": 1,
             "pmc_key": "gemm_nt D.fc2.0 M=65536 N=1024 K=256 (affine prologue + statistics + pooling partials, output not stored)"}
 
@@ -164,7 +166,7 @@ class MfmaAccounting:
         ms = sum(e0.elapsed_time(e1) for e0, e1 in dom) / len(dom)
         flops = 2.0 * self.M * DOMINANT["N"] * DOMINANT["K"]          # 2*N*256*1024 per shape x the shapes of one launch
         achieved = flops / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "gemm_nt_wide_kernel<1,0> at D.fc2.0 (M=%d N=%d K=%d, BN+LeakyReLU prologue, column-statistics + max-pool epilogue, output not stored)"
+        return {"bound": "mfma", "kernel": "gemm_nt_wide_kernel<1,0,0> at D.fc2.0 (M=%d N=%d K=%d, BN+LeakyReLU prologue, column-statistics + max-pool epilogue, output not stored)"
                                            % (self.M, DOMINANT["N"], DOMINANT["K"]),
                 "achieved": round(achieved, 2), "peak": self.peak, "unit": "TFLOP/s", "frac": round(achieved / self.peak, 4),
                 "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches_timed": len(dom), "traffic": _pmc_traffic(),
