@@ -204,14 +204,24 @@ class DHeadFn(Function):
         logits, hs = nets.d_head_forward(P, pooled)
         ctx.holder, ctx.hs = holder, hs
         ctx.save_for_backward(pooled, *params)
-        return logits
+        sizes = getattr(holder, "sizes", None)
+        if sizes is None:
+            return logits
+        # one output per pass (row blocks of the one logits buffer): the caller's per-pass losses then hand their gradients straight to
+        # this node -- slicing a single output instead costs a zero-fill, a copy and an add per slice in autograd's slice backward
+        return tuple(logits.split(list(sizes), dim=0))
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         pooled, *params = ctx.saved_tensors
         names = ctx.holder.names
         need_dp = any(ctx.needs_input_grad[2:])
         P = dict(zip(names, [nets.owned(p) for p in params]))
+        if len(douts) == 1:
+            dout = douts[0]
+        else:
+            sizes = ctx.holder.sizes
+            dout = torch.cat([d if d is not None else pooled.new_zeros((n, 1)) for d, n in zip(douts, sizes)], dim=0)
         gpool, grads, _ = nets.d_head_backward(P, pooled, ctx.hs, dout.detach().contiguous(), need_dp)
         gp = gpool if ctx.needs_input_grad[1] else None
         if not need_dp:

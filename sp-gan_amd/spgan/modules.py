@@ -409,12 +409,9 @@ def _discriminator_forward_stack(self, x, pre=None):
 def _discriminator_forward_heads(self, pooled):
     """The per-shape MLP head of several forward_stack() results as one batch -> one logits tensor per pass."""
     hn, hp = _named(self.mlp, "mlp.")
-    logits = Fn.DHeadFn.apply(_Holder(names=hn), torch.cat(list(pooled), dim=0), *hp)
-    out, lo = [], 0
-    for p in pooled:
-        out.append(logits[lo:lo + p.shape[0]])
-        lo += p.shape[0]
-    return out
+    pooled = list(pooled)
+    outs = Fn.DHeadFn.apply(_Holder(names=hn, sizes=[p.shape[0] for p in pooled]), torch.cat(pooled, dim=0), *hp)
+    return list(outs)
 
 
 Discriminator.forward_many = _discriminator_forward_many
