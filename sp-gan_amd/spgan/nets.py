@@ -536,15 +536,17 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
             sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, s0, s1)
             grads[bn + ".bias"] = s0
         ybar = ops.bn_bwd_apply(xbarA[li], ys[li], mu, inv, None, sums, M, add=add)
+        # phase B's weight-gradient term is accumulated onto phase A's by the split-K reduction itself (beta = 1): no separate add
+        gA = grads[conv + ".weight"]
         if li > 0:
             psc, psh, pinv, pmu = bns[li - 1]
-            gw = ops.gemm_tn(ybar, ys[li - 1], pro=(psc, psh, NEG))
+            ops.gemm_tn(ybar, ys[li - 1], pro=(psc, psh, NEG), out=gA, beta=1.0)
             abar_g = ops.gemm_nt_bnbwd(ybar, _t(W), ys[li - 1], psc, psh, pmu, pinv, NEG)
         else:
-            gw = ops.gemm_tn(ybar, ctx["x_pm"])
+            ops.gemm_tn(ybar, ctx["x_pm"], out=gA, beta=1.0)
             if need_dx:
                 dx = ops.pm_to_cm(ops.gemm_nt(ybar, _t(W)), B, N)
-        grads[conv + ".weight"] = ops.axpby(1.0, gw, 1.0, grads[conv + ".weight"]).view_as(P[conv + ".weight"])
+        grads[conv + ".weight"] = gA.view_as(P[conv + ".weight"])
         grads[conv + ".bias"] = ZERO_GRAD
     return grads, dx
 
