@@ -373,6 +373,19 @@ class Discriminator(nn.Module, _BNCounts):
         h = _Holder(names=names, buffers=_buffers(self), training=self.training, pre=pre)
         return Fn.DiscriminatorFn.apply(h, x.contiguous(), *params)
 
+    def forward_stack_after_stats_pass(self, stats_x, x):
+        """The side effect of a train-mode D(stats_x) whose result nobody reads (`advance_running_stats`) followed by the conv stack of
+        D(x), the shared first three layers of the two passes as one batch (nets.d_forward_after_stats_pass): the G step's
+        D(real); D(G(z)).  Returns the entry to hand to `forward(x, pre=...)`."""
+        _require_gpu(x, "Discriminator"); _require_gpu(stats_x, "Discriminator")
+        if not self.training:
+            raise RuntimeError("forward_stack_after_stats_pass is a train-mode path (batch statistics)")
+        from . import nets
+        names, params = _named(self)
+        with torch.no_grad():
+            P = dict(zip(names, [nets.owned(p) for p in params]))
+            return nets.d_forward_after_stats_pass(P, _buffers(self), stats_x.detach(), x.detach())
+
     def forward_stacks_grouped(self, xs):
         """The conv stacks of several train-mode passes as ONE batch (nets.d_forward_groups): one GEMM and one finalize launch per layer
         for all of them, per-pass BatchNorm statistics, running statistics advanced in list order -- bit-identical to separate calls.

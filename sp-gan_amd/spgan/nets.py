@@ -288,6 +288,53 @@ def d_forward_groups(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], xs
     return res
 
 
+def d_forward_after_stats_pass(P: Dict[str, Tensor], bufs: Dict[str, Tensor], stats_cm: Tensor, x_cm: Tensor):
+    """d_advance_running_stats(stats_cm) followed by d_forward(x_cm, head=False) -- the G step's D(real) side effect and D(G(z)) -- with
+    the first three layers of the two passes evaluated as ONE batch (per-pass BatchNorm, running statistics real first): three GEMM and
+    three finalize launches instead of six and six.  The 1024-wide layer stays separate: the statistics pass replaces it by the
+    covariance form (d_advance_running_stats), the real pass runs it with the pooling epilogue.  Bit-identical to the two calls.
+    Returns (pooled, ctx) of x_cm."""
+    B, _, N = x_cm.shape
+    M = B * N
+    if tuple(stats_cm.shape) != (B, 3, N) or N % ops.ROW_TILE:
+        raise ValueError("d_forward_after_stats_pass needs equally shaped inputs [B,3,N] with N %% %d == 0" % ops.ROW_TILE)
+    x_pm = ops.cm_to_pm(torch.cat([stats_cm.contiguous(), x_cm.contiguous()], dim=0))
+    ys_all, outs = [], []
+    a, pro = x_pm, None
+    for conv, bn in D_LAYERS[:3]:
+        y, out = ops.gemm_bn_groups(a, _w2(P[conv + ".weight"]), P[conv + ".bias"],
+                                    (P[bn + ".weight"], P[bn + ".bias"], bufs[bn + ".running_mean"], bufs[bn + ".running_var"]), 2, pro=pro)
+        _count_bn_call(bufs, bn); _count_bn_call(bufs, bn)
+        ys_all.append(y); outs.append(out)
+        a, pro = y, (out[0], out[1], NEG)
+    conv, bn = D_LAYERS[3]
+    W, b4 = _w2(P[conv + ".weight"]), P[conv + ".bias"]
+    # pass 0 (statistics only): fc2.1's running statistics from the covariance of a3 (see d_advance_running_stats)
+    _advance_top_running_stats(P, bufs, ys_all[2][:M], outs[2][0, 0], outs[2][1, 0], M)
+    # pass 1: the real forward of the 1024-wide layer with BatchNorm + LeakyReLU + max-pool fused
+    y3 = ys_all[2][M:]
+    _, (sc, sh, inv, mu), pooled, argmax, yarg = ops.gemm_bn_pool(y3, W, b4, (P[bn + ".weight"], P[bn + ".bias"], bufs[bn + ".running_mean"], bufs[bn + ".running_var"]),
+                                                                 N, NEG, pro=(outs[2][0, 1], outs[2][1, 1], NEG))
+    _count_bn_call(bufs, bn)
+    ys = [y[M:] for y in ys_all] + [None]
+    bns = [(o[0, 1], o[1, 1], o[2, 1], o[3, 1]) for o in outs] + [(sc, sh, inv, mu)]
+    ctx = dict(B=B, N=N, x_pm=x_pm[M:], ys=ys, bns=bns, pooled=pooled, argmax=argmax, yarg=yarg, hs=None, training=True)
+    return pooled, ctx
+
+
+def _advance_top_running_stats(P, bufs, y3: Tensor, sc3: Tensor, sh3: Tensor, M: int) -> None:
+    """fc2.1's running statistics for a pass whose 1024-wide output is never formed: mean4 = mean(a3).W^T + b4, var4[c] = w_c^T Cov(a3) w_c."""
+    conv, bn = D_LAYERS[3]
+    W, b4 = _w2(P[conv + ".weight"]), P[conv + ".bias"]
+    a3 = ops.affine_act(y3, sc3, sh3, NEG)
+    mu_a = ops.colsum(a3)[0] * (1.0 / M)
+    neg_ones, neg_inv_m = _const_vec(mu_a.numel(), -1.0, mu_a.device), _const_vec(mu_a.numel(), -1.0 / M, mu_a.device)
+    cov = ops.rowscale_outer(ops.gemm_tn(a3, a3, pro=(neg_ones, mu_a, 1.0)), neg_inv_m)
+    mean4 = ops.gemm_nt(mu_a.view(1, -1), W, b4, exact=True)[0]
+    var4 = ops.rowdot(W, ops.gemm_nt(W, cov, exact=True))
+    _bn_train(mean4.contiguous(), var4, P, bufs, bn, M, True, True)
+
+
 def d_advance_running_stats(P: Dict[str, Tensor], bufs: Dict[str, Tensor], x_cm: Tensor) -> None:
     """The side effect of a train-mode D(x) whose logits nobody reads: the G-step of the reference loop calls D(real)
     (model.py:272-273) although gen_loss ignores d_real -- only the four BatchNorm layers' running statistics (and call counts)
@@ -300,19 +347,11 @@ def d_advance_running_stats(P: Dict[str, Tensor], bufs: Dict[str, Tensor], x_cm:
     for conv, bn in D_LAYERS[:3]:
         y, (sc, sh, inv, mu) = _gemm_bn(a, _w2(P[conv + ".weight"]), P[conv + ".bias"], P, bufs, bn, M, True, True, pro=pro)
         a, pro = y, (sc, sh, NEG)
-    conv, bn = D_LAYERS[3]
-    W, b4 = _w2(P[conv + ".weight"]), P[conv + ".bias"]
-    a3 = ops.affine_act(a, pro[0], pro[1], NEG)
-    mu_a = ops.colsum(a3)[0] * (1.0 / M)
-    neg_ones, neg_inv_m = _const_vec(mu_a.numel(), -1.0, mu_a.device), _const_vec(mu_a.numel(), -1.0 / M, mu_a.device)
     # Cov(a3) = a3^T (a3 - 1 mu^T) / M: the second operand is centred on load (gemm_tn's affine prologue with slope 1), so no
     # Gram/M - mu mu^T difference of two large numbers is formed (a3 is a LeakyReLU output: its means are not small); what
     # rounding leaves of a negative variance is clamped by bn_prepare.  Written with constant vectors only: the prologue forms
     # -(a3 - mu) = a3*(-1) + mu and the row scaling multiplies by -1/M.
-    cov = ops.rowscale_outer(ops.gemm_tn(a3, a3, pro=(neg_ones, mu_a, 1.0)), neg_inv_m)
-    mean4 = ops.gemm_nt(mu_a.view(1, -1), W, b4, exact=True)[0]
-    var4 = ops.rowdot(W, ops.gemm_nt(W, cov, exact=True))
-    _bn_train(mean4.contiguous(), var4, P, bufs, bn, M, True, True)
+    _advance_top_running_stats(P, bufs, a, pro[0], pro[1], M)
 
 
 def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for_double: bool = False, gpool: Optional[Tensor] = None):

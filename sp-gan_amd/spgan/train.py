@@ -280,9 +280,14 @@ class TrainStep:
         g_real_logit = None
         if self.reference_schedule:
             g_real_logit = D(real_t)
+            g_fake_logit = D(g_fake)
+        elif (self.batch_d_forwards and hasattr(D, "forward_stack_after_stats_pass") and D.training and g_fake.shape[2] % ops.ROW_TILE == 0
+              and tuple(g_fake.shape) == tuple(real_t.shape)):
+            # the statistics pass of D(real) and the conv stack of D(G(z)) share their first three layers as one batch
+            g_fake_logit = D(g_fake, pre=D.forward_stack_after_stats_pass(real_t, g_fake))
         else:
             D.advance_running_stats(real_t)
-        g_fake_logit = D(g_fake)
+            g_fake_logit = D(g_fake)
         out5, seed = gen_loss_with_grads(g_fake_logit, self.gan, self.flip_g)      # gen_loss ignores d_real (loss_utils.py:727-802)
         with fused_grad_accumulation():
             torch.autograd.backward([g_fake_logit], [seed])

@@ -594,3 +594,52 @@ def test_discriminator_forward_many_equals_separate_calls_gpu(sp):
         assert rel_l2(a_.numpy(), b_.numpy(), "forward_many|grad|" + n) <= 3e-6 or (a_ - b_).abs().max().item() <= 1e-7, n
     for k in res[0][2]:
         assert torch.equal(res[1][2][k], res[0][2][k]), k
+
+
+def test_discriminator_grouped_passes_equal_separate_calls(sp):
+    """Discriminator.forward_stacks_grouped (the D step's D(real), D(fake), D(x_hat) conv stacks as one batch) and
+    forward_stack_after_stats_pass (the G step's statistics pass + D(G(z))): logits, every gradient and all BatchNorm buffers are those
+    of the separate calls, bit for bit."""
+    B, N = 4, 256
+    params = fr.init_params(orc.discriminator_shapes(), salt=11)
+    xs = [(fr.synthetic_real(B, N, seed=90 + i) * (1.0 + 0.2 * i)).transpose(2, 1).contiguous().cuda() for i in range(3)]
+    seeds = [fr.normal("grp.seed%d" % i, (B, 1)).cuda() for i in range(3)]
+
+    def run(grouped):
+        D = _load(sp.Discriminator(Opts), params).train()
+        ins = [x.clone().requires_grad_(True) for x in xs]
+        if grouped:
+            pre = D.forward_stacks_grouped(ins)
+            logits = D.forward_heads([D.forward_stack(ins[0], pre=pre[0]), D.forward_stack(ins[1], pre=pre[1])]) + [D(ins[2], pre=pre[2])]
+        else:
+            logits = D.forward_heads([D.forward_stack(ins[0]), D.forward_stack(ins[1])]) + [D(ins[2])]
+        torch.autograd.backward(logits, seeds)
+        return ([l.detach().clone() for l in logits], [i.grad.clone() for i in ins], {n: p.grad.clone() for n, p in D.named_parameters()},
+                {k: v.clone() for k, v in D.state_dict().items() if k in dict(D.named_buffers())})
+
+    a, b = run(False), run(True)
+    for la, lb in zip(a[0], b[0]):
+        assert torch.equal(la, lb)
+    for ga, gb in zip(a[1], b[1]):
+        assert torch.equal(ga, gb)
+    for n in a[2]:
+        assert torch.equal(a[2][n], b[2][n]), n
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+
+    def run_g(grouped):
+        D = _load(sp.Discriminator(Opts), params).train()
+        x = xs[1].clone().requires_grad_(True)
+        if grouped:
+            logit = D(x, pre=D.forward_stack_after_stats_pass(xs[0], x))
+        else:
+            D.advance_running_stats(xs[0])
+            logit = D(x)
+        sp.requires_grad(D, False)
+        (logit * seeds[0]).sum().backward()
+        return logit.detach().clone(), x.grad.clone(), {k: v.clone() for k, v in D.state_dict().items() if k in dict(D.named_buffers())}
+
+    a, b = run_g(False), run_g(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
