@@ -98,8 +98,8 @@ def _pmc_traffic():
 # statistics + max-pool partials>, 256x256 tiles (csrc/gemm_wide.hip; round 1 and the first half of round 2 ran it as gemm_nt_kernel<1,0,1,0,1,0>
 # with 128x64 tiles), at the Discriminator's 256->1024 layer (Discriminator.py:74-81,104): N = 1024, K = 256, M = B*N points per pass.
 # Per step: ONE launch over the rows of three passes (D(real), D(fake), D(interpolate) of the D step, batched with per-pass BatchNorm:
-# M = 3*B*N, 103 GF) and ONE launch for D(fake) of the G step (M = B*N, 34.4 GF) -- the roofline entry times the latter, the launch
-# whose shape is the per-pass figure of SURVEY 8(d); the batched launch runs at the same rate (profiles/r02_mfma_shapes.txt: 891 us = 115.6 TF).
+# M = 3*B*N, 103 GF) and ONE launch for D(fake) of the G step (M = B*N, 34.4 GF).  The roofline entry covers both: FLOPs and time
+# averaged per launch (achieved = sum FLOPs / sum time), each shape also listed on its own (`per_shape`).
 # (The G step's unused D(real) only advances running statistics, TrainStep._seg_g.)
 DOMINANT = {"N": 1024, "K": 256, "a_mode": 1,
             "pmc_key": "gemm_nt D.fc2.0 M=65536 N=1024 K=256 (affine prologue + statistics + pooling partials, output not stored)"}
@@ -133,7 +133,8 @@ class MfmaAccounting:
                 bn = 128 if (a.N > 64 and a.K >= 512) else (64 if a.N > 32 else 32)
             useful = 2.0 * a.M * a.N * a.K * batch
             issued = 2.0 * _cdiv(a.M, 128) * 128 * _cdiv(a.N, bn) * bn * _cdiv(a.K, 32) * 32 * batch
-            dom = (a.M == self.M and a.N == DOMINANT["N"] and a.K == DOMINANT["K"] and a.a_mode == DOMINANT["a_mode"] and bool(a.stats))
+            # every launch of the dominant kernel at this layer: one pass (M = B*N, the G step) or three passes in one launch (D step)
+            dom = (a.M % self.M == 0 and a.N == DOMINANT["N"] and a.K == DOMINANT["K"] and a.a_mode == DOMINANT["a_mode"] and bool(a.stats))
             return useful, issued, dom
         if kind == "gemm_tn":
             skinny = (a.Na <= 4 or a.Nb <= 4) and a.Na <= 2048 and a.Nb <= 2048
@@ -156,22 +157,34 @@ class MfmaAccounting:
         stream = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        self.rec.append((kind, c[0], c[1], e0, e1, c[2]))
+        self.rec.append((kind, c[0], c[1], e0, e1, c[2], int(getattr(a, "M", 0))))
         return lambda: e1.record(stream)
 
     def roofline(self):
-        dom = [(r[3], r[4]) for r in self.rec if r[5]]
+        dom = [(r[3], r[4], r[6]) for r in self.rec if r[5]]
         if not dom:
             return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1 in dom) / len(dom)
-        flops = 2.0 * self.M * DOMINANT["N"] * DOMINANT["K"]          # 2*N*256*1024 per shape x the shapes of one launch
+        # All launches of the dominant kernel at this layer.  SURVEY 8(d): 2*256*1024 FLOPs per point x the points of a launch; the
+        # launches differ in size (one pass or three), so FLOPs and time are averaged per launch: achieved = sum FLOPs / sum time.
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in dom) / len(dom)
+        flops = sum(2.0 * m * DOMINANT["N"] * DOMINANT["K"] for _, _, m in dom) / len(dom)
         achieved = flops / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "gemm_nt_wide_kernel<1,0,0> at D.fc2.0 (M=%d N=%d K=%d, BN+LeakyReLU prologue, column-statistics + max-pool epilogue, output not stored)"
-                                           % (self.M, DOMINANT["N"], DOMINANT["K"]),
+        by_m = {}
+        for e0, e1, m in dom:
+            d = by_m.setdefault(m, [0, 0.0]); d[0] += 1; d[1] += e0.elapsed_time(e1)
+        per_shape = {("M=%d" % m): {"launches_timed": c, "avg_launch_ms": round(t / c, 4),
+                                    "frac": round(2.0 * m * DOMINANT["N"] * DOMINANT["K"] / (t / c * 1e-3) / 1e12 / self.peak, 4)} for m, (c, t) in sorted(by_m.items())}
+        rows_avg = sum(m for _, _, m in dom) / len(dom)
+        t1 = _pmc_traffic()
+        return {"bound": "mfma", "kernel": "gemm_nt_wide_kernel<1,0,0> at D.fc2.0 (N=%d K=%d, BN+LeakyReLU prologue, column-statistics + max-pool epilogue, output not stored): "
+                                           "per step one launch over the three D-step passes (M=%d) and one for the G step (M=%d)"
+                                           % (DOMINANT["N"], DOMINANT["K"], 3 * self.M, self.M),
                 "achieved": round(achieved, 2), "peak": self.peak, "unit": "TFLOP/s", "frac": round(achieved / self.peak, 4),
-                "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches_timed": len(dom), "traffic": _pmc_traffic(),
-                "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/); algorithmic = A 67.1 MB + W 1.0 MB read once "
-                                "(68.2 MB) + this kernel's own statistics/pooling partials 12.6 MB written"}
+                "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches_timed": len(dom), "per_shape": per_shape,
+                "traffic": None if t1 is None else int(t1 * rows_avg / self.M),
+                "traffic_note": "HBM bytes per launch: measured for the one-pass launch (M=%d) in separate rocprofv3 --pmc passes (profiles/r02_pmc_gemm_nt.json: %s B "
+                                "= 1.10x its algorithmic 80.7 MB: A 67.1 MB + W 1.0 MB read once + own statistics/pooling records 12.6 MB written), scaled by the "
+                                "average rows per launch (operand and records grow with the rows)" % (self.M, t1)}
 
     def summary(self, steps, step_ms):
         if not self.rec:

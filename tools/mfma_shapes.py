@@ -46,7 +46,7 @@ def main():
     spgan.ops.launch_timer = None
     agg = {}
     for r in acct.rec:
-        d = agg.setdefault(r[6], [0, 0.0, 0.0, 0.0])
+        d = agg.setdefault(r[-1], [0, 0.0, 0.0, 0.0])
         d[0] += 1; d[1] += r[3].elapsed_time(r[4]); d[2] += r[1]; d[3] += r[2]
     tot = sum(v[1] for v in agg.values()) / steps
     print("# matrix-core launches of one WGAN-GP train step (B=32, N=2048, %s operands): %.3f ms/step in %d launches" % ("f16" if f16 else "f32", tot, len(acct.rec) // steps))
