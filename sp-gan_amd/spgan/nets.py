@@ -309,12 +309,14 @@ def d_forward_after_stats_pass(P: Dict[str, Tensor], bufs: Dict[str, Tensor], st
         a, pro = y, (out[0], out[1], NEG)
     conv, bn = D_LAYERS[3]
     W, b4 = _w2(P[conv + ".weight"]), P[conv + ".bias"]
-    # pass 0 (statistics only): fc2.1's running statistics from the covariance of a3 (see d_advance_running_stats)
-    _advance_top_running_stats(P, bufs, ys_all[2][:M], outs[2][0, 0], outs[2][1, 0], M)
-    # pass 1: the real forward of the 1024-wide layer with BatchNorm + LeakyReLU + max-pool fused
+    # pass 1: the real forward of the 1024-wide layer with BatchNorm + LeakyReLU + max-pool fused -- its GEMM directly behind the layer
+    # that produced its operand (still in the last-level cache); pass 0 (statistics only: fc2.1's running statistics from the
+    # covariance of a3, see d_advance_running_stats) is issued between that GEMM and its finalize, so the running statistics still
+    # see pass 0 first
     y3 = ys_all[2][M:]
+    stats_pass = lambda: _advance_top_running_stats(P, bufs, ys_all[2][:M], outs[2][0, 0], outs[2][1, 0], M)
     _, (sc, sh, inv, mu), pooled, argmax, yarg = ops.gemm_bn_pool(y3, W, b4, (P[bn + ".weight"], P[bn + ".bias"], bufs[bn + ".running_mean"], bufs[bn + ".running_var"]),
-                                                                 N, NEG, pro=(outs[2][0, 1], outs[2][1, 1], NEG))
+                                                                 N, NEG, pro=(outs[2][0, 1], outs[2][1, 1], NEG), before_finalize=stats_pass)
     _count_bn_call(bufs, bn)
     ys = [y[M:] for y in ys_all] + [None]
     bns = [(o[0, 1], o[1, 1], o[2, 1], o[3, 1]) for o in outs] + [(sc, sh, inv, mu)]

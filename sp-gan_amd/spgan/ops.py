@@ -765,10 +765,12 @@ def maxpool(y: Tensor, B: int, N: int, scale: Optional[Tensor] = None, shift: Op
     return out, arg
 
 
-def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, slope: float, pro=None, keep_y: bool = False):
+def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, slope: float, pro=None, keep_y: bool = False, before_finalize=None):
     """Y = pro(A) @ W^T + bias, train-mode BatchNorm over all rows, LeakyReLU, max over each group of `rows` rows -- the
     tail of the Discriminator's conv stack (Discriminator.py:74-81,104) in one GEMM launch + two small finalize launches; Y
     itself is only written when keep_y.  bn = (gamma, beta, running_mean | None, running_var | None).
+    before_finalize: a callable issued between the GEMM launch and the finalize launches (which update the running statistics) -- for a
+    caller that has to advance the same running statistics with ANOTHER pass first but wants this GEMM to follow its producer directly.
     Returns (Y | None, (scale, shift, invstd, mean), pooled [B,C], argmax int32 [B,C] (global rows), yarg [B,C])."""
     _rowmajor2d(A, "A"); _rowmajor2d(W, "W")
     N, K = W.shape
@@ -805,6 +807,10 @@ def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, sl
     if done is not None:
         done()
     del keep
+    if before_finalize is not None:
+        if FANIN[0]:
+            raise RuntimeError("gemm_bn_pool(before_finalize=...) needs the separate finalize launch (SPGAN_FANIN=0)")
+        before_finalize()
     if not FANIN[0]:
         check(lib.spgan_colstats_finalize_bn(_p(part), tiles, N, M_, 0, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM, _p(rm), _p(rv),
                                              _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _s()), "colstats_finalize_bn", N=N, M=M_)

@@ -467,7 +467,9 @@ def gemm_bn_groups(A, W, bias, bn, groups, pro=None, rows=0, slope=0.0):
     return out, torch.cat(pooled).contiguous(), torch.cat(args).contiguous(), torch.cat(yargs).contiguous()
 
 
-def gemm_bn_pool(A, W, bias, bn, rows, slope, pro=None, keep_y=False):
+def gemm_bn_pool(A, W, bias, bn, rows, slope, pro=None, keep_y=False, before_finalize=None):
+    if before_finalize is not None:
+        before_finalize()                                   # before this pass touches the running statistics
     y, st = gemm_nt(A, W, bias, pro=pro, bn=bn)
     B = y.shape[0] // rows
     pooled, arg = maxpool(y, B, rows, st[0], st[1], slope)
