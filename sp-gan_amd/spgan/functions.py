@@ -263,9 +263,18 @@ class EdgeBlockFn(Function):
     def forward(ctx, holder, x, *params):
         P = dict(zip(holder.names, params))
         x = x.contiguous()
-        idx = holder.idx if holder.idx is not None else ops.knn(x, holder.B, holder.N, holder.k, holder.knn_mode)
-        out, ectx = nets.edgeblock_forward(P, holder.buffers, holder.prefix, x, idx, holder.B, holder.N, holder.training, True,
-                                           getattr(holder, "count_rep", 1))
+        reuse = getattr(holder, "reuse", None)
+        if reuse is not None:
+            out, ectx = reuse                       # evaluated by an earlier identical forward (bn_repeats accounted for it there)
+            out = out.view_as(out)                  # a fresh tensor object for autograd to hang this node on
+            idx = ectx["idx"]
+        else:
+            idx = holder.idx if holder.idx is not None else ops.knn(x, holder.B, holder.N, holder.k, holder.knn_mode)
+            out, ectx = nets.edgeblock_forward(P, holder.buffers, holder.prefix, x, idx, holder.B, holder.N, holder.training, True,
+                                               getattr(holder, "count_rep", 1), getattr(holder, "bn_repeats", 1))
+            keep = getattr(holder, "keep", None)
+            if keep is not None:
+                keep["out"], keep["ctx"] = out, ectx
         ctx.holder, ctx.ectx = holder, ectx
         holder.last_idx = idx
         ctx.save_for_backward(*params)

@@ -201,14 +201,18 @@ class EdgeBlock(nn.Module, _BNCounts):
         self._install_count_hook()
 
     def forward_pm(self, x_pm, B: int, N: int, idx: Optional[torch.Tensor] = None, knn_mode: Optional[int] = None,
-                   graph_cache: Optional[dict] = None, count_rep: int = 1):
+                   graph_cache: Optional[dict] = None, count_rep: int = 1, bn_repeats: int = 1, reuse=None, keep: Optional[dict] = None):
+        """bn_repeats / reuse / keep: one evaluation standing for several identical forwards (Generator: the two forwards of a train
+        step see the same sphere prior and the same weights).  keep: a dict that receives (out, ctx) of this evaluation;
+        reuse = (out, ctx): skip the evaluation, return `out` with `ctx` behind it for the backward pass."""
         names, params = _named(self, "e.")
         if knn_mode is None:
             knn_mode = 1 if self.Fin <= 4 else 0          # coordinates: exact fp64 order (SURVEY H1a); features: fp32 expanded form
         if graph_cache is not None and idx is None:
             idx = graph_cache.get("idx")
         h = _Holder(prefix="e", names=names, buffers=_buffers(self, "e."), B=B, N=N, k=self.k, training=self.training,
-                    knn_mode=knn_mode, idx=idx, last_idx=None, graph_cache=graph_cache, count_rep=count_rep)
+                    knn_mode=knn_mode, idx=idx, last_idx=None, graph_cache=graph_cache, count_rep=count_rep, bn_repeats=bn_repeats,
+                    reuse=reuse, keep=keep)
         out = Fn.EdgeBlockFn.apply(h, x_pm, *params)
         self.last_idx = h.last_idx
         if graph_cache is not None and graph_cache.get("idx") is None:
@@ -307,7 +311,21 @@ class Generator(nn.Module, _BNCounts):
             # EdgeConv1 sees the same N points in every shape: evaluate it for ONE copy (B times less work in forward and
             # backward; exact -- batch statistics of identical copies are those of one copy, and the backward is linear in the
             # upstream gradient, which RepeatRowsFn sums over the copies) and repeat the rows for the per-shape AdaIN.
-            x1_one = self.EdgeConv1.forward_pm(feat[:N], 1, N, knn_mode=1, graph_cache=cache, count_rep=B)
+            # TrainStep announces that this forward and the next one see the same prior and the same weights (D step, then G step):
+            # EdgeConv1 is evaluated once, its running statistics advanced twice (`twin_forward`: "first" / "second")
+            twin = getattr(self, "twin_forward", None)
+            saved = self.__dict__.get("_ec1_twin")
+            stamp = (id(cache), tuple(p._version for p in self.EdgeConv1.parameters()), ops.weights_epoch_of(next(self.EdgeConv1.parameters())), B, N)
+            if twin == "second" and saved is not None and saved["stamp"] == stamp and self.training:
+                x1_one = self.EdgeConv1.forward_pm(feat[:N], 1, N, knn_mode=1, graph_cache=cache, count_rep=B, reuse=(saved["out"], saved["ctx"]))
+                self.__dict__["_ec1_twin"] = None
+            elif twin == "first" and self.training:
+                keep = {"stamp": stamp}
+                x1_one = self.EdgeConv1.forward_pm(feat[:N], 1, N, knn_mode=1, graph_cache=cache, count_rep=B, bn_repeats=2, keep=keep)
+                self.__dict__["_ec1_twin"] = keep
+            else:
+                self.__dict__["_ec1_twin"] = None
+                x1_one = self.EdgeConv1.forward_pm(feat[:N], 1, N, knn_mode=1, graph_cache=cache, count_rep=B)
             if cache["idx_full"] is None:
                 off = (torch.arange(B, device=x.device, dtype=torch.int32) * N).view(B, 1, 1)
                 cache["idx_full"] = (cache["idx"].view(1, N, -1) + off).reshape(B * N, -1).contiguous()

@@ -619,7 +619,22 @@ def conv_out_weight_grad_from_pm(g: Tensor, F_: int, k: int) -> Tensor:
 
 
 def edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int, training: bool = True, update_running: bool = True,
-                      count_rep: int = 1):
+                      count_rep: int = 1, bn_repeats: int = 1):
+    if bn_repeats > 1 and training:
+        # this forward stands for bn_repeats identical ones (same input, same weights: the two generator forwards of a train step see
+        # the same sphere prior): one evaluation, the running statistics advanced bn_repeats times with the same batch statistics
+        with ops.bn_momentum(1.0 - (1.0 - ops.BN_MOMENTUM) ** bn_repeats):
+            out, ctx = edgeblock_forward(P, bufs, pre, x, idx, B, N, training, update_running, count_rep, 1)
+        if bufs is not None and update_running:
+            for _ in range(bn_repeats - 1):
+                for bn in (".conv_w.1", ".conv_x.1", ".conv_w.4"):
+                    _count_bn_call(bufs, pre + bn)
+        return out, ctx
+    return _edgeblock_forward(P, bufs, pre, x, idx, B, N, training, update_running, count_rep)
+
+
+def _edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int, training: bool = True, update_running: bool = True,
+                       count_rep: int = 1):
     """x [M,C] (point-major), idx int32 [M,k] -> out [M,F] + ctx.
     count_rep > 1: x stands for count_rep identical copies of these M rows (the tiled sphere prior): batch statistics are those
     of one copy, only the unbiased-variance count of the running statistics is count_rep times larger."""

@@ -21,6 +21,21 @@ A_PLAIN, A_AFFINE_LRELU, A_EDGE = 0, 1, 2
 EPI_LINEAR, EPI_MASK_OUT, EPI_BNBWD, EPI_EDGE_BNBWD = 0, 1, 2, 3
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+# momentum the train-mode BatchNorm bookkeeping launches use for the running statistics (nets.edgeblock_forward(bn_repeats=r) sets
+# 1 - (1 - BN_MOMENTUM)**r: r updates with the same batch statistics in one)
+_BN_MOM = [BN_MOMENTUM]
+
+
+class bn_momentum:
+    def __init__(self, m: float):
+        self.m = float(m)
+
+    def __enter__(self):
+        self.prev = _BN_MOM[0]
+        _BN_MOM[0] = self.m
+
+    def __exit__(self, *exc):
+        _BN_MOM[0] = self.prev
 ROW_TILE = 128
 
 Tensor = torch.Tensor
@@ -271,7 +286,7 @@ def _fanin_bn(fin, gamma, beta, rm, rv, out4, count_rep: int = 1):
     fin.mode = 0
     fin.gamma, fin.beta, fin.rmean, fin.rvar = _p(gamma), _p(beta), _p(rm), _p(rv)
     fin.scale, fin.shift, fin.invstd, fin.mean_out = _p(out4[0]), _p(out4[1]), _p(out4[2]), _p(out4[3])
-    fin.eps, fin.momentum, fin.count_rep = BN_EPS, BN_MOMENTUM, int(count_rep)
+    fin.eps, fin.momentum, fin.count_rep = BN_EPS, _BN_MOM[0], int(count_rep)
 
 
 # ----------------------------------------------------------------------------- contractions
@@ -358,7 +373,7 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
             mean, var = _finalize(part, 1, part.shape[0], N, M_, 0)
             return Y, bn_prepare(mean[0].contiguous(), var[0].contiguous(), gamma, beta, M_ * count_rep, True, rm, rv)
         out = torch.empty((4, N), dtype=torch.float32, device=A.device)
-        check(lib.spgan_colstats_finalize_bn(_p(part), part.shape[0], N, M_, 0, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM, _p(rm), _p(rv),
+        check(lib.spgan_colstats_finalize_bn(_p(part), part.shape[0], N, M_, 0, _p(gamma), _p(beta), BN_EPS, _BN_MOM[0], _p(rm), _p(rv),
                                              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _s()), "colstats_finalize_bn", N=N, M=M_)
         return Y, (out[0], out[1], out[2], out[3])
     if stats:
@@ -723,8 +738,10 @@ def colsum(X: Tensor, G: Optional[int] = None) -> Tensor:
 
 def bn_prepare(mean: Optional[Tensor], var: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor], count: int,
                training: bool = True, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
-               momentum: float = BN_MOMENTUM, eps: float = BN_EPS):
+               momentum: Optional[float] = None, eps: float = BN_EPS):
     """-> (scale, shift, invstd, mean_used) each [C]; updates the running statistics in place (train mode)."""
+    if momentum is None:
+        momentum = _BN_MOM[0]
     ref = mean if mean is not None else running_mean
     Cn = ref.numel()
     out = torch.empty((4, Cn), dtype=torch.float32, device=ref.device)
@@ -812,7 +829,7 @@ def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, sl
             raise RuntimeError("gemm_bn_pool(before_finalize=...) needs the separate finalize launch (SPGAN_FANIN=0)")
         before_finalize()
     if not FANIN[0]:
-        check(lib.spgan_colstats_finalize_bn(_p(part), tiles, N, M_, 0, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM, _p(rm), _p(rv),
+        check(lib.spgan_colstats_finalize_bn(_p(part), tiles, N, M_, 0, _p(gamma), _p(beta), BN_EPS, _BN_MOM[0], _p(rm), _p(rv),
                                              _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _s()), "colstats_finalize_bn", N=N, M=M_)
     pooled = torch.empty((B, N), dtype=torch.float32, device=dev)
     yarg = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -874,7 +891,7 @@ def gemm_bn_groups(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, groups: int
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_bn_groups", M=M_, N=N, K=K, groups=groups)
     if done is not None:
         done()
-    check(lib.spgan_colstats_finalize_bn_groups(_p(part), groups, tiles // groups, N, Mg, 0, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM, _p(rm), _p(rv),
+    check(lib.spgan_colstats_finalize_bn_groups(_p(part), groups, tiles // groups, N, Mg, 0, _p(gamma), _p(beta), BN_EPS, _BN_MOM[0], _p(rm), _p(rv),
                                                 _p(out), _s()), "colstats_finalize_bn_groups", N=N, groups=groups)
     if rows == 0:
         return Y, out
@@ -952,7 +969,7 @@ def edge_stats_bn(PQR: Tensor, idx: Tensor, b1: Tensor, bx: Tensor, bn_w, bn_x, 
     gw, bw, rmw, rvw = bn_w
     gx, bx_, rmx, rvx = bn_x
     check(lib.spgan_colstats_finalize_bn2(_p(part), tiles, Cn, M_ * k, tr, H, _p(_vec(gw, H, "gamma_w")), _p(_vec(bw, H, "beta_w")), _p(rmw), _p(rvw),
-                                          _p(_vec(gx, F_, "gamma_x")), _p(_vec(bx_, F_, "beta_x")), _p(rmx), _p(rvx), BN_EPS, BN_MOMENTUM, int(count_rep),
+                                          _p(_vec(gx, F_, "gamma_x")), _p(_vec(bx_, F_, "beta_x")), _p(rmx), _p(rvx), BN_EPS, _BN_MOM[0], int(count_rep),
                                           _p(out), _s()), "colstats_finalize_bn2", C=Cn, G=M_ * k)
     return tuple(out[i, :H] for i in range(4)), tuple(out[i, H:] for i in range(4))
 

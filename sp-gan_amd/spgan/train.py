@@ -71,6 +71,9 @@ class TrainStep:
         # the separate calls, running statistics advanced in the reference's order real, fake, x_hat).  The backward passes run per
         # pass as before, on views of the batched activations.
         self.batch_d_forwards = not reference_schedule and hasattr(D, "forward_stacks_grouped") and os.environ.get("SPGAN_BATCH_D", "1") != "0"
+        # The generator's two forwards of a step (D step, G step) see the same sphere prior and the same weights: EdgeConv1, which
+        # depends on nothing else, is evaluated once and its BatchNorm running statistics are advanced twice (Generator.twin_forward).
+        self.twin_g_forwards = not reference_schedule and os.environ.get("SPGAN_TWIN_G", "1") != "0"
 
     # ------------------------------------------------------------------ hipGraph replay
     def _bn_modules(self):
@@ -233,7 +236,11 @@ class TrainStep:
         B, N, _ = real.shape
         requires_grad(G, False); requires_grad(D, True)
         self.optD.zero_grad()
-        fake = G(x, z_d).detach()
+        G.twin_forward = "first" if self.twin_g_forwards else None
+        try:
+            fake = G(x, z_d).detach()
+        finally:
+            G.twin_forward = None
         real_t = ops.pm_to_cm(real.reshape(B * N, 3), B, N)                      # real_points.transpose(2,1)
         pre_hat = x_hat = None
         if self.batch_d_forwards and D.training and N % ops.ROW_TILE == 0 and tuple(fake.shape) == tuple(real_t.shape):
@@ -274,7 +281,11 @@ class TrainStep:
         self.optD.step(scale_d)
         requires_grad(G, True); requires_grad(D, False)
         self.optG.zero_grad()
-        g_fake = G(x, z_g)
+        G.twin_forward = "second" if self.twin_g_forwards else None
+        try:
+            g_fake = G(x, z_g)
+        finally:
+            G.twin_forward = None
         # model.py:272-274: d_real = D(real) is computed but gen_loss ignores it (loss_utils.py:727-802) -- what lasts of that call
         # are D's BatchNorm running statistics, advanced here without the 1024-wide layer, the pool and the head
         g_real_logit = None

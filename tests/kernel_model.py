@@ -295,7 +295,10 @@ def colsum(X, G=None):
     return X.reshape(M // G, G, C).sum(1)
 
 
-def bn_prepare(mean, var, gamma, beta, count, training=True, running_mean=None, running_var=None, momentum=BN_MOMENTUM, eps=BN_EPS):
+def bn_prepare(mean, var, gamma, beta, count, training=True, running_mean=None, running_var=None, momentum=None, eps=BN_EPS):
+    if momentum is None:
+        from spgan import ops as _ops
+        momentum = _ops._BN_MOM[0]                       # ops.bn_momentum(...) contexts apply to the doubles as they do to the kernels
     if training:
         m, v = mean, var.clamp(min=0)
         if running_mean is not None:

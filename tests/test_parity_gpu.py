@@ -643,3 +643,37 @@ def test_discriminator_grouped_passes_equal_separate_calls(sp):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for k in a[2]:
         assert torch.equal(a[2][k], b[2][k]), k
+
+
+def test_twin_generator_forwards_reuse_edgeconv1(sp):
+    """TrainStep evaluates EdgeConv1 once for the generator's two forwards of a step (same sphere prior, same weights) and advances
+    its BatchNorm running statistics twice in one update.  Against the step that evaluates it twice: every output, gradient and
+    parameter bit for bit; the three running-statistics pairs to rounding (one combined update vs two), the call counters exactly."""
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    real = fr.synthetic_real(B, N, seed=81).cuda()
+    z_d, z_g = fr.latent(B, N, seed=82)[:, :1, :].contiguous().cuda(), fr.latent(B, N, seed=83)[:, :1, :].contiguous().cuda()
+    alpha = fr.uniform("twin.alpha", (B, 1, 1), 0.0, 1.0).cuda()
+    res = []
+    for twin in (False, True):
+        G = _load(sp.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=8))
+        D = _load(sp.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=8))
+        tr = sp.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0)
+        tr.twin_g_forwards = twin
+        infos = [tr.step(x, real, z_d, z_g, alpha=alpha, keep_grads=True) for _ in range(2)]
+        res.append((infos, {k: v.clone() for k, v in G.state_dict().items()}, {k: v.clone() for k, v in D.state_dict().items()}))
+    (ia, ga, da), (ib, gb, db) = res
+    for s in range(2):
+        assert torch.equal(ia[s]["fake_d"], ib[s]["fake_d"]) and torch.equal(ia[s]["fake_g"], ib[s]["fake_g"])
+        assert torch.equal(ia[s]["loss_d"], ib[s]["loss_d"]) and torch.equal(ia[s]["loss_g"], ib[s]["loss_g"])
+        for n in ia[s]["g_grads"]:
+            assert torch.equal(ia[s]["g_grads"][n], ib[s]["g_grads"][n]), n
+        for n in ia[s]["d_grads"]:
+            assert torch.equal(ia[s]["d_grads"][n], ib[s]["d_grads"][n]), n
+    for k in da:
+        assert torch.equal(da[k], db[k]), k
+    for k in ga:
+        if k.startswith("EdgeConv1.") and ("running_mean" in k or "running_var" in k):
+            assert torch.allclose(ga[k], gb[k], rtol=2e-6, atol=1e-8), k
+        else:
+            assert torch.equal(ga[k], gb[k]), k                   # parameters, the other buffers and every num_batches_tracked
