@@ -158,7 +158,9 @@ typedef struct spgan_gemm_nt_args {
   /* p_group_rows > 0: the rows form M / p_group_rows groups of p_group_rows consecutive rows, and p_scale / p_shift hold one vector per
    * group ([groups, K], row g for the rows of group g) -- several passes of a network with their own train-mode BatchNorm statistics
    * evaluated as ONE product (D(real), D(fake) and D(x_hat) of a D step).  A multiple of 128 (of 256 for the 256 x 256-tile kernel),
-   * M a multiple of it, M > 64.  0: one vector for all rows. */
+   * M a multiple of it, M > 64.  0: one vector for all rows.  Also accepted without a prologue (a_mode PLAIN): then it only tells the
+   * automatic tile-size rule (tile_hint 0) to decide from the rows of ONE group, so that a grouped launch runs the kernel its groups
+   * would run as separate calls (bit-identical results). */
   int p_group_rows;
 } spgan_gemm_nt_args;
 /* number of column blocks (N-tiles) spgan_gemm_nt uses for this problem: sizes the fan-in counters */

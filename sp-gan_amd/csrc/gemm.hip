@@ -1662,8 +1662,8 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a->lda >= a->K && a->ldw >= a->K && a->ldy >= a->N);
   SPGAN_CHECK_ARG((uint64_t)a->M * (uint64_t)a->lda < (1ull << 32) && (uint64_t)a->N * (uint64_t)a->ldw < (1ull << 32));  // 32-bit operand offsets
   if (a->a_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
-  if (a->p_group_rows != 0)  // per-group prologue vectors: whole 128-row tiles per group, not for the M <= 64 kernel
-    SPGAN_CHECK_ARG(a->a_mode != SPGAN_A_PLAIN && a->p_group_rows > 0 && a->p_group_rows % BM == 0 && a->M % a->p_group_rows == 0 && a->M > 64);
+  if (a->p_group_rows != 0)  // row groups (per-group prologue vectors when there is a prologue): whole 128-row tiles per group, not for the M <= 64 kernel
+    SPGAN_CHECK_ARG(a->p_group_rows > 0 && a->p_group_rows % BM == 0 && a->M % a->p_group_rows == 0 && a->M > 64);
   if (a->a_mode == SPGAN_A_EDGE) SPGAN_CHECK_ARG(a->e_idx && a->e_bias && a->e_k > 0);
   if (a->rowbias) SPGAN_CHECK_ARG(a->rows_per_group > 0 && a->ld_rowbias >= a->N);
   if (a->sp_val) SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_AFFINE_LRELU && a->sp_arg && a->sp_rows > 0);

@@ -405,7 +405,9 @@ bool spgan_nt_wide_eligible(const spgan_gemm_nt_args& a) {
 // [M,N]) that costs what the leaner main loop gains (65536 x 256 x 256: 103 -> 107 us), and k-loops of two tiles are all ramp
 // (K = 64: 40 -> 45 us).  Wins: 65536 x 1024 x 256 + statistics/pooling 327 -> 300 us, 65536 x 256 x 128: 57 -> 54, 65536 x 1280 x 128: 224 -> 214.
 bool spgan_nt_wide_pays(const spgan_gemm_nt_args& a) {
-  const long tiles = (long)(a.M / WM) * (a.N / WN);
+  // decided from the rows of ONE group: a grouped launch (several passes of a layer as one product) must run the kernel its passes
+  // would run as separate calls -- the two kernels sum in different orders, and the grouped form is specified as bit-identical
+  const long tiles = (long)((a.p_group_rows > 0 ? a.p_group_rows : a.M) / WM) * (a.N / WN);
   if (tiles < 256 || a.K < 128) return false;
   return a.epi_mode == SPGAN_EPI_LINEAR || tiles >= 512;
 }

@@ -7,6 +7,7 @@ Importing the package does not touch the GPU; the shared library is loaded on fi
 absence is a hard error (there is no CPU fallback).
 """
 from . import dataset, fixture_rng, metrics, ops, pointnet_util, sampling  # noqa: F401
+from .capture import CapturedBody                                          # noqa: F401
 from .losses import GradientPenalty, dis_loss, gen_loss                    # noqa: F401
 from .modules import AdaptivePointNorm, Discriminator, EdgeBlock, Generator, get_edge_features   # noqa: F401
 from .optim import Adam, flatten_module                                    # noqa: F401
@@ -14,4 +15,4 @@ from .parallel import DataParallel, init_process_group_from_env, shard_batch   #
 from .train import TrainStep, requires_grad                                # noqa: F401
 
 __all__ = ["Generator", "Discriminator", "EdgeBlock", "AdaptivePointNorm", "get_edge_features", "dis_loss", "gen_loss",
-           "GradientPenalty", "TrainStep", "Adam", "DataParallel", "requires_grad", "ops", "fixture_rng", "sampling"]
+           "GradientPenalty", "TrainStep", "CapturedBody", "Adam", "DataParallel", "requires_grad", "ops", "fixture_rng", "sampling"]

@@ -118,8 +118,10 @@ class HostStagedLoader:
     the normalised set stays in pinned host memory; a batch is gathered / shuffled / augmented on the host (numpy, as the reference's
     DataLoader workers do, H5DataLoader.py:113-118) straight into one of two pinned staging buffers and copied to the device on a
     side stream while the previous batch is being consumed; the consumer's stream waits on the copy's event, never the host.
-    Same iteration contract as DeviceDataset (shuffle=True, drop_last=True); yields [bs, np, 3] device tensors that stay valid
-    until the batch after next is requested."""
+    Same iteration contract as DeviceDataset (shuffle=True, drop_last=True); yields [bs, np, 3] device tensors.  A yielded batch is
+    valid only UNTIL THE NEXT ONE IS REQUESTED: asking for batch b+1 stages batch b+2 into the device slot batch b was handed out from
+    (the copy waits for the consumer-stream work enqueued before that request, not for work enqueued later) -- clone a batch that
+    has to outlive the next `next()`."""
 
     def __init__(self, source, num_points: int = 2048, batch_size: int = 32, scale: float = 1.0, augment: bool = False,
                  device="cuda", seed: Optional[int] = None):
@@ -179,8 +181,12 @@ class HostStagedLoader:
                 self._stage(slot ^ 1, order[(b + 1) * bs:(b + 2) * bs])        # next batch: host work + H2D overlap the consumer
             if self._copy is not None:
                 torch.cuda.current_stream().wait_event(self._done[slot])
-            yield self._dev[slot]
-            if self._copy is not None:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                self._free[slot] = ev
+            try:
+                yield self._dev[slot]
+            finally:
+                # also when the consumer leaves the loop early (break / exception / generator close): the next epoch's copy into
+                # this slot must still wait for the work that read it
+                if self._copy is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    self._free[slot] = ev

@@ -270,7 +270,8 @@ class EdgeBlockFn(Function):
             idx = ectx["idx"]
         else:
             idx = holder.idx if holder.idx is not None else ops.knn(x, holder.B, holder.N, holder.k, holder.knn_mode)
-            out, ectx = nets.edgeblock_forward(P, holder.buffers, holder.prefix, x, idx, holder.B, holder.N, holder.training, True,
+            out, ectx = nets.edgeblock_forward(P, holder.buffers, holder.prefix, x, idx, holder.B, holder.N, holder.training,
+                                               getattr(holder, "update_running", True),
                                                getattr(holder, "count_rep", 1), getattr(holder, "bn_repeats", 1))
             keep = getattr(holder, "keep", None)
             if keep is not None:

@@ -59,7 +59,8 @@ def _ones_like(t: torch.Tensor) -> torch.Tensor:
     o = _ONES.get(key)
     if o is None:
         o = torch.ones_like(t)
-        _ONES[key] = o
+        if not ops.capturing():        # see nets._const_vec
+            _ONES[key] = o
     return o
 
 

@@ -201,7 +201,8 @@ class EdgeBlock(nn.Module, _BNCounts):
         self._install_count_hook()
 
     def forward_pm(self, x_pm, B: int, N: int, idx: Optional[torch.Tensor] = None, knn_mode: Optional[int] = None,
-                   graph_cache: Optional[dict] = None, count_rep: int = 1, bn_repeats: int = 1, reuse=None, keep: Optional[dict] = None):
+                   graph_cache: Optional[dict] = None, count_rep: int = 1, bn_repeats: int = 1, reuse=None, keep: Optional[dict] = None,
+                   update_running: bool = True):
         """bn_repeats / reuse / keep: one evaluation standing for several identical forwards (Generator: the two forwards of a train
         step see the same sphere prior and the same weights).  keep: a dict that receives (out, ctx) of this evaluation;
         reuse = (out, ctx): skip the evaluation, return `out` with `ctx` behind it for the backward pass."""
@@ -212,7 +213,7 @@ class EdgeBlock(nn.Module, _BNCounts):
             idx = graph_cache.get("idx")
         h = _Holder(prefix="e", names=names, buffers=_buffers(self, "e."), B=B, N=N, k=self.k, training=self.training,
                     knn_mode=knn_mode, idx=idx, last_idx=None, graph_cache=graph_cache, count_rep=count_rep, bn_repeats=bn_repeats,
-                    reuse=reuse, keep=keep)
+                    reuse=reuse, keep=keep, update_running=update_running)
         out = Fn.EdgeBlockFn.apply(h, x_pm, *params)
         self.last_idx = h.last_idx
         if graph_cache is not None and graph_cache.get("idx") is None:
@@ -323,8 +324,15 @@ class Generator(nn.Module, _BNCounts):
                 keep = {"stamp": stamp}
                 x1_one = self.EdgeConv1.forward_pm(feat[:N], 1, N, knn_mode=1, graph_cache=cache, count_rep=B, bn_repeats=2, keep=keep)
                 self.__dict__["_ec1_twin"] = keep
-            else:
+            elif twin == "second" and saved is not None and self.training:
+                # announced as the twin of an earlier forward that already advanced EdgeConv1's running statistics for BOTH, but its
+                # output cannot be reused (the weights, the prior or the batch changed in between): evaluate, do not advance them a
+                # third time
                 self.__dict__["_ec1_twin"] = None
+                x1_one = self.EdgeConv1.forward_pm(feat[:N], 1, N, knn_mode=1, graph_cache=cache, count_rep=B, update_running=False)
+            else:
+                if twin is not None:                 # a forward outside the twin protocol (eval call, sample dump) leaves a pending twin alone
+                    self.__dict__["_ec1_twin"] = None
                 x1_one = self.EdgeConv1.forward_pm(feat[:N], 1, N, knn_mode=1, graph_cache=cache, count_rep=B)
             if cache["idx_full"] is None:
                 off = (torch.arange(B, device=x.device, dtype=torch.int32) * N).view(B, 1, 1)
@@ -335,8 +343,16 @@ class Generator(nn.Module, _BNCounts):
             x1 = self.EdgeConv1.forward_pm(feat, B, N, knn_mode=0 if self.use_head else 1, graph_cache=cache)
         x1 = self.adain1.forward_pm(x1, style, N, slope)           # lrelu1 fused into the instance norm (Generator.py:175-176)
         self.last_x1 = x1.detach()                                 # [M,64] input of EdgeConv2's graph (diagnostics / parity tests)
-        x2 = self.EdgeConv2.forward_pm(x1, B, N, knn_mode=0)
+        # Tie-aware parity protocol: a caller may hand over EdgeConv2's kNN graph(s) for the next forward(s) --
+        # `inject_graph2([idx, ...])`, int32 [B*N,k] global rows or the reference's int64 [B,N*k] local indices -- e.g. the graph
+        # the reference itself built on this stage, so that everything behind the discrete choice is compared tightly.
+        q = self.__dict__.get("_graph2_queue")
+        idx2 = q.pop(0) if q else None
+        if idx2 is not None and idx2.dtype != torch.int32:
+            idx2 = ops.idx_from_local64(idx2.to(torch.int64).reshape(B, -1), B, N, self.nk)
+        x2 = self.EdgeConv2.forward_pm(x1, B, N, idx=idx2, knn_mode=0)
         x2 = self.adain2.forward_pm(x2, style, N, slope)
+        self.last_x2 = x2.detach()                                 # [M,128] adain2's output (parity tests)
         h = _Holder(buffers=_buffers(self), B=B, N=N, training=self.training)
         if self.use_attn:
             feat = Fn.GlobalFeatFn.apply(h, x2, *self._params_of(Fn.GF_NAMES))                    # [M,640], Generator.py:183-189
@@ -351,6 +367,10 @@ class Generator(nn.Module, _BNCounts):
     def forward(self, x, z):
         _require_gpu(x, "Generator")
         return self._body(x, self._style(x, z))
+
+    def inject_graph2(self, graphs) -> None:
+        """EdgeConv2's neighbour graph for the next len(graphs) forwards, consumed in order (see _body).  None = build it."""
+        self.__dict__["_graph2_queue"] = [None if g is None else g.to(next(self.parameters()).device) for g in graphs]
 
     def interpolate(self, x, z1, z2, selection, alpha, use_latent: bool = False):
         """Generator.py:200-261: blend two latents (or two styles) on the selected points."""

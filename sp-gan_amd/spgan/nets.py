@@ -114,7 +114,8 @@ def _const_vec(n: int, value: float, device) -> Tensor:
     v = _CONST_VEC.get(key)
     if v is None:
         v = torch.full((n,), float(value), dtype=torch.float32, device=device)
-        _CONST_VEC[key] = v
+        if not ops.capturing():        # a constant born inside a capture lives in the graph's pool and is only filled on replay: not cached
+            _CONST_VEC[key] = v
     return v
 
 
@@ -612,6 +613,15 @@ def conv_out_weight_pm(w: Tensor) -> Tensor:
     out = w.detach()[:, :, 0, :].permute(0, 2, 1).reshape(F_, k * F_).contiguous()
     _WO_CACHE[w.data_ptr()] = (stamp, out, weakref.ref(owner))
     return out
+
+
+def drop_weight_caches() -> None:
+    """Forget every cached weight-derived tensor (transposes, permuted conv_out weights).  TrainStep calls this right before it
+    captures a step into a hipGraph: a cache entry filled by an EAGER call after the last optimiser step (a sample dump, an eval
+    forward) would be a hit during the capture, the kernel that derives it would not be recorded, and every replay would read a
+    tensor frozen at capture time that lives outside the graph's memory pool."""
+    _T_CACHE.clear()
+    _WO_CACHE.clear()
 
 
 def conv_out_weight_grad_from_pm(g: Tensor, F_: int, k: int) -> Tensor:

@@ -155,6 +155,11 @@ def weights_epoch_of(p: Tensor) -> int:
     return WEIGHTS_EPOCH_OF.get(p.untyped_storage().data_ptr(), 0)
 
 
+def capturing() -> bool:
+    """Is the current stream being captured into a hipGraph?  (False on a CPU-only build: the host-composition tests.)"""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 class _KnnInfo:
     def __init__(self, B, N, C, k, mode):
         self.B, self.N, self.C, self.k, self.mode = B, N, C, k, mode
@@ -867,7 +872,7 @@ def gemm_bn_groups(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, groups: int
                 raise ValueError("%s must be contiguous [groups, K]" % nm)
         a.a_mode = A_AFFINE_LRELU
         a.p_scale = _p(sc); a.p_shift = _p(sh); a.p_slope = float(ps)
-        a.p_group_rows = Mg if groups > 1 else 0
+    a.p_group_rows = Mg if groups > 1 else 0      # also without a prologue: the tile-size rule looks at the rows of ONE pass
     a.epi_mode = EPI_LINEAR
     a.bias = _p(_vec(bias, N, "bias"))
     tiles = M_ // ROW_TILE

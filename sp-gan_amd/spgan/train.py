@@ -153,6 +153,11 @@ class TrainStep:
         if self._graph is None:
             before = self._bn_snapshot()
             tG, tD = self.optG.t, self.optD.t
+            # weight-derived host caches (transposes, permuted conv_out weights) must be derived INSIDE the capture: an eager forward
+            # since the last optimiser step (a sample dump between two steps) may have filled them
+            from . import nets
+            nets.drop_weight_caches()
+            self.G.__dict__["_ec1_twin"] = None
             try:
                 if self.dpD is None:
                     g = torch.cuda.CUDAGraph()

@@ -661,9 +661,140 @@ def g16():
     d["angle_y"] = np.array(angles, dtype=np.float64); d["scale"] = np.array(scales, dtype=np.float64)
     save("g16_data_path.npz", d)
 
+# ---------------------------------------------------------------- G17: the BENCHMARKED sizes (BASELINE configs[1] and configs[3] per GPU)
+def _g17_cfgs():
+    return (("c2", 32, 2048), ("c4", 16, 4096))
+
+
+def g17():
+    """Round-2 review item 1: numeric pins at the sizes bench.py times -- C2 (B=32, N=2048) and C4's per-GPU shape (B=16, N=4096).
+    (a) Discriminator.forward / backward and the gradient penalty (Discriminator.py:97-115, gradient_penalty.py:19-37): logits in
+        full, summaries (l2, sum, strided samples) of the input gradient and every parameter gradient, BatchNorm buffers in full;
+    (b) Generator.forward (Generator.py:160-198) with the reference's own EdgeConv2 graph stored as int16 (the tie-aware protocol:
+        the graph is injected into the build under test), stage summaries x1 / x2 / out and parameter gradients for an injected
+        upstream;
+    (c) at C2 one full WGAN-GP D-step + G-step (model.py:239-279 with the build contract of SURVEY 8(a)7), both EdgeConv2 graphs
+        stored, losses, generated clouds, gradients, post-Adam parameters and buffers as summaries."""
+    for tag, B, N in _g17_cfgs():
+        class O(Opts):
+            np = N
+        d = {}
+        # ---- (a) D
+        D = load_into(Discriminator(O, num_point=N), fr.init_params(orc.discriminator_shapes(), salt=17)).train()
+        real = fr.synthetic_real(B, N, seed=171).transpose(2, 1).contiguous().requires_grad_(True)
+        logit = D(real)
+        loss = ((logit - 1.0) ** 2).mean()
+        grads = torch.autograd.grad(loss, [real] + list(D.parameters()))
+        d["d|logit"] = logit.detach().numpy()
+        put(d, "d|dx", grads[0], nsamp=4096)
+        for (n, _), g in zip(D.named_parameters(), grads[1:]):
+            put(d, "d|grad|" + n, g)
+        for n, b in D.named_buffers():
+            d["d|buf|" + n] = b.numpy().copy()
+        print(tag, "D done", flush=True)
+        # ---- (a) gradient penalty on a fresh D (same weights, untouched running statistics)
+        D = load_into(Discriminator(O, num_point=N), fr.init_params(orc.discriminator_shapes(), salt=17)).train()
+        realc = real.detach()
+        fake = (0.8 * fr.synthetic_real(B, N, seed=172) + 0.05 * fr.normal("g17.n.%s" % tag, (B, N, 3))).transpose(2, 1).contiguous()
+        alpha = fr.uniform("g17.alpha", (B, 1, 1), 0.0, 1.0)
+        orig = torch.rand
+        torch.rand = lambda *a, **k: alpha.clone().requires_grad_(k.get("requires_grad", False))
+        try:
+            gp = GradientPenalty(10.0, gamma=1)(D, realc, fake)
+        finally:
+            torch.rand = orig
+        grads = torch.autograd.grad(gp, list(D.parameters()), allow_unused=True)
+        d["gp|alpha"] = alpha.numpy(); d["gp|value"] = gp.detach().numpy()
+        for (n, p), g in zip(D.named_parameters(), grads):
+            put(d, "gp|grad|" + n, g if g is not None else torch.zeros_like(p))
+        print(tag, "GP done", flush=True)
+        # ---- (b) G with its own graphs recorded
+        G = load_into(Generator(O), fr.init_params(orc.generator_shapes(), salt=17)).train()
+        x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+        z = fr.latent(B, N, seed=173)
+        stages = {}
+        hooks = [G.adain1.register_forward_hook(lambda m, i, o: stages.__setitem__("x1", o.detach().clone())),
+                 G.adain2.register_forward_hook(lambda m, i, o: stages.__setitem__("x2", o.detach().clone()))]
+        out = G(x, z)
+        for h in hooks:
+            h.remove()
+        _, idx2 = get_edge_features(stages["x1"], 10, return_idx=True)
+        assert N <= 32767
+        d["g|idx2"] = idx2.view(B, N, 10).numpy().astype(np.int16)
+        put(d, "g|x1", stages["x1"], nsamp=4096); put(d, "g|x2", stages["x2"], nsamp=4096); put(d, "g|out", out, nsamp=8192)
+        dy = fr.normal("g17.dy.%s" % tag, out.shape)
+        grads = torch.autograd.grad(out, list(G.parameters()), dy)
+        for (n, _), g in zip(G.named_parameters(), grads):
+            put(d, "g|grad|" + n, g)
+        for n, b in G.named_buffers():
+            d["g|buf|" + n] = b.numpy().copy()
+        print(tag, "G done", flush=True)
+        save("g17_fullsize_%s.npz" % tag, d)
+    # ---- (c) the benchmarked train step
+    B, N = 32, 2048
+    d = {}
+    G, D = make_gd(salt=18)
+    optG = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.99))
+    optD = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.99))
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    real = fr.synthetic_real(B, N, seed=181)
+    z_d, z_g = fr.latent(B, N, seed=182), fr.latent(B, N, seed=183)
+    alpha = fr.uniform("g17.step.alpha", (B, 1, 1), 0.0, 1.0)
+    stages = {}
+    hook = G.adain1.register_forward_hook(lambda m, i, o: stages.__setitem__("x1", o.detach().clone()))
+
+    def req(m, f):
+        for p in m.parameters():
+            p.requires_grad = f
+    req(G, False); req(D, True); optD.zero_grad()
+    fake = G(x, z_d).detach()
+    _, idx2 = get_edge_features(stages["x1"], 10, return_idx=True)
+    d["idx2_d"] = idx2.view(B, N, 10).numpy().astype(np.int16)
+    real_t = real.transpose(2, 1).contiguous()
+    d_real, d_fake = D(real_t), D(fake)
+    lossD, _ = LU.dis_loss(d_real, d_fake, gan="wgan")
+    d["d_real"] = d_real.detach().numpy(); d["d_fake"] = d_fake.detach().numpy()
+    orig = torch.rand
+    torch.rand = lambda *a, **k: alpha.clone().requires_grad_(k.get("requires_grad", False))
+    try:
+        gpv = GradientPenalty(10.0, gamma=1)(D, real_t, fake)
+    finally:
+        torch.rand = orig
+    d["gp"] = gpv.detach().numpy()
+    lossD = lossD + gpv
+    lossD.backward()
+    for n, p in D.named_parameters():
+        put(d, "dgrad|" + n, p.grad)
+    optD.step()
+    print("step: D done", flush=True)
+    req(G, True); req(D, False); optG.zero_grad()
+    g_fake = G(x, z_g)
+    _, idx2 = get_edge_features(stages["x1"], 10, return_idx=True)
+    d["idx2_g"] = idx2.view(B, N, 10).numpy().astype(np.int16)
+    hook.remove()
+    g_real_logit = D(real_t)
+    d_gfake = D(g_fake)
+    lossG, _ = LU.gen_loss(g_real_logit, d_gfake, gan="wgan")
+    d["d_gfake"] = d_gfake.detach().numpy()
+    lossG.backward()
+    for n, p in G.named_parameters():
+        put(d, "ggrad|" + n, p.grad)
+    optG.step()
+    d["lossD"] = lossD.detach().numpy(); d["lossG"] = lossG.detach().numpy(); d["alpha"] = alpha.numpy()
+    put(d, "fake_d", fake, nsamp=8192); put(d, "fake_g", g_fake, nsamp=8192)
+    for n, p in G.named_parameters():
+        put(d, "gparam|" + n, p)
+    for n, p in D.named_parameters():
+        put(d, "dparam|" + n, p)
+    for n, b in G.named_buffers():
+        d["gbuf|" + n] = b.numpy().copy()
+    for n, b in D.named_buffers():
+        d["dbuf|" + n] = b.numpy().copy()
+    save("g17_step_c2.npz", d)
+
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for name in which:
         globals()[name]()

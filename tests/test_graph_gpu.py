@@ -10,7 +10,7 @@ from test_parity_gpu import Opts, _load, sp  # noqa: F401  (sp is a fixture)
 pytestmark = pytest.mark.gpu
 
 
-def _run(sp, graph, steps, B=4, N=256, flags=None, lr_change_at=None):
+def _run(sp, graph, steps, B=4, N=256, flags=None, lr_change_at=None, sample_dump_at=()):
     flags = flags or {}
     o = type("O", (Opts,), flags)()
     G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(**flags), salt=8))
@@ -24,6 +24,9 @@ def _run(sp, graph, steps, B=4, N=256, flags=None, lr_change_at=None):
     for i in range(steps):
         if lr_change_at is not None and i == lr_change_at:
             tr.optD.set_lr(5e-5); tr.optG.set_lr(2.5e-5)      # a schedule step (model.py:309-312) after the graph was captured
+        if i in sample_dump_at:
+            with torch.no_grad():                             # model.py:385-392: a sample dump between two iterations (train mode, no_grad)
+                G(x, zs[2])
         info = tr.step(x, real[i % 2], zs[i % 3], zs[(i + 1) % 3], alpha=alpha)
         losses.append((info["loss_d"].item(), info["loss_g"].item()))
     torch.cuda.synchronize()
@@ -42,6 +45,20 @@ def test_graph_replay_equals_eager(sp):
     assert (tre.optG.t, tre.optD.t) == (trg.optG.t, trg.optD.t) == (steps, steps)
     assert torch.equal(tre.optD.m, trg.optD.m) and torch.equal(tre.optG.v, trg.optG.v)
     assert int(trg.optD.dev_state[:1].view(torch.int32).item()) == steps
+
+
+def test_graph_capture_after_an_eager_generator_call(sp):
+    """An eager G(x, z) between the last warm-up step and the capture step (a periodic sample dump) fills the weight-derived host
+    caches (permuted conv_out weights, transposes): the capture must still record the kernels that derive them -- otherwise every
+    replay reads weights frozen at capture time.  Also one dump between replays."""
+    steps = 7
+    Ge, De, tre, le = _run(sp, False, steps, sample_dump_at=(2, 5))       # step 2 is the capture step (graph_warmup=2)
+    Gg, Dg, trg, lg = _run(sp, True, steps, sample_dump_at=(2, 5))
+    assert trg._graph is not None
+    assert le == lg, (le, lg)
+    for (n, a), (_, b) in zip(list(Ge.state_dict().items()) + list(De.state_dict().items()),
+                              list(Gg.state_dict().items()) + list(Dg.state_dict().items())):
+        assert torch.equal(a, b), n
 
 
 def test_graph_replay_follows_lr_schedule(sp):

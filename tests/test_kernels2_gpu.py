@@ -335,7 +335,8 @@ def test_reduce_chunks(ops, parts, n):
 
 @pytest.mark.parametrize("hint", [0, 2])
 @pytest.mark.parametrize("groups,Mg,N,K", [(3, 512, 256, 128), (2, 768, 128, 64), (3, 256, 1024, 256), (1, 512, 256, 32), (3, 20480, 128, 64),
-                                           (2, 16384, 256, 32), (5, 256, 64, 32)])
+                                           (2, 16384, 256, 32), (5, 256, 64, 32),
+                                           (3, 24576, 256, 128)])   # 96 tiles of 256 x 256 per pass, 288 grouped: straddles the tile-size rule
 def test_gemm_bn_groups(ops, groups, Mg, N, K, hint):
     """Several passes through one layer as ONE product (per-pass BatchNorm of the operand and of the output, running statistics
     updated pass after pass): against `groups` separate calls of the single-pass ops -- the activations bit for bit."""

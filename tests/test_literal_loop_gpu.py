@@ -1,0 +1,159 @@
+"""GPU: the reference's train-loop body EXECUTED LITERALLY (Generation/model.py:239-279, statement for statement:
+spgan.reference_loop.reference_loop_body -- separate G() / D() calls, requires_grad toggles per Common/network_utils.py:92-94,
+dis_loss / gen_loss, .backward(), torch.optim.Adam(lr=1e-4, betas=(0.5, 0.99)) per model.py:94-97) on the HIP modules, against
+the golden train steps captured from the reference (G8: the C1 shape B=4, N=512 LS and a B=4, N=256 WGAN-GP step; G17: the
+benchmarked C2 step).  No TrainStep, no spgan.Adam, no fused gradient accumulation, latent tiled [B,N,128] as the reference's
+noise_generator delivers it.  Then the same body under spgan.CapturedBody (the caller's loop replayed as a hipGraph):
+bit-identical parameters, buffers and optimiser state."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import check, golden
+from oracle import spgan_oracle as orc
+from spgan import fixture_rng as fr
+
+pytestmark = pytest.mark.gpu
+
+ZERO_GRAD_BIASES = ("conv_w.0.bias", "conv_w.3.bias", "conv_x.0.bias", "global_conv.0.bias", "global_conv.3.bias",
+                    "mlps.0.bias", "mlps.3.bias", "mlps.6.bias", "fc2.0.bias")
+
+
+def _opts(N):
+    class O:
+        np = N; nk = 20; nz = 128; softmax = True; off = False; attn = False
+        use_head = False; eql = False; z_norm = False; small_d = False
+    return O
+
+
+@pytest.fixture(scope="module")
+def sp():
+    import spgan
+    from spgan import _lib
+    _lib.load()
+    return spgan
+
+
+def _load(module, params):
+    sd = module.state_dict()
+    module.load_state_dict({**sd, **{k: v.detach().clone() for k, v in params.items()}})
+    return module.cuda()
+
+
+def _atol(n):
+    return 2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7
+
+
+def _setup(sp, salt, N, capturable=False):
+    from spgan.reference_loop import LoopState
+    o = _opts(N)
+    G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(), salt=salt))
+    D = _load(sp.Discriminator(o, num_point=N), fr.init_params(orc.discriminator_shapes(), salt=salt))
+    G.train(); D.train()                                                         # model.py:235-236
+    # model.py:94-97
+    optimizerG = torch.optim.Adam(filter(lambda p: p.requires_grad, G.parameters()), lr=1e-4, betas=(0.5, 0.99), capturable=capturable)
+    optimizerD = torch.optim.Adam(filter(lambda p: p.requires_grad, D.parameters()), lr=1e-4, betas=(0.5, 0.99), capturable=capturable)
+    return G, D, optimizerG, optimizerD, LoopState
+
+
+def _compare_with_golden(d, G, D, lossD, lossG, keep, loose_fake=6e-5):
+    np.testing.assert_allclose(lossD.item(), float(d["lossD"]), rtol=3e-3)
+    np.testing.assert_allclose(lossG.item(), float(d["lossG"]), rtol=5e-3, atol=1e-6)
+    check(d, "fake_d", keep["fake_d"], rtol=loose_fake)
+    for n, g in keep["d_grads"].items():
+        check(d, "dgrad|" + n, g, rtol=4e-3, atol=_atol(n))
+    for n, g in keep["g_grads"].items():
+        check(d, "ggrad|" + n, g, rtol=2.5e-2, atol=_atol(n))
+    for n, p in D.named_parameters():
+        if not n.endswith(ZERO_GRAD_BIASES):
+            check(d, "dparam|" + n, p, rtol=1e-3, atol=2.5e-4)
+    for n, p in G.named_parameters():
+        if not n.endswith(ZERO_GRAD_BIASES):
+            check(d, "gparam|" + n, p, rtol=1e-3, atol=2.5e-4)
+    dbuf = dict(D.named_buffers())
+    for n, b in [(k, v) for k, v in D.state_dict().items() if k in dbuf]:
+        np.testing.assert_allclose(b.cpu().numpy(), d["dbuf|" + n], rtol=2e-3, atol=2e-4, err_msg=n)
+    gbuf = dict(G.named_buffers())
+    for n, b in [(k, v) for k, v in G.state_dict().items() if k in gbuf]:
+        np.testing.assert_allclose(b.cpu().numpy(), d["gbuf|" + n], rtol=2e-3, atol=2e-4, err_msg=n)
+
+
+@pytest.mark.parametrize("tag,gan,use_gp,B,N,gp_impl", [("ls", "ls", False, 4, 512, None), ("wgangp", "wgan", True, 4, 256, "spgan"),
+                                                        ("wgangp", "wgan", True, 4, 256, "caller")])
+def test_literal_reference_loop_matches_reference_step(sp, tag, gan, use_gp, B, N, gp_impl):
+    """gp_impl "caller": the penalty written the way Common/gradient_penalty.py:19-37 writes it (plain torch: interpolate,
+    autograd.grad(create_graph=True), norm) around OUR Discriminator -- the caller's code, not spgan.GradientPenalty."""
+    from spgan.reference_loop import reference_loop_body
+    d = golden("g8_train_step_%s.npz" % tag)
+    G, D, optG, optD, LoopState = _setup(sp, 8, N)
+    alpha = torch.from_numpy(d["alpha"]).cuda()
+    gp = None
+    if use_gp and gp_impl == "spgan":
+        gp = lambda netD, real, fake: sp.GradientPenalty(10.0, gamma=1)(netD, real, fake, alpha=alpha)
+    elif use_gp:
+        gp = lambda netD, real, fake: orc.gradient_penalty(netD, real.detach(), fake, alpha, 10.0, 1.0)
+    s = LoopState(G, D, optG, optD, gan=gan, gp=gp)
+    s.keep = {}
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    data = fr.synthetic_real(B, N, seed=81).cuda()
+    z_d, z_g = fr.latent(B, N, seed=82).cuda(), fr.latent(B, N, seed=83).cuda()       # tiled [B,N,128], model.py:128-131
+    lossD, lossG, info = reference_loop_body(s, x, data, z_d, z_g)
+    assert all(p.requires_grad for p in G.parameters()) and not any(p.requires_grad for p in D.parameters())   # the state the loop leaves
+    _compare_with_golden(d, G, D, lossD, lossG, s.keep)
+
+
+def test_literal_reference_loop_at_the_benchmarked_size(sp):
+    """C2 (B=32, N=2048, WGAN-GP) through the literal statements against the reference's step (golden G17), own kNN graphs."""
+    from spgan.reference_loop import reference_loop_body
+    B, N = 32, 2048
+    d = golden("g17_step_c2.npz")
+    G, D, optG, optD, LoopState = _setup(sp, 18, N)
+    alpha = torch.from_numpy(d["alpha"]).cuda()
+    s = LoopState(G, D, optG, optD, gan="wgan", gp=lambda netD, real, fake: sp.GradientPenalty(10.0, gamma=1)(netD, real, fake, alpha=alpha))
+    s.keep = {}
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    data = fr.synthetic_real(B, N, seed=181).cuda()
+    z_d, z_g = fr.latent(B, N, seed=182).cuda(), fr.latent(B, N, seed=183).cuda()
+    lossD, lossG, info = reference_loop_body(s, x, data, z_d, z_g)
+    _compare_with_golden(d, G, D, lossD, lossG, s.keep, loose_fake=2e-3)
+
+
+@pytest.mark.parametrize("gan,use_gp", [("ls", False), ("wgan", True)])
+def test_captured_literal_loop_equals_eager_literal_loop(sp, gan, use_gp):
+    """spgan.CapturedBody around the caller's loop body: 3 eager warm-up calls, one capture, replays -- parameters, BatchNorm buffers
+    (incl. num_batches_tracked) and Adam state bit-identical to issuing the same body eagerly 7 times, with a fresh `data` / latent
+    tensor on every call and an eager generator call (a sample dump) right before the capture."""
+    from spgan.reference_loop import reference_loop_body
+    B, N, steps = 4, 256, 7
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    alpha = fr.uniform("cap.alpha", (B, 1, 1), 0.0, 1.0).cuda()
+    res = []
+    for captured in (False, True):
+        G, D, optG, optD, LoopState = _setup(sp, 9, N, capturable=True)
+        gp = (lambda netD, real, fake: sp.GradientPenalty(10.0, gamma=1)(netD, real, fake, alpha=alpha)) if use_gp else None
+        s = LoopState(G, D, optG, optD, gan=gan, gp=gp)
+        fn = lambda x_, data_, zd_, zg_: reference_loop_body(s, x_, data_, zd_, zg_)[:2]
+        body = sp.CapturedBody(fn, modules=(G, D), warmup=3) if captured else fn
+        losses = []
+        for i in range(steps):
+            data = fr.synthetic_real(B, N, seed=900 + i).cuda()
+            z_d, z_g = fr.latent(B, N, seed=910 + i).cuda(), fr.latent(B, N, seed=920 + i).cuda()
+            if i == 3:
+                with torch.no_grad():
+                    G(x, z_g)                                                # fills the weight-derived host caches right before the capture
+            lossD, lossG = body(x, data, z_d, z_g)
+            losses.append((lossD.item(), lossG.item()))
+        if captured:
+            assert body._graph is not None and not body.eager
+        torch.cuda.synchronize()
+        G.flush_bn_counts(); D.flush_bn_counts()
+        state = {"G." + k: v.detach().clone() for k, v in G.state_dict().items()}
+        state.update({"D." + k: v.detach().clone() for k, v in D.state_dict().items()})
+        for nm, opt in (("optG", optG), ("optD", optD)):
+            for i, st in enumerate(opt.state_dict()["state"].values()):
+                for k, v in st.items():
+                    state["%s.%d.%s" % (nm, i, k)] = v.detach().clone() if torch.is_tensor(v) else torch.tensor(v)
+        res.append((state, losses))
+    assert res[0][1] == res[1][1], "losses differ between eager and captured issue"
+    for k in res[0][0]:
+        assert torch.equal(res[0][0][k], res[1][0][k]), k

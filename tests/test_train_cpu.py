@@ -150,3 +150,32 @@ def test_noisy_labels_semantics(spgan_cpu):
     assert 1 <= changed.numel() <= 3                                   # int(0.05*64) = 3 draws with replacement
     assert torch.allclose(y2[changed], 1 - y[changed])
     assert torch.equal(losses._noisy_labels(torch.ones(8)), torch.ones(8))   # int(0.05*8) = 0: nothing flips
+
+
+@pytest.mark.parametrize("tag,gan,use_gp,B,N", [("ls", "ls", False, 4, 512), ("wgangp", "wgan", True, 4, 256)])
+def test_literal_reference_loop_body_golden(spgan_cpu, tag, gan, use_gp, B, N):
+    """CPU twin of tests/test_literal_loop_gpu.py: the reference's loop body statement for statement (spgan.reference_loop,
+    Generation/model.py:239-279) with torch.optim.Adam over the host pipelines (kernel-model doubles) against golden G8."""
+    import spgan
+    from spgan.reference_loop import LoopState, reference_loop_body
+    d = golden("g8_train_step_%s.npz" % tag)
+    G = _load(spgan.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=8)).train()
+    D = _load(spgan.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=8)).train()
+    optG = torch.optim.Adam(filter(lambda p: p.requires_grad, G.parameters()), lr=1e-4, betas=(0.5, 0.99))
+    optD = torch.optim.Adam(filter(lambda p: p.requires_grad, D.parameters()), lr=1e-4, betas=(0.5, 0.99))
+    alpha = torch.from_numpy(d["alpha"])
+    gp = (lambda netD, real, fake: spgan.GradientPenalty(10.0, gamma=1)(netD, real, fake, alpha=alpha)) if use_gp else None
+    s = LoopState(G, D, optG, optD, gan=gan, gp=gp)
+    s.keep = {}
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    lossD, lossG, _ = reference_loop_body(s, x, fr.synthetic_real(B, N, seed=81), fr.latent(B, N, seed=82), fr.latent(B, N, seed=83))
+    np.testing.assert_allclose(lossD.item(), float(d["lossD"]), rtol=2e-3 if use_gp else 1e-4)
+    np.testing.assert_allclose(lossG.item(), float(d["lossG"]), rtol=2e-3)
+    check(d, "fake_d", s.keep["fake_d"], rtol=2e-4)
+    for n, g in s.keep["d_grads"].items():
+        check(d, "dgrad|" + n, g, rtol=3e-2, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    for n, p in list(D.named_parameters()) + list(G.named_parameters()):
+        if not n.endswith(ZERO_GRAD_BIASES):
+            check(d, ("dparam|" if p in set(D.parameters()) else "gparam|") + n, p, rtol=1e-3, atol=2.5e-4)
+    for n, b in [(k, v) for k, v in D.state_dict().items() if k in dict(D.named_buffers())]:
+        np.testing.assert_allclose(b.numpy(), d["dbuf|" + n], rtol=2e-3, atol=2e-4)
