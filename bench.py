@@ -42,14 +42,21 @@ import torch   # noqa: E402
 # the JSON line; its numbers are meaningless and the line says so.
 SELFTEST = os.environ.get("SPGAN_BENCH_SELFTEST", "0") == "1"
 N_POINTS = 128 if SELFTEST else 2048
-PER_GPU_BATCH = 2 if SELFTEST else int(os.environ.get("SPGAN_BENCH_BATCH", "32"))   # 32 = BASELINE configs[1]; the override is for experiments only
+# 32 = BASELINE configs[1].  `--experiment-batch B` (experiments only; the line is then marked "experiment") is read before argparse because
+# module-level code sizes things with it; the old SPGAN_BENCH_BATCH environment override is refused.
+if os.environ.get("SPGAN_BENCH_BATCH"):
+    raise SystemExit("SPGAN_BENCH_BATCH is no longer honoured: use `--experiment-batch B` (the JSON line is then marked as an experiment)")
+EXPERIMENT_BATCH = next((int(sys.argv[i + 1]) for i, a in enumerate(sys.argv[:-1]) if a == "--experiment-batch"), None)
+PER_GPU_BATCH = 2 if SELFTEST else (EXPERIMENT_BATCH or 32)
 NZ = 128
 K_NN = 10
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 FP16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (never the 2:1-sparsity figure)
 # algorithmic FLOPs per shape per step, reference formulation: WGAN-GP at N=2048
 GF_PER_SHAPE_STEP = 32.6
-PMC_FILES = ("r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json")
+PMC_FILES = ("r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json")
+PMC_STEP_FILES = ("r03_pmc_step.json", "r02_pmc_step.json")
+ALGORITHMIC_HBM_GB_PER_STEP = 3.5      # ~110 MB per shape per step x 32 shapes
 
 
 class Opts:
@@ -80,6 +87,22 @@ def make_inputs(dev, rank, b, tiled_z=False):
     zs = [(z if tiled_z else z[:, :1, :]).contiguous().to(dev) for z in zs]
     alpha = fr.uniform("bench.alpha.%d" % rank, (b, 1, 1), 0.0, 1.0).to(dev)
     return x, real, zs, alpha
+
+
+def _pmc_step_traffic():
+    """Whole-step HBM bytes from the committed rocprofv3 PMC passes of tools/pmc_step.py (FETCH_SIZE doubled + WRITE_SIZE)."""
+    for name in PMC_STEP_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            gb = d.get("hbm_bytes_per_step", {}).get("total_GB")
+            if gb:
+                return {"hbm_gb_per_step": round(float(gb), 2), "algorithmic_gb_per_step": ALGORITHMIC_HBM_GB_PER_STEP,
+                        "ratio": round(float(gb) / ALGORITHMIC_HBM_GB_PER_STEP, 2), "source": "profiles/" + name,
+                        "note": "committed rocprofv3 --pmc passes over a replayed step (not sampled in this run; batch 32)"}
+        except Exception:
+            continue
+    return None
 
 
 def _pmc_traffic():
@@ -331,6 +354,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--experiment-batch", type=int, default=None, help="per-GPU batch other than BASELINE's 32: an experiment, marked as such in the line")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the drop-in-caller and MFMA-accounting legs (they run after the timed region)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--mfma", choices=("f32", "f16", "bf16x3"), default="f32",
@@ -427,6 +451,37 @@ def main():
                            "forward in the G step; 10 steps after priming"}
         del tr2, G2, D2, zt
 
+    literal = None
+    if not SELFTEST and not args.no_extra_legs and not variant and world == 1:
+        # The reference's loop body EXECUTED LITERALLY (spgan.reference_loop: model.py:239-279 statement for statement -- separate G() /
+        # D() calls, requires_grad toggles, dis_loss / gen_loss, .backward(), torch.optim.Adam) on the HIP modules, latent tiled
+        # [B,N,128]; no TrainStep.  (a) issued eagerly from Python, (b) the same function under spgan.CapturedBody (the caller's own
+        # loop body replayed as a hipGraph).
+        from spgan.reference_loop import LoopState, reference_loop_body
+        G3, D3 = build_models(dev, variant)
+        G3.train(); D3.train()
+        oG = torch.optim.Adam(filter(lambda p: p.requires_grad, G3.parameters()), lr=1e-4, betas=(0.5, 0.99), capturable=True)
+        oD = torch.optim.Adam(filter(lambda p: p.requires_grad, D3.parameters()), lr=1e-4, betas=(0.5, 0.99), capturable=True)
+        gp3 = spgan.GradientPenalty(10.0, gamma=1)
+        x3, real3, zt3, alpha3 = make_inputs(dev, rank, PER_GPU_BATCH, tiled_z=True)
+        st3 = LoopState(G3, D3, oG, oD, gan="wgan", gp=lambda netD, r, f: gp3(netD, r, f, alpha=alpha3))
+        fn3 = lambda x_, d_, a_, b_: reference_loop_body(st3, x_, d_, a_, b_)[:2]
+        body = spgan.CapturedBody(fn3, modules=(G3, D3), warmup=2)             # captured leg first: the body is wrapped from its first call
+        for i in range(4):
+            body(x3, real3, zt3[i % 2], zt3[(i + 1) % 2])
+        dt4, iss4 = time_steps(None, lambda i: body(x3, real3, zt3[i % 2], zt3[(i + 1) % 2]), 10, False, dev)
+        for _ in range(3):
+            fn3(x3, real3, zt3[0], zt3[1])
+        dt3, iss3 = time_steps(None, lambda i: fn3(x3, real3, zt3[i % 2], zt3[(i + 1) % 2]), 10, False, dev)
+        literal = {"eager_ms_per_step": round(dt3 / 10 * 1e3, 3), "eager_host_issue_ms_per_step": round(iss3 / 10 * 1e3, 3),
+                   "eager_shapes_per_s": round(PER_GPU_BATCH * 10 / dt3, 2),
+                   "captured_ms_per_step": round(dt4 / 10 * 1e3, 3), "captured_shapes_per_s": round(PER_GPU_BATCH * 10 / dt4, 2),
+                   "captured": bool(body._graph is not None and not body.eager),
+                   "note": "model.py:239-279 statement for statement (spgan.reference_loop.reference_loop_body) with torch.optim.Adam(capturable=True), "
+                           "tiled latent [B,N,128], WGAN-GP composition; eager = issued from Python, captured = the same function under "
+                           "spgan.CapturedBody (hipGraph replay of the caller's own loop body); 10 steps each after warm-up"}
+        del G3, D3, body, st3
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         shapes_s = PER_GPU_BATCH * world * args.steps / dt
@@ -436,14 +491,18 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate/epilogues/weight-gradients",
                                                                                   "bf16x3": "f32 operands split into 3 bf16 terms (6 bf16 MFMA cross products, f32 accumulate); weight gradients f32 MFMA"}[args.mfma],
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Chair-shaped synthetic clouds, 2048 pts, per-GPU batch 32, WGAN + gradient penalty (lambda 10), "
-                                   "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10; one latent per shape (default noise_generator) handed over un-tiled [b,1,128]", "global_batch": PER_GPU_BATCH * world, "n_points": N_POINTS,
+            "config": {"workload": "%s: Chair-shaped synthetic clouds, %d pts, per-GPU batch %d, WGAN + gradient penalty (lambda 10), "
+                                   "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10; one latent per shape (default noise_generator) handed over un-tiled [b,1,128]"
+                                   % ("BASELINE configs[1]" if PER_GPU_BATCH == 32 else "EXPERIMENT (not a BASELINE config)", N_POINTS, PER_GPU_BATCH),
+                       "global_batch": PER_GPU_BATCH * world, "n_points": N_POINTS,
                        "parallelism": "dp%d" % world},
             "world_size_observed": world_seen, "collective_backend": (torch.distributed.get_backend() if dist_on else None),
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3), "hipgraph_replay": bool(use_graph), "reference_schedule": bool(args.reference_schedule),
             "step_tflops_algorithmic": round(shapes_s * GF_PER_SHAPE_STEP / 1e3, 2),
             "step_frac_of_fp32_matrix_peak_reference_flops": round(shapes_s * GF_PER_SHAPE_STEP / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
         }
+        if EXPERIMENT_BATCH is not None and not SELFTEST:
+            line["experiment"] = "per-GPU batch %d instead of BASELINE's 32" % PER_GPU_BATCH
         if SELFTEST:
             line["selftest"] = True
             line["data"] = "selftest: CPU test doubles, tiny shapes -- NOT a measurement"
@@ -454,8 +513,16 @@ def main():
         if acct is not None:
             line["roofline"] = acct.roofline()
             line["mfma"] = acct.summary(ACCT_STEPS, ms)
+            if line["mfma"] is not None:
+                # FLOPs the build really issues on the matrix cores / whole step time / peak (the reference-formulation fraction above
+                # divides FLOPs the build does not execute)
+                line["step_mfma_frac_issued"] = round(line["mfma"]["mfma_flops_issued_per_step"] / (ms * 1e-3) / 1e12 / (peak * 1.0), 4)
+            if PER_GPU_BATCH == 32:
+                line["hbm_traffic"] = _pmc_step_traffic()
         if drop_in is not None:
             line["drop_in_caller"] = drop_in
+        if literal is not None:
+            line["literal_loop"] = literal
         if world == 1 and not args.no_cpu_baseline and not SELFTEST:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(shapes_s / line["cpu_baseline"]["value"], 1)

@@ -81,28 +81,23 @@ enum { SPGAN_A_PLAIN = 0, SPGAN_A_AFFINE_LRELU = 1, SPGAN_A_EDGE = 2 };
 enum { SPGAN_EPI_LINEAR = 0, SPGAN_EPI_MASK_OUT = 1, SPGAN_EPI_BNBWD = 2, SPGAN_EPI_EDGE_BNBWD = 3 };
 enum { SPGAN_ACT_NONE = 0, SPGAN_ACT_LRELU = 1, SPGAN_ACT_TANH = 2 };
 
-/* In-launch finish of per-tile column records by the last-arriving workgroup (csrc/fanin.hpp): instead of leaving the merge
- * over the row tiles to a follow-up launch (spgan_colstats_finalize*), the producer's workgroups count their arrivals and the last
- * one merges -- in tile order, so the result does not depend on the arrival order -- and runs the tail:
- *   mode 0: records are (sum, centred M2) -> out0 = mean, out1 = biased variance (either may be NULL) and, when scale != NULL,
- *           the train-mode BatchNorm bookkeeping of spgan_bn_prepare (scale, shift, invstd, mean_out; running statistics
- *           updated with momentum when rmean != NULL; count_rep multiplies the row count of the unbiased-variance factor);
- *   mode 1: records are plain sums -> out0 = sum of x, out1 = sum of y.
- * counters: int32 [col_blocks * (spgan_fanin_groups(tiles) + 1)], zero before the first use; the kernels leave them zero.
- * group_part: float scratch [spgan_fanin_groups(tiles), C, 2] (unused when there is a single group).  enabled = 0: off. */
-typedef struct spgan_fanin {
+/* Column tail of the M <= 64 product kernel (the per-shape linears: one workgroup owns its columns entirely, so what would be a
+ * follow-up spgan_colstats_finalize* launch is finished in the producing launch):
+ *   mode 0: the column records are (sum, centred M2) -> out0 = mean, out1 = biased variance (either may be NULL) and, when
+ *           scale != NULL, the train-mode BatchNorm bookkeeping of spgan_bn_prepare (scale, shift, invstd, mean_out; running
+ *           statistics updated with momentum when rmean != NULL; count_rep multiplies the row count of the unbiased-variance factor);
+ *   mode 1: plain sums -> out0 = sum of x, out1 = sum of y.
+ * enabled = 0: off.  Only accepted with M <= 64.  (Round 2 carried a generalisation to many row tiles -- last-arriving workgroup
+ * merges -- that measured slower than the finalize launch on every shape of the step; it lives in tools/exp/fanin.hpp now.) */
+typedef struct spgan_coltail {
   int enabled;
-  int32_t* counters;
-  float* group_part;
   int mode;
   float* out0; float* out1;
   const float* gamma; const float* beta; float* rmean; float* rvar;
   float* scale; float* shift; float* invstd; float* mean_out;
   float eps, momentum;
   int count_rep;
-} spgan_fanin;
-/* number of first-level groups the row tiles of a launch are cut into (1 for <= 48 tiles) */
-int spgan_fanin_groups(int tiles);
+} spgan_coltail;
 
 typedef struct spgan_gemm_nt_args {
   /* Y[M,N] = epilogue( prologue(A)[M,K] . W[N,K]^T ) */
@@ -148,12 +143,11 @@ typedef struct spgan_gemm_nt_args {
    * product z uses A + z*batch_stride_a, W + z*batch_stride_w, Y + z*batch_stride_y (strides in floats; bias is shared).
    * The per-shape [N,N] contractions of the --attn variant (Generation/modules.py:554-556).  Default 0 / 1: a single product. */
   int batch; long batch_stride_a, batch_stride_w, batch_stride_y;
-  /* fin.enabled (needs `stats`): the column records are merged in this launch -- column blocks = the kernel's N-tiles
-   * (spgan_gemm_nt_col_blocks), row tiles of 128 rows.  Not with pooling-only launches (stats == NULL). */
-  spgan_fanin fin;
+  /* tail.enabled (needs `stats`, M <= 64): the column records are finished in this launch, see spgan_coltail */
+  spgan_coltail tail;
   /* Tile geometry.  0: automatic -- 256 x 256 tiles (csrc/gemm_wide.hip) for large aligned products whose tiles fill the chip, the
    * 128-row kernels otherwise; 1: 128-row kernels only; 2: 256 x 256 tiles whenever the problem is eligible (M % 256 == 0,
-   * N % 256 == 0, K % 32 == 0, 16-byte aligned rows, fp32 operands, no per-edge mode / fan-in / batching): for tests and A/B runs. */
+   * N % 256 == 0, K % 32 == 0, 16-byte aligned rows, fp32 operands, no per-edge mode / batching): for tests and A/B runs. */
   int tile_hint;
   /* p_group_rows > 0: the rows form M / p_group_rows groups of p_group_rows consecutive rows, and p_scale / p_shift hold one vector per
    * group ([groups, K], row g for the rows of group g) -- several passes of a network with their own train-mode BatchNorm statistics
@@ -163,7 +157,10 @@ typedef struct spgan_gemm_nt_args {
    * would run as separate calls (bit-identical results). */
   int p_group_rows;
 } spgan_gemm_nt_args;
-/* number of column blocks (N-tiles) spgan_gemm_nt uses for this problem: sizes the fan-in counters */
+/* 1 when spgan_gemm_nt will run this problem on the M <= 64 kernel, i.e. when `tail.enabled` is acceptable (else the launch
+ * returns SPGAN_EINVAL for a tail request) */
+int spgan_gemm_nt_owns_columns(const spgan_gemm_nt_args* a);
+/* number of column blocks (N-tiles) spgan_gemm_nt uses for this problem */
 int spgan_gemm_nt_col_blocks(const spgan_gemm_nt_args* a);
 
 int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s);

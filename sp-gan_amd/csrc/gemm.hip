@@ -23,7 +23,6 @@
 // for the following train-mode BatchNorm, and the LeakyReLU/BatchNorm backward masks with their
 // column sums.
 #include "common.hpp"
-#include "fanin.hpp"
 #include "gemm_wide.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -660,8 +659,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           }
           if (p.stats) {
             float* o = p.stats + ((size_t)t.tm * p.N + col) * 2;
-            if (p.fin.enabled) fanin::st_record(o, S, M2);
-            else { o[0] = S; o[1] = M2; }
+            o[0] = S;
+            o[1] = M2;
           }
           if (do_pool) {
             float vx = xvx[c], vn = xvn[c];
@@ -753,8 +752,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           const int col = cbase + j * 32;
           if (col < p.N) {
             float* o = p.stats + ((size_t)t.tm * p.N + col) * 2;
-            if (p.fin.enabled) fanin::st_record(o, csum[j], m2[j]);
-            else { o[0] = csum[j]; o[1] = m2[j]; }
+            o[0] = csum[j];
+            o[1] = m2[j];
           }
         }
       }
@@ -907,8 +906,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           const int col = cbase + j * 32;
           if (col < p.N) {
             float* o = p.stats + ((size_t)t.tm * p.N + col) * 2;
-            if (p.fin.enabled) fanin::st_record(o, s0[j], s1[j]);
-            else { o[0] = s0[j]; o[1] = s1[j]; }
+            o[0] = s0[j];
+            o[1] = s1[j];
           }
         }
       }
@@ -916,10 +915,6 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   }
 #undef ROW_OF
 #undef ROFF
-  if constexpr (EPI != SPGAN_EPI_MASK_OUT) {
-    // column records of all row tiles are merged by the last-arriving workgroup of this column block (fanin.hpp)
-    if (p.stats && p.fin.enabled) fanin::finalize(p.fin, p.stats, t.tm, tilesM, p.N, n0, min(BN, p.N - n0), t.tn, p.M, BM, As);
-  }
   TRC(4);
 }
 
@@ -1053,8 +1048,8 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_
       float* o = p.stats + (size_t)(n0 + tid) * 2;  // a single 128-row tile: partials [1, N, 2]
       o[0] = s0;
       o[1] = s1;
-      if (p.fin.enabled) {  // this workgroup owns its columns entirely: finish them here (the tail of fanin::finalize)
-        const spgan_fanin& f = p.fin;
+      if (p.tail.enabled) {  // this workgroup owns its columns entirely: finish them here (spgan_coltail)
+        const spgan_coltail& f = p.tail;
         const int c = n0 + tid;
         if (f.mode != 0) {
           f.out0[c] = s0;
@@ -1100,6 +1095,7 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
       return spgan_launch_status();
     }
   }
+  if (a.tail.enabled) return SPGAN_EINVAL;  // only the M <= 64 kernel above finishes its columns in the launch (spgan_gemm_nt_owns_columns)
   if constexpr (AMODE != A_AFFINE_SPARSE) {
     if (a.mfma_f16 == 2 && fast && a.N > 32) {  // fp32 operands split into three bf16 terms: 128x64 tiles (three operand planes in LDS)
       launch_nt_cfg<AMODE, EPI, 1, 0, 1, 2>(a, s);
@@ -1637,8 +1633,6 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int spgan_fanin_groups(int tiles) { return tiles > 0 ? fanin::group_count(tiles) : 0; }
-
 // N-tile width launch_nt picks for this problem (must mirror launch_nt)
 static int nt_tile_n(const spgan_gemm_nt_args& a) {
   if (spgan_nt_wide_selected(a)) return 256;
@@ -1652,6 +1646,15 @@ static int nt_tile_n(const spgan_gemm_nt_args& a) {
 extern "C" int spgan_gemm_nt_col_blocks(const spgan_gemm_nt_args* a) {
   if (!a || a->N <= 0) return 0;
   return cdiv(a->N, nt_tile_n(*a));
+}
+
+extern "C" int spgan_gemm_nt_owns_columns(const spgan_gemm_nt_args* a) {
+  // mirrors launch_nt: the M <= 64 kernel (one workgroup walks all rows of its columns) takes aligned, unbatched problems
+  if (!a || a->M <= 0 || a->M > 64 || a->sp_val || a->batch > 1 || a->pool_val) return 0;
+  if (a->a_mode == SPGAN_A_EDGE || a->epi_mode == SPGAN_EPI_EDGE_BNBWD) return 0;
+  bool fast = (a->K % 4 == 0) && (a->lda % 4 == 0) && (a->ldw % 4 == 0) && al16(a->A) && al16(a->W);
+  if (a->a_mode != SPGAN_A_PLAIN) fast = fast && al16(a->p_scale) && al16(a->p_shift);
+  return fast ? 1 : 0;
 }
 
 extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
@@ -1670,13 +1673,12 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   if (a->batch > 1)
     SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->epi_mode == SPGAN_EPI_LINEAR && a->Y && !a->stats && !a->rowbias && !a->pool_val &&
                     a->batch <= 65535 && a->batch_stride_a >= 0 && a->batch_stride_w >= 0 && a->batch_stride_y > 0);
-  if (a->fin.enabled) {
-    const spgan_fanin& f = a->fin;
-    SPGAN_CHECK_ARG(a->stats && (f.mode == 0 || f.mode == 1));
-    if (a->epi_mode == SPGAN_EPI_MASK_OUT) SPGAN_CHECK_ARG(a->M <= 64 && f.mode == 1);  // column sums of a masked product: the per-shape linears only
+  if (a->tail.enabled) {  // finished in the launch only where one workgroup owns its columns: the M <= 64 kernel
+    const spgan_coltail& f = a->tail;
+    SPGAN_CHECK_ARG(a->stats && a->M <= 64 && (f.mode == 0 || f.mode == 1));
+    if (a->epi_mode == SPGAN_EPI_MASK_OUT) SPGAN_CHECK_ARG(f.mode == 1);  // column sums of a masked product
     if (f.mode == 1) SPGAN_CHECK_ARG(f.out0 && f.out1);
     if (f.scale) SPGAN_CHECK_ARG(f.mode == 0 && f.shift && f.invstd && f.mean_out && (!f.rmean || f.rvar));
-    SPGAN_CHECK_ARG(f.counters && (fanin::group_count(cdiv(a->M, BM)) == 1 || f.group_part));  // the M <= 64 kernel does not use them
   }
   switch (a->epi_mode) {
     case SPGAN_EPI_LINEAR:

@@ -17,8 +17,8 @@ c_i64p = C.c_void_p
 stream_t = C.c_void_p
 
 
-class FanIn(C.Structure):
-    _fields_ = [("enabled", C.c_int), ("counters", c_i32p), ("group_part", c_f32p), ("mode", C.c_int),
+class ColTail(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("mode", C.c_int),
                 ("out0", c_f32p), ("out1", c_f32p),
                 ("gamma", c_f32p), ("beta", c_f32p), ("rmean", c_f32p), ("rvar", c_f32p),
                 ("scale", c_f32p), ("shift", c_f32p), ("invstd", c_f32p), ("mean_out", c_f32p),
@@ -45,7 +45,7 @@ class GemmNTArgs(C.Structure):
         ("pool_val", c_f32p), ("pool_arg", c_i32p),
         ("mfma_f16", C.c_int),
         ("batch", C.c_int), ("batch_stride_a", C.c_long), ("batch_stride_w", C.c_long), ("batch_stride_y", C.c_long),
-        ("fin", FanIn),
+        ("tail", ColTail),
         ("tile_hint", C.c_int),
         ("p_group_rows", C.c_int),
     ]
@@ -103,7 +103,7 @@ SIGNATURES = {
     "spgan_concat2": (I, [P, I, P, I, I, P, P]),
     "spgan_gemm_nt": (I, [C.POINTER(GemmNTArgs), P]),
     "spgan_gemm_nt_col_blocks": (I, [C.POINTER(GemmNTArgs)]),
-    "spgan_fanin_groups": (I, [I]),
+    "spgan_gemm_nt_owns_columns": (I, [C.POINTER(GemmNTArgs)]),
     "spgan_pool_finalize": (I, [P, P, I, I, I, P, P, F, P, P, P, P]),
     "spgan_pool_finalize_groups": (I, [P, P, I, I, I, P, P, I, I, F, P, P, P, I, P]),
     "spgan_gemm_tn_ws_bytes": (SZ, [I, I, I]),

@@ -14,7 +14,9 @@ captured, all later ones replay.  Contract for the function (the usual stream-ca
   * positional tensor arguments only, static shapes; everything else through the closure;
   * no host synchronisation inside (`.item()`, `.cpu()`, printing a device value): return device tensors instead;
   * optimisers must be capturable: `torch.optim.Adam(..., capturable=True)` or `spgan.Adam(..., capturable=True)`;
-  * random draws must come from the device generators.
+  * random draws must come from the device generators;
+  * wrap the body from its FIRST iteration: do not run the same modules' backward eagerly on another stream beforehand (autograd
+    binds the gradient-accumulation nodes of the parameters to the stream that first used them).
 What the wrapper takes care of: input staging (an argument that is the same tensor object at the same version as on the previous
 call -- the constant sphere prior -- is adopted without a copy, so the Generator keeps its cached neighbour graph), the host-side
 BatchNorm call counters of the spgan modules (replayed per call), the weight-derived host caches (dropped before the capture
@@ -112,8 +114,12 @@ class CapturedBody:
                 m.__dict__["_ec1_twin"] = None
             before = _bn_snapshot(mods)
             g = torch.cuda.CUDAGraph()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
             try:
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                # captured on the stream the warm-up calls ran on: autograd's AccumulateGrad nodes are bound to the stream they were
+                # created on, and one that survives from the warm-up must not pull a foreign stream into the capture
+                with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
                     self._out = self.fn(*self._static)
             except Exception as e:                                   # noqa: BLE001
                 warnings.warn("CapturedBody: hipGraph capture failed (%s: %s); issuing the body eagerly from now on" % (type(e).__name__, e))

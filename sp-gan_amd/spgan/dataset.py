@@ -79,11 +79,12 @@ class DeviceDataset:
 
     def __init__(self, source, num_points: int = 2048, batch_size: int = 32, scale: float = 1.0, augment: bool = False,
                  device="cuda", seed: Optional[int] = None):
-        pts = load_points(source, num_points)[:, :num_points, :3]
+        pts = load_points(source, num_points)[:, :, :3]
         if pts.dim() != 3 or pts.shape[1] < num_points:
             raise ValueError("need [S, >=%d, >=3] points, got %s" % (num_points, tuple(pts.shape)))
         self.device = torch.device(device)
-        self.data = (scale * normalize_point_cloud(pts)).to(self.device).contiguous()
+        # H5DataLoader.py:107 normalises the clouds as stored; :113 takes the first num_points of the normalised cloud
+        self.data = (scale * normalize_point_cloud(pts))[:, :num_points].to(self.device).contiguous()
         self.num_points, self.batch_size, self.augment = num_points, batch_size, augment
         self.gen = torch.Generator(device=self.device)
         if seed is not None:
@@ -125,11 +126,11 @@ class HostStagedLoader:
 
     def __init__(self, source, num_points: int = 2048, batch_size: int = 32, scale: float = 1.0, augment: bool = False,
                  device="cuda", seed: Optional[int] = None):
-        pts = load_points(source, num_points)[:, :num_points, :3]
+        pts = load_points(source, num_points)[:, :, :3]
         if pts.dim() != 3 or pts.shape[1] < num_points:
             raise ValueError("need [S, >=%d, >=3] points, got %s" % (num_points, tuple(pts.shape)))
         self.device = torch.device(device)
-        self.data = (scale * normalize_point_cloud(pts)).contiguous().numpy()
+        self.data = (scale * normalize_point_cloud(pts))[:, :num_points].contiguous().numpy()        # H5DataLoader.py:107, then :113
         self.num_points, self.batch_size, self.augment = num_points, batch_size, augment
         self.rng = np.random.default_rng(seed)
         cuda = self.device.type == "cuda"

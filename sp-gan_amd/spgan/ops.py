@@ -246,52 +246,20 @@ def concat2(a: Tensor, b: Tensor) -> Tensor:
     return out
 
 
-# ----------------------------------------------------------------------------- in-launch finish of column records (csrc/fanin.hpp)
-# Kernels that produce per-tile column records (GEMM statistics epilogues) can merge them in the same launch instead of leaving
-# that to a finalize launch:
-#   * M <= 64 (gemm_nt_small_kernel, one workgroup owns its columns): always -- the tail costs nothing;
-#   * MFMA grids (M > 64): by the last-arriving workgroup (two-level fan-in).  MEASURED SLOWER than the separate launch on every
-#     shape of the train step (profiles/r02_fanin_ab.txt: +5..+27 us per GEMM against ~6 us per finalize launch; the chain
-#     store-drain -> device-scope atomic -> L2/L1 invalidate -> dependent loads is ~6 us per level on MI355X), so it is OFF by
-#     default; SPGAN_FANIN=1 / ops.FANIN[0] = True switch it on (tests/test_fanin_gpu.py keeps it correct).
-import os as _os
-FANIN = [_os.environ.get("SPGAN_FANIN", "0") == "1"]
-_FANIN_RING = {}        # device -> [int32 counters (zero; the kernels leave them zero), cursor]
-_FANIN_RING_SIZE = 1 << 16
+# ----------------------------------------------------------------------------- column tail of the M <= 64 kernel (spgan_coltail)
+# The per-shape linears (M = batch <= 64) run on a kernel whose workgroups own their columns entirely: their column statistics are
+# finished inside the producing launch instead of a finalize launch.  Larger products always use the separate finalize launches
+# (round 2's last-arriving-workgroup merge measured slower on every shape of the step: tools/exp/fanin.hpp, profiles/r02_fanin_ab.txt).
+def _owns_columns(lib, a) -> bool:
+    return bool(lib.spgan_gemm_nt_owns_columns(C.byref(a)))
 
 
-def _fanin_counters(device, n: int) -> int:
-    st = _FANIN_RING.get(device)
-    if st is None:
-        st = [torch.zeros(_FANIN_RING_SIZE, dtype=torch.int32, device=device), 0]
-        _FANIN_RING[device] = st
-    if n > _FANIN_RING_SIZE:
-        raise ValueError("fan-in counter request too large: %d" % n)
-    if st[1] + n > _FANIN_RING_SIZE:
-        st[1] = 0
-    off = st[1]
-    st[1] += n
-    return st[0].data_ptr() + 4 * off
-
-
-def _fanin_setup(fin, lib, device, tiles: int, col_blocks: int, Cn: int, need_counters: bool = True):
-    """Counters and group scratch of one fan-in launch; returns the scratch tensor (keep it alive until the launch was issued)."""
-    fin.enabled = 1
-    gp = None
-    if need_counters:
-        ng = lib.spgan_fanin_groups(tiles)
-        fin.counters = _fanin_counters(device, col_blocks * (ng + 1))
-        if ng > 1:
-            gp = torch.empty((ng, Cn, 2), dtype=torch.float32, device=device)
-            fin.group_part = gp.data_ptr()
-    return gp
-
-
-def _fanin_bn(fin, gamma, beta, rm, rv, out4, count_rep: int = 1):
-    fin.mode = 0
-    fin.gamma, fin.beta, fin.rmean, fin.rvar = _p(gamma), _p(beta), _p(rm), _p(rv)
-    fin.scale, fin.shift, fin.invstd, fin.mean_out = _p(out4[0]), _p(out4[1]), _p(out4[2]), _p(out4[3])
-    fin.eps, fin.momentum, fin.count_rep = BN_EPS, _BN_MOM[0], int(count_rep)
+def _tail_bn(tail, gamma, beta, rm, rv, out4, count_rep: int = 1):
+    tail.enabled = 1
+    tail.mode = 0
+    tail.gamma, tail.beta, tail.rmean, tail.rvar = _p(gamma), _p(beta), _p(rm), _p(rv)
+    tail.scale, tail.shift, tail.invstd, tail.mean_out = _p(out4[0]), _p(out4[1]), _p(out4[2]), _p(out4[3])
+    tail.eps, tail.momentum, tail.count_rep = BN_EPS, _BN_MOM[0], int(count_rep)
 
 
 # ----------------------------------------------------------------------------- contractions
@@ -307,8 +275,8 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
     """Y[M,N] = act( pro(A) @ W^T + bias + rowbias[m // rows_per_group] ).
     out  = destination [M,N] (unit column stride; may be a column slice of a wider buffer) instead of a fresh tensor.
     bn = (gamma, beta, running_mean | None, running_var | None): train-mode BatchNorm of Y fused behind the GEMM: returns
-         (Y, (scale, shift, invstd, mean)) and updates the running statistics -- column statistics in the epilogue, merged and
-         finished by the last-arriving workgroup of the same launch (csrc/fanin.hpp).  count_rep: the rows stand for count_rep
+         (Y, (scale, shift, invstd, mean)) and updates the running statistics -- column statistics in the epilogue, merged by a
+         finalize launch (in the producing launch itself for M <= 64: spgan_coltail).  count_rep: the rows stand for count_rep
          identical copies (only the unbiased-variance count of the running statistics changes).
     pro  = (scale[K], shift[K], slope): operand a = lrelu(A*scale+shift)            (A_AFFINE_LRELU)
     edge = (idx[M,k], ebias[K]) with pro: rows are edges, a = lrelu((A[j]-A[i]+ebias)*scale+shift)  (A_EDGE)
@@ -355,21 +323,19 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
         part = torch.empty((tiles, N, 2), dtype=torch.float32, device=A.device)
         a.stats = _p(part)
     lib = _lib.load()
-    fused = part is not None and (FANIN[0] or M_ <= 64)
-    res = keep = None
+    fused = part is not None and _owns_columns(lib, a)
+    res = None
     if fused:
-        keep = _fanin_setup(a.fin, lib, A.device, part.shape[0], lib.spgan_gemm_nt_col_blocks(C.byref(a)), N)
         if bn is not None:
             res = torch.empty((4, N), dtype=torch.float32, device=A.device)
-            _fanin_bn(a.fin, bn[0], bn[1], bn[2], bn[3], res, count_rep)
+            _tail_bn(a.tail, bn[0], bn[1], bn[2], bn[3], res, count_rep)
         else:
             res = torch.empty((2, N), dtype=torch.float32, device=A.device)
-            a.fin.mode = 0; a.fin.out0 = _p(res[0]); a.fin.out1 = _p(res[1])
+            a.tail.enabled = 1; a.tail.mode = 0; a.tail.out0 = _p(res[0]); a.tail.out1 = _p(res[1])
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt", M=M_, N=N, K=K, a_mode=a.a_mode)
     if done is not None:
         done()
-    del keep
     if bn is not None:
         if fused:
             return Y, (res[0], res[1], res[2], res[3])
@@ -435,13 +401,12 @@ def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float, with_colsum
     a.ref = _p(ref); a.ld_ref = _ld(ref); a.b_slope = float(slope)
     lib = _lib.load()
     res = part = None
-    # the M <= 64 kernel (the only one with this epilogue's column sums) is taken for 16-byte aligned operands with K % 4 == 0
-    if with_colsum and M_ <= 64 and K % 4 == 0 and a.lda % 4 == 0 and a.ldw % 4 == 0 and A.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0:
+    # the M <= 64 kernel is the only one with this epilogue's column sums
+    if with_colsum and _owns_columns(lib, a):
         part = torch.empty((1, N, 2), dtype=torch.float32, device=A.device)
         res = torch.empty((2, N), dtype=torch.float32, device=A.device)
         a.stats = _p(part)
-        _fanin_setup(a.fin, lib, A.device, 1, lib.spgan_gemm_nt_col_blocks(C.byref(a)), N)
-        a.fin.mode = 1; a.fin.out0 = _p(res[0]); a.fin.out1 = _p(res[1])
+        a.tail.enabled = 1; a.tail.mode = 1; a.tail.out0 = _p(res[0]); a.tail.out1 = _p(res[1])
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_maskout", M=M_, N=N, K=K)
     if done is not None:
@@ -537,16 +502,14 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
         _i32(idx, "idx")
         a.epi_mode = EPI_EDGE_BNBWD; a.e_idx = _p(idx); a.e_k = idx.shape[1]; a.e_bias2 = _p(_vec(ebias, N, "ebias"))
     lib = _lib.load()
-    res = keep = None
-    if FANIN[0] or M_ <= 64:
+    res = None
+    if _owns_columns(lib, a):
         res = torch.empty((2, N), dtype=torch.float32, device=A.device)          # [sum g | sum g*xhat], contiguous (nets._cat2)
-        keep = _fanin_setup(a.fin, lib, A.device, tiles, lib.spgan_gemm_nt_col_blocks(C.byref(a)), N)
-        a.fin.mode = 1; a.fin.out0 = _p(res[0]); a.fin.out1 = _p(res[1])
+        a.tail.enabled = 1; a.tail.mode = 1; a.tail.out0 = _p(res[0]); a.tail.out1 = _p(res[1])
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_bnbwd", M=M_, N=N, K=K)
     if done is not None:
         done()
-    del keep
     if res is not None:
         return g, res[0], res[1]
     s0, s1 = _finalize(part, 1, tiles, N, M_, 1)
@@ -820,22 +783,14 @@ def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, sl
     lib = _lib.load()
     gamma, beta, rm, rv = bn
     st = torch.empty((4, N), dtype=torch.float32, device=dev)
-    keep = None
-    if FANIN[0]:
-        keep = _fanin_setup(a.fin, lib, dev, tiles, lib.spgan_gemm_nt_col_blocks(C.byref(a)), N)
-        _fanin_bn(a.fin, gamma, beta, rm, rv, st)
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_bn_pool", M=M_, N=N, K=K)
     if done is not None:
         done()
-    del keep
     if before_finalize is not None:
-        if FANIN[0]:
-            raise RuntimeError("gemm_bn_pool(before_finalize=...) needs the separate finalize launch (SPGAN_FANIN=0)")
         before_finalize()
-    if not FANIN[0]:
-        check(lib.spgan_colstats_finalize_bn(_p(part), tiles, N, M_, 0, _p(gamma), _p(beta), BN_EPS, _BN_MOM[0], _p(rm), _p(rv),
-                                             _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _s()), "colstats_finalize_bn", N=N, M=M_)
+    check(lib.spgan_colstats_finalize_bn(_p(part), tiles, N, M_, 0, _p(gamma), _p(beta), BN_EPS, _BN_MOM[0], _p(rm), _p(rv),
+                                         _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _s()), "colstats_finalize_bn", N=N, M=M_)
     pooled = torch.empty((B, N), dtype=torch.float32, device=dev)
     yarg = torch.empty((B, N), dtype=torch.float32, device=dev)
     arg = torch.empty((B, N), dtype=torch.int32, device=dev)

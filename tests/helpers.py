@@ -56,6 +56,37 @@ def check(d, name, t, rtol=1e-4, atol=1e-6, what=""):
     return err
 
 
+def _entry(d, name, a):
+    """(reference values, the matching elements of `a`) for a full or a sampled golden entry."""
+    if name + "|full" in d:
+        ref = d[name + "|full"]
+        assert a.shape == ref.shape, (name, a.shape, ref.shape)
+        return ref.reshape(-1), a.reshape(-1)
+    stride = int(d[name + "|stride"])
+    ref = d[name + "|samples"]
+    return ref, a.reshape(-1)[::stride][:ref.size]
+
+
+def check_bounded_by_reference_noise(d, name32, name64, t, floor, factor=1.5, atol=0.0, what=""):
+    """For quantities the reference itself only reproduces to its own float32 rounding amplified by an ill-conditioned or
+    discrete step (a near-tied arg-max below D's pool, BatchNorm1d over a batch of nearly equal global features): the golden file
+    holds the reference's float32 AND float64 result.  The build's error against the float64 result must not exceed
+    max(factor x the reference's own float32 error against it, floor) -- i.e. the build is at least as close to the exact value as
+    the reference's float32 path, up to `factor`."""
+    a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    r32, got = _entry(d, name32, a)
+    r64, _ = _entry(d, name64, a)
+    den = max(float(np.sqrt((r64.astype(np.float64) ** 2).sum())), 1e-30)
+    e_ref = float(np.sqrt(((r32.astype(np.float64) - r64) ** 2).sum())) / den
+    e_own = float(np.sqrt(((got.astype(np.float64) - r64) ** 2).sum())) / den
+    maxerr = float(np.abs(got - r64).max()) if got.size else 0.0
+    _log(name64 + " (vs float64; reference's own float32 error %.2e)" % e_ref, e_own, maxerr, float(np.abs(r64).max()) if r64.size else 0.0,
+         rtol=max(factor * e_ref, floor), atol=atol)
+    assert e_own <= max(factor * e_ref, floor) or maxerr <= atol, \
+        "%s %s: rel-L2 vs float64 reference %.3e > max(%.1f x %.3e [reference float32 vs float64], %.1e) (max-abs %.3e)" % (what, name64, e_own, factor, e_ref, floor, maxerr)
+    return e_own, e_ref
+
+
 def params_from(shapes, salt, requires_grad=False):
     from spgan import fixture_rng as fr
     p = fr.init_params(shapes, salt=salt)

@@ -663,3 +663,7 @@ def reduce_chunks(recv, out=None):
 def multi_add(dsts, srcs):
     for d, s in zip(dsts, srcs):
         d.add_(s.reshape(d.shape))
+
+
+def capturing():
+    return False

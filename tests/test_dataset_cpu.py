@@ -27,7 +27,7 @@ def test_epoch_semantics(tmp_path):
     assert len(ds) == 37 and ds.num_batches == 4
     batches = list(ds)
     assert len(batches) == 4 and all(b.shape == (8, 64, 3) for b in batches)          # drop_last
-    norm = dataset.normalize_point_cloud(torch.from_numpy(raw)[:, :64])
+    norm = dataset.normalize_point_cloud(torch.from_numpy(raw))[:, :64]          # H5DataLoader.py:107 normalises the stored cloud, :113 slices
     keys = {tuple(np.round(np.sort(c.numpy(), axis=0).ravel(), 5)) for c in norm}
     seen = [tuple(np.round(np.sort(c.numpy(), axis=0).ravel(), 5)) for b in batches for c in b]
     assert all(k in keys for k in seen) and len(set(seen)) == 32                        # every item a permuted copy, no repeats
@@ -79,7 +79,7 @@ def test_host_staged_loader_semantics():
     raw = _raw()
     ld = dataset.HostStagedLoader(raw, num_points=64, batch_size=8, device="cpu", seed=5)
     assert len(ld) == 37 and ld.num_batches == 4
-    norm = dataset.normalize_point_cloud(torch.from_numpy(raw)[:, :64])
+    norm = dataset.normalize_point_cloud(torch.from_numpy(raw))[:, :64]
     seen = []
     for b in ld:
         assert b.shape == (8, 64, 3)
@@ -88,7 +88,7 @@ def test_host_staged_loader_semantics():
             assert len(hit) == 1
             seen.append(hit[0])
     assert len(set(seen)) == 32                                                       # 4 batches x 8 distinct shapes, drop_last
-    aug = dataset.HostStagedLoader(raw, num_points=64, batch_size=8, augment=True, device="cpu", seed=6)
+    aug = dataset.HostStagedLoader(raw[:, :64], num_points=64, batch_size=8, augment=True, device="cpu", seed=6)    # the stored cloud has exactly num_points (as the reference's poisson_<np> sets)
     b = next(iter(aug))
     r = b.norm(dim=-1).amax(dim=1)
     assert float(r.min()) >= 0.8 - 1e-5 and float(r.max()) <= 1.25 + 1e-5             # unit-radius clouds scaled by U[0.8, 1.25]

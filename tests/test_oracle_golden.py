@@ -416,3 +416,23 @@ def test_emd_auction_against_optimal_assignment():
     # short runs (the module's default 50 iterations) leave a valid, possibly non-bijective assignment
     dist, assign = orc.emd_auction(a, b, eps=0.005, iters=5)
     assert assign.min() >= 0 and assign.max() < n
+
+
+# ---------------------------------------------------------------- G17: the benchmarked size (C2: B=32, N=2048)
+def test_oracle_at_the_benchmarked_size():
+    """The oracle is also the CPU baseline bench.py times at C2: its Discriminator logits and its Generator output (the reference's
+    EdgeConv2 graph injected) against the reference's at B=32, N=2048 (golden G17)."""
+    B, N = 32, 2048
+    d = golden("g17_fullsize_c2.npz")
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        dp = fr.init_params(orc.discriminator_shapes(), salt=17)
+        real = fr.synthetic_real(B, N, seed=171).transpose(2, 1).contiguous()
+        logit = orc.discriminator_forward(dp, real, True, None)
+        np.testing.assert_allclose(logit.numpy(), d["d|logit"], rtol=2e-4, atol=2e-6)
+        gp_ = fr.init_params(orc.generator_shapes(), salt=17)
+        x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+        z = fr.latent(B, N, seed=173)
+        idx2 = torch.from_numpy(d["g|idx2"].astype(np.int64)).view(B, N * 10)
+        out = orc.generator_forward(gp_, x, z, training=True, buffers=None, idx2=idx2)
+    check(d, "g|out", out, rtol=2e-5)
