@@ -173,10 +173,10 @@ def test_train_step_benchsize_golden(sp, inject):
     for n, p in G.named_parameters():
         if not n.endswith(ZERO_GRAD_BIASES):
             check(d, "gparam|" + n, p, rtol=1e-3, atol=2.5e-4)
-    for n, b in _buffers(D):
-        np.testing.assert_allclose(b.cpu().numpy(), d["dbuf|" + n], rtol=2e-3, atol=2e-4, err_msg=n)
+    for n, b in _buffers(D):          # own graphs: D's running statistics saw a generated cloud that differs by ~1e-2 (above)
+        np.testing.assert_allclose(b.cpu().numpy(), d["dbuf|" + n], rtol=2e-3 if tight else 2e-2, atol=2e-4 if tight else 2e-3, err_msg=n)
     for n, b in _buffers(G):
-        np.testing.assert_allclose(b.cpu().numpy(), d["gbuf|" + n], rtol=2e-3, atol=2e-4, err_msg=n)
+        np.testing.assert_allclose(b.cpu().numpy(), d["gbuf|" + n], rtol=2e-3 if tight else 2e-2, atol=2e-4 if tight else 2e-3, err_msg=n)
 
 
 def _check_within_tie_sensitivity(d, name, t, n_diff, factor=3.0, table=None):
