@@ -71,13 +71,28 @@ class DataParallel(nn.Module):
 
     def allreduce_grads(self) -> float:
         """Sum gradients over ranks in place; returns the scale (1/world) the optimiser must apply."""
+        self.allreduce_grads_begin()
+        return self.allreduce_grads_end()
+
+    def allreduce_grads_begin(self) -> None:
+        """Start the reduction of the flat gradient buffer WITHOUT making the current stream wait for it: the collective runs on the
+        backend's own stream (it first waits for the work already enqueued on the current stream, i.e. for the backward pass that
+        produced the gradients); kernels issued on the current stream afterwards overlap with it.  `allreduce_grads_end()` joins.
+        Nothing issued in between may read or write the gradient buffer (TrainStep issues the generator's forward of the G step
+        there: it touches neither D's gradients nor D's weights)."""
+        self._work = None
         w = self.world_size
         if w > 1:
             if self.collective == "one_hop":
-                self._allreduce_one_hop(w)
+                self._allreduce_one_hop(w)                 # three dependent steps with a local kernel in the middle: issued in order
             else:
-                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg)
-        return 1.0 / w
+                self._work = dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def allreduce_grads_end(self) -> float:
+        work, self._work = getattr(self, "_work", None), None
+        if work is not None:
+            work.wait()                                    # stream-level join for RCCL (the host does not block); a host wait on gloo
+        return 1.0 / self.world_size
 
     def _allreduce_one_hop(self, w: int) -> None:
         from . import ops

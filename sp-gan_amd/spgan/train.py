@@ -74,6 +74,9 @@ class TrainStep:
         # The generator's two forwards of a step (D step, G step) see the same sphere prior and the same weights: EdgeConv1, which
         # depends on nothing else, is evaluated once and its BatchNorm running statistics are advanced twice (Generator.twin_forward).
         self.twin_g_forwards = not reference_schedule and os.environ.get("SPGAN_TWIN_G", "1") != "0"
+        # Data parallel: the generator's forward of the G step does not depend on D's update, so it is issued while D's gradient
+        # all-reduce is in flight (SPGAN_DP_OVERLAP=0: the strictly sequential schedule, for A/B measurements on a node).
+        self.overlap_g_forward = distributed and os.environ.get("SPGAN_DP_OVERLAP", "1") != "0"
 
     # ------------------------------------------------------------------ hipGraph replay
     def _bn_modules(self):
@@ -169,16 +172,20 @@ class TrainStep:
                     # the capture); all three share one memory pool
                     sx, sreal, szd, szg, salpha = self._static
                     info: Dict[str, torch.Tensor] = {}
-                    g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    g1, gf, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                     w = 1.0 / self.dpD.world_size
                     with torch.cuda.graph(g1, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to call HIP
                         real_t = self._seg_d(sx, sreal, szd, salpha, False, info)
+                    g_fake = None
+                    if self.overlap_g_forward:          # replayed while D's all-reduce is in flight
+                        with torch.cuda.graph(gf, pool=g1.pool(), capture_error_mode="thread_local"):
+                            g_fake = self._seg_gfwd(sx, szg)
                     with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
-                        self._seg_g(sx, real_t, szg, w, False, info)
+                        self._seg_g(sx, real_t, szg, w, False, info, g_fake=g_fake)
                     with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode="thread_local"):
                         self._seg_opt_g(w, False, info)
                     self._static_info = info
-                    graphs = [g1, g2, g3]
+                    graphs = [g1, gf if self.overlap_g_forward else None, g2, g3]
             except Exception as e:                                   # noqa: BLE001
                 # a failed capture must not cost the run: undo the host-side bookkeeping of the aborted attempt and issue this and all
                 # later steps eagerly (data parallel: the collectives are eager in both modes, so ranks stay in lockstep)
@@ -211,11 +218,15 @@ class TrainStep:
         if len(self._graph) == 1:
             self._graph[0].replay()
         else:
-            self._graph[0].replay()
-            self.dpD.allreduce_grads()
-            self._graph[1].replay()
+            g1, gf, g2, g3 = self._graph
+            g1.replay()
+            self.dpD.allreduce_grads_begin()
+            if gf is not None:
+                gf.replay()                          # G(x, z_g) of the G step, under D's all-reduce
+            self.dpD.allreduce_grads_end()
+            g2.replay()
             self.dpG.allreduce_grads()
-            self._graph[2].replay()
+            g3.replay()
         ops.bump_weights_epoch(self.optD.fp.flat); ops.bump_weights_epoch(self.optG.fp.flat)   # both networks were updated by the replayed Adam kernels: host-side weight caches are stale
         for m, d in zip(self._bn_modules(), self._bn_delta):
             store = m.__dict__.setdefault("_bn_pending", {})
@@ -278,19 +289,30 @@ class TrainStep:
         info.update(loss_d=loss_d.detach(), real_acc=out5[3], fake_acc=out5[4])
         return real_t
 
-    def _seg_g(self, x, real_t, z_g, scale_d, keep_grads, info):
-        """optimizerD.step(), then the G step up to lossG.backward() (model.py:259-277)."""
+    def _seg_gfwd(self, x, z_g):
+        """The generator's forward of the G step (model.py:264-271 without D's half of the requires_grad toggle).  It reads neither
+        D's weights nor D's gradients, so the data-parallel schedule issues it BEFORE optimizerD.step() (model.py:260), while D's
+        gradient all-reduce is in flight; every tensor it produces is what the reference's order produces (G is untouched by D's
+        update), and the order of all updates of D's and G's running statistics is unchanged."""
+        G = self.G
+        requires_grad(G, True)
+        self.optG.zero_grad()
+        G.twin_forward = "second" if self.twin_g_forwards else None
+        try:
+            return G(x, z_g)
+        finally:
+            G.twin_forward = None
+
+    def _seg_g(self, x, real_t, z_g, scale_d, keep_grads, info, g_fake=None):
+        """optimizerD.step(), then the G step up to lossG.backward() (model.py:259-277).  g_fake: the generator's forward when the
+        caller already issued it (_seg_gfwd)."""
         G, D = self.G, self.D
         if keep_grads:
             info["d_grads"] = {n: p.grad.detach().clone() * scale_d for n, p in D.named_parameters()}
         self.optD.step(scale_d)
         requires_grad(G, True); requires_grad(D, False)
-        self.optG.zero_grad()
-        G.twin_forward = "second" if self.twin_g_forwards else None
-        try:
-            g_fake = G(x, z_g)
-        finally:
-            G.twin_forward = None
+        if g_fake is None:
+            g_fake = self._seg_gfwd(x, z_g)
         # model.py:272-274: d_real = D(real) is computed but gen_loss ignores it (loss_utils.py:727-802) -- what lasts of that call
         # are D's BatchNorm running statistics, advanced here without the 1024-wide layer, the pool and the head
         g_real_logit = None
@@ -319,8 +341,14 @@ class TrainStep:
     def _eager_step(self, x, real, z_d, z_g, alpha=None, keep_grads: bool = False) -> Dict[str, torch.Tensor]:
         info: Dict[str, torch.Tensor] = {}
         real_t = self._seg_d(x, real, z_d, alpha, keep_grads, info)
-        scale = self.dpD.allreduce_grads() if self.dpD is not None else 1.0
-        self._seg_g(x, real_t, z_g, scale, keep_grads, info)
+        g_fake, scale = None, 1.0
+        if self.dpD is not None:
+            # data parallel: the generator's forward of the G step is issued under D's gradient all-reduce (it depends on neither)
+            self.dpD.allreduce_grads_begin()
+            if self.overlap_g_forward:
+                g_fake = self._seg_gfwd(x, z_g)
+            scale = self.dpD.allreduce_grads_end()
+        self._seg_g(x, real_t, z_g, scale, keep_grads, info, g_fake=g_fake)
         scale = self.dpG.allreduce_grads() if self.dpG is not None else 1.0
         self._seg_opt_g(scale, keep_grads, info)
         return info

@@ -38,6 +38,18 @@ def test_bench_self_launches_its_ranks(n):
         assert line["collective_backend"] == "gloo"
 
 
+def test_bench_eight_ranks():
+    """`python bench.py --gpus 8` -- the driver's scaling run -- as a plumbing self-test: eight gloo ranks on this host, the line
+    reports world size 8, global batch 8 x the per-rank batch, weak scaling."""
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "1"], {"OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["selftest"] is True and line["n_gpus"] == 8 and line["world_size_observed"] == 8
+    assert line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp8" and line["scaling"] == "weak"
+
+
 def test_bench_refuses_a_mismatched_world():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -206,3 +206,22 @@ def test_one_hop_collective_equals_all_reduce(world, tmp_path):
             assert torch.equal(ranks[r][n_out]["one_hop"], ranks[0][n_out]["one_hop"])          # every rank holds the same bits
             assert torch.allclose(ranks[r][n_out]["one_hop"].double(), want, rtol=0, atol=1e-5)
             assert torch.allclose(ranks[r][n_out]["one_hop"], ranks[r][n_out]["all_reduce"], rtol=0, atol=1e-5)
+
+
+def test_collective_probe_selftest():
+    """tools/collective_probe.py (the script for the first hour on a multi-GPU node: all_reduce vs one_hop at the step's two message
+    sizes, and the step under both collectives with / without the generator forward issued under D's all-reduce) runs end to end on
+    two gloo ranks and prints its JSON object -- a plumbing check, the numbers are meaningless here."""
+    import json
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SPGAN_DP_COLLECTIVE", "SPGAN_DP_OVERLAP"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "collective_probe.py"), "--selftest"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and out[0]["world"] == 2 and out[0]["selftest"] is True
+    assert set(out[0]["messages"]) == {"G", "D"} and all("one_hop_us" in v and "all_reduce_us" in v for v in out[0]["messages"].values())
+    assert len(out[0]["step_ms"]) == 4
