@@ -195,6 +195,11 @@ typedef struct spgan_gemm_tn_args {
   /* 1: only write the split partials into ws; the caller finishes C = beta*C + sum(partials) later with
    * spgan_splitk_reduce_multi (one launch for all the weight gradients of a backward pass).  Not with a_sp_val.  Default 0. */
   int defer_reduce;
+  /* 1: both operands are rounded to bfloat16 (after the fp32 prologues) when they are staged into LDS and multiplied on the bf16
+   * matrix pipe, fp32 accumulation / partials / reduction (BASELINE configs[4]; bf16 rather than fp16: per-point gradients of
+   * magnitude 1e-8 must not flush).  Honoured for 16-byte aligned operands with Na, Nb, lda, ldb multiples of 4 outside the
+   * skinny (Na or Nb <= 4) path; ignored otherwise.  Default 0: exact fp32 products. */
+  int mfma_lp;
 } spgan_gemm_tn_args;
 
 size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb);

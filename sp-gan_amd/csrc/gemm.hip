@@ -1316,6 +1316,164 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
       }
 }
 
+// gemm_tn with bfloat16 operands (spgan_gemm_tn_args.mfma_lp == 1; BASELINE configs[4], "fp16 MFMA MLPs"): both operands are
+// rounded to bf16 (round to nearest even; bf16 keeps fp32's exponent range -- weight gradients multiply activations with
+// per-point gradients of magnitude 1e-5..1e-8, which fp16 would flush) when they are staged into LDS, AFTER the fp32 prologues,
+// and multiplied with v_mfma_f32_32x32x16_bf16; accumulation, split-K partials and their fixed-order sum stay fp32.
+// The MFMA wants, per lane, 8 consecutive k (= m-rows) of one operand column, while the operands lie [m][column] in memory: a
+// thread therefore loads RP consecutive m-rows of 4 columns (RP = 4 / 2 / 1 for 128 / 64 / 32 staged columns per row), transposes
+// that block in registers and writes RP packed values per column: the LDS tiles are [column][32 m-values as bf16] with a row
+// stride of 20 words (16-byte aligned rows; 16 consecutive rows land on 16 distinct 4-bank groups: conflict-free b128 reads).
+// Same split plan, workspace layout, epilogue and reduction as gemm_tn_kernel.  Aligned operands only (the FAST path).
+constexpr int LDH = 20;  // words per LDS row: 32 bf16 = 16 words + 4 of padding
+template <int BMODE, int CFG>
+__global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_args p, int rows_per_split) {
+  using G = Geo<CFG>;
+  constexpr int TI = G::TI, TJ = G::TJ;
+  constexpr int TB = G::WGN * TJ * 32;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (TA + TB) * LDH];
+  float* As = smem;                 // [2][TA*LDH]
+  float* Bs = smem + 2 * TA * LDH;  // [2][TB*LDH]
+
+  const int tilesB = (p.Nb + TB - 1) / TB;
+  const int ta = blockIdx.x / tilesB, tb = blockIdx.x % tilesB;
+  const int a0 = ta * TA, b0 = tb * TB;
+  const int split = blockIdx.y;
+  const int mbeg = split * rows_per_split;
+  const int mend = min(p.M, mbeg + rows_per_split);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / G::WGN, wn = wave % G::WGN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // A: 32 float4 per m-row, thread (tid & 31) owns 4 columns, (tid >> 5) the m-rows 4*(tid>>5) .. +3
+  // B: QB = TB/4 float4 per m-row, 256/QB row groups of RP = 32*QB/256 rows
+  constexpr int QB = TB / 4, RP = TKM * QB / 256;
+  const int ac = (tid & 31) * 4, ar = 4 * (tid >> 5);
+  const int bc = (tid % QB) * 4, br = RP * (tid / QB);
+  const bool aok = a0 + ac < p.Na, bok = b0 + bc < p.Nb;
+  float4 ra[4], rb[RP];
+  float4 rb2[BMODE == SPGAN_A_EDGE ? RP : 1];
+  ColPro cp;
+  cp.sc = cp.sh = cp.eb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (BMODE != SPGAN_A_PLAIN && bok) {
+    cp.sc = *reinterpret_cast<const float4*>(p.p_scale + b0 + bc);
+    cp.sh = *reinterpret_cast<const float4*>(p.p_shift + b0 + bc);
+    if (BMODE == SPGAN_A_EDGE) cp.eb = *reinterpret_cast<const float4*>(p.e_bias + b0 + bc);
+  }
+  const bool apro = p.a_scale != nullptr;
+  float4 asc = make_float4(0.f, 0.f, 0.f, 0.f), ash = asc;
+  if (apro && aok) {
+    asc = *reinterpret_cast<const float4*>(p.a_scale + a0 + ac);
+    ash = *reinterpret_cast<const float4*>(p.a_shift + a0 + ac);
+  }
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)min(mb + ar + i, p.M - 1) * p.lda + (aok ? a0 + ac : 0));
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const int mc = min(mb + br + i, p.M - 1), cc = bok ? b0 + bc : 0;
+      if (BMODE == SPGAN_A_EDGE) {
+        rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)p.e_idx[mc] * p.ldb + cc);
+        rb2[i] = *reinterpret_cast<const float4*>(p.B + (size_t)fast_div(mc, p.e_k) * p.ldb + cc);
+      } else {
+        rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)mc * p.ldb + cc);
+      }
+    }
+  };
+  auto sstore = [&](int buf, int mb) {
+    __bf16* a = reinterpret_cast<__bf16*>(As + buf * TA * LDH);
+    __bf16* b = reinterpret_cast<__bf16*>(Bs + buf * TB * LDH);
+    float va[4][4];  // [m-row][column]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = ra[i];
+      const bool ok = mb + ar + i < mend && aok;
+      if (apro && ok) v = affine_lrelu4(v, asc, ash, 1.0f);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      va[i][0] = v.x; va[i][1] = v.y; va[i][2] = v.z; va[i][3] = v.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // column ac+q: m-rows ar..ar+3 as 4 bf16 = one 8-byte store
+      f32x4v f = {va[0][q], va[1][q], va[2][q], va[3][q]};
+      *reinterpret_cast<bf16x4*>(a + (ac + q) * (2 * LDH) + ar) = __builtin_convertvector(f, bf16x4);
+    }
+    float vb[RP][4];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      float4 v = rb[i];
+      const bool ok = mb + br + i < mend && bok;
+      if (BMODE != SPGAN_A_PLAIN && ok) {
+        if (BMODE == SPGAN_A_EDGE) {
+          v.x = (v.x - rb2[i].x) + cp.eb.x;
+          v.y = (v.y - rb2[i].y) + cp.eb.y;
+          v.z = (v.z - rb2[i].z) + cp.eb.z;
+          v.w = (v.w - rb2[i].w) + cp.eb.w;
+        }
+        v = affine_lrelu4(v, cp.sc, cp.sh, p.p_slope);
+      }
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      vb[i][0] = v.x; vb[i][1] = v.y; vb[i][2] = v.z; vb[i][3] = v.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __bf16* d = b + (bc + q) * (2 * LDH) + br;
+      if constexpr (RP == 4) {
+        f32x4v f = {vb[0][q], vb[1][q], vb[2][q], vb[3][q]};
+        *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(f, bf16x4);
+      } else {
+#pragma unroll
+        for (int i = 0; i < RP; ++i) d[i] = (__bf16)vb[i][q];
+      }
+    }
+  };
+
+  if (mbeg < mend) {
+    gload(mbeg);
+    sstore(0, mbeg);
+    __syncthreads();
+    int buf = 0;
+    for (int mb = mbeg; mb < mend; mb += TKM, buf ^= 1) {
+      const bool more = mb + TKM < mend;
+      if (more) gload(mb + TKM);
+      const __bf16* a = reinterpret_cast<const __bf16*>(As + buf * TA * LDH) + (wm * TI * 32 + l31) * (2 * LDH) + 8 * lh;
+      const __bf16* b = reinterpret_cast<const __bf16*>(Bs + buf * TB * LDH) + (wn * TJ * 32 + l31) * (2 * LDH) + 8 * lh;
+#pragma unroll
+      for (int kk = 0; kk < TKM / 16; ++kk) {  // MFMA k = 16 m-rows: lane half lh takes rows 16*kk + 8*lh .. +7
+        bf16x8 af[TI], bf[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * (2 * LDH) + 16 * kk);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * (2 * LDH) + 16 * kk);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) sstore(buf ^ 1, mb + TKM);
+      __syncthreads();
+    }
+  }
+  float* out = p.ws + (size_t)split * p.Na * p.Nb;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = a0 + (wm * TI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = b0 + (wn * TJ + j) * 32 + l31;
+        if (row < p.Na && col < p.Nb) out[(size_t)row * p.Nb + col] = acc[i][j][r];
+      }
+}
+
 // Sparse addend of A (a_sp_val/a_sp_arg): each (shape b, A-column a) contributes val[b,a] * pro(B)[arg[b,a], :] to output
 // row a.  That is a gather of one B row per (b, a) -- done here after the dense reduction, one workgroup per A-column,
 // shapes in ascending order (deterministic), the gathers of a chunk of shapes all in flight together.
@@ -1615,7 +1773,11 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
   const int TB = tn_tb(a.Nb);
   const dim3 grid(cdiv(a.Na, TA) * cdiv(a.Nb, TB), splits);
   const bool fast = (a.Na % 4 == 0) && (a.Nb % 4 == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && al16(a.A) && al16(a.B);
-  if (fast) {
+  if (fast && a.mfma_lp == 1) {  // bf16 operands (aligned problems only; others keep the fp32 kernel)
+    if (TB == 128) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 0>), grid, dim3(256), 0, s, a, rows);
+    else if (TB == 64) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 1>), grid, dim3(256), 0, s, a, rows);
+    else hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 2>), grid, dim3(256), 0, s, a, rows);
+  } else if (fast) {
     if (TB == 128) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 0, 1>), grid, dim3(256), 0, s, a, rows);
     else if (TB == 64) hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 1, 1>), grid, dim3(256), 0, s, a, rows);
     else hipLaunchKernelGGL((gemm_tn_kernel<BMODE, 2, 1>), grid, dim3(256), 0, s, a, rows);

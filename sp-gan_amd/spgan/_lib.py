@@ -64,6 +64,7 @@ class GemmTNArgs(C.Structure):
         ("ws", c_f32p), ("ws_bytes", C.c_size_t),
         ("a_scale", c_f32p), ("a_shift", c_f32p), ("a_sp_val", c_f32p), ("a_sp_arg", c_i32p), ("a_sp_rows", C.c_int),
         ("defer_reduce", C.c_int),
+        ("mfma_lp", C.c_int),
     ]
 
 

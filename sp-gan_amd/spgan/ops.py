@@ -95,7 +95,8 @@ launch_timer = None
 
 # Operand precision of the matrix-core contractions behind gemm_nt / gemm_nt_maskout / gemm_nt_bnbwd / gemm_bn_pool:
 # "f32" (default: exact fp32 products) or "f16" (operands rounded to fp16 at the LDS staging, fp32 accumulation: BASELINE
-# configs[4] "fp16 MFMA MLPs").  Weight gradients (gemm_tn), kNN distances, statistics and every epilogue stay fp32.
+# configs[4] "fp16 MFMA MLPs"; the weight gradients that reduce over the points / edges then use bfloat16 operands, gemm_tn).  kNN
+# distances, statistics, every prologue / epilogue and all accumulation stay fp32.
 _MFMA_F16 = [0]
 
 
@@ -540,9 +541,16 @@ def flush_tn() -> None:
         check(lib.spgan_splitk_reduce_multi(C.byref(a), _s()), "splitk_reduce_multi", count=len(chunk))
 
 
-def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor] = None, beta: float = 0.0, defer: bool = False) -> Tensor:
+TN_LP_MIN_ROWS = 8192     # "f16" operand mode: weight gradients reduce over >= this many points/edges on the bf16 matrix pipe
+
+
+def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor] = None, beta: float = 0.0, defer: bool = False,
+            exact: bool = False) -> Tensor:
     """C[Na,Nb] = beta*C + A^T @ pro(Bm): weight gradient, reduction over the M rows (points or edges).
     A may be a SparseAffine operand (evaluated on load).
+    In the "f16" operand mode (set_mfma_operands) the products that reduce over the points / edges (M >= TN_LP_MIN_ROWS) round
+    both operands to bfloat16 at the LDS staging -- fp32's exponent range: per-point gradients are 1e-5..1e-8 -- and accumulate in
+    fp32 (spgan_gemm_tn_args.mfma_lp); the small weight-by-weight products and exact=True calls keep fp32 operands.
     defer=True: the returned tensor is NOT valid until flush_tn() ran -- the split-K partial sums of all the weight gradients of a
     backward pass are then finished by one launch (functions._deliver flushes before it hands gradients on)."""
     sa = A if isinstance(A, SparseAffine) else None
@@ -581,6 +589,7 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     a.beta = float(beta); a.ws = _p(ws); a.ws_bytes = wsb
     defer = bool(defer) and sa is None
     a.defer_reduce = 1 if defer else 0
+    a.mfma_lp = 1 if (_MFMA_F16[0] == 1 and not exact and M_ >= TN_LP_MIN_ROWS) else 0
     done = launch_timer("gemm_tn", a) if launch_timer is not None else None
     check(lib.spgan_gemm_tn(C.byref(a), _s()), "gemm_tn", M=M_, Na=Na, Nb=Nb)
     if done is not None:

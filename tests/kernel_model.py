@@ -272,7 +272,7 @@ def flush_tn():
     pass
 
 
-def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0, defer=False):
+def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0, defer=False, exact=False):
     A = _dense(A)
     b = _operand(Bm, pro, edge, Bm.shape[1])
     c = A.t() @ b

@@ -47,6 +47,30 @@ def _gemm_nt_f16(ops, M, N, K):
         close(a_, b_, rtol=2e-3, atol=2e-3, what="bnbwd")
 
 
+@pytest.mark.parametrize("M,Na,Nb", [(16384, 256, 256), (65536, 128, 1280), (20480, 128, 64), (9000, 64, 32), (8192, 320, 64), (12288, 132, 36)])
+def test_gemm_tn_bf16_operands(f16, M, Na, Nb):
+    """Weight gradients in the "f16" operand mode: both operands rounded to bfloat16 at the LDS staging (after the fp32 prologue),
+    fp32 accumulation / split partials / reduction.  Against the exact product of bf16-rounded operands (tight: only the fp32
+    summation order differs) and against the fp32 model at bf16-operand accuracy; tiny per-point gradients (1e-7) must survive
+    (fp16 would flush them); exact=True and short reductions keep fp32 operands."""
+    ops = f16
+    A, Bm = rnd("tb.A%d.%d" % (M, Na), (M, Na)) * 1e-7, rnd("tb.B%d.%d" % (M, Nb), (M, Nb))
+    sc, sh = rnd("tb.sc%d" % Nb, (Nb,)).abs() + 0.5, rnd("tb.sh%d" % Nb, (Nb,), 0.3)
+    r = lambda t: t.bfloat16().float()
+    for pro in (None, (sc, sh, 0.01)):
+        got = ops.gemm_tn(A, Bm, pro=pro)
+        b = Bm if pro is None else torch.where(Bm * sc + sh > 0, Bm * sc + sh, (Bm * sc + sh) * 0.01)
+        exact = (r(A).double().t() @ r(b).double()).float()
+        close(got, exact, rtol=3e-5, atol=1e-12, what="bf16-operand arithmetic")
+        close(got, km.gemm_tn(A, Bm, pro=pro), rtol=6e-3 * (1 + (pro is not None)), atol=1e-12, what="vs fp32 model")
+        close(ops.gemm_tn(A, Bm, pro=pro, exact=True), km.gemm_tn(A, Bm, pro=pro), rtol=2e-5, atol=1e-12, what="exact=True keeps fp32 operands")
+    out = rnd("tb.out%d.%d" % (Na, Nb), (Na, Nb)) * 1e-4
+    want = 0.5 * out + (r(A).double().t() @ r(Bm).double()).float()
+    close(ops.gemm_tn(A, Bm, out=out.clone(), beta=0.5), want, rtol=3e-5, atol=1e-12, what="beta accumulate")
+    short = ops.gemm_tn(A[:4096], Bm[:4096])                                     # below TN_LP_MIN_ROWS: fp32 operands
+    close(short, km.gemm_tn(A[:4096], Bm[:4096]), rtol=2e-5, atol=1e-12, what="short reduction stays fp32")
+
+
 def test_networks_f16_close_to_f32(sp):
     """fp16 MFMA operands against fp32: the stage in front of EdgeConv2's graph and the discriminator logits stay within fp16-
     operand accuracy; most feature-space kNN rows coincide (a flipped near-tie row changes the downstream features discretely,
