@@ -267,6 +267,192 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float* __restrict__
   }
 }
 
+// The same kernel with the inner products on the bf16 matrix pipe at fp32-equivalent accuracy: every fp32 value is split exactly
+// into three bfloat16 terms (hi + mid + lo) when a tile is staged into LDS, and a product is the six leading cross terms
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation; the split-bf16 scheme of csrc/gemm.hip) -- 24 MFMAs of 8 passes per 32 x 32 x 64
+// tile instead of 32 of 16 passes.  Distances and selection are unchanged; the squared norms still come from the fp32 values.
+// The matrix-pipe time and the selection's VALU time of a wave add up on this kernel (profiles/r02_knn_phase_ablation.txt), so
+// shrinking the former to 3/8 is a direct gain: see profiles/r03_knn_ab.txt.
+template <int KP, int CP>
+__global__ __launch_bounds__(256) void knn_mfma3_kernel(const float* __restrict__ x, int N, int C, int k, int32_t* __restrict__ idx) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  constexpr int PW = CP / 2;            // words per plane of a row (CP bf16)
+  constexpr int LDC = 3 * PW + 4;       // 100 / 196 words: 25 / 49 four-word groups per row (odd) -> the 16 lanes of a b128 read phase hit 16 distinct groups
+  constexpr int KS = CP / 16;           // MFMA k-steps (16 channels each) per tile
+  constexpr int SL = CP / 32;           // float4 staging slots per thread (32 rows x CP/4 float4 / 256 threads)
+  __shared__ __attribute__((aligned(16))) float cand[2][32 * LDC];
+  __shared__ __attribute__((aligned(16))) float cn[2][32];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float* xb = x + (size_t)b * N * C;
+  const int qbase = blockIdx.x * 128;
+  const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+
+  float4 st[SL];
+  auto stage = [&](int row0) {  // global -> registers: rows row0..row0+31, zero padded
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      const int e = tid + 256 * i, r = e / (CP / 4), c = (e % (CP / 4)) * 4;
+      const int row = row0 + r;
+      st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < N && c < C) {
+        const float* p = xb + (size_t)row * C + c;
+        if (vec) st[i] = *reinterpret_cast<const float4*>(p);
+        else {
+          st[i].x = p[0];
+          if (c + 1 < C) st[i].y = p[1];
+          if (c + 2 < C) st[i].z = p[2];
+          if (c + 3 < C) st[i].w = p[3];
+        }
+      }
+    }
+  };
+  auto commit = [&](int buf) {  // registers -> LDS tile + squared norms of its 32 rows
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      const int e = tid + 256 * i, r = e / (CP / 4), c = (e % (CP / 4)) * 4;
+      {  // v = hi + mid + lo exactly (three bf16 terms = fp32's 24 significand bits); plane p at words [p*PW, (p+1)*PW) of the row
+        const f32x4v f = {st[i].x, st[i].y, st[i].z, st[i].w};
+        const bf16x4 hi = __builtin_convertvector(f, bf16x4);
+        const f32x4v r1 = f - __builtin_convertvector(hi, f32x4v);
+        const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
+        const f32x4v r2 = r1 - __builtin_convertvector(mid, f32x4v);
+        const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
+        float* row = &cand[buf][r * LDC + (c >> 1)];
+        *reinterpret_cast<bf16x4*>(row) = hi;
+        *reinterpret_cast<bf16x4*>(row + PW) = mid;
+        *reinterpret_cast<bf16x4*>(row + 2 * PW) = lo;
+      }
+      float s = fmaf(st[i].w, st[i].w, fmaf(st[i].z, st[i].z, fmaf(st[i].y, st[i].y, st[i].x * st[i].x)));
+#pragma unroll
+      for (int o = 1; o < CP / 4; o <<= 1) s += __shfl_xor(s, o);  // the CP/4 lanes of a row are consecutive
+      if ((e % (CP / 4)) == 0) cn[buf][r] = s;
+    }
+  };
+
+  // queries: the workgroup's 4 x 32 rows go through the same staging path, wave w keeps tile w
+  bf16x8 qv[3][KS];   // the query's three planes: lane (l31, lh) holds channels 16*t + 8*lh .. +7 of k-step t
+  float qn = 0.f;
+  for (int w = 0; w < 4; ++w) {
+    stage(qbase + 32 * w);
+    __syncthreads();
+    commit(0);
+    __syncthreads();
+    if (w == wave) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int t = 0; t < KS; ++t) qv[pl][t] = *reinterpret_cast<const bf16x8*>(&cand[0][l31 * LDC + pl * PW + 8 * t + 4 * lh]);
+      qn = cn[0][l31];
+    }
+  }
+  __syncthreads();
+
+  float bd[KP];
+  int bi[KP];
+#pragma unroll
+  for (int t = 0; t < KP; ++t) {
+    bd[t] = INFINITY;
+    bi[t] = 0x7fffffff;
+  }
+
+  const int ntiles = (N + 31) / 32;
+  stage(0);
+  commit(0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int buf = tile & 1;
+    if (tile + 1 < ntiles) stage((tile + 1) * 32);  // in flight under the MFMAs
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    const float* a = &cand[buf][l31 * LDC + 4 * lh];
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a + 8 * t), am = *reinterpret_cast<const bf16x8*>(a + PW + 8 * t),
+                   al = *reinterpret_cast<const bf16x8*>(a + 2 * PW + 8 * t);
+      // a*q ~ ah*qh + (ah*qm + am*qh) + (ah*ql + al*qh + am*qm): every partial product is exact in fp32, the dropped terms are
+      // <= 3*2^-24 relative -- fp32-equivalent inner products at 6/16 of the fp32-MFMA time; small terms first
+      f32x16& c = (t & 1) ? acc1 : acc0;
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qv[0][t], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qv[2][t], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qv[1][t], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qv[0][t], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qv[1][t], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qv[0][t], c, 0, 0, 0);
+    }
+    const int j0 = tile * 32;
+    // Selection.  After the first tiles a candidate rarely beats the lane's current worst, but SOME lane of the wave
+    // nearly always has one among its 16 -- running the insertion under a per-candidate branch would execute it almost
+    // every time.  Instead: 16 compares build a per-lane bit mask of the survivors, and a per-lane loop pops them in
+    // index order (the wave iterates max-over-lanes(#survivors) times, typically 1-2 instead of ~12).
+    float d[16];
+    unsigned live = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 nrm = *reinterpret_cast<const float4*>(&cn[buf][8 * g + 4 * lh]);
+      const float nn[4] = {nrm.x, nrm.y, nrm.z, nrm.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = 4 * g + u;
+        const float dot = acc0[r] + acc1[r];
+        d[r] = (-2.f * dot + qn) + nn[u];
+        if (j0 + 8 * g + 4 * lh + u >= N) d[r] = INFINITY;
+        live |= (d[r] < bd[KP - 1]) ? (1u << r) : 0u;
+      }
+    }
+    while (live) {
+      const int r = __ffs(live) - 1;
+      live &= live - 1;
+      float dv = d[0];
+#pragma unroll
+      for (int u = 1; u < 16; ++u) dv = (r == u) ? d[u] : dv;
+      if (dv < bd[KP - 1]) {  // the threshold may have tightened since the mask was built
+        bd[KP - 1] = dv;
+        bi[KP - 1] = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int t = KP - 1; t > 0; --t) {
+          if (bd[t] < bd[t - 1]) {  // strict: equal distances keep the lower (earlier) index first
+            const float td = bd[t]; bd[t] = bd[t - 1]; bd[t - 1] = td;
+            const int ti = bi[t]; bi[t] = bi[t - 1]; bi[t - 1] = ti;
+          }
+        }
+      }
+    }
+    if (tile + 1 < ntiles) commit(buf ^ 1);  // its last readers passed the previous barrier
+    __syncthreads();
+  }
+
+  // merge the two half-lists of a query into lane lh == 0 by (distance, index)
+#pragma unroll
+  for (int t = 0; t < KP; ++t) {
+    const float od = __shfl_xor(bd[t], 32);
+    const int oi = __shfl_xor(bi[t], 32);
+    if (lh == 0 && (od < bd[KP - 1] || (od == bd[KP - 1] && oi < bi[KP - 1]))) {
+      bd[KP - 1] = od;
+      bi[KP - 1] = oi;
+#pragma unroll
+      for (int u = KP - 1; u > 0; --u) {
+        if (bd[u] < bd[u - 1] || (bd[u] == bd[u - 1] && bi[u] < bi[u - 1])) {
+          const float td = bd[u]; bd[u] = bd[u - 1]; bd[u - 1] = td;
+          const int ti = bi[u]; bi[u] = bi[u - 1]; bi[u - 1] = ti;
+        }
+      }
+    }
+  }
+  const int q = qbase + 32 * wave + l31;
+  if (lh == 0 && q < N) {
+    int32_t* o = idx + ((size_t)b * N + q) * k;
+#pragma unroll
+    for (int t = 1; t < KP; ++t)
+      if (t <= k) o[t - 1] = b * N + bi[t];
+  }
+}
+
 // fp64 direct differences for coordinate-space inputs (C <= 8): the query sits in registers.
 template <int KP, int C>
 __global__ __launch_bounds__(256) void knn_f64_kernel(const float* __restrict__ x, int N, int k, int32_t* __restrict__ idx) {
@@ -338,7 +524,11 @@ int launch_knn(const float* x, int B, int N, int C, int k, int mode, int32_t* id
     else if (C <= 16) hipLaunchKernelGGL((knn_f32_kernel<KP, 16>), grid, block, 0, s, x, N, C, k, idx);
     else if (C > 128) return SPGAN_EINVAL;
     else if constexpr (KP == 11) {  // k <= 10 (SP-GAN: nk/2 = 10): matrix-core distances; the longer lists spill there
-      if (C <= 64) hipLaunchKernelGGL((knn_mfma_kernel<KP, 64>), dim3(cdiv(N, 128), B), dim3(256), 0, s, x, N, C, k, idx);
+      static const bool x3 = !(getenv("SPGAN_KNN_BF16X3") && atoi(getenv("SPGAN_KNN_BF16X3")) == 0);   // 0: the fp32-MFMA kernel (A/B measurements)
+      if (x3) {
+        if (C <= 64) hipLaunchKernelGGL((knn_mfma3_kernel<KP, 64>), dim3(cdiv(N, 128), B), dim3(256), 0, s, x, N, C, k, idx);
+        else hipLaunchKernelGGL((knn_mfma3_kernel<KP, 128>), dim3(cdiv(N, 128), B), dim3(256), 0, s, x, N, C, k, idx);
+      } else if (C <= 64) hipLaunchKernelGGL((knn_mfma_kernel<KP, 64>), dim3(cdiv(N, 128), B), dim3(256), 0, s, x, N, C, k, idx);
       else hipLaunchKernelGGL((knn_mfma_kernel<KP, 128>), dim3(cdiv(N, 128), B), dim3(256), 0, s, x, N, C, k, idx);
     } else {
       if (C <= 32) hipLaunchKernelGGL((knn_f32_kernel<KP, 32>), grid, block, 0, s, x, N, C, k, idx);
