@@ -620,8 +620,9 @@ def drop_weight_caches() -> None:
     captures a step into a hipGraph: a cache entry filled by an EAGER call after the last optimiser step (a sample dump, an eval
     forward) would be a hit during the capture, the kernel that derives it would not be recorded, and every replay would read a
     tensor frozen at capture time that lives outside the graph's memory pool."""
-    _T_CACHE.clear()
-    _WO_CACHE.clear()
+    for key, (stamp, t, oref, view) in list(_T_CACHE.items()):
+        _T_CACHE[key] = ((-1, -1), t, oref, view)          # stale, not forgotten: the capture's first use re-transposes the whole
+    _WO_CACHE.clear()                                      # network's matrices in ONE launch (_refresh_transposes), as every step does
 
 
 def conv_out_weight_grad_from_pm(g: Tensor, F_: int, k: int) -> Tensor:

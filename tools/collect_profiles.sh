@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the measurement artefacts of a round on the GPU box into gpurun_out/ (copy what shall be judged to profiles/).
-# usage (through gpurun): bash tools/collect_profiles.sh r02
+# usage (through gpurun): bash tools/collect_profiles.sh r03
 set -u
 TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT
@@ -19,4 +19,6 @@ for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do rm -rf /tmp/p_$c; rocprofv3 --pmc $c
 python $R/tools/pmc_step_total.py $(find /tmp/p_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/p_WRITE_SIZE -name "*.db" | head -1) $(find /tmp/p_MfmaUtil -name "*.db" | head -1) > $O/${TAG}_pmc_step.json
 for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/g_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/g_$c -o r -- python $R/tools/pmc_gemm.py > /tmp/glog_$c 2>&1; python $R/tools/pmc_summary.py $(find /tmp/g_$c -name "*.db" | head -1) gemm_nt > $O/${TAG}_pmc_gemm_$c.txt; done
 python $R/tools/mfma_shapes.py > $O/${TAG}_mfma_shapes.txt 2>/dev/null
+python $R/tools/mfma_shapes.py --mfma f16 > $O/${TAG}_mfma_shapes_f16.txt 2>/dev/null
+python $R/tools/knn_ab.py > $O/${TAG}_knn_ab_raw.txt 2>&1
 echo collected; ls -la $O | tail -20
