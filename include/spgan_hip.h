@@ -33,6 +33,7 @@ typedef void* spgan_stream_t; /* hipStream_t */
 
 #define SPGAN_OK 0
 #define SPGAN_EINVAL (-22)
+#define SPGAN_ECOMM (-70) /* collective layer: RCCL not loadable, or an RCCL call failed (spgan_comm_last_error) */
 
 int spgan_version(void);
 /* returns the compiled-for architecture string, e.g. "gfx950" */
@@ -433,6 +434,20 @@ int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s);
  * all ranks end up with bit-identical sums.  recv and out 16-byte aligned.  The exchanges themselves are torch.distributed / RCCL
  * (spgan.parallel.DataParallel(collective="one_hop")). */
 int spgan_reduce_chunks(const float* recv, int parts, size_t n, float* out, spgan_stream_t s);
+/* ---- allreduce_flat: the data-parallel exchange of a train step -- what replaces nn.DataParallel's per-call
+ * scatter / parameter broadcast / gather (Generation/model.py:79-84): ONE all-reduce (sum, in place) of a network's flat gradient
+ * buffer over RCCL, enqueued on the caller's stream (capturable into a hipGraph together with the kernels around it).  RCCL is
+ * dlopen'ed at first use (no link-time dependency).  Rendezvous: rank 0 calls spgan_comm_unique_id and hands the 128 bytes to
+ * every rank through the host program's own channel; then every rank calls spgan_comm_init with the HIP device it trains on
+ * current.  spgan_comm_available() == 0 (or status SPGAN_ECOMM) when librccl cannot be loaded; spgan_comm_last_error() is the
+ * ncclResult_t of the last failing call.  The caller divides by the world size (spgan_adam_step's grad_scale). */
+int spgan_comm_available(void);
+int spgan_comm_last_error(void);
+int spgan_comm_unique_id(void* id128);
+int spgan_comm_init(const void* id128, int rank, int world, void** comm);
+int spgan_comm_world(void* comm);
+int spgan_allreduce_flat(void* comm, float* buf, size_t n, spgan_stream_t s);
+int spgan_comm_destroy(void* comm);
 /* dst[t][i] = src[t][i] for the same argument block: up to SPGAN_MULTI_MAX device-to-device copies in ONE launch. */
 int spgan_multi_copy(const spgan_multi_add_args* a, spgan_stream_t s);
 /* Finish up to SPGAN_MULTI_MAX deferred spgan_gemm_tn products in one launch: C[e] = beta[e]*C[e] + fixed-order sum of the

@@ -178,6 +178,13 @@ SIGNATURES = {
     "spgan_scale_residual_bwd": (I, [P, P, P, P, P, P, SZ, SZ, P]),
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
     "spgan_reduce_chunks": (I, [P, I, C.c_size_t, P, P]),
+    "spgan_comm_available": (I, []),
+    "spgan_comm_last_error": (I, []),
+    "spgan_comm_unique_id": (I, [P]),
+    "spgan_comm_init": (I, [P, I, I, C.POINTER(C.c_void_p)]),
+    "spgan_comm_world": (I, [P]),
+    "spgan_allreduce_flat": (I, [P, P, C.c_size_t, P]),
+    "spgan_comm_destroy": (I, [P]),
     "spgan_multi_copy": (I, [C.POINTER(MultiAddArgs), P]),
     "spgan_multi_transpose": (I, [C.POINTER(MultiTransposeArgs), P]),
     "spgan_gemm_tn_splits": (I, [I, I, I]),

@@ -45,16 +45,20 @@ class DataParallel(nn.Module):
         ONE all-to-all (on a fully connected xGMI node every pair is one hop apart) + a local sum of the received chunks in rank order
         (spgan_reduce_chunks) + one all-gather -- two hops for the 2.3 / 3.9 MB latency-bound gradient messages instead of a ring's
         2(W-1) steps.  Both give every rank the same sums (one_hop: bit-identical on all ranks by construction).
-        Which is faster on an 8-GPU MI355X node is NOT measured (no multi-GPU box in this build's loop); the environment variable
-        SPGAN_DP_COLLECTIVE overrides the default for such a measurement."""
+        "rccl": the library's own entry point spgan_allreduce_flat (include/spgan_hip.h): one RCCL all-reduce issued by
+        libspgan_hip.so itself on the CURRENT stream through a communicator of its own (the 128-byte RCCL id travels from rank 0
+        through torch.distributed once) -- what a host program without torch.distributed would call, and capturable into a hipGraph.
+        Which is fastest on an 8-GPU MI355X node is NOT measured (no multi-GPU box in this build's loop: tools/collective_probe.py
+        is the script for it); the environment variable SPGAN_DP_COLLECTIVE overrides the default for such a measurement."""
         super().__init__()
         self.module = module
         self.pg = process_group
         self.flat = flatten_module(module)
         self.collective = collective or os.environ.get("SPGAN_DP_COLLECTIVE", "all_reduce")
-        if self.collective not in ("all_reduce", "one_hop"):
-            raise ValueError("collective must be 'all_reduce' or 'one_hop'")
+        if self.collective not in ("all_reduce", "one_hop", "rccl"):
+            raise ValueError("collective must be 'all_reduce', 'one_hop' or 'rccl'")
         self._hop = None             # (send [W, chunk], recv [W, chunk], mine [chunk], full [W*chunk]) staging buffers of the one-hop path
+        self._comm = None            # native RCCL communicator of the "rccl" path (lazy)
 
     @property
     def world_size(self) -> int:
@@ -85,6 +89,8 @@ class DataParallel(nn.Module):
         if w > 1:
             if self.collective == "one_hop":
                 self._allreduce_one_hop(w)                 # three dependent steps with a local kernel in the middle: issued in order
+            elif self.collective == "rccl":
+                self._allreduce_native()                   # on the current stream: the following kernels queue behind it
             else:
                 self._work = dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
@@ -93,6 +99,49 @@ class DataParallel(nn.Module):
         if work is not None:
             work.wait()                                    # stream-level join for RCCL (the host does not block); a host wait on gloo
         return 1.0 / self.world_size
+
+    def native_comm(self):
+        """The library's own RCCL communicator over the ranks of this process group (created on first use): rank 0 draws the 128-byte
+        id (spgan_comm_unique_id), torch.distributed carries it to the other ranks once, every rank calls spgan_comm_init."""
+        if self._comm is not None:
+            return self._comm
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        dev = self.flat.flat.device
+        if dev.type != "cuda":
+            raise RuntimeError("collective='rccl' needs the parameters on a GPU")
+        if not lib.spgan_comm_available():
+            raise RuntimeError("collective='rccl': librccl could not be loaded by libspgan_hip.so")
+        rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
+        w = self.world_size
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            _lib.check(lib.spgan_comm_unique_id(buf), "comm_unique_id")
+        ident = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+        if w > 1:
+            dist.broadcast(ident, src=0, group=self.pg)
+        raw = (C.c_ubyte * 128)(*ident.cpu().tolist())
+        comm = C.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(lib.spgan_comm_init(raw, rank, w, C.byref(comm)), "comm_init", rank=rank, world=w, rccl_error=lib.spgan_comm_last_error())
+        self._comm = comm
+        return comm
+
+    def _allreduce_native(self) -> None:
+        from . import _lib
+        g = self.flat.grad
+        _lib.check(_lib.load().spgan_allreduce_flat(self.native_comm(), g.data_ptr(), g.numel(), torch.cuda.current_stream().cuda_stream),
+                   "allreduce_flat", n=g.numel())
+
+    def __del__(self):
+        comm, self._comm = getattr(self, "_comm", None), None
+        if comm is not None:
+            try:
+                from . import _lib
+                _lib.load().spgan_comm_destroy(comm)
+            except Exception:      # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def _allreduce_one_hop(self, w: int) -> None:
         from . import ops

@@ -77,6 +77,10 @@ class TrainStep:
         # Data parallel: the generator's forward of the G step does not depend on D's update, so it is issued while D's gradient
         # all-reduce is in flight (SPGAN_DP_OVERLAP=0: the strictly sequential schedule, for A/B measurements on a node).
         self.overlap_g_forward = distributed and os.environ.get("SPGAN_DP_OVERLAP", "1") != "0"
+        # collective="rccl" (spgan_allreduce_flat) is enqueued on the current stream by the library itself, so the whole data-parallel
+        # step -- both collectives included -- can be ONE captured graph.  Opt-in (SPGAN_DP_SINGLE_GRAPH=1): not measured on a
+        # multi-GPU node yet (tools/collective_probe.py tries it).
+        self.single_graph_dp = (distributed and self.dpD.collective == "rccl" and os.environ.get("SPGAN_DP_SINGLE_GRAPH", "0") == "1")
 
     # ------------------------------------------------------------------ hipGraph replay
     def _bn_modules(self):
@@ -162,7 +166,7 @@ class TrainStep:
             nets.drop_weight_caches()
             self.G.__dict__["_ec1_twin"] = None
             try:
-                if self.dpD is None:
+                if self.dpD is None or self.single_graph_dp:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         self._static_info = self._eager_step(*self._static)

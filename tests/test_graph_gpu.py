@@ -276,3 +276,77 @@ def test_graph_mode_with_noisy_labels(sp):
     assert tr._graph is not None and tr.use_graph, "capture must succeed with device-side label draws"
     # lr = 0: parameters never move, BatchNorm is in train mode -> the only thing that changes between replays is the label draw
     assert len(set(vals[3:])) == len(vals[3:]), vals
+
+
+def test_native_rccl_allreduce_flat_one_rank_and_in_a_graph(sp):
+    """spgan_allreduce_flat (include/spgan_hip.h): the library's own RCCL communicator (dlopen'ed librccl, id drawn
+    by spgan_comm_unique_id) -- exercised with the one rank this box has: the sum over one rank is the buffer itself, eagerly and
+    captured into a hipGraph together with a kernel before and after it; and a data-parallel TrainStep with collective='rccl'
+    equals the single-process step (world size 1: scale 1)."""
+    import ctypes as C
+    import os
+    import torch.distributed as dist
+    from spgan import _lib
+    lib = _lib.load()
+    assert lib.spgan_comm_available() == 1, "librccl not loadable on the GPU box"
+    ident = (C.c_ubyte * 128)()
+    assert lib.spgan_comm_unique_id(ident) == 0
+    comm = C.c_void_p()
+    assert lib.spgan_comm_init(ident, 0, 1, C.byref(comm)) == 0, lib.spgan_comm_last_error()
+    assert lib.spgan_comm_world(comm) == 1
+    buf = fr.normal("rccl.buf", (980353 + 3,)).cuda()
+    want = buf.clone()
+    assert lib.spgan_allreduce_flat(comm, buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    # captured: scale -> all-reduce -> scale, replayed three times
+    static = buf.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        static.mul_(1.0)
+        assert lib.spgan_allreduce_flat(comm, static.data_ptr(), static.numel(), side.cuda_stream) == 0
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+        static.mul_(2.0)
+        assert lib.spgan_allreduce_flat(comm, static.data_ptr(), static.numel(), torch.cuda.current_stream().cuda_stream) == 0
+        static.add_(1.0)
+    static.copy_(want)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    ref = want.clone()
+    for _ in range(3):
+        ref = ref * 2.0 + 1.0
+    assert torch.equal(static, ref)
+    assert lib.spgan_comm_destroy(comm) == 0
+    assert lib.spgan_allreduce_flat(None, buf.data_ptr(), 4, None) != 0            # argument validation, not a crash
+    # the data-parallel harness over it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29534", rank=0, world_size=1)
+    os.environ["SPGAN_DP_COLLECTIVE"] = "rccl"
+    try:
+        steps = 4
+        Ge, De, tre, le = _run(sp, False, steps)
+        o = Opts()
+        G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(), salt=8))
+        D = _load(sp.Discriminator(o), fr.init_params(orc.discriminator_shapes(), salt=8))
+        tr = sp.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=True)
+        assert tr.dpD.collective == "rccl"
+        B, N = 4, 256
+        x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+        real = [fr.synthetic_real(B, N, seed=90 + i).cuda() for i in range(2)]
+        zs = [fr.latent(B, N, seed=70 + i).cuda() for i in range(3)]
+        alpha = fr.uniform("graph.alpha", (B, 1, 1), 0.0, 1.0).cuda()
+        for i in range(steps):
+            tr.step(x, real[i % 2], zs[i % 3], zs[(i + 1) % 3], alpha=alpha)
+            tr.dpD._allreduce_native(); tr.dpG._allreduce_native()       # world 1: allreduce_grads() skips the call; issue it explicitly (identity)
+        torch.cuda.synchronize()
+        for (n, a), (_, b) in zip(list(Ge.state_dict().items()) + list(De.state_dict().items()),
+                                  list(G.state_dict().items()) + list(D.state_dict().items())):
+            assert torch.equal(a, b), n
+    finally:
+        os.environ.pop("SPGAN_DP_COLLECTIVE", None)
+        dist.destroy_process_group()

@@ -5,6 +5,7 @@
 
 Times, at the two message sizes of the step (G: 585,155 floats = 2.34 MB, D: 980,353 floats = 3.92 MB),
   * all_reduce           : one dist.all_reduce of the flat buffer (RCCL picks ring / tree),
+  * rccl                 : spgan_allreduce_flat -- the library's own RCCL communicator, issued on the step's stream (GPU runs only),
   * one_hop              : all_to_all_single (reduce-scatter in one hop on the fully connected xGMI node) + spgan_reduce_chunks (local,
                            fixed order) + all_gather_into_tensor  (spgan.DataParallel(collective="one_hop")),
 and the train step itself with SPGAN_DP_COLLECTIVE = all_reduce / one_hop and SPGAN_DP_OVERLAP = 1 / 0 (generator forward issued
@@ -52,7 +53,7 @@ def main():
     out = {"world": world, "backend": dist.get_backend(), "iters": iters, "messages": {}}
     for name, n in sizes.items():
         res = {}
-        for coll in ("all_reduce", "one_hop"):
+        for coll in ("all_reduce", "one_hop") + (() if selftest else ("rccl",)):
             m = Holder(n)
             dp = spgan.DataParallel(m, collective=coll)
             nf = dp.flat.grad.numel()                       # the flat buffer is padded to 16-byte multiples
@@ -77,9 +78,9 @@ def main():
         np = N; nk = 20; nz = 128; softmax = True; off = False; attn = False; use_head = False; eql = False; z_norm = False; small_d = False
     from spgan import fixture_rng as fr
     out["step_ms"] = {}
-    for coll in ("all_reduce", "one_hop"):
-        for overlap in ("1", "0"):
-            os.environ["SPGAN_DP_COLLECTIVE"] = coll; os.environ["SPGAN_DP_OVERLAP"] = overlap
+    for coll, overlap, single in [(c, o, "0") for c in ("all_reduce", "one_hop") for o in ("1", "0")] + ([] if selftest else [("rccl", "1", "0"), ("rccl", "1", "1")]):
+        if True:
+            os.environ["SPGAN_DP_COLLECTIVE"] = coll; os.environ["SPGAN_DP_OVERLAP"] = overlap; os.environ["SPGAN_DP_SINGLE_GRAPH"] = single
             torch.manual_seed(123)
             G, D = spgan.Generator(O).to(dev), spgan.Discriminator(O, num_point=N).to(dev)
             tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, distributed=True, graph=not selftest)
@@ -97,7 +98,7 @@ def main():
             sync()
             t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            out["step_ms"]["%s,overlap=%s" % (coll, overlap)] = round(t.item(), 3)
+            out["step_ms"]["%s,overlap=%s%s" % (coll, overlap, ",single_graph" if single == "1" else "")] = round(t.item(), 3)
             del tr, G, D
     if rank == 0:
         if selftest:
