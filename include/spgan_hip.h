@@ -157,6 +157,11 @@ typedef struct spgan_gemm_nt_args {
    * automatic tile-size rule (tile_hint 0) to decide from the rows of ONE group, so that a grouped launch runs the kernel its groups
    * would run as separate calls (bit-identical results). */
   int p_group_rows;
+  /* A2 != NULL (with a_mode = SPGAN_A_AFFINE_LRELU, no sparse addend): the operand is a = A*p_scale[k] + A2*p_scale2[k] + p_shift[k]
+   * -- two tensors of the same shape [M,K] (leading dimensions lda, lda2), no activation (p_slope is ignored): the BatchNorm-backward
+   * tensor dy = p*g + q*y + r (spgan_bn_bwd_coeffs) evaluated on the operand load of its consumers instead of by a pass of its own.
+   * Epilogues LINEAR / BNBWD / EDGE_BNBWD; M > 64; 128-row kernels only. */
+  const float* A2; int lda2; const float* p_scale2;
 } spgan_gemm_nt_args;
 /* 1 when spgan_gemm_nt will run this problem on the M <= 64 kernel, i.e. when `tail.enabled` is acceptable (else the launch
  * returns SPGAN_EINVAL for a tail request) */
@@ -201,7 +206,16 @@ typedef struct spgan_gemm_tn_args {
    * magnitude 1e-8 must not flush).  Honoured for 16-byte aligned operands with Na, Nb, lda, ldb multiples of 4 outside the
    * skinny (Na or Nb <= 4) path; ignored otherwise.  Default 0: exact fp32 products. */
   int mfma_lp;
+  /* A2 != NULL (needs a_scale, a_shift; not with a_sp_val): a = A*a_scale[c] + A2*a_scale2[c] + a_shift[c] -- the same two-tensor
+   * operand as spgan_gemm_nt_args.A2, on the A side of the weight-gradient product. */
+  const float* A2; int lda2; const float* a_scale2;
 } spgan_gemm_tn_args;
+
+/* Coefficient vectors of the BatchNorm backward as an affine combination of two tensors (Generator.py:58-67 / Discriminator.py:57-79
+ * backward): dy = gamma*invstd*(g - S0/count - xhat*S1/count), xhat = (y - mean)*invstd  ==  p*g + q*y + r  with
+ *   p = gamma*invstd,  q = -p*invstd*S1/count,  r = -p*S0/count - q*mean        (gamma == NULL: 1)
+ * sums = [S0 | S1] (2C); coef [3, C] = [p | q | r].  Consumers: spgan_gemm_nt_args.A2 / spgan_gemm_tn_args.A2. */
+int spgan_bn_bwd_coeffs(const float* sums, const float* mean, const float* invstd, const float* gamma, int C, float count, float* coef, spgan_stream_t s);
 
 size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb);
 int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s);

@@ -34,6 +34,9 @@ namespace {
 // internal operand mode: A_AFFINE_LRELU with the sparse addend (sp_val != NULL) -- its own instantiation, so the plain
 // affine kernels do not carry the addend's registers and LDS-patch code
 constexpr int A_AFFINE_SPARSE = 3;
+// internal operand mode: a = A*p_scale[k] + A2*p_scale2[k] + p_shift[k] (two tensors, no activation): the BatchNorm-backward operand
+// dy = p*g + q*y + r evaluated on the operand load instead of by a pass of its own (spgan_gemm_nt_args.A2)
+constexpr int A_AFFINE2 = 4;
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -262,19 +265,21 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   // difference, the sparse addend) is applied in sstore, i.e. after this tile's MFMAs were issued.  Transforming at load
   // time would put a vmcnt wait in front of the MFMAs and expose the whole HBM/L2 latency once per k-tile.
   float4 ra[4], rb[BSLOT];
-  float4 ra2[AMODE == SPGAN_A_EDGE ? 4 : 1];  // EDGE: the centre rows
+  float4 ra2[(AMODE == SPGAN_A_EDGE || AMODE == A_AFFINE2) ? 4 : 1];  // EDGE: the centre rows; AFFINE2: the rows of the second tensor
   float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f), peb = psh;
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;  // staging slot: row (tid/8 + 32*i), k offset 4*(tid%8)
   // Element offset of the operand row (EDGE: neighbour j) and centre row i of each staging slot, 32-bit (checked on the
   // host: M*lda, N*ldw < 2^32) so the loads use the scalar-base + 32-bit-offset addressing form.  Rows >= M are clamped
   // to M-1: what they stage only reaches accumulator rows >= M, which no epilogue reads -- so the aligned path loads
   // unconditionally.  Likewise weight rows >= N only feed output columns >= N.
-  unsigned offA[4], offC[AMODE == SPGAN_A_EDGE ? 4 : 1], offW[BSLOT];
+  unsigned offA[4], offC[(AMODE == SPGAN_A_EDGE || AMODE == A_AFFINE2) ? 4 : 1], offW[BSLOT];
+  const float* pA2 = AMODE == A_AFFINE2 ? p_.A2 : pA;   // second operand tensor (EDGE: the same tensor, centre rows)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = min(m0 + lrow + 32 * i, p.M - 1);
     offA[i] = (unsigned)((AMODE == SPGAN_A_EDGE) ? p.e_idx[m] : m) * (unsigned)p.lda;
     if (AMODE == SPGAN_A_EDGE) offC[i] = (unsigned)fast_div(m, p.e_k) * (unsigned)p.lda;
+    if (AMODE == A_AFFINE2) offC[i] = (unsigned)m * (unsigned)p.lda2;
   }
 #pragma unroll
   for (int i = 0; i < BSLOT; ++i) offW[i] = (unsigned)min(n0 + lrow + 32 * i, p.N - 1) * (unsigned)p.ldw;
@@ -305,12 +310,13 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         ra[i] = ldrow(pA, offA[i], kc, true);
-        if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(pA, offC[i], kc, true);
+        if (AMODE == SPGAN_A_EDGE || AMODE == A_AFFINE2) ra2[i] = ldrow(pA2, offC[i], kc, true);
       }
       if (AMODE != SPGAN_A_PLAIN) {
         psc = ldpar(pPsc, kc);
         psh = ldpar(pPsh, kc);
         if (AMODE == SPGAN_A_EDGE) peb = ldpar(p.e_bias, kc);
+        if (AMODE == A_AFFINE2) peb = ldpar(p.p_scale2, kc);
       }
       if (sp_reg) {
         const size_t off = (size_t)sp_b * p.K + kc;
@@ -324,16 +330,18 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (AMODE == SPGAN_A_EDGE) ra2[i] = ra[i];
+      if (AMODE == SPGAN_A_EDGE || AMODE == A_AFFINE2) ra2[i] = ra[i];
       if (kok) {
         ra[i] = ldrow(pA, offA[i], k, vecA);
         if (AMODE == SPGAN_A_EDGE) ra2[i] = ldrow(pA, offC[i], k, vecA);
+        if (AMODE == A_AFFINE2) ra2[i] = ldrow(pA2, offC[i], k, ((p.lda2 & 3) == 0) && ((reinterpret_cast<uintptr_t>(pA2) & 15) == 0));
       }
     }
     if (AMODE != SPGAN_A_PLAIN && kok) {
       psc = ldpar(pPsc, k);
       psh = ldpar(pPsh, k);
       if (AMODE == SPGAN_A_EDGE) peb = ldpar(p.e_bias, k);
+      if (AMODE == A_AFFINE2) peb = ldpar(p.p_scale2, k);
     }
 #pragma unroll
     for (int i = 0; i < BSLOT; ++i) rb[i] = kok ? ldrow(pW, offW[i], k, vecW) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -353,6 +361,12 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           v.z = (v.z - ra2[i].z) + peb.z;
           v.w = (v.w - ra2[i].w) + peb.w;
         }
+        if (AMODE == A_AFFINE2) {  // p*g + (q*y + r): the same expression as bn_bwd_coef_apply in tests/kernel_model.py
+          v.x = fmaf(v.x, psc.x, fmaf(ra2[i].x, peb.x, psh.x));
+          v.y = fmaf(v.y, psc.y, fmaf(ra2[i].y, peb.y, psh.y));
+          v.z = fmaf(v.z, psc.z, fmaf(ra2[i].z, peb.z, psh.z));
+          v.w = fmaf(v.w, psc.w, fmaf(ra2[i].w, peb.w, psh.w));
+        } else
         v = affine_lrelu4(v, psc, psh, p.p_slope);
         if (!FAST) v = mask_tail(v, k, p.K);
         ra[i] = v;
@@ -1085,10 +1099,11 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   if (AMODE != SPGAN_A_PLAIN) fast = fast && al16(a.p_scale) && al16(a.p_shift);
   if (AMODE == SPGAN_A_EDGE) fast = fast && al16(a.e_bias);
   if (AMODE == A_AFFINE_SPARSE) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
-  if constexpr (AMODE != SPGAN_A_EDGE && EPI != SPGAN_EPI_EDGE_BNBWD) {
+  if (AMODE == A_AFFINE2) fast = fast && al16(a.A2) && (a.lda2 % 4 == 0) && al16(a.p_scale2);
+  if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE2 && EPI != SPGAN_EPI_EDGE_BNBWD) {
     if (spgan_nt_wide_selected(a)) return spgan_launch_nt_wide(a, s);  // large aligned products: 256 x 256 tiles (gemm_wide.hip)
   }
-  if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE_SPARSE && EPI != SPGAN_EPI_EDGE_BNBWD) {
+  if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE_SPARSE && AMODE != A_AFFINE2 && EPI != SPGAN_EPI_EDGE_BNBWD) {
     if (a.M <= 64 && fast && !a.sp_val && a.batch <= 1 && !a.pool_val) {
       const bool whole = a.stats != nullptr || EPI == SPGAN_EPI_BNBWD;  // column statistics: one workgroup walks all rows of its columns
       hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(cdiv(a.N, SC), (whole || a.M <= SR) ? 1 : cdiv(a.M, SR)), dim3(256), 0, s, a);
@@ -1133,15 +1148,16 @@ struct ColPro {
 
 // grid: (tilesA * tilesB, splits).  Each workgroup reduces `rows_per_split` m-rows into one
 // TA x TB partial tile written to ws[split][Na][Nb].  CFG as in gemm_nt: TB = 128 / 64 / 32.
+constexpr int TKF = TKM;  // fp32 kernel: m-rows per staging step (16 measured slower: 90.8 -> 100.2 us on 65536 x 256 x 256 although three workgroups fit a CU)
 template <int BMODE, int CFG, int FAST>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p, int rows_per_split) {
   using G = Geo<CFG>;
   constexpr int TI = G::TI, TJ = G::TJ;
   constexpr int TB = G::WGN * TJ * 32;
   constexpr int LDA_ = TA, LDB_ = TB;  // fragment reads are 32 consecutive floats of one row: conflict-free as is
-  __shared__ __attribute__((aligned(16))) float smem[2 * TKM * (LDA_ + LDB_)];
-  float* As = smem;                   // [2][TKM*LDA_]
-  float* Bs = smem + 2 * TKM * LDA_;  // [2][TKM*LDB_]
+  __shared__ __attribute__((aligned(16))) float smem[2 * TKF * (LDA_ + LDB_)];
+  float* As = smem;                   // [2][TKF*LDA_]
+  float* Bs = smem + 2 * TKF * LDA_;  // [2][TKF*LDB_]
 
   const int tilesB = (p.Nb + TB - 1) / TB;
   const int ta = blockIdx.x / tilesB, tb = blockIdx.x % tilesB;
@@ -1164,9 +1180,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging: A tile TKM x 128 floats -> ASLOTS float4 per thread; B tile TKM x TB -> BSLOTS per thread
-  constexpr int ASLOTS = TKM * TA / 4 / 256;
-  constexpr int BSLOTS = (TKM * TB / 4 + 255) / 256;
+  // staging: A tile TKF x 128 floats -> ASLOTS float4 per thread; B tile TKF x TB -> BSLOTS per thread
+  constexpr int ASLOTS = TKF * TA / 4 / 256;
+  constexpr int BSLOTS = (TKF * TB / 4 + 255) / 256;
   float4 ra[ASLOTS], rb[BSLOTS];
   ColPro cp[BSLOTS];
 #pragma unroll
@@ -1182,14 +1198,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
   }
   // optional A-side prologue (per column of A; the column of a staging slot is fixed -> parameters hoisted)
   const bool apro = p.a_scale != nullptr;
-  float4 asc = make_float4(0.f, 0.f, 0.f, 0.f), ash = asc;  // slot i covers column (tid + 256 i) & 31: the same for every i
+  const bool a2 = p.A2 != nullptr;  // two-tensor A operand: a = A*a_scale + A2*a_scale2 + a_shift (host: with a_scale, without a_sp_val)
+  float4 asc = make_float4(0.f, 0.f, 0.f, 0.f), ash = asc, asc2 = asc;  // slot i covers column (tid + 256 i) & 31: the same for every i
   {
     const int col = a0 + (tid & 31) * 4;
     if (apro && col < p.Na) {
       asc = ld4(p.a_scale + col, false, col, p.Na);
       ash = ld4(p.a_shift + col, false, col, p.Na);
+      if (a2) asc2 = ld4(p.a_scale2 + col, false, col, p.Na);
     }
   }
+  float4 ra2[ASLOTS];
   // As in gemm_nt the staging registers keep RAW loads; the prologues run in sstore, after the MFMAs of the current tile.
   float4 rb2[BMODE == SPGAN_A_EDGE ? BSLOTS : 1];
   // FAST (16-byte aligned operands, Na/Nb/lda/ldb multiples of 4): straight-line float4 loads from clamped addresses --
@@ -1201,6 +1220,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
       const int m = mb + r, col = a0 + c;
       if (FAST) ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)min(m, p.M - 1) * p.lda + (col < p.Na ? col : 0));
       else ra[i] = (m < mend && col < p.Na) ? ld4(p.A + (size_t)m * p.lda + col, vecA, col, p.Na) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a2) {
+        if (FAST) ra2[i] = *reinterpret_cast<const float4*>(p.A2 + (size_t)min(m, p.M - 1) * p.lda2 + (col < p.Na ? col : 0));
+        else ra2[i] = (m < mend && col < p.Na) ? ld4(p.A2 + (size_t)m * p.lda2 + col, false, col, p.Na) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int i = 0; i < BSLOTS; ++i) {
@@ -1208,7 +1231,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
       const int r = s / (TB / 4), c = b0 + (s % (TB / 4)) * 4;
       const int m = mb + r;
       if (FAST) {
-        if (r < TKM) {
+        if (r < TKF) {
           const int mc = min(m, p.M - 1), cc = c < p.Nb ? c : 0;
           if (BMODE == SPGAN_A_EDGE) {
             rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)p.e_idx[mc] * p.ldb + cc);
@@ -1220,7 +1243,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
       } else {
         rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (BMODE == SPGAN_A_EDGE) rb2[i] = rb[i];
-        if (r < TKM && m < mend && c < p.Nb) {
+        if (r < TKF && m < mend && c < p.Nb) {
           if (BMODE == SPGAN_A_EDGE) {
             rb[i] = ld4(p.B + (size_t)p.e_idx[m] * p.ldb + c, vecB, c, p.Nb);
             rb2[i] = ld4(p.B + (size_t)fast_div(m, p.e_k) * p.ldb + c, vecB, c, p.Nb);
@@ -1232,14 +1255,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
     }
   };
   auto sstore = [&](int buf, int mb) {
-    float* a = As + buf * TKM * LDA_;
-    float* b = Bs + buf * TKM * LDB_;
+    float* a = As + buf * TKF * LDA_;
+    float* b = Bs + buf * TKF * LDB_;
 #pragma unroll
     for (int i = 0; i < ASLOTS; ++i) {
       const int s = tid + 256 * i, r = s >> 5, c = (s & 31) * 4;
       float4 v = ra[i];
       const bool ok = mb + r < mend && a0 + c < p.Na;
-      if (apro && ok) v = mask_tail(affine_lrelu4(v, asc, ash, 1.0f), a0 + c, p.Na);
+      if (a2 && ok) {
+        v.x = fmaf(v.x, asc.x, fmaf(ra2[i].x, asc2.x, ash.x));
+        v.y = fmaf(v.y, asc.y, fmaf(ra2[i].y, asc2.y, ash.y));
+        v.z = fmaf(v.z, asc.z, fmaf(ra2[i].z, asc2.z, ash.z));
+        v.w = fmaf(v.w, asc.w, fmaf(ra2[i].w, asc2.w, ash.w));
+        v = mask_tail(v, a0 + c, p.Na);
+      } else if (apro && ok) v = mask_tail(affine_lrelu4(v, asc, ash, 1.0f), a0 + c, p.Na);
       if (FAST && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(&a[r * LDA_ + c]) = v;
     }
@@ -1247,7 +1276,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
     for (int i = 0; i < BSLOTS; ++i) {
       const int s = tid + 256 * i;
       const int r = s / (TB / 4), c = (s % (TB / 4)) * 4;
-      if (r < TKM) {
+      if (r < TKF) {
         float4 v = rb[i];
         const bool ok = mb + r < mend && b0 + c < p.Nb;
         if (FAST && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1270,13 +1299,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
     sstore(0, mbeg);
     __syncthreads();
     int buf = 0;
-    for (int mb = mbeg; mb < mend; mb += TKM, buf ^= 1) {
-      const bool more = mb + TKM < mend;
-      if (more) gload(mb + TKM);
-      const float* a = As + buf * TKM * LDA_ + wm * TI * 32 + l31;
-      const float* b = Bs + buf * TKM * LDB_ + wn * TJ * 32 + l31;
+    for (int mb = mbeg; mb < mend; mb += TKF, buf ^= 1) {
+      const bool more = mb + TKF < mend;
+      if (more) gload(mb + TKF);
+      const float* a = As + buf * TKF * LDA_ + wm * TI * 32 + l31;
+      const float* b = Bs + buf * TKF * LDB_ + wn * TJ * 32 + l31;
 #pragma unroll
-      for (int kq = 0; kq < TKM / 2; ++kq) {  // MFMA k = 2 m-rows: lane half lh takes row 2*kq + lh
+      for (int kq = 0; kq < TKF / 2; ++kq) {  // MFMA k = 2 m-rows: lane half lh takes row 2*kq + lh
         float af[TI], bf[TJ];
 #pragma unroll
         for (int i = 0; i < TI; ++i) af[i] = a[(kq * 2 + lh) * LDA_ + i * 32];
@@ -1287,7 +1316,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
 #pragma unroll
           for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
-      if (more) sstore(buf ^ 1, mb + TKM);
+      if (more) sstore(buf ^ 1, mb + TKF);
       __syncthreads();
     }
   }
@@ -1369,14 +1398,21 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
     if (BMODE == SPGAN_A_EDGE) cp.eb = *reinterpret_cast<const float4*>(p.e_bias + b0 + bc);
   }
   const bool apro = p.a_scale != nullptr;
-  float4 asc = make_float4(0.f, 0.f, 0.f, 0.f), ash = asc;
+  const bool a2 = p.A2 != nullptr;
+  float4 asc = make_float4(0.f, 0.f, 0.f, 0.f), ash = asc, asc2 = asc;
   if (apro && aok) {
     asc = *reinterpret_cast<const float4*>(p.a_scale + a0 + ac);
     ash = *reinterpret_cast<const float4*>(p.a_shift + a0 + ac);
+    if (a2) asc2 = *reinterpret_cast<const float4*>(p.a_scale2 + a0 + ac);
   }
+  float4 ra2[4];
   auto gload = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)min(mb + ar + i, p.M - 1) * p.lda + (aok ? a0 + ac : 0));
+    if (a2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra2[i] = *reinterpret_cast<const float4*>(p.A2 + (size_t)min(mb + ar + i, p.M - 1) * p.lda2 + (aok ? a0 + ac : 0));
+    }
 #pragma unroll
     for (int i = 0; i < RP; ++i) {
       const int mc = min(mb + br + i, p.M - 1), cc = bok ? b0 + bc : 0;
@@ -1396,7 +1432,12 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
     for (int i = 0; i < 4; ++i) {
       float4 v = ra[i];
       const bool ok = mb + ar + i < mend && aok;
-      if (apro && ok) v = affine_lrelu4(v, asc, ash, 1.0f);
+      if (a2 && ok) {
+        v.x = fmaf(v.x, asc.x, fmaf(ra2[i].x, asc2.x, ash.x));
+        v.y = fmaf(v.y, asc.y, fmaf(ra2[i].y, asc2.y, ash.y));
+        v.z = fmaf(v.z, asc.z, fmaf(ra2[i].z, asc2.z, ash.z));
+        v.w = fmaf(v.w, asc.w, fmaf(ra2[i].w, asc2.w, ash.w));
+      } else if (apro && ok) v = affine_lrelu4(v, asc, ash, 1.0f);
       if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
       va[i][0] = v.x; va[i][1] = v.y; va[i][2] = v.z; va[i][3] = v.w;
     }
@@ -1772,7 +1813,8 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
   }
   const int TB = tn_tb(a.Nb);
   const dim3 grid(cdiv(a.Na, TA) * cdiv(a.Nb, TB), splits);
-  const bool fast = (a.Na % 4 == 0) && (a.Nb % 4 == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && al16(a.A) && al16(a.B);
+  const bool fast = (a.Na % 4 == 0) && (a.Nb % 4 == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && al16(a.A) && al16(a.B) &&
+                    (!a.A2 || (al16(a.A2) && a.lda2 % 4 == 0));
   if (fast && a.mfma_lp == 1) {  // bf16 operands (aligned problems only; others keep the fp32 kernel)
     if (TB == 128) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 0>), grid, dim3(256), 0, s, a, rows);
     else if (TB == 64) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 1>), grid, dim3(256), 0, s, a, rows);
@@ -1812,7 +1854,7 @@ extern "C" int spgan_gemm_nt_col_blocks(const spgan_gemm_nt_args* a) {
 
 extern "C" int spgan_gemm_nt_owns_columns(const spgan_gemm_nt_args* a) {
   // mirrors launch_nt: the M <= 64 kernel (one workgroup walks all rows of its columns) takes aligned, unbatched problems
-  if (!a || a->M <= 0 || a->M > 64 || a->sp_val || a->batch > 1 || a->pool_val) return 0;
+  if (!a || a->M <= 0 || a->M > 64 || a->sp_val || a->batch > 1 || a->pool_val || a->A2) return 0;
   if (a->a_mode == SPGAN_A_EDGE || a->epi_mode == SPGAN_EPI_EDGE_BNBWD) return 0;
   bool fast = (a->K % 4 == 0) && (a->lda % 4 == 0) && (a->ldw % 4 == 0) && al16(a->A) && al16(a->W);
   if (a->a_mode != SPGAN_A_PLAIN) fast = fast && al16(a->p_scale) && al16(a->p_shift);
@@ -1832,6 +1874,9 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   if (a->a_mode == SPGAN_A_EDGE) SPGAN_CHECK_ARG(a->e_idx && a->e_bias && a->e_k > 0);
   if (a->rowbias) SPGAN_CHECK_ARG(a->rows_per_group > 0 && a->ld_rowbias >= a->N);
   if (a->sp_val) SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_AFFINE_LRELU && a->sp_arg && a->sp_rows > 0);
+  if (a->A2)  // two-tensor operand a = A*p_scale + A2*p_scale2 + p_shift (no activation, no sparse addend, one vector set for all rows)
+    SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_AFFINE_LRELU && !a->sp_val && a->p_scale2 && a->lda2 >= a->K && a->p_group_rows == 0 && a->batch <= 1 &&
+                    a->M > 64 && (uint64_t)a->M * (uint64_t)a->lda2 < (1ull << 32) && a->epi_mode != SPGAN_EPI_MASK_OUT);
   if (a->batch > 1)
     SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->epi_mode == SPGAN_EPI_LINEAR && a->Y && !a->stats && !a->rowbias && !a->pool_val &&
                     a->batch <= 65535 && a->batch_stride_a >= 0 && a->batch_stride_w >= 0 && a->batch_stride_y > 0);
@@ -1845,6 +1890,7 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   switch (a->epi_mode) {
     case SPGAN_EPI_LINEAR:
       if (a->a_mode == SPGAN_A_PLAIN) return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_LINEAR>(*a, s);
+      if (a->A2) return launch_nt<A_AFFINE2, SPGAN_EPI_LINEAR>(*a, s);
       if (a->a_mode == SPGAN_A_AFFINE_LRELU)
         return a->sp_val ? launch_nt<A_AFFINE_SPARSE, SPGAN_EPI_LINEAR>(*a, s) : launch_nt<SPGAN_A_AFFINE_LRELU, SPGAN_EPI_LINEAR>(*a, s);
       if (a->a_mode == SPGAN_A_EDGE) return launch_nt<SPGAN_A_EDGE, SPGAN_EPI_LINEAR>(*a, s);
@@ -1854,12 +1900,14 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
       return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_MASK_OUT>(*a, s);
     case SPGAN_EPI_BNBWD:
       SPGAN_CHECK_ARG(a->a_mode != SPGAN_A_EDGE && a->ref && a->ld_ref >= a->N && a->b_scale && a->b_shift && a->b_mean && a->b_invstd);
+      if (a->A2) return launch_nt<A_AFFINE2, SPGAN_EPI_BNBWD>(*a, s);
       if (a->a_mode == SPGAN_A_AFFINE_LRELU)
         return a->sp_val ? launch_nt<A_AFFINE_SPARSE, SPGAN_EPI_BNBWD>(*a, s) : launch_nt<SPGAN_A_AFFINE_LRELU, SPGAN_EPI_BNBWD>(*a, s);
       return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_BNBWD>(*a, s);
     case SPGAN_EPI_EDGE_BNBWD:
-      SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->ref && a->ld_ref >= a->N && a->b_scale && a->b_shift && a->b_mean && a->b_invstd &&
+      SPGAN_CHECK_ARG((a->a_mode == SPGAN_A_PLAIN || a->A2) && a->ref && a->ld_ref >= a->N && a->b_scale && a->b_shift && a->b_mean && a->b_invstd &&
                       a->e_idx && a->e_k > 0 && a->e_bias2);
+      if (a->A2) return launch_nt<A_AFFINE2, SPGAN_EPI_EDGE_BNBWD>(*a, s);
       return launch_nt<SPGAN_A_PLAIN, SPGAN_EPI_EDGE_BNBWD>(*a, s);
     default:
       return SPGAN_EINVAL;
@@ -1928,6 +1976,7 @@ extern "C" int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a->ws_bytes >= spgan_gemm_tn_ws_bytes(a->M, a->Na, a->Nb));
   if (a->b_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
   if (a->a_scale) SPGAN_CHECK_ARG(a->a_shift && (!a->a_sp_val || (a->a_sp_arg && a->a_sp_rows > 0 && a->b_mode != SPGAN_A_EDGE)));
+  if (a->A2) SPGAN_CHECK_ARG(a->a_scale && a->a_scale2 && !a->a_sp_val && a->lda2 >= a->Na);
   SPGAN_CHECK_ARG(a->M < (1 << 24));  // fast_div domain
   switch (a->b_mode) {
     case SPGAN_A_PLAIN: return launch_tn<SPGAN_A_PLAIN>(*a, s);

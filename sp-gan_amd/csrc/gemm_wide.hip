@@ -380,7 +380,7 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 bool spgan_nt_wide_eligible(const spgan_gemm_nt_args& a) {
   if (a.M < WM || a.M % WM || a.N % WN || a.K % WK || a.K < WK) return false;
-  if ((a.mfma_f16 != 0 && a.mfma_f16 != 1) || a.tail.enabled || a.batch > 1) return false;  // fp32 or fp16 operands (not the split-bf16 mode)
+  if ((a.mfma_f16 != 0 && a.mfma_f16 != 1) || a.tail.enabled || a.batch > 1 || a.A2) return false;  // fp32 or fp16 operands (not the split-bf16 mode)
   if (a.mfma_f16 == 1 && a.sp_val) return false;                                              // the sparse addend is an fp32-operand path (gemm.hip: same rule)
   if (a.a_mode == SPGAN_A_EDGE || a.epi_mode == SPGAN_EPI_EDGE_BNBWD) return false;
   if (a.lda % 4 || a.ldw % 4 || !al16(a.A) || !al16(a.W)) return false;

@@ -641,3 +641,27 @@ extern "C" int spgan_maxpool(const float* y, int ld, int B, int N, int C, const 
   else hipLaunchKernelGGL(maxpool_kernel, dim3(B, cdiv(C, 64)), dim3(256), 0, s, y, ld, N, C, scale, shift, slope, out, argmax);
   return spgan_launch_status();
 }
+
+// BatchNorm backward as an affine combination of two tensors: dy = p*g + q*y + r (spgan_hip.h: spgan_bn_bwd_coeffs).  One thread per
+// channel; the consumers (spgan_gemm_nt_args.A2 / spgan_gemm_tn_args.A2) evaluate the combination on their operand loads.
+namespace {
+__global__ void bn_bwd_coeffs_kernel(const float* __restrict__ sums, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     const float* __restrict__ gamma, int C, float rcount, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float inv = invstd[c];
+  const float p = (gamma ? gamma[c] : 1.f) * inv;
+  const float q = -(p * inv) * (sums[C + c] * rcount);
+  const float r = -(p * (sums[c] * rcount)) - q * mean[c];
+  coef[c] = p;
+  coef[C + c] = q;
+  coef[2 * C + c] = r;
+}
+}  // namespace
+
+extern "C" int spgan_bn_bwd_coeffs(const float* sums, const float* mean, const float* invstd, const float* gamma, int C, float count, float* coef,
+                                   spgan_stream_t s) {
+  SPGAN_CHECK_ARG(sums && mean && invstd && coef && C > 0 && count > 0.f);
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)s, sums, mean, invstd, gamma, C, 1.0f / count, coef);
+  return spgan_launch_status();
+}

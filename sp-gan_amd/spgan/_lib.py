@@ -48,6 +48,7 @@ class GemmNTArgs(C.Structure):
         ("tail", ColTail),
         ("tile_hint", C.c_int),
         ("p_group_rows", C.c_int),
+        ("A2", c_f32p), ("lda2", C.c_int), ("p_scale2", c_f32p),
     ]
 
 
@@ -65,6 +66,7 @@ class GemmTNArgs(C.Structure):
         ("a_scale", c_f32p), ("a_shift", c_f32p), ("a_sp_val", c_f32p), ("a_sp_arg", c_i32p), ("a_sp_rows", C.c_int),
         ("defer_reduce", C.c_int),
         ("mfma_lp", C.c_int),
+        ("A2", c_f32p), ("lda2", C.c_int), ("a_scale2", c_f32p),
     ]
 
 
@@ -178,6 +180,7 @@ SIGNATURES = {
     "spgan_scale_residual_bwd": (I, [P, P, P, P, P, P, SZ, SZ, P]),
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
     "spgan_reduce_chunks": (I, [P, I, C.c_size_t, P, P]),
+    "spgan_bn_bwd_coeffs": (I, [P, P, P, P, I, F, P, P]),
     "spgan_comm_available": (I, []),
     "spgan_comm_last_error": (I, []),
     "spgan_comm_unique_id": (I, [P]),

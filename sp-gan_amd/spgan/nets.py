@@ -10,6 +10,8 @@ formulas in the WGAN-GP double backward.
 """
 from __future__ import annotations
 
+import os
+
 import weakref
 from typing import Dict, List, Optional, Tuple
 
@@ -103,6 +105,23 @@ def _refresh_transposes(trigger: Tensor) -> None:
     if srcs:
         for (key, cur, oref, view), t in zip(todo, ops.multi_transpose(srcs)):
             _T_CACHE[key] = (cur, t, oref, view)
+
+
+LAZY_BN_BWD = [os.environ.get("SPGAN_LAZY_BN_BWD", "1") != "0"]     # 0: materialise every BatchNorm-backward tensor (A/B measurements)
+
+
+def _bn_bwd(g: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma, sums: Tensor, count: int, lazy: bool = True):
+    """The BatchNorm backward dy = gamma*invstd*(g - S0/count - xhat*S1/count) of a layer whose dy is consumed by GEMMs only: as a lazy
+    two-tensor operand (ops.Affine2: the weight-gradient and input-gradient products evaluate p*g + q*y + r on their operand loads; one
+    C-sized launch instead of a pass that reads g and y and writes dy), or materialised (ops.bn_bwd_apply) for the few consumers without
+    that operand mode."""
+    if lazy and LAZY_BN_BWD[0] and g.shape[0] > 64 and g.shape[1] % 4 == 0:
+        return ops.bn_bwd_lazy(g, y, mean, invstd, gamma, sums, count)
+    return ops.bn_bwd_apply(g, y, mean, invstd, gamma, sums, count)
+
+
+def _dense(t):
+    return t.dense() if isinstance(t, ops.Affine2) else t
 
 
 _CONST_VEC: Dict[Tuple[int, float, str], Tensor] = {}
@@ -420,7 +439,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             if need_dparams:
                 grads[D_LAYERS[2][1] + ".weight"] = s1; grads[D_LAYERS[2][1] + ".bias"] = s0
             sums = _cat2(s0, s1)
-            dy = ops.bn_bwd_apply(g, ys[2], mu, inv, P[D_LAYERS[2][1] + ".weight"], sums, M)
+            dy = _bn_bwd(g, ys[2], mu, inv, P[D_LAYERS[2][1] + ".weight"], sums, M)
             dys[2] = dy; gs[2] = g; sums_all[2] = sums
             continue
         if need_dparams:
@@ -430,7 +449,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
                 grads[conv + ".weight"] = ops.gemm_tn(dy, ctx["x_pm"], defer=True).view_as(P[conv + ".weight"])
             grads[conv + ".bias"] = ZERO_GRAD     # bias before a train-mode BN: exactly zero gradient
             if not ctx["training"]:
-                grads[conv + ".bias"] = ops.colsum(dy)[0]
+                grads[conv + ".bias"] = ops.colsum(_dense(dy))[0]
         if li > 0:
             pconv, pbn = D_LAYERS[li - 1]
             sc, sh, inv, mu = bns[li - 1]
@@ -438,7 +457,9 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             if need_dparams:
                 grads[pbn + ".weight"] = s1; grads[pbn + ".bias"] = s0
             sums = _cat2(s0, s1) if ctx["training"] else torch.zeros(2 * s0.numel(), device=s0.device)
-            dy = ops.bn_bwd_apply(g, ys[li - 1], mu, inv, P[pbn + ".weight"], sums, M)
+            # layer 1's dy (64 channels) feeds a 3-column weight gradient and the 3-column input gradient: kernels without the
+            # two-tensor operand -> materialised; the 128- and 256-channel ones stay lazy
+            dy = _bn_bwd(g, ys[li - 1], mu, inv, P[pbn + ".weight"], sums, M, lazy=li - 1 > 0)
             dys[li - 1] = dy; gs[li - 1] = g; sums_all[li - 1] = sums
     dx_cm = None
     if need_dx:
@@ -697,10 +718,10 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     if not ctx["training"]:
         sums2 = torch.zeros_like(sums2); sumsy = torch.zeros_like(sumsy)
     # conv_w.4 BN backward -> conv_w.3
-    dh2 = ops.bn_bwd_apply(g2, ctx["h2pre"], bn2[3], bn2[2], P[pre + ".conv_w.4.weight"], sums2, E)
+    dh2 = _bn_bwd(g2, ctx["h2pre"], bn2[3], bn2[2], P[pre + ".conv_w.4.weight"], sums2, E)     # lazy: consumed by the two edge GEMMs below
     W2 = _w2(P[pre + ".conv_w.3.weight"])
     g[pre + ".conv_w.3.weight"] = ops.gemm_tn(dh2, PQR[:, :H], pro=(bn1[0], bn1[1], NEG), edge=(idx, b1), defer=True).view_as(P[pre + ".conv_w.3.weight"])
-    g[pre + ".conv_w.3.bias"] = ZERO_GRAD if ctx["training"] else ops.colsum(dh2)[0]
+    g[pre + ".conv_w.3.bias"] = ZERO_GRAD if ctx["training"] else ops.colsum(_dense(dh2))[0]
     g1, s10, s11 = ops.gemm_nt_bnbwd(dh2, _t(W2), PQR[:, :H], bn1[0], bn1[1], bn1[3], bn1[2], NEG, edge=(idx, b1))
     g[pre + ".conv_w.1.weight"] = s11; g[pre + ".conv_w.1.bias"] = s10
     sums1 = _cat2(s10, s11) if ctx["training"] else torch.zeros(2 * H, device=x.device)

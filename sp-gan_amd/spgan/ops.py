@@ -429,6 +429,36 @@ class SparseAffine:
         self.device = sp_val.device
 
 
+class Affine2:
+    """A lazily evaluated [M,C] operand  g*p[c] + y*q[c] + r[c]: the BatchNorm backward dy = gamma*invstd*(g - S0/count - xhat*S1/count)
+    written as an affine combination of the incoming gradient g and the layer's pre-BatchNorm output y (spgan_bn_bwd_coeffs).  The
+    weight-gradient and input-gradient GEMMs that consume dy evaluate it on their operand loads (spgan_gemm_tn_args.A2 /
+    spgan_gemm_nt_args.A2) -- the [M,C] tensor is never written or read back."""
+
+    def __init__(self, g: Tensor, y: Tensor, coef: Tensor):
+        if g.shape != y.shape or coef.shape != (3, g.shape[1]):
+            raise ValueError("Affine2: g and y must have equal shapes, coef [3,C]")
+        self.g, self.y, self.coef = g, y, coef
+        self.p, self.q, self.r = coef[0], coef[1], coef[2]
+        self.shape, self.device = g.shape, g.device
+
+    def dense(self) -> Tensor:
+        """The materialised tensor (for a consumer without the two-tensor operand): p*g + (q*y + r), the kernels' expression."""
+        return torch.addcmul(torch.addcmul(self.r, self.y, self.q), self.g, self.p)
+
+
+def bn_bwd_lazy(g: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Optional[Tensor], sums: Tensor, count: int) -> Affine2:
+    """bn_bwd_apply as a lazy operand: one C-sized launch for the coefficients instead of a pass over [M,C]."""
+    _f32(g, "g", 2); _f32(y, "y", 2)
+    if not (g.is_contiguous() and y.is_contiguous()) or g.shape != y.shape:
+        raise ValueError("g and y must be contiguous with equal shapes")
+    Cn = g.shape[1]
+    coef = torch.empty((3, Cn), dtype=torch.float32, device=g.device)
+    check(_lib.load().spgan_bn_bwd_coeffs(_p(_vec(sums, 2 * Cn, "sums")), _p(_vec(mean, Cn, "mean")), _p(_vec(invstd, Cn, "invstd")),
+                                          _p(None if gamma is None else _vec(gamma, Cn, "gamma")), Cn, float(count), _p(coef), _s()), "bn_bwd_coeffs", C=Cn)
+    return Affine2(g, y, coef)
+
+
 def sparse_bn_bwd_operand(gval: Tensor, argmax: Tensor, y: Tensor, N: int, mean, invstd, gamma, sums, count: int) -> SparseAffine:
     """The same quantity bn_bwd_apply_sparse materialises, as a lazy operand (O(C) + O(B*C) preparation only)."""
     B, Cn = gval.shape
@@ -466,8 +496,14 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
     With edge=(idx, ebias) y is the per-edge difference y[e] = P[idx[e]] - P[i] + ebias of the point tensor P=y_ref.
     A may be a SparseAffine operand; pro=(scale[K], shift[K], slope) as in gemm_nt; rowadd is a dense [M,N] addend."""
     sa = A if isinstance(A, SparseAffine) else None
+    a2 = A if isinstance(A, Affine2) else None
     if sa is not None:
         A = sa.y
+    if a2 is not None:
+        if A.shape[0] <= 64 or pro is not None:
+            a2, A = None, A.dense()              # the two-tensor operand is a path of the 128-row kernels
+        else:
+            A = a2.g
     _rowmajor2d(A, "A"); _rowmajor2d(W, "W"); _rowmajor2d(y_ref, "y_ref")
     N, K = W.shape
     M_ = A.shape[0]
@@ -482,6 +518,10 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
         a.a_mode = A_AFFINE_LRELU
         a.p_scale = _p(_vec(sa.alpha, K, "alpha")); a.p_shift = _p(_vec(sa.beta, K, "beta")); a.p_slope = 1.0
         a.sp_val = _p(sa.sp_val); a.sp_arg = _p(_i32(sa.sp_arg, "sp_arg")); a.sp_rows = sa.rows
+    elif a2 is not None:
+        a.a_mode = A_AFFINE_LRELU
+        a.p_scale = _p(_vec(a2.p, K, "p")); a.p_shift = _p(_vec(a2.r, K, "r")); a.p_slope = 1.0
+        a.A2 = _p(a2.y); a.lda2 = _ld(a2.y); a.p_scale2 = _p(_vec(a2.q, K, "q"))
     elif pro is not None:
         a.a_mode = A_AFFINE_LRELU
         a.p_scale = _p(_vec(pro[0], K, "pro.scale")); a.p_shift = _p(_vec(pro[1], K, "pro.shift")); a.p_slope = float(pro[2])
@@ -554,12 +594,18 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     defer=True: the returned tensor is NOT valid until flush_tn() ran -- the split-K partial sums of all the weight gradients of a
     backward pass are then finished by one launch (functions._deliver flushes before it hands gradients on)."""
     sa = A if isinstance(A, SparseAffine) else None
+    a2 = A if isinstance(A, Affine2) else None
     if sa is not None:
         A = sa.y
+    if a2 is not None:
+        A = a2.g
     _rowmajor2d(A, "A"); _rowmajor2d(Bm, "B")
     M_, Na = A.shape
     Nb = Bm.shape[1]
     a = GemmTNArgs()
+    if a2 is not None:
+        a.a_scale = _p(_vec(a2.p, Na, "p")); a.a_shift = _p(_vec(a2.r, Na, "r"))
+        a.A2 = _p(a2.y); a.lda2 = _ld(a2.y); a.a_scale2 = _p(_vec(a2.q, Na, "q"))
     if sa is not None:
         a.a_scale = _p(_vec(sa.alpha, Na, "alpha")); a.a_shift = _p(_vec(sa.beta, Na, "beta"))
         a.a_sp_val = _p(sa.sp_val); a.a_sp_arg = _p(_i32(sa.sp_arg, "sp_arg")); a.a_sp_rows = sa.rows

@@ -127,4 +127,5 @@ def install_kernel_models():
         if not name.startswith("_"):
             setattr(ops, name, fn)
     ops.SparseAffine = km.SparseAffine
+    ops.Affine2 = km.Affine2
     modules._require_gpu = lambda t, what: None

@@ -163,7 +163,27 @@ def bn_dbl_phaseb(coeffs, gamma, invstd, s0, s1):
     return torch.cat([coeffs[2] + gamma * a0, coeffs[3] + gamma * a1 + invstd * coeffs[1]]), coeffs[0] + a1
 
 
+class Affine2:
+    def __init__(self, g, y, coef):
+        self.g, self.y, self.coef = g, y, coef
+        self.p, self.q, self.r = coef[0], coef[1], coef[2]
+        self.shape, self.device = g.shape, g.device
+
+    def dense(self):
+        return self.g * self.p + (self.y * self.q + self.r)
+
+
+def bn_bwd_lazy(g, y, mean, invstd, gamma, sums, count):
+    C = g.shape[1]
+    p = (gamma if gamma is not None else torch.ones_like(invstd)) * invstd
+    q = -(p * invstd) * (sums[C:] / count)
+    r = -(p * (sums[:C] / count)) - q * mean
+    return Affine2(g, y, torch.stack([p, q, r]))
+
+
 def _dense(A):
+    if isinstance(A, Affine2):
+        return A.dense()
     if isinstance(A, SparseAffine):
         return A.y * A.alpha + A.beta + scatter_rows(A.sp_val, A.sp_arg, A.y.shape[0])
     return A

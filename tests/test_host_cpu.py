@@ -34,6 +34,7 @@ def spgan_cpu(monkeypatch):
         assert hasattr(ops, name), "kernel_model.%s has no counterpart in spgan.ops" % name
         monkeypatch.setattr(ops, name, fn)
     monkeypatch.setattr(ops, "SparseAffine", km.SparseAffine)          # isinstance checks in nets.py select the collapsed paths
+    monkeypatch.setattr(ops, "Affine2", km.Affine2)
     monkeypatch.setattr(modules, "_require_gpu", lambda t, what: None)
     return types.SimpleNamespace(ops=ops, modules=modules)
 

@@ -371,3 +371,60 @@ def test_gemm_bn_groups(ops, groups, Mg, N, K, hint):
             for q in range(4):
                 assert torch.equal(out[q, g], st1[q]), (g, q)
         assert torch.equal(rm, rm2) and torch.equal(rv, rv2)
+
+
+@pytest.mark.parametrize("M,C,Nout", [(2048, 256, 128), (1024, 128, 64), (700, 132, 40), (4096, 64, 256)])
+def test_bn_bwd_lazy_operand(ops, M, C, Nout):
+    """ops.bn_bwd_lazy: the BatchNorm-backward tensor dy = p*g + q*y + r evaluated on the operand loads of its consumers
+    (spgan_gemm_tn_args.A2: weight gradient, plain / affine / per-edge B side; spgan_gemm_nt_args.A2: input gradient with the
+    BNBWD and EDGE_BNBWD epilogues, and plain) against the materialised bn_bwd_apply."""
+    g, y = rnd("lz.g%d.%d" % (M, C), (M, C)), rnd("lz.y%d.%d" % (M, C), (M, C), 2.0) + 0.3
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    inv = 1.0 / torch.sqrt(var + 1e-5)
+    gamma = rnd("lz.ga%d" % C, (C,)).abs() + 0.5
+    xh = (y - mean) * inv
+    sums = torch.cat([g.sum(0), (g * xh).sum(0)])
+    dense = ops.bn_bwd_apply(g, y, mean, inv, gamma, sums, M)
+    lazy = ops.bn_bwd_lazy(g, y, mean, inv, gamma, sums, M)
+    close(lazy.dense(), dense, rtol=2e-6, atol=1e-6, what="coefficients")
+    close(lazy.dense(), km.bn_bwd_lazy(g, y, mean, inv, gamma, sums, M).dense(), rtol=1e-6, atol=1e-6, what="vs model")
+    # weight gradient: A side lazy
+    prev = rnd("lz.prev%d.%d" % (M, Nout), (M, Nout))
+    sc, sh = rnd("lz.sc%d" % Nout, (Nout,)).abs() + 0.5, rnd("lz.sh%d" % Nout, (Nout,), 0.3)
+    for pro in (None, (sc, sh, 0.01)):
+        close(ops.gemm_tn(lazy, prev, pro=pro), ops.gemm_tn(dense, prev, pro=pro), rtol=5e-6, atol=1e-5, what="gemm_tn A2")
+    out = rnd("lz.out%d.%d" % (C, Nout), (C, Nout))
+    close(ops.gemm_tn(lazy, prev, out=out.clone(), beta=1.0), ops.gemm_tn(dense, prev, out=out.clone(), beta=1.0), rtol=5e-6, atol=1e-5, what="gemm_tn A2 beta")
+    # input gradient through the previous layer's BatchNorm-backward epilogue
+    W = rnd("lz.W%d.%d" % (Nout, C), (Nout, C), 0.1)
+    bsc, bsh, mu2, inv2 = rnd("lz.bsc%d" % Nout, (Nout,)), rnd("lz.bsh%d" % Nout, (Nout,), 0.3), rnd("lz.mu%d" % Nout, (Nout,), 0.2), rnd("lz.inv%d" % Nout, (Nout,)).abs() + 0.5
+    for a_, b_ in zip(ops.gemm_nt_bnbwd(lazy, W, prev, bsc, bsh, mu2, inv2, 0.01), ops.gemm_nt_bnbwd(dense, W, prev, bsc, bsh, mu2, inv2, 0.01)):
+        close(a_, b_, rtol=5e-6, atol=2e-5, what="gemm_nt_bnbwd A2")
+
+
+def test_bn_bwd_lazy_operand_edge_consumers(ops):
+    """The EdgeBlock's two consumers of the per-edge BatchNorm backward (conv_w.4 -> conv_w.3): weight gradient with the per-edge B
+    operand, input gradient with the EDGE_BNBWD epilogue."""
+    B, N, k, H, F_ = 2, 256, 10, 64, 128
+    M = B * N
+    E = M * k
+    g, y = rnd("lze.g", (E, F_)), rnd("lze.y", (E, F_), 1.5)
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    inv = 1.0 / torch.sqrt(var + 1e-5)
+    gamma = rnd("lze.ga", (F_,)).abs() + 0.5
+    sums = torch.cat([g.sum(0), (g * ((y - mean) * inv)).sum(0)])
+    dense = ops.bn_bwd_apply(g, y, mean, inv, gamma, sums, E)
+    lazy = ops.bn_bwd_lazy(g, y, mean, inv, gamma, sums, E)
+    Pm = rnd("lze.P", (M, H + 2 * F_))
+    x = rnd("lze.x", (M, 16), 0.5)
+    idx = ops.knn(x, B, N, k, 0)
+    b1 = rnd("lze.b1", (H,), 0.1)
+    sc, sh = rnd("lze.sc", (H,)).abs() + 0.5, rnd("lze.sh", (H,), 0.3)
+    a = ops.gemm_tn(lazy, Pm[:, :H], pro=(sc, sh, 0.01), edge=(idx, b1))
+    b = ops.gemm_tn(dense, Pm[:, :H], pro=(sc, sh, 0.01), edge=(idx, b1))
+    close(a, b, rtol=5e-6, atol=2e-5, what="edge gemm_tn A2")
+    W2t = rnd("lze.W", (H, F_), 0.1)
+    mu1, inv1 = rnd("lze.mu1", (H,), 0.2), rnd("lze.inv1", (H,)).abs() + 0.5
+    for a_, b_ in zip(ops.gemm_nt_bnbwd(lazy, W2t, Pm[:, :H], sc, sh, mu1, inv1, 0.01, edge=(idx, b1)),
+                      ops.gemm_nt_bnbwd(dense, W2t, Pm[:, :H], sc, sh, mu1, inv1, 0.01, edge=(idx, b1))):
+        close(a_, b_, rtol=5e-6, atol=2e-5, what="edge gemm_nt_bnbwd A2")
