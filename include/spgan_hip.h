@@ -215,6 +215,10 @@ typedef struct spgan_gemm_tn_args {
  * backward): dy = gamma*invstd*(g - S0/count - xhat*S1/count), xhat = (y - mean)*invstd  ==  p*g + q*y + r  with
  *   p = gamma*invstd,  q = -p*invstd*S1/count,  r = -p*S0/count - q*mean        (gamma == NULL: 1)
  * sums = [S0 | S1] (2C); coef [3, C] = [p | q | r].  Consumers: spgan_gemm_nt_args.A2 / spgan_gemm_tn_args.A2. */
+/* spgan_colstats_finalize (mode 1: plain sums, one group) that ALSO emits those coefficient vectors from the sums it just merged:
+ * the finalize launch behind a BNBWD-epilogue GEMM hands the lazy operand to the next products without a launch of its own. */
+int spgan_colstats_finalize_bnbwd(const float* partials, int tiles, int C, int G, int tile_rows, const float* mean, const float* invstd,
+                                  const float* gamma, float count, float* s0, float* s1, float* coef, spgan_stream_t s);
 int spgan_bn_bwd_coeffs(const float* sums, const float* mean, const float* invstd, const float* gamma, int C, float count, float* coef, spgan_stream_t s);
 
 size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb);

@@ -94,6 +94,9 @@ struct BnTail {
   // seq_groups > 1 (grid.y == 1): the workgroup walks seq_groups row groups one after the other -- the same BatchNorm layer applied to
   // several passes: outputs of group g at offset g * group_stride, running statistics updated in group order by the same thread.
   int seq_groups; size_t group_stride;
+  // mode 1 (plain sums S0 = out0, S1 = out1): also emit the BatchNorm-backward coefficient vectors coef[3,C] = [p | q | r] of
+  // dy = p*g + q*y + r (spgan_bn_bwd_coeffs) -- the finalize of a BNBWD-epilogue GEMM hands the lazy operand to its consumers
+  float* bwd_coef; const float* bwd_mean; const float* bwd_invstd; const float* bwd_gamma; float bwd_rcount;
 };
 
 template <int FS, int FC>
@@ -166,6 +169,15 @@ __global__ __launch_bounds__(256) void colfinalize_t_kernel(const float* __restr
     const float var = (mode == 0) ? b / (float)G : b;
     if (out0) out0[(size_t)g * C + c] = a;
     if (out1) out1[(size_t)g * C + c] = var;
+    if (bn.bwd_coef) {  // single group, mode 1: the arithmetic of bn_bwd_coeffs_kernel
+      const float inv = bn.bwd_invstd[c];
+      const float pc = (bn.bwd_gamma ? bn.bwd_gamma[c] : 1.f) * inv;
+      const float qc = -(pc * inv) * (b * bn.bwd_rcount);
+      const float rc = -(pc * (a * bn.bwd_rcount)) - qc * bn.bwd_mean[c];
+      bn.bwd_coef[c] = pc;
+      bn.bwd_coef[C + c] = qc;
+      bn.bwd_coef[2 * C + c] = rc;
+    }
     if (bn.scale) {  // single group, mode 0: same arithmetic as bn_prepare_kernel
       const bool second = bn.split > 0 && c >= bn.split;
       const int cc = second ? c - bn.split : c;
@@ -502,6 +514,18 @@ extern "C" int spgan_colstats_finalize(const float* partials, int groups, int ti
   SPGAN_CHECK_ARG(partials && out0 && out1 && groups > 0 && tiles_per_group > 0 && C > 0 && G > 0 && (mode == 0 || mode == 1));
   SPGAN_CHECK_ARG(tiles_per_group == cdiv(G, tile_rows));
   launch_colfinalize(s, partials, groups, tiles_per_group, C, G, mode, tile_rows, out0, out1, BnTail{});
+  return spgan_launch_status();
+}
+
+// Finalize plain column sums (mode 1, one group) AND emit the BatchNorm-backward coefficients of spgan_bn_bwd_coeffs from them.
+extern "C" int spgan_colstats_finalize_bnbwd(const float* partials, int tiles, int C, int G, int tile_rows, const float* mean, const float* invstd,
+                                             const float* gamma, float count, float* s0, float* s1, float* coef, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (tile_rows <= 0) tile_rows = RT;
+  SPGAN_CHECK_ARG(partials && s0 && s1 && coef && mean && invstd && tiles > 0 && C > 0 && G > 0 && count > 0.f && tiles == cdiv(G, tile_rows));
+  BnTail bn{};
+  bn.bwd_coef = coef; bn.bwd_mean = mean; bn.bwd_invstd = invstd; bn.bwd_gamma = gamma; bn.bwd_rcount = 1.0f / count;
+  launch_colfinalize(s, partials, 1, tiles, C, G, 1, tile_rows, s0, s1, bn);
   return spgan_launch_status();
 }
 

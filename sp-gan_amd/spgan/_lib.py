@@ -181,6 +181,7 @@ SIGNATURES = {
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
     "spgan_reduce_chunks": (I, [P, I, C.c_size_t, P, P]),
     "spgan_bn_bwd_coeffs": (I, [P, P, P, P, I, F, P, P]),
+    "spgan_colstats_finalize_bnbwd": (I, [P, I, I, I, I, P, P, P, F, P, P, P, P]),
     "spgan_comm_available": (I, []),
     "spgan_comm_last_error": (I, []),
     "spgan_comm_unique_id": (I, [P]),

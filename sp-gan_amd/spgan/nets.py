@@ -110,12 +110,16 @@ def _refresh_transposes(trigger: Tensor) -> None:
 LAZY_BN_BWD = [os.environ.get("SPGAN_LAZY_BN_BWD", "1") != "0"]     # 0: materialise every BatchNorm-backward tensor (A/B measurements)
 
 
+def _lazy_ok(rows: int, channels: int) -> bool:
+    return LAZY_BN_BWD[0] and rows > 64 and channels % 4 == 0
+
+
 def _bn_bwd(g: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma, sums: Tensor, count: int, lazy: bool = True):
     """The BatchNorm backward dy = gamma*invstd*(g - S0/count - xhat*S1/count) of a layer whose dy is consumed by GEMMs only: as a lazy
     two-tensor operand (ops.Affine2: the weight-gradient and input-gradient products evaluate p*g + q*y + r on their operand loads; one
     C-sized launch instead of a pass that reads g and y and writes dy), or materialised (ops.bn_bwd_apply) for the few consumers without
     that operand mode."""
-    if lazy and LAZY_BN_BWD[0] and g.shape[0] > 64 and g.shape[1] % 4 == 0:
+    if lazy and _lazy_ok(g.shape[0], g.shape[1]):
         return ops.bn_bwd_lazy(g, y, mean, invstd, gamma, sums, count)
     return ops.bn_bwd_apply(g, y, mean, invstd, gamma, sums, count)
 
@@ -432,14 +436,16 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             G4 = ops.gemm_tn(W, ops.rowscale_outer(W, alpha))                     # W^T diag(alpha) W
             cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(alpha, beta, 1.0), exact=True)[0]  # (alpha*b4 + beta).W
             E = ops.sparse_rows_nt(dy.sp_val, dy.sp_arg, N, W)                    # S.W, dense rows
+            lazy = _lazy_ok(M, sc.numel())
+            cb = dict(coef_bn=(P[D_LAYERS[2][1] + ".weight"], M)) if lazy else {}     # the finalize launch also emits the lazy operand's coefficients
             if a3 is not None:
-                g, s0, s1 = ops.gemm_nt_bnbwd(a3, G4, ys[2], sc, sh, mu, inv, NEG, bias=cvec, rowadd=E)
+                g, s0, s1, *coef = ops.gemm_nt_bnbwd(a3, G4, ys[2], sc, sh, mu, inv, NEG, bias=cvec, rowadd=E, **cb)
             else:
-                g, s0, s1 = ops.gemm_nt_bnbwd(ys[2], G4, ys[2], sc, sh, mu, inv, NEG, pro=(sc, sh, NEG), bias=cvec, rowadd=E)
+                g, s0, s1, *coef = ops.gemm_nt_bnbwd(ys[2], G4, ys[2], sc, sh, mu, inv, NEG, pro=(sc, sh, NEG), bias=cvec, rowadd=E, **cb)
             if need_dparams:
                 grads[D_LAYERS[2][1] + ".weight"] = s1; grads[D_LAYERS[2][1] + ".bias"] = s0
             sums = _cat2(s0, s1)
-            dy = _bn_bwd(g, ys[2], mu, inv, P[D_LAYERS[2][1] + ".weight"], sums, M)
+            dy = ops.Affine2(g, ys[2], coef[0]) if lazy else _bn_bwd(g, ys[2], mu, inv, P[D_LAYERS[2][1] + ".weight"], sums, M, lazy=False)
             dys[2] = dy; gs[2] = g; sums_all[2] = sums
             continue
         if need_dparams:
@@ -453,13 +459,14 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
         if li > 0:
             pconv, pbn = D_LAYERS[li - 1]
             sc, sh, inv, mu = bns[li - 1]
-            g, s0, s1 = ops.gemm_nt_bnbwd(dy, _t(W), ys[li - 1], sc, sh, mu, inv, NEG)
+            # layer 1's dy (64 channels) feeds a 3-column weight gradient and the 3-column input gradient: kernels without the
+            # two-tensor operand -> materialised; the 128- and 256-channel ones stay lazy (coefficients from the finalize launch)
+            lazy = li - 1 > 0 and ctx["training"] and _lazy_ok(M, sc.numel())
+            g, s0, s1, *coef = ops.gemm_nt_bnbwd(dy, _t(W), ys[li - 1], sc, sh, mu, inv, NEG, **(dict(coef_bn=(P[pbn + ".weight"], M)) if lazy else {}))
             if need_dparams:
                 grads[pbn + ".weight"] = s1; grads[pbn + ".bias"] = s0
             sums = _cat2(s0, s1) if ctx["training"] else torch.zeros(2 * s0.numel(), device=s0.device)
-            # layer 1's dy (64 channels) feeds a 3-column weight gradient and the 3-column input gradient: kernels without the
-            # two-tensor operand -> materialised; the 128- and 256-channel ones stay lazy
-            dy = _bn_bwd(g, ys[li - 1], mu, inv, P[pbn + ".weight"], sums, M, lazy=li - 1 > 0)
+            dy = ops.Affine2(g, ys[li - 1], coef[0]) if lazy else _bn_bwd(g, ys[li - 1], mu, inv, P[pbn + ".weight"], sums, M, lazy=li - 1 > 0)
             dys[li - 1] = dy; gs[li - 1] = g; sums_all[li - 1] = sums
     dx_cm = None
     if need_dx:

@@ -491,10 +491,12 @@ def bn_dbl_phaseb(coeffs: Tensor, gamma: Tensor, invstd: Tensor, s0: Optional[Te
 
 
 def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float,
-                  edge=None, pro=None, bias: Optional[Tensor] = None, rowadd: Optional[Tensor] = None):
+                  edge=None, pro=None, bias: Optional[Tensor] = None, rowadd: Optional[Tensor] = None, coef_bn=None):
     """g = (pro(A) @ W^T + bias + rowadd) * lrelu'(z), z = y*scale+shift; returns (g, sum_c g, sum_c g*xhat), xhat = (y-mean)*invstd.
     With edge=(idx, ebias) y is the per-edge difference y[e] = P[idx[e]] - P[i] + ebias of the point tensor P=y_ref.
-    A may be a SparseAffine operand; pro=(scale[K], shift[K], slope) as in gemm_nt; rowadd is a dense [M,N] addend."""
+    A may be a SparseAffine or an Affine2 operand; pro=(scale[K], shift[K], slope) as in gemm_nt; rowadd is a dense [M,N] addend.
+    coef_bn = (gamma | None, count): also return the BatchNorm-backward coefficients coef [3,N] of bn_bwd_lazy(g, y_ref, mean, invstd,
+    gamma, [sum g | sum g*xhat], count) as a fourth result -- emitted by the launch that finishes the column sums (not with edge)."""
     sa = A if isinstance(A, SparseAffine) else None
     a2 = A if isinstance(A, Affine2) else None
     if sa is not None:
@@ -551,6 +553,16 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_bnbwd", M=M_, N=N, K=K)
     if done is not None:
         done()
+    if coef_bn is not None:
+        gamma, count = coef_bn
+        if res is not None:                     # the M <= 64 kernel finished its sums itself: coefficients by the small kernel
+            return g, res[0], res[1], bn_bwd_lazy(g, y_ref, mean, invstd, gamma, torch.cat([res[0], res[1]]), count).coef
+        out = torch.empty((2, N), dtype=torch.float32, device=A.device)
+        coef = torch.empty((3, N), dtype=torch.float32, device=A.device)
+        check(lib.spgan_colstats_finalize_bnbwd(_p(part), tiles, N, M_, 0, _p(_vec(mean, N, "mean")), _p(_vec(invstd, N, "invstd")),
+                                                _p(None if gamma is None else _vec(gamma, N, "gamma")), float(count), _p(out[0]), _p(out[1]), _p(coef), _s()),
+              "colstats_finalize_bnbwd", N=N, M=M_)
+        return g, out[0], out[1], coef
     if res is not None:
         return g, res[0], res[1]
     s0, s1 = _finalize(part, 1, tiles, N, M_, 1)

@@ -189,7 +189,7 @@ def _dense(A):
     return A
 
 
-def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None, pro=None, bias=None, rowadd=None):
+def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None, pro=None, bias=None, rowadd=None, coef_bn=None):
     A = _dense(A)
     if pro is not None:
         A = _lrelu(A * pro[0] + pro[1], pro[2])
@@ -209,6 +209,9 @@ def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None, pro
         acc = acc + rowadd
     g = acc * torch.where(z > 0, 1.0, slope)
     xh = (y - mean) * invstd
+    if coef_bn is not None:
+        s0, s1 = g.sum(0), (g * xh).sum(0)
+        return g.contiguous(), s0, s1, bn_bwd_lazy(g, y, mean, invstd, coef_bn[0], torch.cat([s0, s1]), coef_bn[1]).coef
     return g.contiguous(), g.sum(0), (g * xh).sum(0)
 
 

@@ -400,6 +400,11 @@ def test_bn_bwd_lazy_operand(ops, M, C, Nout):
     bsc, bsh, mu2, inv2 = rnd("lz.bsc%d" % Nout, (Nout,)), rnd("lz.bsh%d" % Nout, (Nout,), 0.3), rnd("lz.mu%d" % Nout, (Nout,), 0.2), rnd("lz.inv%d" % Nout, (Nout,)).abs() + 0.5
     for a_, b_ in zip(ops.gemm_nt_bnbwd(lazy, W, prev, bsc, bsh, mu2, inv2, 0.01), ops.gemm_nt_bnbwd(dense, W, prev, bsc, bsh, mu2, inv2, 0.01)):
         close(a_, b_, rtol=5e-6, atol=2e-5, what="gemm_nt_bnbwd A2")
+    # the finalize launch of a BNBWD product emits the NEXT lazy operand's coefficients (coef_bn)
+    gam2 = rnd("lz.gam2%d" % Nout, (Nout,)).abs() + 0.5
+    g2, s0, s1, coef = ops.gemm_nt_bnbwd(dense, W, prev, bsc, bsh, mu2, inv2, 0.01, coef_bn=(gam2, M))
+    ref = ops.bn_bwd_lazy(g2, prev, mu2, inv2, gam2, torch.cat([s0, s1]), M)
+    close(coef, ref.coef, rtol=1e-6, atol=1e-7, what="coef from the finalize launch")
 
 
 def test_bn_bwd_lazy_operand_edge_consumers(ops):
