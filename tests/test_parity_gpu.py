@@ -677,3 +677,33 @@ def test_twin_generator_forwards_reuse_edgeconv1(sp):
             assert torch.allclose(ga[k], gb[k], rtol=2e-6, atol=1e-8), k
         else:
             assert torch.equal(ga[k], gb[k]), k                   # parameters, the other buffers and every num_batches_tracked
+
+
+def test_twin_second_without_a_reusable_first_does_not_advance_statistics_again(sp):
+    """The advisor's twin-forward case: the forward announced as "second" cannot reuse its twin (EdgeConv1's weights changed in
+    between) -- it must evaluate EdgeConv1 WITHOUT advancing the running statistics a third time ("first" already accounted for
+    two updates); a forward outside the protocol (twin_forward None: an eval call / sample dump) in between leaves a pending twin alone."""
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    z = fr.latent(B, N, seed=82)[:, :1, :].contiguous().cuda()
+    G = _load(sp.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=8)).train()
+    stats = lambda: {k: v.clone() for k, v in G.state_dict().items() if k.startswith("EdgeConv1.") and ("running" in k or "tracked" in k)}
+    with torch.no_grad():
+        G.twin_forward = "first"
+        G(x, z)
+        G.twin_forward = None
+        after_first = stats()
+        assert G.__dict__.get("_ec1_twin") is not None
+        G(x, z)                                                   # a call outside the protocol: advances the statistics once, keeps the twin
+        assert G.__dict__.get("_ec1_twin") is not None
+        between = stats()
+        assert any(not torch.equal(after_first[k], between[k]) for k in between if "running" in k)
+        G.EdgeConv1.conv_x[0].weight.mul_(1.0)                    # in-place touch: the version stamp of the twin no longer matches
+        G.twin_forward = "second"
+        out = G(x, z)
+        G.twin_forward = None
+        G.flush_bn_counts()
+        for k, v in stats().items():
+            if "running" in k:
+                assert torch.equal(v, between[k]), k              # not advanced a third time
+    assert torch.isfinite(out).all() and G.__dict__.get("_ec1_twin") is None
