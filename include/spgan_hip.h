@@ -209,6 +209,11 @@ typedef struct spgan_gemm_tn_args {
   /* A2 != NULL (needs a_scale, a_shift; not with a_sp_val): a = A*a_scale[c] + A2*a_scale2[c] + a_shift[c] -- the same two-tensor
    * operand as spgan_gemm_nt_args.A2, on the A side of the weight-gradient product. */
   const float* A2; int lda2; const float* a_scale2;
+  /* != NULL: also write the column sums of the (transformed) A operand over the rows of every split: a_colsum_ws [splits, Na]
+   * (splits = spgan_gemm_tn_splits(M, Na, Nb)); their fixed-order sum over the splits -- e.g. one more entry (Na = 1, Nb = Na) of
+   * spgan_splitk_reduce_multi -- is colsum(A): the bias gradient that belongs to this weight gradient, without a pass of its own.
+   * Not with a_sp_val, not on the Na / Nb <= 4 streaming path. */
+  float* a_colsum_ws;
 } spgan_gemm_tn_args;
 
 /* Coefficient vectors of the BatchNorm backward as an affine combination of two tensors (Generator.py:58-67 / Discriminator.py:57-79

@@ -1209,6 +1209,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
     }
   }
   float4 ra2[ASLOTS];
+  // column sums of the (transformed) A operand: the bias gradient next to this weight gradient, for free (a_colsum_ws)
+  const bool acs = p.a_colsum_ws != nullptr && tb == 0;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
   // As in gemm_nt the staging registers keep RAW loads; the prologues run in sstore, after the MFMAs of the current tile.
   float4 rb2[BMODE == SPGAN_A_EDGE ? BSLOTS : 1];
   // FAST (16-byte aligned operands, Na/Nb/lda/ldb multiples of 4): straight-line float4 loads from clamped addresses --
@@ -1270,6 +1273,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
         v = mask_tail(v, a0 + c, p.Na);
       } else if (apro && ok) v = mask_tail(affine_lrelu4(v, asc, ash, 1.0f), a0 + c, p.Na);
       if (FAST && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (acs) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }   // rows in ascending order per thread: deterministic
       *reinterpret_cast<float4*>(&a[r * LDA_ + c]) = v;
     }
 #pragma unroll
@@ -1318,6 +1322,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
       }
       if (more) sstore(buf ^ 1, mb + TKF);
       __syncthreads();
+    }
+  }
+  if (p.a_colsum_ws != nullptr && tb == 0) {  // 8 row groups per column quad -> one partial per (split, column); the LDS tiles are dead
+    __syncthreads();
+    *reinterpret_cast<float4*>(&As[(tid >> 5) * TA + (tid & 31) * 4]) = cs;
+    __syncthreads();
+    if (tid < TA && a0 + tid < p.Na) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += As[g * TA + tid];
+      p.a_colsum_ws[(size_t)split * p.Na + a0 + tid] = t;
     }
   }
   // partial tile -> ws[split][Na][Nb]   (D: row = A-col index, col = B-col index)
@@ -1406,6 +1421,8 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
     if (a2) asc2 = *reinterpret_cast<const float4*>(p.a_scale2 + a0 + ac);
   }
   float4 ra2[4];
+  const bool acs = p.a_colsum_ws != nullptr && tb == 0;   // fp32 column sums of the transformed A operand (before the bf16 rounding)
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)min(mb + ar + i, p.M - 1) * p.lda + (aok ? a0 + ac : 0));
@@ -1439,6 +1456,7 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
         v.w = fmaf(v.w, asc.w, fmaf(ra2[i].w, asc2.w, ash.w));
       } else if (apro && ok) v = affine_lrelu4(v, asc, ash, 1.0f);
       if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (acs) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
       va[i][0] = v.x; va[i][1] = v.y; va[i][2] = v.z; va[i][3] = v.w;
     }
 #pragma unroll
@@ -1500,6 +1518,17 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
       }
       if (more) sstore(buf ^ 1, mb + TKM);
       __syncthreads();
+    }
+  }
+  if (p.a_colsum_ws != nullptr && tb == 0) {
+    __syncthreads();
+    *reinterpret_cast<float4*>(&As[(tid >> 5) * TA + ac]) = cs;      // [8 row groups][128 columns] floats: 4 KB of the dead A tiles
+    __syncthreads();
+    if (tid < TA && a0 + tid < p.Na) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += As[g * TA + tid];
+      p.a_colsum_ws[(size_t)split * p.Na + a0 + tid] = t;
     }
   }
   float* out = p.ws + (size_t)split * p.Na * p.Nb;
@@ -1977,6 +2006,7 @@ extern "C" int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s_) {
   if (a->b_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
   if (a->a_scale) SPGAN_CHECK_ARG(a->a_shift && (!a->a_sp_val || (a->a_sp_arg && a->a_sp_rows > 0 && a->b_mode != SPGAN_A_EDGE)));
   if (a->A2) SPGAN_CHECK_ARG(a->a_scale && a->a_scale2 && !a->a_sp_val && a->lda2 >= a->Na);
+  if (a->a_colsum_ws) SPGAN_CHECK_ARG(!a->a_sp_val && !(a->b_mode == SPGAN_A_PLAIN && !a->a_scale && tn_skinny(a->Na, a->Nb)));  // not on the streaming kernels
   SPGAN_CHECK_ARG(a->M < (1 << 24));  // fast_div domain
   switch (a->b_mode) {
     case SPGAN_A_PLAIN: return launch_tn<SPGAN_A_PLAIN>(*a, s);

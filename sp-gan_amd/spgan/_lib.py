@@ -67,6 +67,7 @@ class GemmTNArgs(C.Structure):
         ("defer_reduce", C.c_int),
         ("mfma_lp", C.c_int),
         ("A2", c_f32p), ("lda2", C.c_int), ("a_scale2", c_f32p),
+        ("a_colsum_ws", c_f32p),
     ]
 
 

@@ -715,8 +715,8 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     g: Dict[str, Tensor] = {}
     dout = dout.contiguous()
     # conv_out
-    g[pre + ".conv_out.bias"] = ops.colsum(dout)[0]
-    g[pre + ".conv_out.weight"] = conv_out_weight_grad_from_pm(ops.gemm_tn(dout, ctx["T"]), F_, k)
+    gwo, g[pre + ".conv_out.bias"] = ops.gemm_tn(dout, ctx["T"], with_colsum=True)      # the bias gradient rides along (column sums of dout)
+    g[pre + ".conv_out.weight"] = conv_out_weight_grad_from_pm(gwo, F_, k)
     dT = ops.gemm_nt(dout, _t(ctx["Wo"]))                                         # [M, k*F]
     # softmax * conv_x product, both LeakyReLUs
     g2, gy, sums2, sumsy = ops.edge_attend_bwd(dT, ctx["h2pre"], bn2[0], bn2[1], bn2[3], bn2[2], PQR, idx, bx, bnx[0], bnx[1], bnx[3], bnx[2], NEG)
@@ -762,8 +762,8 @@ def adain_backward(P, pre: str, ctx, dout: Tensor, need_dx: bool = True, need_ds
     dx, dgb = ops.adain_bwd(dout.contiguous(), ctx["x"], ctx["N"], ctx["slope"], ctx["imean"], ctx["ivar"], ctx["gb"])
     g = {}
     if need_dparams:
-        g[pre + ".style.weight"] = ops.gemm_tn(dgb, ctx["style"], defer=True).view_as(P[pre + ".style.weight"])
-        g[pre + ".style.bias"] = ops.colsum(dgb)[0]
+        gws, g[pre + ".style.bias"] = ops.gemm_tn(dgb, ctx["style"], defer=True, with_colsum=True)
+        g[pre + ".style.weight"] = gws.view_as(P[pre + ".style.weight"])
     dstyle = ops.gemm_nt(dgb, _t(_w2(P[pre + ".style.weight"]))) if need_dstyle else None
     return (dx if need_dx else None), dstyle, g
 
@@ -799,15 +799,17 @@ def mlp_backward(P, ctx, dout: Tensor, need_dx: bool = True, need_dparams: bool 
         first_part = i == 0 and ctx["first_weight"] is not None
         W = ctx["first_weight"] if first_part else _w2(P[names[i] + ".weight"])
         if need_dparams:
-            gw = ops.gemm_tn(d, inp, defer=True)
+            per_shape_bias = i == 0 and ctx["rowbias"]
+            if per_shape_bias:
+                gw = ops.gemm_tn(d, inp, defer=True)
+            else:                                                                # the bias gradient = column sums of d: a by-product of the product
+                gw, g[names[i] + ".bias"] = ops.gemm_tn(d, inp, defer=True, with_colsum=True)
             if first_part:
                 g[names[i] + ".weight.part"] = gw
             else:
                 g[names[i] + ".weight"] = gw.view_as(P[names[i] + ".weight"])
-            if i == 0 and ctx["rowbias"]:
+            if per_shape_bias:
                 drb = ops.colsum(d, ctx["N"])                                    # per-shape bias gradient [B, C]
-            else:
-                g[names[i] + ".bias"] = ops.colsum(d)[0]
         elif i == 0 and ctx["rowbias"]:
             drb = ops.colsum(d, ctx["N"])
         if i > 0:

@@ -597,14 +597,17 @@ TN_LP_MIN_ROWS = 8192     # "f16" operand mode: weight gradients reduce over >= 
 
 
 def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor] = None, beta: float = 0.0, defer: bool = False,
-            exact: bool = False) -> Tensor:
+            exact: bool = False, with_colsum: bool = False):
     """C[Na,Nb] = beta*C + A^T @ pro(Bm): weight gradient, reduction over the M rows (points or edges).
     A may be a SparseAffine operand (evaluated on load).
     In the "f16" operand mode (set_mfma_operands) the products that reduce over the points / edges (M >= TN_LP_MIN_ROWS) round
     both operands to bfloat16 at the LDS staging -- fp32's exponent range: per-point gradients are 1e-5..1e-8 -- and accumulate in
     fp32 (spgan_gemm_tn_args.mfma_lp); the small weight-by-weight products and exact=True calls keep fp32 operands.
     defer=True: the returned tensor is NOT valid until flush_tn() ran -- the split-K partial sums of all the weight gradients of a
-    backward pass are then finished by one launch (functions._deliver flushes before it hands gradients on)."""
+    backward pass are then finished by one launch (functions._deliver flushes before it hands gradients on).
+    with_colsum=True: -> (C, colsum(A) [Na]): the column sums of the (transformed) A operand -- the bias gradient that belongs to this
+    weight gradient -- come out of the same launch (spgan_gemm_tn_args.a_colsum_ws) and are finished by the same split reduction
+    (deferred like C with defer=True) instead of a colsum pass of their own."""
     sa = A if isinstance(A, SparseAffine) else None
     a2 = A if isinstance(A, Affine2) else None
     if sa is not None:
@@ -648,13 +651,29 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     defer = bool(defer) and sa is None
     a.defer_reduce = 1 if defer else 0
     a.mfma_lp = 1 if (_MFMA_F16[0] == 1 and not exact and M_ >= TN_LP_MIN_ROWS) else 0
+    splits = lib.spgan_gemm_tn_splits(M_, Na, Nb)
+    cs_out = cs_ws = None
+    streaming = (Na <= 4 or Nb <= 4) and Na <= 2048 and Nb <= 2048 and pro is None and edge is None and sa is None and a2 is None
+    if with_colsum and sa is not None:
+        raise NotImplementedError("gemm_tn(with_colsum=True) with a SparseAffine operand")
+    if with_colsum and not streaming:
+        cs_ws = torch.empty((splits, Na), dtype=torch.float32, device=A.device)
+        cs_out = torch.empty((Na,), dtype=torch.float32, device=A.device)
+        a.a_colsum_ws = _p(cs_ws)
     done = launch_timer("gemm_tn", a) if launch_timer is not None else None
     check(lib.spgan_gemm_tn(C.byref(a), _s()), "gemm_tn", M=M_, Na=Na, Nb=Nb)
     if done is not None:
         done()
     if defer:
-        _PENDING_TN.append((ws, out, lib.spgan_gemm_tn_splits(M_, Na, Nb), Na, Nb, _ld(out), float(beta)))
-    return out
+        _PENDING_TN.append((ws, out, splits, Na, Nb, _ld(out), float(beta)))
+    if not with_colsum:
+        return out
+    if cs_ws is None:                       # the streaming kernels have no such by-product: the separate reduction
+        return out, colsum(A)[0]
+    _PENDING_TN.append((cs_ws, cs_out, splits, 1, Na, Na, 0.0))           # [splits][1 x Na] partials: one more entry of the multi-reduce
+    if not defer:
+        flush_tn()
+    return out, cs_out
 
 
 # ----------------------------------------------------------------------------- reductions / norms

@@ -295,14 +295,16 @@ def flush_tn():
     pass
 
 
-def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0, defer=False, exact=False):
+def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0, defer=False, exact=False, with_colsum=False):
     A = _dense(A)
     b = _operand(Bm, pro, edge, Bm.shape[1])
     c = A.t() @ b
     if out is None:
-        return c.contiguous()
-    out.copy_(beta * out + c if beta != 0 else c)          # beta == 0: the destination is not read (it may be uninitialised)
-    return out
+        res = c.contiguous()
+    else:
+        out.copy_(beta * out + c if beta != 0 else c)          # beta == 0: the destination is not read (it may be uninitialised)
+        res = out
+    return (res, A.sum(0)) if with_colsum else res
 
 
 # ----------------------------------------------------------------------------- reductions / norms

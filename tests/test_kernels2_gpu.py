@@ -433,3 +433,25 @@ def test_bn_bwd_lazy_operand_edge_consumers(ops):
     for a_, b_ in zip(ops.gemm_nt_bnbwd(lazy, W2t, Pm[:, :H], sc, sh, mu1, inv1, 0.01, edge=(idx, b1)),
                       ops.gemm_nt_bnbwd(dense, W2t, Pm[:, :H], sc, sh, mu1, inv1, 0.01, edge=(idx, b1))):
         close(a_, b_, rtol=5e-6, atol=2e-5, what="edge gemm_nt_bnbwd A2")
+
+
+@pytest.mark.parametrize("M,Na,Nb,defer", [(4096, 256, 128, True), (65536, 64, 256, True), (3000, 132, 36, False), (20480, 128, 1280, False), (700, 3, 64, False)])
+def test_gemm_tn_colsum_by_product(ops, M, Na, Nb, defer):
+    """gemm_tn(with_colsum=True): the column sums of the A operand (the bias gradient next to a weight gradient) come out of the
+    product's own launch and its split reduction -- against the separate colsum pass; with a lazy BatchNorm-backward operand too."""
+    A, Bm = rnd("cs.A%d.%d" % (M, Na), (M, Na)), rnd("cs.B%d.%d" % (M, Nb), (M, Nb))
+    out, cs = ops.gemm_tn(A, Bm, defer=defer, with_colsum=True)
+    if defer:
+        ops.flush_tn()
+    close(out, km.gemm_tn(A, Bm), rtol=2e-5, what="product")
+    close(cs, A.double().sum(0).float(), rtol=2e-6, atol=2e-5, what="column sums")
+    out2, cs2 = ops.gemm_tn(A, Bm, with_colsum=True)
+    assert torch.equal(cs, cs2), "not deterministic"
+    if Na % 4 == 0 and M > 64:
+        y = rnd("cs.y%d.%d" % (M, Na), (M, Na), 2.0)
+        mean, inv = y.mean(0), 1.0 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+        sums = torch.cat([A.sum(0), (A * ((y - mean) * inv)).sum(0)])
+        lazy = ops.bn_bwd_lazy(A, y, mean, inv, None, sums, M)
+        o3, cs3 = ops.gemm_tn(lazy, Bm, with_colsum=True)
+        close(cs3, lazy.dense().double().sum(0).float(), rtol=1e-5, atol=5e-4, what="column sums of the lazy operand")
+        close(o3, km.gemm_tn(lazy.dense(), Bm), rtol=2e-5, atol=1e-4, what="product of the lazy operand")
