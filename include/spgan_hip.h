@@ -214,6 +214,10 @@ typedef struct spgan_gemm_tn_args {
    * spgan_splitk_reduce_multi -- is colsum(A): the bias gradient that belongs to this weight gradient, without a pass of its own.
    * Not with a_sp_val, not on the Na / Nb <= 4 streaming path. */
   float* a_colsum_ws;
+  /* a_lrelu = 1 (needs a_scale, a_shift; not with A2 / a_sp_val): the A-side prologue is a = lrelu(A*a_scale[c] + a_shift[c], a_slope)
+   * -- a BatchNorm + LeakyReLU'd activation as the A operand without materialising it (the Gram matrix a^T a of the collapsed
+   * backward takes the same pre-activation tensor on both sides).  0: the affine map alone. */
+  int a_lrelu; float a_slope;
 } spgan_gemm_tn_args;
 
 /* Coefficient vectors of the BatchNorm backward as an affine combination of two tensors (Generator.py:58-67 / Discriminator.py:57-79

@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
         v.z = fmaf(v.z, asc.z, fmaf(ra2[i].z, asc2.z, ash.z));
         v.w = fmaf(v.w, asc.w, fmaf(ra2[i].w, asc2.w, ash.w));
         v = mask_tail(v, a0 + c, p.Na);
-      } else if (apro && ok) v = mask_tail(affine_lrelu4(v, asc, ash, 1.0f), a0 + c, p.Na);
+      } else if (apro && ok) v = mask_tail(affine_lrelu4(v, asc, ash, p.a_lrelu ? p.a_slope : 1.0f), a0 + c, p.Na);
       if (FAST && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (acs) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }   // rows in ascending order per thread: deterministic
       *reinterpret_cast<float4*>(&a[r * LDA_ + c]) = v;
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
         v.y = fmaf(v.y, asc.y, fmaf(ra2[i].y, asc2.y, ash.y));
         v.z = fmaf(v.z, asc.z, fmaf(ra2[i].z, asc2.z, ash.z));
         v.w = fmaf(v.w, asc.w, fmaf(ra2[i].w, asc2.w, ash.w));
-      } else if (apro && ok) v = affine_lrelu4(v, asc, ash, 1.0f);
+      } else if (apro && ok) v = affine_lrelu4(v, asc, ash, p.a_lrelu ? p.a_slope : 1.0f);
       if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (acs) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
       va[i][0] = v.x; va[i][1] = v.y; va[i][2] = v.z; va[i][3] = v.w;
@@ -2006,6 +2006,7 @@ extern "C" int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s_) {
   if (a->b_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
   if (a->a_scale) SPGAN_CHECK_ARG(a->a_shift && (!a->a_sp_val || (a->a_sp_arg && a->a_sp_rows > 0 && a->b_mode != SPGAN_A_EDGE)));
   if (a->A2) SPGAN_CHECK_ARG(a->a_scale && a->a_scale2 && !a->a_sp_val && a->lda2 >= a->Na);
+  if (a->a_lrelu) SPGAN_CHECK_ARG(a->a_scale && !a->A2 && !a->a_sp_val);
   if (a->a_colsum_ws) SPGAN_CHECK_ARG(!a->a_sp_val && !(a->b_mode == SPGAN_A_PLAIN && !a->a_scale && tn_skinny(a->Na, a->Nb)));  // not on the streaming kernels
   SPGAN_CHECK_ARG(a->M < (1 << 24));  // fast_div domain
   switch (a->b_mode) {

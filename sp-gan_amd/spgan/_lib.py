@@ -68,6 +68,7 @@ class GemmTNArgs(C.Structure):
         ("mfma_lp", C.c_int),
         ("A2", c_f32p), ("lda2", C.c_int), ("a_scale2", c_f32p),
         ("a_colsum_ws", c_f32p),
+        ("a_lrelu", C.c_int), ("a_slope", C.c_float),
     ]
 
 

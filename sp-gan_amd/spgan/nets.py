@@ -424,13 +424,13 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             # -- a quarter of the FLOPs, and y4 is not read at all.
             sc, sh, inv, mu = bns[2]
             alpha, beta, b4 = dy.alpha, dy.beta, P[conv + ".bias"]
-            # a3 = lrelu(bn3(y3)) is materialised only where the weight gradients need it as a plain operand (Gram matrix, column
-            # sums, the sparse rows); the input-gradient GEMM below applies the same affine + LeakyReLU in its operand prologue
-            a3 = ops.affine_act(ys[2], sc, sh, NEG) if need_dparams else None
+            # a3 = lrelu(bn3(y3)) is never materialised: every consumer applies the affine + LeakyReLU to y3 on its operand load (both
+            # sides of the Gram product, whose launch also yields colsum(a3); the sparse rows; the input-gradient GEMM)
+            pro3 = (sc, sh, NEG)
             if need_dparams:
-                gram = ops.gemm_tn(a3, a3)                                        # [256,256]
-                dW = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), alpha, b4, beta, ops.colsum(a3)[0])   # gram: a sum over B*N points
-                ops.sparse_rows_tn(dy.sp_val, dy.sp_arg, N, a3, dW)
+                gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)          # a3^T a3 [256,256], colsum(a3)
+                dW = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), alpha, b4, beta, cs3)     # gram: a sum over B*N points
+                ops.sparse_rows_tn(dy.sp_val, dy.sp_arg, N, ys[2], dW, pro=pro3)
                 grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
                 grads[conv + ".bias"] = ZERO_GRAD
             G4 = ops.gemm_tn(W, ops.rowscale_outer(W, alpha))                     # W^T diag(alpha) W
@@ -438,10 +438,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             E = ops.sparse_rows_nt(dy.sp_val, dy.sp_arg, N, W)                    # S.W, dense rows
             lazy = _lazy_ok(M, sc.numel())
             cb = dict(coef_bn=(P[D_LAYERS[2][1] + ".weight"], M)) if lazy else {}     # the finalize launch also emits the lazy operand's coefficients
-            if a3 is not None:
-                g, s0, s1, *coef = ops.gemm_nt_bnbwd(a3, G4, ys[2], sc, sh, mu, inv, NEG, bias=cvec, rowadd=E, **cb)
-            else:
-                g, s0, s1, *coef = ops.gemm_nt_bnbwd(ys[2], G4, ys[2], sc, sh, mu, inv, NEG, pro=(sc, sh, NEG), bias=cvec, rowadd=E, **cb)
+            g, s0, s1, *coef = ops.gemm_nt_bnbwd(ys[2], G4, ys[2], sc, sh, mu, inv, NEG, pro=pro3, bias=cvec, rowadd=E, **cb)
             if need_dparams:
                 grads[D_LAYERS[2][1] + ".weight"] = s1; grads[D_LAYERS[2][1] + ".bias"] = s0
             sums = _cat2(s0, s1)
@@ -493,8 +490,8 @@ def _d_double_top_phase_a(P, ctx, saved, q3: Tensor, grads) -> dict:
     C = W.shape[0]
     dz = saved["dys"][3]
     S0, S1 = saved["sums"][3][:C], saved["sums"][3][C:]
-    a3 = ops.affine_act(ys[2], bns[2][0], bns[2][1], NEG)
-    Qqa = ops.gemm_tn(q3, a3)                                                    # q3^T a3 [256,256]
+    pro3 = (bns[2][0], bns[2][1], NEG)                                           # a3 = lrelu(bn3(y3)), applied to y3 on the operand loads
+    Qqa = ops.gemm_tn(q3, ys[2], pro=pro3)                                       # q3^T a3 [256,256]
     cq = ops.colsum(q3)[0]
     T = ops.gemm_nt(W, Qqa, exact=True)                                          # W.(a3^T q3) [1024,256]; Qqa: a sum over B*N points
     dW = ops.rowscale_outer(T, dz.alpha, b4, dz.beta, cq)
@@ -505,7 +502,7 @@ def _d_double_top_phase_a(P, ctx, saved, q3: Tensor, grads) -> dict:
     uarg = ops.gather_rowdot(q3, argmax, W)                                      # u at the arg-max rows [B,1024]
     yarg = ctx["yarg"] if ctx.get("yarg") is not None else ops.gather_rows(ys[3], argmax)
     t, spB, c4 = ops.bn_dbl_pool(uarg, saved["gval"], yarg, pooled, U0, quad, b4, mu, inv, gamma, S0, S1, M, NEG)
-    return dict(t=t, spB=spB, c4=c4, a3=a3, q3=q3, Qqa=Qqa)
+    return dict(t=t, spB=spB, c4=c4, pro3=pro3, q3=q3, Qqa=Qqa)
 
 
 def _d_double_top_phase_b(P, ctx, top: dict, grads):
@@ -516,22 +513,22 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
     ys, bns, argmax = ctx["ys"], ctx["bns"], ctx["argmax"]
     conv, bn = D_LAYERS[3]
     W, b4 = _w2(P[conv + ".weight"]), P[conv + ".bias"]
-    c4, a3, q3, spB = top["c4"], top["a3"], top["q3"], top["spB"]
+    c4, pro3, q3, spB = top["c4"], top["pro3"], top["q3"], top["spB"]
     dgamma, c1, c2, c3 = c4[0], c4[1], c4[2], c4[3]
     grads[bn + ".weight"] = dgamma
     grads[bn + ".bias"] = ZERO_GRAD
     Wc1, Wc2 = ops.rowscale_outer(W, c1), ops.rowscale_outer(W, c2)
-    gram = ops.gemm_tn(a3, a3)
-    gw = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), c2, b4, c3, ops.colsum(a3)[0])
+    gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)                # a3^T a3 and colsum(a3) from one launch
+    gw = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), c2, b4, c3, cs3)
     gw = ops.axpby(1.0, ops.gemm_nt(Wc1, _t(top["Qqa"]), exact=True), 1.0, gw)             # + diag(c1).W.(q3^T a3)
-    ops.sparse_rows_tn(spB, argmax, N, a3, gw)
+    ops.sparse_rows_tn(spB, argmax, N, ys[2], gw, pro=pro3)
     grads[conv + ".weight"] = ops.axpby(1.0, gw, 1.0, grads[conv + ".weight"]).view_as(P[conv + ".weight"])
     grads[conv + ".bias"] = ZERO_GRAD
     G1, G2 = ops.gemm_tn(W, Wc1), ops.gemm_tn(W, Wc2)
     cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(c2, c3, 1.0), exact=True)[0]
     part = ops.gemm_nt(q3, G1, rowbias=ops.sparse_rows_nt(spB, argmax, N, W), rows_per_group=1)
     psc, psh, pinv, pmu = bns[2]
-    return ops.gemm_nt_bnbwd(a3, G2, ys[2], psc, psh, pmu, pinv, NEG, bias=cvec, rowadd=part)
+    return ops.gemm_nt_bnbwd(ys[2], G2, ys[2], psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part)
 
 
 def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):

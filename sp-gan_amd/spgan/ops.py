@@ -597,7 +597,7 @@ TN_LP_MIN_ROWS = 8192     # "f16" operand mode: weight gradients reduce over >= 
 
 
 def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor] = None, beta: float = 0.0, defer: bool = False,
-            exact: bool = False, with_colsum: bool = False):
+            exact: bool = False, with_colsum: bool = False, a_pro=None):
     """C[Na,Nb] = beta*C + A^T @ pro(Bm): weight gradient, reduction over the M rows (points or edges).
     A may be a SparseAffine operand (evaluated on load).
     In the "f16" operand mode (set_mfma_operands) the products that reduce over the points / edges (M >= TN_LP_MIN_ROWS) round
@@ -605,6 +605,7 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     fp32 (spgan_gemm_tn_args.mfma_lp); the small weight-by-weight products and exact=True calls keep fp32 operands.
     defer=True: the returned tensor is NOT valid until flush_tn() ran -- the split-K partial sums of all the weight gradients of a
     backward pass are then finished by one launch (functions._deliver flushes before it hands gradients on).
+    a_pro = (scale [Na], shift [Na], slope): the A operand is lrelu(A*scale + shift, slope), evaluated on load (plain A only).
     with_colsum=True: -> (C, colsum(A) [Na]): the column sums of the (transformed) A operand -- the bias gradient that belongs to this
     weight gradient -- come out of the same launch (spgan_gemm_tn_args.a_colsum_ws) and are finished by the same split reduction
     (deferred like C with defer=True) instead of a colsum pass of their own."""
@@ -621,6 +622,11 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     if a2 is not None:
         a.a_scale = _p(_vec(a2.p, Na, "p")); a.a_shift = _p(_vec(a2.r, Na, "r"))
         a.A2 = _p(a2.y); a.lda2 = _ld(a2.y); a.a_scale2 = _p(_vec(a2.q, Na, "q"))
+    if a_pro is not None:
+        if sa is not None or a2 is not None:
+            raise ValueError("a_pro goes with a plain A operand")
+        a.a_scale = _p(_vec(a_pro[0], Na, "a_pro.scale")); a.a_shift = _p(_vec(a_pro[1], Na, "a_pro.shift"))
+        a.a_lrelu = 1; a.a_slope = float(a_pro[2])
     if sa is not None:
         a.a_scale = _p(_vec(sa.alpha, Na, "alpha")); a.a_shift = _p(_vec(sa.beta, Na, "beta"))
         a.a_sp_val = _p(sa.sp_val); a.a_sp_arg = _p(_i32(sa.sp_arg, "sp_arg")); a.a_sp_rows = sa.rows
@@ -653,7 +659,7 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     a.mfma_lp = 1 if (_MFMA_F16[0] == 1 and not exact and M_ >= TN_LP_MIN_ROWS) else 0
     splits = lib.spgan_gemm_tn_splits(M_, Na, Nb)
     cs_out = cs_ws = None
-    streaming = (Na <= 4 or Nb <= 4) and Na <= 2048 and Nb <= 2048 and pro is None and edge is None and sa is None and a2 is None
+    streaming = (Na <= 4 or Nb <= 4) and Na <= 2048 and Nb <= 2048 and pro is None and edge is None and sa is None and a2 is None and a_pro is None
     if with_colsum and sa is not None:
         raise NotImplementedError("gemm_tn(with_colsum=True) with a SparseAffine operand")
     if with_colsum and not streaming:

@@ -295,8 +295,10 @@ def flush_tn():
     pass
 
 
-def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0, defer=False, exact=False, with_colsum=False):
+def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0, defer=False, exact=False, with_colsum=False, a_pro=None):
     A = _dense(A)
+    if a_pro is not None:
+        A = _lrelu(A * a_pro[0] + a_pro[1], a_pro[2])
     b = _operand(Bm, pro, edge, Bm.shape[1])
     c = A.t() @ b
     if out is None:

@@ -455,3 +455,16 @@ def test_gemm_tn_colsum_by_product(ops, M, Na, Nb, defer):
         o3, cs3 = ops.gemm_tn(lazy, Bm, with_colsum=True)
         close(cs3, lazy.dense().double().sum(0).float(), rtol=1e-5, atol=5e-4, what="column sums of the lazy operand")
         close(o3, km.gemm_tn(lazy.dense(), Bm), rtol=2e-5, atol=1e-4, what="product of the lazy operand")
+
+
+@pytest.mark.parametrize("M,C", [(4096, 256), (20000, 128), (1500, 68)])
+def test_gemm_tn_gram_of_an_activation_without_materialising_it(ops, M, C):
+    """a^T a and colsum(a) of a = lrelu(y*scale + shift) from ONE launch over y (A-side and B-side prologues, column-sum by-product):
+    what the collapsed 256 -> 1024 backward needs of a3 = lrelu(bn3(y3))."""
+    y = rnd("gram.y%d.%d" % (M, C), (M, C), 1.5)
+    sc, sh = rnd("gram.sc%d" % C, (C,)).abs() + 0.5, rnd("gram.sh%d" % C, (C,), 0.3)
+    a = ops.affine_act(y, sc, sh, 0.01)
+    gram, cs = ops.gemm_tn(y, y, a_pro=(sc, sh, 0.01), pro=(sc, sh, 0.01), with_colsum=True)
+    close(gram, (a.double().t() @ a.double()).float(), rtol=2e-5, what="gram")
+    close(cs, a.double().sum(0).float(), rtol=2e-6, atol=1e-4, what="colsum")
+    close(gram, ops.gemm_tn(a, a), rtol=1e-6, what="vs the materialised operand")
