@@ -1781,6 +1781,10 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(const spgan_gemm_tn
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int l = blockIdx.x * 64 + cl;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // two-tensor A operand (spgan_gemm_tn_args.A2) on the wide side: a = A*a_scale[l] + A2*a_scale2[l] + a_shift[l], column l fixed per thread
+  const bool a2 = NARROW_B && p.A2 != nullptr;
+  float cp = 1.f, cq = 0.f, cr = 0.f;
+  if (a2 && l < Ln) { cp = p.a_scale[l]; cq = p.a_scale2[l]; cr = p.a_shift[l]; }
   if (l < Ln) {
     int m = mbeg + rl;
     for (; m + 28 < mend; m += 32) {  // 8 rows in flight per thread
@@ -1788,6 +1792,7 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(const spgan_gemm_tn
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         v[u] = Lm[(size_t)(m + 4 * u) * ldl + l];
+        if (a2) v[u] = fmaf(v[u], cp, fmaf(p.A2[(size_t)(m + 4 * u) * p.lda2 + l], cq, cr));
         const float* srow = Sm + (size_t)(m + 4 * u) * lds_;
 #pragma unroll
         for (int q = 0; q < 4; ++q) sv[u][q] = (q < Sn) ? srow[q] : 0.f;
@@ -1798,7 +1803,8 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(const spgan_gemm_tn
         for (int q = 0; q < 4; ++q) acc[q] = fmaf(v[u], sv[u][q], acc[q]);
     }
     for (; m < mend; m += 4) {
-      const float v = Lm[(size_t)m * ldl + l];
+      float v = Lm[(size_t)m * ldl + l];
+      if (a2) v = fmaf(v, cp, fmaf(p.A2[(size_t)m * p.lda2 + l], cq, cr));
       const float* srow = Sm + (size_t)m * lds_;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -1832,7 +1838,9 @@ template <int BMODE>
 int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
   int splits, rows;
   tn_plan(a.M, a.Na, a.Nb, &splits, &rows);
-  if (BMODE == SPGAN_A_PLAIN && !a.a_scale && tn_skinny(a.Na, a.Nb)) {
+  // the streaming kernels: no prologues -- except the two-tensor A operand on the wide side (a lazy BatchNorm-backward tensor against 3 input columns)
+  if (BMODE == SPGAN_A_PLAIN && tn_skinny(a.Na, a.Nb) && !a.a_colsum_ws &&
+      (!a.a_scale || (a.A2 && a.Nb <= 4 && !a.a_lrelu && !a.a_sp_val))) {
     const bool narrow_b = a.Nb <= 4;
     const dim3 g(cdiv(narrow_b ? a.Na : a.Nb, 64), splits);
     if (narrow_b) hipLaunchKernelGGL((gemm_tn_skinny_kernel<true>), g, dim3(256), 0, s, a, rows);
@@ -2007,7 +2015,7 @@ extern "C" int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s_) {
   if (a->a_scale) SPGAN_CHECK_ARG(a->a_shift && (!a->a_sp_val || (a->a_sp_arg && a->a_sp_rows > 0 && a->b_mode != SPGAN_A_EDGE)));
   if (a->A2) SPGAN_CHECK_ARG(a->a_scale && a->a_scale2 && !a->a_sp_val && a->lda2 >= a->Na);
   if (a->a_lrelu) SPGAN_CHECK_ARG(a->a_scale && !a->A2 && !a->a_sp_val);
-  if (a->a_colsum_ws) SPGAN_CHECK_ARG(!a->a_sp_val && !(a->b_mode == SPGAN_A_PLAIN && !a->a_scale && tn_skinny(a->Na, a->Nb)));  // not on the streaming kernels
+  if (a->a_colsum_ws) SPGAN_CHECK_ARG(!a->a_sp_val);  // (a streaming-shaped problem with this by-product runs on the MFMA kernel)
   SPGAN_CHECK_ARG(a->M < (1 << 24));  // fast_div domain
   switch (a->b_mode) {
     case SPGAN_A_PLAIN: return launch_tn<SPGAN_A_PLAIN>(*a, s);

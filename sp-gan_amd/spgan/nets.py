@@ -456,14 +456,14 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
         if li > 0:
             pconv, pbn = D_LAYERS[li - 1]
             sc, sh, inv, mu = bns[li - 1]
-            # layer 1's dy (64 channels) feeds a 3-column weight gradient and the 3-column input gradient: kernels without the
-            # two-tensor operand -> materialised; the 128- and 256-channel ones stay lazy (coefficients from the finalize launch)
-            lazy = li - 1 > 0 and ctx["training"] and _lazy_ok(M, sc.numel())
+            # lazy for every layer (coefficients from the finalize launch); layer 1's dy (64 channels) is consumed by the 3-column
+            # weight gradient (the streaming kernel takes the two-tensor operand on its wide side) and the 3-column input gradient
+            lazy = ctx["training"] and _lazy_ok(M, sc.numel())
             g, s0, s1, *coef = ops.gemm_nt_bnbwd(dy, _t(W), ys[li - 1], sc, sh, mu, inv, NEG, **(dict(coef_bn=(P[pbn + ".weight"], M)) if lazy else {}))
             if need_dparams:
                 grads[pbn + ".weight"] = s1; grads[pbn + ".bias"] = s0
             sums = _cat2(s0, s1) if ctx["training"] else torch.zeros(2 * s0.numel(), device=s0.device)
-            dy = ops.Affine2(g, ys[li - 1], coef[0]) if lazy else _bn_bwd(g, ys[li - 1], mu, inv, P[pbn + ".weight"], sums, M, lazy=li - 1 > 0)
+            dy = ops.Affine2(g, ys[li - 1], coef[0]) if lazy else _bn_bwd(g, ys[li - 1], mu, inv, P[pbn + ".weight"], sums, M)
             dys[li - 1] = dy; gs[li - 1] = g; sums_all[li - 1] = sums
     dx_cm = None
     if need_dx:

@@ -283,7 +283,14 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
     edge = (idx[M,k], ebias[K]) with pro: rows are edges, a = lrelu((A[j]-A[i]+ebias)*scale+shift)  (A_EDGE)
     stats=True additionally returns (mean[N], biased var[N]) of the pre-activation output over all M rows.
     exact=True keeps fp32 operands even in fp16-operand mode: for products whose operands are sums over all points (Gram matrices,
-    column sums: they grow with B*N and leave fp16's range at full size) rather than per-point activations."""
+    column sums: they grow with B*N and leave fp16's range at full size) rather than per-point activations.
+    A may be an Affine2 operand (a lazy BatchNorm-backward tensor; plain products only: no pro / edge)."""
+    a2 = A if isinstance(A, Affine2) else None
+    if a2 is not None:
+        if pro is not None or edge is not None or a2.shape[0] <= 64 or M is not None:
+            a2, A = None, A.dense()
+        else:
+            A = a2.g
     _rowmajor2d(A, "A"); _rowmajor2d(W, "W")
     N, K = W.shape
     a = GemmNTArgs(); a.mfma_f16 = 0 if exact else _MFMA_F16[0]; a.tile_hint = _NT_TILE_HINT[0]
@@ -302,6 +309,10 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
     if pro is not None:
         sc, sh, ps = pro
         a.p_scale = _p(_vec(sc, K, "pro.scale")); a.p_shift = _p(_vec(sh, K, "pro.shift")); a.p_slope = float(ps)
+    if a2 is not None:
+        a.a_mode = A_AFFINE_LRELU
+        a.p_scale = _p(_vec(a2.p, K, "p")); a.p_shift = _p(_vec(a2.r, K, "r")); a.p_slope = 1.0
+        a.A2 = _p(a2.y); a.lda2 = _ld(a2.y); a.p_scale2 = _p(_vec(a2.q, K, "q"))
     if out is None:
         Y = torch.empty((M_, N), dtype=torch.float32, device=A.device)
     else:
@@ -659,7 +670,7 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     a.mfma_lp = 1 if (_MFMA_F16[0] == 1 and not exact and M_ >= TN_LP_MIN_ROWS) else 0
     splits = lib.spgan_gemm_tn_splits(M_, Na, Nb)
     cs_out = cs_ws = None
-    streaming = (Na <= 4 or Nb <= 4) and Na <= 2048 and Nb <= 2048 and pro is None and edge is None and sa is None and a2 is None and a_pro is None
+    streaming = (Na <= 4 or Nb <= 4) and Na <= 2048 and Nb <= 2048 and pro is None and edge is None and sa is None and a_pro is None   # 3-column layers: the streaming kernel + a colsum pass stay cheaper
     if with_colsum and sa is not None:
         raise NotImplementedError("gemm_tn(with_colsum=True) with a SparseAffine operand")
     if with_colsum and not streaming:

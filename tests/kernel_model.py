@@ -106,6 +106,7 @@ def gemm_nt(A, W, bias=None, *, pro=None, edge=None, rowbias=None, rows_per_grou
         gamma, beta, rm, rv = bn
         return y, bn_prepare(mean, var, gamma, beta, y.shape[0] * count_rep, True, rm, rv)
     N, K = W.shape
+    A = _dense(A)
     a = _operand(A, pro, edge, K)
     if M is not None:
         a = a[:M]

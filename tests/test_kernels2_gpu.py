@@ -400,6 +400,12 @@ def test_bn_bwd_lazy_operand(ops, M, C, Nout):
     bsc, bsh, mu2, inv2 = rnd("lz.bsc%d" % Nout, (Nout,)), rnd("lz.bsh%d" % Nout, (Nout,), 0.3), rnd("lz.mu%d" % Nout, (Nout,), 0.2), rnd("lz.inv%d" % Nout, (Nout,)).abs() + 0.5
     for a_, b_ in zip(ops.gemm_nt_bnbwd(lazy, W, prev, bsc, bsh, mu2, inv2, 0.01), ops.gemm_nt_bnbwd(dense, W, prev, bsc, bsh, mu2, inv2, 0.01)):
         close(a_, b_, rtol=5e-6, atol=2e-5, what="gemm_nt_bnbwd A2")
+    # 3-column consumers (D's first layer): the streaming weight-gradient kernel and the plain input-gradient product
+    x3 = rnd("lz.x3%d" % M, (M, 3))
+    close(ops.gemm_tn(lazy, x3), ops.gemm_tn(dense, x3), rtol=5e-6, atol=1e-5, what="streaming gemm_tn A2")
+    W3 = rnd("lz.W3%d" % C, (3, C), 0.2)
+    close(ops.gemm_nt(lazy, W3), ops.gemm_nt(dense, W3), rtol=5e-6, atol=1e-5, what="gemm_nt A2 (3 output columns)")
+    close(ops.gemm_nt(lazy, W), ops.gemm_nt(dense, W), rtol=5e-6, atol=1e-5, what="gemm_nt A2")
     # the finalize launch of a BNBWD product emits the NEXT lazy operand's coefficients (coef_bn)
     gam2 = rnd("lz.gam2%d" % Nout, (Nout,)).abs() + 0.5
     g2, s0, s1, coef = ops.gemm_nt_bnbwd(dense, W, prev, bsc, bsh, mu2, inv2, 0.01, coef_bn=(gam2, M))
