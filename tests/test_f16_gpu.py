@@ -67,6 +67,18 @@ def test_gemm_tn_bf16_operands(f16, M, Na, Nb):
     out = rnd("tb.out%d.%d" % (Na, Nb), (Na, Nb)) * 1e-4
     want = 0.5 * out + (r(A).double().t() @ r(Bm).double()).float()
     close(ops.gemm_tn(A, Bm, out=out.clone(), beta=0.5), want, rtol=3e-5, atol=1e-12, what="beta accumulate")
+    # by-products and operand modes of this round on the bf16 kernel: fp32 column sums of A, the lazy two-tensor A operand, A-side LeakyReLU
+    o2, cs = ops.gemm_tn(A, Bm, with_colsum=True)
+    close(o2, (r(A).double().t() @ r(Bm).double()).float(), rtol=3e-5, atol=1e-12, what="with_colsum: product"); close(cs, A.double().sum(0).float(), rtol=3e-6, atol=1e-10, what="with_colsum: fp32 column sums")
+    if Na % 4 == 0:
+        y = rnd("tb.y%d.%d" % (M, Na), (M, Na)) * 1e-7
+        coef = torch.stack([rnd("tb.p%d" % Na, (Na,)).abs() + 0.5, rnd("tb.q%d" % Na, (Na,), 0.3), rnd("tb.r%d" % Na, (Na,), 1e-8)])
+        lazy = ops.Affine2(A, y, coef)
+        d = lazy.dense()
+        close(ops.gemm_tn(lazy, Bm), (r(d).double().t() @ r(Bm).double()).float(), rtol=5e-5, atol=1e-12, what="lazy A operand")
+        asc, ash = rnd("tb.asc%d" % Na, (Na,)).abs() + 0.5, rnd("tb.ash%d" % Na, (Na,), 1e-8)
+        a_act = torch.where(A * asc + ash > 0, A * asc + ash, (A * asc + ash) * 0.01)
+        close(ops.gemm_tn(A, Bm, a_pro=(asc, ash, 0.01)), (r(a_act).double().t() @ r(Bm).double()).float(), rtol=5e-5, atol=1e-12, what="A-side LeakyReLU")
     short = ops.gemm_tn(A[:4096], Bm[:4096])                                     # below TN_LP_MIN_ROWS: fp32 operands
     close(short, km.gemm_tn(A[:4096], Bm[:4096]), rtol=2e-5, atol=1e-12, what="short reduction stays fp32")
 
