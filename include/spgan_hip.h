@@ -162,7 +162,13 @@ typedef struct spgan_gemm_nt_args {
    * tensor dy = p*g + q*y + r (spgan_bn_bwd_coeffs) evaluated on the operand load of its consumers instead of by a pass of its own.
    * Epilogues LINEAR / BNBWD / EDGE_BNBWD; M > 64; 128-row kernels only. */
   const float* A2; int lda2; const float* p_scale2;
+  /* 16-bit operand / result storage, "f16" operand mode (mfma_f16 == 1) only:
+   * a_half = 1: A points at IEEE fp16 values (lda in elements; a_mode PLAIN): staged into LDS as they are (128-row kernels);
+   * y_bf16 = 1: Y points at bfloat16 storage (ldy in elements; LINEAR epilogue of the 256 x 256-tile kernel: spgan_gemm_nt_y16_ok()). */
+  int a_half, y_bf16;
 } spgan_gemm_nt_args;
+/* 1 when spgan_gemm_nt will honour y_bf16 for this problem (it runs on the 256 x 256-tile kernel with fp16 operands) */
+int spgan_gemm_nt_y16_ok(const spgan_gemm_nt_args* a);
 /* 1 when spgan_gemm_nt will run this problem on the M <= 64 kernel, i.e. when `tail.enabled` is acceptable (else the launch
  * returns SPGAN_EINVAL for a tail request) */
 int spgan_gemm_nt_owns_columns(const spgan_gemm_nt_args* a);
@@ -218,6 +224,8 @@ typedef struct spgan_gemm_tn_args {
    * -- a BatchNorm + LeakyReLU'd activation as the A operand without materialising it (the Gram matrix a^T a of the collapsed
    * backward takes the same pre-activation tensor on both sides).  0: the affine map alone. */
   int a_lrelu; float a_slope;
+  /* b_half = 1 (with mfma_lp == 1, b_mode PLAIN): B points at IEEE fp16 values (ldb in elements). */
+  int b_half;
 } spgan_gemm_tn_args;
 
 /* Coefficient vectors of the BatchNorm backward as an affine combination of two tensors (Generator.py:58-67 / Discriminator.py:57-79
@@ -330,6 +338,15 @@ int spgan_edge_attend_fwd(const float* h2pre, const float* sc2, const float* sh2
                           float* T, spgan_stream_t s);
 /* Backward of edge_attend: g2/gy = gradients w.r.t. the two BatchNorm outputs, and plain-sum partials
  * [ceil(M/spgan_edge_attend_bwd_tile_points())][2F][2]: col f -> (sum g2, sum g2*xhat2), col F+f -> (sum gy, sum gy*xhaty). */
+/* 16-bit storage variants for the "f16" operand mode (BASELINE configs[4]): T is written as IEEE fp16 (consumed by conv_out's products
+ * with spgan_gemm_nt_args.a_half / spgan_gemm_tn_args.b_half), dT is read as bfloat16 (written by spgan_gemm_nt_args.y_bf16: a gradient
+ * keeps fp32's exponent range).  k = 10 and F % 4 == 0 only; everything else as the fp32 entry points. */
+int spgan_edge_attend_fwd_h(const float* h2pre, const float* sc2, const float* sh2, const float* PQR, int ld, int H, int F, const int32_t* idx,
+                            int M, int k, const float* bx, const float* scx, const float* shx, float slope, uint16_t* T_f16, spgan_stream_t s);
+int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
+                            const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k, const float* bx,
+                            const float* scx, const float* shx, const float* meanx, const float* invx, float slope, float* g2, float* gy,
+                            float* partials, spgan_stream_t s);
 int spgan_edge_attend_bwd_tile_points(void);
 int spgan_edge_attend_bwd(const float* dT, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
                           const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k,

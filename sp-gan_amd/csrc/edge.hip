@@ -245,7 +245,27 @@ __device__ __forceinline__ void stv(float* p, const float (&o)[VEC]) {
   *reinterpret_cast<typename VecT<VEC>::T*>(p) = v;
 }
 
-template <int K, int VEC>
+// 16-bit storage of the two tensors only GEMMs consume / produce (spgan_edge_attend_fwd_h / _bwd_b; the "f16" operand mode):
+// T is written as fp16 (an activation of magnitude O(1): what the fp16 MFMA would round it to anyway), dT is read as bfloat16
+// (a gradient: needs fp32's exponent range).
+template <int VEC>
+__device__ __forceinline__ void stv_h(_Float16* p, const float (&o)[VEC]) {
+  _Float16 h[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) h[q] = (_Float16)o[q];
+  if (VEC == 2) *reinterpret_cast<unsigned*>(p) = *reinterpret_cast<const unsigned*>(h);
+  else p[0] = h[0];
+}
+template <int VEC>
+__device__ __forceinline__ void ldv_b(const __bf16* p, float (&o)[VEC]) {
+  __bf16 h[VEC];
+  if (VEC == 2) *reinterpret_cast<unsigned*>(h) = *reinterpret_cast<const unsigned*>(p);
+  else h[0] = p[0];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) o[q] = (float)h[q];
+}
+
+template <int K, int VEC, int TH = 0>
 __global__ __launch_bounds__(256) void edge_attend_fwd_k_kernel(const float* __restrict__ h2, const float* __restrict__ sc2,
                                                                 const float* __restrict__ sh2, const float* __restrict__ PQR, int ld, int H,
                                                                 int F, const int32_t* __restrict__ idx, int M, const float* __restrict__ bx,
@@ -290,11 +310,14 @@ __global__ __launch_bounds__(256) void edge_attend_fwd_k_kernel(const float* __r
       }
     }
 #pragma unroll
-    for (int r = 0; r < K; ++r) stv<VEC>(T + ((size_t)i * K + r) * F + f, z[r]);
+    for (int r = 0; r < K; ++r) {
+      if (TH) stv_h<VEC>(reinterpret_cast<_Float16*>(T) + ((size_t)i * K + r) * F + f, z[r]);
+      else stv<VEC>(T + ((size_t)i * K + r) * F + f, z[r]);
+    }
   }
 }
 
-template <int K, int VEC>
+template <int K, int VEC, int TB = 0>
 __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
     const float* __restrict__ dT, const float* __restrict__ h2, const float* __restrict__ sc2, const float* __restrict__ sh2,
     const float* __restrict__ mean2, const float* __restrict__ inv2, const float* __restrict__ PQR, int ld, int H, int F,
@@ -324,7 +347,8 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
         for (int r = 0; r < K; ++r) {
           const int j = __builtin_amdgcn_readfirstlane(idx[(size_t)i * K + r]);
           ldv<VEC>(h2 + ((size_t)i * K + r) * F + f, hp[r]);
-          ldv<VEC>(dT + ((size_t)i * K + r) * F + f, d[r]);
+          if (TB) ldv_b<VEC>(reinterpret_cast<const __bf16*>(dT) + ((size_t)i * K + r) * F + f, d[r]);
+          else ldv<VEC>(dT + ((size_t)i * K + r) * F + f, d[r]);
           ldv<VEC>(PQR + (size_t)j * ld + H + f, yp[r]);
         }
         float o2[K][VEC], oy[K][VEC];
@@ -546,6 +570,35 @@ extern "C" int spgan_edge_attend_fwd(const float* h2pre, const float* sc2, const
   else
     hipLaunchKernelGGL(edge_attend_fwd_kernel, dim3(cdiv(M, EA_PT)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, k,
                        bx, scx, shx, slope, T);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_edge_attend_fwd_h(const float* h2pre, const float* sc2, const float* sh2, const float* PQR, int ld, int H, int F,
+                                       const int32_t* idx, int M, int k, const float* bx, const float* scx, const float* shx, float slope,
+                                       uint16_t* T_f16, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(h2pre && sc2 && sh2 && PQR && idx && bx && scx && shx && T_f16 && M > 0 && ld >= H + 2 * F);
+  SPGAN_CHECK_ARG(k == 10 && F % 4 == 0);   // the k = 10 kernels only; rows of T stay 8-byte aligned for the consumers' loads
+  if (((ld | H) % 2 == 0) && F % 128 == 0)
+    hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 2, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, bx,
+                       scx, shx, slope, reinterpret_cast<float*>(T_f16));
+  else
+    hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 1, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, bx,
+                       scx, shx, slope, reinterpret_cast<float*>(T_f16));
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
+                                       const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k,
+                                       const float* bx, const float* scx, const float* shx, const float* meanx, const float* invx,
+                                       float slope, float* g2, float* gy, float* partials, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dT_bf16 && h2pre && sc2 && sh2 && mean2 && inv2 && PQR && idx && bx && scx && shx && meanx && invx && g2 && gy && partials);
+  SPGAN_CHECK_ARG(M > 0 && ld >= H + 2 * F && k == 10 && F % 4 == 0);
+  if (((ld | H) % 2 == 0) && F % 128 == 0)
+    hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 2, 1>), dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, reinterpret_cast<const float*>(dT_bf16),
+                       h2pre, sc2, sh2, mean2, inv2, PQR, ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
+  else
+    hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 1, 1>), dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, reinterpret_cast<const float*>(dT_bf16),
+                       h2pre, sc2, sh2, mean2, inv2, PQR, ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
   return spgan_launch_status();
 }
 

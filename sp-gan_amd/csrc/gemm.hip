@@ -27,6 +27,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -200,7 +201,9 @@ __device__ __forceinline__ void col_reduce2(float (&pa)[Geo<CFG>::TJ], float (&p
 // v_mfma_f32_32x32x8_f16 (fp32 accumulate): BASELINE configs[4] "fp16 MFMA MLPs".  Global loads, prologues and epilogues stay
 // fp32; an LDS row holds the 32 k-values of the tile as 16 words + 2 words of padding (stride 18 == 2 mod 16: the 32 rows x
 // 8-byte fragment reads of a half-wave are conflict-free), a fragment read (4 halfs) feeds ONE MFMA of k = 8.
-template <int AMODE, int EPI, int CFG, int DB, int FAST, int F16 = 0>
+// AH = 1 (F16 = 1, plain A, straight-line loads only; spgan_gemm_nt_args.a_half): the A operand lies in memory as fp16 already (the
+// EdgeBlock's T, written by spgan_edge_attend_fwd_h): a staging slot is one 8-byte load that goes to LDS as it is.
+template <int AMODE, int EPI, int CFG, int DB, int FAST, int F16 = 0, int AH = 0>
 __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_args p_) {  // <= 168 VGPRs: 3 waves/SIMD
   // The argument block stays in the kernarg segment (scalar loads): it is never copied or modified -- a modified copy of a
   // struct this size lands in scratch.  Only the three operand pointers of a batched product are adjusted, as locals.
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   constexpr int LDX = F16 == 2 ? LDX3 : (F16 ? 18 : LDT);   // LDS row stride in 4-byte words
   constexpr int KK = F16 == 2 ? BK / 16 : (F16 ? BK / 8 : BK / 4);  // fragment reads per k-tile
   static_assert(!(F16 && AMODE == A_AFFINE_SPARSE), "the LDS patch path of the sparse addend is fp32 only");
+  static_assert(!AH || (F16 == 1 && FAST && AMODE == SPGAN_A_PLAIN), "fp16-stored A: plain operand, fp16 MFMA, aligned problems");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [NB][BM*LDX]
   float* Bs = smem + NB * BM * LDX;  // [NB][BN*LDX]
@@ -309,6 +313,11 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       const int kc = kok ? k : 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if (AH) {
+          const float2 h = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(pA) + (offA[i] + (unsigned)kc));
+          ra[i].x = h.x;
+          ra[i].y = h.y;
+        } else
         ra[i] = ldrow(pA, offA[i], kc, true);
         if (AMODE == SPGAN_A_EDGE || AMODE == A_AFFINE2) ra2[i] = ldrow(pA2, offC[i], kc, true);
       }
@@ -395,7 +404,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       for (int i = 0; i < BSLOT; ++i) st_row4b3(&b[(lrow + 32 * i) * LDX + (lc4 >> 1)], rb[i]);
     } else if (F16) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) st_row4h(&a[(lrow + 32 * i) * LDX + (lc4 >> 1)], ra[i]);
+      for (int i = 0; i < 4; ++i) {
+        if (AH) *reinterpret_cast<float2*>(&a[(lrow + 32 * i) * LDX + (lc4 >> 1)]) = make_float2(ra[i].x, ra[i].y);
+        else st_row4h(&a[(lrow + 32 * i) * LDX + (lc4 >> 1)], ra[i]);
+      }
 #pragma unroll
       for (int i = 0; i < BSLOT; ++i) st_row4h(&b[(lrow + 32 * i) * LDX + (lc4 >> 1)], rb[i]);
     } else {
@@ -434,15 +446,23 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
             acc[i][j] = c;
           }
       } else if (F16) {
-        f16x4 ah[TI], bh[TJ];
+        // two 8-byte fragment reads (k-groups kk and kk+1 of this lane half) feed ONE v_mfma_f32_32x32x16_f16: gfx950's k = 16 form
+        // issues in the cycles the k = 8 one takes (any assignment of the tile's k values to MFMA k-slots is legal as long as both
+        // operands use the same one); kk0/kk1 are even (KK = 4).
+        if (kk & 1) continue;
+        f16x8 ah[TI], bh[TJ];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) ah[i] = *reinterpret_cast<const f16x4*>(a + i * 32 * LDX + kk * 4);
+        for (int i = 0; i < TI; ++i)
+          ah[i] = __builtin_shufflevector(*reinterpret_cast<const f16x4*>(a + i * 32 * LDX + kk * 4),
+                                          *reinterpret_cast<const f16x4*>(a + i * 32 * LDX + kk * 4 + 4), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) bh[j] = *reinterpret_cast<const f16x4*>(b + j * 32 * LDX + kk * 4);
+        for (int j = 0; j < TJ; ++j)
+          bh[j] = __builtin_shufflevector(*reinterpret_cast<const f16x4*>(b + j * 32 * LDX + kk * 4),
+                                          *reinterpret_cast<const f16x4*>(b + j * 32 * LDX + kk * 4 + 4), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       } else {
         float2 af[TI], bf[TJ];
 #pragma unroll
@@ -564,7 +584,16 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           }
         }
       }
-      if (pY) {
+      if (F16 == 1 && pY && p.y_bf16) {   // bfloat16 result storage (the EdgeBlock's dT; no activation: checked on the host)
+        __bf16* yb = reinterpret_cast<__bf16*>(pY) + (size_t)rbase * p.ldy + cbase;
+        const unsigned ldy = (unsigned)p.ldy;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = (__bf16)acc[i][j][r];
+      } else if (pY) {
         float* yb = pY + (size_t)rbase * p.ldy + cbase;
         const unsigned ldy = (unsigned)p.ldy;
         auto store_all = [&](auto actf) {
@@ -604,6 +633,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
             float o = v;
             if (p.act == SPGAN_ACT_LRELU) o = lrelu_f(v, p.act_slope);
             else if (p.act == SPGAN_ACT_TANH) o = tanhf(v);
+            if (F16 == 1 && p.y_bf16) reinterpret_cast<__bf16*>(pY)[(size_t)row * p.ldy + col] = (__bf16)o;
+            else
             pY[(size_t)row * p.ldy + col] = o;
           }
         }
@@ -938,18 +969,18 @@ constexpr size_t nt_lds_bytes() {
          sizeof(float);
 }
 
-template <int AMODE, int EPI, int CFG, int DB, int FAST, int F16 = 0>
+template <int AMODE, int EPI, int CFG, int DB, int FAST, int F16 = 0, int AH = 0>
 void launch_nt_cfg(const spgan_gemm_nt_args& a, hipStream_t s) {
   constexpr int BN = Geo<CFG>::WGN * Geo<CFG>::TJ * 32;
   constexpr size_t lds = nt_lds_bytes<CFG, DB, F16>();
   static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16, AH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int tm8 = cdiv(cdiv(a.M, BM), 8) * 8;
   const int batch = (AMODE == SPGAN_A_PLAIN && EPI == SPGAN_EPI_LINEAR && a.batch > 1) ? a.batch : 1;
-  hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16>), dim3(tm8 * cdiv(a.N, BN), batch), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16, AH>), dim3(tm8 * cdiv(a.N, BN), batch), dim3(256), lds, s, a);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -1100,6 +1131,13 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   if (AMODE == SPGAN_A_EDGE) fast = fast && al16(a.e_bias);
   if (AMODE == A_AFFINE_SPARSE) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
   if (AMODE == A_AFFINE2) fast = fast && al16(a.A2) && (a.lda2 % 4 == 0) && al16(a.p_scale2);
+  if constexpr (AMODE == SPGAN_A_PLAIN && EPI == SPGAN_EPI_LINEAR) {
+    if (a.a_half) {  // fp16-stored A (validated in spgan_gemm_nt: fp16 mode, aligned, N > 32, M > 64, one product): the 128-row kernels only
+      if (a.N > 64 && a.K >= 512) launch_nt_cfg<AMODE, EPI, 0, 1, 1, 1, 1>(a, s);
+      else launch_nt_cfg<AMODE, EPI, 1, 0, 1, 1, 1>(a, s);
+      return spgan_launch_status();
+    }
+  }
   if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE2 && EPI != SPGAN_EPI_EDGE_BNBWD) {
     if (spgan_nt_wide_selected(a)) return spgan_launch_nt_wide(a, s);  // large aligned products: 256 x 256 tiles (gemm_wide.hip)
   }
@@ -1421,6 +1459,7 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
     if (a2) asc2 = *reinterpret_cast<const float4*>(p.a_scale2 + a0 + ac);
   }
   float4 ra2[4];
+  const bool bh = BMODE == SPGAN_A_PLAIN && p.b_half;     // B lies in memory as fp16 (the EdgeBlock's T: spgan_edge_attend_fwd_h)
   const bool acs = p.a_colsum_ws != nullptr && tb == 0;   // fp32 column sums of the transformed A operand (before the bf16 rounding)
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int mb) {
@@ -1436,6 +1475,10 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
       if (BMODE == SPGAN_A_EDGE) {
         rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)p.e_idx[mc] * p.ldb + cc);
         rb2[i] = *reinterpret_cast<const float4*>(p.B + (size_t)fast_div(mc, p.e_k) * p.ldb + cc);
+      } else if (bh) {   // fp16-stored B: 4 values = 8 bytes, kept raw until sstore
+        const float2 h = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(p.B) + (size_t)mc * p.ldb + cc);
+        rb[i].x = h.x;
+        rb[i].y = h.y;
       } else {
         rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)mc * p.ldb + cc);
       }
@@ -1468,6 +1511,11 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
 #pragma unroll
     for (int i = 0; i < RP; ++i) {
       float4 v = rb[i];
+      if (bh) {
+        const float2 raw = make_float2(rb[i].x, rb[i].y);
+        const f16x4 h = *reinterpret_cast<const f16x4*>(&raw);
+        v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+      }
       const bool ok = mb + br + i < mend && bok;
       if (BMODE != SPGAN_A_PLAIN && ok) {
         if (BMODE == SPGAN_A_EDGE) {
@@ -1839,7 +1887,7 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
   int splits, rows;
   tn_plan(a.M, a.Na, a.Nb, &splits, &rows);
   // the streaming kernels: no prologues -- except the two-tensor A operand on the wide side (a lazy BatchNorm-backward tensor against 3 input columns)
-  if (BMODE == SPGAN_A_PLAIN && tn_skinny(a.Na, a.Nb) && !a.a_colsum_ws &&
+  if (BMODE == SPGAN_A_PLAIN && tn_skinny(a.Na, a.Nb) && !a.a_colsum_ws && !a.b_half &&
       (!a.a_scale || (a.A2 && a.Nb <= 4 && !a.a_lrelu && !a.a_sp_val))) {
     const bool narrow_b = a.Nb <= 4;
     const dim3 g(cdiv(narrow_b ? a.Na : a.Nb, 64), splits);
@@ -1848,10 +1896,12 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
     if (!a.defer_reduce) launch_reduce(a, splits, s);
     return spgan_launch_status();
   }
+  if (a.b_half && (BMODE != SPGAN_A_PLAIN || a.mfma_lp != 1 || a.a_sp_val)) return SPGAN_EINVAL;  // fp16-stored B: the bf16 kernel only
   const int TB = tn_tb(a.Nb);
   const dim3 grid(cdiv(a.Na, TA) * cdiv(a.Nb, TB), splits);
   const bool fast = (a.Na % 4 == 0) && (a.Nb % 4 == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && al16(a.A) && al16(a.B) &&
                     (!a.A2 || (al16(a.A2) && a.lda2 % 4 == 0));
+  if (a.b_half && !fast) return SPGAN_EINVAL;
   if (fast && a.mfma_lp == 1) {  // bf16 operands (aligned problems only; others keep the fp32 kernel)
     if (TB == 128) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 0>), grid, dim3(256), 0, s, a, rows);
     else if (TB == 64) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 1>), grid, dim3(256), 0, s, a, rows);
@@ -1898,6 +1948,16 @@ extern "C" int spgan_gemm_nt_owns_columns(const spgan_gemm_nt_args* a) {
   return fast ? 1 : 0;
 }
 
+// y_bf16 is honoured by the fp16-operand kernels' LINEAR epilogues (128-row and 256 x 256): everything fp16 mode sends there
+extern "C" int spgan_gemm_nt_y16_ok(const spgan_gemm_nt_args* a) {
+  if (!a || a->mfma_f16 != 1 || a->epi_mode != SPGAN_EPI_LINEAR || a->act != SPGAN_ACT_NONE || a->batch > 1 || a->M <= 64 || a->N <= 32) return 0;
+  if (a->sp_val || a->a_mode == SPGAN_A_EDGE) return 0;   // the sparse-addend kernels have no fp16 form
+  bool fast = (a->K % 4 == 0) && (a->lda % 4 == 0) && (a->ldw % 4 == 0) && al16(a->A) && al16(a->W);
+  if (a->a_mode != SPGAN_A_PLAIN) fast = fast && al16(a->p_scale) && al16(a->p_shift);
+  if (a->A2) fast = fast && al16(a->A2) && (a->lda2 % 4 == 0) && al16(a->p_scale2);
+  return fast ? 1 : 0;
+}
+
 extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   SPGAN_CHECK_ARG(a && a->A && a->W && a->M > 0 && a->N > 0 && a->K > 0);
@@ -1923,6 +1983,12 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
     if (a->epi_mode == SPGAN_EPI_MASK_OUT) SPGAN_CHECK_ARG(f.mode == 1);  // column sums of a masked product
     if (f.mode == 1) SPGAN_CHECK_ARG(f.out0 && f.out1);
     if (f.scale) SPGAN_CHECK_ARG(f.mode == 0 && f.shift && f.invstd && f.mean_out && (!f.rmean || f.rvar));
+  }
+  if (a->a_half || a->y_bf16) {  // 16-bit storage: the fp16-operand kernels, aligned problems, plain linear product
+    SPGAN_CHECK_ARG(a->mfma_f16 == 1 && a->epi_mode == SPGAN_EPI_LINEAR && a->act == SPGAN_ACT_NONE && a->batch <= 1 && !a->tail.enabled &&
+                    a->M > 64 && a->N > 32 && a->K % 4 == 0 && a->lda % 4 == 0 && a->ldw % 4 == 0 && al16(a->A) && al16(a->W));
+    if (a->a_half) SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && !a->A2);
+    if (a->y_bf16) SPGAN_CHECK_ARG(a->Y && spgan_gemm_nt_y16_ok(a));
   }
   switch (a->epi_mode) {
     case SPGAN_EPI_LINEAR:

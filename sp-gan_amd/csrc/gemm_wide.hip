@@ -20,6 +20,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -153,16 +154,21 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_g
     const float* b = Bs + buf * WN * LDX + (wn * TJ * 32 + l31) * LDX + 2 * lh;
 #pragma unroll
     for (int kk = kk0; kk < kk1; ++kk) {
-      if (F16) {  // one 8-byte read = 4 halfs = the lane's k-operands of ONE k = 8 MFMA
-        f16x4 ah[TI], bh[TJ];
+      if (F16) {  // two 8-byte reads = 8 halfs = the lane's k-operands of ONE v_mfma_f32_32x32x16_f16 (k-groups kk, kk+1; kk0/kk1 even)
+        if (kk & 1) continue;
+        f16x8 ah[TI], bh[TJ];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) ah[i] = *reinterpret_cast<const f16x4*>(a + i * 32 * LDX + kk * 4);
+        for (int i = 0; i < TI; ++i)
+          ah[i] = __builtin_shufflevector(*reinterpret_cast<const f16x4*>(a + i * 32 * LDX + kk * 4),
+                                          *reinterpret_cast<const f16x4*>(a + i * 32 * LDX + kk * 4 + 4), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) bh[j] = *reinterpret_cast<const f16x4*>(b + j * 32 * LDX + kk * 4);
+        for (int j = 0; j < TJ; ++j)
+          bh[j] = __builtin_shufflevector(*reinterpret_cast<const f16x4*>(b + j * 32 * LDX + kk * 4),
+                                          *reinterpret_cast<const f16x4*>(b + j * 32 * LDX + kk * 4 + 4), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         continue;
       }
       float2 af[TI], bf[TJ];
@@ -226,7 +232,16 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_g
         }
       }
     }
-    if (p.Y) {
+    if (F16 && p.Y && p.y_bf16) {   // bfloat16 result storage (the EdgeBlock's dT; no activation: checked on the host)
+      __bf16* yb = reinterpret_cast<__bf16*>(p.Y) + (size_t)rbase * p.ldy + cbase;
+      const unsigned ldy = (unsigned)p.ldy;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = (__bf16)acc[i][j][r];
+    } else if (p.Y) {
       float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
       const unsigned ldy = (unsigned)p.ldy;
       auto store_all = [&](auto actf) {

@@ -695,7 +695,8 @@ def _edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int
     W2, b2 = _w2(P[pre + ".conv_w.3.weight"]), P[pre + ".conv_w.3.bias"]
     h2pre, bn2 = _gemm_bn(PQR[:, :H], W2, b2, P, bufs, pre + ".conv_w.4", E, training, update_running, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1),
                           **({"count_rep": count_rep} if training and count_rep > 1 else {}))
-    T = ops.edge_attend_fwd(h2pre, bn2[0], bn2[1], PQR, idx, bx, bnx[0], bnx[1], NEG)
+    s16 = ops.storage16(E, F_, k)    # "f16" operand mode at full size: T lives in HBM as float16, dT as bfloat16 (only GEMMs touch them)
+    T = ops.edge_attend_fwd(h2pre, bn2[0], bn2[1], PQR, idx, bx, bnx[0], bnx[1], NEG, half=s16)
     Wo = conv_out_weight_pm(P[pre + ".conv_out.weight"])
     out = ops.gemm_nt(T, Wo, P[pre + ".conv_out.bias"])
     ctx = dict(x=x, idx=idx, B=B, N=N, PQR=PQR, Wcat=Wcat, bn1=bn1, bnx=bnx, bn2=bn2, h2pre=h2pre, T=T, Wo=Wo, H=H, F=F_, k=k, training=training)
@@ -714,7 +715,7 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     # conv_out
     gwo, g[pre + ".conv_out.bias"] = ops.gemm_tn(dout, ctx["T"], with_colsum=True)      # the bias gradient rides along (column sums of dout)
     g[pre + ".conv_out.weight"] = conv_out_weight_grad_from_pm(gwo, F_, k)
-    dT = ops.gemm_nt(dout, _t(ctx["Wo"]))                                         # [M, k*F]
+    dT = ops.gemm_nt(dout, _t(ctx["Wo"]), out_bf16=ctx["T"].dtype == torch.float16)     # [M, k*F]
     # softmax * conv_x product, both LeakyReLUs
     g2, gy, sums2, sumsy = ops.edge_attend_bwd(dT, ctx["h2pre"], bn2[0], bn2[1], bn2[3], bn2[2], PQR, idx, bx, bnx[0], bnx[1], bnx[3], bnx[2], NEG)
     g[pre + ".conv_w.4.weight"] = sums2[F_:]; g[pre + ".conv_w.4.bias"] = sums2[:F_]

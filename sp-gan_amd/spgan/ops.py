@@ -10,6 +10,7 @@ Shapes: "pm" = point-major [M, C]; idx = int32 [M, k] global row ids.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -66,6 +67,15 @@ def _rowmajor2d(t: Tensor, name: str) -> Tensor:
     _f32(t, name, 2)
     if t.shape[1] > 1 and t.stride(1) != 1:
         raise ValueError("%s must have unit column stride, got strides %s" % (name, t.stride()))
+    return t
+
+
+def _rowmajor2d_as(t: Tensor, name: str, dtype) -> Tensor:
+    """_rowmajor2d for a 16-bit storage tensor (the "f16" operand mode's T / dT): 2-D, unit column stride, on the GPU, of `dtype`."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a tensor on the GPU (spgan has no CPU path)" % name)
+    if t.dtype != dtype or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError("%s must be 2-D %s with unit column stride, got %s %s strides %s" % (name, dtype, t.dtype, tuple(t.shape), t.stride()))
     return t
 
 
@@ -272,8 +282,10 @@ def _finalize(partials: Tensor, groups: int, tpg: int, Cn: int, G: int, mode: in
 
 def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, edge=None, rowbias: Optional[Tensor] = None,
             rows_per_group: int = 0, act: int = ACT_NONE, slope: float = 0.0, stats: bool = False, M: Optional[int] = None, bn=None,
-            out: Optional[Tensor] = None, exact: bool = False, count_rep: int = 1):
+            out: Optional[Tensor] = None, exact: bool = False, count_rep: int = 1, out_bf16: bool = False):
     """Y[M,N] = act( pro(A) @ W^T + bias + rowbias[m // rows_per_group] ).
+    16-bit storage ("f16" operand mode only; see storage16()): A may be a float16 tensor (plain operand: the EdgeBlock's T, written
+    by edge_attend_fwd(half=True)); out_bf16=True returns Y as bfloat16 (plain linear product: the EdgeBlock's dT).
     out  = destination [M,N] (unit column stride; may be a column slice of a wider buffer) instead of a fresh tensor.
     bn = (gamma, beta, running_mean | None, running_var | None): train-mode BatchNorm of Y fused behind the GEMM: returns
          (Y, (scale, shift, invstd, mean)) and updates the running statistics -- column statistics in the epilogue, merged by a
@@ -291,9 +303,17 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
             a2, A = None, A.dense()
         else:
             A = a2.g
-    _rowmajor2d(A, "A"); _rowmajor2d(W, "W")
+    a_half = isinstance(A, torch.Tensor) and A.dtype == torch.float16
+    if a_half:
+        if pro is not None or edge is not None or a2 is not None or exact or _MFMA_F16[0] != 1:
+            raise ValueError("a float16 A is a plain operand of the fp16-operand mode (set_mfma_operands('f16'))")
+        _rowmajor2d_as(A, "A", torch.float16)
+    else:
+        _rowmajor2d(A, "A")
+    _rowmajor2d(W, "W")
     N, K = W.shape
     a = GemmNTArgs(); a.mfma_f16 = 0 if exact else _MFMA_F16[0]; a.tile_hint = _NT_TILE_HINT[0]
+    a.a_half = 1 if a_half else 0
     if edge is not None:
         idx, ebias = edge
         _i32(idx, "idx")
@@ -313,7 +333,12 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
         a.a_mode = A_AFFINE_LRELU
         a.p_scale = _p(_vec(a2.p, K, "p")); a.p_shift = _p(_vec(a2.r, K, "r")); a.p_slope = 1.0
         a.A2 = _p(a2.y); a.lda2 = _ld(a2.y); a.p_scale2 = _p(_vec(a2.q, K, "q"))
-    if out is None:
+    if out_bf16:
+        if out is not None or stats or bn is not None or act != ACT_NONE:
+            raise ValueError("out_bf16 goes with a plain linear product into a fresh tensor")
+        Y = torch.empty((M_, N), dtype=torch.bfloat16, device=A.device)
+        a.y_bf16 = 1
+    elif out is None:
         Y = torch.empty((M_, N), dtype=torch.float32, device=A.device)
     else:
         Y = _rowmajor2d(out, "out")
@@ -604,6 +629,16 @@ def flush_tn() -> None:
         check(lib.spgan_splitk_reduce_multi(C.byref(a), _s()), "splitk_reduce_multi", count=len(chunk))
 
 
+STORAGE16 = [os.environ.get("SPGAN_F16_STORAGE", "1") != "0"]
+
+
+def storage16(E: int, F_: int, k: int) -> bool:
+    """True when the EdgeBlock keeps T as float16 and dT as bfloat16 in HBM: the "f16" operand mode (BASELINE configs[4]) at sizes
+    where its 16-bit kernels are the ones that run.  Both tensors have GEMMs as their only consumer / producer, which round them to
+    16 bits anyway (T: the fp16 MFMA operand of conv_out; dT: one more rounding, bfloat16 for the exponent range of a gradient)."""
+    return STORAGE16[0] and _MFMA_F16[0] == 1 and k == 10 and F_ % 4 == 0 and F_ > 32 and E >= 10 * TN_LP_MIN_ROWS
+
+
 TN_LP_MIN_ROWS = 8192     # "f16" operand mode: weight gradients reduce over >= this many points/edges on the bf16 matrix pipe
 
 
@@ -626,10 +661,18 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
         A = sa.y
     if a2 is not None:
         A = a2.g
-    _rowmajor2d(A, "A"); _rowmajor2d(Bm, "B")
+    b_half = Bm.dtype == torch.float16
+    _rowmajor2d(A, "A")
+    if b_half:
+        _rowmajor2d_as(Bm, "B", torch.float16)
+        if pro is not None or edge is not None or sa is not None:
+            raise ValueError("a float16 B is a plain operand (the EdgeBlock's T)")
+    else:
+        _rowmajor2d(Bm, "B")
     M_, Na = A.shape
     Nb = Bm.shape[1]
     a = GemmTNArgs()
+    a.b_half = 1 if b_half else 0
     if a2 is not None:
         a.a_scale = _p(_vec(a2.p, Na, "p")); a.a_shift = _p(_vec(a2.r, Na, "r"))
         a.A2 = _p(a2.y); a.lda2 = _ld(a2.y); a.a_scale2 = _p(_vec(a2.q, Na, "q"))
@@ -668,6 +711,8 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     defer = bool(defer) and sa is None
     a.defer_reduce = 1 if defer else 0
     a.mfma_lp = 1 if (_MFMA_F16[0] == 1 and not exact and M_ >= TN_LP_MIN_ROWS) else 0
+    if b_half and not a.mfma_lp:
+        raise ValueError("a float16 B needs the bf16 weight-gradient kernel ('f16' operand mode, M >= %d, exact=False)" % TN_LP_MIN_ROWS)
     splits = lib.spgan_gemm_tn_splits(M_, Na, Nb)
     cs_out = cs_ws = None
     streaming = (Na <= 4 or Nb <= 4) and Na <= 2048 and Nb <= 2048 and pro is None and edge is None and sa is None and a_pro is None   # 3-column layers: the streaming kernel + a colsum pass stay cheaper
@@ -1038,8 +1083,9 @@ def edge_stats_bn(PQR: Tensor, idx: Tensor, b1: Tensor, bx: Tensor, bn_w, bn_x, 
 
 
 def edge_attend_fwd(h2pre: Tensor, sc2: Tensor, sh2: Tensor, PQR: Tensor, idx: Tensor, bx: Tensor, scx: Tensor, shx: Tensor,
-                    slope: float) -> Tensor:
-    """T[M, k*F]: softmax over the k neighbours of lrelu(bn(h2pre)) times lrelu(bn((R_i+Q_j)+bx))."""
+                    slope: float, half: bool = False) -> Tensor:
+    """T[M, k*F]: softmax over the k neighbours of lrelu(bn(h2pre)) times lrelu(bn((R_i+Q_j)+bx)).
+    half=True: T is stored as float16 (k = 10, F % 4 == 0; consumed by gemm_nt / gemm_tn in the "f16" operand mode: storage16())."""
     F_ = bx.numel()
     H = PQR.shape[1] - 2 * F_
     _pqr(PQR, H, F_); _i32(idx, "idx")
@@ -1047,10 +1093,11 @@ def edge_attend_fwd(h2pre: Tensor, sc2: Tensor, sh2: Tensor, PQR: Tensor, idx: T
     _f32(h2pre, "h2pre", 2)
     if not h2pre.is_contiguous() or h2pre.shape != (M_ * k, F_):
         raise ValueError("h2pre must be contiguous [M*k, F]")
-    T = torch.empty((M_, k * F_), dtype=torch.float32, device=PQR.device)
-    check(_lib.load().spgan_edge_attend_fwd(_p(h2pre), _p(_vec(sc2, F_, "sc2")), _p(_vec(sh2, F_, "sh2")), _p(PQR), PQR.shape[1], H, F_,
-                                            _p(idx), M_, k, _p(_vec(bx, F_, "bx")), _p(_vec(scx, F_, "scx")), _p(_vec(shx, F_, "shx")),
-                                            float(slope), _p(T), _s()), "edge_attend_fwd", M=M_, k=k, F=F_)
+    T = torch.empty((M_, k * F_), dtype=torch.float16 if half else torch.float32, device=PQR.device)
+    fn = _lib.load().spgan_edge_attend_fwd_h if half else _lib.load().spgan_edge_attend_fwd
+    check(fn(_p(h2pre), _p(_vec(sc2, F_, "sc2")), _p(_vec(sh2, F_, "sh2")), _p(PQR), PQR.shape[1], H, F_, _p(idx), M_, k,
+             _p(_vec(bx, F_, "bx")), _p(_vec(scx, F_, "scx")), _p(_vec(shx, F_, "shx")), float(slope), _p(T), _s()),
+          "edge_attend_fwd", M=M_, k=k, F=F_, half=half)
     return T
 
 
@@ -1060,7 +1107,12 @@ def edge_attend_bwd(dT: Tensor, h2pre: Tensor, sc2, sh2, mean2, inv2, PQR: Tenso
     H = PQR.shape[1] - 2 * F_
     _pqr(PQR, H, F_); _i32(idx, "idx")
     M_, k = idx.shape
-    _f32(dT, "dT", 2); _f32(h2pre, "h2pre", 2)
+    dT_b = dT.dtype == torch.bfloat16           # bfloat16 storage (gemm_nt(out_bf16=True)): k = 10, F % 4 == 0
+    if dT_b:
+        _rowmajor2d_as(dT, "dT", torch.bfloat16)
+    else:
+        _f32(dT, "dT", 2)
+    _f32(h2pre, "h2pre", 2)
     if not (dT.is_contiguous() and h2pre.is_contiguous()) or dT.numel() != M_ * k * F_ or h2pre.numel() != M_ * k * F_:
         raise ValueError("dT / h2pre must be contiguous with M*k*F elements")
     lib = _lib.load()
@@ -1070,7 +1122,7 @@ def edge_attend_bwd(dT: Tensor, h2pre: Tensor, sc2, sh2, mean2, inv2, PQR: Tenso
     gy = torch.empty((M_ * k, F_), dtype=torch.float32, device=PQR.device)
     part = torch.empty((tiles, 2 * F_, 2), dtype=torch.float32, device=PQR.device)
     v = lambda t, n: _p(_vec(t, F_, n))
-    check(lib.spgan_edge_attend_bwd(_p(dT), _p(h2pre), v(sc2, "sc2"), v(sh2, "sh2"), v(mean2, "mean2"), v(inv2, "inv2"), _p(PQR), PQR.shape[1],
+    check((lib.spgan_edge_attend_bwd_b if dT_b else lib.spgan_edge_attend_bwd)(_p(dT), _p(h2pre), v(sc2, "sc2"), v(sh2, "sh2"), v(mean2, "mean2"), v(inv2, "inv2"), _p(PQR), PQR.shape[1],
                                     H, F_, _p(idx), M_, k, v(bx, "bx"), v(scx, "scx"), v(shx, "shx"), v(meanx, "meanx"), v(invx, "invx"),
                                     float(slope), _p(g2), _p(gy), _p(part), _s()), "edge_attend_bwd", M=M_, k=k, F=F_)
     # partial columns are laid out so that the two finalize outputs ARE [sum g2 | sum g2*xhat2] and [sum gy | sum gy*xhaty]

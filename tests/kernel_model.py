@@ -97,7 +97,11 @@ def _operand(A, pro, edge, K):
 
 
 def gemm_nt(A, W, bias=None, *, pro=None, edge=None, rowbias=None, rows_per_group=0, act=ACT_NONE, slope=0.0, stats=False, M=None, bn=None,
-            out=None, exact=False, count_rep=1):
+            out=None, exact=False, count_rep=1, out_bf16=False):
+    if out_bf16:     # bfloat16 storage of the result (ops.gemm_nt(out_bf16=True))
+        return gemm_nt(A, W, bias, pro=pro, edge=edge, rowbias=rowbias, rows_per_group=rows_per_group, M=M).to(torch.bfloat16)
+    if isinstance(A, torch.Tensor) and A.dtype == torch.float16:   # float16-stored operand
+        A = A.float()
     if out is not None:
         out.copy_(gemm_nt(A, W, bias, pro=pro, edge=edge, rowbias=rowbias, rows_per_group=rows_per_group, act=act, slope=slope, M=M))
         return out
@@ -300,6 +304,8 @@ def gemm_tn(A, Bm, *, pro=None, edge=None, out=None, beta=0.0, defer=False, exac
     A = _dense(A)
     if a_pro is not None:
         A = _lrelu(A * a_pro[0] + a_pro[1], a_pro[2])
+    if Bm.dtype == torch.float16:      # float16-stored operand
+        Bm = Bm.float()
     b = _operand(Bm, pro, edge, Bm.shape[1])
     c = A.t() @ b
     if out is None:
@@ -412,17 +418,22 @@ def edge_stats_bn(PQR, idx, b1, bx, bn_w, bn_x, count_rep=1):
             bn_prepare(mean[H:].contiguous(), var[H:].contiguous(), bn_x[0], bn_x[1], E * count_rep, True, bn_x[2], bn_x[3]))
 
 
-def edge_attend_fwd(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope):
+def edge_attend_fwd(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope, half=False):
     M, k = idx.shape
     z2, zy, w, yv, _ = _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope)
-    return (w * yv).reshape(M, k * bx.numel()).contiguous()
+    T = (w * yv).reshape(M, k * bx.numel()).contiguous()
+    return T.half() if half else T
+
+
+def storage16(E, F_, k):
+    return False     # the CPU models run the fp32 operand mode
 
 
 def edge_attend_bwd(dT, h2pre, sc2, sh2, mean2, inv2, PQR, idx, bx, scx, shx, meanx, invx, slope):
     M, k = idx.shape
     F_ = bx.numel()
     z2, zy, w, yv, yp = _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope)
-    d = dT.view(M, k, F_)
+    d = dT.float().view(M, k, F_)
     dw = d * yv
     ds = w * (dw - (dw * w).sum(1, keepdim=True))
     g2 = (ds * torch.where(z2 > 0, 1.0, slope)).reshape(M * k, F_)

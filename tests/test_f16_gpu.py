@@ -83,6 +83,124 @@ def test_gemm_tn_bf16_operands(f16, M, Na, Nb):
     close(short, km.gemm_tn(A[:4096], Bm[:4096]), rtol=2e-5, atol=1e-12, what="short reduction stays fp32")
 
 
+# ------------------------------------------------------------------ 16-bit storage of the EdgeBlock's GEMM-only tensors
+@pytest.mark.parametrize("M,N,K", [(4096, 128, 1280), (2048, 64, 640), (700, 64, 64), (1024, 256, 256)])
+def test_storage16_gemm_nt_half_operand(f16, M, N, K):
+    """A float16-stored A operand (the EdgeBlock's T) goes to LDS as it lies in memory: bit-identical to the same values handed over
+    as float32 (which the 128-row fp16 kernel rounds to the same halfs), bias / statistics epilogues included."""
+    ops = f16
+    A, W, b = rnd("s16.A%d" % K, (M, K)), rnd("s16.W%d.%d" % (N, K), (N, K), 0.1), rnd("s16.b%d" % N, (N,))
+    Ah = A.half()
+    with ops.nt_tile_hint(1):       # the float32-stored twin through the 128-row kernel too (the 256-wide one sums in another order)
+        want = ops.gemm_nt(Ah.float(), W, b)
+        want_s = ops.gemm_nt(Ah.float(), W, b, stats=True)
+    assert torch.equal(ops.gemm_nt(Ah, W, b), want)
+    for g, w in zip(ops.gemm_nt(Ah, W, b, stats=True), want_s):
+        assert torch.equal(g, w)
+    close(ops.gemm_nt(Ah, W, b), km.gemm_nt(Ah, W, b), rtol=1e-3, what="vs model")
+    ops.set_mfma_operands("f32")
+    with pytest.raises(ValueError):
+        ops.gemm_nt(Ah, W, b)       # fp32 operand mode has no 16-bit storage
+    ops.set_mfma_operands("f16")
+    with pytest.raises(ValueError):
+        ops.gemm_nt(Ah, W, b, pro=(rnd("s16.sc", (K,)), rnd("s16.sh", (K,)), 0.01))
+
+
+@pytest.mark.parametrize("hint", [0, 2])
+@pytest.mark.parametrize("M,N,K", [(4096, 1280, 128), (2048, 640, 64), (700, 640, 64), (65536, 1280, 128)])
+def test_storage16_gemm_nt_bf16_result(f16, M, N, K, hint):
+    """out_bf16=True: the float32 result of the same kernel rounded to bfloat16 (round to nearest even) at the store -- both the
+    128-row and the 256 x 256-tile kernel (hint 2; (65536, 1280, 128) is G.EdgeConv2's dT and takes the wide kernel by itself)."""
+    ops = f16
+    if hint == 2 and (M % 256 or N % 256 or K % 32):
+        pytest.skip("not a 256 x 256-tile shape")
+    A, W = rnd("s16.dA%d.%d" % (M, K), (M, K)) * 1e-6, rnd("s16.dW%d.%d" % (N, K), (N, K), 0.1)     # gradient-sized values: bf16 keeps them, fp16 would not
+    with ops.nt_tile_hint(hint):
+        y32 = ops.gemm_nt(A, W)
+        y16 = ops.gemm_nt(A, W, out_bf16=True)
+    assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.bfloat16())
+    assert float(y16.float().abs().max()) > 0
+    with pytest.raises(ValueError):
+        ops.gemm_nt(A, W, out_bf16=True, stats=True)
+    ops.set_mfma_operands("f32")
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(A, W, out_bf16=True)      # refused by the library (SPGAN_EINVAL): only the fp16-operand kernels store bfloat16
+    ops.set_mfma_operands("f16")
+
+
+@pytest.mark.parametrize("M,Na,Nb", [(65536, 128, 1280), (16384, 64, 640), (9000, 64, 640)])
+def test_storage16_gemm_tn_half_operand(f16, M, Na, Nb):
+    """conv_out's weight gradient with T stored as float16: the same bfloat16 operand values as from the float32-stored T, so the
+    same bits; the fp32 by-product (column sums of A) unchanged."""
+    ops = f16
+    A, Bm = rnd("s16.tA%d.%d" % (M, Na), (M, Na)) * 1e-6, rnd("s16.tB%d.%d" % (M, Nb), (M, Nb))
+    Bh = Bm.half()
+    assert torch.equal(ops.gemm_tn(A, Bh), ops.gemm_tn(A, Bh.float()))
+    (c1, s1), (c2, s2) = ops.gemm_tn(A, Bh, with_colsum=True), ops.gemm_tn(A, Bh.float(), with_colsum=True)
+    assert torch.equal(c1, c2) and torch.equal(s1, s2)
+    close(c1, km.gemm_tn(A, Bh), rtol=8e-3, atol=1e-12, what="vs model")
+    with pytest.raises(ValueError):
+        ops.gemm_tn(A, Bh, exact=True)
+    with pytest.raises(ValueError):
+        ops.gemm_tn(A[:4096], Bh[:4096])        # short reductions keep the fp32 kernel, which has no float16 operand
+
+
+@pytest.mark.parametrize("B,N,H,F_", [(2, 200, 32, 64), (2, 130, 64, 128), (1, 77, 16, 36)])
+def test_storage16_edge_attend(f16, B, N, H, F_):
+    """T written as float16 == the float32 T rounded to half (up to the last bit of the float32 value in front of the rounding: the
+    two instantiations may contract their multiply-adds differently); the backward reading a bfloat16 dT == the float32 kernel on the
+    same values."""
+    ops = f16
+    k, M = 10, B * N
+    x = rnd("s16.x%d" % N, (M, 3))
+    idx = ops.knn(x, B, N, k, mode=1)
+    PQR = rnd("s16.PQR%d" % N, (M, H + 2 * F_))
+    bx = rnd("s16.bx%d" % F_, (F_,), 0.1)
+    h2 = rnd("s16.h2%d" % N, (M * k, F_))
+    sc2, sh2 = rnd("s16.sc2%d" % F_, (F_,)).abs() + 0.5, rnd("s16.sh2%d" % F_, (F_,), 0.3)
+    scx, shx = rnd("s16.scx%d" % F_, (F_,)).abs() + 0.5, rnd("s16.shx%d" % F_, (F_,), 0.3)
+    T32 = ops.edge_attend_fwd(h2, sc2, sh2, PQR, idx, bx, scx, shx, 0.01)
+    T16 = ops.edge_attend_fwd(h2, sc2, sh2, PQR, idx, bx, scx, shx, 0.01, half=True)
+    assert T16.dtype == torch.float16
+    close(T16.float(), T32, rtol=6e-4, atol=6e-8, what="float16 T")                  # half a unit in the last place of a half (2^-11), subnormal spacing
+    assert float((T16 == T32.half()).float().mean()) > 0.99
+    dT = (rnd("s16.dT%d" % N, (M, k * F_)) * 1e-6).bfloat16()
+    m2, i2 = rnd("s16.m2%d" % F_, (F_,), 0.2), rnd("s16.i2%d" % F_, (F_,)).abs() + 0.5
+    mx, ix = rnd("s16.mx%d" % F_, (F_,), 0.2), rnd("s16.ix%d" % F_, (F_,)).abs() + 0.5
+    got = ops.edge_attend_bwd(dT, h2, sc2, sh2, m2, i2, PQR, idx, bx, scx, shx, mx, ix, 0.01)
+    want = ops.edge_attend_bwd(dT.float(), h2, sc2, sh2, m2, i2, PQR, idx, bx, scx, shx, mx, ix, 0.01)
+    for g, w, what in zip(got, want, ("g2", "gy", "sums2", "sumsy")):
+        close(g, w, rtol=2e-5, atol=1e-12, what="bfloat16 dT: " + what)
+
+
+def test_storage16_edgeblock_close_to_float32_storage(f16, sp):
+    """The generator's second EdgeBlock (64 -> 128 channels) at a bench-like edge count, "f16" operand mode, with and without 16-bit
+    storage of T / dT: the forward is identical (T is rounded to the same halfs either way), gradients within bfloat16 rounding of dT."""
+    ops = f16
+    B, N, k = 4, 2048, 10
+    assert ops.storage16(B * N * k, 128, k) and not ops.storage16(B * N * k, 128, 20) and not ops.storage16(8192, 128, k)
+    torch.manual_seed(5)
+    blk = sp.EdgeBlock(64, 128, k).cuda().train()
+    x0 = rnd("s16.xb", (B, 64, N))
+    dout = rnd("s16.dout", (B, 128, N)) * 1e-4
+    res = {}
+    for on in (True, False):
+        ops.STORAGE16[0] = on
+        try:
+            x = x0.clone().requires_grad_(True)
+            blk.zero_grad(set_to_none=True)
+            out = blk(x)
+            out.backward(dout)
+            res[on] = (out.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in blk.named_parameters()})
+        finally:
+            ops.STORAGE16[0] = True
+    assert torch.equal(res[True][0], res[False][0])
+    close(res[True][1], res[False][1], rtol=6e-3, what="dx")
+    for n, t in res[False][2].items():
+        close(res[True][2][n], t, rtol=6e-3, atol=1e-9 + 1e-4 * float(t.abs().max()), what=n)
+
+
+
 def test_networks_f16_close_to_f32(sp):
     """fp16 MFMA operands against fp32: the stage in front of EdgeConv2's graph and the discriminator logits stay within fp16-
     operand accuracy; most feature-space kNN rows coincide (a flipped near-tie row changes the downstream features discretely,
