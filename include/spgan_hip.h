@@ -340,13 +340,18 @@ int spgan_edge_attend_fwd(const float* h2pre, const float* sc2, const float* sh2
  * [ceil(M/spgan_edge_attend_bwd_tile_points())][2F][2]: col f -> (sum g2, sum g2*xhat2), col F+f -> (sum gy, sum gy*xhaty). */
 /* 16-bit storage variants for the "f16" operand mode (BASELINE configs[4]): T is written as IEEE fp16 (consumed by conv_out's products
  * with spgan_gemm_nt_args.a_half / spgan_gemm_tn_args.b_half), dT is read as bfloat16 (written by spgan_gemm_nt_args.y_bf16: a gradient
- * keeps fp32's exponent range).  k = 10 and F % 4 == 0 only; everything else as the fp32 entry points. */
+ * keeps fp32's exponent range) and gy -- whose only consumer is spgan_edge_scatter_b -- is written as bfloat16; g2 and the partials stay float.  k = 10 and F % 4 == 0 only; everything else as the fp32 entry points. */
 int spgan_edge_attend_fwd_h(const float* h2pre, const float* sc2, const float* sh2, const float* PQR, int ld, int H, int F, const int32_t* idx,
                             int M, int k, const float* bx, const float* scx, const float* shx, float slope, uint16_t* T_f16, spgan_stream_t s);
 int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
                             const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k, const float* bx,
-                            const float* scx, const float* shx, const float* meanx, const float* invx, float slope, float* g2, float* gy,
-                            float* partials, spgan_stream_t s);
+                            const float* scx, const float* shx, const float* meanx, const float* invx, float slope, float* g2,
+                            uint16_t* gy_bf16, float* partials, spgan_stream_t s);
+/* spgan_edge_scatter with the gy operand as written by spgan_edge_attend_bwd_b (bfloat16; k = 10) */
+int spgan_edge_scatter_b(const float* g1, const uint16_t* gy_bf16, const float* PQR, int ld, int H, int F, const int32_t* idx,
+                         const int32_t* rowptr, const int32_t* src, int M, int k, const float* b1, const float* mean1, const float* inv1,
+                         const float* gam1, const float* sums1, const float* bx, const float* meanx, const float* invx, const float* gamx,
+                         const float* sumsx, float* dPQR, spgan_stream_t s);
 int spgan_edge_attend_bwd_tile_points(void);
 int spgan_edge_attend_bwd(const float* dT, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
                           const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k,

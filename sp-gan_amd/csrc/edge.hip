@@ -265,6 +265,15 @@ __device__ __forceinline__ void ldv_b(const __bf16* p, float (&o)[VEC]) {
   for (int q = 0; q < VEC; ++q) o[q] = (float)h[q];
 }
 
+template <int VEC>
+__device__ __forceinline__ void stv_b(__bf16* p, const float (&o)[VEC]) {
+  __bf16 h[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) h[q] = (__bf16)o[q];
+  if (VEC == 2) *reinterpret_cast<unsigned*>(p) = *reinterpret_cast<const unsigned*>(h);
+  else p[0] = h[0];
+}
+
 template <int K, int VEC, int TH = 0>
 __global__ __launch_bounds__(256) void edge_attend_fwd_k_kernel(const float* __restrict__ h2, const float* __restrict__ sc2,
                                                                 const float* __restrict__ sh2, const float* __restrict__ PQR, int ld, int H,
@@ -393,7 +402,8 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
 #pragma unroll
         for (int r = 0; r < K; ++r) {
           stv<VEC>(g2 + ((size_t)i * K + r) * F + f, o2[r]);
-          stv<VEC>(gy + ((size_t)i * K + r) * F + f, oy[r]);
+          if (TB) stv_b<VEC>(reinterpret_cast<__bf16*>(gy) + ((size_t)i * K + r) * F + f, oy[r]);   // consumed by edge_scatter only
+          else stv<VEC>(gy + ((size_t)i * K + r) * F + f, oy[r]);
         }
       }
     }
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
 // One wave per point, lanes over channels.  The loads of a point's k out-edges (KT > 0: compile-time k) and of its
 // in-edges (chunks of 4) are issued together before they are consumed -- a serial edge loop leaves one row in flight per
 // wave and ran at 1.7 TB/s; sums are still taken in edge order (deterministic).
-template <int KT>
+template <int KT, int GB = 0>
 __global__ __launch_bounds__(256) void edge_scatter_kernel(
     const float* __restrict__ g1, const float* __restrict__ gy, const float* __restrict__ PQR, int ld, int H, int F,
     const int32_t* __restrict__ idx, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, int M, int k_,
@@ -438,6 +448,9 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
   const int lane = threadIdx.x & 63;
   const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // wave-uniform: scalar index loads
   if (j >= M) return;
+  auto ldgy = [&](size_t off) -> float {   // GB: gy lies in memory as bfloat16 (written by spgan_edge_attend_bwd_b)
+    return GB ? (float)reinterpret_cast<const __bf16*>(gy)[off] : gy[off];
+  };
   const int t0 = rowptr[j], t1 = rowptr[j + 1];
   int jo[KU];  // out-edge neighbours
   if (KT > 0) {
@@ -497,7 +510,7 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
 #pragma unroll
       for (int r = 0; r < KU; ++r) {
         qv[r] = PQR[(size_t)jo[r] * ld + H + f];
-        gv[r] = gy[(size_t)(j * KT + r) * F + f];
+        gv[r] = ldgy((size_t)(j * KT + r) * F + f);
       }
 #pragma unroll
       for (int r = 0; r < KU; ++r) {
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
       for (int r = 0; r < k; ++r) {
         const int e = j * k + r;
         const float xh = (((Rj + PQR[(size_t)idx[e] * ld + H + f]) + bb) - mu) * iv;
-        accR += coef * (gy[(size_t)e * F + f] - a0 - xh * a1);
+        accR += coef * (ldgy((size_t)e * F + f) - a0 - xh * a1);
       }
     }
     for (int t = t0; t < t1; t += 4) {
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
       for (int u = 0; u < 4; ++u) {
         const int e = src[min(t + u, t1 - 1)];
         rv[u] = PQR[(size_t)(e / k) * ld + H + F + f];
-        gv[u] = gy[(size_t)e * F + f];
+        gv[u] = ldgy((size_t)e * F + f);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -590,7 +603,8 @@ extern "C" int spgan_edge_attend_fwd_h(const float* h2pre, const float* sc2, con
 extern "C" int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
                                        const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k,
                                        const float* bx, const float* scx, const float* shx, const float* meanx, const float* invx,
-                                       float slope, float* g2, float* gy, float* partials, spgan_stream_t s_) {
+                                       float slope, float* g2, uint16_t* gy_bf16, float* partials, spgan_stream_t s_) {
+  float* gy = reinterpret_cast<float*>(gy_bf16);
   SPGAN_CHECK_ARG(dT_bf16 && h2pre && sc2 && sh2 && mean2 && inv2 && PQR && idx && bx && scx && shx && meanx && invx && g2 && gy && partials);
   SPGAN_CHECK_ARG(M > 0 && ld >= H + 2 * F && k == 10 && F % 4 == 0);
   if (((ld | H) % 2 == 0) && F % 128 == 0)
@@ -618,6 +632,17 @@ extern "C" int spgan_edge_attend_bwd(const float* dT, const float* h2pre, const 
   else
     hipLaunchKernelGGL(edge_attend_bwd_kernel, dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR, ld,
                        H, F, idx, M, k, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_edge_scatter_b(const float* g1, const uint16_t* gy_bf16, const float* PQR, int ld, int H, int F, const int32_t* idx,
+                                    const int32_t* rowptr, const int32_t* src, int M, int k, const float* b1, const float* mean1,
+                                    const float* inv1, const float* gam1, const float* sums1, const float* bx, const float* meanx,
+                                    const float* invx, const float* gamx, const float* sumsx, float* dPQR, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(g1 && gy_bf16 && PQR && idx && rowptr && src && b1 && mean1 && inv1 && gam1 && sums1 && bx && meanx && invx && gamx && sumsx && dPQR);
+  SPGAN_CHECK_ARG(M > 0 && k == 10 && ld >= H + 2 * F);
+  hipLaunchKernelGGL((edge_scatter_kernel<10, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, reinterpret_cast<const float*>(gy_bf16), PQR, ld,
+                     H, F, idx, rowptr, src, M, k, b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
   return spgan_launch_status();
 }
 

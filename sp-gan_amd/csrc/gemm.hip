@@ -1124,6 +1124,178 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ gemm_nt, K <= 4 or N <= 4
+// The products against the 3 coordinate columns (D.conv1, the EdgeBlocks' P|Q|R of the sphere / the points: K = 3; the input gradients
+// of those layers and G's last conv: N = 3) have nothing for the matrix cores to do: 128 x 64 MFMA tiles ran them at 1.1 TB/s of
+// the result / operand stream.  Two streaming kernels instead (fp32 FMAs in every operand mode):
+//   * K <= 4 (gemm_nt_k4_kernel): a workgroup owns 128 rows (= one statistics record); a thread owns 4 fixed output columns (its 4 x K
+//     weights in registers) and walks the rows in steps of 256/(N/4): float4 stores, consecutive lanes on consecutive columns.
+//     LINEAR (bias, activation, per-tile (sum, centred M2) statistics) and MASK_OUT epilogues.
+//   * N <= 4 (gemm_nt_n4_kernel): K/4 lanes share a row (one float4 each), the N partial dot products are summed over those lanes by
+//     a butterfly; plain or affine + LeakyReLU operand, bias, activation.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const spgan_gemm_nt_args p, int N4) {
+  __shared__ float4 As[BM];
+  __shared__ float red[256 * 4];
+  __shared__ float mean_s[512];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * BM;
+  const int rows = min(BM, p.M - m0);
+  if (tid < BM) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < rows) {
+      const float* ar = p.A + (size_t)(m0 + tid) * p.lda;
+      a.x = ar[0];
+      if (p.K > 1) a.y = ar[1];
+      if (p.K > 2) a.z = ar[2];
+      if (p.K > 3) a.w = ar[3];
+    }
+    As[tid] = a;
+  }
+  const int c4 = tid % N4, r0 = tid / N4, rpp = 256 / N4;   // N4 = N/4 is a power of two in 2 .. 128
+  const int col = c4 * 4;
+  float4 w[4];
+  float bias[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float* wr = p.W + (size_t)(col + q) * p.ldw;
+    w[q] = make_float4(wr[0], p.K > 1 ? wr[1] : 0.f, p.K > 2 ? wr[2] : 0.f, p.K > 3 ? wr[3] : 0.f);
+    bias[q] = (EPI == SPGAN_EPI_LINEAR && p.bias) ? p.bias[col + q] : 0.f;
+  }
+  __syncthreads();
+  const bool rbias = EPI == SPGAN_EPI_LINEAR && p.rowbias != nullptr;   // per-group rows of a [groups, N] addend (the generator's per-shape latent part)
+  auto value = [&](int r, int q) -> float {   // one fixed expression: the statistics pass below recomputes exactly the stored value
+    const float4 a = As[r];
+    float v = fmaf(a.w, w[q].w, fmaf(a.z, w[q].z, fmaf(a.y, w[q].y, a.x * w[q].x))) + bias[q];
+    if (rbias) v += p.rowbias[(size_t)fast_div(m0 + r, p.rows_per_group) * p.ld_rowbias + col + q];
+    return v;
+  };
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < rows; r += rpp) {
+    float v[4], o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = value(r, q);
+    if (EPI == SPGAN_EPI_LINEAR) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s[q] += v[q];
+        o[q] = p.act == SPGAN_ACT_LRELU ? lrelu_f(v[q], p.act_slope) : (p.act == SPGAN_ACT_TANH ? tanhf(v[q]) : v[q]);
+      }
+    } else {  // MASK_OUT
+      const float4 rv = *reinterpret_cast<const float4*>(p.ref + (size_t)(m0 + r) * p.ld_ref + col);
+      o[0] = v[0] * lrelu_mask(rv.x, p.b_slope); o[1] = v[1] * lrelu_mask(rv.y, p.b_slope);
+      o[2] = v[2] * lrelu_mask(rv.z, p.b_slope); o[3] = v[3] * lrelu_mask(rv.w, p.b_slope);
+    }
+    if (p.Y) *reinterpret_cast<float4*>(p.Y + (size_t)(m0 + r) * p.ldy + col) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  if (EPI == SPGAN_EPI_LINEAR && p.stats) {
+    // per-tile (sum, M2 about the tile mean) like the MFMA kernels' records; row groups summed in ascending order (deterministic)
+    *reinterpret_cast<float4*>(&red[tid * 4]) = make_float4(s[0], s[1], s[2], s[3]);   // red[r0][c4][q] = red[tid*4 + q]
+    __syncthreads();
+    for (int c = tid; c < p.N; c += 256) {
+      float t = 0.f;
+      for (int g = 0; g < rpp; ++g) t += red[(g * N4 + (c >> 2)) * 4 + (c & 3)];
+      mean_s[c] = t;
+    }
+    __syncthreads();
+    float mu[4], m2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mu[q] = mean_s[col + q] / (float)rows;
+    __syncthreads();
+    for (int r = r0; r < rows; r += rpp) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float d = value(r, q) - mu[q];
+        m2[q] = fmaf(d, d, m2[q]);
+      }
+    }
+    *reinterpret_cast<float4*>(&red[tid * 4]) = make_float4(m2[0], m2[1], m2[2], m2[3]);
+    __syncthreads();
+    for (int c = tid; c < p.N; c += 256) {
+      float t = 0.f;
+      for (int g = 0; g < rpp; ++g) t += red[(g * N4 + (c >> 2)) * 4 + (c & 3)];
+      float* o = p.stats + ((size_t)blockIdx.x * p.N + c) * 2;
+      o[0] = mean_s[c];
+      o[1] = t;
+    }
+  }
+}
+
+constexpr int N4_U = 8;  // row groups in flight per wave
+template <int AMODE, int LPR>
+__global__ __launch_bounds__(256) void gemm_nt_n4_kernel(const spgan_gemm_nt_args p) {
+  constexpr int RW = 64 / LPR;                 // rows per wave-wide load
+  constexpr int RB = 4 * N4_U * RW;            // rows per workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kq = (lane % LPR) * 4, lr = lane / LPR;
+  float4 w[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {   // element loads: a weight slice of a flat parameter buffer need not be 16-byte aligned
+    const float* wr = p.W + (size_t)min(n, p.N - 1) * p.ldw + kq;
+    w[n] = n < p.N ? make_float4(wr[0], wr[1], wr[2], wr[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (AMODE == SPGAN_A_AFFINE_LRELU) {
+    sc = make_float4(p.p_scale[kq], p.p_scale[kq + 1], p.p_scale[kq + 2], p.p_scale[kq + 3]);
+    sh = make_float4(p.p_shift[kq], p.p_shift[kq + 1], p.p_shift[kq + 2], p.p_shift[kq + 3]);
+  }
+  const int base = blockIdx.x * RB + wave * (N4_U * RW) + lr;
+  float4 a[N4_U];
+#pragma unroll
+  for (int u = 0; u < N4_U; ++u) a[u] = *reinterpret_cast<const float4*>(p.A + (size_t)min(base + u * RW, p.M - 1) * p.lda + kq);
+#pragma unroll
+  for (int u = 0; u < N4_U; ++u) {
+    float4 v = a[u];
+    if (AMODE == SPGAN_A_AFFINE_LRELU) v = affine_lrelu4(v, sc, sh, p.p_slope);
+    float d[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) d[n] = fmaf(v.w, w[n].w, fmaf(v.z, w[n].z, fmaf(v.y, w[n].y, v.x * w[n].x)));
+#pragma unroll
+    for (int st = 1; st < LPR; st <<= 1)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) d[n] += __shfl_xor(d[n], st);
+    const int row = base + u * RW;
+    if (lane % LPR == 0 && row < p.M) {
+      for (int n = 0; n < p.N; ++n) {
+        float o = d[n] + (p.bias ? p.bias[n] : 0.f);
+        o = p.act == SPGAN_ACT_LRELU ? lrelu_f(o, p.act_slope) : (p.act == SPGAN_ACT_TANH ? tanhf(o) : o);
+        p.Y[(size_t)row * p.ldy + n] = o;
+      }
+    }
+  }
+}
+
+// which problems the two streaming kernels take (mirrored by nothing on the host: results, not layouts, depend on it)
+inline bool nt_skinny_on(const spgan_gemm_nt_args& a) {
+  static const bool off = getenv("SPGAN_NT_SKINNY") && atoi(getenv("SPGAN_NT_SKINNY")) == 0;
+  return !off && a.tile_hint != 1 && a.M > 64 && a.batch <= 1 && !a.tail.enabled && !a.pool_val && !a.sp_val && !a.A2 && !a.a_half && !a.y_bf16 &&
+         true;
+}
+inline bool nt_k4_ok(const spgan_gemm_nt_args& a) {
+  if (!nt_skinny_on(a) || a.K > 4 || a.a_mode != SPGAN_A_PLAIN || a.N % 4 || a.N < 8 || a.N > 512) return false;
+  const int n4 = a.N / 4;
+  if (n4 & (n4 - 1)) return false;
+  if (a.ldy % 4 || !al16(a.Y)) return false;
+  if (a.epi_mode == SPGAN_EPI_MASK_OUT) return !a.stats && !a.bias && !a.rowbias && a.ld_ref % 4 == 0 && al16(a.ref);
+  return a.epi_mode == SPGAN_EPI_LINEAR;
+}
+inline bool nt_n4_ok(const spgan_gemm_nt_args& a) {
+  if (!nt_skinny_on(a) || a.N > 4 || a.epi_mode != SPGAN_EPI_LINEAR || a.stats || !a.Y || a.rowbias) return false;
+  if (a.a_mode != SPGAN_A_PLAIN && (a.a_mode != SPGAN_A_AFFINE_LRELU || a.p_group_rows > 0)) return false;
+  if (a.K != 32 && a.K != 64 && a.K != 128 && a.K != 256) return false;
+  return a.lda % 4 == 0 && al16(a.A);
+}
+template <int AMODE>
+void launch_nt_n4(const spgan_gemm_nt_args& a, hipStream_t s) {
+  const int lpr = a.K / 4, rb = 4 * N4_U * (64 / lpr);
+  const dim3 g(cdiv(a.M, rb));
+  if (lpr == 8) hipLaunchKernelGGL((gemm_nt_n4_kernel<AMODE, 8>), g, dim3(256), 0, s, a);
+  else if (lpr == 16) hipLaunchKernelGGL((gemm_nt_n4_kernel<AMODE, 16>), g, dim3(256), 0, s, a);
+  else if (lpr == 32) hipLaunchKernelGGL((gemm_nt_n4_kernel<AMODE, 32>), g, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_nt_n4_kernel<AMODE, 64>), g, dim3(256), 0, s, a);
+}
+
 template <int AMODE, int EPI>
 int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   bool fast = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A) && al16(a.W);
@@ -1131,6 +1303,18 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   if (AMODE == SPGAN_A_EDGE) fast = fast && al16(a.e_bias);
   if (AMODE == A_AFFINE_SPARSE) fast = fast && al16(a.sp_val) && al16(a.sp_arg);
   if (AMODE == A_AFFINE2) fast = fast && al16(a.A2) && (a.lda2 % 4 == 0) && al16(a.p_scale2);
+  if constexpr (AMODE == SPGAN_A_PLAIN && (EPI == SPGAN_EPI_LINEAR || EPI == SPGAN_EPI_MASK_OUT)) {
+    if (nt_k4_ok(a)) {  // 3 coordinate columns in: the streaming kernel
+      hipLaunchKernelGGL((gemm_nt_k4_kernel<EPI>), dim3(cdiv(a.M, BM)), dim3(256), 0, s, a, a.N / 4);
+      return spgan_launch_status();
+    }
+  }
+  if constexpr ((AMODE == SPGAN_A_PLAIN || AMODE == SPGAN_A_AFFINE_LRELU) && EPI == SPGAN_EPI_LINEAR) {
+    if (nt_n4_ok(a)) {  // <= 4 output columns: the streaming kernel
+      launch_nt_n4<AMODE>(a, s);
+      return spgan_launch_status();
+    }
+  }
   if constexpr (AMODE == SPGAN_A_PLAIN && EPI == SPGAN_EPI_LINEAR) {
     if (a.a_half) {  // fp16-stored A (validated in spgan_gemm_nt: fp16 mode, aligned, N > 32, M > 64, one product): the 128-row kernels only
       if (a.N > 64 && a.K >= 512) launch_nt_cfg<AMODE, EPI, 0, 1, 1, 1, 1>(a, s);

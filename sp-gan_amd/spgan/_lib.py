@@ -140,6 +140,7 @@ SIGNATURES = {
     "spgan_gemm_nt_y16_ok": (I, [P]),
     "spgan_edge_attend_bwd_tile_points": (I, []),
     "spgan_edge_attend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, I, I, P, P, P, P, P, F, P, P, P, P]),
+    "spgan_edge_scatter_b": (I, [P, P, P, I, I, I, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "spgan_edge_scatter": (I, [P, P, P, I, I, I, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "spgan_adain_fwd": (I, [P, I, I, I, F, P, P, F, P, P, P]),
     "spgan_adain_bwd1": (I, [P, P, I, I, I, F, P, P, F, P, P, P, P]),

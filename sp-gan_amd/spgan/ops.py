@@ -1119,7 +1119,7 @@ def edge_attend_bwd(dT: Tensor, h2pre: Tensor, sc2, sh2, mean2, inv2, PQR: Tenso
     tp = lib.spgan_edge_attend_bwd_tile_points()
     tiles = (M_ + tp - 1) // tp
     g2 = torch.empty((M_ * k, F_), dtype=torch.float32, device=PQR.device)
-    gy = torch.empty((M_ * k, F_), dtype=torch.float32, device=PQR.device)
+    gy = torch.empty((M_ * k, F_), dtype=torch.bfloat16 if dT_b else torch.float32, device=PQR.device)   # 16-bit storage: gy too (edge_scatter reads it)
     part = torch.empty((tiles, 2 * F_, 2), dtype=torch.float32, device=PQR.device)
     v = lambda t, n: _p(_vec(t, F_, n))
     check((lib.spgan_edge_attend_bwd_b if dT_b else lib.spgan_edge_attend_bwd)(_p(dT), _p(h2pre), v(sc2, "sc2"), v(sh2, "sh2"), v(mean2, "mean2"), v(inv2, "inv2"), _p(PQR), PQR.shape[1],
@@ -1136,13 +1136,18 @@ def edge_scatter(g1: Tensor, gy: Tensor, PQR: Tensor, idx: Tensor, rowptr: Tenso
     H, F_ = b1.numel(), bx.numel()
     _pqr(PQR, H, F_); _i32(idx, "idx"); _i32(rowptr, "rowptr"); _i32(src, "src")
     M_, k = idx.shape
-    _f32(g1, "g1", 2); _f32(gy, "gy", 2)
+    gy_b = gy.dtype == torch.bfloat16          # written by edge_attend_bwd in the 16-bit storage mode
+    _f32(g1, "g1", 2)
+    if gy_b:
+        _rowmajor2d_as(gy, "gy", torch.bfloat16)
+    else:
+        _f32(gy, "gy", 2)
     if not (g1.is_contiguous() and gy.is_contiguous()) or g1.shape != (M_ * k, H) or gy.shape != (M_ * k, F_):
         raise ValueError("g1 [E,H] / gy [E,F] shape mismatch")
     out = torch.empty_like(PQR)
     vh = lambda t, n: _p(_vec(t, H, n))
     vf = lambda t, n: _p(_vec(t, F_, n))
-    check(_lib.load().spgan_edge_scatter(_p(g1), _p(gy), _p(PQR), PQR.shape[1], H, F_, _p(idx), _p(rowptr), _p(src), M_, k, vh(b1, "b1"),
+    check((_lib.load().spgan_edge_scatter_b if gy_b else _lib.load().spgan_edge_scatter)(_p(g1), _p(gy), _p(PQR), PQR.shape[1], H, F_, _p(idx), _p(rowptr), _p(src), M_, k, vh(b1, "b1"),
                                          vh(mean1, "mean1"), vh(inv1, "inv1"), vh(gam1, "gam1"), _p(_vec(sums1, 2 * H, "sums1")), vf(bx, "bx"),
                                          vf(meanx, "meanx"), vf(invx, "invx"), vf(gamx, "gamx"), _p(_vec(sumsx, 2 * F_, "sumsx")), _p(out), _s()),
           "edge_scatter", M=M_, k=k, H=H, F=F_)

@@ -438,12 +438,16 @@ def edge_attend_bwd(dT, h2pre, sc2, sh2, mean2, inv2, PQR, idx, bx, scx, shx, me
     ds = w * (dw - (dw * w).sum(1, keepdim=True))
     g2 = (ds * torch.where(z2 > 0, 1.0, slope)).reshape(M * k, F_)
     gy = (d * w * torch.where(zy > 0, 1.0, slope)).reshape(M * k, F_)
+    if dT.dtype == torch.bfloat16:           # 16-bit storage mode: gy is handed on as bfloat16 (statistics from the float values)
+        return (g2.contiguous(), gy.to(torch.bfloat16).contiguous(), torch.cat([g2.sum(0), (g2 * ((h2pre - mean2) * inv2)).sum(0)]),
+                torch.cat([gy.sum(0), (gy * ((yp.reshape(M * k, F_) - meanx) * invx)).sum(0)]))
     xh2 = (h2pre - mean2) * inv2
     xhy = (yp.reshape(M * k, F_) - meanx) * invx
     return (g2.contiguous(), gy.contiguous(), torch.cat([g2.sum(0), (g2 * xh2).sum(0)]), torch.cat([gy.sum(0), (gy * xhy).sum(0)]))
 
 
 def edge_scatter(g1, gy, PQR, idx, rowptr, src, b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx):
+    gy = gy.float()
     M, k = idx.shape
     H, F_ = b1.numel(), bx.numel()
     E = M * k

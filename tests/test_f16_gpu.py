@@ -169,8 +169,21 @@ def test_storage16_edge_attend(f16, B, N, H, F_):
     mx, ix = rnd("s16.mx%d" % F_, (F_,), 0.2), rnd("s16.ix%d" % F_, (F_,)).abs() + 0.5
     got = ops.edge_attend_bwd(dT, h2, sc2, sh2, m2, i2, PQR, idx, bx, scx, shx, mx, ix, 0.01)
     want = ops.edge_attend_bwd(dT.float(), h2, sc2, sh2, m2, i2, PQR, idx, bx, scx, shx, mx, ix, 0.01)
+    assert got[1].dtype == torch.bfloat16                 # gy travels on as bfloat16 (edge_scatter is its only consumer)
     for g, w, what in zip(got, want, ("g2", "gy", "sums2", "sumsy")):
-        close(g, w, rtol=2e-5, atol=1e-12, what="bfloat16 dT: " + what)
+        close(g.float(), w, rtol=3e-3 if what == "gy" else 2e-5, atol=1e-12, what="bfloat16 dT: " + what)
+    assert float((got[1] == want[1].bfloat16()).float().mean()) > 0.99
+    # edge_scatter on the bfloat16 gy == the float kernel on the same values
+    H_ = H
+    rowptr, src = ops.csr_build(idx, B, N)
+    g1 = rnd("s16.g1%d" % N, (M * k, H_)) * 1e-6
+    b1 = rnd("s16.b1%d" % H_, (H_,), 0.1)
+    gam1, gamx = rnd("s16.gam1%d" % H_, (H_,)).abs() + 0.5, rnd("s16.gamx%d" % F_, (F_,)).abs() + 0.5
+    m1, i1 = rnd("s16.m1%d" % H_, (H_,), 0.2), rnd("s16.i1%d" % H_, (H_,)).abs() + 0.5
+    s1, sx = rnd("s16.s1%d" % H_, (2 * H_,), 1e-5), rnd("s16.sx%d" % F_, (2 * F_,), 1e-5)
+    d16 = ops.edge_scatter(g1, got[1], PQR, idx, rowptr, src, b1, m1, i1, gam1, s1, bx, mx, ix, gamx, sx)
+    d32 = ops.edge_scatter(g1, got[1].float(), PQR, idx, rowptr, src, b1, m1, i1, gam1, s1, bx, mx, ix, gamx, sx)
+    close(d16, d32, rtol=1e-6, atol=1e-12, what="edge_scatter on bfloat16 gy")
 
 
 def test_storage16_edgeblock_close_to_float32_storage(f16, sp):
