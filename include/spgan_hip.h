@@ -166,6 +166,11 @@ typedef struct spgan_gemm_nt_args {
    * a_half = 1: A points at IEEE fp16 values (lda in elements; a_mode PLAIN): staged into LDS as they are (128-row kernels);
    * y_bf16 = 1: Y points at bfloat16 storage (ldy in elements; LINEAR epilogue of the 256 x 256-tile kernel: spgan_gemm_nt_y16_ok()). */
   int a_half, y_bf16;
+  /* y_half = 1: Y points at IEEE fp16 storage (ldy in elements; same kernels and conditions as y_bf16; also the edge operand mode: the
+   * EdgeBlock's h2pre, a pre-BatchNorm activation whose statistics are still taken from the fp32 accumulators).
+   * a_half = 1 together with A2 (epi_mode EDGE_BNBWD): A points at bfloat16 values (g2 of spgan_edge_attend_bwd_b), A2 at fp16 values
+   * (h2pre): the EdgeBlock's lazy BatchNorm-backward operand p*A + q*A2 + r with both tensors in 16-bit storage. */
+  int y_half;
 } spgan_gemm_nt_args;
 /* 1 when spgan_gemm_nt will honour y_bf16 for this problem (it runs on the 256 x 256-tile kernel with fp16 operands) */
 int spgan_gemm_nt_y16_ok(const spgan_gemm_nt_args* a);
@@ -226,6 +231,8 @@ typedef struct spgan_gemm_tn_args {
   int a_lrelu; float a_slope;
   /* b_half = 1 (with mfma_lp == 1, b_mode PLAIN): B points at IEEE fp16 values (ldb in elements). */
   int b_half;
+  /* a_half = 1 (with mfma_lp == 1): A points at bfloat16 values, A2 (when given) at IEEE fp16 values (lda / lda2 in elements). */
+  int a_half;
 } spgan_gemm_tn_args;
 
 /* Coefficient vectors of the BatchNorm backward as an affine combination of two tensors (Generator.py:58-67 / Discriminator.py:57-79
@@ -338,14 +345,17 @@ int spgan_edge_attend_fwd(const float* h2pre, const float* sc2, const float* sh2
                           float* T, spgan_stream_t s);
 /* Backward of edge_attend: g2/gy = gradients w.r.t. the two BatchNorm outputs, and plain-sum partials
  * [ceil(M/spgan_edge_attend_bwd_tile_points())][2F][2]: col f -> (sum g2, sum g2*xhat2), col F+f -> (sum gy, sum gy*xhaty). */
-/* 16-bit storage variants for the "f16" operand mode (BASELINE configs[4]): T is written as IEEE fp16 (consumed by conv_out's products
- * with spgan_gemm_nt_args.a_half / spgan_gemm_tn_args.b_half), dT is read as bfloat16 (written by spgan_gemm_nt_args.y_bf16: a gradient
- * keeps fp32's exponent range) and gy -- whose only consumer is spgan_edge_scatter_b -- is written as bfloat16; g2 and the partials stay float.  k = 10 and F % 4 == 0 only; everything else as the fp32 entry points. */
-int spgan_edge_attend_fwd_h(const float* h2pre, const float* sc2, const float* sh2, const float* PQR, int ld, int H, int F, const int32_t* idx,
-                            int M, int k, const float* bx, const float* scx, const float* shx, float slope, uint16_t* T_f16, spgan_stream_t s);
-int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
+/* 16-bit storage variants for the "f16" operand mode (BASELINE configs[4]).  Forward: T is written as IEEE fp16 (consumed by conv_out's
+ * products: spgan_gemm_nt_args.a_half / spgan_gemm_tn_args.b_half).  Backward: dT is read as bfloat16 (written by spgan_gemm_nt_args.y_bf16: a
+ * gradient keeps fp32's exponent range); g2 -- a GEMM operand only (a_half of spgan_gemm_tn_args / spgan_gemm_nt_args) -- and gy -- consumed
+ * by spgan_edge_scatter_b -- are written as bfloat16; the partials stay float.  h2_half = 1: h2pre lies in memory as fp16 (written by the
+ * edge GEMM with spgan_gemm_nt_args.y_half).  k = 10 and F % 4 == 0 only; everything else as the fp32 entry points. */
+int spgan_edge_attend_fwd_h(const void* h2pre, int h2_half, const float* sc2, const float* sh2, const float* PQR, int ld, int H, int F,
+                            const int32_t* idx, int M, int k, const float* bx, const float* scx, const float* shx, float slope, uint16_t* T_f16,
+                            spgan_stream_t s);
+int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const void* h2pre, int h2_half, const float* sc2, const float* sh2, const float* mean2,
                             const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k, const float* bx,
-                            const float* scx, const float* shx, const float* meanx, const float* invx, float slope, float* g2,
+                            const float* scx, const float* shx, const float* meanx, const float* invx, float slope, uint16_t* g2_bf16,
                             uint16_t* gy_bf16, float* partials, spgan_stream_t s);
 /* spgan_edge_scatter with the gy operand as written by spgan_edge_attend_bwd_b (bfloat16; k = 10) */
 int spgan_edge_scatter_b(const float* g1, const uint16_t* gy_bf16, const float* PQR, int ld, int H, int F, const int32_t* idx,

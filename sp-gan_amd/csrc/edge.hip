@@ -266,6 +266,14 @@ __device__ __forceinline__ void ldv_b(const __bf16* p, float (&o)[VEC]) {
 }
 
 template <int VEC>
+__device__ __forceinline__ void ldv_h(const _Float16* p, float (&o)[VEC]) {
+  _Float16 h[VEC];
+  if (VEC == 2) *reinterpret_cast<unsigned*>(h) = *reinterpret_cast<const unsigned*>(p);
+  else h[0] = p[0];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) o[q] = (float)h[q];
+}
+template <int VEC>
 __device__ __forceinline__ void stv_b(__bf16* p, const float (&o)[VEC]) {
   __bf16 h[VEC];
 #pragma unroll
@@ -274,7 +282,8 @@ __device__ __forceinline__ void stv_b(__bf16* p, const float (&o)[VEC]) {
   else p[0] = h[0];
 }
 
-template <int K, int VEC, int TH = 0>
+// HH = 1: h2pre lies in memory as fp16 (written by the edge GEMM with spgan_gemm_nt_args.y_half)
+template <int K, int VEC, int TH = 0, int HH = 0>
 __global__ __launch_bounds__(256) void edge_attend_fwd_k_kernel(const float* __restrict__ h2, const float* __restrict__ sc2,
                                                                 const float* __restrict__ sh2, const float* __restrict__ PQR, int ld, int H,
                                                                 int F, const int32_t* __restrict__ idx, int M, const float* __restrict__ bx,
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(256) void edge_attend_fwd_k_kernel(const float* __r
 #pragma unroll
   for (int r = 0; r < K; ++r) nb[r] = __builtin_amdgcn_readfirstlane(idx[(size_t)i * K + r]);
   const float* h2i = h2 + (size_t)i * K * F;
+  const _Float16* h2h = reinterpret_cast<const _Float16*>(h2) + (size_t)i * K * F;
   for (int f = lane * VEC; f < F; f += 64 * VEC) {
     float a2[VEC], c2[VEC], ax[VEC], cx[VEC], bb[VEC], Ri[VEC];
     ldv<VEC>(sc2 + f, a2); ldv<VEC>(sh2 + f, c2); ldv<VEC>(scx + f, ax); ldv<VEC>(shx + f, cx); ldv<VEC>(bx + f, bb);
@@ -294,7 +304,8 @@ __global__ __launch_bounds__(256) void edge_attend_fwd_k_kernel(const float* __r
     float z[K][VEC], qv[K][VEC];
 #pragma unroll
     for (int r = 0; r < K; ++r) {
-      ldv<VEC>(h2i + (size_t)r * F + f, z[r]);
+      if (HH) ldv_h<VEC>(h2h + (size_t)r * F + f, z[r]);
+      else ldv<VEC>(h2i + (size_t)r * F + f, z[r]);
       ldv<VEC>(PQR + (size_t)nb[r] * ld + H + f, qv[r]);
     }
 #pragma unroll
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(256) void edge_attend_fwd_k_kernel(const float* __r
   }
 }
 
-template <int K, int VEC, int TB = 0>
+template <int K, int VEC, int TB = 0, int HH = 0>
 __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
     const float* __restrict__ dT, const float* __restrict__ h2, const float* __restrict__ sc2, const float* __restrict__ sh2,
     const float* __restrict__ mean2, const float* __restrict__ inv2, const float* __restrict__ PQR, int ld, int H, int F,
@@ -355,7 +366,8 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
 #pragma unroll
         for (int r = 0; r < K; ++r) {
           const int j = __builtin_amdgcn_readfirstlane(idx[(size_t)i * K + r]);
-          ldv<VEC>(h2 + ((size_t)i * K + r) * F + f, hp[r]);
+          if (HH) ldv_h<VEC>(reinterpret_cast<const _Float16*>(h2) + ((size_t)i * K + r) * F + f, hp[r]);
+          else ldv<VEC>(h2 + ((size_t)i * K + r) * F + f, hp[r]);
           if (TB) ldv_b<VEC>(reinterpret_cast<const __bf16*>(dT) + ((size_t)i * K + r) * F + f, d[r]);
           else ldv<VEC>(dT + ((size_t)i * K + r) * F + f, d[r]);
           ldv<VEC>(PQR + (size_t)j * ld + H + f, yp[r]);
@@ -401,7 +413,8 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
         }
 #pragma unroll
         for (int r = 0; r < K; ++r) {
-          stv<VEC>(g2 + ((size_t)i * K + r) * F + f, o2[r]);
+          if (TB) stv_b<VEC>(reinterpret_cast<__bf16*>(g2) + ((size_t)i * K + r) * F + f, o2[r]);   // consumed as a GEMM operand only
+          else stv<VEC>(g2 + ((size_t)i * K + r) * F + f, o2[r]);
           if (TB) stv_b<VEC>(reinterpret_cast<__bf16*>(gy) + ((size_t)i * K + r) * F + f, oy[r]);   // consumed by edge_scatter only
           else stv<VEC>(gy + ((size_t)i * K + r) * F + f, oy[r]);
         }
@@ -586,33 +599,44 @@ extern "C" int spgan_edge_attend_fwd(const float* h2pre, const float* sc2, const
   return spgan_launch_status();
 }
 
-extern "C" int spgan_edge_attend_fwd_h(const float* h2pre, const float* sc2, const float* sh2, const float* PQR, int ld, int H, int F,
+extern "C" int spgan_edge_attend_fwd_h(const void* h2pre, int h2_half, const float* sc2, const float* sh2, const float* PQR, int ld, int H, int F,
                                        const int32_t* idx, int M, int k, const float* bx, const float* scx, const float* shx, float slope,
                                        uint16_t* T_f16, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(h2pre && sc2 && sh2 && PQR && idx && bx && scx && shx && T_f16 && M > 0 && ld >= H + 2 * F);
   SPGAN_CHECK_ARG(k == 10 && F % 4 == 0);   // the k = 10 kernels only; rows of T stay 8-byte aligned for the consumers' loads
-  if (((ld | H) % 2 == 0) && F % 128 == 0)
-    hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 2, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, bx,
-                       scx, shx, slope, reinterpret_cast<float*>(T_f16));
-  else
-    hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 1, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, bx,
-                       scx, shx, slope, reinterpret_cast<float*>(T_f16));
+  const float* h2 = reinterpret_cast<const float*>(h2pre);
+  float* T = reinterpret_cast<float*>(T_f16);
+  const dim3 g(cdiv(M, 4)), b(256);
+  hipStream_t s = (hipStream_t)s_;
+  const bool v2 = ((ld | H) % 2 == 0) && F % 128 == 0;
+  if (v2 && h2_half) hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 2, 1, 1>), g, b, 0, s, h2, sc2, sh2, PQR, ld, H, F, idx, M, bx, scx, shx, slope, T);
+  else if (v2) hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 2, 1, 0>), g, b, 0, s, h2, sc2, sh2, PQR, ld, H, F, idx, M, bx, scx, shx, slope, T);
+  else if (h2_half) hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 1, 1, 1>), g, b, 0, s, h2, sc2, sh2, PQR, ld, H, F, idx, M, bx, scx, shx, slope, T);
+  else hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 1, 1, 0>), g, b, 0, s, h2, sc2, sh2, PQR, ld, H, F, idx, M, bx, scx, shx, slope, T);
   return spgan_launch_status();
 }
 
-extern "C" int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
-                                       const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k,
-                                       const float* bx, const float* scx, const float* shx, const float* meanx, const float* invx,
-                                       float slope, float* g2, uint16_t* gy_bf16, float* partials, spgan_stream_t s_) {
-  float* gy = reinterpret_cast<float*>(gy_bf16);
-  SPGAN_CHECK_ARG(dT_bf16 && h2pre && sc2 && sh2 && mean2 && inv2 && PQR && idx && bx && scx && shx && meanx && invx && g2 && gy && partials);
+extern "C" int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const void* h2pre, int h2_half, const float* sc2, const float* sh2,
+                                       const float* mean2, const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M,
+                                       int k, const float* bx, const float* scx, const float* shx, const float* meanx, const float* invx,
+                                       float slope, uint16_t* g2_bf16, uint16_t* gy_bf16, float* partials, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dT_bf16 && h2pre && sc2 && sh2 && mean2 && inv2 && PQR && idx && bx && scx && shx && meanx && invx && g2_bf16 && gy_bf16 && partials);
   SPGAN_CHECK_ARG(M > 0 && ld >= H + 2 * F && k == 10 && F % 4 == 0);
-  if (((ld | H) % 2 == 0) && F % 128 == 0)
-    hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 2, 1>), dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, reinterpret_cast<const float*>(dT_bf16),
-                       h2pre, sc2, sh2, mean2, inv2, PQR, ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
-  else
-    hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 1, 1>), dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, reinterpret_cast<const float*>(dT_bf16),
-                       h2pre, sc2, sh2, mean2, inv2, PQR, ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
+  const float* dT = reinterpret_cast<const float*>(dT_bf16);
+  const float* h2 = reinterpret_cast<const float*>(h2pre);
+  float* g2 = reinterpret_cast<float*>(g2_bf16);
+  float* gy = reinterpret_cast<float*>(gy_bf16);
+  const dim3 g(cdiv(M, EB_PT)), b(256);
+  hipStream_t s = (hipStream_t)s_;
+  const bool v2 = ((ld | H) % 2 == 0) && F % 128 == 0;
+#define SPGAN_ATT_BWD(V, HHV)                                                                                                               \
+  hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, V, 1, HHV>), g, b, 0, s, dT, h2, sc2, sh2, mean2, inv2, PQR, ld, H, F, idx, M, bx, scx, shx, \
+                     meanx, invx, slope, g2, gy, partials)
+  if (v2 && h2_half) SPGAN_ATT_BWD(2, 1);
+  else if (v2) SPGAN_ATT_BWD(2, 0);
+  else if (h2_half) SPGAN_ATT_BWD(1, 1);
+  else SPGAN_ATT_BWD(1, 0);
+#undef SPGAN_ATT_BWD
   return spgan_launch_status();
 }
 

@@ -22,6 +22,8 @@
 // EdgeBlock per-edge difference gather, bias / per-shape bias / activation, per-tile column statistics
 // for the following train-mode BatchNorm, and the LeakyReLU/BatchNorm backward masks with their
 // column sums.
+#include <type_traits>
+
 #include "common.hpp"
 #include "gemm_wide.hpp"
 
@@ -201,8 +203,10 @@ __device__ __forceinline__ void col_reduce2(float (&pa)[Geo<CFG>::TJ], float (&p
 // v_mfma_f32_32x32x8_f16 (fp32 accumulate): BASELINE configs[4] "fp16 MFMA MLPs".  Global loads, prologues and epilogues stay
 // fp32; an LDS row holds the 32 k-values of the tile as 16 words + 2 words of padding (stride 18 == 2 mod 16: the 32 rows x
 // 8-byte fragment reads of a half-wave are conflict-free), a fragment read (4 halfs) feeds ONE MFMA of k = 8.
-// AH = 1 (F16 = 1, plain A, straight-line loads only; spgan_gemm_nt_args.a_half): the A operand lies in memory as fp16 already (the
-// EdgeBlock's T, written by spgan_edge_attend_fwd_h): a staging slot is one 8-byte load that goes to LDS as it is.
+// AH = 1 (F16 = 1, straight-line loads only; spgan_gemm_nt_args.a_half): 16-bit operand storage.  Plain A: the operand lies in memory
+// as fp16 already (the EdgeBlock's T, written by spgan_edge_attend_fwd_h): a staging slot is one 8-byte load that goes to LDS as it is.
+// Two-tensor A (the EdgeBlock's lazy BatchNorm-backward operand p*g + q*y + r): g is stored as bfloat16 (spgan_edge_attend_bwd_b), y as
+// fp16 (h2pre: spgan_gemm_nt_args.y_half); both 8-byte loads, converted where the operand is evaluated.
 template <int AMODE, int EPI, int CFG, int DB, int FAST, int F16 = 0, int AH = 0>
 __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_args p_) {  // <= 168 VGPRs: 3 waves/SIMD
   // The argument block stays in the kernarg segment (scalar loads): it is never copied or modified -- a modified copy of a
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
   constexpr int LDX = F16 == 2 ? LDX3 : (F16 ? 18 : LDT);   // LDS row stride in 4-byte words
   constexpr int KK = F16 == 2 ? BK / 16 : (F16 ? BK / 8 : BK / 4);  // fragment reads per k-tile
   static_assert(!(F16 && AMODE == A_AFFINE_SPARSE), "the LDS patch path of the sparse addend is fp32 only");
-  static_assert(!AH || (F16 == 1 && FAST && AMODE == SPGAN_A_PLAIN), "fp16-stored A: plain operand, fp16 MFMA, aligned problems");
+  static_assert(!AH || (F16 == 1 && FAST && (AMODE == SPGAN_A_PLAIN || AMODE == A_AFFINE2)), "16-bit stored A: plain / two-tensor operand, fp16 MFMA, aligned problems");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [NB][BM*LDX]
   float* Bs = smem + NB * BM * LDX;  // [NB][BN*LDX]
@@ -313,12 +317,17 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
       const int kc = kok ? k : 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (AH) {
-          const float2 h = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(pA) + (offA[i] + (unsigned)kc));
+        if (AH) {   // 4 values of 16 bits: fp16 (plain A) or bfloat16 (two-tensor A), kept raw until sstore
+          const float2 h = *reinterpret_cast<const float2*>(reinterpret_cast<const uint16_t*>(pA) + (offA[i] + (unsigned)kc));
           ra[i].x = h.x;
           ra[i].y = h.y;
         } else
         ra[i] = ldrow(pA, offA[i], kc, true);
+        if (AH && AMODE == A_AFFINE2) {
+          const float2 h = *reinterpret_cast<const float2*>(reinterpret_cast<const uint16_t*>(pA2) + (offC[i] + (unsigned)kc));
+          ra2[i].x = h.x;
+          ra2[i].y = h.y;
+        } else
         if (AMODE == SPGAN_A_EDGE || AMODE == A_AFFINE2) ra2[i] = ldrow(pA2, offC[i], kc, true);
       }
       if (AMODE != SPGAN_A_PLAIN) {
@@ -370,6 +379,13 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           v.z = (v.z - ra2[i].z) + peb.z;
           v.w = (v.w - ra2[i].w) + peb.w;
         }
+        if (AH && AMODE == A_AFFINE2) {   // g: 4 bfloat16, y: 4 fp16
+          const float2 rg = make_float2(ra[i].x, ra[i].y), ry = make_float2(ra2[i].x, ra2[i].y);
+          const bf16x4 gb = *reinterpret_cast<const bf16x4*>(&rg);
+          const f16x4 yh = *reinterpret_cast<const f16x4*>(&ry);
+          v = make_float4((float)gb[0], (float)gb[1], (float)gb[2], (float)gb[3]);
+          ra2[i] = make_float4((float)yh[0], (float)yh[1], (float)yh[2], (float)yh[3]);
+        }
         if (AMODE == A_AFFINE2) {  // p*g + (q*y + r): the same expression as bn_bwd_coef_apply in tests/kernel_model.py
           v.x = fmaf(v.x, psc.x, fmaf(ra2[i].x, peb.x, psh.x));
           v.y = fmaf(v.y, psc.y, fmaf(ra2[i].y, peb.y, psh.y));
@@ -405,7 +421,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
     } else if (F16) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (AH) *reinterpret_cast<float2*>(&a[(lrow + 32 * i) * LDX + (lc4 >> 1)]) = make_float2(ra[i].x, ra[i].y);
+        if (AH && AMODE == SPGAN_A_PLAIN) *reinterpret_cast<float2*>(&a[(lrow + 32 * i) * LDX + (lc4 >> 1)]) = make_float2(ra[i].x, ra[i].y);
         else st_row4h(&a[(lrow + 32 * i) * LDX + (lc4 >> 1)], ra[i]);
       }
 #pragma unroll
@@ -584,7 +600,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           }
         }
       }
-      if (F16 == 1 && pY && p.y_bf16) {   // bfloat16 result storage (the EdgeBlock's dT; no activation: checked on the host)
+      if (F16 == 1 && pY && p.y_bf16) {   // 16-bit result storage (no activation: checked on the host): bfloat16 for the EdgeBlock's dT (a gradient)
         __bf16* yb = reinterpret_cast<__bf16*>(pY) + (size_t)rbase * p.ldy + cbase;
         const unsigned ldy = (unsigned)p.ldy;
 #pragma unroll
@@ -593,6 +609,15 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
           for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = (__bf16)acc[i][j][r];
+      } else if (F16 == 1 && pY && p.y_half) {   // ... fp16 for its h2pre (a pre-BatchNorm activation)
+        _Float16* yb = reinterpret_cast<_Float16*>(pY) + (size_t)rbase * p.ldy + cbase;
+        const unsigned ldy = (unsigned)p.ldy;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = (_Float16)acc[i][j][r];
       } else if (pY) {
         float* yb = pY + (size_t)rbase * p.ldy + cbase;
         const unsigned ldy = (unsigned)p.ldy;
@@ -634,6 +659,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const spgan_gemm_nt_arg
             if (p.act == SPGAN_ACT_LRELU) o = lrelu_f(v, p.act_slope);
             else if (p.act == SPGAN_ACT_TANH) o = tanhf(v);
             if (F16 == 1 && p.y_bf16) reinterpret_cast<__bf16*>(pY)[(size_t)row * p.ldy + col] = (__bf16)o;
+            else if (F16 == 1 && p.y_half) reinterpret_cast<_Float16*>(pY)[(size_t)row * p.ldy + col] = (_Float16)o;
             else
             pY[(size_t)row * p.ldy + col] = o;
           }
@@ -1125,20 +1151,19 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const spgan_gemm_nt_
 }
 
 
-// ------------------------------------------------------------------------------------------ gemm_nt, K <= 4 or N <= 4
-// The products against the 3 coordinate columns (D.conv1, the EdgeBlocks' P|Q|R of the sphere / the points: K = 3; the input gradients
-// of those layers and G's last conv: N = 3) have nothing for the matrix cores to do: 128 x 64 MFMA tiles ran them at 1.1 TB/s of
-// the result / operand stream.  Two streaming kernels instead (fp32 FMAs in every operand mode):
-//   * K <= 4 (gemm_nt_k4_kernel): a workgroup owns 128 rows (= one statistics record); a thread owns 4 fixed output columns (its 4 x K
-//     weights in registers) and walks the rows in steps of 256/(N/4): float4 stores, consecutive lanes on consecutive columns.
-//     LINEAR (bias, activation, per-tile (sum, centred M2) statistics) and MASK_OUT epilogues.
-//   * N <= 4 (gemm_nt_n4_kernel): K/4 lanes share a row (one float4 each), the N partial dot products are summed over those lanes by
-//     a butterfly; plain or affine + LeakyReLU operand, bias, activation.
+// ------------------------------------------------------------------------------------------ gemm_nt, K <= 4
+// The products against the 3 coordinate columns (D.conv1, G's first conv, the EdgeBlocks' P|Q|R of the points: K = 3) have nothing for
+// the matrix cores to do: 128 x 64 MFMA tiles ran them at 1.1 TB/s of the result stream.  A streaming kernel instead (fp32 FMAs in every
+// operand mode, in the MFMA kernel's summation order: bit-identical results): a workgroup owns 128 rows (= one statistics record); a
+// thread owns 4 fixed output columns (its 4 x K weights in registers) and walks the rows in steps of 256/(N/4): float4 stores,
+// consecutive lanes on consecutive columns.  LINEAR (bias, per-group bias rows, activation; products that also want column statistics
+// stay on the MFMA kernel: the epilogue's reduction tree is part of the BatchNorm bits, and a gradient-penalty golden sits on a LeakyReLU
+// kink that a last-bit change of those statistics moves) and MASK_OUT epilogues.  (A butterfly kernel for the N <= 4 products -- the input gradients of those layers, G's last conv -- was tried:
+// 14.7 -> 11.6 us per launch, but it sums K in another order than the MFMA kernel and moved a LeakyReLU kink of the gradient-penalty
+// golden; not kept.)
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const spgan_gemm_nt_args p, int N4) {
   __shared__ float4 As[BM];
-  __shared__ float red[256 * 4];
-  __shared__ float mean_s[512];
   const int tid = threadIdx.x;
   const int m0 = blockIdx.x * BM;
   const int rows = min(BM, p.M - m0);
@@ -1165,13 +1190,14 @@ __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const spgan_gemm_nt_arg
   }
   __syncthreads();
   const bool rbias = EPI == SPGAN_EPI_LINEAR && p.rowbias != nullptr;   // per-group rows of a [groups, N] addend (the generator's per-shape latent part)
-  auto value = [&](int r, int q) -> float {   // one fixed expression: the statistics pass below recomputes exactly the stored value
+  auto value = [&](int r, int q) -> float {
     const float4 a = As[r];
-    float v = fmaf(a.w, w[q].w, fmaf(a.z, w[q].z, fmaf(a.y, w[q].y, a.x * w[q].x))) + bias[q];
-    if (rbias) v += p.rowbias[(size_t)fast_div(m0 + r, p.rows_per_group) * p.ld_rowbias + col + q];
-    return v;
+    // k order 0, 2, 1, 3: the order the 128-row MFMA kernel's LDS layout feeds v_mfma_f32_32x32x2_f32 (lane half 0 holds k = 0, 1, lane
+    // half 1 k = 2, 3 of a quad; the first MFMA takes the .x values = k 0 and 2) -- this kernel reproduces its results bit for bit
+    float b = bias[q];
+    if (rbias) b += p.rowbias[(size_t)fast_div(m0 + r, p.rows_per_group) * p.ld_rowbias + col + q];   // (bias + group row) first, like the MFMA epilogue
+    return fmaf(a.w, w[q].w, fmaf(a.y, w[q].y, fmaf(a.z, w[q].z, a.x * w[q].x))) + b;
   };
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int r = r0; r < rows; r += rpp) {
     float v[4], o[4];
 #pragma unroll
@@ -1179,7 +1205,6 @@ __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const spgan_gemm_nt_arg
     if (EPI == SPGAN_EPI_LINEAR) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        s[q] += v[q];
         o[q] = p.act == SPGAN_ACT_LRELU ? lrelu_f(v[q], p.act_slope) : (p.act == SPGAN_ACT_TANH ? tanhf(v[q]) : v[q]);
       }
     } else {  // MASK_OUT
@@ -1189,111 +1214,23 @@ __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const spgan_gemm_nt_arg
     }
     if (p.Y) *reinterpret_cast<float4*>(p.Y + (size_t)(m0 + r) * p.ldy + col) = make_float4(o[0], o[1], o[2], o[3]);
   }
-  if (EPI == SPGAN_EPI_LINEAR && p.stats) {
-    // per-tile (sum, M2 about the tile mean) like the MFMA kernels' records; row groups summed in ascending order (deterministic)
-    *reinterpret_cast<float4*>(&red[tid * 4]) = make_float4(s[0], s[1], s[2], s[3]);   // red[r0][c4][q] = red[tid*4 + q]
-    __syncthreads();
-    for (int c = tid; c < p.N; c += 256) {
-      float t = 0.f;
-      for (int g = 0; g < rpp; ++g) t += red[(g * N4 + (c >> 2)) * 4 + (c & 3)];
-      mean_s[c] = t;
-    }
-    __syncthreads();
-    float mu[4], m2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) mu[q] = mean_s[col + q] / (float)rows;
-    __syncthreads();
-    for (int r = r0; r < rows; r += rpp) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float d = value(r, q) - mu[q];
-        m2[q] = fmaf(d, d, m2[q]);
-      }
-    }
-    *reinterpret_cast<float4*>(&red[tid * 4]) = make_float4(m2[0], m2[1], m2[2], m2[3]);
-    __syncthreads();
-    for (int c = tid; c < p.N; c += 256) {
-      float t = 0.f;
-      for (int g = 0; g < rpp; ++g) t += red[(g * N4 + (c >> 2)) * 4 + (c & 3)];
-      float* o = p.stats + ((size_t)blockIdx.x * p.N + c) * 2;
-      o[0] = mean_s[c];
-      o[1] = t;
-    }
-  }
 }
 
-constexpr int N4_U = 8;  // row groups in flight per wave
-template <int AMODE, int LPR>
-__global__ __launch_bounds__(256) void gemm_nt_n4_kernel(const spgan_gemm_nt_args p) {
-  constexpr int RW = 64 / LPR;                 // rows per wave-wide load
-  constexpr int RB = 4 * N4_U * RW;            // rows per workgroup
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int kq = (lane % LPR) * 4, lr = lane / LPR;
-  float4 w[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {   // element loads: a weight slice of a flat parameter buffer need not be 16-byte aligned
-    const float* wr = p.W + (size_t)min(n, p.N - 1) * p.ldw + kq;
-    w[n] = n < p.N ? make_float4(wr[0], wr[1], wr[2], wr[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (AMODE == SPGAN_A_AFFINE_LRELU) {
-    sc = make_float4(p.p_scale[kq], p.p_scale[kq + 1], p.p_scale[kq + 2], p.p_scale[kq + 3]);
-    sh = make_float4(p.p_shift[kq], p.p_shift[kq + 1], p.p_shift[kq + 2], p.p_shift[kq + 3]);
-  }
-  const int base = blockIdx.x * RB + wave * (N4_U * RW) + lr;
-  float4 a[N4_U];
-#pragma unroll
-  for (int u = 0; u < N4_U; ++u) a[u] = *reinterpret_cast<const float4*>(p.A + (size_t)min(base + u * RW, p.M - 1) * p.lda + kq);
-#pragma unroll
-  for (int u = 0; u < N4_U; ++u) {
-    float4 v = a[u];
-    if (AMODE == SPGAN_A_AFFINE_LRELU) v = affine_lrelu4(v, sc, sh, p.p_slope);
-    float d[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) d[n] = fmaf(v.w, w[n].w, fmaf(v.z, w[n].z, fmaf(v.y, w[n].y, v.x * w[n].x)));
-#pragma unroll
-    for (int st = 1; st < LPR; st <<= 1)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) d[n] += __shfl_xor(d[n], st);
-    const int row = base + u * RW;
-    if (lane % LPR == 0 && row < p.M) {
-      for (int n = 0; n < p.N; ++n) {
-        float o = d[n] + (p.bias ? p.bias[n] : 0.f);
-        o = p.act == SPGAN_ACT_LRELU ? lrelu_f(o, p.act_slope) : (p.act == SPGAN_ACT_TANH ? tanhf(o) : o);
-        p.Y[(size_t)row * p.ldy + n] = o;
-      }
-    }
-  }
-}
-
-// which problems the two streaming kernels take (mirrored by nothing on the host: results, not layouts, depend on it)
+// which problems the streaming kernel takes (nothing on the host mirrors this: neither results nor layouts depend on it)
 inline bool nt_skinny_on(const spgan_gemm_nt_args& a) {
   static const bool off = getenv("SPGAN_NT_SKINNY") && atoi(getenv("SPGAN_NT_SKINNY")) == 0;
-  return !off && a.tile_hint != 1 && a.M > 64 && a.batch <= 1 && !a.tail.enabled && !a.pool_val && !a.sp_val && !a.A2 && !a.a_half && !a.y_bf16 &&
-         true;
+  return !off && a.tile_hint != 1 && a.M > 64 && a.batch <= 1 && !a.tail.enabled && !a.pool_val && !a.sp_val && !a.A2 && !a.a_half && !a.y_bf16 && !a.y_half;
 }
 inline bool nt_k4_ok(const spgan_gemm_nt_args& a) {
   if (!nt_skinny_on(a) || a.K > 4 || a.a_mode != SPGAN_A_PLAIN || a.N % 4 || a.N < 8 || a.N > 512) return false;
   const int n4 = a.N / 4;
   if (n4 & (n4 - 1)) return false;
   if (a.ldy % 4 || !al16(a.Y)) return false;
-  if (a.epi_mode == SPGAN_EPI_MASK_OUT) return !a.stats && !a.bias && !a.rowbias && a.ld_ref % 4 == 0 && al16(a.ref);
+  if (a.stats) return false;   // column statistics stay with the MFMA epilogue: its reduction tree is part of the BatchNorm bits
+  // per-group bias rows: only where the MFMA kernel would take its whole-tile path (bias + group row added first: same bits)
+  if (a.rowbias && (a.rows_per_group <= 0 || a.rows_per_group % BM || a.M % BM || a.N % 64)) return false;
+  if (a.epi_mode == SPGAN_EPI_MASK_OUT) return !a.bias && !a.rowbias && a.ld_ref % 4 == 0 && al16(a.ref);
   return a.epi_mode == SPGAN_EPI_LINEAR;
-}
-inline bool nt_n4_ok(const spgan_gemm_nt_args& a) {
-  if (!nt_skinny_on(a) || a.N > 4 || a.epi_mode != SPGAN_EPI_LINEAR || a.stats || !a.Y || a.rowbias) return false;
-  if (a.a_mode != SPGAN_A_PLAIN && (a.a_mode != SPGAN_A_AFFINE_LRELU || a.p_group_rows > 0)) return false;
-  if (a.K != 32 && a.K != 64 && a.K != 128 && a.K != 256) return false;
-  return a.lda % 4 == 0 && al16(a.A);
-}
-template <int AMODE>
-void launch_nt_n4(const spgan_gemm_nt_args& a, hipStream_t s) {
-  const int lpr = a.K / 4, rb = 4 * N4_U * (64 / lpr);
-  const dim3 g(cdiv(a.M, rb));
-  if (lpr == 8) hipLaunchKernelGGL((gemm_nt_n4_kernel<AMODE, 8>), g, dim3(256), 0, s, a);
-  else if (lpr == 16) hipLaunchKernelGGL((gemm_nt_n4_kernel<AMODE, 16>), g, dim3(256), 0, s, a);
-  else if (lpr == 32) hipLaunchKernelGGL((gemm_nt_n4_kernel<AMODE, 32>), g, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_nt_n4_kernel<AMODE, 64>), g, dim3(256), 0, s, a);
 }
 
 template <int AMODE, int EPI>
@@ -1309,9 +1246,10 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
       return spgan_launch_status();
     }
   }
-  if constexpr ((AMODE == SPGAN_A_PLAIN || AMODE == SPGAN_A_AFFINE_LRELU) && EPI == SPGAN_EPI_LINEAR) {
-    if (nt_n4_ok(a)) {  // <= 4 output columns: the streaming kernel
-      launch_nt_n4<AMODE>(a, s);
+  if constexpr (AMODE == A_AFFINE2 && EPI == SPGAN_EPI_EDGE_BNBWD) {
+    if (a.a_half) {  // bfloat16 g / fp16 y (validated in spgan_gemm_nt): the EdgeBlock's lazy BatchNorm-backward operand in 16-bit storage
+      if (a.N > 64 && a.K >= 512) launch_nt_cfg<AMODE, EPI, 0, 1, 1, 1, 1>(a, s);
+      else launch_nt_cfg<AMODE, EPI, 1, 0, 1, 1, 1>(a, s);
       return spgan_launch_status();
     }
   }
@@ -1643,15 +1581,30 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
     if (a2) asc2 = *reinterpret_cast<const float4*>(p.a_scale2 + a0 + ac);
   }
   float4 ra2[4];
+  const bool a16 = p.a_half != 0;                          // A lies in memory as bfloat16, A2 (when given) as fp16: the EdgeBlock's 16-bit lazy operand
   const bool bh = BMODE == SPGAN_A_PLAIN && p.b_half;     // B lies in memory as fp16 (the EdgeBlock's T: spgan_edge_attend_fwd_h)
   const bool acs = p.a_colsum_ws != nullptr && tb == 0;   // fp32 column sums of the transformed A operand (before the bf16 rounding)
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int mb) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)min(mb + ar + i, p.M - 1) * p.lda + (aok ? a0 + ac : 0));
+    for (int i = 0; i < 4; ++i) {
+      if (a16) {   // A stored as bfloat16 (+ A2 as fp16): 8-byte loads, kept raw until sstore
+        const float2 h = *reinterpret_cast<const float2*>(reinterpret_cast<const uint16_t*>(p.A) + (size_t)min(mb + ar + i, p.M - 1) * p.lda + (aok ? a0 + ac : 0));
+        ra[i].x = h.x;
+        ra[i].y = h.y;
+      } else
+      ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)min(mb + ar + i, p.M - 1) * p.lda + (aok ? a0 + ac : 0));
+    }
     if (a2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ra2[i] = *reinterpret_cast<const float4*>(p.A2 + (size_t)min(mb + ar + i, p.M - 1) * p.lda2 + (aok ? a0 + ac : 0));
+      for (int i = 0; i < 4; ++i) {
+        if (a16) {
+          const float2 h = *reinterpret_cast<const float2*>(reinterpret_cast<const uint16_t*>(p.A2) + (size_t)min(mb + ar + i, p.M - 1) * p.lda2 + (aok ? a0 + ac : 0));
+          ra2[i].x = h.x;
+          ra2[i].y = h.y;
+        } else
+        ra2[i] = *reinterpret_cast<const float4*>(p.A2 + (size_t)min(mb + ar + i, p.M - 1) * p.lda2 + (aok ? a0 + ac : 0));
+      }
     }
 #pragma unroll
     for (int i = 0; i < RP; ++i) {
@@ -1675,6 +1628,13 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = ra[i];
+      if (a16) {
+        const float2 rg = make_float2(ra[i].x, ra[i].y), ry = make_float2(ra2[i].x, ra2[i].y);
+        const bf16x4 gb = *reinterpret_cast<const bf16x4*>(&rg);
+        const f16x4 yh = *reinterpret_cast<const f16x4*>(&ry);
+        v = make_float4((float)gb[0], (float)gb[1], (float)gb[2], (float)gb[3]);
+        if (a2) ra2[i] = make_float4((float)yh[0], (float)yh[1], (float)yh[2], (float)yh[3]);
+      }
       const bool ok = mb + ar + i < mend && aok;
       if (a2 && ok) {
         v.x = fmaf(v.x, asc.x, fmaf(ra2[i].x, asc2.x, ash.x));
@@ -2081,11 +2041,12 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
     return spgan_launch_status();
   }
   if (a.b_half && (BMODE != SPGAN_A_PLAIN || a.mfma_lp != 1 || a.a_sp_val)) return SPGAN_EINVAL;  // fp16-stored B: the bf16 kernel only
+  if (a.a_half && (a.mfma_lp != 1 || a.a_sp_val || tn_skinny(a.Na, a.Nb))) return SPGAN_EINVAL;    // 16-bit stored A (/A2): likewise
   const int TB = tn_tb(a.Nb);
   const dim3 grid(cdiv(a.Na, TA) * cdiv(a.Nb, TB), splits);
   const bool fast = (a.Na % 4 == 0) && (a.Nb % 4 == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && al16(a.A) && al16(a.B) &&
                     (!a.A2 || (al16(a.A2) && a.lda2 % 4 == 0));
-  if (a.b_half && !fast) return SPGAN_EINVAL;
+  if ((a.b_half || a.a_half) && !fast) return SPGAN_EINVAL;
   if (fast && a.mfma_lp == 1) {  // bf16 operands (aligned problems only; others keep the fp32 kernel)
     if (TB == 128) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 0>), grid, dim3(256), 0, s, a, rows);
     else if (TB == 64) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 1>), grid, dim3(256), 0, s, a, rows);
@@ -2132,12 +2093,13 @@ extern "C" int spgan_gemm_nt_owns_columns(const spgan_gemm_nt_args* a) {
   return fast ? 1 : 0;
 }
 
-// y_bf16 is honoured by the fp16-operand kernels' LINEAR epilogues (128-row and 256 x 256): everything fp16 mode sends there
+// y_bf16 / y_half are honoured by the fp16-operand kernels' LINEAR epilogues (128-row and 256 x 256): everything fp16 mode sends there
 extern "C" int spgan_gemm_nt_y16_ok(const spgan_gemm_nt_args* a) {
   if (!a || a->mfma_f16 != 1 || a->epi_mode != SPGAN_EPI_LINEAR || a->act != SPGAN_ACT_NONE || a->batch > 1 || a->M <= 64 || a->N <= 32) return 0;
-  if (a->sp_val || a->a_mode == SPGAN_A_EDGE) return 0;   // the sparse-addend kernels have no fp16 form
+  if (a->sp_val) return 0;   // the sparse-addend kernels have no fp16 form
   bool fast = (a->K % 4 == 0) && (a->lda % 4 == 0) && (a->ldw % 4 == 0) && al16(a->A) && al16(a->W);
   if (a->a_mode != SPGAN_A_PLAIN) fast = fast && al16(a->p_scale) && al16(a->p_shift);
+  if (a->a_mode == SPGAN_A_EDGE) fast = fast && al16(a->e_bias);
   if (a->A2) fast = fast && al16(a->A2) && (a->lda2 % 4 == 0) && al16(a->p_scale2);
   return fast ? 1 : 0;
 }
@@ -2168,11 +2130,13 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
     if (f.mode == 1) SPGAN_CHECK_ARG(f.out0 && f.out1);
     if (f.scale) SPGAN_CHECK_ARG(f.mode == 0 && f.shift && f.invstd && f.mean_out && (!f.rmean || f.rvar));
   }
-  if (a->a_half || a->y_bf16) {  // 16-bit storage: the fp16-operand kernels, aligned problems, plain linear product
-    SPGAN_CHECK_ARG(a->mfma_f16 == 1 && a->epi_mode == SPGAN_EPI_LINEAR && a->act == SPGAN_ACT_NONE && a->batch <= 1 && !a->tail.enabled &&
+  if (a->a_half || a->y_bf16 || a->y_half) {  // 16-bit storage: the fp16-operand kernels, aligned problems
+    SPGAN_CHECK_ARG(a->mfma_f16 == 1 && a->batch <= 1 && !a->tail.enabled && !a->sp_val &&
                     a->M > 64 && a->N > 32 && a->K % 4 == 0 && a->lda % 4 == 0 && a->ldw % 4 == 0 && al16(a->A) && al16(a->W));
-    if (a->a_half) SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && !a->A2);
-    if (a->y_bf16) SPGAN_CHECK_ARG(a->Y && spgan_gemm_nt_y16_ok(a));
+    if (a->a_half && !a->A2) SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->epi_mode == SPGAN_EPI_LINEAR);   // fp16 A of a plain linear product
+    if (a->a_half && a->A2)   // bfloat16 A + fp16 A2: the EdgeBlock's lazy BatchNorm-backward operand into the edge BatchNorm-backward epilogue
+      SPGAN_CHECK_ARG(a->epi_mode == SPGAN_EPI_EDGE_BNBWD && a->lda2 % 4 == 0 && al16(a->A2) && al16(a->p_scale) && al16(a->p_shift) && al16(a->p_scale2));
+    if (a->y_bf16 || a->y_half) SPGAN_CHECK_ARG(a->Y && !(a->y_bf16 && a->y_half) && a->act == SPGAN_ACT_NONE && spgan_gemm_nt_y16_ok(a));
   }
   switch (a->epi_mode) {
     case SPGAN_EPI_LINEAR:

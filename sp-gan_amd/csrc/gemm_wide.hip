@@ -16,6 +16,7 @@
 //
 // Only straight-line code: shapes that do not tile exactly, the split-bf16 operand mode, the per-edge prologue/epilogue and the
 // in-launch fan-in stay with gemm.hip (launch_nt falls through).  fp16 operands (mfma_f16 == 1) are served here: D.fc2.0 114 -> 99 us.
+#include <type_traits>
 #include "gemm_wide.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_g
         }
       }
     }
-    if (F16 && p.Y && p.y_bf16) {   // bfloat16 result storage (the EdgeBlock's dT; no activation: checked on the host)
+    if (F16 && p.Y && p.y_bf16) {   // 16-bit result storage (no activation: checked on the host): bfloat16 (the EdgeBlock's dT)
       __bf16* yb = reinterpret_cast<__bf16*>(p.Y) + (size_t)rbase * p.ldy + cbase;
       const unsigned ldy = (unsigned)p.ldy;
 #pragma unroll
@@ -241,6 +242,15 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_g
         for (int i = 0; i < TI; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = (__bf16)acc[i][j][r];
+    } else if (F16 && p.Y && p.y_half) {   // ... or fp16
+      _Float16* yb = reinterpret_cast<_Float16*>(p.Y) + (size_t)rbase * p.ldy + cbase;
+      const unsigned ldy = (unsigned)p.ldy;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = (_Float16)acc[i][j][r];
     } else if (p.Y) {
       float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
       const unsigned ldy = (unsigned)p.ldy;

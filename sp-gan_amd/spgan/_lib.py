@@ -49,7 +49,7 @@ class GemmNTArgs(C.Structure):
         ("tile_hint", C.c_int),
         ("p_group_rows", C.c_int),
         ("A2", c_f32p), ("lda2", C.c_int), ("p_scale2", c_f32p),
-        ("a_half", C.c_int), ("y_bf16", C.c_int),
+        ("a_half", C.c_int), ("y_bf16", C.c_int), ("y_half", C.c_int),
     ]
 
 
@@ -70,7 +70,7 @@ class GemmTNArgs(C.Structure):
         ("A2", c_f32p), ("lda2", C.c_int), ("a_scale2", c_f32p),
         ("a_colsum_ws", c_f32p),
         ("a_lrelu", C.c_int), ("a_slope", C.c_float),
-        ("b_half", C.c_int),
+        ("b_half", C.c_int), ("a_half", C.c_int),
     ]
 
 
@@ -135,8 +135,8 @@ SIGNATURES = {
     "spgan_edge_stats_tile_rows": (I, [I]),
     "spgan_edge_stats": (I, [P, I, P, I, I, I, I, P, P, P, P]),
     "spgan_edge_attend_fwd": (I, [P, P, P, P, I, I, I, P, I, I, P, P, P, F, P, P]),
-    "spgan_edge_attend_fwd_h": (I, [P, P, P, P, I, I, I, P, I, I, P, P, P, F, P, P]),
-    "spgan_edge_attend_bwd_b": (I, [P, P, P, P, P, P, P, I, I, I, P, I, I, P, P, P, P, P, F, P, P, P, P]),
+    "spgan_edge_attend_fwd_h": (I, [P, I, P, P, P, I, I, I, P, I, I, P, P, P, F, P, P]),
+    "spgan_edge_attend_bwd_b": (I, [P, P, I, P, P, P, P, P, I, I, I, P, I, I, P, P, P, P, P, F, P, P, P, P]),
     "spgan_gemm_nt_y16_ok": (I, [P]),
     "spgan_edge_attend_bwd_tile_points": (I, []),
     "spgan_edge_attend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, I, I, P, P, P, P, P, F, P, P, P, P]),

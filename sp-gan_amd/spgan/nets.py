@@ -693,9 +693,11 @@ def _edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int
         bn1 = _bn_train(None, None, P, bufs, pre + ".conv_w.1", E, False, False)
         bnx = _bn_train(None, None, P, bufs, pre + ".conv_x.1", E, False, False)
     W2, b2 = _w2(P[pre + ".conv_w.3.weight"]), P[pre + ".conv_w.3.bias"]
+    # "f16" operand mode at full size: the per-edge tensors live in HBM in 16 bits -- h2pre and T as float16 (activations), dT, g2 and gy as
+    # bfloat16 (gradients); BatchNorm statistics and every sum stay fp32 (taken from the accumulators / the unrounded values)
+    s16 = ops.storage16(E, F_, k) and _lazy_ok(E, F_)
     h2pre, bn2 = _gemm_bn(PQR[:, :H], W2, b2, P, bufs, pre + ".conv_w.4", E, training, update_running, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1),
-                          **({"count_rep": count_rep} if training and count_rep > 1 else {}))
-    s16 = ops.storage16(E, F_, k)    # "f16" operand mode at full size: T lives in HBM as float16, dT as bfloat16 (only GEMMs touch them)
+                          **({"count_rep": count_rep} if training and count_rep > 1 else {}), **({"out_half": True} if s16 else {}))
     T = ops.edge_attend_fwd(h2pre, bn2[0], bn2[1], PQR, idx, bx, bnx[0], bnx[1], NEG, half=s16)
     Wo = conv_out_weight_pm(P[pre + ".conv_out.weight"])
     out = ops.gemm_nt(T, Wo, P[pre + ".conv_out.bias"])

@@ -282,10 +282,11 @@ def _finalize(partials: Tensor, groups: int, tpg: int, Cn: int, G: int, mode: in
 
 def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, edge=None, rowbias: Optional[Tensor] = None,
             rows_per_group: int = 0, act: int = ACT_NONE, slope: float = 0.0, stats: bool = False, M: Optional[int] = None, bn=None,
-            out: Optional[Tensor] = None, exact: bool = False, count_rep: int = 1, out_bf16: bool = False):
+            out: Optional[Tensor] = None, exact: bool = False, count_rep: int = 1, out_bf16: bool = False, out_half: bool = False):
     """Y[M,N] = act( pro(A) @ W^T + bias + rowbias[m // rows_per_group] ).
     16-bit storage ("f16" operand mode only; see storage16()): A may be a float16 tensor (plain operand: the EdgeBlock's T, written
-    by edge_attend_fwd(half=True)); out_bf16=True returns Y as bfloat16 (plain linear product: the EdgeBlock's dT).
+    by edge_attend_fwd(half=True)); out_bf16=True returns Y as bfloat16 (plain linear product: the EdgeBlock's dT); out_half=True
+    returns Y as float16 (no activation; statistics / bn still from the fp32 accumulators: the EdgeBlock's h2pre).
     out  = destination [M,N] (unit column stride; may be a column slice of a wider buffer) instead of a fresh tensor.
     bn = (gamma, beta, running_mean | None, running_var | None): train-mode BatchNorm of Y fused behind the GEMM: returns
          (Y, (scale, shift, invstd, mean)) and updates the running statistics -- column statistics in the epilogue, merged by a
@@ -338,6 +339,11 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
             raise ValueError("out_bf16 goes with a plain linear product into a fresh tensor")
         Y = torch.empty((M_, N), dtype=torch.bfloat16, device=A.device)
         a.y_bf16 = 1
+    elif out_half:
+        if out is not None or act != ACT_NONE:
+            raise ValueError("out_half goes with a linear product (no activation) into a fresh tensor")
+        Y = torch.empty((M_, N), dtype=torch.float16, device=A.device)
+        a.y_half = 1
     elif out is None:
         Y = torch.empty((M_, N), dtype=torch.float32, device=A.device)
     else:
@@ -474,18 +480,24 @@ class Affine2:
     def __init__(self, g: Tensor, y: Tensor, coef: Tensor):
         if g.shape != y.shape or coef.shape != (3, g.shape[1]):
             raise ValueError("Affine2: g and y must have equal shapes, coef [3,C]")
+        self.half = g.dtype == torch.bfloat16       # 16-bit storage ("f16" operand mode): g bfloat16 + y float16, both or neither
+        if self.half != (y.dtype == torch.float16):
+            raise ValueError("Affine2: a bfloat16 g goes with a float16 y (16-bit storage), float32 with float32")
         self.g, self.y, self.coef = g, y, coef
         self.p, self.q, self.r = coef[0], coef[1], coef[2]
         self.shape, self.device = g.shape, g.device
 
     def dense(self) -> Tensor:
         """The materialised tensor (for a consumer without the two-tensor operand): p*g + (q*y + r), the kernels' expression."""
-        return torch.addcmul(torch.addcmul(self.r, self.y, self.q), self.g, self.p)
+        return torch.addcmul(torch.addcmul(self.r, self.y.float(), self.q), self.g.float(), self.p)
 
 
 def bn_bwd_lazy(g: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Optional[Tensor], sums: Tensor, count: int) -> Affine2:
     """bn_bwd_apply as a lazy operand: one C-sized launch for the coefficients instead of a pass over [M,C]."""
-    _f32(g, "g", 2); _f32(y, "y", 2)
+    if g.dtype == torch.bfloat16:               # 16-bit storage: the tensors are only handed on, the coefficients come from the sums
+        _rowmajor2d_as(g, "g", torch.bfloat16); _rowmajor2d_as(y, "y", torch.float16)
+    else:
+        _f32(g, "g", 2); _f32(y, "y", 2)
     if not (g.is_contiguous() and y.is_contiguous()) or g.shape != y.shape:
         raise ValueError("g and y must be contiguous with equal shapes")
     Cn = g.shape[1]
@@ -542,7 +554,13 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
             a2, A = None, A.dense()              # the two-tensor operand is a path of the 128-row kernels
         else:
             A = a2.g
-    _rowmajor2d(A, "A"); _rowmajor2d(W, "W"); _rowmajor2d(y_ref, "y_ref")
+    if a2 is not None and a2.half:
+        if edge is None or _MFMA_F16[0] != 1:
+            raise ValueError("a 16-bit Affine2 operand is the EdgeBlock's (edge=...) in the 'f16' operand mode")
+        _rowmajor2d_as(A, "A", torch.bfloat16)
+    else:
+        _rowmajor2d(A, "A")
+    _rowmajor2d(W, "W"); _rowmajor2d(y_ref, "y_ref")
     N, K = W.shape
     M_ = A.shape[0]
     g = torch.empty((M_, N), dtype=torch.float32, device=A.device)
@@ -560,6 +578,7 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
         a.a_mode = A_AFFINE_LRELU
         a.p_scale = _p(_vec(a2.p, K, "p")); a.p_shift = _p(_vec(a2.r, K, "r")); a.p_slope = 1.0
         a.A2 = _p(a2.y); a.lda2 = _ld(a2.y); a.p_scale2 = _p(_vec(a2.q, K, "q"))
+        a.a_half = 1 if a2.half else 0
     elif pro is not None:
         a.a_mode = A_AFFINE_LRELU
         a.p_scale = _p(_vec(pro[0], K, "pro.scale")); a.p_shift = _p(_vec(pro[1], K, "pro.shift")); a.p_slope = float(pro[2])
@@ -633,10 +652,10 @@ STORAGE16 = [os.environ.get("SPGAN_F16_STORAGE", "1") != "0"]
 
 
 def storage16(E: int, F_: int, k: int) -> bool:
-    """True when the EdgeBlock keeps T as float16 and dT as bfloat16 in HBM: the "f16" operand mode (BASELINE configs[4]) at sizes
-    where its 16-bit kernels are the ones that run.  Both tensors have GEMMs as their only consumer / producer, which round them to
-    16 bits anyway (T: the fp16 MFMA operand of conv_out; dT: one more rounding, bfloat16 for the exponent range of a gradient)."""
-    return STORAGE16[0] and _MFMA_F16[0] == 1 and k == 10 and F_ % 4 == 0 and F_ > 32 and E >= 10 * TN_LP_MIN_ROWS
+    """True when the EdgeBlock keeps its per-edge tensors in 16 bits in HBM: the "f16" operand mode (BASELINE configs[4]) at sizes where
+    its 16-bit kernels are the ones that run.  Activations (h2pre, T) as float16, gradients (dT, g2, gy) as bfloat16 (fp32's exponent
+    range); BatchNorm statistics and all column sums are taken from the fp32 accumulators / unrounded values."""
+    return STORAGE16[0] and _MFMA_F16[0] == 1 and k == 10 and F_ % 8 == 0 and F_ > 64 and E >= 10 * TN_LP_MIN_ROWS    # F/2 > 32 columns: the fp16 128-row kernels
 
 
 TN_LP_MIN_ROWS = 8192     # "f16" operand mode: weight gradients reduce over >= this many points/edges on the bf16 matrix pipe
@@ -662,7 +681,11 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     if a2 is not None:
         A = a2.g
     b_half = Bm.dtype == torch.float16
-    _rowmajor2d(A, "A")
+    a16 = a2 is not None and a2.half
+    if a16:
+        _rowmajor2d_as(A, "A", torch.bfloat16)
+    else:
+        _rowmajor2d(A, "A")
     if b_half:
         _rowmajor2d_as(Bm, "B", torch.float16)
         if pro is not None or edge is not None or sa is not None:
@@ -711,8 +734,9 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     defer = bool(defer) and sa is None
     a.defer_reduce = 1 if defer else 0
     a.mfma_lp = 1 if (_MFMA_F16[0] == 1 and not exact and M_ >= TN_LP_MIN_ROWS) else 0
-    if b_half and not a.mfma_lp:
-        raise ValueError("a float16 B needs the bf16 weight-gradient kernel ('f16' operand mode, M >= %d, exact=False)" % TN_LP_MIN_ROWS)
+    if (b_half or a16) and not a.mfma_lp:
+        raise ValueError("16-bit stored operands need the bf16 weight-gradient kernel ('f16' operand mode, M >= %d, exact=False)" % TN_LP_MIN_ROWS)
+    a.a_half = 1 if a16 else 0
     splits = lib.spgan_gemm_tn_splits(M_, Na, Nb)
     cs_out = cs_ws = None
     streaming = (Na <= 4 or Nb <= 4) and Na <= 2048 and Nb <= 2048 and pro is None and edge is None and sa is None and a_pro is None   # 3-column layers: the streaming kernel + a colsum pass stay cheaper
@@ -1090,12 +1114,18 @@ def edge_attend_fwd(h2pre: Tensor, sc2: Tensor, sh2: Tensor, PQR: Tensor, idx: T
     H = PQR.shape[1] - 2 * F_
     _pqr(PQR, H, F_); _i32(idx, "idx")
     M_, k = idx.shape
-    _f32(h2pre, "h2pre", 2)
+    h2_half = h2pre.dtype == torch.float16      # written by gemm_nt(out_half=True): 16-bit storage, goes with half=True
+    if h2_half:
+        if not half:
+            raise ValueError("a float16 h2pre belongs to the 16-bit storage mode (half=True)")
+        _rowmajor2d_as(h2pre, "h2pre", torch.float16)
+    else:
+        _f32(h2pre, "h2pre", 2)
     if not h2pre.is_contiguous() or h2pre.shape != (M_ * k, F_):
         raise ValueError("h2pre must be contiguous [M*k, F]")
     T = torch.empty((M_, k * F_), dtype=torch.float16 if half else torch.float32, device=PQR.device)
     fn = _lib.load().spgan_edge_attend_fwd_h if half else _lib.load().spgan_edge_attend_fwd
-    check(fn(_p(h2pre), _p(_vec(sc2, F_, "sc2")), _p(_vec(sh2, F_, "sh2")), _p(PQR), PQR.shape[1], H, F_, _p(idx), M_, k,
+    check(fn(*((_p(h2pre), 1 if h2_half else 0) if half else (_p(h2pre),)), _p(_vec(sc2, F_, "sc2")), _p(_vec(sh2, F_, "sh2")), _p(PQR), PQR.shape[1], H, F_, _p(idx), M_, k,
              _p(_vec(bx, F_, "bx")), _p(_vec(scx, F_, "scx")), _p(_vec(shx, F_, "shx")), float(slope), _p(T), _s()),
           "edge_attend_fwd", M=M_, k=k, F=F_, half=half)
     return T
@@ -1112,17 +1142,23 @@ def edge_attend_bwd(dT: Tensor, h2pre: Tensor, sc2, sh2, mean2, inv2, PQR: Tenso
         _rowmajor2d_as(dT, "dT", torch.bfloat16)
     else:
         _f32(dT, "dT", 2)
-    _f32(h2pre, "h2pre", 2)
+    h2_half = h2pre.dtype == torch.float16
+    if h2_half:
+        if not dT_b:
+            raise ValueError("a float16 h2pre belongs to the 16-bit storage mode (bfloat16 dT)")
+        _rowmajor2d_as(h2pre, "h2pre", torch.float16)
+    else:
+        _f32(h2pre, "h2pre", 2)
     if not (dT.is_contiguous() and h2pre.is_contiguous()) or dT.numel() != M_ * k * F_ or h2pre.numel() != M_ * k * F_:
         raise ValueError("dT / h2pre must be contiguous with M*k*F elements")
     lib = _lib.load()
     tp = lib.spgan_edge_attend_bwd_tile_points()
     tiles = (M_ + tp - 1) // tp
-    g2 = torch.empty((M_ * k, F_), dtype=torch.float32, device=PQR.device)
+    g2 = torch.empty((M_ * k, F_), dtype=torch.bfloat16 if dT_b else torch.float32, device=PQR.device)    # 16-bit storage: a GEMM operand only
     gy = torch.empty((M_ * k, F_), dtype=torch.bfloat16 if dT_b else torch.float32, device=PQR.device)   # 16-bit storage: gy too (edge_scatter reads it)
     part = torch.empty((tiles, 2 * F_, 2), dtype=torch.float32, device=PQR.device)
     v = lambda t, n: _p(_vec(t, F_, n))
-    check((lib.spgan_edge_attend_bwd_b if dT_b else lib.spgan_edge_attend_bwd)(_p(dT), _p(h2pre), v(sc2, "sc2"), v(sh2, "sh2"), v(mean2, "mean2"), v(inv2, "inv2"), _p(PQR), PQR.shape[1],
+    check((lib.spgan_edge_attend_bwd_b if dT_b else lib.spgan_edge_attend_bwd)(_p(dT), *((_p(h2pre), 1 if h2_half else 0) if dT_b else (_p(h2pre),)), v(sc2, "sc2"), v(sh2, "sh2"), v(mean2, "mean2"), v(inv2, "inv2"), _p(PQR), PQR.shape[1],
                                     H, F_, _p(idx), M_, k, v(bx, "bx"), v(scx, "scx"), v(shx, "shx"), v(meanx, "meanx"), v(invx, "invx"),
                                     float(slope), _p(g2), _p(gy), _p(part), _s()), "edge_attend_bwd", M=M_, k=k, F=F_)
     # partial columns are laid out so that the two finalize outputs ARE [sum g2 | sum g2*xhat2] and [sum gy | sum gy*xhaty]

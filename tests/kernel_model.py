@@ -97,9 +97,12 @@ def _operand(A, pro, edge, K):
 
 
 def gemm_nt(A, W, bias=None, *, pro=None, edge=None, rowbias=None, rows_per_group=0, act=ACT_NONE, slope=0.0, stats=False, M=None, bn=None,
-            out=None, exact=False, count_rep=1, out_bf16=False):
+            out=None, exact=False, count_rep=1, out_bf16=False, out_half=False):
     if out_bf16:     # bfloat16 storage of the result (ops.gemm_nt(out_bf16=True))
         return gemm_nt(A, W, bias, pro=pro, edge=edge, rowbias=rowbias, rows_per_group=rows_per_group, M=M).to(torch.bfloat16)
+    if out_half:     # float16 storage of the result; statistics / bn from the unrounded values
+        r = gemm_nt(A, W, bias, pro=pro, edge=edge, rowbias=rowbias, rows_per_group=rows_per_group, stats=stats, M=M, bn=bn, count_rep=count_rep)
+        return (r[0].half(),) + tuple(r[1:]) if isinstance(r, tuple) else r.half()
     if isinstance(A, torch.Tensor) and A.dtype == torch.float16:   # float16-stored operand
         A = A.float()
     if out is not None:
@@ -175,7 +178,7 @@ class Affine2:
         self.shape, self.device = g.shape, g.device
 
     def dense(self):
-        return self.g * self.p + (self.y * self.q + self.r)
+        return self.g.float() * self.p + (self.y.float() * self.q + self.r)      # .float(): the 16-bit storage mode hands g / y over as bfloat16 / float16
 
 
 def bn_bwd_lazy(g, y, mean, invstd, gamma, sums, count):
@@ -404,7 +407,7 @@ def _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope):
     F_ = bx.numel()
     H = PQR.shape[1] - 2 * F_
     _, yp = _edge_pre(PQR, idx, torch.zeros(H, device=PQR.device), bx)
-    z2 = (h2pre * sc2 + sh2).view(M, k, F_)
+    z2 = (h2pre.float() * sc2 + sh2).view(M, k, F_)
     zy = (yp * scx + shx).view(M, k, F_)
     w = torch.softmax(_lrelu(z2, slope), dim=1)
     return z2, zy, w, _lrelu(zy, slope), yp.view(M, k, F_)
@@ -439,7 +442,7 @@ def edge_attend_bwd(dT, h2pre, sc2, sh2, mean2, inv2, PQR, idx, bx, scx, shx, me
     g2 = (ds * torch.where(z2 > 0, 1.0, slope)).reshape(M * k, F_)
     gy = (d * w * torch.where(zy > 0, 1.0, slope)).reshape(M * k, F_)
     if dT.dtype == torch.bfloat16:           # 16-bit storage mode: gy is handed on as bfloat16 (statistics from the float values)
-        return (g2.contiguous(), gy.to(torch.bfloat16).contiguous(), torch.cat([g2.sum(0), (g2 * ((h2pre - mean2) * inv2)).sum(0)]),
+        return (g2.to(torch.bfloat16).contiguous(), gy.to(torch.bfloat16).contiguous(), torch.cat([g2.sum(0), (g2 * ((h2pre.float() - mean2) * inv2)).sum(0)]),
                 torch.cat([gy.sum(0), (gy * ((yp.reshape(M * k, F_) - meanx) * invx)).sum(0)]))
     xh2 = (h2pre - mean2) * inv2
     xhy = (yp.reshape(M * k, F_) - meanx) * invx

@@ -169,10 +169,20 @@ def test_storage16_edge_attend(f16, B, N, H, F_):
     mx, ix = rnd("s16.mx%d" % F_, (F_,), 0.2), rnd("s16.ix%d" % F_, (F_,)).abs() + 0.5
     got = ops.edge_attend_bwd(dT, h2, sc2, sh2, m2, i2, PQR, idx, bx, scx, shx, mx, ix, 0.01)
     want = ops.edge_attend_bwd(dT.float(), h2, sc2, sh2, m2, i2, PQR, idx, bx, scx, shx, mx, ix, 0.01)
-    assert got[1].dtype == torch.bfloat16                 # gy travels on as bfloat16 (edge_scatter is its only consumer)
+    assert got[0].dtype == torch.bfloat16 and got[1].dtype == torch.bfloat16     # g2 (a GEMM operand only) and gy (edge_scatter only) travel on as bfloat16
     for g, w, what in zip(got, want, ("g2", "gy", "sums2", "sumsy")):
-        close(g.float(), w, rtol=3e-3 if what == "gy" else 2e-5, atol=1e-12, what="bfloat16 dT: " + what)
-    assert float((got[1] == want[1].bfloat16()).float().mean()) > 0.99
+        close(g.float(), w, rtol=3e-3 if what in ("g2", "gy") else 2e-5, atol=1e-12, what="bfloat16 dT: " + what)      # the sums come from the unrounded values
+    assert float((got[0] == want[0].bfloat16()).float().mean()) > 0.99 and float((got[1] == want[1].bfloat16()).float().mean()) > 0.99
+    # h2pre stored as float16 (written by the edge GEMM with out_half=True): the same kernels reading halfs
+    h2h = h2.half()
+    close(ops.edge_attend_fwd(h2h, sc2, sh2, PQR, idx, bx, scx, shx, 0.01, half=True).float(),
+          ops.edge_attend_fwd(h2h.float(), sc2, sh2, PQR, idx, bx, scx, shx, 0.01, half=True).float(), rtol=1e-6, atol=6e-8, what="float16 h2pre: T")
+    gh = ops.edge_attend_bwd(dT, h2h, sc2, sh2, m2, i2, PQR, idx, bx, scx, shx, mx, ix, 0.01)
+    wh = ops.edge_attend_bwd(dT, h2h.float(), sc2, sh2, m2, i2, PQR, idx, bx, scx, shx, mx, ix, 0.01)
+    for g, w, what in zip(gh, wh, ("g2", "gy", "sums2", "sumsy")):
+        close(g.float(), w.float(), rtol=2e-5, atol=1e-12, what="float16 h2pre: " + what)
+    with pytest.raises(ValueError):
+        ops.edge_attend_fwd(h2h, sc2, sh2, PQR, idx, bx, scx, shx, 0.01)
     # edge_scatter on the bfloat16 gy == the float kernel on the same values
     H_ = H
     rowptr, src = ops.csr_build(idx, B, N)
@@ -186,12 +196,54 @@ def test_storage16_edge_attend(f16, B, N, H, F_):
     close(d16, d32, rtol=1e-6, atol=1e-12, what="edge_scatter on bfloat16 gy")
 
 
+@pytest.mark.parametrize("B,N,H,F_", [(4, 2048, 64, 128), (3, 700, 48, 96)])
+def test_storage16_edge_gemms(f16, B, N, H, F_):
+    """The three edge GEMMs of the EdgeBlock in 16-bit storage mode: h2pre written as float16 by the edge-operand product (statistics
+    from the fp32 accumulators: unchanged), the lazy BatchNorm-backward operand p*g2 + q*h2pre + r with g2 bfloat16 / h2pre float16 in
+    the weight-gradient (gemm_tn) and input-gradient (gemm_nt_bnbwd, edge epilogue) products: each against the same kernel fed the same
+    values from float32 storage."""
+    ops = f16
+    k, M = 10, B * N
+    E = M * k
+    x = rnd("s16g.x%d" % N, (M, 3))
+    idx = ops.knn(x, B, N, k, mode=1)
+    Pm = rnd("s16g.P%d.%d" % (N, H), (M, H))
+    b1 = rnd("s16g.b1%d" % H, (H,), 0.1)
+    sc1, sh1 = rnd("s16g.sc1%d" % H, (H,)).abs() + 0.5, rnd("s16g.sh1%d" % H, (H,), 0.3)
+    W2, b2 = rnd("s16g.W2%d.%d" % (F_, H), (F_, H), 0.2), rnd("s16g.b2%d" % F_, (F_,), 0.1)
+    mk = lambda: (rnd("s16g.ga%d" % F_, (F_,)).abs() + 0.5, rnd("s16g.be%d" % F_, (F_,), 0.2), torch.zeros(F_, device=x.device), torch.ones(F_, device=x.device))
+    bn_a, bn_b = mk(), mk()
+    y32, st32 = ops.gemm_nt(Pm, W2, b2, pro=(sc1, sh1, 0.2), edge=(idx, b1), bn=bn_a)
+    y16, st16 = ops.gemm_nt(Pm, W2, b2, pro=(sc1, sh1, 0.2), edge=(idx, b1), bn=bn_b, out_half=True)
+    assert y16.dtype == torch.float16 and torch.equal(y16, y32.half())
+    for a_, b_ in zip(st16 + (bn_b[2], bn_b[3]), st32 + (bn_a[2], bn_a[3])):
+        assert torch.equal(a_, b_)
+    # the lazy operand
+    g2 = (rnd("s16g.g2%d.%d" % (N, F_), (E, F_)) * 1e-2).bfloat16()        # (the fp16 MFMA operand of the input-gradient product would flush 1e-6)
+    coef = torch.stack([rnd("s16g.p%d" % F_, (F_,)).abs() + 0.5, rnd("s16g.q%d" % F_, (F_,), 1e-3), rnd("s16g.r%d" % F_, (F_,), 1e-4)])
+    lazy16, lazy32 = ops.Affine2(g2, y16, coef), ops.Affine2(g2.float(), y16.float(), coef)
+    with pytest.raises(ValueError):
+        ops.Affine2(g2, y16.float(), coef)
+    wg16 = ops.gemm_tn(lazy16, Pm, pro=(sc1, sh1, 0.2), edge=(idx, b1))
+    wg32 = ops.gemm_tn(lazy32, Pm, pro=(sc1, sh1, 0.2), edge=(idx, b1))
+    close(wg16, wg32, rtol=1e-6, atol=1e-14, what="weight gradient from 16-bit storage")
+    close(wg16, km.gemm_tn(km.Affine2(g2, y16, coef), Pm, pro=(sc1, sh1, 0.2), edge=(idx, b1)), rtol=8e-3, atol=1e-12, what="weight gradient vs model")
+    m1, i1 = rnd("s16g.m1%d" % H, (H,), 0.2), rnd("s16g.i1%d" % H, (H,)).abs() + 0.5
+    r16 = ops.gemm_nt_bnbwd(lazy16, W2.t().contiguous(), Pm, sc1, sh1, m1, i1, 0.2, edge=(idx, b1))
+    r32 = ops.gemm_nt_bnbwd(lazy32, W2.t().contiguous(), Pm, sc1, sh1, m1, i1, 0.2, edge=(idx, b1))
+    for a_, b_, what in zip(r16, r32, ("g1", "s0", "s1")):
+        close(a_, b_, rtol=1e-6, atol=1e-14, what="input gradient from 16-bit storage: " + what)
+    rm = km.gemm_nt_bnbwd(km.Affine2(g2, y16, coef), W2.t().contiguous(), Pm, sc1, sh1, m1, i1, 0.2, edge=(idx, b1))
+    for a_, b_, what in zip(r16, rm, ("g1", "s0", "s1")):
+        close(a_, b_, rtol=3e-3, atol=1e-9, what="input gradient vs model: " + what)
+
+
 def test_storage16_edgeblock_close_to_float32_storage(f16, sp):
     """The generator's second EdgeBlock (64 -> 128 channels) at a bench-like edge count, "f16" operand mode, with and without 16-bit
-    storage of T / dT: the forward is identical (T is rounded to the same halfs either way), gradients within bfloat16 rounding of dT."""
+    storage of the per-edge tensors (h2pre, T: float16; dT, g2, gy: bfloat16): within fp16 / bfloat16 rounding of those tensors."""
     ops = f16
     B, N, k = 4, 2048, 10
-    assert ops.storage16(B * N * k, 128, k) and not ops.storage16(B * N * k, 128, 20) and not ops.storage16(8192, 128, k)
+    assert ops.storage16(B * N * k, 128, k) and not ops.storage16(B * N * k, 128, 20) and not ops.storage16(8192, 128, k) and not ops.storage16(B * N * k, 64, k)
     torch.manual_seed(5)
     blk = sp.EdgeBlock(64, 128, k).cuda().train()
     x0 = rnd("s16.xb", (B, 64, N))
@@ -207,10 +259,10 @@ def test_storage16_edgeblock_close_to_float32_storage(f16, sp):
             res[on] = (out.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in blk.named_parameters()})
         finally:
             ops.STORAGE16[0] = True
-    assert torch.equal(res[True][0], res[False][0])
-    close(res[True][1], res[False][1], rtol=6e-3, what="dx")
-    for n, t in res[False][2].items():
-        close(res[True][2][n], t, rtol=6e-3, atol=1e-9 + 1e-4 * float(t.abs().max()), what=n)
+    close(res[True][0], res[False][0], rtol=1e-3, what="out")
+    close(res[True][1], res[False][1], rtol=8e-3, what="dx")
+    for n, t in res[False][2].items():         # BatchNorm weight / bias gradients are sums over all edges with heavy cancellation: looser
+        close(res[True][2][n], t, rtol=2e-2 if ".1." in n or ".4." in n else 8e-3, atol=1e-9 + 1e-4 * float(t.abs().max()), what=n)
 
 
 
