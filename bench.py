@@ -111,10 +111,10 @@ def _pmc_traffic():
     for name in PMC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["kernels"][DOMINANT["pmc_key"]]["hbm_bytes_per_launch_corrected"]
+                return json.load(f)["kernels"][DOMINANT["pmc_key"]]["hbm_bytes_per_launch_corrected"], name
         except Exception:
             continue
-    return None
+    return None, None
 
 
 # Dominant kernel of the step (profiles/r0*_bench_*_kernel_stats.txt): gemm_nt_wide_kernel<affine prologue, linear epilogue + column
@@ -198,16 +198,16 @@ class MfmaAccounting:
         per_shape = {("M=%d" % m): {"launches_timed": c, "avg_launch_ms": round(t / c, 4),
                                     "frac": round(2.0 * m * DOMINANT["N"] * DOMINANT["K"] / (t / c * 1e-3) / 1e12 / self.peak, 4)} for m, (c, t) in sorted(by_m.items())}
         rows_avg = sum(m for _, _, m in dom) / len(dom)
-        t1 = _pmc_traffic()
+        t1, t1_file = _pmc_traffic()
         return {"bound": "mfma", "kernel": "gemm_nt_wide_kernel<1,0,0> at D.fc2.0 (N=%d K=%d, BN+LeakyReLU prologue, column-statistics + max-pool epilogue, output not stored): "
                                            "per step one launch over the three D-step passes (M=%d) and one for the G step (M=%d)"
                                            % (DOMINANT["N"], DOMINANT["K"], 3 * self.M, self.M),
                 "achieved": round(achieved, 2), "peak": self.peak, "unit": "TFLOP/s", "frac": round(achieved / self.peak, 4),
                 "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches_timed": len(dom), "per_shape": per_shape,
                 "traffic": None if t1 is None else int(t1 * rows_avg / self.M),
-                "traffic_note": "HBM bytes per launch: measured for the one-pass launch (M=%d) in separate rocprofv3 --pmc passes (profiles/r02_pmc_gemm_nt.json: %s B "
+                "traffic_note": "HBM bytes per launch: measured for the one-pass launch (M=%d) in separate rocprofv3 --pmc passes (profiles/%s: %s B "
                                 "= 1.10x its algorithmic 80.7 MB: A 67.1 MB + W 1.0 MB read once + own statistics/pooling records 12.6 MB written), scaled by the "
-                                "average rows per launch (operand and records grow with the rows)" % (self.M, t1)}
+                                "average rows per launch (operand and records grow with the rows)" % (self.M, t1_file, t1)}
 
     def summary(self, steps, step_ms):
         if not self.rec:

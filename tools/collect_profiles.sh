@@ -12,7 +12,7 @@ python $R/bench.py --mfma f16 --no-cpu-baseline --no-extra-legs > $O/${TAG}_benc
 python $R/bench.py --mfma bf16x3 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_bf16x3.json 2>> $O/${TAG}_bench.err
 rm -rf /tmp/prof_s; rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/bench_s.log 2>&1
 DB=$(find /tmp/prof_s -name "*.db" | head -1)
-python $R/tools/rocprof_summary.py $DB 32 > $O/${TAG}_bench_kernel_stats.txt      # 4 priming + 3 warm-up + 20 timed + 4 eager accounting steps + the keep-busy launches
+python $R/tools/rocprof_summary.py $DB 31 > $O/${TAG}_bench_kernel_stats.txt      # 31 steps: 4 priming + 3 warm-up + 20 timed + 4 eager accounting steps (+ the keep-busy launches: the Cijk_ row)
 python $R/tools/gap_analysis.py $DB 0.35 0.7 > $O/${TAG}_bench_graph_replay_window.txt
 python $R/tools/step_sequence.py $DB -8 > $O/${TAG}_step_sequence.txt
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do rm -rf /tmp/p_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/p_$c -o r -- python $R/tools/pmc_step.py > /tmp/log_$c 2>&1; done
@@ -22,4 +22,7 @@ python $R/tools/pmc_gemm_json.py $O/${TAG}_pmc_gemm_FETCH_SIZE.txt $O/${TAG}_pmc
 python $R/tools/mfma_shapes.py > $O/${TAG}_mfma_shapes.txt 2>/dev/null
 python $R/tools/mfma_shapes.py --mfma f16 > $O/${TAG}_mfma_shapes_f16.txt 2>/dev/null
 python $R/tools/knn_ab.py > $O/${TAG}_knn_ab_raw.txt 2>&1
+bash $R/tools/profile_f16.sh $TAG > /dev/null 2>&1      # kernel table of the "f16" operand mode
+python $R/tools/exp/wide_k_sweep.py > $O/${TAG}_wide_k_sweep.txt 2>/dev/null
+python $R/tools/exp/mid_k_sweep.py > $O/${TAG}_mid_k_sweep.txt 2>/dev/null
 echo collected; ls -la $O | tail -20

@@ -9,7 +9,7 @@ import sys
 KERNELS = {
     "gemm_nt_wide_kernel<1, 0, 0>": ("gemm_nt D.fc2.0 M=65536 N=1024 K=256 (affine prologue + statistics + pooling partials, output not stored)",
                                      80740352, "A 67.1 MB + W 1.05 MB read once = 68.2 MB; own statistics/pooling records 12.6 MB written"),
-    "gemm_nt_kernel<0, 0, 0, 1, 1, 0>": ("gemm_nt conv_out M=65536 N=128 K=1280", 369754112, "A 335.5 MB + W 0.66 MB read, Y 33.6 MB written"),
+    "gemm_nt_kernel<0, 0, 0, 1, 1, 0, 0>": ("gemm_nt conv_out M=65536 N=128 K=1280", 369754112, "A 335.5 MB + W 0.66 MB read, Y 33.6 MB written"),
 }
 
 

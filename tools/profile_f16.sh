@@ -11,5 +11,5 @@ rm -rf /tmp/prof_h; rocprofv3 --kernel-trace --stats -d /tmp/prof_h -o r -- pyth
 tail -1 /tmp/bench_h.log | cut -c1-240
 DB=$(find /tmp/prof_h -name "*.db" | head -1)
 [ -n "$DB" ] || { echo "no rocprofv3 database"; exit 1; }
-python $R/tools/rocprof_summary.py $DB 27 8 > $O/${TAG}_bench_f16_kernel_stats.txt      # 4 priming + 3 warm-up + 20 timed steps
+python $R/tools/rocprof_summary.py $DB 31 8 > $O/${TAG}_bench_f16_kernel_stats.txt      # 31 steps: 4 priming + 3 warm-up + 20 timed + 4 eager accounting steps (+ the keep-busy launches: the Cijk_ row)
 head -50 $O/${TAG}_bench_f16_kernel_stats.txt | cut -c1-200
