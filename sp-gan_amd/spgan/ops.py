@@ -649,13 +649,14 @@ def flush_tn() -> None:
 
 
 STORAGE16 = [os.environ.get("SPGAN_F16_STORAGE", "1") != "0"]
+STORAGE16_MIN_EDGES = [81920]     # below this the fp32 tensors are small change
 
 
 def storage16(E: int, F_: int, k: int) -> bool:
     """True when the EdgeBlock keeps its per-edge tensors in 16 bits in HBM: the "f16" operand mode (BASELINE configs[4]) at sizes where
     its 16-bit kernels are the ones that run.  Activations (h2pre, T) as float16, gradients (dT, g2, gy) as bfloat16 (fp32's exponent
     range); BatchNorm statistics and all column sums are taken from the fp32 accumulators / unrounded values."""
-    return STORAGE16[0] and _MFMA_F16[0] == 1 and k == 10 and F_ % 8 == 0 and F_ > 64 and E >= 10 * TN_LP_MIN_ROWS    # F/2 > 32 columns: the fp16 128-row kernels
+    return STORAGE16[0] and _MFMA_F16[0] == 1 and k == 10 and F_ % 8 == 0 and F_ > 64 and E >= max(STORAGE16_MIN_EDGES[0], k * TN_LP_MIN_ROWS)    # F/2 > 32 columns: the fp16 128-row kernels; E/k points: conv_out's bf16 weight-gradient kernel
 
 
 TN_LP_MIN_ROWS = 8192     # "f16" operand mode: weight gradients reduce over >= this many points/edges on the bf16 matrix pipe

@@ -332,11 +332,13 @@ def test_f16_generator_stage_vs_reference_golden(f16sp):
     assert torch.isfinite(out).all()
 
 
-def test_f16_generator_vs_oracle_with_injected_graph(f16sp):
+@pytest.mark.parametrize("B,N,stored16", [(4, 256, False), (4, 2048, True)], ids=["f32-storage", "16-bit-storage"])
+def test_f16_generator_vs_oracle_with_injected_graph(f16sp, B, N, stored16):
     """The fp32 CPU oracle evaluated on the kNN graphs the fp16-operand run chose (tie-aware protocol): output and parameter
-    gradients within fp16-operand accuracy."""
+    gradients within fp16-operand accuracy -- at a size where EdgeConv2's per-edge tensors stay fp32 and at one where ops.storage16
+    keeps them in 16 bits (81920 edges), same tolerances."""
     sp = f16sp
-    B, N = 4, 256
+    assert sp.ops.storage16(B * N * 10, 128, 10) == stored16
     p = fr.init_params(orc.generator_shapes(), salt=31)
     G = _load(sp.Generator(Opts), p).train()
     x = fr.synthetic_real(B, N, seed=32); z = fr.latent(B, N, seed=33)
