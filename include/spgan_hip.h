@@ -356,27 +356,23 @@ int spgan_edge_attend_fwd_h(const void* h2pre, int h2_half, const float* sc2, co
 int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const void* h2pre, int h2_half, const float* sc2, const float* sh2, const float* mean2,
                             const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k, const float* bx,
                             const float* scx, const float* shx, const float* meanx, const float* invx, float slope, uint16_t* g2_bf16,
-                            uint16_t* gy_bf16, float* partials, float* sgy, float* syp, spgan_stream_t s);
+                            uint16_t* gy_bf16, float* partials, spgan_stream_t s);
 /* spgan_edge_scatter with the gy operand as written by spgan_edge_attend_bwd_b (bfloat16; k = 10) */
 int spgan_edge_scatter_b(const float* g1, const uint16_t* gy_bf16, const float* PQR, int ld, int H, int F, const int32_t* idx,
                          const int32_t* rowptr, const int32_t* src, int M, int k, const float* b1, const float* mean1, const float* inv1,
                          const float* gam1, const float* sums1, const float* bx, const float* meanx, const float* invx, const float* gamx,
-                         const float* sumsx, float* dPQR, const float* sgy, const float* syp, spgan_stream_t s);
+                         const float* sumsx, float* dPQR, spgan_stream_t s);
 int spgan_edge_attend_bwd_tile_points(void);
-/* sgy, syp (both or neither; k = 10): optional [M,F] by-products -- per point the sums over its k out-edges of gy and of the conv_x
- * pre-activation (R_i + Q_j) + bx.  Handed to spgan_edge_scatter they replace its pass over the point's k gy rows and Q gathers for the R
- * column (the BatchNorm backward is affine in both): dR = gamma*invstd*(sgy - k*S0/E - ((syp - k*mean)*invstd)*S1/E). */
 int spgan_edge_attend_bwd(const float* dT, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
                           const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k,
                           const float* bx, const float* scx, const float* shx, const float* meanx, const float* invx,
-                          float slope, float* g2, float* gy, float* partials, float* sgy, float* syp, spgan_stream_t s);
+                          float slope, float* g2, float* gy, float* partials, spgan_stream_t s);
 /* BatchNorm backward of both per-edge pre-activations fused with the reduction onto points (gather over the CSR
  * in-edge lists; the backward obligation of modules.py:708-720): dPQR[M, H+2F]. sums* = [sum g | sum g*xhat]. */
 int spgan_edge_scatter(const float* g1, const float* gy, const float* PQR, int ld, int H, int F, const int32_t* idx,
                        const int32_t* rowptr, const int32_t* src, int M, int k, const float* b1, const float* mean1,
                        const float* inv1, const float* gam1, const float* sums1, const float* bx, const float* meanx,
-                       const float* invx, const float* gamx, const float* sumsx, float* dPQR, const float* sgy, const float* syp,
-                       spgan_stream_t s);
+                       const float* invx, const float* gamx, const float* sumsx, float* dPQR, spgan_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * AdaptivePointNorm (Generator.py:24-45): out = gamma*xhat + beta with xhat = InstanceNorm1d(lrelu(x, slope))

@@ -343,10 +343,8 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
     const float* __restrict__ mean2, const float* __restrict__ inv2, const float* __restrict__ PQR, int ld, int H, int F,
     const int32_t* __restrict__ idx, int M, const float* __restrict__ bx, const float* __restrict__ scx, const float* __restrict__ shx,
     const float* __restrict__ meanx, const float* __restrict__ invx, float slope, float* __restrict__ g2, float* __restrict__ gy,
-    float* __restrict__ part, float* __restrict__ sgy, float* __restrict__ syp) {
-  // EB_PT points per workgroup (4 waves x EB_PT/4 points) so the partial format matches the generic kernel.
-  // sgy / syp (optional, [M,F]): per point the sums over its k out-edges of gy and of the conv_x pre-activation (R_i + Q_j) + bx -- all that
-  // edge_scatter's R column needs of them (the BatchNorm backward is affine in both), so it neither re-reads the k gy rows nor gathers Q
+    float* __restrict__ part) {
+  // EB_PT points per workgroup (4 waves x EB_PT/4 points) so the partial format matches the generic kernel
   __shared__ float red[4][4][64 * VEC];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int f0 = 0; f0 < F; f0 += 64 * VEC) {
@@ -413,17 +411,6 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
             s3[q] = fmaf(vy, (yp[r][q] - mxm[q]) * ixv[q], s3[q]);
           }
         }
-        if (sgy) {
-          float a[VEC], b[VEC];
-#pragma unroll
-          for (int q = 0; q < VEC; ++q) {
-            a[q] = 0.f; b[q] = 0.f;
-#pragma unroll
-            for (int r = 0; r < K; ++r) { a[q] += oy[r][q]; b[q] += yp[r][q]; }
-          }
-          stv<VEC>(sgy + (size_t)i * F + f, a);
-          stv<VEC>(syp + (size_t)i * F + f, b);
-        }
 #pragma unroll
         for (int r = 0; r < K; ++r) {
           if (TB) stv_b<VEC>(reinterpret_cast<__bf16*>(g2) + ((size_t)i * K + r) * F + f, o2[r]);   // consumed as a GEMM operand only
@@ -468,8 +455,7 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
     const int32_t* __restrict__ idx, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, int M, int k_,
     const float* __restrict__ b1, const float* __restrict__ mean1, const float* __restrict__ inv1, const float* __restrict__ gam1,
     const float* __restrict__ sums1, const float* __restrict__ bx, const float* __restrict__ meanx, const float* __restrict__ invx,
-    const float* __restrict__ gamx, const float* __restrict__ sumsx, float rE, float* __restrict__ dPQR, const float* __restrict__ sgy,
-    const float* __restrict__ syp) {
+    const float* __restrict__ gamx, const float* __restrict__ sumsx, float rE, float* __restrict__ dPQR) {
   constexpr int KU = KT > 0 ? KT : 1;
   const int k = KT > 0 ? KT : k_;
   const int lane = threadIdx.x & 63;
@@ -532,11 +518,7 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
     const float coef = gamx[f] * iv, a0 = sumsx[f] * rE, a1 = sumsx[F + f] * rE;
     const float Rj = PQR[(size_t)j * ld + H + F + f], Qj = PQR[(size_t)j * ld + H + f];
     float accR = 0.f, accQ = 0.f;
-    if (sgy) {   // the out-edge sums were taken by spgan_edge_attend_bwd: dR = coef*(sum gy - k*a0 - a1*sum xhat), sum xhat = (sum yp - k*mu)*iv
-      const float kf = (float)k;
-      const float xs = (syp[(size_t)j * F + f] - kf * mu) * iv;
-      accR = coef * ((sgy[(size_t)j * F + f] - kf * a0) - xs * a1);
-    } else if (KT > 0) {
+    if (KT > 0) {
       float qv[KU], gv[KU];
 #pragma unroll
       for (int r = 0; r < KU; ++r) {
@@ -637,9 +619,7 @@ extern "C" int spgan_edge_attend_fwd_h(const void* h2pre, int h2_half, const flo
 extern "C" int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const void* h2pre, int h2_half, const float* sc2, const float* sh2,
                                        const float* mean2, const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M,
                                        int k, const float* bx, const float* scx, const float* shx, const float* meanx, const float* invx,
-                                       float slope, uint16_t* g2_bf16, uint16_t* gy_bf16, float* partials, float* sgy, float* syp,
-                                       spgan_stream_t s_) {
-  SPGAN_CHECK_ARG((sgy == nullptr) == (syp == nullptr));
+                                       float slope, uint16_t* g2_bf16, uint16_t* gy_bf16, float* partials, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(dT_bf16 && h2pre && sc2 && sh2 && mean2 && inv2 && PQR && idx && bx && scx && shx && meanx && invx && g2_bf16 && gy_bf16 && partials);
   SPGAN_CHECK_ARG(M > 0 && ld >= H + 2 * F && k == 10 && F % 4 == 0);
   const float* dT = reinterpret_cast<const float*>(dT_bf16);
@@ -651,7 +631,7 @@ extern "C" int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const void* h2pr
   const bool v2 = ((ld | H) % 2 == 0) && F % 128 == 0;
 #define SPGAN_ATT_BWD(V, HHV)                                                                                                               \
   hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, V, 1, HHV>), g, b, 0, s, dT, h2, sc2, sh2, mean2, inv2, PQR, ld, H, F, idx, M, bx, scx, shx, \
-                     meanx, invx, slope, g2, gy, partials, sgy, syp)
+                     meanx, invx, slope, g2, gy, partials)
   if (v2 && h2_half) SPGAN_ATT_BWD(2, 1);
   else if (v2) SPGAN_ATT_BWD(2, 0);
   else if (h2_half) SPGAN_ATT_BWD(1, 1);
@@ -663,17 +643,16 @@ extern "C" int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const void* h2pr
 extern "C" int spgan_edge_attend_bwd(const float* dT, const float* h2pre, const float* sc2, const float* sh2, const float* mean2,
                                      const float* inv2, const float* PQR, int ld, int H, int F, const int32_t* idx, int M, int k,
                                      const float* bx, const float* scx, const float* shx, const float* meanx, const float* invx,
-                                     float slope, float* g2, float* gy, float* partials, float* sgy, float* syp, spgan_stream_t s_) {
-  SPGAN_CHECK_ARG((sgy == nullptr) == (syp == nullptr) && (!sgy || k == 10));   // the per-point sums are a by-product of the k = 10 kernels
+                                     float slope, float* g2, float* gy, float* partials, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(dT && h2pre && sc2 && sh2 && mean2 && inv2 && PQR && idx && bx && scx && shx && meanx && invx && g2 && gy && partials);
   SPGAN_CHECK_ARG(M > 0 && k > 0 && ld >= H + 2 * F);
   const bool al = ((ld | H | F) % 2 == 0);
   if (k == 10 && al && F % 128 == 0)
     hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 2>), dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR,
-                       ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials, sgy, syp);
+                       ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
   else if (k == 10)
     hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 1>), dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR,
-                       ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials, sgy, syp);
+                       ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
   else
     hipLaunchKernelGGL(edge_attend_bwd_kernel, dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR, ld,
                        H, F, idx, M, k, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
@@ -683,30 +662,25 @@ extern "C" int spgan_edge_attend_bwd(const float* dT, const float* h2pre, const 
 extern "C" int spgan_edge_scatter_b(const float* g1, const uint16_t* gy_bf16, const float* PQR, int ld, int H, int F, const int32_t* idx,
                                     const int32_t* rowptr, const int32_t* src, int M, int k, const float* b1, const float* mean1,
                                     const float* inv1, const float* gam1, const float* sums1, const float* bx, const float* meanx,
-                                    const float* invx, const float* gamx, const float* sumsx, float* dPQR, const float* sgy, const float* syp,
-                                    spgan_stream_t s_) {
-  SPGAN_CHECK_ARG((sgy == nullptr) == (syp == nullptr));
+                                    const float* invx, const float* gamx, const float* sumsx, float* dPQR, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(g1 && gy_bf16 && PQR && idx && rowptr && src && b1 && mean1 && inv1 && gam1 && sums1 && bx && meanx && invx && gamx && sumsx && dPQR);
   SPGAN_CHECK_ARG(M > 0 && k == 10 && ld >= H + 2 * F);
   hipLaunchKernelGGL((edge_scatter_kernel<10, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, reinterpret_cast<const float*>(gy_bf16), PQR, ld,
-                     H, F, idx, rowptr, src, M, k, b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR, sgy,
-                     syp);
+                     H, F, idx, rowptr, src, M, k, b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
   return spgan_launch_status();
 }
 
 extern "C" int spgan_edge_scatter(const float* g1, const float* gy, const float* PQR, int ld, int H, int F, const int32_t* idx,
                                   const int32_t* rowptr, const int32_t* src, int M, int k, const float* b1, const float* mean1,
                                   const float* inv1, const float* gam1, const float* sums1, const float* bx, const float* meanx,
-                                  const float* invx, const float* gamx, const float* sumsx, float* dPQR, const float* sgy, const float* syp,
-                                  spgan_stream_t s_) {
-  SPGAN_CHECK_ARG((sgy == nullptr) == (syp == nullptr));
+                                  const float* invx, const float* gamx, const float* sumsx, float* dPQR, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(g1 && gy && PQR && idx && rowptr && src && b1 && mean1 && inv1 && gam1 && sums1 && bx && meanx && invx && gamx && sumsx && dPQR);
   SPGAN_CHECK_ARG(M > 0 && k > 0 && ld >= H + 2 * F);
   if (k == 10)
     hipLaunchKernelGGL(edge_scatter_kernel<10>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, gy, PQR, ld, H, F, idx, rowptr, src, M, k,
-                       b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR, sgy, syp);
+                       b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
   else
     hipLaunchKernelGGL(edge_scatter_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, gy, PQR, ld, H, F, idx, rowptr, src, M, k,
-                       b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR, sgy, syp);
+                       b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
   return spgan_launch_status();
 }

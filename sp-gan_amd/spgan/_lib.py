@@ -136,12 +136,12 @@ SIGNATURES = {
     "spgan_edge_stats": (I, [P, I, P, I, I, I, I, P, P, P, P]),
     "spgan_edge_attend_fwd": (I, [P, P, P, P, I, I, I, P, I, I, P, P, P, F, P, P]),
     "spgan_edge_attend_fwd_h": (I, [P, I, P, P, P, I, I, I, P, I, I, P, P, P, F, P, P]),
-    "spgan_edge_attend_bwd_b": (I, [P, P, I, P, P, P, P, P, I, I, I, P, I, I, P, P, P, P, P, F, P, P, P, P, P, P]),
+    "spgan_edge_attend_bwd_b": (I, [P, P, I, P, P, P, P, P, I, I, I, P, I, I, P, P, P, P, P, F, P, P, P, P]),
     "spgan_gemm_nt_y16_ok": (I, [P]),
     "spgan_edge_attend_bwd_tile_points": (I, []),
-    "spgan_edge_attend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, I, I, P, P, P, P, P, F, P, P, P, P, P, P]),
-    "spgan_edge_scatter_b": (I, [P, P, P, I, I, I, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "spgan_edge_scatter": (I, [P, P, P, I, I, I, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "spgan_edge_attend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, I, I, P, P, P, P, P, F, P, P, P, P]),
+    "spgan_edge_scatter_b": (I, [P, P, P, I, I, I, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "spgan_edge_scatter": (I, [P, P, P, I, I, I, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "spgan_adain_fwd": (I, [P, I, I, I, F, P, P, F, P, P, P]),
     "spgan_adain_bwd1": (I, [P, P, I, I, I, F, P, P, F, P, P, P, P]),
     "spgan_adain_bwd2": (I, [P, P, I, I, I, F, P, P, F, P, P, P, P, P]),

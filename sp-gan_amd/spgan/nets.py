@@ -719,12 +719,7 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     g[pre + ".conv_out.weight"] = conv_out_weight_grad_from_pm(gwo, F_, k)
     dT = ops.gemm_nt(dout, _t(ctx["Wo"]), out_bf16=ctx["T"].dtype == torch.float16)     # [M, k*F]
     # softmax * conv_x product, both LeakyReLUs
-    psums = None
-    if k == 10:      # per-point out-edge sums of gy / the conv_x pre-activation ride along: edge_scatter's R column is finished from them
-        g2, gy, sums2, sumsy, psums = ops.edge_attend_bwd(dT, ctx["h2pre"], bn2[0], bn2[1], bn2[3], bn2[2], PQR, idx, bx, bnx[0], bnx[1], bnx[3], bnx[2], NEG,
-                                                          point_sums=True)
-    else:
-        g2, gy, sums2, sumsy = ops.edge_attend_bwd(dT, ctx["h2pre"], bn2[0], bn2[1], bn2[3], bn2[2], PQR, idx, bx, bnx[0], bnx[1], bnx[3], bnx[2], NEG)
+    g2, gy, sums2, sumsy = ops.edge_attend_bwd(dT, ctx["h2pre"], bn2[0], bn2[1], bn2[3], bn2[2], PQR, idx, bx, bnx[0], bnx[1], bnx[3], bnx[2], NEG)
     g[pre + ".conv_w.4.weight"] = sums2[F_:]; g[pre + ".conv_w.4.bias"] = sums2[:F_]
     g[pre + ".conv_x.1.weight"] = sumsy[F_:]; g[pre + ".conv_x.1.bias"] = sumsy[:F_]
     if not ctx["training"]:
@@ -739,7 +734,7 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     sums1 = _cat2(s10, s11) if ctx["training"] else torch.zeros(2 * H, device=x.device)
     # BN backward of conv_w.0 / conv_x.0 outputs fused with the edge -> point reduction
     dPQR = ops.edge_scatter(g1, gy, PQR, idx, csr[0], csr[1], b1, bn1[3], bn1[2], P[pre + ".conv_w.1.weight"], sums1,
-                            bx, bnx[3], bnx[2], P[pre + ".conv_x.1.weight"], sumsy, point_sums=psums)
+                            bx, bnx[3], bnx[2], P[pre + ".conv_x.1.weight"], sumsy)
     dWcat = ops.gemm_tn(dPQR, x)
     dW0, dWx = ops.edge_wcat_bwd(dWcat, H, F_)
     g[pre + ".conv_w.0.weight"] = dW0.view_as(P[pre + ".conv_w.0.weight"])

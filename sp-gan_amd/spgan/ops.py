@@ -1132,11 +1132,8 @@ def edge_attend_fwd(h2pre: Tensor, sc2: Tensor, sh2: Tensor, PQR: Tensor, idx: T
     return T
 
 
-def edge_attend_bwd(dT: Tensor, h2pre: Tensor, sc2, sh2, mean2, inv2, PQR: Tensor, idx: Tensor, bx, scx, shx, meanx, invx, slope: float,
-                    point_sums: bool = False):
-    """-> (g2 [E,F], gy [E,F], sums2 [2F] = [sum g2 | sum g2*xhat2], sumsy [2F]).
-    point_sums=True (k = 10): additionally (sgy [M,F], syp [M,F]) -- per point the sums over its out-edges of gy and of the conv_x
-    pre-activation: hand them to edge_scatter(point_sums=...) and its R column needs neither the k gy rows nor the Q gathers."""
+def edge_attend_bwd(dT: Tensor, h2pre: Tensor, sc2, sh2, mean2, inv2, PQR: Tensor, idx: Tensor, bx, scx, shx, meanx, invx, slope: float):
+    """-> (g2 [E,F], gy [E,F], sums2 [2F] = [sum g2 | sum g2*xhat2], sumsy [2F])."""
     F_ = bx.numel()
     H = PQR.shape[1] - 2 * F_
     _pqr(PQR, H, F_); _i32(idx, "idx")
@@ -1162,26 +1159,17 @@ def edge_attend_bwd(dT: Tensor, h2pre: Tensor, sc2, sh2, mean2, inv2, PQR: Tenso
     gy = torch.empty((M_ * k, F_), dtype=torch.bfloat16 if dT_b else torch.float32, device=PQR.device)   # 16-bit storage: gy too (edge_scatter reads it)
     part = torch.empty((tiles, 2 * F_, 2), dtype=torch.float32, device=PQR.device)
     v = lambda t, n: _p(_vec(t, F_, n))
-    ps = None
-    if point_sums:
-        if k != 10:
-            raise ValueError("point_sums is a by-product of the k = 10 kernels")
-        ps = (torch.empty((M_, F_), dtype=torch.float32, device=PQR.device), torch.empty((M_, F_), dtype=torch.float32, device=PQR.device))
     check((lib.spgan_edge_attend_bwd_b if dT_b else lib.spgan_edge_attend_bwd)(_p(dT), *((_p(h2pre), 1 if h2_half else 0) if dT_b else (_p(h2pre),)), v(sc2, "sc2"), v(sh2, "sh2"), v(mean2, "mean2"), v(inv2, "inv2"), _p(PQR), PQR.shape[1],
                                     H, F_, _p(idx), M_, k, v(bx, "bx"), v(scx, "scx"), v(shx, "shx"), v(meanx, "meanx"), v(invx, "invx"),
-                                    float(slope), _p(g2), _p(gy), _p(part), _p(ps[0] if ps else None), _p(ps[1] if ps else None), _s()),
-          "edge_attend_bwd", M=M_, k=k, F=F_)
+                                    float(slope), _p(g2), _p(gy), _p(part), _s()), "edge_attend_bwd", M=M_, k=k, F=F_)
     # partial columns are laid out so that the two finalize outputs ARE [sum g2 | sum g2*xhat2] and [sum gy | sum gy*xhaty]
     s0, s1 = _finalize(part, 1, tiles, 2 * F_, tiles * tp, 1, tp)
-    if point_sums:
-        return g2, gy, s0[0], s1[0], ps
     return g2, gy, s0[0], s1[0]
 
 
 def edge_scatter(g1: Tensor, gy: Tensor, PQR: Tensor, idx: Tensor, rowptr: Tensor, src: Tensor, b1, mean1, inv1, gam1, sums1, bx, meanx,
-                 invx, gamx, sumsx, point_sums=None) -> Tensor:
-    """BatchNorm backward of both per-edge pre-activations + reduction onto points -> dPQR [M, H+2F].
-    point_sums = (sgy, syp) of edge_attend_bwd(point_sums=True): the R column from the per-point sums."""
+                 invx, gamx, sumsx) -> Tensor:
+    """BatchNorm backward of both per-edge pre-activations + reduction onto points -> dPQR [M, H+2F]."""
     H, F_ = b1.numel(), bx.numel()
     _pqr(PQR, H, F_); _i32(idx, "idx"); _i32(rowptr, "rowptr"); _i32(src, "src")
     M_, k = idx.shape
@@ -1194,19 +1182,11 @@ def edge_scatter(g1: Tensor, gy: Tensor, PQR: Tensor, idx: Tensor, rowptr: Tenso
     if not (g1.is_contiguous() and gy.is_contiguous()) or g1.shape != (M_ * k, H) or gy.shape != (M_ * k, F_):
         raise ValueError("g1 [E,H] / gy [E,F] shape mismatch")
     out = torch.empty_like(PQR)
-    sg = sp_ = None
-    if point_sums is not None:
-        sg, sp_ = point_sums
-        for t, n in ((sg, "sgy"), (sp_, "syp")):
-            _f32(t, n, 2)
-            if not t.is_contiguous() or t.shape != (M_, F_):
-                raise ValueError("%s must be contiguous [M,F]" % n)
     vh = lambda t, n: _p(_vec(t, H, n))
     vf = lambda t, n: _p(_vec(t, F_, n))
     check((_lib.load().spgan_edge_scatter_b if gy_b else _lib.load().spgan_edge_scatter)(_p(g1), _p(gy), _p(PQR), PQR.shape[1], H, F_, _p(idx), _p(rowptr), _p(src), M_, k, vh(b1, "b1"),
                                          vh(mean1, "mean1"), vh(inv1, "inv1"), vh(gam1, "gam1"), _p(_vec(sums1, 2 * H, "sums1")), vf(bx, "bx"),
-                                         vf(meanx, "meanx"), vf(invx, "invx"), vf(gamx, "gamx"), _p(_vec(sumsx, 2 * F_, "sumsx")), _p(out),
-                                         _p(sg), _p(sp_), _s()),
+                                         vf(meanx, "meanx"), vf(invx, "invx"), vf(gamx, "gamx"), _p(_vec(sumsx, 2 * F_, "sumsx")), _p(out), _s()),
           "edge_scatter", M=M_, k=k, H=H, F=F_)
     return out
 

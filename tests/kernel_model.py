@@ -432,17 +432,7 @@ def storage16(E, F_, k):
     return False     # the CPU models run the fp32 operand mode
 
 
-def edge_attend_bwd(dT, h2pre, sc2, sh2, mean2, inv2, PQR, idx, bx, scx, shx, meanx, invx, slope, point_sums=False):
-    if point_sums:     # + per point the out-edge sums of gy and of the conv_x pre-activation
-        M, k = idx.shape
-        F_ = bx.numel()
-        r = edge_attend_bwd(dT, h2pre, sc2, sh2, mean2, inv2, PQR, idx, bx, scx, shx, meanx, invx, slope)
-        yp = _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope)[4]
-        d = dT.float().view(M, k, F_)
-        w = _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope)[2]
-        zy = _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope)[1]
-        gy = d * w * torch.where(zy > 0, 1.0, slope)
-        return r + ((gy.sum(1).contiguous(), yp.sum(1).contiguous()),)
+def edge_attend_bwd(dT, h2pre, sc2, sh2, mean2, inv2, PQR, idx, bx, scx, shx, meanx, invx, slope):
     M, k = idx.shape
     F_ = bx.numel()
     z2, zy, w, yv, yp = _attend(h2pre, sc2, sh2, PQR, idx, bx, scx, shx, slope)
@@ -459,8 +449,8 @@ def edge_attend_bwd(dT, h2pre, sc2, sh2, mean2, inv2, PQR, idx, bx, scx, shx, me
     return (g2.contiguous(), gy.contiguous(), torch.cat([g2.sum(0), (g2 * xh2).sum(0)]), torch.cat([gy.sum(0), (gy * xhy).sum(0)]))
 
 
-def edge_scatter(g1, gy, PQR, idx, rowptr, src, b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, point_sums=None):
-    gy = gy.float()      # (point_sums: the same quantity by another route -- the model keeps the direct sums)
+def edge_scatter(g1, gy, PQR, idx, rowptr, src, b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx):
+    gy = gy.float()
     M, k = idx.shape
     H, F_ = b1.numel(), bx.numel()
     E = M * k
