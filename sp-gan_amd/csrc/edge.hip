@@ -449,6 +449,14 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
 // One wave per point, lanes over channels.  The loads of a point's k out-edges (KT > 0: compile-time k) and of its
 // in-edges (chunks of 4) are issued together before they are consumed -- a serial edge loop leaves one row in flight per
 // wave and ran at 1.7 TB/s; sums are still taken in edge order (deterministic).
+// In-edges whose rows are in flight together.  The kernel's time is the dependent chain source list -> gathered rows, not its bytes (a
+// variant that read 35 % fewer bytes ran no faster: DESIGN.md section 10.4): chunks of 4 left ~3 serial round trips per point and channel
+// pass (mean in-degree k = 10); 16 covers almost every point in one.  Measured in the replayed step: 239 -> 206 us (4 -> 16), sums still
+// taken in edge order (bit-identical).  72 VGPRs, 7 waves per SIMD.
+#ifndef SPGAN_SCATTER_CHUNK
+#define SPGAN_SCATTER_CHUNK 16
+#endif
+constexpr int SCH = SPGAN_SCATTER_CHUNK;
 template <int KT, int GB = 0>
 __global__ __launch_bounds__(256) void edge_scatter_kernel(
     const float* __restrict__ g1, const float* __restrict__ gy, const float* __restrict__ PQR, int ld, int H, int F,
@@ -495,16 +503,16 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
         acc -= coef * (g1[(size_t)e * H + c] - a0 - xh * a1);
       }
     }
-    for (int t = t0; t < t1; t += 4) {  // in-edges: j is the neighbour
-      float pv[4], gv[4];
+    for (int t = t0; t < t1; t += SCH) {  // in-edges: j is the neighbour
+      float pv[SCH], gv[SCH];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SCH; ++u) {
         const int e = src[min(t + u, t1 - 1)];
         pv[u] = PQR[(size_t)(e / k) * ld + c];
         gv[u] = g1[(size_t)e * H + c];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SCH; ++u) {
         if (t + u < t1) {
           const float xh = (((Pj - pv[u]) + bb) - mu) * iv;
           acc += coef * (gv[u] - a0 - xh * a1);
@@ -537,16 +545,16 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
         accR += coef * (ldgy((size_t)e * F + f) - a0 - xh * a1);
       }
     }
-    for (int t = t0; t < t1; t += 4) {
-      float rv[4], gv[4];
+    for (int t = t0; t < t1; t += SCH) {
+      float rv[SCH], gv[SCH];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SCH; ++u) {
         const int e = src[min(t + u, t1 - 1)];
         rv[u] = PQR[(size_t)(e / k) * ld + H + F + f];
         gv[u] = ldgy((size_t)e * F + f);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SCH; ++u) {
         if (t + u < t1) {
           const float xh = (((rv[u] + Qj) + bb) - mu) * iv;
           accQ += coef * (gv[u] - a0 - xh * a1);
