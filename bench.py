@@ -382,7 +382,10 @@ def main():
         install_kernel_models()
         torch.set_num_threads(2)
     world = world_env
-    rank = spgan.init_process_group_from_env("gloo" if SELFTEST else "nccl")        # no-op for a plain single-process launch
+    # SPGAN_DIST_BACKEND=gloo: rehearse the N > 1 schedule (graphs, overlapped all-reduce, rank-synchronous Adam) on a box with ONE GPU -- all
+    # ranks share device 0 and the all-reduce goes through gloo's CUDA path.  A functional check only: such a line carries "rehearsal".
+    backend = "gloo" if SELFTEST else os.environ.get("SPGAN_DIST_BACKEND", "nccl")
+    rank = spgan.init_process_group_from_env(backend)        # no-op for a plain single-process launch
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if SELFTEST:
@@ -390,6 +393,8 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+        if backend != "nccl":
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     world_seen = torch.distributed.get_world_size() if dist_on else 1
@@ -503,6 +508,8 @@ def main():
         }
         if EXPERIMENT_BATCH is not None and not SELFTEST:
             line["experiment"] = "per-GPU batch %d instead of BASELINE's 32" % PER_GPU_BATCH
+        if dist_on and not SELFTEST and backend != "nccl":
+            line["rehearsal"] = "all %d ranks on one GPU, all-reduce through %s: a functional run of the N > 1 schedule, not a measurement" % (world, backend)
         if SELFTEST:
             line["selftest"] = True
             line["data"] = "selftest: CPU test doubles, tiny shapes -- NOT a measurement"
