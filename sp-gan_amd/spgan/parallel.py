@@ -135,8 +135,9 @@ class DataParallel(nn.Module):
                    "allreduce_flat", n=g.numel())
 
     def __del__(self):
-        comm, self._comm = getattr(self, "_comm", None), None
+        comm = self.__dict__.get("_comm")          # plain dict access: nn.Module.__setattr__ / __getattr__ are not usable at interpreter shutdown
         if comm is not None:
+            self.__dict__["_comm"] = None
             try:
                 from . import _lib
                 _lib.load().spgan_comm_destroy(comm)
