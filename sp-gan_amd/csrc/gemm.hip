@@ -1801,6 +1801,7 @@ __global__ __launch_bounds__(256) void sparse_rows_nt_kernel(const float* __rest
     const unsigned long long* mrow = reinterpret_cast<const unsigned long long*>(mask + rl * 2 * words);
     for (int n0 = 0; n0 < N; n0 += 256) {
       const int n = n0 + lane * 4;
+      const bool vec = n0 + 256 <= N && (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;   // all 64 lanes on whole, aligned float4s
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int w0 = 0; w0 < words; w0 += 64) {
         const unsigned long long mine = (w0 + lane < words) ? mrow[w0 + lane] : 0ull;
@@ -1809,6 +1810,28 @@ __global__ __launch_bounds__(256) void sparse_rows_nt_kernel(const float* __rest
           const int wl = __ffsll((long long)nz) - 1;
           nz &= nz - 1;
           unsigned long long bits = __shfl(mine, wl);
+          if (vec) {
+            // up to 8 W rows in flight per round (the set bits are wave-uniform: scalar indices): a row that carries the arg-max of dozens of
+            // channels -- a few extreme points of a shape do -- was a chain of that many dependent row loads; the sums keep ascending c
+            while (bits) {
+              int cc[8];
+              float4 wv[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                cc[u] = bits ? (w0 + wl) * 64 + __ffsll((long long)bits) - 1 : -1;
+                bits &= bits - 1;   // 0 stays 0
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const float4*>(W + (size_t)max(cc[u], 0) * ldw + n);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                if (cc[u] >= 0) {
+                  const float v = sval[cc[u]];
+                  acc.x = fmaf(v, wv[u].x, acc.x); acc.y = fmaf(v, wv[u].y, acc.y); acc.z = fmaf(v, wv[u].z, acc.z); acc.w = fmaf(v, wv[u].w, acc.w);
+                }
+              }
+            }
+          }
           while (bits) {
             const int cc = (w0 + wl) * 64 + __ffsll((long long)bits) - 1;
             bits &= bits - 1;
