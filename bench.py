@@ -198,16 +198,19 @@ class MfmaAccounting:
         per_shape = {("M=%d" % m): {"launches_timed": c, "avg_launch_ms": round(t / c, 4),
                                     "frac": round(2.0 * m * DOMINANT["N"] * DOMINANT["K"] / (t / c * 1e-3) / 1e12 / self.peak, 4)} for m, (c, t) in sorted(by_m.items())}
         rows_avg = sum(m for _, _, m in dom) / len(dom)
-        t1, t1_file = _pmc_traffic()
-        return {"bound": "mfma", "kernel": "gemm_nt_wide_kernel<1,0,0> at D.fc2.0 (N=%d K=%d, BN+LeakyReLU prologue, column-statistics + max-pool epilogue, output not stored): "
+        t1, t1_file = _pmc_traffic() if self.f16 == "f32" else (None, None)       # the committed PMC passes measured the fp32-operand kernel
+        ksym = {"f32": "gemm_nt_wide_kernel<1,0,0>", "f16": "gemm_nt_wide_kernel<1,0,1> (fp16 operands, v_mfma_f32_32x32x16_f16)",
+                "bf16x3": "gemm_nt_kernel<1,0,1,0,1,2> (split-bf16 operands, 128-row kernel)"}.get(self.f16, "gemm_nt")
+        return {"bound": "mfma", "kernel": "%s at D.fc2.0 (N=%d K=%d, BN+LeakyReLU prologue, column-statistics + max-pool epilogue, output not stored): "
                                            "per step one launch over the three D-step passes (M=%d) and one for the G step (M=%d)"
-                                           % (DOMINANT["N"], DOMINANT["K"], 3 * self.M, self.M),
+                                           % (ksym, DOMINANT["N"], DOMINANT["K"], 3 * self.M, self.M),
                 "achieved": round(achieved, 2), "peak": self.peak, "unit": "TFLOP/s", "frac": round(achieved / self.peak, 4),
                 "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches_timed": len(dom), "per_shape": per_shape,
                 "traffic": None if t1 is None else int(t1 * rows_avg / self.M),
-                "traffic_note": "HBM bytes per launch: measured for the one-pass launch (M=%d) in separate rocprofv3 --pmc passes (profiles/%s: %s B "
-                                "= 1.10x its algorithmic 80.7 MB: A 67.1 MB + W 1.0 MB read once + own statistics/pooling records 12.6 MB written), scaled by the "
-                                "average rows per launch (operand and records grow with the rows)" % (self.M, t1_file, t1)}
+                "traffic_note": ("HBM bytes per launch: measured for the one-pass launch (M=%d) in separate rocprofv3 --pmc passes (profiles/%s: %s B "
+                                 "= 1.10x its algorithmic 80.7 MB: A 67.1 MB + W 1.0 MB read once + own statistics/pooling records 12.6 MB written), scaled by the "
+                                 "average rows per launch (operand and records grow with the rows)" % (self.M, t1_file, t1)) if t1 is not None else
+                                "not measured for this operand mode (the committed PMC passes are of the fp32-operand kernel; operands and records are the same bytes)"}
 
     def summary(self, steps, step_ms):
         if not self.rec:
