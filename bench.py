@@ -31,7 +31,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "sp-gan_amd")):
+for p in (ROOT, os.path.join(ROOT, "sp-gan_amd"), os.path.join(ROOT, "examples")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -41,21 +41,30 @@ import torch   # noqa: E402
 # test doubles of tests/kernel_model.py.  Exercises argument handling, the self-launch, the rendezvous, the data-parallel step and
 # the JSON line; its numbers are meaningless and the line says so.
 SELFTEST = os.environ.get("SPGAN_BENCH_SELFTEST", "0") == "1"
-N_POINTS = 128 if SELFTEST else 2048
+# --config {c2,c4,c5} (read before argparse: module-level code sizes things with it).  c2 = BASELINE configs[1] (N=2048, per-GPU batch 32,
+# fp32: the headline, the default and what the driver runs); c4 = the per-GPU shape of configs[3] (N=4096, per-GPU batch 16: its
+# 8-GPU global batch 128 is reached with --gpus 8); c5 = the per-GPU shape of configs[4] (N=2048, per-GPU batch 32, fp16 MFMA operands
+# = `--mfma f16`).
+CONFIG = next((sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--config"), "c2")
+CONFIG = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--config=")), CONFIG)
+if CONFIG not in ("c2", "c4", "c5"):
+    raise SystemExit("--config must be one of c2, c4, c5")
+N_POINTS = 128 if SELFTEST else (4096 if CONFIG == "c4" else 2048)
 # 32 = BASELINE configs[1].  `--experiment-batch B` (experiments only; the line is then marked "experiment") is read before argparse because
 # module-level code sizes things with it; the old SPGAN_BENCH_BATCH environment override is refused.
 if os.environ.get("SPGAN_BENCH_BATCH"):
     raise SystemExit("SPGAN_BENCH_BATCH is no longer honoured: use `--experiment-batch B` (the JSON line is then marked as an experiment)")
 EXPERIMENT_BATCH = next((int(sys.argv[i + 1]) for i, a in enumerate(sys.argv[:-1]) if a == "--experiment-batch"), None)
-PER_GPU_BATCH = 2 if SELFTEST else (EXPERIMENT_BATCH or 32)
+CONFIG_BATCH = 16 if CONFIG == "c4" else 32
+PER_GPU_BATCH = 2 if SELFTEST else (EXPERIMENT_BATCH or CONFIG_BATCH)
 NZ = 128
 K_NN = 10
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 FP16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (never the 2:1-sparsity figure)
 # algorithmic FLOPs per shape per step, reference formulation: WGAN-GP at N=2048
-GF_PER_SHAPE_STEP = 32.6
-PMC_FILES = ("r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json")
-PMC_STEP_FILES = ("r03_pmc_step.json", "r02_pmc_step.json")
+GF_PER_SHAPE_STEP = 67.3 if CONFIG == "c4" else 32.6     # 2 F_Gf + 4N*779,520 + 15 F_Df at N = 4096 / 2048
+PMC_FILES = ("r04_pmc_gemm_nt.json", "r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json")
+PMC_STEP_FILES = ("r04_pmc_step.json", "r03_pmc_step.json", "r02_pmc_step.json")
 ALGORITHMIC_HBM_GB_PER_STEP = 3.5      # ~110 MB per shape per step x 32 shapes
 
 
@@ -354,8 +363,11 @@ def time_steps(tr, step_fn, steps, dist_on, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)        # >= 50 timed steps after >= 10 warm-up steps
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=("c2", "c4", "c5"), default="c2",
+                    help="BASELINE config whose per-GPU shape is timed: c2 = configs[1] (N=2048, batch 32, fp32; default, the headline), "
+                         "c4 = configs[3] per GPU (N=4096, batch 16), c5 = configs[4] per GPU (N=2048, batch 32, fp16 MFMA operands)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--experiment-batch", type=int, default=None, help="per-GPU batch other than BASELINE's 32: an experiment, marked as such in the line")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the drop-in-caller and MFMA-accounting legs (they run after the timed region)")
@@ -369,6 +381,10 @@ def main():
     ap.add_argument("--variant", default="", help="comma-separated non-default generator flags (attn, eql, use_head, off, z_norm) or "
                     "small_d: times that variant instead of the headline configuration (SURVEY 8(f) N4); the JSON line says so")
     args = ap.parse_args()
+    if args.config == "c5":
+        if args.mfma not in ("f32", "f16"):
+            raise SystemExit("--config c5 is the fp16-operand mode (--mfma f16)")
+        args.mfma = "f16"
     variant = tuple(v for v in args.variant.split(",") if v)
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -461,11 +477,11 @@ def main():
 
     literal = None
     if not SELFTEST and not args.no_extra_legs and not variant and world == 1:
-        # The reference's loop body EXECUTED LITERALLY (spgan.reference_loop: model.py:239-279 statement for statement -- separate G() /
+        # The reference's loop body EXECUTED LITERALLY (examples/reference_loop.py: model.py:239-279 statement for statement -- separate G() /
         # D() calls, requires_grad toggles, dis_loss / gen_loss, .backward(), torch.optim.Adam) on the HIP modules, latent tiled
         # [B,N,128]; no TrainStep.  (a) issued eagerly from Python, (b) the same function under spgan.CapturedBody (the caller's own
         # loop body replayed as a hipGraph).
-        from spgan.reference_loop import LoopState, reference_loop_body
+        from reference_loop import LoopState, reference_loop_body
         G3, D3 = build_models(dev, variant)
         G3.train(); D3.train()
         oG = torch.optim.Adam(filter(lambda p: p.requires_grad, G3.parameters()), lr=1e-4, betas=(0.5, 0.99), capturable=True)
@@ -485,7 +501,7 @@ def main():
                    "eager_shapes_per_s": round(PER_GPU_BATCH * 10 / dt3, 2),
                    "captured_ms_per_step": round(dt4 / 10 * 1e3, 3), "captured_shapes_per_s": round(PER_GPU_BATCH * 10 / dt4, 2),
                    "captured": bool(body._graph is not None and not body.eager),
-                   "note": "model.py:239-279 statement for statement (spgan.reference_loop.reference_loop_body) with torch.optim.Adam(capturable=True), "
+                   "note": "model.py:239-279 statement for statement (examples/reference_loop.py::reference_loop_body) with torch.optim.Adam(capturable=True), "
                            "tiled latent [B,N,128], WGAN-GP composition; eager = issued from Python, captured = the same function under "
                            "spgan.CapturedBody (hipGraph replay of the caller's own loop body); 10 steps each after warm-up"}
         del G3, D3, body, st3
@@ -494,17 +510,20 @@ def main():
         ms = dt / args.steps * 1e3
         shapes_s = PER_GPU_BATCH * world * args.steps / dt
         line = {
-            "metric": "G+D train-step shapes/sec @2048 pts, bs=32 per GPU (WGAN-GP)", "value": round(shapes_s, 2), "unit": "shapes/s",
+            "metric": "G+D train-step shapes/sec @%d pts, bs=%d per GPU (WGAN-GP)" % (N_POINTS, PER_GPU_BATCH), "value": round(shapes_s, 2), "unit": "shapes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate/epilogues/weight-gradients",
                                                                                   "bf16x3": "f32 operands split into 3 bf16 terms (6 bf16 MFMA cross products, f32 accumulate); weight gradients f32 MFMA"}[args.mfma],
             "data": "synthetic",
             "config": {"workload": "%s: Chair-shaped synthetic clouds, %d pts, per-GPU batch %d, WGAN + gradient penalty (lambda 10), "
                                    "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10; one latent per shape (default noise_generator) handed over un-tiled [b,1,128]"
-                                   % ("BASELINE configs[1]" if PER_GPU_BATCH == 32 else "EXPERIMENT (not a BASELINE config)", N_POINTS, PER_GPU_BATCH),
+                                   % ("EXPERIMENT (not a BASELINE config)" if EXPERIMENT_BATCH is not None else
+                                      {"c2": "BASELINE configs[1]", "c4": "BASELINE configs[3] per-GPU shape (4096 pts, 128 shapes over 8 GPUs = 16 per GPU)",
+                                       "c5": "BASELINE configs[4] per-GPU shape (fp16 MFMA operands)"}[args.config], N_POINTS, PER_GPU_BATCH),
                        "global_batch": PER_GPU_BATCH * world, "n_points": N_POINTS,
                        "parallelism": "dp%d" % world},
             "world_size_observed": world_seen, "collective_backend": (torch.distributed.get_backend() if dist_on else None),
+            "bench_config": args.config, "gf_per_shape_step_reference": GF_PER_SHAPE_STEP,
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3), "hipgraph_replay": bool(use_graph), "reference_schedule": bool(args.reference_schedule),
             "step_tflops_algorithmic": round(shapes_s * GF_PER_SHAPE_STEP / 1e3, 2),
             "step_frac_of_fp32_matrix_peak_reference_flops": round(shapes_s * GF_PER_SHAPE_STEP / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
@@ -527,7 +546,7 @@ def main():
                 # FLOPs the build really issues on the matrix cores / whole step time / peak (the reference-formulation fraction above
                 # divides FLOPs the build does not execute)
                 line["step_mfma_frac_issued"] = round(line["mfma"]["mfma_flops_issued_per_step"] / (ms * 1e-3) / 1e12 / (peak * 1.0), 4)
-            if PER_GPU_BATCH == 32:
+            if PER_GPU_BATCH == 32 and args.config == "c2" and args.mfma == "f32":
                 line["hbm_traffic"] = _pmc_step_traffic()
         if drop_in is not None:
             line["drop_in_caller"] = drop_in

@@ -1,8 +1,8 @@
 """The reference's train-loop body (Generation/model.py:239-279), statement for statement, over whatever `Generator`,
 `Discriminator`, loss functions and optimisers the caller hands in -- i.e. what `Model.train` executes per iteration once its
 imports point at this package.  Nothing here knows about spgan's own harness (`TrainStep`): it is the CALLER's
-code, kept in the package so that the parity test (tests/test_literal_loop_gpu.py), `bench.py`'s `literal_loop` leg and
-`examples/` run the very same statements.
+code, kept under examples/ (not in the shipped package) so that the parity test (tests/test_literal_loop_gpu.py), `bench.py`'s
+`literal_loop` leg and `examples/train.py` run the very same statements.
 
     state = LoopState(G, D, optimizerG, optimizerD, gan="ls")
     lossD, lossG, info = reference_loop_body(state, x, data, z_d, z_g)
@@ -19,14 +19,14 @@ from typing import Callable, Optional
 import torch
 from torch.autograd import Variable
 
-from .train import requires_grad
+from spgan.train import requires_grad
 
 
 class LoopState:
     def __init__(self, G, D, optimizerG, optimizerD, gan: str = "ls", flip_d: bool = False, flip_g: bool = False,
                  dis_loss: Optional[Callable] = None, gen_loss: Optional[Callable] = None, gp: Optional[Callable] = None,
                  gp_kwargs: Optional[dict] = None):
-        from . import losses
+        from spgan import losses
         self.G, self.D, self.optimizerG, self.optimizerD = G, D, optimizerG, optimizerD
         self.gan, self.flip_d, self.flip_g = gan, flip_d, flip_g
         self.dis_loss = dis_loss or losses.dis_loss

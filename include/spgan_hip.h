@@ -455,6 +455,19 @@ int spgan_knn_point(int nsample, const float* xyz, const float* new_xyz, int B, 
 /* out[b,s,j,:] = [xyz[b,idx] - center[b,s] | feat[b,idx]]   pointnet_util.py:127-139, pointconv_util.py:186-195 */
 int spgan_group_concat(const float* xyz, const float* center, const float* feat, const int64_t* idx, int B, int N, int S, int K,
                        int C, int D, float* out, spgan_stream_t s);
+/* Adjoints of the gathers above (the reference gets them from torch indexing: index_put / the side-car's atomicAdd scatter,
+ * metrics/pointops/src/grouping/grouping_cuda_kernel.cu:28-45, metrics/pointnet2/src/group_points_gpu.cu:8-30).  Deterministic:
+ * spgan_gather_csr lists, per point, the gather slots that read it (ascending), the sums run over those lists in order.
+ *   spgan_gather_csr:           idx int64 [B,S] local indices -> rowptr int32 [B*N,2] (begin,end) into src int32 [B*S]; *bad |= 1 on an index outside [0,N)
+ *   spgan_scatter_slots:        dpoints[n,c] = sum_{e in slots(n)} dout[e*ld + col0 + c]      (index_points / grouping backward)
+ *   spgan_group_center_bwd:     dcenter[q,c] = -sum_j dout[(q*K+j)*ld + c]                    (pointnet_util.py:128, pointconv_util.py:189)
+ *   spgan_edge_features_cm_bwd: dx [B,C,N] from dE [B,2C,N,k] (central + "-central" + in-edge terms, Generation/modules.py:708-720) */
+int spgan_gather_csr(const int64_t* idx, int B, int S, int N, int32_t* rowptr, int32_t* src, int32_t* bad, spgan_stream_t s);
+int spgan_scatter_slots(const float* dout, int ld, int col0, int C, const int32_t* rowptr, const int32_t* src, int BN, float* dpoints,
+                        spgan_stream_t s);
+int spgan_group_center_bwd(const float* dout, int ld, int Q, int K, int C, float* dcenter, spgan_stream_t s);
+int spgan_edge_features_cm_bwd(const float* dE, const int32_t* rowptr, const int32_t* src, int B, int C, int N, int k, float* dx,
+                               spgan_stream_t s);
 /* Per-channel scalar algebra of the double backward, one launch each:
  *   coeffs out4C = [dgammaA | sbarA | xsum0 | xsum1];  phaseb: sums2C = [xsum0+gamma*s0 | xsum1+gamma*s1+invstd*sbarA], dgamma = dgammaA+s1 */
 int spgan_bn_dbl_coeffs(const float* U0, const float* U1, const float* Ugz, const float* S0, const float* S1, const float* gamma,

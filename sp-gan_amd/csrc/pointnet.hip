@@ -194,6 +194,133 @@ __global__ void group_concat_kernel(const float* __restrict__ xyz, const float* 
   out[t] = c < C ? xyz[((size_t)b * N + j) * C + c] - center[bs * C + c] : feat[((size_t)b * N + j) * D + (c - C)];
 }
 
+// ------------------------------------------------------------------------------------------ adjoints of the gathers
+// The reference's gathers (index_points pointnet_util.py:43-60, grouping pointconv_util.py:174-197, the neighbour gather of
+// get_edge_features modules.py:708-720) are differentiable through torch indexing; autograd's backward is an index_put with
+// float atomics (and the CUDA side-car's grouping_backward an atomicAdd scatter, metrics/pointops/src/grouping/grouping_cuda_kernel.cu:28-45).
+// Here: a CSR of "which gather slots read point n" (one workgroup per shape, LDS integer atomics, every segment sorted
+// ascending), then a gather-style sum over each point's slots in slot order -- deterministic, no float atomics.
+__global__ __launch_bounds__(1024) void gather_csr_kernel(const int64_t* __restrict__ idx, int S, int N, int32_t* __restrict__ rowptr,
+                                                          int32_t* __restrict__ src, int* __restrict__ bad) {
+  extern __shared__ int ism[];
+  int* deg = ism;          // [N]
+  int* start = ism + N;    // [N]
+  int* wsum = ism + 2 * N; // [32]
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int64_t* ib = idx + (size_t)b * S;
+  for (int i = tid; i < N; i += nt) deg[i] = 0;
+  __syncthreads();
+  for (int e = tid; e < S; e += nt) {
+    const int64_t j = ib[e];
+    if (j < 0 || j >= N) { if (bad) atomicOr(bad, 1); continue; }
+    atomicAdd(&deg[(int)j], 1);
+  }
+  __syncthreads();
+  const int chunk = (N + nt - 1) / nt;
+  const int lo = min(N, tid * chunk), hi = min(N, lo + chunk);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += deg[i];
+  int incl = s;
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 0; w < (nt + 63) / 64; ++w) {
+      const int v = wsum[w];
+      wsum[w] = run;
+      run += v;
+    }
+    wsum[31] = run;   // valid slots of this shape
+  }
+  __syncthreads();
+  int run = wsum[wv] + incl - s;
+  for (int i = lo; i < hi; ++i) {
+    start[i] = run;
+    run += deg[i];
+  }
+  __syncthreads();
+  // segments of shape b live in src[b*S, (b+1)*S) (invalid indices leave the tail of that range unused)
+  for (int i = tid; i < N; i += nt) {
+    rowptr[((size_t)b * N + i) * 2] = b * S + start[i];
+    rowptr[((size_t)b * N + i) * 2 + 1] = b * S + start[i] + deg[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += nt) deg[i] = 0;  // reuse as cursor
+  __syncthreads();
+  for (int e = tid; e < S; e += nt) {
+    const int64_t j = ib[e];
+    if (j < 0 || j >= N) continue;
+    const int slot = atomicAdd(&deg[(int)j], 1);
+    src[(size_t)b * S + start[(int)j] + slot] = b * S + e;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = tid; i < N; i += nt) {
+    int32_t* seg = src + (size_t)b * S + start[i];
+    const int n = deg[i];
+    for (int a = 1; a < n; ++a) {
+      const int v = seg[a];
+      int c = a - 1;
+      while (c >= 0 && seg[c] > v) {
+        seg[c + 1] = seg[c];
+        --c;
+      }
+      seg[c + 1] = v;
+    }
+  }
+}
+
+// dpoints[n, c] = sum over the slots e of point n (ascending) of dout[e*ld + col0 + c]
+__global__ void scatter_slots_kernel(const float* __restrict__ dout, int ld, int col0, int C, const int32_t* __restrict__ rowptr,
+                                     const int32_t* __restrict__ src, size_t total, float* __restrict__ dpoints) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const size_t n = t / C;
+  const int c = t % C;
+  float acc = 0.f;
+  for (int e = rowptr[2 * n], e1 = rowptr[2 * n + 1]; e < e1; ++e) acc += dout[(size_t)src[e] * ld + col0 + c];
+  dpoints[t] = acc;
+}
+
+// dcenter[q, c] = -sum_j dout[(q*K + j)*ld + c]   (the "- center" term of the grouping, pointnet_util.py:128 / pointconv_util.py:189)
+__global__ void group_center_bwd_kernel(const float* __restrict__ dout, int ld, int K, int C, size_t total, float* __restrict__ dcenter) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const size_t q = t / C;
+  const int c = t % C;
+  float acc = 0.f;
+  for (int j = 0; j < K; ++j) acc += dout[(q * K + j) * ld + c];
+  dcenter[t] = -acc;
+}
+
+// dx[b,c,i] = sum_r dE[b,c,i,r] - sum_r dE[b,C+c,i,r] + sum over the slots (i',r) that gathered point i of dE[b,C+c,i',r]    modules.py:708-720
+__global__ void edge_features_cm_bwd_kernel(const float* __restrict__ dE, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                            int C, int N, int k, float* __restrict__ dx) {
+  const int b = blockIdx.y;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)C * N) return;
+  const int i = t % N;
+  const int c = t / N;
+  const size_t S = (size_t)N * k;
+  const float* ec = dE + ((size_t)b * 2 * C + c) * S;
+  const float* ed = dE + ((size_t)b * 2 * C + C + c) * S;
+  float acc = 0.f;
+  for (int r = 0; r < k; ++r) acc += ec[(size_t)i * k + r];
+  float dsum = 0.f;
+  for (int r = 0; r < k; ++r) dsum += ed[(size_t)i * k + r];
+  acc -= dsum;
+  const size_t n = (size_t)b * N + i;
+  float in = 0.f;
+  for (int e = rowptr[2 * n], e1 = rowptr[2 * n + 1]; e < e1; ++e) in += ed[(size_t)src[e] - (size_t)b * S];
+  dx[((size_t)b * C + c) * N + i] = acc + in;
+}
+
 }  // namespace
 
 extern "C" int spgan_square_distance(const float* src, const float* dst, int B, int N, int M, int C, float* out, spgan_stream_t s_) {
@@ -241,5 +368,36 @@ extern "C" int spgan_group_concat(const float* xyz, const float* center, const f
   SPGAN_CHECK_ARG(xyz && center && idx && out && B > 0 && N > 0 && S > 0 && K > 0 && C > 0 && D >= 0 && (D == 0 || feat));
   const size_t total = (size_t)B * S * K * (C + D);
   hipLaunchKernelGGL(group_concat_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s_, xyz, center, feat, idx, N, S, K, C, D, total, out);
+  return spgan_launch_status();
+}
+
+/* CSR of the gather slots per point: rowptr int32 [B*N, 2] = (begin, end) into src int32 [B*S] (global slot ids b*S + s, ascending per
+ * point); bad (optional, one int, zeroed by the caller) is set when an index lies outside [0, N). */
+extern "C" int spgan_gather_csr(const int64_t* idx, int B, int S, int N, int32_t* rowptr, int32_t* src, int32_t* bad, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(idx && rowptr && src && B > 0 && S > 0 && N > 0 && N <= 16384 && (size_t)B * S < 2147483647u);
+  const size_t sh = (size_t)(2 * N + 32) * sizeof(int);
+  hipLaunchKernelGGL(gather_csr_kernel, dim3(B), dim3(1024), sh, (hipStream_t)s_, idx, S, N, rowptr, src, (int*)bad);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_scatter_slots(const float* dout, int ld, int col0, int C, const int32_t* rowptr, const int32_t* src, int BN,
+                                   float* dpoints, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dout && rowptr && src && dpoints && ld > 0 && col0 >= 0 && C > 0 && col0 + C <= ld && BN > 0);
+  const size_t total = (size_t)BN * C;
+  hipLaunchKernelGGL(scatter_slots_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s_, dout, ld, col0, C, rowptr, src, total, dpoints);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_group_center_bwd(const float* dout, int ld, int Q, int K, int C, float* dcenter, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dout && dcenter && ld >= C && Q > 0 && K > 0 && C > 0);
+  const size_t total = (size_t)Q * C;
+  hipLaunchKernelGGL(group_center_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s_, dout, ld, K, C, total, dcenter);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_edge_features_cm_bwd(const float* dE, const int32_t* rowptr, const int32_t* src, int B, int C, int N, int k, float* dx,
+                                          spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(dE && rowptr && src && dx && B > 0 && C > 0 && N > 0 && k > 0);
+  hipLaunchKernelGGL(edge_features_cm_bwd_kernel, dim3(cdiv((size_t)C * N, 256), B), dim3(256), 0, (hipStream_t)s_, dE, rowptr, src, C, N, k, dx);
   return spgan_launch_status();
 }

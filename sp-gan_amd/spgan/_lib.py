@@ -172,6 +172,10 @@ SIGNATURES = {
     "spgan_query_ball_point": (I, [F, I, P, P, I, I, I, I, P, P]),
     "spgan_knn_point": (I, [I, P, P, I, I, I, I, P, P]),
     "spgan_group_concat": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+    "spgan_gather_csr": (I, [P, I, I, I, P, P, P, P]),
+    "spgan_scatter_slots": (I, [P, I, I, I, P, P, I, P, P]),
+    "spgan_group_center_bwd": (I, [P, I, I, I, I, P, P]),
+    "spgan_edge_features_cm_bwd": (I, [P, P, P, I, I, I, I, P, P]),
     "spgan_nn_distance": (I, [P, P, I, I, I, P, P, P]),
     "spgan_chamfer_bwd": (I, [P, P, I, I, I, P, P, P, P, P, P]),
     "spgan_chamfer_pairs": (I, [P, P, I, I, I, I, P, P]),

@@ -244,11 +244,10 @@ class DiscriminatorBackwardFn(Function):
     def backward(ctx, v):
         params = ctx.saved_tensors
         names = ctx.holder.names
-        if not ctx.dctx["training"]:
-            raise NotImplementedError("double backward through eval-mode BatchNorm is not implemented")
         P = dict(zip(names, [nets.owned(p) for p in params]))
         need_x = ctx.needs_input_grad[3]
-        grads, dx2 = nets.d_double_backward(P, ctx.dctx, ctx.saved, v.detach(), need_dx=need_x)
+        dbl = nets.d_double_backward if ctx.dctx["training"] else nets.d_double_backward_eval      # eval(): BatchNorm is a fixed affine
+        grads, dx2 = dbl(P, ctx.dctx, ctx.saved, v.detach(), need_dx=need_x)
         # (holder, dctx, dout, x, *params); the gradient w.r.t. dout is not provided (constant ones in WGAN-GP)
         return (None, None, None, dx2) + _deliver(params, [grads[n] for n in names], ctx.needs_input_grad[4:])
 
@@ -295,6 +294,21 @@ class EdgeBlockFn(Function):
                 cache["csr"] = csr
         dx, g = nets.edgeblock_backward(P, h.prefix, ctx.ectx, dout, csr, need_dx=ctx.needs_input_grad[1])
         return (None, dx) + _deliver(params, [g[n] for n in h.names], ctx.needs_input_grad[2:])
+
+
+class EdgeFeaturesFn(Function):
+    """ee [B,2C,N,k] = cat[x_i, x_j - x_i] (Generation/modules.py:708-720) with its adjoint w.r.t. x [B,C,N]."""
+
+    @staticmethod
+    def forward(ctx, x, idx, k):
+        ctx.save_for_backward(idx)
+        ctx.k = k
+        return ops.edge_features_cm(x, idx, k)
+
+    @staticmethod
+    def backward(ctx, dE):
+        (idx,) = ctx.saved_tensors
+        return ops.edge_features_cm_bwd(dE.contiguous(), idx, ctx.k), None, None
 
 
 class RepeatRowsFn(Function):

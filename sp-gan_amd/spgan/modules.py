@@ -493,16 +493,20 @@ Discriminator.advance_running_stats = _discriminator_advance_running_stats
 
 def get_edge_features(x, k, num=-1, idx=None, return_idx=False):
     """Generation/modules.py:683-725: x [B,C,N] -> ee [B,2C,N,k] (= cat[central, neighbour-central]); optional injected /
-    returned idx is int64 [B, N*k] with per-shape local indices, like the reference.  Forward only (the Generator path
-    never materialises ee; EdgeBlock carries the gradient)."""
+    returned idx is int64 [B, N*k] with per-shape local indices, like the reference.  Differentiable in x like the reference's
+    gather/concat (the indices carry no gradient): the backward sums, per point, its own k central / difference terms and the
+    difference terms of the edges that gathered it, in edge order (Fn.EdgeFeaturesFn; no float atomics).  The Generator path itself
+    never materialises ee -- EdgeBlock carries its own fused backward."""
     _require_gpu(x, "get_edge_features")
-    if x.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("get_edge_features is forward-only; use EdgeBlock for a differentiable edge convolution")
     B, C, N = x.shape
     x = x.contiguous()
     if idx is None:
-        gidx = ops.knn(ops.cm_to_pm(x), B, N, k, 1 if C <= 4 else 0)
-        idx = ops.idx_to_local64(gidx, B, N)
+        with torch.no_grad():
+            gidx = ops.knn(ops.cm_to_pm(x.detach()), B, N, k, 1 if C <= 4 else 0)
+            idx = ops.idx_to_local64(gidx, B, N)
     idx = idx.contiguous().view(B, N * k)
-    ee = ops.edge_features_cm(x, idx, k)
+    if x.requires_grad and torch.is_grad_enabled():
+        ee = Fn.EdgeFeaturesFn.apply(x, idx, k)
+    else:
+        ee = ops.edge_features_cm(x, idx, k)
     return (ee, idx) if return_idx else ee

@@ -618,6 +618,45 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
     return grads, dx
 
 
+def d_double_backward_eval(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
+    """d_double_backward for a Discriminator in eval() mode (Common/gradient_penalty.py:28-33 works in either mode).  With running
+    statistics every BatchNorm is a fixed per-channel affine, so the first-order backward is gy_l = sc_l * gz_l, gz_l = ga_l * m_l,
+    ga_{l-1} = gy_l.W_l with piecewise-constant masks: R(dx) reaches the parameters only through phase A (the reverse of the backward
+    graph) -- nothing is deposited on the forward activations, the biases and BatchNorm shifts get exactly zero, and dR/dx = 0 almost
+    everywhere (D is piecewise linear in x).
+      u_l = q_{l-1}.W_l^T;  Wbar_l = gy_l^T q_{l-1};  gammabar_l = invstd_l * sum(u_l*gz_l);  q_l = sc_l * u_l * m_l."""
+    B, N = ctx["B"], ctx["N"]
+    M = B * N
+    ys, bns, hs, pooled, argmax = ctx["ys"], ctx["bns"], ctx["hs"], ctx["pooled"], ctx["argmax"]
+    dys, gs = saved["dys"], saved["gs"]
+    grads: Dict[str, Tensor] = {}
+    q = ops.cm_to_pm(v_dx_cm.contiguous())
+    for li in range(4):
+        conv, bn = D_LAYERS[li]
+        W = _w2(P[conv + ".weight"])
+        sc, sh, inv, mu = bns[li]
+        C = W.shape[0]
+        grads[conv + ".weight"] = ops.gemm_tn(_dense(dys[li]), q).view_as(P[conv + ".weight"])
+        grads[conv + ".bias"] = ZERO_GRAD
+        u = ops.gemm_nt(q, W)
+        gz = ops.scatter_rows(saved["gval"], argmax, M) if li == 3 else gs[li]
+        _, _, Ugz = ops.bn_dbl_stats(u, ys[li], gz, mu, inv)
+        grads[bn + ".weight"] = Ugz * inv                     # O(C) per-channel scalar formula
+        grads[bn + ".bias"] = ZERO_GRAD
+        zero = _const_vec(C, 0.0, u.device)
+        q, _ = ops.bn_dbl_apply(u, ys[li], gz, mu, inv, sc, sh, NEG, P[bn + ".weight"], zero, zero, zero, M)
+    t = ops.gather_rows(q, argmax)
+    dhs = saved["dhs"]
+    for li in (0, 1, 2, 3):
+        name = D_MLP[li]
+        grads[name + ".weight"] = ops.gemm_tn(dhs[li], t, defer=True)
+        grads[name + ".bias"] = ZERO_GRAD
+        if li < 3:
+            t = ops.gemm_nt_maskout(t, P[name + ".weight"], hs[li], NEG)
+    dx = torch.zeros((B, 3, N), dtype=torch.float32, device=q.device) if need_dx else None
+    return grads, dx
+
+
 # =============================================================================================
 # EdgeBlock (Generation/Generator.py:47-88), point-major, restructured per point
 # =============================================================================================

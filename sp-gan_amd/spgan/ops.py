@@ -212,6 +212,22 @@ def edge_features_cm(x_cm: Tensor, idx_local: Tensor, k: int) -> Tensor:
     return ee
 
 
+def edge_features_cm_bwd(dE: Tensor, idx_local: Tensor, k: int) -> Tensor:
+    """Adjoint of edge_features_cm w.r.t. x: dE [B,2C,N,k], idx int64 [B,N*k] local -> dx [B,C,N] (deterministic: per-point slot lists)."""
+    _f32(dE, "dE", 4)
+    B, C2, N, kk = dE.shape
+    if kk != k or C2 % 2 or idx_local.dtype != torch.int64 or idx_local.numel() != B * N * k:
+        raise ValueError("edge_features_cm_bwd: dE [B,2C,N,k] and idx int64 [B,N*k] expected")
+    lib = _lib.load()
+    idx_local = idx_local.contiguous()
+    rowptr = torch.empty((B * N, 2), dtype=torch.int32, device=dE.device)
+    src = torch.empty((B * N * k,), dtype=torch.int32, device=dE.device)
+    check(lib.spgan_gather_csr(_p(idx_local), B, N * k, N, _p(rowptr), _p(src), None, _s()), "gather_csr", B=B, S=N * k, N=N)
+    dx = torch.empty((B, C2 // 2, N), dtype=torch.float32, device=dE.device)
+    check(lib.spgan_edge_features_cm_bwd(_p(dE), _p(rowptr), _p(src), B, C2 // 2, N, k, _p(dx), _s()), "edge_features_cm_bwd", B=B, C=C2 // 2, N=N, k=k)
+    return dx
+
+
 def idx_to_local64(idx: Tensor, B: int, N: int) -> Tensor:
     _i32(idx, "idx")
     k = idx.shape[1]

@@ -866,8 +866,150 @@ def g17():
     save("g17_step_c2.npz", d)
 
 
+# ---------------------------------------------------------------- G18: the reference's OWN noise on the benchmarked step
+ZERO_GRAD_BIASES = ("EdgeConv1.conv_w.0.bias", "EdgeConv1.conv_w.3.bias", "EdgeConv1.conv_x.0.bias", "EdgeConv2.conv_w.0.bias",
+                    "EdgeConv2.conv_w.3.bias", "EdgeConv2.conv_x.0.bias", "global_conv.0.bias", "global_conv.3.bias",
+                    "mlps.0.bias", "mlps.3.bias", "mlps.6.bias", "fc2.0.bias")
+
+
+def _ref_wgangp_step(dtype, graphs=None):
+    """One WGAN-GP D-step + G-step of the imported reference at C2 (the run g17 (c) stores), in `dtype`, optionally with both
+    EdgeConv2 graphs injected.  Returns the two graphs, the stage tensors in front of them, the clouds and every gradient."""
+    import Generation.Generator as GG
+    B, N = 32, 2048
+    G, D = make_gd(salt=18)
+    G, D = G.to(dtype), D.to(dtype)
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).to(dtype)
+    real = fr.synthetic_real(B, N, seed=181).to(dtype)
+    z_d, z_g = fr.latent(B, N, seed=182).to(dtype), fr.latent(B, N, seed=183).to(dtype)
+    alpha = fr.uniform("g17.step.alpha", (B, 1, 1), 0.0, 1.0).to(dtype)
+    stages, rec = {}, {}
+    hook = G.adain1.register_forward_hook(lambda m, i, o: stages.__setitem__("x1", o.detach().clone()))
+    orig_gef, calls, inject = GG.get_edge_features, [0], [None]
+
+    def patched(x_, k_, num=-1, idx=None, return_idx=False):
+        calls[0] += 1
+        return orig_gef(x_, k_, num, inject[0] if (calls[0] % 2 == 0 and inject[0] is not None) else idx, return_idx)
+
+    def req(m, f):
+        for p in m.parameters():
+            p.requires_grad = f
+    GG.get_edge_features = patched
+    orig_rand = torch.rand
+    torch.rand = lambda *a, **k: alpha.clone().requires_grad_(k.get("requires_grad", False))
+    torch.set_default_dtype(dtype)                              # gradient_penalty.py:32 builds its seed with torch.ones(...)
+    try:
+        optD = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.99))
+        req(G, False); req(D, True); optD.zero_grad()
+        inject[0] = None if graphs is None else graphs[0]
+        fake = G(x, z_d).detach()
+        rec["x1_d"] = stages["x1"]
+        rec["idx2_d"] = orig_gef(stages["x1"], 10, return_idx=True)[1] if graphs is None else graphs[0]
+        real_t = real.transpose(2, 1).contiguous()
+        d_real, d_fake = D(real_t), D(fake)
+        lossD, _ = LU.dis_loss(d_real, d_fake, gan="wgan")
+        lossD = lossD + GradientPenalty(10.0, gamma=1)(D, real_t, fake)
+        lossD.backward()
+        rec["dgrad"] = {n: p.grad.detach().clone() for n, p in D.named_parameters()}
+        optD.step()
+        req(G, True); req(D, False)
+        inject[0] = None if graphs is None else graphs[1]
+        g_fake = G(x, z_g)
+        rec["x1_g"] = stages["x1"]
+        rec["idx2_g"] = orig_gef(stages["x1"], 10, return_idx=True)[1] if graphs is None else graphs[1]
+        D(real_t)
+        lossG, _ = LU.gen_loss(None, D(g_fake), gan="wgan")
+        lossG.backward()
+        rec["ggrad"] = {n: p.grad.detach().clone() for n, p in G.named_parameters()}
+        rec["fake_d"], rec["fake_g"] = fake, g_fake.detach()
+    finally:
+        GG.get_edge_features = orig_gef
+        torch.rand = orig_rand
+        torch.set_default_dtype(torch.float32)
+        hook.remove()
+    return rec
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-300))
+
+
+def _whole(grads, skip):
+    return torch.cat([g.double().reshape(-1) for n, g in grads.items() if not n.endswith(skip)])
+
+
+def g18():
+    """Round-3 review item 3(a): bounds for the own-graph step tests DERIVED from the reference instead of asserted.
+    (a) the benchmarked C2 step (g17 (c)) once more in float64 on the float32 run's two EdgeConv2 graphs: what the reference's own
+        float32 rounding does to every D and G gradient of the step with the discrete kNN choice held fixed;
+    (b) the float32 step with the n most nearly tied kNN rows of BOTH graphs resolved the other way (n = 1 .. 100): how far every D
+        gradient, the whole G gradient (cosine, norm ratio) and the clouds move when the reference itself lands on the other side of
+        n ties -- the build's own graphs differ from the reference's in 15-20 such rows."""
+    B, N = 32, 2048
+    d = {}
+    base = _ref_wgangp_step(torch.float32)
+    ref = np.load(os.path.join(HERE, "g17_step_c2.npz"))
+    assert np.array_equal(ref["idx2_d"], base["idx2_d"].view(B, N, 10).numpy().astype(np.int16)), "not the run g17 (c) stored"
+    graphs = (base["idx2_d"], base["idx2_g"])
+    print("g18: float32 step done", flush=True)
+    r64 = _ref_wgangp_step(torch.float64, graphs=graphs)
+    for n, g in r64["dgrad"].items():
+        put(d, "dgrad64|" + n, g.float())
+        d["noise32|dgrad|" + n] = np.float64(_rel(base["dgrad"][n], g))
+    for n, g in r64["ggrad"].items():
+        put(d, "ggrad64|" + n, g.float())
+        d["noise32|ggrad|" + n] = np.float64(_rel(base["ggrad"][n], g))
+    put(d, "fake_d64", r64["fake_d"].float(), nsamp=8192); put(d, "fake_g64", r64["fake_g"].float(), nsamp=8192)
+    a, b = _whole(base["ggrad"], ZERO_GRAD_BIASES), _whole(r64["ggrad"], ZERO_GRAD_BIASES)
+    d["noise32|ggrad_cos"] = np.float64(a @ b / (a.norm() * b.norm())); d["noise32|ggrad_ratio"] = np.float64(a.norm() / b.norm())
+    print("g18: float64 step done; whole-G cosine %.7f ratio %.5f; worst D tensor %.2e" % (
+        d["noise32|ggrad_cos"], d["noise32|ggrad_ratio"], max(float(v) for k, v in d.items() if k.startswith("noise32|dgrad|"))), flush=True)
+    del r64
+    # (b) tie flips in both graphs
+    ns = [1, 5, 20, 50, 100]
+    alts = {}
+    for which in ("d", "g"):
+        with torch.no_grad():
+            dist = orc.pairwise_sqdist(base["x1_" + which])
+            srt, order = torch.sort(dist, dim=2)
+            gap = ((srt[:, :, 11] - srt[:, :, 10]) / srt[:, :, 10]).reshape(-1)
+            alts[which] = (gap, order[:, :, 1:12].clone())
+            del dist, srt, order
+    tab = {k: [] for k in ("ggrad_cos", "ggrad_ratio", "fake_d", "fake_g", "gap")}
+    dtab = {n: [] for n in base["dgrad"]}
+    gtab = {n: [] for n in base["ggrad"]}
+    for nflip in ns:
+        gs = []
+        for which in ("d", "g"):
+            gap, order = alts[which]
+            rows = torch.topk(-gap, nflip)[1]
+            alt = order[:, :, :10].clone().reshape(B * N, 10)
+            for r in rows.tolist():
+                alt[r, 9] = order[r // N, r % N, 10]
+            gs.append(alt.view(B, N * 10))
+            tab["gap"].append(gap[rows].max().item())
+        fl = _ref_wgangp_step(torch.float32, graphs=tuple(gs))
+        for n in dtab:
+            dtab[n].append(_rel(fl["dgrad"][n], base["dgrad"][n]))
+        for n in gtab:
+            gtab[n].append(_rel(fl["ggrad"][n], base["ggrad"][n]))
+        a, b = _whole(fl["ggrad"], ZERO_GRAD_BIASES), _whole(base["ggrad"], ZERO_GRAD_BIASES)
+        tab["ggrad_cos"].append(float(a @ b / (a.norm() * b.norm()))); tab["ggrad_ratio"].append(float(a.norm() / b.norm()))
+        tab["fake_d"].append(_rel(fl["fake_d"], base["fake_d"])); tab["fake_g"].append(_rel(fl["fake_g"], base["fake_g"]))
+        print("g18: %3d flips per graph: cloud %.2e / %.2e, whole-G cosine %.5f ratio %.4f, worst D tensor %.2e" % (
+            nflip, tab["fake_d"][-1], tab["fake_g"][-1], tab["ggrad_cos"][-1], tab["ggrad_ratio"][-1], max(v[-1] for v in dtab.values())), flush=True)
+    d["tie|nflip"] = np.array(ns)
+    for k, v in tab.items():
+        d["tie|" + k] = np.array(v, dtype=np.float64)
+    for n, v in dtab.items():
+        d["tie|dgrad|" + n] = np.array(v, dtype=np.float64)
+    for n, v in gtab.items():
+        d["tie|ggrad|" + n] = np.array(v, dtype=np.float64)
+    save("g18_step_noise_c2.npz", d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     for name in which:
         globals()[name]()

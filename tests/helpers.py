@@ -87,23 +87,78 @@ def check_bounded_by_reference_noise(d, name32, name64, t, floor, factor=1.5, at
     return e_own, e_ref
 
 
-def check_gradient_direction(d, prefix, grads, skip=(), min_cos=0.95, max_norm_dev=0.15):
-    """End-to-end gradients behind discrete choices the build may resolve differently from the reference (its own kNN near-ties, then
-    D's arg-max / LeakyReLU kinks): individual tensors can move by tens of percent when one choice flips, the gradient as a whole
-    keeps its direction and size.  Compares the concatenation of all (full or sampled) golden entries `prefix + name`: cosine and
-    norm ratio."""
+class StepNoise:
+    """Golden G18 (tests/golden/make_golden.py::g18): the REFERENCE's own noise on the benchmarked C2 WGAN-GP step, from which the bounds of
+    the step tests are derived instead of asserted:
+      * `noise32|*`: its float32 run against its float64 run on the same two EdgeConv2 graphs (per D / G gradient tensor, whole-G cosine);
+      * `tie|*`:     its float32 run with the n most nearly tied kNN rows of both graphs resolved the other way, n = 1 .. 100 (per tensor
+                     movement, whole-G cosine and norm ratio, clouds).
+    A build whose own graphs differ from the reference's in n_diff near-tie rows may move by `factor` x what the reference itself moves
+    when it lands on the other side of >= n_diff ties."""
+
+    def __init__(self):
+        self.d = golden("g18_step_noise_c2.npz")
+        self.ns = [int(n) for n in self.d["tie|nflip"]]
+
+    def _pick(self, arr, n_diff):
+        for n, v in zip(self.ns, arr):
+            if n >= n_diff:
+                return float(v)
+        return float(arr[-1]) * n_diff / self.ns[-1]
+
+    def tensor_bound(self, kind, name, n_diff, factor):
+        """rel-L2 bound for gradient tensor `name` (kind 'dgrad' / 'ggrad') with n_diff differing near-tie rows (0: same graphs)."""
+        noise = max(float(self.d["noise32|%s|%s" % (kind, name)]), 4e-7)       # floor: a few float32 ulps (tensors the reference reproduces exactly)
+        if n_diff <= 0:
+            return factor * noise
+        return factor * max(self._pick(self.d["tie|%s|%s" % (kind, name)], n_diff), noise)
+
+    def whole_g_bound(self, n_diff, factor):
+        """rel-L2 movement of the whole G gradient: sqrt(1 + r^2 - 2 r cos) of the reference's own (cosine, norm ratio)."""
+        def mov(c, r):
+            return float(np.sqrt(max(1.0 + r * r - 2.0 * r * c, 0.0)))
+        noise = mov(float(self.d["noise32|ggrad_cos"]), float(self.d["noise32|ggrad_ratio"]))
+        if n_diff <= 0:
+            return factor * noise
+        tab = [mov(c, r) for c, r in zip(self.d["tie|ggrad_cos"], self.d["tie|ggrad_ratio"])]
+        return factor * max(self._pick(tab, n_diff), noise)
+
+
+def check_step_gradients_bounded(step_d, noise, kind, grads, n_diff, factor, skip=(), atol=None):
+    """Every gradient tensor of the step against golden `step_d` (g17_step_c2: '<kind>|<name>'), bound = StepNoise.tensor_bound."""
+    worst = 0.0
+    for n, g in grads.items():
+        a = g.detach().cpu().numpy()
+        ref, got = _entry(step_d, "%s|%s" % (kind, n), a)
+        if n.endswith(tuple(skip)):
+            # zero-gradient biases (SURVEY H1c): the reference holds rounding noise, the build exact zeros -- absolute bound only
+            assert float(np.abs(got - ref).max()) <= (atol or 2e-3), n
+            continue
+        bound = noise.tensor_bound(kind, n, n_diff, factor)
+        err = float(np.sqrt(((got.astype(np.float64) - ref) ** 2).sum()) / max(np.sqrt((ref.astype(np.float64) ** 2).sum()), 1e-30))
+        _log("%s|%s (bound = %.1f x the reference's own movement for %d differing tie rows)" % (kind, n, factor, n_diff), err,
+             float(np.abs(got - ref).max()), float(np.abs(ref).max()), rtol=bound)
+        assert err <= bound, "%s|%s: rel-L2 %.3e > %.1f x the reference's own noise (%.3e) with %d differing tie rows" % (kind, n, err, factor, bound / factor, n_diff)
+        worst = max(worst, err / bound)
+    return worst
+
+
+def check_whole_gradient_bounded(step_d, noise, prefix, grads, n_diff, factor, skip=()):
+    """The whole G gradient (all golden entries concatenated): rel-L2 movement <= factor x the reference's own for n_diff tie rows."""
     a_all, b_all = [], []
     for n, g in grads.items():
         if n.endswith(tuple(skip)):
             continue
-        ref, got = _entry(d, prefix + n, g.detach().cpu().numpy())
+        ref, got = _entry(step_d, prefix + n, g.detach().cpu().numpy())
         a_all.append(got.astype(np.float64)); b_all.append(ref.astype(np.float64))
     a, b = np.concatenate(a_all), np.concatenate(b_all)
+    mov = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
     cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
-    ratio = float(np.linalg.norm(a) / max(np.linalg.norm(b), 1e-300))
-    _log(prefix + "* (whole gradient: 1 - cosine; norm ratio %.4f)" % ratio, 1.0 - cos, abs(ratio - 1.0), float(np.abs(b).max()), rtol=1.0 - min_cos, atol=max_norm_dev)
-    assert cos >= min_cos and abs(ratio - 1.0) <= max_norm_dev, "%s*: cosine %.4f, norm ratio %.4f" % (prefix, cos, ratio)
-    return cos, ratio
+    bound = noise.whole_g_bound(n_diff, factor)
+    _log(prefix + "* (whole gradient rel-L2; cosine %.4f; bound = %.1f x the reference's own movement for %d differing tie rows)" % (cos, factor, n_diff),
+         mov, 0.0, float(np.abs(b).max()), rtol=bound)
+    assert mov <= bound, "%s*: whole-gradient rel-L2 %.3e (cosine %.4f) > %.1f x the reference's own %.3e" % (prefix, mov, cos, factor, bound / factor)
+    return mov, bound
 
 
 def params_from(shapes, salt, requires_grad=False):

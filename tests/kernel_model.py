@@ -55,6 +55,16 @@ def edge_features_cm(x_cm, idx_local, k):
     return torch.cat([ctr, nb - ctr], dim=1).contiguous()
 
 
+def edge_features_cm_bwd(dE, idx_local, k):
+    """adjoint of edge_features_cm w.r.t. x (modules.py:708-720): central + '-central' + in-edge scatter."""
+    B, C2, N, _ = dE.shape
+    C = C2 // 2
+    dc, dd = dE[:, :C], dE[:, C:]
+    dx = dc.sum(3) - dd.sum(3)
+    idx3 = idx_local.view(B, 1, N * k).expand(B, C, N * k)
+    return dx.scatter_add(2, idx3, dd.reshape(B, C, N * k)).contiguous()
+
+
 def idx_to_local64(idx, B, N):
     k = idx.shape[1]
     off = (torch.arange(B, device=idx.device) * N).view(B, 1)

@@ -17,7 +17,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check, check_bounded_by_reference_noise as check64, check_gradient_direction, golden, rel_l2
+from helpers import (StepNoise, check, check_bounded_by_reference_noise as check64, check_step_gradients_bounded,
+                     check_whole_gradient_bounded, golden, rel_l2)
 from oracle import spgan_oracle as orc
 from spgan import fixture_rng as fr
 
@@ -145,6 +146,7 @@ def test_train_step_benchsize_golden(sp, inject):
     z_d, z_g = fr.latent(B, N, seed=182).cuda(), fr.latent(B, N, seed=183).cuda()
     alpha = torch.from_numpy(d["alpha"]).cuda()
     n_diff = 0
+    noise = StepNoise()      # golden G18: the reference's own float32-vs-float64 and tie-flip movements of exactly this step
     if inject:
         G.inject_graph2([torch.from_numpy(d["idx2_d"].astype(np.int64)).view(B, N * 10), torch.from_numpy(d["idx2_g"].astype(np.int64)).view(B, N * 10)])
     info = tr.step(x, real, z_d, z_g, alpha=alpha, keep_grads=True)
@@ -160,16 +162,23 @@ def test_train_step_benchsize_golden(sp, inject):
         check(d, "fake_g", info["fake_g"], rtol=2e-4)
     else:
         n_diff = _tie_aware_graph_check(sp, G, torch.from_numpy(d["idx2_g"].astype(np.int64)).view(B * N, 10), B, N)
+        # the D step's graph (first generator forward) is not kept by the module; its stage tensor is the same function of the same
+        # weights on another latent -- the flip tables are indexed by the larger of the two counts, taken >= the G step's
+        n_diff = max(n_diff, 1)
         table = golden("g17_fullsize_c2.npz")
         _check_within_tie_sensitivity(d, "fake_d", info["fake_d"], max(n_diff, 1), table=table)
         _check_within_tie_sensitivity(d, "fake_g", info["fake_g"], max(n_diff, 1), factor=6.0, table=table)      # also behind D's and nothing else's update: G's weights are the same
-    for n, g in info["d_grads"].items():
-        check(d, "dgrad|" + n, g, rtol=4e-3 if tight else 1.5e-1, atol=_atol(n))          # own graphs: D's gradients are functions of the generated cloud (above); measured 6.1e-2
+    # Gradient bounds DERIVED from the reference (golden G18), not asserted.  Same graphs: every tensor within 2.5 x the reference's own
+    # float32-vs-float64 movement of that tensor (two float32 evaluations differ by up to 2 x one's distance from the exact value; D's
+    # gradients 2e-4 .. 3.5e-3, G's -- behind D's Adam step and its kinks -- 8e-3 .. 1.9e-2).  Own graphs (n_diff near-tie rows differ):
+    # every D tensor and the whole G gradient within 2 x what the reference moves when it resolves >= n_diff ties the other way.
     if tight:
-        for n, g in info["g_grads"].items():
-            check(d, "ggrad|" + n, g, rtol=6e-2, atol=_atol(n))        # through D after its Adam step: kink-limited (measured 2.5e-2)
-    else:   # own graphs: a single tensor can move by tens of percent when a tie row / kink flips; the gradient keeps direction and size
-        check_gradient_direction(d, "ggrad|", info["g_grads"], skip=ZERO_GRAD_BIASES)
+        check_step_gradients_bounded(d, noise, "dgrad", info["d_grads"], 0, 2.5, skip=ZERO_GRAD_BIASES)
+        check_step_gradients_bounded(d, noise, "ggrad", info["g_grads"], 0, 2.5, skip=ZERO_GRAD_BIASES)
+        check_whole_gradient_bounded(d, noise, "ggrad|", info["g_grads"], 0, 2.5, skip=ZERO_GRAD_BIASES)
+    else:
+        check_step_gradients_bounded(d, noise, "dgrad", info["d_grads"], n_diff, 2.0, skip=ZERO_GRAD_BIASES)
+        check_whole_gradient_bounded(d, noise, "ggrad|", info["g_grads"], n_diff, 2.0, skip=ZERO_GRAD_BIASES)
     for n, p in D.named_parameters():
         if not n.endswith(ZERO_GRAD_BIASES):
             check(d, "dparam|" + n, p, rtol=1e-3, atol=2.5e-4)

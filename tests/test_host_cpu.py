@@ -125,6 +125,37 @@ def test_discriminator_gradient_penalty(spgan_cpu):
         _cmp("gp grad " + n, mine, g, 2e-3, atol=1e-3 if n.endswith(ZERO_GRAD_BIASES) else 2e-6)
 
 
+def test_discriminator_gradient_penalty_eval_mode(spgan_cpu):
+    """The same double backward through a Discriminator in eval() mode (running statistics: BatchNorm is a fixed affine;
+    Common/gradient_penalty.py:28-33 works in either mode) == oracle autograd."""
+    B, N = 3, 128
+    p = fr.init_params(orc.discriminator_shapes(), salt=13)
+    D = _load(spgan_cpu.modules.Discriminator(Opts), p)
+    buf = orc.bn_buffers(orc.discriminator_shapes())
+    for k in buf:                                       # non-trivial running statistics
+        if k.endswith("running_mean"):
+            buf[k] = fr.normal("hgpe.m." + k, buf[k].shape, 0.05)
+        elif k.endswith("running_var"):
+            buf[k] = fr.uniform("hgpe.v." + k, buf[k].shape, 0.5, 1.5)
+    D.load_state_dict({**D.state_dict(), **buf})
+    D.eval()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    real = fr.synthetic_real(B, N, seed=14).transpose(2, 1).contiguous()
+    fake = (0.8 * fr.synthetic_real(B, N, seed=15) + 0.05 * fr.normal("hgp.n", (B, N, 3))).transpose(2, 1).contiguous()
+    alpha = fr.uniform("hgp.alpha", (B, 1, 1), 0.0, 1.0)
+    gp_ref = orc.gradient_penalty(lambda t: orc.discriminator_forward(po, t, False, buf), real, fake, alpha, 10.0, 1.0)
+    names = list(po.keys())
+    gref = torch.autograd.grad(gp_ref, [po[n] for n in names], allow_unused=True)
+    gp = orc.gradient_penalty(D, real, fake, alpha, 10.0, 1.0)
+    np.testing.assert_allclose(gp.item(), gp_ref.item(), rtol=1e-4)
+    gp.backward()
+    for n, g in zip(names, gref):
+        mine = dict(D.named_parameters())[n].grad
+        g = torch.zeros_like(po[n]) if g is None else g
+        mine = torch.zeros_like(g) if mine is None else mine
+        _cmp("gp(eval) grad " + n, mine, g, 2e-3, atol=2e-6)
+
+
 @pytest.mark.parametrize("fin,fout", [(3, 64), (64, 128)])
 def test_edgeblock(spgan_cpu, fin, fout):
     B, N, k = 2, 96, 10

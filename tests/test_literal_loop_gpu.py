@@ -1,5 +1,5 @@
 """GPU: the reference's train-loop body EXECUTED LITERALLY (Generation/model.py:239-279, statement for statement:
-spgan.reference_loop.reference_loop_body -- separate G() / D() calls, requires_grad toggles per Common/network_utils.py:92-94,
+examples/reference_loop.py::reference_loop_body -- separate G() / D() calls, requires_grad toggles per Common/network_utils.py:92-94,
 dis_loss / gen_loss, .backward(), torch.optim.Adam(lr=1e-4, betas=(0.5, 0.99)) per model.py:94-97) on the HIP modules, against
 the golden train steps captured from the reference (G8: the C1 shape B=4, N=512 LS and a B=4, N=256 WGAN-GP step; G17: the
 benchmarked C2 step).  No TrainStep, no spgan.Adam, no fused gradient accumulation, latent tiled [B,N,128] as the reference's
@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check, check_gradient_direction, golden
+from helpers import StepNoise, check, check_step_gradients_bounded, check_whole_gradient_bounded, golden
 from oracle import spgan_oracle as orc
 from spgan import fixture_rng as fr
 
@@ -45,7 +45,7 @@ def _atol(n):
 
 
 def _setup(sp, salt, N, capturable=False):
-    from spgan.reference_loop import LoopState
+    from reference_loop import LoopState
     o = _opts(N)
     G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(), salt=salt))
     D = _load(sp.Discriminator(o, num_point=N), fr.init_params(orc.discriminator_shapes(), salt=salt))
@@ -56,15 +56,19 @@ def _setup(sp, salt, N, capturable=False):
     return G, D, optimizerG, optimizerD, LoopState
 
 
-def _compare_with_golden(d, G, D, lossD, lossG, keep, loose_fake=6e-5, dgrad_rtol=4e-3, lossg_atol=0.0, ggrad_rtol=2.5e-2, buf_tol=(2e-3, 2e-4)):
+def _compare_with_golden(d, G, D, lossD, lossG, keep, loose_fake=6e-5, dgrad_rtol=4e-3, lossg_atol=0.0, ggrad_rtol=2.5e-2, buf_tol=(2e-3, 2e-4), own_graph_rows=None):
     np.testing.assert_allclose(lossD.item(), float(d["lossD"]), rtol=3e-3)
     np.testing.assert_allclose(lossG.item(), float(d["lossG"]), rtol=5e-3, atol=max(lossg_atol, 1e-6))
     check(d, "fake_d", keep["fake_d"], rtol=loose_fake)
-    for n, g in keep["d_grads"].items():
-        check(d, "dgrad|" + n, g, rtol=dgrad_rtol, atol=_atol(n))
-    if ggrad_rtol is None:      # own graphs at the benchmarked size: direction and size of the whole gradient (helpers.check_gradient_direction)
-        check_gradient_direction(d, "ggrad|", keep["g_grads"], skip=ZERO_GRAD_BIASES)
+    if own_graph_rows is not None:
+        # own graphs at the benchmarked size: bounds derived from the reference's own movement when it resolves that many near-tied kNN
+        # rows the other way (golden G18; test_benchsize_golden_gpu.py::test_train_step_benchsize_golden[False])
+        noise = StepNoise()
+        check_step_gradients_bounded(d, noise, "dgrad", keep["d_grads"], own_graph_rows, 2.0, skip=ZERO_GRAD_BIASES)
+        check_whole_gradient_bounded(d, noise, "ggrad|", keep["g_grads"], own_graph_rows, 2.0, skip=ZERO_GRAD_BIASES)
     else:
+        for n, g in keep["d_grads"].items():
+            check(d, "dgrad|" + n, g, rtol=dgrad_rtol, atol=_atol(n))
         for n, g in keep["g_grads"].items():
             check(d, "ggrad|" + n, g, rtol=ggrad_rtol, atol=_atol(n))
     for n, p in D.named_parameters():
@@ -86,7 +90,7 @@ def _compare_with_golden(d, G, D, lossD, lossG, keep, loose_fake=6e-5, dgrad_rto
 def test_literal_reference_loop_matches_reference_step(sp, tag, gan, use_gp, B, N, gp_impl):
     """gp_impl "caller": the penalty written the way Common/gradient_penalty.py:19-37 writes it (plain torch: interpolate,
     autograd.grad(create_graph=True), norm) around OUR Discriminator -- the caller's code, not spgan.GradientPenalty."""
-    from spgan.reference_loop import reference_loop_body
+    from reference_loop import reference_loop_body
     d = golden("g8_train_step_%s.npz" % tag)
     G, D, optG, optD, LoopState = _setup(sp, 8, N)
     alpha = torch.from_numpy(d["alpha"]).cuda()
@@ -111,7 +115,7 @@ def test_literal_reference_loop_matches_reference_step(sp, tag, gan, use_gp, B, 
 
 def test_literal_reference_loop_at_the_benchmarked_size(sp):
     """C2 (B=32, N=2048, WGAN-GP) through the literal statements against the reference's step (golden G17), own kNN graphs."""
-    from spgan.reference_loop import reference_loop_body
+    from reference_loop import reference_loop_body
     B, N = 32, 2048
     d = golden("g17_step_c2.npz")
     G, D, optG, optD, LoopState = _setup(sp, 18, N)
@@ -122,9 +126,13 @@ def test_literal_reference_loop_at_the_benchmarked_size(sp):
     data = fr.synthetic_real(B, N, seed=181).cuda()
     z_d, z_g = fr.latent(B, N, seed=182).cuda(), fr.latent(B, N, seed=183).cuda()
     lossD, lossG, info = reference_loop_body(s, x, data, z_d, z_g)
-    # own kNN graphs: see test_benchsize_golden_gpu.py::test_train_step_benchsize_golden[False] for the tolerances and the tie-aware graph check
+    # own kNN graphs: the rows of the G step's EdgeConv2 graph that differ from the reference's (all near-ties: the tie-aware check itself is
+    # test_benchsize_golden_gpu.py::test_train_step_benchsize_golden[False]) index the reference's own tie-flip movement table (golden G18)
+    own = sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).view(B * N, 10).cpu()
+    n_diff = int((own != torch.from_numpy(d["idx2_g"].astype(np.int64)).view(B * N, 10)).any(dim=1).sum().item())
+    assert n_diff <= 0.01 * B * N
     _compare_with_golden(d, G, D, lossD, lossG, s.keep, loose_fake=3e-2, lossg_atol=2e-2 * float(np.abs(d["d_gfake"]).max()),
-                         dgrad_rtol=1.5e-1, ggrad_rtol=None, buf_tol=(2e-2, 2e-3))
+                         buf_tol=(2e-2, 2e-3), own_graph_rows=max(n_diff, 1))
 
 
 @pytest.mark.parametrize("gan,use_gp", [("ls", False), ("wgan", True)])
@@ -132,7 +140,7 @@ def test_captured_literal_loop_equals_eager_literal_loop(sp, gan, use_gp):
     """spgan.CapturedBody around the caller's loop body: 3 eager warm-up calls, one capture, replays -- parameters, BatchNorm buffers
     (incl. num_batches_tracked) and Adam state bit-identical to issuing the same body eagerly 7 times, with a fresh `data` / latent
     tensor on every call and an eager generator call (a sample dump) right before the capture."""
-    from spgan.reference_loop import reference_loop_body
+    from reference_loop import reference_loop_body
     B, N, steps = 4, 256, 7
     x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
     alpha = fr.uniform("cap.alpha", (B, 1, 1), 0.0, 1.0).cuda()

@@ -436,3 +436,19 @@ def test_oracle_at_the_benchmarked_size():
         idx2 = torch.from_numpy(d["g|idx2"].astype(np.int64)).view(B, N * 10)
         out = orc.generator_forward(gp_, x, z, training=True, buffers=None, idx2=idx2)
     check(d, "g|out", out, rtol=2e-5)
+
+
+def test_step_noise_tables_g18():
+    """Golden G18 (the reference's own float32-vs-float64 and tie-flip movements of the benchmarked step) is present, covers every
+    gradient tensor of the step golden and yields finite, monotone bounds -- the GPU step tests derive their tolerances from it."""
+    from helpers import StepNoise, golden
+    sn, step = StepNoise(), golden("g17_step_c2.npz")
+    names_d = [k[len("dgrad|"):].split("|")[0] for k in step.files if k.startswith("dgrad|")]
+    names_g = [k[len("ggrad|"):].split("|")[0] for k in step.files if k.startswith("ggrad|")]
+    assert names_d and names_g
+    for kind, names in (("dgrad", names_d), ("ggrad", names_g)):
+        for n in set(names):
+            b0, b20, b100 = sn.tensor_bound(kind, n, 0, 2.0), sn.tensor_bound(kind, n, 20, 2.0), sn.tensor_bound(kind, n, 100, 2.0)
+            assert np.isfinite([b0, b20, b100]).all() and b0 > 0 and b20 >= b0 * 0.999, (kind, n, b0, b20, b100)
+    w = [sn.whole_g_bound(n, 1.0) for n in (0, 1, 5, 20, 100)]
+    assert w[0] < 0.05 and w[0] < w[2] < w[4] < 0.5, w          # float32 noise 1.4e-2; 20 flipped ties move the whole G gradient by 0.18

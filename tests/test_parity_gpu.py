@@ -500,6 +500,40 @@ def test_gradient_penalty_loss_utils_variant(sp, mapping):
         assert e <= 5e-3 or (got.cpu() - want).abs().max().item() <= (2e-3 if n.endswith(ZERO_GRAD_BIASES) else 2e-6), (n, e)
 
 
+def test_gradient_penalty_through_eval_mode_discriminator(sp):
+    """Common/gradient_penalty.py:28-33 on a D.eval(): double backward through BatchNorm with running statistics (a fixed affine) --
+    value, parameter gradients (zero for biases and BatchNorm shifts) against torch autograd through the oracle; the reference's own
+    formula (plain torch around our Discriminator) and spgan.GradientPenalty agree."""
+    B, N = 3, 256
+    params = fr.init_params(orc.discriminator_shapes(), salt=7)
+    bufs = orc.bn_buffers(orc.discriminator_shapes())
+    for k in bufs:
+        if k.endswith("running_mean"):
+            bufs[k] = fr.normal("gpe.m." + k, bufs[k].shape, 0.05)
+        elif k.endswith("running_var"):
+            bufs[k] = fr.uniform("gpe.v." + k, bufs[k].shape, 0.5, 1.5)
+    D = _load(sp.Discriminator(Opts), {**params, **bufs}).eval()
+    real = fr.synthetic_real(B, N, seed=71).transpose(2, 1).contiguous()
+    fake = (0.8 * fr.synthetic_real(B, N, seed=72) + 0.05 * fr.normal("g7.n", (B, N, 3))).transpose(2, 1).contiguous()
+    alpha = fr.uniform("gpe.alpha", (B, 1, 1), 0.0, 1.0)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = orc.gradient_penalty(lambda x: orc.discriminator_forward(po, x, False, bufs), real, fake, alpha, 10.0, 1.0)
+    grads = torch.autograd.grad(ref, list(po.values()), allow_unused=True)
+    for impl in ("spgan", "caller"):
+        D.zero_grad(set_to_none=True)
+        if impl == "spgan":
+            gp = sp.GradientPenalty(10.0, gamma=1)(D, real.cuda(), fake.cuda(), alpha=alpha.cuda())
+        else:
+            gp = orc.gradient_penalty(D, real.cuda(), fake.cuda(), alpha.cuda(), 10.0, 1.0)
+        np.testing.assert_allclose(gp.item(), ref.item(), rtol=2e-4)
+        gp.backward()
+        for (n, p), g in zip(D.named_parameters(), grads):
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            want = g if g is not None else torch.zeros(p.shape)
+            e = rel_l2(got.cpu().numpy(), want.numpy(), "gp eval %s|%s" % (impl, n))
+            assert e <= 2e-3 or (got.cpu() - want).abs().max().item() <= 2e-6, (impl, n, e)
+
+
 # ---------------------------------------------------------------- one latent per shape, passed un-tiled
 def test_generator_per_shape_latent_matches_tiled_and_oracle(sp):
     """z handed over un-tiled [B,1,nz] (HeadFn: latent half of head.0 once per shape, coordinate half as a K = 3 product) against

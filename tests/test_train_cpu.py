@@ -154,10 +154,10 @@ def test_noisy_labels_semantics(spgan_cpu):
 
 @pytest.mark.parametrize("tag,gan,use_gp,B,N", [("ls", "ls", False, 4, 512), ("wgangp", "wgan", True, 4, 256)])
 def test_literal_reference_loop_body_golden(spgan_cpu, tag, gan, use_gp, B, N):
-    """CPU twin of tests/test_literal_loop_gpu.py: the reference's loop body statement for statement (spgan.reference_loop,
+    """CPU twin of tests/test_literal_loop_gpu.py: the reference's loop body statement for statement (examples/reference_loop.py,
     Generation/model.py:239-279) with torch.optim.Adam over the host pipelines (kernel-model doubles) against golden G8."""
     import spgan
-    from spgan.reference_loop import LoopState, reference_loop_body
+    from reference_loop import LoopState, reference_loop_body
     d = golden("g8_train_step_%s.npz" % tag)
     G = _load(spgan.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=8)).train()
     D = _load(spgan.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=8)).train()
