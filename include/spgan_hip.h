@@ -514,7 +514,7 @@ int spgan_reduce_chunks(const float* recv, int parts, size_t n, float* out, spga
  * current.  spgan_comm_available() == 0 (or status SPGAN_ECOMM) when librccl cannot be loaded; spgan_comm_last_error() is the
  * ncclResult_t of the last failing call.  The caller divides by the world size (spgan_adam_step's grad_scale). */
 int spgan_comm_available(void);
-int spgan_comm_last_error(void);
+int spgan_comm_last_error(void* comm);   /* RCCL code of the last failed call ON THIS communicator; comm == NULL: of the calling thread's last failed spgan_comm_unique_id / spgan_comm_init */
 int spgan_comm_unique_id(void* id128);
 int spgan_comm_init(const void* id128, int rank, int world, void** comm);
 int spgan_comm_world(void* comm);

@@ -7,7 +7,7 @@
 // load it), and the host language needs no RCCL binding.  Rendezvous stays with the host: rank 0 obtains the 128-byte unique id
 // (spgan_comm_unique_id) and hands it to the other ranks by whatever channel the host program has (torch.distributed's store / a
 // broadcast; MPI; a file), then every rank calls spgan_comm_init.  Errors come back as status codes (SPGAN_ECOMM = RCCL missing or
-// an RCCL call failed; spgan_comm_last_error gives the RCCL code); nothing here synchronises the device.
+// an RCCL call failed; spgan_comm_last_error(comm) gives the RCCL code of that communicator's last failure); nothing here synchronises the device.
 #include <dlfcn.h>
 #include <string.h>
 
@@ -29,7 +29,13 @@ struct Api {
   bool ok = false;
 };
 
-int g_last_error = 0;
+// No process-global mutable state: the RCCL code of a failed call is kept IN the communicator it failed on; failures
+// before a communicator exists (unique id, init) are kept per calling thread.
+struct Handle {
+  Comm c = nullptr;
+  int last_error = 0;
+};
+thread_local int t_last_error = 0;
 
 Api& api() {
   static Api a = [] {
@@ -51,16 +57,17 @@ Api& api() {
   return a;
 }
 
-inline int rc(int nccl_result) {
+inline int rc(int nccl_result, Handle* h = nullptr) {
   if (nccl_result == 0) return SPGAN_OK;
-  g_last_error = nccl_result;
+  if (h) h->last_error = nccl_result;
+  else t_last_error = nccl_result;
   return SPGAN_ECOMM;
 }
 
 }  // namespace
 
 extern "C" int spgan_comm_available(void) { return api().ok ? 1 : 0; }
-extern "C" int spgan_comm_last_error(void) { return g_last_error; }
+extern "C" int spgan_comm_last_error(void* comm) { return comm ? static_cast<Handle*>(comm)->last_error : t_last_error; }
 
 extern "C" int spgan_comm_unique_id(void* id128) {
   SPGAN_CHECK_ARG(id128);
@@ -78,25 +85,33 @@ extern "C" int spgan_comm_init(const void* id128, int rank, int world, void** co
   memcpy(id.internal, id128, sizeof(id.internal));
   Comm c = nullptr;
   const int r = rc(api().CommInitRank(&c, world, id, rank));   // binds to the calling thread's current HIP device
-  if (r == SPGAN_OK) *comm = c;
+  if (r == SPGAN_OK) {
+    Handle* h = new Handle;
+    h->c = c;
+    *comm = h;
+  }
   return r;
 }
 
 extern "C" int spgan_comm_world(void* comm) {
   if (!comm || !api().ok || !api().CommCount) return -1;
   int n = -1;
-  return api().CommCount(comm, &n) == 0 ? n : -1;
+  return api().CommCount(static_cast<Handle*>(comm)->c, &n) == 0 ? n : -1;
 }
 
 extern "C" int spgan_allreduce_flat(void* comm, float* buf, size_t n, spgan_stream_t s) {
   SPGAN_CHECK_ARG(comm && buf);
   if (n == 0) return SPGAN_OK;
   if (!api().ok) return SPGAN_ECOMM;
-  return rc(api().AllReduce(buf, buf, n, kFloat32, kSum, comm, (hipStream_t)s));   // in place, sum; the caller scales (Adam's grad_scale)
+  Handle* h = static_cast<Handle*>(comm);
+  return rc(api().AllReduce(buf, buf, n, kFloat32, kSum, h->c, (hipStream_t)s), h);   // in place, sum; the caller scales (Adam's grad_scale)
 }
 
 extern "C" int spgan_comm_destroy(void* comm) {
   if (!comm) return SPGAN_OK;
   if (!api().ok) return SPGAN_ECOMM;
-  return rc(api().CommDestroy(comm));
+  Handle* h = static_cast<Handle*>(comm);
+  const int r = rc(api().CommDestroy(h->c));
+  delete h;
+  return r;
 }

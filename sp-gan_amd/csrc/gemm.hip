@@ -1218,8 +1218,7 @@ __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const spgan_gemm_nt_arg
 
 // which problems the streaming kernel takes (nothing on the host mirrors this: neither results nor layouts depend on it)
 inline bool nt_skinny_on(const spgan_gemm_nt_args& a) {
-  static const bool off = getenv("SPGAN_NT_SKINNY") && atoi(getenv("SPGAN_NT_SKINNY")) == 0;
-  return !off && a.tile_hint != 1 && a.M > 64 && a.batch <= 1 && !a.tail.enabled && !a.pool_val && !a.sp_val && !a.A2 && !a.a_half && !a.y_bf16 && !a.y_half;
+  return a.tile_hint != 1 && a.M > 64 && a.batch <= 1 && !a.tail.enabled && !a.pool_val && !a.sp_val && !a.A2 && !a.a_half && !a.y_bf16 && !a.y_half;
 }
 inline bool nt_k4_ok(const spgan_gemm_nt_args& a) {
   if (!nt_skinny_on(a) || a.K > 4 || a.a_mode != SPGAN_A_PLAIN || a.N % 4 || a.N < 8 || a.N > 512) return false;

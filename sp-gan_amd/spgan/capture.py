@@ -18,7 +18,11 @@ captured, all later ones replay.  Contract for the function (the usual stream-ca
   * wrap the body from its FIRST iteration: do not run the same modules' backward eagerly on another stream beforehand (autograd
     binds the gradient-accumulation nodes of the parameters to the stream that first used them).
 What the wrapper takes care of: input staging (an argument that is the same tensor object at the same version as on the previous
-call -- the constant sphere prior -- is adopted without a copy, so the Generator keeps its cached neighbour graph), the host-side
+call -- the constant sphere prior -- is adopted without a copy, so the Generator keeps its cached neighbour graph; an argument the
+modules derived cached graph structure from -- that prior's kNN graph, its CSR, the "every shape carries the same prior" decision, none
+of which is re-derived inside the captured graph -- is compared by CONTENT when its object or version changes: on a difference the
+graph is dropped, one call runs eagerly (the caches are rebuilt) and the next one is captured again; a prior that keeps changing,
+sphere_generator(static=False), ends in eager issue with a warning after a few re-captures), the host-side
 BatchNorm call counters of the spgan modules (replayed per call), the weight-derived host caches (dropped before the capture
 so that their kernels are recorded; invalidated after every replay because the captured optimiser kernels changed the weights
 behind torch's version counters).  A failed capture falls back to eager issue with a warning.
@@ -55,16 +59,32 @@ class CapturedBody:
         self._bn_delta = None
         self._side = None
         self.eager = False
+        self._struct = set()         # positions of arguments the modules hold cached graph structure for (the sphere prior)
+        self._recaptures = 0
 
     # ------------------------------------------------------------------ inputs
-    def _bind(self, args):
+    def _structure_args(self):
+        """Static buffers some module keeps cached graph structure for (Generator._sphere_graphs: kNN graph / CSR / dedup decision of the
+        prior, keyed by tensor object and version)."""
+        held = []
+        for net in self.modules:
+            for sub in net.modules():
+                for e in sub.__dict__.get("_sphere_graphs", ()):
+                    t = e["ref"]()
+                    if t is not None:
+                        held.append(t)
+        return {i for i, st in enumerate(self._static or ()) if any(st is t for t in held)}
+
+    def _bind(self, args) -> bool:
+        """Stage the arguments; returns True when an argument that feeds cached graph structure changed its CONTENT under a captured graph."""
         if self._static is None:
             self._static = [a.detach().clone() for a in args]
             self._src = [(weakref.ref(a), a._version) for a in args]
-            return
+            return False
         if len(args) != len(self._static):
             raise ValueError("CapturedBody: %d arguments, captured with %d" % (len(args), len(self._static)))
         dst, src = [], []
+        structure_changed = False
         for i, (a, st) in enumerate(zip(args, self._static)):
             if a.shape != st.shape or a.dtype != st.dtype:
                 raise ValueError("CapturedBody needs static shapes/dtypes: argument %d is %s %s, captured %s %s"
@@ -73,12 +93,21 @@ class CapturedBody:
             if ref() is a and ver == a._version:
                 continue                                   # same object, unmodified: the static copy is current
             self._src[i] = (weakref.ref(a), a._version)
+            if i in self._struct:
+                # the modules cached structure derived from this buffer and the captured graph does not re-derive it: compare on the
+                # device (one host sync, off the steady-state path); a real change goes through torch's copy_, whose version bump
+                # invalidates the modules' cache entries
+                if self._graph is None or not bool(torch.equal(st, a)):
+                    structure_changed = self._graph is not None
+                    st.copy_(a)
+                continue
             if a.is_cuda and a.is_contiguous() and a.dtype == torch.float32:
                 dst.append(st); src.append(a)
             else:
                 st.copy_(a)
         if dst:
             ops.multi_copy(dst, src)
+        return structure_changed
 
     # ------------------------------------------------------------------ call
     def _invalidate_weight_caches(self):
@@ -96,7 +125,18 @@ class CapturedBody:
                 raise TypeError("CapturedBody takes CUDA tensors as positional arguments")
         if self.eager:
             return self.fn(*args)
-        self._bind(args)
+        if self._bind(args):
+            # The prior changed after the capture: the captured kernels hold the OLD prior's kNN graph, CSR and dedup decision (the
+            # modules cache them per tensor and version, so the capture contains no kNN launch).  Drop the graph, run this call
+            # eagerly (rebuilds the caches) and capture again on the next one.
+            self._graph = None
+            self._recaptures += 1
+            if self._recaptures > 3:
+                warnings.warn("CapturedBody: an argument the modules derive cached graph structure from (the sphere prior) keeps changing "
+                              "between calls; the captured graph depends on it, so the body is issued eagerly from now on")
+                self.eager = True
+                return self.fn(*args)
+            self._calls = max(self.warmup - 1, 0)
         if self._graph is None and self._calls < self.warmup:
             if self._side is None:
                 self._side = torch.cuda.Stream()
@@ -105,6 +145,7 @@ class CapturedBody:
                 out = self.fn(*self._static)
             torch.cuda.current_stream().wait_stream(self._side)
             self._calls += 1
+            self._struct = self._structure_args()
             return out
         mods = _bn_modules(self.modules)
         if self._graph is None:
@@ -143,6 +184,7 @@ class CapturedBody:
                     for k, n in pend.items():
                         store[pre][k] -= n
             self._graph = g
+            self._struct = self._structure_args()
         self._graph.replay()
         self._invalidate_weight_caches()
         for m, d in zip(mods, self._bn_delta):

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import threading
+
 import torch
 from torch.autograd import Function
 
@@ -18,18 +20,32 @@ Tensor = torch.Tensor
 
 
 _HAS_ENGINE_QUERY = hasattr(torch._C, "_will_engine_execute_node")     # private API (present in torch 1.13 .. 2.10); guarded, see below
-_INPUT_GRAD_ONLY = [0]       # > 0 while spgan.losses.GradientPenalty runs its autograd.grad(D(x_hat), x_hat, create_graph=True)
+# No process-global mutable flags: the two caller-selected backward modes below are THREAD-LOCAL on the thread that runs the
+# forward pass, and every Function records them in its own ctx when its forward runs.  The backward of that node (which autograd executes
+# on its device thread, not on the caller's) reads the record of ITS graph -- two threads driving two model pairs, or one thread
+# interleaving a fused and a plain backward, cannot see each other's modes.
+_TLS = threading.local()
 
 
-class input_grad_only:
-    """Context: the backward passes started inside it want input gradients only (no parameter gradients).  spgan's own
-    GradientPenalty says so explicitly, which makes the WGAN-GP route independent of the private engine query below."""
+def _mode(name: str) -> bool:
+    return getattr(_TLS, name, 0) > 0
+
+
+class _Mode:
+    name = ""
 
     def __enter__(self):
-        _INPUT_GRAD_ONLY[0] += 1
+        setattr(_TLS, self.name, getattr(_TLS, self.name, 0) + 1)
 
     def __exit__(self, *exc):
-        _INPUT_GRAD_ONLY[0] -= 1
+        setattr(_TLS, self.name, getattr(_TLS, self.name, 0) - 1)
+
+
+class input_grad_only(_Mode):
+    """Context: Discriminator forwards evaluated inside it build nodes whose backward delivers INPUT gradients only (no parameter
+    gradients) -- spgan.losses.GradientPenalty wraps `D(x_hat)` and its `autograd.grad(..., create_graph=True)` in it, which makes the
+    WGAN-GP route independent of the private engine query below."""
+    name = "input_only"
 
 
 def _engine_needs(ctx, pos: int, tpos: int) -> bool:
@@ -54,30 +70,31 @@ def _engine_needs(ctx, pos: int, tpos: int) -> bool:
 
 # Parameter gradients are handed back to autograd (AccumulateGrad, hooks, torch.autograd.grad all behave as usual) unless the
 # caller opted into the fused route with `fused_grad_accumulation()` -- spgan.TrainStep does, around its two backward() calls.
-_FUSED = [0]
+class fused_grad_accumulation(_Mode):
+    """Context: the nodes of forward passes evaluated inside it add their parameter gradients straight into the pre-bound flat `.grad`
+    buffers (spgan.optim.flatten_module) with one fused launch per Function and return None to autograd.  Only for callers that read
+    gradients from `.grad` afterwards and use no parameter hooks (TrainStep wraps its segments in it, CapturedBody the caller's body on
+    request); everything else gets normal autograd semantics."""
+    name = "fused"
 
 
-class fused_grad_accumulation:
-    """Context: backward passes started inside add parameter gradients straight into the pre-bound flat `.grad` buffers
-    (spgan.optim.flatten_module) with one fused launch per Function and return None to autograd.  Only for callers that read
-    gradients from `.grad` afterwards and use no parameter hooks (TrainStep); everything else gets normal autograd semantics."""
-
-    def __enter__(self):
-        _FUSED[0] += 1
-
-    def __exit__(self, *exc):
-        _FUSED[0] -= 1
+def _record_modes(ctx, holder=None) -> None:
+    """Called in every Function.forward (on the caller's thread): remember the backward modes selected for this graph."""
+    ctx.fused = _mode("fused")
+    ctx.input_only = _mode("input_only")
+    if holder is not None:                       # nodes created later INSIDE this node's backward (the double-backward node) inherit them
+        holder.fused, holder.input_only = ctx.fused, ctx.input_only
 
 
-def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool]):
-    """Hand parameter gradients back to autograd -- or, inside `fused_grad_accumulation()`, for every wanted leaf parameter that
+def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool], fused: bool = False):
+    """Hand parameter gradients back to autograd -- or, for a graph built inside `fused_grad_accumulation()` (`fused`), for every wanted leaf parameter that
     already owns a contiguous `.grad` (the flat buffer of spgan.optim.flatten_module) while no graph is being recorded, add them
     into `.grad` with ONE fused launch (spgan_multi_add) and return None: the same sums AccumulateGrad would form with one
     elementwise launch per parameter tensor (and on the launch stream, which keeps the step capturable as a hipGraph).  Non-leaf
     "parameters" (the scaled weights of equalised-LR layers) get their gradient returned.  Exact-zero gradients (nets.ZERO_GRAD)
     cost nothing on the fused path."""
     ops.flush_tn()                     # weight gradients whose split-K sums were deferred (ops.gemm_tn(defer=True)) become valid here
-    fused = _FUSED[0] > 0 and not torch.is_grad_enabled()
+    fused = fused and not torch.is_grad_enabled()
     out: List[Optional[Tensor]] = [None] * len(params)
     pairs = []
     for i, (p, g, need) in enumerate(zip(params, grads, needs)):
@@ -134,6 +151,7 @@ class DiscriminatorFn(Function):
 
     @staticmethod
     def forward(ctx, holder, x, *params):
+        _record_modes(ctx, holder)
         P = dict(zip(holder.names, params))
         pre = getattr(holder, "pre", None)
         if pre is not None:
@@ -150,7 +168,7 @@ class DiscriminatorFn(Function):
     def backward(ctx, dout):
         x, *params = ctx.saved_tensors
         names = ctx.holder.names
-        if _INPUT_GRAD_ONLY[0] > 0:
+        if ctx.input_only:
             need_dx, need_dp = bool(ctx.needs_input_grad[1]), False
         else:
             need_dx = _engine_needs(ctx, 1, 0)
@@ -163,7 +181,7 @@ class DiscriminatorFn(Function):
         dx, grads, _ = nets.d_backward(P, ctx.dctx, dout.detach(), need_dx, need_dp, False)
         if grads is None:
             return (None, dx) + (None,) * len(params)
-        return (None, dx) + _deliver(params, [grads[n] for n in names], ctx.needs_input_grad[2:])
+        return (None, dx) + _deliver(params, [grads[n] for n in names], ctx.needs_input_grad[2:], ctx.fused)
 
 
 class DStackFn(Function):
@@ -172,6 +190,7 @@ class DStackFn(Function):
 
     @staticmethod
     def forward(ctx, holder, x, *params):
+        _record_modes(ctx, holder)
         P = dict(zip(holder.names, params))
         pre = getattr(holder, "pre", None)
         if pre is not None:
@@ -191,7 +210,7 @@ class DStackFn(Function):
         dx, grads, _ = nets.d_backward(P, ctx.dctx, None, ctx.needs_input_grad[1], need_dp, False, gpool=gpool.detach())
         if grads is None:
             return (None, dx) + (None,) * len(params)
-        return (None, dx) + _deliver(params, [grads.get(n) for n in names], ctx.needs_input_grad[2:])
+        return (None, dx) + _deliver(params, [grads.get(n) for n in names], ctx.needs_input_grad[2:], ctx.fused)
 
 
 class DHeadFn(Function):
@@ -199,6 +218,7 @@ class DHeadFn(Function):
 
     @staticmethod
     def forward(ctx, holder, pooled, *params):
+        _record_modes(ctx, holder)
         P = dict(zip(holder.names, params))
         pooled = pooled.contiguous()
         logits, hs = nets.d_head_forward(P, pooled)
@@ -226,7 +246,7 @@ class DHeadFn(Function):
         gp = gpool if ctx.needs_input_grad[1] else None
         if not need_dp:
             return (None, gp) + (None,) * len(params)
-        return (None, gp) + _deliver(params, [grads.get(n) for n in names], ctx.needs_input_grad[2:])
+        return (None, gp) + _deliver(params, [grads.get(n) for n in names], ctx.needs_input_grad[2:], ctx.fused)
 
 
 class DiscriminatorBackwardFn(Function):
@@ -234,6 +254,7 @@ class DiscriminatorBackwardFn(Function):
 
     @staticmethod
     def forward(ctx, holder, dctx, dout, x, *params):
+        ctx.fused, ctx.input_only = getattr(holder, "fused", False), False      # created inside DiscriminatorFn.backward (engine thread): modes inherited from that graph
         P = dict(zip(holder.names, params))
         dx, _, saved = nets.d_backward(P, dctx, dout, True, False, keep_for_double=True)
         ctx.holder, ctx.dctx, ctx.saved = holder, dctx, saved
@@ -249,7 +270,7 @@ class DiscriminatorBackwardFn(Function):
         dbl = nets.d_double_backward if ctx.dctx["training"] else nets.d_double_backward_eval      # eval(): BatchNorm is a fixed affine
         grads, dx2 = dbl(P, ctx.dctx, ctx.saved, v.detach(), need_dx=need_x)
         # (holder, dctx, dout, x, *params); the gradient w.r.t. dout is not provided (constant ones in WGAN-GP)
-        return (None, None, None, dx2) + _deliver(params, [grads[n] for n in names], ctx.needs_input_grad[4:])
+        return (None, None, None, dx2) + _deliver(params, [grads[n] for n in names], ctx.needs_input_grad[4:], ctx.fused)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -260,6 +281,7 @@ class EdgeBlockFn(Function):
 
     @staticmethod
     def forward(ctx, holder, x, *params):
+        _record_modes(ctx, holder)
         P = dict(zip(holder.names, params))
         x = x.contiguous()
         reuse = getattr(holder, "reuse", None)
@@ -293,7 +315,7 @@ class EdgeBlockFn(Function):
             if cache is not None:
                 cache["csr"] = csr
         dx, g = nets.edgeblock_backward(P, h.prefix, ctx.ectx, dout, csr, need_dx=ctx.needs_input_grad[1])
-        return (None, dx) + _deliver(params, [g[n] for n in h.names], ctx.needs_input_grad[2:])
+        return (None, dx) + _deliver(params, [g[n] for n in h.names], ctx.needs_input_grad[2:], ctx.fused)
 
 
 class EdgeFeaturesFn(Function):
@@ -332,6 +354,7 @@ class AdaINFn(Function):
 
     @staticmethod
     def forward(ctx, holder, x, style, w, b):
+        _record_modes(ctx, holder)
         P = {holder.prefix + ".style.weight": w, holder.prefix + ".style.bias": b}
         out, actx = nets.adain_forward(P, holder.prefix, x.contiguous(), style.contiguous(), holder.N, holder.slope)
         ctx.holder, ctx.actx = holder, actx
@@ -345,7 +368,7 @@ class AdaINFn(Function):
         P = {pre + ".style.weight": nets.owned(w), pre + ".style.bias": nets.owned(b)}
         need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         dx, ds, g = nets.adain_backward(P, pre, ctx.actx, dout, ctx.needs_input_grad[1], ctx.needs_input_grad[2], need_p)
-        return (None, dx, ds) + _deliver((w, b), [g.get(pre + ".style.weight"), g.get(pre + ".style.bias")], ctx.needs_input_grad[3:])
+        return (None, dx, ds) + _deliver((w, b), [g.get(pre + ".style.weight"), g.get(pre + ".style.bias")], ctx.needs_input_grad[3:], ctx.fused)
 
 
 class MLPFn(Function):
@@ -353,6 +376,7 @@ class MLPFn(Function):
 
     @staticmethod
     def forward(ctx, holder, x, *params):
+        _record_modes(ctx, holder)
         P = {}
         for i, n in enumerate(holder.names):
             P[n + ".weight"], P[n + ".bias"] = params[2 * i], params[2 * i + 1]
@@ -374,7 +398,7 @@ class MLPFn(Function):
         for n in h.names:
             out.append(g.get(n + ".weight"))
             out.append(g.get(n + ".bias"))
-        return (None, dx) + _deliver(params, out, ctx.needs_input_grad[2:])
+        return (None, dx) + _deliver(params, out, ctx.needs_input_grad[2:], ctx.fused)
 
 
 class ScaleFn(Function):
@@ -382,6 +406,7 @@ class ScaleFn(Function):
 
     @staticmethod
     def forward(ctx, w, c):
+        _record_modes(ctx)
         ctx.c = c
         ctx.save_for_backward(w)
         return ops.axpby(c, w.contiguous(), 0.0, torch.empty_like(w, memory_format=torch.contiguous_format))
@@ -390,7 +415,7 @@ class ScaleFn(Function):
     def backward(ctx, g):
         (w,) = ctx.saved_tensors
         gw = ops.axpby(ctx.c, g.contiguous(), 0.0, torch.empty_like(g, memory_format=torch.contiguous_format))
-        return _deliver((w,), [gw], ctx.needs_input_grad[:1]) + (None,)
+        return _deliver((w,), [gw], ctx.needs_input_grad[:1], ctx.fused) + (None,)
 
 
 class HeadFn(Function):
@@ -401,6 +426,7 @@ class HeadFn(Function):
 
     @staticmethod
     def forward(ctx, holder, x_pm, zb, w0, b0, w2, b2):
+        _record_modes(ctx, holder)
         W0 = nets._w2(w0)
         c = x_pm.shape[1]
         rb = ops.gemm_nt(zb.contiguous(), W0[:, c:], b0)                               # [B,128]
@@ -426,7 +452,7 @@ class HeadFn(Function):
             gz = ops.gemm_tn(drb, zb.contiguous())                                       # [128, nz]
             ops.flush_tn()
             grads = [torch.cat([g["head.0.weight.part"], gz], dim=1).view_as(w0), ops.colsum(drb)[0], g["head.2.weight"], g["head.2.bias"]]
-        return (None, dx, dz) + _deliver(params, grads, ctx.needs_input_grad[3:])
+        return (None, dx, dz) + _deliver(params, grads, ctx.needs_input_grad[3:], ctx.fused)
 
 
 GF_NAMES = ("global_conv.0.weight", "global_conv.0.bias", "global_conv.1.weight", "global_conv.1.bias",
@@ -439,6 +465,7 @@ class GlobalFeatFn(Function):
 
     @staticmethod
     def forward(ctx, holder, a2, *params):
+        _record_modes(ctx, holder)
         P = dict(zip(GF_NAMES, params))
         feat, gctx = nets.global_feat_forward(P, holder.buffers, a2.contiguous(), holder.B, holder.N, holder.training, True)
         ctx.gctx = gctx
@@ -450,7 +477,7 @@ class GlobalFeatFn(Function):
         params = ctx.saved_tensors
         P = dict(zip(GF_NAMES, [nets.owned(p) for p in params]))
         da2, g = nets.global_feat_backward(P, ctx.gctx, dfeat.contiguous())
-        return (None, da2 if ctx.needs_input_grad[1] else None) + _deliver(params, [g[n] for n in GF_NAMES], ctx.needs_input_grad[2:])
+        return (None, da2 if ctx.needs_input_grad[1] else None) + _deliver(params, [g[n] for n in GF_NAMES], ctx.needs_input_grad[2:], ctx.fused)
 
 
 ATTN_NAMES = ("attn.theta.weight", "attn.phi.weight", "attn.g.weight", "attn.o.weight", "attn.gamma")
@@ -462,6 +489,7 @@ class AttentionFn(Function):
 
     @staticmethod
     def forward(ctx, holder, x, *params):
+        _record_modes(ctx, holder)
         P = dict(zip(ATTN_NAMES, params))
         y, actx = nets.attention_forward(P, "attn", x.contiguous(), holder.B, holder.N)
         ctx.actx = actx
@@ -473,7 +501,7 @@ class AttentionFn(Function):
         params = ctx.saved_tensors
         P = dict(zip(ATTN_NAMES, [nets.owned(p) for p in params]))
         dx, g = nets.attention_backward(P, "attn", ctx.actx, dy, ctx.needs_input_grad[1])
-        return (None, dx) + _deliver(params, [g[n] for n in ATTN_NAMES], ctx.needs_input_grad[2:])
+        return (None, dx) + _deliver(params, [g[n] for n in ATTN_NAMES], ctx.needs_input_grad[2:], ctx.fused)
 
 
 GT_NAMES = ("global_conv.0.weight", "global_conv.0.bias", "global_conv.1.weight", "global_conv.1.bias",
@@ -487,6 +515,7 @@ class GlobalTailFn(Function):
 
     @staticmethod
     def forward(ctx, holder, a2, *params):
+        _record_modes(ctx, holder)
         P = dict(zip(GT_NAMES, params))
         a2 = a2.contiguous()
         B, N = holder.B, holder.N
@@ -512,4 +541,4 @@ class GlobalTailFn(Function):
         g.update({k: v for k, v in gg.items() if k != "tail.0.weight.global"})
         ops.flush_tn()                 # the per-point half of tail.0's weight gradient was deferred
         g["tail.0.weight"] = torch.cat([gg["tail.0.weight.global"], g.pop("tail.0.weight.part")], dim=1).view_as(P["tail.0.weight"])
-        return (None, da2 if ctx.needs_input_grad[1] else None) + _deliver(params, [g[n] for n in GT_NAMES], ctx.needs_input_grad[2:])
+        return (None, da2 if ctx.needs_input_grad[1] else None) + _deliver(params, [g[n] for n in GT_NAMES], ctx.needs_input_grad[2:], ctx.fused)

@@ -207,8 +207,8 @@ class GradientPenalty:
         if interpolates is None:
             interpolates = self.interpolate(real_data, fake_data, alpha, mapping)
         interpolates = interpolates.requires_grad_(True)
-        disc = netD(interpolates) if pre is None else netD(interpolates, pre=pre)
-        with input_grad_only():          # explicit: this backward wants d disc / d x_hat only, as a differentiable node
+        with input_grad_only():          # explicit: the node this forward builds delivers d disc / d x_hat only, as a differentiable node
+            disc = netD(interpolates) if pre is None else netD(interpolates, pre=pre)
             grads = torch.autograd.grad(outputs=disc, inputs=interpolates, grad_outputs=_ones_like(disc),
                                         create_graph=True, retain_graph=True, only_inputs=True)[0]
         return grads

@@ -10,8 +10,6 @@ formulas in the WGAN-GP double backward.
 """
 from __future__ import annotations
 
-import os
-
 import weakref
 from typing import Dict, List, Optional, Tuple
 
@@ -107,7 +105,7 @@ def _refresh_transposes(trigger: Tensor) -> None:
             _T_CACHE[key] = (cur, t, oref, view)
 
 
-LAZY_BN_BWD = [os.environ.get("SPGAN_LAZY_BN_BWD", "1") != "0"]     # 0: materialise every BatchNorm-backward tensor (A/B measurements)
+LAZY_BN_BWD = [True]     # test hook: False materialises every BatchNorm-backward tensor (tests/test_kernels2_gpu.py compares the two forms; A/B-measured in round 3)
 
 
 def _lazy_ok(rows: int, channels: int) -> bool:

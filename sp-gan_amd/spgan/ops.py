@@ -756,7 +756,7 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     a.a_half = 1 if a16 else 0
     splits = lib.spgan_gemm_tn_splits(M_, Na, Nb)
     cs_out = cs_ws = None
-    streaming = (Na <= 4 or Nb <= 4) and Na <= 2048 and Nb <= 2048 and pro is None and edge is None and sa is None and a_pro is None   # 3-column layers: the streaming kernel + a colsum pass stay cheaper
+    streaming = (Na <= 4 or Nb <= 4) and Na <= 2048 and Nb <= 2048 and pro is None and edge is None and sa is None and a_pro is None and (a2 is None or Nb <= 4)   # 3-column layers: the streaming kernel + a colsum pass stay cheaper (mirrors launch_tn: a narrow-A two-tensor operand runs on the MFMA kernel)
     if with_colsum and sa is not None:
         raise NotImplementedError("gemm_tn(with_colsum=True) with a SparseAffine operand")
     if with_colsum and not streaming:
@@ -771,8 +771,8 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
         _PENDING_TN.append((ws, out, splits, Na, Nb, _ld(out), float(beta)))
     if not with_colsum:
         return out
-    if cs_ws is None:                       # the streaming kernels have no such by-product: the separate reduction
-        return out, colsum(A)[0]
+    if cs_ws is None:                       # the streaming kernels have no such by-product: the separate reduction (of the TRANSFORMED operand)
+        return out, colsum(a2.dense() if a2 is not None else A)[0]
     _PENDING_TN.append((cs_ws, cs_out, splits, 1, Na, Na, 0.0))           # [splits][1 x Na] partials: one more entry of the multi-reduce
     if not defer:
         flush_tn()

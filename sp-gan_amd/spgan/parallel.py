@@ -18,6 +18,11 @@ import torch.nn as nn
 from .optim import flatten_module
 
 
+def ops_capturing() -> bool:
+    from . import ops
+    return ops.capturing()
+
+
 def init_process_group_from_env(backend: Optional[str] = None) -> int:
     """torchrun-style rendezvous (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  'nccl' is RCCL on ROCm."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -58,7 +63,9 @@ class DataParallel(nn.Module):
         if self.collective not in ("all_reduce", "one_hop", "rccl"):
             raise ValueError("collective must be 'all_reduce', 'one_hop' or 'rccl'")
         self._hop = None             # (send [W, chunk], recv [W, chunk], mine [chunk], full [W*chunk]) staging buffers of the one-hop path
-        self._comm = None            # native RCCL communicator of the "rccl" path (lazy)
+        self._comm = None            # native RCCL communicator of the "rccl" path
+        if self.collective == "rccl" and dist.is_initialized() and self.flat.flat.is_cuda:
+            self.native_comm()       # created eagerly: its rendezvous (a broadcast + a host copy) must not first happen inside a stream capture
 
     @property
     def world_size(self) -> int:
@@ -69,9 +76,10 @@ class DataParallel(nn.Module):
 
     def sync_params(self):
         if self.world_size > 1:
-            dist.broadcast(self.flat.flat, src=0, group=self.pg)
+            src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0     # the group's first member (a sub-group's need not be global rank 0)
+            dist.broadcast(self.flat.flat, src=src, group=self.pg)
             for b in self.module.buffers():
-                dist.broadcast(b, src=0, group=self.pg)
+                dist.broadcast(b, src=src, group=self.pg)
 
     def allreduce_grads(self) -> float:
         """Sum gradients over ranks in place; returns the scale (1/world) the optimiser must apply."""
@@ -115,24 +123,37 @@ class DataParallel(nn.Module):
             raise RuntimeError("collective='rccl': librccl could not be loaded by libspgan_hip.so")
         rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
         w = self.world_size
+        if ops_capturing():
+            raise RuntimeError("collective='rccl': the communicator must exist before a stream capture starts (DataParallel creates it in "
+                               "__init__ when the parameters are on a GPU; call native_comm() once before capturing otherwise)")
         buf = (C.c_ubyte * 128)()
+        status = 0
         if rank == 0:
-            _lib.check(lib.spgan_comm_unique_id(buf), "comm_unique_id")
-        ident = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+            status = int(lib.spgan_comm_unique_id(buf))       # a failure here must reach every rank: the others wait in the broadcast
+        # 128 id bytes + rank 0's status, carried by the process group's first member (a sub-group's rank 0 need not be global rank 0)
+        ident = torch.tensor(list(bytes(buf)) + [status & 0xFF], dtype=torch.uint8, device=dev)
         if w > 1:
-            dist.broadcast(ident, src=0, group=self.pg)
-        raw = (C.c_ubyte * 128)(*ident.cpu().tolist())
+            src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+            dist.broadcast(ident, src=src, group=self.pg)
+        host = ident.cpu().tolist()
+        if host[128] != 0:
+            raise RuntimeError("collective='rccl': spgan_comm_unique_id failed on the group's first rank (status byte %d, RCCL code %d on that "
+                               "rank's thread)" % (host[128], lib.spgan_comm_last_error(None) if rank == 0 else -1))
+        raw = (C.c_ubyte * 128)(*host[:128])
         comm = C.c_void_p()
         with torch.cuda.device(dev):
-            _lib.check(lib.spgan_comm_init(raw, rank, w, C.byref(comm)), "comm_init", rank=rank, world=w, rccl_error=lib.spgan_comm_last_error())
+            _lib.check(lib.spgan_comm_init(raw, rank, w, C.byref(comm)), "comm_init", rank=rank, world=w, rccl_error=lib.spgan_comm_last_error(None))
         self._comm = comm
         return comm
 
     def _allreduce_native(self) -> None:
         from . import _lib
         g = self.flat.grad
-        _lib.check(_lib.load().spgan_allreduce_flat(self.native_comm(), g.data_ptr(), g.numel(), torch.cuda.current_stream().cuda_stream),
-                   "allreduce_flat", n=g.numel())
+        comm = self.native_comm()
+        lib = _lib.load()
+        st = lib.spgan_allreduce_flat(comm, g.data_ptr(), g.numel(), torch.cuda.current_stream().cuda_stream)
+        if st != 0:
+            _lib.check(st, "allreduce_flat", n=g.numel(), rccl_error=lib.spgan_comm_last_error(comm))
 
     def __del__(self):
         comm = self.__dict__.get("_comm")          # plain dict access: nn.Module.__setattr__ / __getattr__ are not usable at interpreter shutdown

@@ -70,10 +70,10 @@ class TrainStep:
         # finalize launch per layer for all three, per-pass BatchNorm statistics (Discriminator.forward_stacks_grouped; bit-identical to
         # the separate calls, running statistics advanced in the reference's order real, fake, x_hat).  The backward passes run per
         # pass as before, on views of the batched activations.
-        self.batch_d_forwards = not reference_schedule and hasattr(D, "forward_stacks_grouped") and os.environ.get("SPGAN_BATCH_D", "1") != "0"
+        self.batch_d_forwards = not reference_schedule and hasattr(D, "forward_stacks_grouped")      # attribute = test hook (the separate-calls side was measured in rounds 2 and 3)
         # The generator's two forwards of a step (D step, G step) see the same sphere prior and the same weights: EdgeConv1, which
         # depends on nothing else, is evaluated once and its BatchNorm running statistics are advanced twice (Generator.twin_forward).
-        self.twin_g_forwards = not reference_schedule and os.environ.get("SPGAN_TWIN_G", "1") != "0"
+        self.twin_g_forwards = not reference_schedule      # attribute = test hook
         # Data parallel: the generator's forward of the G step does not depend on D's update, so it is issued while D's gradient
         # all-reduce is in flight (SPGAN_DP_OVERLAP=0: the strictly sequential schedule, for A/B measurements on a node).
         self.overlap_g_forward = distributed and os.environ.get("SPGAN_DP_OVERLAP", "1") != "0"
@@ -206,6 +206,10 @@ class TrainStep:
                     self.optG.dev_state[:1].view(torch.int32).fill_(tG); self.optD.dev_state[:1].view(torch.int32).fill_(tD)
                 self.use_graph = False
                 torch.cuda.synchronize()
+                # cache entries created during the aborted capture carry current stamps but live in the aborted graph's pool and were
+                # never written: the eager fallback must re-derive them
+                nets.drop_weight_caches()
+                self.G.__dict__["_ec1_twin"] = None
                 return self._eager_step(*self._static)
             after = self._bn_snapshot()
             # nothing ran during the capture: take the host-side bookkeeping of that step back, keep it as the per-replay delta
@@ -252,6 +256,10 @@ class TrainStep:
     # The iteration in three segments, split where the data-parallel all-reduces sit (they stay outside the captured graphs).
     def _seg_d(self, x, real, z_d, alpha, keep_grads, info):
         """D step up to lossD.backward() (model.py:240-258)."""
+        with fused_grad_accumulation():      # the nodes built here add their parameter gradients straight into the flat .grad buffers
+            return self._seg_d_body(x, real, z_d, alpha, keep_grads, info)
+
+    def _seg_d_body(self, x, real, z_d, alpha, keep_grads, info):
         G, D = self.G, self.D
         B, N, _ = real.shape
         requires_grad(G, False); requires_grad(D, True)
@@ -286,8 +294,7 @@ class TrainStep:
             pen, gx, v = self.gp.with_grads(D, real_t, fake, alpha=alpha, interpolates=x_hat, pre=pre_hat)
             roots.append(gx); seeds.append(v)
             loss_d = loss_d + pen[0]
-        with fused_grad_accumulation():
-            torch.autograd.backward(roots, seeds)
+        torch.autograd.backward(roots, seeds)
         if keep_grads:
             info["fake_d"] = fake
         info.update(loss_d=loss_d.detach(), real_acc=out5[3], fake_acc=out5[4])
@@ -303,13 +310,18 @@ class TrainStep:
         self.optG.zero_grad()
         G.twin_forward = "second" if self.twin_g_forwards else None
         try:
-            return G(x, z_g)
+            with fused_grad_accumulation():
+                return G(x, z_g)
         finally:
             G.twin_forward = None
 
     def _seg_g(self, x, real_t, z_g, scale_d, keep_grads, info, g_fake=None):
         """optimizerD.step(), then the G step up to lossG.backward() (model.py:259-277).  g_fake: the generator's forward when the
         caller already issued it (_seg_gfwd)."""
+        with fused_grad_accumulation():
+            self._seg_g_body(x, real_t, z_g, scale_d, keep_grads, info, g_fake)
+
+    def _seg_g_body(self, x, real_t, z_g, scale_d, keep_grads, info, g_fake=None):
         G, D = self.G, self.D
         if keep_grads:
             info["d_grads"] = {n: p.grad.detach().clone() * scale_d for n, p in D.named_parameters()}
@@ -331,8 +343,7 @@ class TrainStep:
             D.advance_running_stats(real_t)
             g_fake_logit = D(g_fake)
         out5, seed = gen_loss_with_grads(g_fake_logit, self.gan, self.flip_g)      # gen_loss ignores d_real (loss_utils.py:727-802)
-        with fused_grad_accumulation():
-            torch.autograd.backward([g_fake_logit], [seed])
+        torch.autograd.backward([g_fake_logit], [seed])
         if keep_grads:
             info["fake_g"] = g_fake.detach()
         info["loss_g"] = out5[0]

@@ -174,3 +174,37 @@ def test_captured_literal_loop_equals_eager_literal_loop(sp, gan, use_gp):
     assert res[0][1] == res[1][1], "losses differ between eager and captured issue"
     for k in res[0][0]:
         assert torch.equal(res[0][0][k], res[1][0][k]), k
+
+
+def test_captured_body_notices_a_changed_prior(sp):
+    """Advisor (round 3): the captured graph holds the kNN graph / CSR / dedup decision of the sphere prior it was captured with (the
+    Generator caches them per tensor and version, so the capture contains no kNN launch).  A caller who later passes a prior with other
+    CONTENT must not get stale neighbours: the graph is dropped, the call runs eagerly, the next one is captured again -- every result
+    equals the eager module call on that prior; after a few such changes the body stays eager (with a warning)."""
+    B, N = 4, 256
+    o = _opts(N)
+    G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(), salt=8)).eval()
+
+    def fn(x_, z_):
+        with torch.no_grad():
+            return G(x_, z_)
+    body = sp.CapturedBody(fn, modules=(G,), warmup=1)
+    x0 = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    rot = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    x1 = (fr.sphere_template(N) @ rot * torch.tensor([1.0, 0.8, 0.6]))[None].repeat(B, 1, 1).contiguous().cuda()      # other neighbours
+    z = fr.latent(B, N, seed=3).cuda()
+    want0, want1 = fn(x0, z).clone(), fn(x1, z).clone()
+    assert not torch.equal(want0, want1)
+    for _ in range(3):
+        assert torch.equal(body(x0, z), want0)
+    assert body._graph is not None and 0 in body._struct
+    assert torch.equal(body(x0.clone(), z), want0) and body._graph is not None      # another object, same content: the graph stays
+    assert torch.equal(body(x1, z), want1)                                         # changed content: eager call, fresh neighbours
+    assert body._graph is None
+    assert torch.equal(body(x1, z), want1) and body._graph is not None             # re-captured on the new prior
+    assert torch.equal(body(x1, z), want1)
+    with pytest.warns(UserWarning, match="keeps changing"):
+        for i in range(6):
+            xa = x0 if i % 2 == 0 else x1
+            assert torch.equal(body(xa, z), want0 if i % 2 == 0 else want1)
+    assert body.eager

@@ -124,6 +124,46 @@ def test_autograd_contract_outside_trainstep(spgan_cpu):
         assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-8)
 
 
+def test_backward_modes_are_thread_local_and_recorded_per_graph(spgan_cpu):
+    """SURVEY 8(b) "no global mutable state": `fused_grad_accumulation()` / `input_grad_only()` held open by ANOTHER thread do not change
+    what this thread's graphs do, and a graph keeps the mode it was BUILT under (autograd runs its backward on an engine thread)."""
+    import threading
+    import spgan
+    from spgan.functions import fused_grad_accumulation, input_grad_only
+    D = _load(spgan.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=21)).train()
+    spgan.flatten_module(D)
+    x = fr.synthetic_real(2, 128, seed=22).transpose(2, 1).contiguous()
+    params = list(D.parameters())
+    entered, release = threading.Event(), threading.Event()
+
+    def other():
+        with fused_grad_accumulation(), input_grad_only():
+            entered.set()
+            release.wait(30)
+    t = threading.Thread(target=other)
+    t.start()
+    assert entered.wait(30)
+    try:
+        before = [p.grad.clone() for p in params]
+        grads = torch.autograd.grad(D(x).sum(), params)                  # plain semantics: every parameter gradient is returned ...
+        assert all(g is not None for g in grads)
+        assert all(torch.equal(p.grad, b) for p, b in zip(params, before))   # ... and .grad is untouched
+    finally:
+        release.set(); t.join()
+    # built outside, differentiated inside the context: the graph keeps the mode it was built under (plain)
+    y = D(x).sum()
+    with fused_grad_accumulation():
+        g2 = torch.autograd.grad(y, params)
+    assert all(g is not None for g in g2)
+    # built inside: fused (nothing returned to autograd for leaf parameters with a bound .grad; the sums land in .grad)
+    D._spgan_flat.zero_grad()
+    with fused_grad_accumulation():
+        y = D(x).sum()
+    y.backward()
+    for p, g in zip(params, grads):
+        assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-8)
+
+
 def test_load_state_dict_discards_pending_bn_counts(spgan_cpu):
     import spgan
     D = spgan.Discriminator(Opts).train()
