@@ -61,6 +61,7 @@ class CapturedBody:
         self.eager = False
         self._struct = set()         # positions of arguments the modules hold cached graph structure for (the sphere prior)
         self._recaptures = 0
+        self._captured_once = False
 
     # ------------------------------------------------------------------ inputs
     def _structure_args(self):
@@ -76,7 +77,8 @@ class CapturedBody:
         return {i for i, st in enumerate(self._static or ()) if any(st is t for t in held)}
 
     def _bind(self, args) -> bool:
-        """Stage the arguments; returns True when an argument that feeds cached graph structure changed its CONTENT under a captured graph."""
+        """Stage the arguments; returns True when an argument that feeds cached graph structure was rewritten (under a captured graph:
+        only if its CONTENT changed) -- the modules' cache entries for it are then stale and must be rebuilt by an eager call."""
         if self._static is None:
             self._static = [a.detach().clone() for a in args]
             self._src = [(weakref.ref(a), a._version) for a in args]
@@ -98,7 +100,7 @@ class CapturedBody:
                 # device (one host sync, off the steady-state path); a real change goes through torch's copy_, whose version bump
                 # invalidates the modules' cache entries
                 if self._graph is None or not bool(torch.equal(st, a)):
-                    structure_changed = self._graph is not None
+                    structure_changed = True        # (without a graph: assumed changed -- no comparison, the next call is eager anyway)
                     st.copy_(a)
                 continue
             if a.is_cuda and a.is_contiguous() and a.dtype == torch.float32:
@@ -126,17 +128,18 @@ class CapturedBody:
         if self.eager:
             return self.fn(*args)
         if self._bind(args):
-            # The prior changed after the capture: the captured kernels hold the OLD prior's kNN graph, CSR and dedup decision (the
-            # modules cache them per tensor and version, so the capture contains no kNN launch).  Drop the graph, run this call
-            # eagerly (rebuilds the caches) and capture again on the next one.
+            # The prior changed: a captured graph holds the OLD prior's kNN graph, CSR and dedup decision (the modules cache them per
+            # tensor and version, so the capture contains no kNN launch), and a capture that found its cache entry stale would have to
+            # rebuild it with a host sync.  Drop the graph, run this call eagerly (rebuilds the caches), capture again on the next one.
+            if self._graph is not None or self._captured_once:
+                self._recaptures += 1
             self._graph = None
-            self._recaptures += 1
             if self._recaptures > 3:
                 warnings.warn("CapturedBody: an argument the modules derive cached graph structure from (the sphere prior) keeps changing "
                               "between calls; the captured graph depends on it, so the body is issued eagerly from now on")
                 self.eager = True
                 return self.fn(*args)
-            self._calls = max(self.warmup - 1, 0)
+            self._calls = self.warmup - 1            # exactly one eager call (also with warmup = 0), then the capture
         if self._graph is None and self._calls < self.warmup:
             if self._side is None:
                 self._side = torch.cuda.Stream()
@@ -184,6 +187,7 @@ class CapturedBody:
                     for k, n in pend.items():
                         store[pre][k] -= n
             self._graph = g
+            self._captured_once = True
             self._struct = self._structure_args()
         self._graph.replay()
         self._invalidate_weight_caches()
