@@ -175,6 +175,9 @@ class MfmaAccounting:
             tb = 128 if a.Nb > 64 else (64 if a.Nb > 32 else 32)
             useful = 2.0 * a.M * a.Na * a.Nb
             return useful, 2.0 * _cdiv(a.M, 32) * 32 * _cdiv(a.Na, 128) * 128 * _cdiv(a.Nb, tb) * tb, False
+        if kind == "gemm_dual":                              # weight-gradient + input-gradient product of one layer in one launch
+            f = 4.0 * a.M * a.Na * a.Nb
+            return f, f, False
         if kind == "knn":
             if a.mode != 0 or a.C < 16:
                 return None                                   # coordinate-space kNN: fp64 VALU kernel

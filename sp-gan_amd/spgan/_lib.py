@@ -74,6 +74,20 @@ class GemmTNArgs(C.Structure):
     ]
 
 
+class GemmDualArgs(C.Structure):
+    _fields_ = [
+        ("A", c_f32p), ("lda", C.c_int),
+        ("A2", c_f32p), ("lda2", C.c_int), ("p", c_f32p), ("q", c_f32p), ("r", c_f32p),
+        ("W", c_f32p), ("ldw", C.c_int),
+        ("B", c_f32p), ("ldb", C.c_int),
+        ("e_idx", c_i32p), ("e_k", C.c_int), ("e_bias", c_f32p),
+        ("b_scale", c_f32p), ("b_shift", c_f32p), ("b_mean", c_f32p), ("b_invstd", c_f32p), ("slope", C.c_float),
+        ("G", c_f32p), ("ldg", C.c_int),
+        ("stats", c_f32p), ("ws", c_f32p),
+        ("M", C.c_int), ("Na", C.c_int), ("Nb", C.c_int),
+    ]
+
+
 MULTI_MAX = 64
 
 
@@ -172,6 +186,9 @@ SIGNATURES = {
     "spgan_query_ball_point": (I, [F, I, P, P, I, I, I, I, P, P]),
     "spgan_knn_point": (I, [I, P, P, I, I, I, I, P, P]),
     "spgan_group_concat": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+    "spgan_gemm_dual_wgs": (I, [I, I, I, I]),
+    "spgan_gemm_dual_rows_per_wg": (I, [I]),
+    "spgan_gemm_dual": (I, [C.POINTER(GemmDualArgs), P]),
     "spgan_gather_csr": (I, [P, I, I, I, P, P, P, P]),
     "spgan_scatter_slots": (I, [P, I, I, I, P, P, I, P, P]),
     "spgan_group_center_bwd": (I, [P, I, I, I, I, P, P]),

@@ -443,7 +443,9 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             dy = ops.Affine2(g, ys[2], coef[0]) if lazy else _bn_bwd(g, ys[2], mu, inv, P[D_LAYERS[2][1] + ".weight"], sums, M, lazy=False)
             dys[2] = dy; gs[2] = g; sums_all[2] = sums
             continue
-        if need_dparams:
+        # one launch for the weight gradient AND the masked input gradient of this layer (ops.gemm_dual: the dy tile is staged once)
+        fused = need_dparams and li > 0 and ctx["training"] and ops.gemm_dual_ok(dy, W, ys[li - 1])
+        if need_dparams and not fused:
             if li > 0:
                 grads[conv + ".weight"] = ops.gemm_tn(dy, ys[li - 1], pro=(bns[li - 1][0], bns[li - 1][1], NEG), defer=True).view_as(P[conv + ".weight"])
             else:
@@ -457,7 +459,12 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             # lazy for every layer (coefficients from the finalize launch); layer 1's dy (64 channels) is consumed by the 3-column
             # weight gradient (the streaming kernel takes the two-tensor operand on its wide side) and the 3-column input gradient
             lazy = ctx["training"] and _lazy_ok(M, sc.numel())
-            g, s0, s1, *coef = ops.gemm_nt_bnbwd(dy, _t(W), ys[li - 1], sc, sh, mu, inv, NEG, **(dict(coef_bn=(P[pbn + ".weight"], M)) if lazy else {}))
+            cb = dict(coef_bn=(P[pbn + ".weight"], M)) if lazy else {}
+            if fused:
+                dW, g, s0, s1, *coef = ops.gemm_dual(dy, W, ys[li - 1], sc, sh, mu, inv, NEG, **cb)
+                grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
+            else:
+                g, s0, s1, *coef = ops.gemm_nt_bnbwd(dy, _t(W), ys[li - 1], sc, sh, mu, inv, NEG, **cb)
             if need_dparams:
                 grads[pbn + ".weight"] = s1; grads[pbn + ".bias"] = s0
             sums = _cat2(s0, s1) if ctx["training"] else torch.zeros(2 * s0.numel(), device=s0.device)
@@ -605,8 +612,12 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         gA = grads[conv + ".weight"]
         if li > 0:
             psc, psh, pinv, pmu = bns[li - 1]
-            ops.gemm_tn(ybar, ys[li - 1], pro=(psc, psh, NEG), out=gA, beta=1.0)
-            abar_g = ops.gemm_nt_bnbwd(ybar, _t(W), ys[li - 1], psc, psh, pmu, pinv, NEG)
+            if ops.gemm_dual_ok(ybar, W, ys[li - 1]):
+                _, *abar = ops.gemm_dual(ybar, W, ys[li - 1], psc, psh, pmu, pinv, NEG, out=gA, beta=1.0)      # both products of this layer in one launch
+                abar_g = tuple(abar)
+            else:
+                ops.gemm_tn(ybar, ys[li - 1], pro=(psc, psh, NEG), out=gA, beta=1.0)
+                abar_g = ops.gemm_nt_bnbwd(ybar, _t(W), ys[li - 1], psc, psh, pmu, pinv, NEG)
         else:
             ops.gemm_tn(ybar, ctx["x_pm"], out=gA, beta=1.0)
             if need_dx:
@@ -764,9 +775,15 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     # conv_w.4 BN backward -> conv_w.3
     dh2 = _bn_bwd(g2, ctx["h2pre"], bn2[3], bn2[2], P[pre + ".conv_w.4.weight"], sums2, E)     # lazy: consumed by the two edge GEMMs below
     W2 = _w2(P[pre + ".conv_w.3.weight"])
-    g[pre + ".conv_w.3.weight"] = ops.gemm_tn(dh2, PQR[:, :H], pro=(bn1[0], bn1[1], NEG), edge=(idx, b1), defer=True).view_as(P[pre + ".conv_w.3.weight"])
+    if ctx["training"] and ops.gemm_dual_ok(dh2, W2, PQR[:, :H], edge=(idx, b1)):
+        # conv_w.3's weight gradient and its masked input gradient from ONE staging of the dh2 tile (csrc/gemm_dual.hip): the two [E,F]
+        # tensors behind the lazy operand are read once instead of twice
+        dW3, g1, s10, s11 = ops.gemm_dual(dh2, W2, PQR[:, :H], bn1[0], bn1[1], bn1[3], bn1[2], NEG, edge=(idx, b1))
+        g[pre + ".conv_w.3.weight"] = dW3.view_as(P[pre + ".conv_w.3.weight"])
+    else:
+        g[pre + ".conv_w.3.weight"] = ops.gemm_tn(dh2, PQR[:, :H], pro=(bn1[0], bn1[1], NEG), edge=(idx, b1), defer=True).view_as(P[pre + ".conv_w.3.weight"])
+        g1, s10, s11 = ops.gemm_nt_bnbwd(dh2, _t(W2), PQR[:, :H], bn1[0], bn1[1], bn1[3], bn1[2], NEG, edge=(idx, b1))
     g[pre + ".conv_w.3.bias"] = ZERO_GRAD if ctx["training"] else ops.colsum(_dense(dh2))[0]
-    g1, s10, s11 = ops.gemm_nt_bnbwd(dh2, _t(W2), PQR[:, :H], bn1[0], bn1[1], bn1[3], bn1[2], NEG, edge=(idx, b1))
     g[pre + ".conv_w.1.weight"] = s11; g[pre + ".conv_w.1.bias"] = s10
     sums1 = _cat2(s10, s11) if ctx["training"] else torch.zeros(2 * H, device=x.device)
     # BN backward of conv_w.0 / conv_x.0 outputs fused with the edge -> point reduction

@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import GemmNTArgs, GemmTNArgs, check
+from ._lib import GemmDualArgs, GemmNTArgs, GemmTNArgs, check
 
 A_PLAIN, A_AFFINE_LRELU, A_EDGE = 0, 1, 2
 EPI_LINEAR, EPI_MASK_OUT, EPI_BNBWD, EPI_EDGE_BNBWD = 0, 1, 2, 3
@@ -638,6 +638,93 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
         return g, res[0], res[1]
     s0, s1 = _finalize(part, 1, tiles, N, M_, 1)
     return g, s0[0], s1[0]
+
+
+def gemm_dual_ok(dy, W: Tensor, y_ref: Tensor, edge=None) -> bool:
+    """True when gemm_dual takes this layer backward (csrc/gemm_dual.hip: fp32 operands, dy 128 columns wide, 64 input channels, M % 32 == 0,
+    M >= 8192, per-edge operand with k = 10); otherwise the caller issues gemm_tn + gemm_nt_bnbwd."""
+    if _MFMA_F16[0] != 0 or _NT_TILE_HINT[0] != 0 or not GEMM_DUAL[0]:
+        return False
+    a2 = dy if isinstance(dy, Affine2) else None
+    g = a2.g if a2 is not None else dy
+    if not isinstance(g, Tensor) or g.dtype != torch.float32 or (a2 is not None and (a2.half or a2.y.dtype != torch.float32)):
+        return False
+    if W.dim() != 2 or y_ref.dtype != torch.float32:
+        return False
+    ek = 0 if edge is None else int(edge[0].shape[1])
+    return bool(_lib.load().spgan_gemm_dual_wgs(g.shape[0], W.shape[0], W.shape[1], ek))
+
+
+GEMM_DUAL = [True]      # test hook: False sends every layer backward through the two separate launches (tests compare the two routes)
+
+
+def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float, edge=None, coef_bn=None,
+              defer: bool = True, out: Optional[Tensor] = None, beta: float = 0.0):
+    """The weight-gradient AND the masked input-gradient product of one conv layer behind BatchNorm + LeakyReLU in one launch:
+      dW [Na,Nb] = dy^T . lrelu(pre*scale + shift),   g = (dy . W) * lrelu'(pre*scale + shift),   s0 = sum g,  s1 = sum g*xhat
+    dy: Affine2 (lazy BatchNorm backward) or a dense [M,Na] tensor; W [Na,Nb] the layer's weight as stored; pre = y_ref [M,Nb], or with
+    edge=(idx, ebias) the per-edge difference y_ref[idx[e]] - y_ref[e // k] + ebias of the point tensor y_ref.
+    Returns (dW, g, s0, s1) and, with coef_bn=(gamma, count), the lazy-operand coefficients [3,Nb] of the NEXT BatchNorm backward as a fifth
+    result.  dW's split sum is deferred like gemm_tn(defer=True): valid after flush_tn(); out / beta: dW = beta*out + sum (accumulated in place)."""
+    a2 = dy if isinstance(dy, Affine2) else None
+    A = a2.g if a2 is not None else dy
+    _rowmajor2d(A, "dy"); _rowmajor2d(W, "W"); _rowmajor2d(y_ref, "y_ref")
+    M_, Na = A.shape
+    Nb = W.shape[1]
+    if W.shape[0] != Na:
+        raise ValueError("W must be [Na, Nb] with Na = columns of dy")
+    lib = _lib.load()
+    ek = 0 if edge is None else int(edge[0].shape[1])
+    wgs = lib.spgan_gemm_dual_wgs(M_, Na, Nb, ek)
+    if not wgs:
+        raise ValueError("gemm_dual: unsupported shape M=%d Na=%d Nb=%d k=%d (see gemm_dual_ok)" % (M_, Na, Nb, ek))
+    rows_wg = lib.spgan_gemm_dual_rows_per_wg(M_)
+    a = GemmDualArgs()
+    a.A = _p(A); a.lda = _ld(A)
+    if a2 is not None:
+        _rowmajor2d(a2.y, "dy.y")
+        a.A2 = _p(a2.y); a.lda2 = _ld(a2.y)
+        a.p = _p(_vec(a2.p, Na, "p")); a.q = _p(_vec(a2.q, Na, "q")); a.r = _p(_vec(a2.r, Na, "r"))
+    a.W = _p(W); a.ldw = _ld(W)
+    a.B = _p(y_ref); a.ldb = _ld(y_ref)
+    if edge is not None:
+        idx, ebias = edge
+        _i32(idx, "idx")
+        if idx.shape[0] * idx.shape[1] != M_:
+            raise ValueError("edge operand: dy must have one row per edge")
+        a.e_idx = _p(idx); a.e_k = ek; a.e_bias = _p(_vec(ebias, Nb, "ebias"))
+    elif y_ref.shape[0] != M_:
+        raise ValueError("dy and y_ref disagree on the rows: %d vs %d" % (M_, y_ref.shape[0]))
+    a.b_scale = _p(_vec(scale, Nb, "scale")); a.b_shift = _p(_vec(shift, Nb, "shift"))
+    a.b_mean = _p(_vec(mean, Nb, "mean")); a.b_invstd = _p(_vec(invstd, Nb, "invstd")); a.slope = float(slope)
+    g = torch.empty((M_, Nb), dtype=torch.float32, device=A.device)
+    part = torch.empty((wgs, Nb, 2), dtype=torch.float32, device=A.device)
+    ws = torch.empty((wgs, Na, Nb), dtype=torch.float32, device=A.device)
+    if out is None:
+        dW, beta = torch.empty((Na, Nb), dtype=torch.float32, device=A.device), 0.0
+    else:
+        dW = _rowmajor2d(out, "out")
+        if tuple(out.shape) != (Na, Nb):
+            raise ValueError("out must be [Na, Nb]")
+    a.G = _p(g); a.ldg = Nb; a.stats = _p(part); a.ws = _p(ws)
+    a.M, a.Na, a.Nb = M_, Na, Nb
+    done = launch_timer("gemm_dual", a) if launch_timer is not None else None
+    check(lib.spgan_gemm_dual(C.byref(a), _s()), "gemm_dual", M=M_, Na=Na, Nb=Nb, k=ek)
+    if done is not None:
+        done()
+    _PENDING_TN.append((ws, dW, wgs, Na, Nb, _ld(dW), float(beta)))
+    if not defer:
+        flush_tn()
+    if coef_bn is not None:
+        gamma, count = coef_bn
+        out = torch.empty((2, Nb), dtype=torch.float32, device=A.device)
+        coef = torch.empty((3, Nb), dtype=torch.float32, device=A.device)
+        check(lib.spgan_colstats_finalize_bnbwd(_p(part), wgs, Nb, M_, rows_wg, _p(_vec(mean, Nb, "mean")), _p(_vec(invstd, Nb, "invstd")),
+                                                _p(None if gamma is None else _vec(gamma, Nb, "gamma")), float(count), _p(out[0]), _p(out[1]), _p(coef), _s()),
+              "colstats_finalize_bnbwd", N=Nb, M=M_)
+        return dW, g, out[0], out[1], coef
+    s0, s1 = _finalize(part, 1, wgs, Nb, M_, 1, rows_wg)
+    return dW, g, s0[0], s1[0]
 
 
 _PENDING_TN: list = []      # deferred split-K reductions: (ws, out, splits, Na, Nb, ldc, beta); see gemm_tn(defer=True) / flush_tn()

@@ -723,3 +723,23 @@ def multi_add(dsts, srcs):
 
 def capturing():
     return False
+
+
+# ----------------------------------------------------------------------------- fused layer backward (csrc/gemm_dual.hip)
+GEMM_DUAL = [True]
+
+
+def gemm_dual_ok(dy, W, y_ref, edge=None):
+    g = dy.g if isinstance(dy, Affine2) else dy
+    ek = 0 if edge is None else int(edge[0].shape[1])
+    return bool(GEMM_DUAL[0] and W.shape[0] == 128 and W.shape[1] == 64 and g.shape[0] >= 8192 and g.shape[0] % 32 == 0 and ek in (0, 10))
+
+
+def gemm_dual(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=None, coef_bn=None, defer=True, out=None, beta=0.0):
+    """= gemm_tn(dy, y_ref, pro / edge) and gemm_nt_bnbwd(dy, W^T, y_ref, ...) of the same operands."""
+    dW = gemm_tn(dy, y_ref, pro=(scale, shift, slope), edge=edge)
+    if out is not None:
+        out.copy_(beta * out + dW)
+        dW = out
+    res = gemm_nt_bnbwd(dy, W.t().contiguous(), y_ref, scale, shift, mean, invstd, slope, edge=edge, **({} if coef_bn is None else dict(coef_bn=coef_bn)))
+    return (dW,) + tuple(res)

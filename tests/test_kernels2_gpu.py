@@ -515,3 +515,84 @@ def test_gemm_nt_k4_streaming(ops, M, N, K):
     for g, w_, what in zip(pa, pb, ("scale", "shift", "invstd", "mean")):
         close(g, w_, rtol=2e-5, atol=1e-6, what="bn." + what)
     close(bn[2], bn2[2], rtol=2e-5, atol=1e-7, what="running mean"); close(bn[3], bn2[3], rtol=2e-5, what="running var")
+
+
+# ---------------------------------------------------------------- the fused layer backward (csrc/gemm_dual.hip)
+@pytest.mark.parametrize("M,lazy", [(8192, True), (65536, True), (20000, False)])
+def test_gemm_dual_plain(ops, M, lazy):
+    """ops.gemm_dual -- weight gradient AND masked input gradient of a conv layer behind BatchNorm + LeakyReLU from ONE staging of the dy
+    tile -- against the two separate launches it replaces (gemm_tn + gemm_nt_bnbwd; other summation orders) and against a float64 model;
+    lazy (two-tensor) and dense dy; the coefficients of the next lazy operand from its finalize launch; accumulation into `out`."""
+    Na, Nb = 128, 64
+    g, y = rnd("gd.g%d" % M, (M, Na)), rnd("gd.y%d" % M, (M, Na), 2.0) + 0.3
+    mean, inv = y.mean(0), 1.0 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+    gamma = rnd("gd.ga", (Na,)).abs() + 0.5
+    sums = torch.cat([g.sum(0), (g * ((y - mean) * inv)).sum(0)])
+    dy = ops.bn_bwd_lazy(g, y, mean, inv, gamma, sums, M) if lazy else ops.bn_bwd_apply(g, y, mean, inv, gamma, sums, M)
+    dense = dy.dense() if lazy else dy
+    W = rnd("gd.W", (Na, Nb), 0.1)
+    prev = rnd("gd.prev%d" % M, (M, Nb), 1.5)
+    sc, sh = rnd("gd.sc", (Nb,)), rnd("gd.sh", (Nb,), 0.3)
+    mu, iv = rnd("gd.mu", (Nb,), 0.2), rnd("gd.iv", (Nb,)).abs() + 0.5
+    assert ops.gemm_dual_ok(dy, W, prev)
+    gam2 = rnd("gd.gam2", (Nb,)).abs() + 0.5
+    dW, gz, s0, s1, coef = ops.gemm_dual(dy, W, prev, sc, sh, mu, iv, 0.01, coef_bn=(gam2, M), defer=False)
+    # float64 model
+    d64, p64 = dense.double(), prev.double()
+    z = p64 * sc.double() + sh.double()
+    a64 = torch.where(z > 0, z, z * 0.01)
+    close(dW, (d64.t() @ a64).float(), rtol=2e-5, atol=2e-5 * float((d64.t() @ a64).abs().max()), what="weight gradient vs float64")
+    g64 = (d64 @ W.double()) * torch.where(z > 0, 1.0, 0.01)
+    xh = (p64 - mu.double()) * iv.double()
+    close(gz, g64.float(), rtol=1e-5, atol=1e-5 * float(g64.abs().max()), what="input gradient vs float64")
+    close(s0, g64.sum(0).float(), rtol=1e-5, atol=3e-5 * float(g64.abs().sum(0).max()), what="sum g")
+    close(s1, (g64 * xh).sum(0).float(), rtol=1e-5, atol=3e-5 * float((g64 * xh).abs().sum(0).max()), what="sum g*xhat")
+    # the two launches it replaces
+    close(dW, ops.gemm_tn(dy, prev, pro=(sc, sh, 0.01)), rtol=1e-5, atol=1e-5 * float(dW.abs().max()), what="vs gemm_tn")
+    g2, t0, t1, coef2 = ops.gemm_nt_bnbwd(dy, W.t().contiguous(), prev, sc, sh, mu, iv, 0.01, coef_bn=(gam2, M))
+    close(gz, g2, rtol=2e-6, atol=2e-6 * float(g2.abs().max()), what="vs gemm_nt_bnbwd")
+    close(s0, t0, rtol=1e-5, atol=1e-5 * float(g2.abs().sum(0).max())); close(s1, t1, rtol=1e-5, atol=3e-5 * float((g64 * xh).abs().sum(0).max()))
+    close(coef, ops.bn_bwd_lazy(gz, prev, mu, iv, gam2, torch.cat([s0, s1]), M).coef, rtol=1e-6, atol=1e-7, what="coef from the finalize launch")
+    # deterministic; accumulation into an existing gradient by the (deferred) split reduction
+    dWb, gzb, s0b, s1b = ops.gemm_dual(dy, W, prev, sc, sh, mu, iv, 0.01, defer=False)
+    assert torch.equal(dW, dWb) and torch.equal(gz, gzb) and torch.equal(s0, s0b) and torch.equal(s1, s1b)
+    acc = rnd("gd.acc", (Na, Nb))
+    out = acc.clone()
+    ops.gemm_dual(dy, W, prev, sc, sh, mu, iv, 0.01, out=out, beta=1.0)
+    ops.flush_tn()
+    close(out, acc + dW, rtol=1e-6, atol=1e-6 * float(dW.abs().max()), what="beta = 1 accumulation")
+
+
+def test_gemm_dual_edge(ops):
+    """The EdgeBlock's conv_w.3 backward (per-edge operand: pre[e] = P[idx[e]] - P[e // k] + b1) in one launch against the two it replaces
+    and a float64 model, at a size with several chunks per workgroup."""
+    B, N, k, H, F_ = 4, 1024, 10, 64, 128
+    M = B * N
+    E = M * k
+    g, y = rnd("gde.g", (E, F_)), rnd("gde.y", (E, F_), 1.5)
+    mean, inv = y.mean(0), 1.0 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+    gamma = rnd("gde.ga", (F_,)).abs() + 0.5
+    sums = torch.cat([g.sum(0), (g * ((y - mean) * inv)).sum(0)])
+    lazy = ops.bn_bwd_lazy(g, y, mean, inv, gamma, sums, E)
+    Pm = rnd("gde.P", (M, H + 2 * F_))
+    idx = ops.knn(rnd("gde.x", (M, 16), 0.5), B, N, k, 0)
+    b1 = rnd("gde.b1", (H,), 0.1)
+    sc, sh = rnd("gde.sc", (H,)), rnd("gde.sh", (H,), 0.3)
+    mu1, inv1 = rnd("gde.mu1", (H,), 0.2), rnd("gde.inv1", (H,)).abs() + 0.5
+    W2 = rnd("gde.W", (F_, H), 0.1)
+    assert ops.gemm_dual_ok(lazy, W2, Pm[:, :H], edge=(idx, b1))
+    dW, g1, s0, s1 = ops.gemm_dual(lazy, W2, Pm[:, :H], sc, sh, mu1, inv1, 0.01, edge=(idx, b1), defer=False)
+    a = ops.gemm_tn(lazy, Pm[:, :H], pro=(sc, sh, 0.01), edge=(idx, b1))
+    close(dW, a, rtol=1e-5, atol=1e-5 * float(a.abs().max()), what="edge weight gradient vs gemm_tn")
+    g2, t0, t1 = ops.gemm_nt_bnbwd(lazy, W2.t().contiguous(), Pm[:, :H], sc, sh, mu1, inv1, 0.01, edge=(idx, b1))
+    close(g1, g2, rtol=2e-6, atol=2e-6 * float(g2.abs().max()), what="edge input gradient vs gemm_nt_bnbwd")
+    close(s0, t0, rtol=1e-5, atol=1e-5 * float(g2.abs().sum(0).max())); close(s1, t1, rtol=1e-5, atol=1e-4 * float(g2.abs().sum(0).max()))
+    # float64 model of the per-edge operand
+    i = torch.arange(M, device=g.device).repeat_interleave(k)
+    pre = (Pm[idx.reshape(-1).long(), :H].double() - Pm[i, :H].double()) + b1.double()
+    z = pre * sc.double() + sh.double()
+    d64 = lazy.dense().double()
+    ref = d64.t() @ torch.where(z > 0, z, z * 0.01)
+    close(dW, ref.float(), rtol=2e-5, atol=2e-5 * float(ref.abs().max()), what="edge weight gradient vs float64")
+    r64 = (d64 @ W2.double()) * torch.where(z > 0, 1.0, 0.01)
+    close(g1, r64.float(), rtol=1e-5, atol=1e-5 * float(r64.abs().max()), what="edge input gradient vs float64")

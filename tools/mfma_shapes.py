@@ -20,6 +20,8 @@ class Shapes(bench.MfmaAccounting):
                 key = ("nt", a.M, a.N, a.K, "a%d e%d%s%s%s" % (a.a_mode, a.epi_mode, " stats" if a.stats else "", " pool" if a.pool_val else "", " z%d" % a.batch if a.batch > 1 else ""))
             elif kind == "gemm_tn":
                 key = ("tn", a.M, a.Na, a.Nb, "b%d%s%s" % (a.b_mode, " sparseA" if a.a_scale else "", " defer" if a.defer_reduce else ""))
+            elif kind == "gemm_dual":
+                key = ("dual", a.M, a.Na, a.Nb, "dgrad+wgrad%s%s" % (" lazyA" if a.A2 else "", " edge" if a.e_idx else ""))
             else:
                 key = ("knn", a.B * a.N, a.N, a.C, "k%d" % a.k)
             self.rec[-1] = self.rec[-1] + (key,)
