@@ -450,6 +450,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
                 grads[conv + ".weight"] = ops.gemm_tn(dy, ys[li - 1], pro=(bns[li - 1][0], bns[li - 1][1], NEG), defer=True).view_as(P[conv + ".weight"])
             else:
                 grads[conv + ".weight"] = ops.gemm_tn(dy, ctx["x_pm"], defer=True).view_as(P[conv + ".weight"])
+        if need_dparams:
             grads[conv + ".bias"] = ZERO_GRAD     # bias before a train-mode BN: exactly zero gradient
             if not ctx["training"]:
                 grads[conv + ".bias"] = ops.colsum(_dense(dy))[0]
