@@ -284,6 +284,11 @@ int spgan_gemm_dual(const spgan_gemm_dual_args* a, spgan_stream_t s);
  * spgan_sparse_rows_nt: E[m, n]  = sum_{c: arg[b,c]==m} val[b,c] * W[c, n]      E [B*rows, N] is fully written (zero rows too)
  * spgan_sparse_rows_tn: C[c, n] += sum_b val[b,c] * pro(Bm)[arg[b,c], n]         pro = lrelu(x*p_scale[n]+p_shift[n], p_slope) or none
  * Both sum in ascending c / b order (deterministic). */
+/* The two weight-only operands of that collapsed backward in one launch (csrc/collapse.hip), W [C, K]:
+ *   G[i,j] = sum_c W[c,i]*alpha[c]*W[c,j]   (W^T diag(alpha) W, [K,K]);   cvec[j] = sum_c (alpha[c]*bias[c] + beta[c])*W[c,j]   (cvec NULL: skipped)
+ * C % 64 == 0, K % 32 == 0; deterministic (fixed-order sums). */
+int spgan_wt_diag_w(const float* W, int ldw, int C, int K, const float* alpha, const float* beta, const float* bias, float* G, int ldg,
+                    float* cvec, spgan_stream_t s);
 int spgan_sparse_rows_nt(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* W, int ldw, int N, float* E, int lde,
                          spgan_stream_t s);
 int spgan_sparse_rows_tn(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* Bm, int ldb, int Nb,
@@ -582,9 +587,10 @@ int spgan_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
                     float grad_scale, spgan_stream_t s);
 /* The same update with its step-dependent state in device memory: state[0] = int step count (advanced by this call), state[1..2] = its
  * bias corrections, state[3] = a multiplier on `lr` (1 = lr as passed; the StepLR schedule of Generation/model.py:99-110,309-312 writes
- * it): no host value changes from one step to the next, so a captured hipGraph of the train step replays it.  state: 4 floats. */
-int spgan_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
-                        float* state, float grad_scale, spgan_stream_t s);
+ * it): no host value changes from one step to the next, so a captured hipGraph of the train step replays it.  state: 4 floats.
+ * zero_grad != 0: g is zeroed after it was read -- the optimizer.zero_grad() of the next iteration (model.py:243,268) without a launch. */
+int spgan_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                        float* state, float grad_scale, int zero_grad, spgan_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * Evaluation metrics: Chamfer distance.

@@ -404,13 +404,14 @@ __global__ void adam_prep_kernel(float beta1, float beta2, float* __restrict__ s
   state[1] = (float)(1.0 - pow((double)beta1, (double)t));
   state[2] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)t)));
 }
-__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
-                                float lr, float b1, float b2, float eps, const float* __restrict__ state, float gscale) {
+__global__ void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                float lr, float b1, float b2, float eps, const float* __restrict__ state, float gscale, int zero_grad) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const float bc1 = state[1], rsqrt_bc2 = state[2];
   lr *= state[3];  // learning-rate multiplier in device memory: a schedule changes it without re-capturing the step
   const float gr = g[t] * gscale;
+  if (zero_grad) g[t] = 0.f;   // optimizer.zero_grad() of the NEXT step, for free (the gradient is in a register anyway)
   const float mm = b1 * m[t] + (1.f - b1) * gr;
   const float vv = b2 * v[t] + (1.f - b2) * gr * gr;
   m[t] = mm;
@@ -666,11 +667,11 @@ extern "C" int spgan_axpby(float a, const float* x, float b, float* y, size_t n,
   return spgan_launch_status();
 }
 
-extern "C" int spgan_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
-                                   float* state3, float grad_scale, spgan_stream_t s_) {  // state3: 4 floats, see spgan_hip.h
+extern "C" int spgan_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                                   float* state3, float grad_scale, int zero_grad, spgan_stream_t s_) {  // state3: 4 floats, see spgan_hip.h
   SPGAN_CHECK_ARG(p && g && m && v && state3 && n > 0);
   hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)s_, beta1, beta2, state3);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, p, g, m, v, n, lr, beta1, beta2, eps, state3, grad_scale);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, p, g, m, v, n, lr, beta1, beta2, eps, state3, grad_scale, zero_grad);
   return spgan_launch_status();
 }
 

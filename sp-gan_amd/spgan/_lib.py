@@ -186,6 +186,7 @@ SIGNATURES = {
     "spgan_query_ball_point": (I, [F, I, P, P, I, I, I, I, P, P]),
     "spgan_knn_point": (I, [I, P, P, I, I, I, I, P, P]),
     "spgan_group_concat": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+    "spgan_wt_diag_w": (I, [P, I, I, I, P, P, P, P, I, P, P]),
     "spgan_gemm_dual_wgs": (I, [I, I, I, I]),
     "spgan_gemm_dual_rows_per_wg": (I, [I]),
     "spgan_gemm_dual": (I, [C.POINTER(GemmDualArgs), P]),
@@ -225,7 +226,7 @@ SIGNATURES = {
     "spgan_splitk_reduce_multi": (I, [C.POINTER(SplitKMultiArgs), P]),
     "spgan_axpby": (I, [F, P, F, P, SZ, P]),
     "spgan_adam_step": (I, [P, P, P, P, SZ, F, F, F, F, I, F, P]),
-    "spgan_adam_step_dev": (I, [P, P, P, P, SZ, F, F, F, F, P, F, P]),
+    "spgan_adam_step_dev": (I, [P, P, P, P, SZ, F, F, F, F, P, F, I, P]),
 }
 
 _lib = None

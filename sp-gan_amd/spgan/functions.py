@@ -367,7 +367,17 @@ class AdaINFn(Function):
         pre = ctx.holder.prefix
         P = {pre + ".style.weight": nets.owned(w), pre + ".style.bias": nets.owned(b)}
         need_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
-        dx, ds, g = nets.adain_backward(P, pre, ctx.actx, dout, ctx.needs_input_grad[1], ctx.needs_input_grad[2], need_p)
+        # Two AdaIN layers on one style tensor (holder.style_chain): the layer whose backward runs FIRST (the later layer: adain2) keeps its
+        # style gradient in the shared dict and hands autograd nothing; the other one (adain1 -- its backward depends on adain2's through
+        # EdgeConv2, so it always runs afterwards) adds that tensor inside its own style-gradient GEMM and returns the sum.
+        chain = getattr(ctx.holder, "style_chain", None)
+        addend = None
+        if chain is not None and ctx.needs_input_grad[2] and chain[1] == "last":
+            addend = chain[0].pop("ds", None)
+        dx, ds, g = nets.adain_backward(P, pre, ctx.actx, dout, ctx.needs_input_grad[1], ctx.needs_input_grad[2], need_p, dstyle_addend=addend)
+        if chain is not None and ctx.needs_input_grad[2] and chain[1] == "first":
+            chain[0]["ds"] = ds
+            ds = None
         return (None, dx, ds) + _deliver((w, b), [g.get(pre + ".style.weight"), g.get(pre + ".style.bias")], ctx.needs_input_grad[3:], ctx.fused)
 
 

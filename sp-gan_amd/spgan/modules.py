@@ -178,8 +178,10 @@ class AdaptivePointNorm(nn.Module):
             self.style.bias.zero_()
             self.style.bias[:in_channel] = 1
 
-    def forward_pm(self, x_pm, style_pm, N: int, slope: float = 1.0):
-        return Fn.AdaINFn.apply(_Holder(prefix="a", N=N, slope=slope), x_pm, style_pm, self.style.weight, self.style.bias)
+    def forward_pm(self, x_pm, style_pm, N: int, slope: float = 1.0, style_chain=None):
+        """style_chain = (dict, role): two AdaIN layers fed by the SAME style tensor (the generator's adain1 / adain2) hand the style
+        gradient along instead of leaving its sum to autograd -- see Fn.AdaINFn.backward."""
+        return Fn.AdaINFn.apply(_Holder(prefix="a", N=N, slope=slope, style_chain=style_chain), x_pm, style_pm, self.style.weight, self.style.bias)
 
     def forward(self, input, style):
         _require_gpu(input, "AdaptivePointNorm")
@@ -349,7 +351,10 @@ class Generator(nn.Module, _BNCounts):
             x1 = Fn.RepeatRowsFn.apply(x1_one, B)
         else:
             x1 = self.EdgeConv1.forward_pm(feat, B, N, knn_mode=0 if self.use_head else 1, graph_cache=cache)
-        x1 = self.adain1.forward_pm(x1, style, N, slope)           # lrelu1 fused into the instance norm (Generator.py:175-176)
+        # both AdaIN layers read the same style tensor: adain2's backward (which runs first) stashes its style gradient, adain1's adds it
+        # in the epilogue of its own style-gradient GEMM -- instead of an autograd add over a [B*N, 128] tensor
+        chain = {} if (style.requires_grad and torch.is_grad_enabled()) else None
+        x1 = self.adain1.forward_pm(x1, style, N, slope, style_chain=None if chain is None else (chain, "last"))    # lrelu1 fused into the instance norm (Generator.py:175-176)
         self.last_x1 = x1.detach()                                 # [M,64] input of EdgeConv2's graph (diagnostics / parity tests)
         # Tie-aware parity protocol: a caller may hand over EdgeConv2's kNN graph(s) for the next forward(s) --
         # `inject_graph2([idx, ...])`, int32 [B*N,k] global rows or the reference's int64 [B,N*k] local indices -- e.g. the graph
@@ -359,7 +364,7 @@ class Generator(nn.Module, _BNCounts):
         if idx2 is not None and idx2.dtype != torch.int32:
             idx2 = ops.idx_from_local64(idx2.to(torch.int64).reshape(B, -1), B, N, self.nk)
         x2 = self.EdgeConv2.forward_pm(x1, B, N, idx=idx2, knn_mode=0)
-        x2 = self.adain2.forward_pm(x2, style, N, slope)
+        x2 = self.adain2.forward_pm(x2, style, N, slope, style_chain=None if chain is None else (chain, "first"))
         self.last_x2 = x2.detach()                                 # [M,128] adain2's output (parity tests)
         h = _Holder(buffers=_buffers(self), B=B, N=N, training=self.training)
         if self.use_attn:

@@ -431,8 +431,11 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
                 ops.sparse_rows_tn(dy.sp_val, dy.sp_arg, N, ys[2], dW, pro=pro3)
                 grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
                 grads[conv + ".bias"] = ZERO_GRAD
-            G4 = ops.gemm_tn(W, ops.rowscale_outer(W, alpha))                     # W^T diag(alpha) W
-            cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(alpha, beta, 1.0), exact=True)[0]  # (alpha*b4 + beta).W
+            if W.shape[0] % 64 == 0 and W.shape[1] % 32 == 0:
+                G4, cvec = ops.wt_diag_w(W, alpha, beta, b4)                      # W^T diag(alpha) W and (alpha*b4 + beta).W in one launch
+            else:
+                G4 = ops.gemm_tn(W, ops.rowscale_outer(W, alpha))                     # W^T diag(alpha) W
+                cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(alpha, beta, 1.0), exact=True)[0]  # (alpha*b4 + beta).W
             E = ops.sparse_rows_nt(dy.sp_val, dy.sp_arg, N, W)                    # S.W, dense rows
             lazy = _lazy_ok(M, sc.numel())
             cb = dict(coef_bn=(P[D_LAYERS[2][1] + ".weight"], M)) if lazy else {}     # the finalize launch also emits the lazy operand's coefficients
@@ -523,15 +526,19 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
     dgamma, c1, c2, c3 = c4[0], c4[1], c4[2], c4[3]
     grads[bn + ".weight"] = dgamma
     grads[bn + ".bias"] = ZERO_GRAD
-    Wc1, Wc2 = ops.rowscale_outer(W, c1), ops.rowscale_outer(W, c2)
+    Wc1 = ops.rowscale_outer(W, c1)
     gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)                # a3^T a3 and colsum(a3) from one launch
     gw = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), c2, b4, c3, cs3)
     gw = ops.axpby(1.0, ops.gemm_nt(Wc1, _t(top["Qqa"]), exact=True), 1.0, gw)             # + diag(c1).W.(q3^T a3)
     ops.sparse_rows_tn(spB, argmax, N, ys[2], gw, pro=pro3)
     grads[conv + ".weight"] = ops.axpby(1.0, gw, 1.0, grads[conv + ".weight"]).view_as(P[conv + ".weight"])
     grads[conv + ".bias"] = ZERO_GRAD
-    G1, G2 = ops.gemm_tn(W, Wc1), ops.gemm_tn(W, Wc2)
-    cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(c2, c3, 1.0), exact=True)[0]
+    if W.shape[0] % 64 == 0 and W.shape[1] % 32 == 0:
+        G1 = ops.wt_diag_w(W, c1)                                                  # W^T diag(c1) W
+        G2, cvec = ops.wt_diag_w(W, c2, c3, b4)                                    # W^T diag(c2) W, (c2*b4 + c3).W
+    else:
+        G1, G2 = ops.gemm_tn(W, Wc1), ops.gemm_tn(W, ops.rowscale_outer(W, c2))
+        cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(c2, c3, 1.0), exact=True)[0]
     part = ops.gemm_nt(q3, G1, rowbias=ops.sparse_rows_nt(spB, argmax, N, W), rows_per_group=1)
     psc, psh, pinv, pmu = bns[2]
     return ops.gemm_nt_bnbwd(ys[2], G2, ys[2], psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part)
@@ -813,13 +820,17 @@ def adain_forward(P, pre: str, x: Tensor, style: Tensor, N: int, slope: float = 
     return out, dict(x=x, style=style, gb=gb, imean=imean, ivar=ivar, N=N, slope=slope)
 
 
-def adain_backward(P, pre: str, ctx, dout: Tensor, need_dx: bool = True, need_dstyle: bool = True, need_dparams: bool = True):
+def adain_backward(P, pre: str, ctx, dout: Tensor, need_dx: bool = True, need_dstyle: bool = True, need_dparams: bool = True,
+                   dstyle_addend: Optional[Tensor] = None):
     dx, dgb = ops.adain_bwd(dout.contiguous(), ctx["x"], ctx["N"], ctx["slope"], ctx["imean"], ctx["ivar"], ctx["gb"])
     g = {}
     if need_dparams:
         gws, g[pre + ".style.bias"] = ops.gemm_tn(dgb, ctx["style"], defer=True, with_colsum=True)
         g[pre + ".style.weight"] = gws.view_as(P[pre + ".style.weight"])
-    dstyle = ops.gemm_nt(dgb, _t(_w2(P[pre + ".style.weight"]))) if need_dstyle else None
+    dstyle = None
+    if need_dstyle:      # dstyle_addend: the style gradient of another AdaIN layer on the same style tensor, added in the GEMM's epilogue
+        kw = dict(rowbias=dstyle_addend.contiguous(), rows_per_group=1) if dstyle_addend is not None else {}
+        dstyle = ops.gemm_nt(dgb, _t(_w2(P[pre + ".style.weight"])), **kw)
     return (dx if need_dx else None), dstyle, g
 
 

@@ -867,6 +867,20 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
 
 
 # ----------------------------------------------------------------------------- reductions / norms
+def wt_diag_w(W: Tensor, alpha: Tensor, beta: Optional[Tensor] = None, bias: Optional[Tensor] = None):
+    """G = W^T diag(alpha) W [K,K] and (with beta, bias) cvec = (alpha*bias + beta) . W [K] of W [C,K] in one launch: the weight-only operands
+    of the collapsed backward of the layer in front of the max-pool.  Returns G, or (G, cvec)."""
+    _rowmajor2d(W, "W")
+    Cn, K = W.shape
+    if Cn % 64 or K % 32:
+        raise ValueError("wt_diag_w: W [C,K] with C % 64 == 0 and K % 32 == 0")
+    G = torch.empty((K, K), dtype=torch.float32, device=W.device)
+    cvec = torch.empty((K,), dtype=torch.float32, device=W.device) if beta is not None else None
+    check(_lib.load().spgan_wt_diag_w(_p(W), _ld(W), Cn, K, _p(_vec(alpha, Cn, "alpha")), _p(None if beta is None else _vec(beta, Cn, "beta")),
+                                      _p(None if beta is None else _vec(bias, Cn, "bias")), _p(G), K, _p(cvec), _s()), "wt_diag_w", C=Cn, K=K)
+    return G if cvec is None else (G, cvec)
+
+
 def sparse_rows_nt(val: Tensor, arg: Tensor, rows: int, W: Tensor) -> Tensor:
     """E[m,:] = sum_{c: arg[b,c]==m} val[b,c] * W[c,:]  (b = m // rows): the row-sparse product S @ W, written densely [B*rows, N]."""
     _f32(val, "val", 2); _rowmajor2d(W, "W")
@@ -1629,7 +1643,7 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float =
 
 
 def adam_step_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, state: Tensor, lr: float = 1e-4, beta1: float = 0.5, beta2: float = 0.99,
-                  eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+                  eps: float = 1e-8, grad_scale: float = 1.0, zero_grad: bool = False) -> None:
     """adam_step with the step count kept in `state` (4 floats on the device: int step bits, 1-beta1^t, 1/sqrt(1-beta2^t), and a
     multiplier on lr that schedules write); every call advances it.  Nothing host-side changes between steps: capturable in a
     hipGraph."""
@@ -1640,4 +1654,4 @@ def adam_step_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, state: Tensor, lr:
     _f32(state, "state")
     if state.numel() != 4 or not state.is_contiguous():
         raise ValueError("adam_step_dev: state must be 4 contiguous floats (step bits, two bias corrections, lr multiplier)")
-    check(_lib.load().spgan_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(state), grad_scale, _s()), "adam_step_dev")
+    check(_lib.load().spgan_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(state), grad_scale, 1 if zero_grad else 0, _s()), "adam_step_dev")

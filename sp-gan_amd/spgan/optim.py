@@ -61,7 +61,8 @@ class Adam:
     """Adam over a module's flat buffer.  `step()` == torch.optim.Adam(lr, betas, eps=1e-8).step();
     `zero_grad()` zeroes the flat gradient buffer in place."""
 
-    def __init__(self, module: nn.Module, lr: float = 1e-4, betas=(0.5, 0.99), eps: float = 1e-8, capturable: bool = False):
+    def __init__(self, module: nn.Module, lr: float = 1e-4, betas=(0.5, 0.99), eps: float = 1e-8, capturable: bool = False,
+                 zero_grad_in_step: bool = False):
         self.fp = flatten_module(module)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.m = torch.zeros_like(self.fp.flat)
@@ -72,15 +73,25 @@ class Adam:
         self.capturable = capturable
         self.dev_state = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=torch.float32, device=self.fp.flat.device) if capturable else None
         self.base_lr = lr
+        # zero_grad_in_step (capturable mode; TrainStep): step() leaves the flat gradient buffer zeroed -- the kernel has every gradient in a
+        # register anyway -- and the zero_grad() that follows it is a no-op instead of a fill launch.  Only for an owner that writes the
+        # gradients exclusively between zero_grad() and step().
+        self.zero_grad_in_step = bool(zero_grad_in_step and capturable)
+        self._grad_clean = False
 
     def zero_grad(self, set_to_none: bool = False):
+        if self._grad_clean:
+            self._grad_clean = False         # the previous step() zeroed the buffer; the parameters' .grad views are bound to it
+            return
         self.fp.zero_grad()
 
     def step(self, grad_scale: float = 1.0):
         self.t += 1
         ops.bump_weights_epoch(self.fp.flat)
         if self.capturable:
-            ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.dev_state, self.lr, self.betas[0], self.betas[1], self.eps, grad_scale)
+            ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.dev_state, self.lr, self.betas[0], self.betas[1], self.eps, grad_scale,
+                              zero_grad=self.zero_grad_in_step)
+            self._grad_clean = self.zero_grad_in_step
         else:
             ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps, grad_scale)
 

@@ -48,8 +48,8 @@ class TrainStep:
         self.dpD = DataParallel(D, process_group) if distributed else None
         if distributed:
             self.dpG.sync_params(); self.dpD.sync_params()
-        self.optG = Adam(G, lr_g, betas, capturable=graph)
-        self.optD = Adam(D, lr_d, betas, capturable=graph)
+        self.optG = Adam(G, lr_g, betas, capturable=graph, zero_grad_in_step=True)
+        self.optD = Adam(D, lr_d, betas, capturable=graph, zero_grad_in_step=True)
         G.train(); D.train()
         # reference_schedule=True evaluates exactly the calls of model.py:239-279, including the two pieces of work this harness
         # otherwise removes because they are provably redundant: EdgeConv1 on every copy of the tiled sphere prior

@@ -591,12 +591,14 @@ def adam_step(p, g, m, v, step, lr=1e-4, beta1=0.5, beta2=0.99, eps=1e-8, grad_s
     p.addcdiv_(m, denom, value=-lr / (1 - beta1 ** step))
 
 
-def adam_step_dev(p, g, m, v, state, lr=1e-4, beta1=0.5, beta2=0.99, eps=1e-8, grad_scale=1.0):
+def adam_step_dev(p, g, m, v, state, lr=1e-4, beta1=0.5, beta2=0.99, eps=1e-8, grad_scale=1.0, zero_grad=False):
     step = int(state[:1].view(torch.int32).item()) + 1
     state[:1].view(torch.int32).fill_(step)
     state[1] = 1.0 - beta1 ** step
     state[2] = 1.0 / math.sqrt(1.0 - beta2 ** step)
     adam_step(p, g, m, v, step, lr * float(state[3]), beta1, beta2, eps, grad_scale)
+    if zero_grad:
+        g.zero_()
 
 
 def act_bwd(dy, y, act, slope=0.0):
@@ -744,3 +746,10 @@ def gemm_dual(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=None, coef_b
         dW = out
     res = gemm_nt_bnbwd(dy, W.t().contiguous(), y_ref, scale, shift, mean, invstd, slope, edge=edge, **({} if coef_bn is None else dict(coef_bn=coef_bn)))
     return (dW,) + tuple(res)
+
+
+def wt_diag_w(W, alpha, beta=None, bias=None):
+    G = (W * alpha[:, None]).t() @ W
+    if beta is None:
+        return G.contiguous()
+    return G.contiguous(), ((alpha * bias + beta) @ W).contiguous()

@@ -127,3 +127,20 @@ def test_gemm_bn_pool(ops, B, N, K, C):
         agree = (arg == arg2).float().mean().item()
         assert agree > 0.99 or C == 70, agree
     close(rm, rm2, rtol=1e-5, atol=1e-6, what="running_mean"); close(rv, rv2, rtol=1e-5, what="running_var")
+
+
+@pytest.mark.parametrize("C,K", [(1024, 256), (512, 256), (64, 32)])
+def test_wt_diag_w(C, K):
+    """ops.wt_diag_w: W^T diag(alpha) W and (alpha*b + beta).W in one launch against float64 and against the launches it replaces."""
+    from spgan import ops
+    from test_kernels_gpu import close, rnd
+    W = rnd("wdw.W%d" % C, (C, K), 0.1)
+    alpha, beta, b = rnd("wdw.a%d" % C, (C,)), rnd("wdw.b%d" % C, (C,), 0.3), rnd("wdw.c%d" % C, (C,), 0.2)
+    G, cvec = ops.wt_diag_w(W, alpha, beta, b)
+    ref = (W.double() * alpha.double()[:, None]).t() @ W.double()
+    close(G, ref.float(), rtol=3e-6, atol=3e-6 * float(ref.abs().max()), what="G vs float64")
+    cref = (alpha.double() * b.double() + beta.double()) @ W.double()
+    close(cvec, cref.float(), rtol=3e-6, atol=3e-6 * float(cref.abs().max()), what="cvec vs float64")
+    close(G, ops.gemm_tn(W, ops.rowscale_outer(W, alpha)), rtol=3e-6, atol=3e-6 * float(ref.abs().max()), what="G vs gemm_tn")
+    G2 = ops.wt_diag_w(W, alpha)
+    assert torch.equal(G, G2) and torch.equal(ops.wt_diag_w(W, alpha, beta, b)[1], cvec)
