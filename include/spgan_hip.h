@@ -286,7 +286,7 @@ int spgan_gemm_dual(const spgan_gemm_dual_args* a, spgan_stream_t s);
  * Both sum in ascending c / b order (deterministic). */
 /* The two weight-only operands of that collapsed backward in one launch (csrc/collapse.hip), W [C, K]:
  *   G[i,j] = sum_c W[c,i]*alpha[c]*W[c,j]   (W^T diag(alpha) W, [K,K]);   cvec[j] = sum_c (alpha[c]*bias[c] + beta[c])*W[c,j]   (cvec NULL: skipped)
- * C % 64 == 0, K % 32 == 0; deterministic (fixed-order sums). */
+ * C % 256 == 0, K % 32 == 0; deterministic (fixed-order sums). */
 int spgan_wt_diag_w(const float* W, int ldw, int C, int K, const float* alpha, const float* beta, const float* bias, float* G, int ldg,
                     float* cvec, spgan_stream_t s);
 int spgan_sparse_rows_nt(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* W, int ldw, int N, float* E, int lde,

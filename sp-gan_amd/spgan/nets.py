@@ -431,7 +431,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
                 ops.sparse_rows_tn(dy.sp_val, dy.sp_arg, N, ys[2], dW, pro=pro3)
                 grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
                 grads[conv + ".bias"] = ZERO_GRAD
-            if W.shape[0] % 64 == 0 and W.shape[1] % 32 == 0:
+            if W.shape[0] % 256 == 0 and W.shape[1] % 32 == 0:
                 G4, cvec = ops.wt_diag_w(W, alpha, beta, b4)                      # W^T diag(alpha) W and (alpha*b4 + beta).W in one launch
             else:
                 G4 = ops.gemm_tn(W, ops.rowscale_outer(W, alpha))                     # W^T diag(alpha) W
@@ -533,7 +533,7 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
     ops.sparse_rows_tn(spB, argmax, N, ys[2], gw, pro=pro3)
     grads[conv + ".weight"] = ops.axpby(1.0, gw, 1.0, grads[conv + ".weight"]).view_as(P[conv + ".weight"])
     grads[conv + ".bias"] = ZERO_GRAD
-    if W.shape[0] % 64 == 0 and W.shape[1] % 32 == 0:
+    if W.shape[0] % 256 == 0 and W.shape[1] % 32 == 0:
         G1 = ops.wt_diag_w(W, c1)                                                  # W^T diag(c1) W
         G2, cvec = ops.wt_diag_w(W, c2, c3, b4)                                    # W^T diag(c2) W, (c2*b4 + c3).W
     else:

@@ -872,8 +872,8 @@ def wt_diag_w(W: Tensor, alpha: Tensor, beta: Optional[Tensor] = None, bias: Opt
     of the collapsed backward of the layer in front of the max-pool.  Returns G, or (G, cvec)."""
     _rowmajor2d(W, "W")
     Cn, K = W.shape
-    if Cn % 64 or K % 32:
-        raise ValueError("wt_diag_w: W [C,K] with C % 64 == 0 and K % 32 == 0")
+    if Cn % 256 or K % 32:
+        raise ValueError("wt_diag_w: W [C,K] with C % 256 == 0 and K % 32 == 0")
     G = torch.empty((K, K), dtype=torch.float32, device=W.device)
     cvec = torch.empty((K,), dtype=torch.float32, device=W.device) if beta is not None else None
     check(_lib.load().spgan_wt_diag_w(_p(W), _ld(W), Cn, K, _p(_vec(alpha, Cn, "alpha")), _p(None if beta is None else _vec(beta, Cn, "beta")),

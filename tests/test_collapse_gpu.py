@@ -129,7 +129,7 @@ def test_gemm_bn_pool(ops, B, N, K, C):
     close(rm, rm2, rtol=1e-5, atol=1e-6, what="running_mean"); close(rv, rv2, rtol=1e-5, what="running_var")
 
 
-@pytest.mark.parametrize("C,K", [(1024, 256), (512, 256), (64, 32)])
+@pytest.mark.parametrize("C,K", [(1024, 256), (512, 256), (256, 32)])
 def test_wt_diag_w(C, K):
     """ops.wt_diag_w: W^T diag(alpha) W and (alpha*b + beta).W in one launch against float64 and against the launches it replaces."""
     from spgan import ops

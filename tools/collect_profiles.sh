@@ -8,7 +8,8 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-python $R/bench.py --mfma f16 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_f16_operands.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --config c5 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_f16_operands.json 2>> $O/${TAG}_bench.err      # c5 = --mfma f16
+python $R/bench.py --config c4 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_c4.json 2>> $O/${TAG}_bench.err                # N = 4096, per-GPU batch 16
 python $R/bench.py --mfma bf16x3 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_bf16x3.json 2>> $O/${TAG}_bench.err
 rm -rf /tmp/prof_s; rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/bench_s.log 2>&1
 DB=$(find /tmp/prof_s -name "*.db" | head -1)
@@ -21,7 +22,10 @@ for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/g_$c; rocprofv3 --pmc $c --kernel
 python $R/tools/pmc_gemm_json.py $O/${TAG}_pmc_gemm_FETCH_SIZE.txt $O/${TAG}_pmc_gemm_WRITE_SIZE.txt ${TAG} > $O/${TAG}_pmc_gemm_nt.json
 python $R/tools/mfma_shapes.py > $O/${TAG}_mfma_shapes.txt 2>/dev/null
 python $R/tools/mfma_shapes.py --mfma f16 > $O/${TAG}_mfma_shapes_f16.txt 2>/dev/null
-python $R/tools/knn_ab.py > $O/${TAG}_knn_ab_raw.txt 2>&1
+(python $R/tools/knn_ab.py 2048 32; python $R/tools/knn_ab.py 4096 16) > $O/${TAG}_knn_ab.txt 2>&1
+python $R/tools/dual_bench.py > $O/${TAG}_dual_bench.txt 2>/dev/null
+rm -rf /tmp/prof_c4; rocprofv3 --kernel-trace --stats -d /tmp/prof_c4 -o r -- python $R/bench.py --config c4 --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/bench_c4.log 2>&1
+python $R/tools/rocprof_summary.py $(find /tmp/prof_c4 -name "*.db" | head -1) 31 > $O/${TAG}_bench_c4_kernel_stats.txt
 bash $R/tools/profile_f16.sh $TAG > /dev/null 2>&1      # kernel table of the "f16" operand mode
 python $R/tools/exp/wide_k_sweep.py > $O/${TAG}_wide_k_sweep.txt 2>/dev/null
 python $R/tools/exp/mid_k_sweep.py > $O/${TAG}_mid_k_sweep.txt 2>/dev/null
