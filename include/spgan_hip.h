@@ -250,17 +250,22 @@ int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s);
 
 /* The backward of one 1x1-conv layer behind a train-mode BatchNorm + LeakyReLU as ONE launch (csrc/gemm_dual.hip): the weight-gradient
  * product and the input-gradient product from ONE staging of the incoming gradient tile -- what autograd does with two convolution
- * backward kernels for conv_w.3 of an EdgeBlock (Generation/Generator.py:56-63,78) and mlps.3 of the Discriminator
- * (Generation/Discriminator.py:55-65); before: spgan_gemm_tn + spgan_gemm_nt with the BNBWD / EDGE_BNBWD epilogue.
- *   dy[m,:]  = A[m,:]*p + A2[m,:]*q + r        (A2 == NULL: dy = A)            [M, Na]   the layer's output gradient (lazy BatchNorm backward)
- *   pre[m,:] = B[m,:]                                                           [M, Nb]   the previous layer's pre-BatchNorm output, or
- *            = B[e_idx[m],:] - B[m / e_k,:] + e_bias   (e_idx != NULL: per-edge operand, B = the point tensor)
- *   ws[wg]   = sum over the rows of workgroup wg of dy^T . lrelu(pre*b_scale + b_shift, slope)       [wgs, Na, Nb] partials of dW
- *   G[m,:]   = (dy[m,:] . W) * (pre*b_scale + b_shift > 0 ? 1 : slope)          [M, Nb]
- *   stats    = per workgroup (sum G, sum G*xhat), xhat = (pre - b_mean)*b_invstd                      [wgs, Nb, 2] plain sums
- * wgs = spgan_gemm_dual_wgs(M, Na, Nb, e_k) (0: shape not supported -- Na = 128, Nb = 64, M % 32 == 0, M >= 8192, e_k 0 or 10; the
- * caller then uses the two separate launches).  dW = the fixed-order sum of the partials (spgan_splitk_reduce_multi with splits = wgs);
- * the statistics are finished by spgan_colstats_finalize(_bnbwd) with tiles = wgs, tile_rows = spgan_gemm_dual_rows_per_wg(M).  fp32 operands, 16-byte aligned rows. */
+ * backward kernels for conv_w.3 of an EdgeBlock (Generation/Generator.py:56-63,78), mlps.3 / mlps.6 of the Discriminator and the
+ * collapsed form of its fc2.0 (Generation/Discriminator.py:55-65,77-81,104); before: spgan_gemm_tn + spgan_gemm_nt with the BNBWD /
+ * EDGE_BNBWD epilogue.
+ *   dy[m,:]  = A[m,:]                                          a_mode 0 (dense)                      [M, Na]
+ *            = A[m,:]*p + A2[m,:]*q + r                        a_mode 1 (the lazy BatchNorm-backward operand of spgan_bn_bwd_coeffs)
+ *            = lrelu(A[m,:]*p + r, a_slope)                    a_mode 2 (an activation formed on load: the collapsed layer's a3)
+ *   pre[m,:] = B[m,:]                                                                               [M, Nb]   the previous layer's pre-BatchNorm output, or
+ *            = B[e_idx[m],:] - B[m / e_k,:] + e_bias   (e_idx != NULL: per-edge operand, B = the point tensor, Nb = 64)
+ *   ws[run]  = sum over the rows of run `run` of dy^T . lrelu(pre*b_scale + b_shift, slope)          [runs, Na, Nb] partials of dW
+ *   G[m,:]   = (dy[m,:] . W + bias + rowadd[m,:]) * (pre*b_scale + b_shift > 0 ? 1 : slope)          [M, Nb]   (bias [Nb], rowadd [M, Nb]: optional)
+ *   stats    = per run (sum G, sum G*xhat), xhat = (pre - b_mean)*b_invstd                           [runs, Nb, 2] plain sums
+ *   colsum_ws (optional) = per run the column sums of dy                                             [runs, Na]
+ * runs = spgan_gemm_dual_wgs(M, Na, Nb, e_k) (0: shape not supported -- (Na, Nb) = (128, 64), (256, 128) or (256, 256), M % 32 == 0,
+ * M >= 8192, e_k 10 only with (128, 64); the caller then uses the two separate launches).  dW = the fixed-order sum of the partials
+ * (spgan_splitk_reduce_multi with splits = runs); the statistics are finished by spgan_colstats_finalize(_bnbwd) with tiles = runs,
+ * tile_rows = spgan_gemm_dual_rows_per_wg(M, Na, Nb).  fp32 operands, 16-byte aligned rows. */
 typedef struct spgan_gemm_dual_args {
   const float* A; int lda;
   const float* A2; int lda2; const float* p; const float* q; const float* r;
@@ -271,9 +276,12 @@ typedef struct spgan_gemm_dual_args {
   float* G; int ldg;
   float* stats; float* ws;
   int M, Na, Nb;
+  int a_mode; float a_slope;
+  const float* bias; const float* rowadd; int ld_rowadd;
+  float* colsum_ws;
 } spgan_gemm_dual_args;
 int spgan_gemm_dual_wgs(int M, int Na, int Nb, int e_k);
-int spgan_gemm_dual_rows_per_wg(int M);          /* rows per workgroup = the `tile_rows` of the statistics partials (tiles = wgs = ceil(M / rows)) */
+int spgan_gemm_dual_rows_per_wg(int M, int Na, int Nb);   /* rows per run = the `tile_rows` of the statistics partials (tiles = runs = ceil(M / rows)) */
 int spgan_gemm_dual(const spgan_gemm_dual_args* a, spgan_stream_t s);
 
 /* Row-sparse products with the max-pool gradient pattern S (Discriminator.py:104 backward): one (value, row) pair per

@@ -85,6 +85,9 @@ class GemmDualArgs(C.Structure):
         ("G", c_f32p), ("ldg", C.c_int),
         ("stats", c_f32p), ("ws", c_f32p),
         ("M", C.c_int), ("Na", C.c_int), ("Nb", C.c_int),
+        ("a_mode", C.c_int), ("a_slope", C.c_float),
+        ("bias", c_f32p), ("rowadd", c_f32p), ("ld_rowadd", C.c_int),
+        ("colsum_ws", c_f32p),
     ]
 
 
@@ -188,7 +191,7 @@ SIGNATURES = {
     "spgan_group_concat": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
     "spgan_wt_diag_w": (I, [P, I, I, I, P, P, P, P, I, P, P]),
     "spgan_gemm_dual_wgs": (I, [I, I, I, I]),
-    "spgan_gemm_dual_rows_per_wg": (I, [I]),
+    "spgan_gemm_dual_rows_per_wg": (I, [I, I, I]),
     "spgan_gemm_dual": (I, [C.POINTER(GemmDualArgs), P]),
     "spgan_gather_csr": (I, [P, I, I, I, P, P, P, P]),
     "spgan_scatter_slots": (I, [P, I, I, I, P, P, I, P, P]),

@@ -425,12 +425,6 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             # a3 = lrelu(bn3(y3)) is never materialised: every consumer applies the affine + LeakyReLU to y3 on its operand load (both
             # sides of the Gram product, whose launch also yields colsum(a3); the sparse rows; the input-gradient GEMM)
             pro3 = (sc, sh, NEG)
-            if need_dparams:
-                gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)          # a3^T a3 [256,256], colsum(a3)
-                dW = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), alpha, b4, beta, cs3)     # gram: a sum over B*N points
-                ops.sparse_rows_tn(dy.sp_val, dy.sp_arg, N, ys[2], dW, pro=pro3)
-                grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
-                grads[conv + ".bias"] = ZERO_GRAD
             if W.shape[0] % 256 == 0 and W.shape[1] % 32 == 0:
                 G4, cvec = ops.wt_diag_w(W, alpha, beta, b4)                      # W^T diag(alpha) W and (alpha*b4 + beta).W in one launch
             else:
@@ -439,7 +433,21 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             E = ops.sparse_rows_nt(dy.sp_val, dy.sp_arg, N, W)                    # S.W, dense rows
             lazy = _lazy_ok(M, sc.numel())
             cb = dict(coef_bn=(P[D_LAYERS[2][1] + ".weight"], M)) if lazy else {}     # the finalize launch also emits the lazy operand's coefficients
-            g, s0, s1, *coef = ops.gemm_nt_bnbwd(ys[2], G4, ys[2], sc, sh, mu, inv, NEG, pro=pro3, bias=cvec, rowadd=E, **cb)
+            a3 = ops.ActOperand(ys[2], sc, sh, NEG)
+            if need_dparams and ops.gemm_dual_ok(a3, G4, ys[2]):
+                # the Gram matrix a3^T a3 (+ colsum(a3)) and the input-gradient product a3.G4 from ONE staging of the y3 tile (ops.gemm_dual
+                # with dy := a3, W := G4 -- symmetric --, pre := y3): both read the same tensor with the same BatchNorm + LeakyReLU on load
+                gram, g, s0, s1, *rest = ops.gemm_dual(a3, G4, ys[2], sc, sh, mu, inv, NEG, bias=cvec, rowadd=E, with_colsum=True, defer=False, **cb)
+                coef, cs3 = rest[:-1], rest[-1]
+            else:
+                if need_dparams:
+                    gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)      # a3^T a3 [256,256], colsum(a3)
+                g, s0, s1, *coef = ops.gemm_nt_bnbwd(ys[2], G4, ys[2], sc, sh, mu, inv, NEG, pro=pro3, bias=cvec, rowadd=E, **cb)
+            if need_dparams:
+                dW = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), alpha, b4, beta, cs3)     # gram: a sum over B*N points
+                ops.sparse_rows_tn(dy.sp_val, dy.sp_arg, N, ys[2], dW, pro=pro3)
+                grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
+                grads[conv + ".bias"] = ZERO_GRAD
             if need_dparams:
                 grads[D_LAYERS[2][1] + ".weight"] = s1; grads[D_LAYERS[2][1] + ".bias"] = s0
             sums = _cat2(s0, s1)
@@ -527,12 +535,7 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
     grads[bn + ".weight"] = dgamma
     grads[bn + ".bias"] = ZERO_GRAD
     Wc1 = ops.rowscale_outer(W, c1)
-    gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)                # a3^T a3 and colsum(a3) from one launch
-    gw = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), c2, b4, c3, cs3)
-    gw = ops.axpby(1.0, ops.gemm_nt(Wc1, _t(top["Qqa"]), exact=True), 1.0, gw)             # + diag(c1).W.(q3^T a3)
-    ops.sparse_rows_tn(spB, argmax, N, ys[2], gw, pro=pro3)
-    grads[conv + ".weight"] = ops.axpby(1.0, gw, 1.0, grads[conv + ".weight"]).view_as(P[conv + ".weight"])
-    grads[conv + ".bias"] = ZERO_GRAD
+    psc, psh, pinv, pmu = bns[2]
     if W.shape[0] % 256 == 0 and W.shape[1] % 32 == 0:
         G1 = ops.wt_diag_w(W, c1)                                                  # W^T diag(c1) W
         G2, cvec = ops.wt_diag_w(W, c2, c3, b4)                                    # W^T diag(c2) W, (c2*b4 + c3).W
@@ -540,8 +543,20 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
         G1, G2 = ops.gemm_tn(W, Wc1), ops.gemm_tn(W, ops.rowscale_outer(W, c2))
         cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(c2, c3, 1.0), exact=True)[0]
     part = ops.gemm_nt(q3, G1, rowbias=ops.sparse_rows_nt(spB, argmax, N, W), rows_per_group=1)
-    psc, psh, pinv, pmu = bns[2]
-    return ops.gemm_nt_bnbwd(ys[2], G2, ys[2], psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part)
+    a3 = ops.ActOperand(ys[2], pro3[0], pro3[1], NEG)
+    if ops.gemm_dual_ok(a3, G2, ys[2]):
+        # a3^T a3, colsum(a3) and the outgoing adjoint a3.G2 (+ addends, layer 3's mask / sums epilogue) from one staging of the y3 tile
+        gram, *abar, cs3 = ops.gemm_dual(a3, G2, ys[2], psc, psh, pmu, pinv, NEG, bias=cvec, rowadd=part, with_colsum=True, defer=False)
+        abar_g = tuple(abar)
+    else:
+        gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)            # a3^T a3 and colsum(a3) from one launch
+        abar_g = ops.gemm_nt_bnbwd(ys[2], G2, ys[2], psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part)
+    gw = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), c2, b4, c3, cs3)
+    gw = ops.axpby(1.0, ops.gemm_nt(Wc1, _t(top["Qqa"]), exact=True), 1.0, gw)             # + diag(c1).W.(q3^T a3)
+    ops.sparse_rows_tn(spB, argmax, N, ys[2], gw, pro=pro3)
+    grads[conv + ".weight"] = ops.axpby(1.0, gw, 1.0, grads[conv + ".weight"]).view_as(P[conv + ".weight"])
+    grads[conv + ".bias"] = ZERO_GRAD
+    return abar_g
 
 
 def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):

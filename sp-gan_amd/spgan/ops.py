@@ -640,13 +640,26 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
     return g, s0[0], s1[0]
 
 
+class ActOperand:
+    """A GEMM operand a = lrelu(x*scale + shift, slope) that is never materialised: the BatchNorm + LeakyReLU'd activation of a layer as
+    the `dy` side of gemm_dual (the collapsed backward of the layer in front of the max-pool: dy := a3 = lrelu(bn3(y3)))."""
+
+    def __init__(self, x: Tensor, scale: Tensor, shift: Tensor, slope: float):
+        self.x, self.scale, self.shift, self.slope = x, scale, shift, float(slope)
+        self.shape, self.device = x.shape, x.device
+
+    def dense(self) -> Tensor:
+        return affine_act(self.x, self.scale, self.shift, self.slope)
+
+
 def gemm_dual_ok(dy, W: Tensor, y_ref: Tensor, edge=None) -> bool:
-    """True when gemm_dual takes this layer backward (csrc/gemm_dual.hip: fp32 operands, dy 128 columns wide, 64 input channels, M % 32 == 0,
-    M >= 8192, per-edge operand with k = 10); otherwise the caller issues gemm_tn + gemm_nt_bnbwd."""
+    """True when gemm_dual takes this layer backward (csrc/gemm_dual.hip: fp32 operands, (columns of dy, input channels) = (128, 64),
+    (256, 128) or (256, 256), M % 32 == 0, M >= 8192, per-edge operand with k = 10 at (128, 64) only); otherwise the caller issues
+    gemm_tn + gemm_nt_bnbwd."""
     if _MFMA_F16[0] != 0 or _NT_TILE_HINT[0] != 0 or not GEMM_DUAL[0]:
         return False
     a2 = dy if isinstance(dy, Affine2) else None
-    g = a2.g if a2 is not None else dy
+    g = a2.g if a2 is not None else (dy.x if isinstance(dy, ActOperand) else dy)
     if not isinstance(g, Tensor) or g.dtype != torch.float32 or (a2 is not None and (a2.half or a2.y.dtype != torch.float32)):
         return False
     if W.dim() != 2 or y_ref.dtype != torch.float32:
@@ -659,15 +672,19 @@ GEMM_DUAL = [True]      # test hook: False sends every layer backward through th
 
 
 def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float, edge=None, coef_bn=None,
-              defer: bool = True, out: Optional[Tensor] = None, beta: float = 0.0):
+              defer: bool = True, out: Optional[Tensor] = None, beta: float = 0.0, bias: Optional[Tensor] = None, rowadd: Optional[Tensor] = None,
+              with_colsum: bool = False):
     """The weight-gradient AND the masked input-gradient product of one conv layer behind BatchNorm + LeakyReLU in one launch:
-      dW [Na,Nb] = dy^T . lrelu(pre*scale + shift),   g = (dy . W) * lrelu'(pre*scale + shift),   s0 = sum g,  s1 = sum g*xhat
-    dy: Affine2 (lazy BatchNorm backward) or a dense [M,Na] tensor; W [Na,Nb] the layer's weight as stored; pre = y_ref [M,Nb], or with
-    edge=(idx, ebias) the per-edge difference y_ref[idx[e]] - y_ref[e // k] + ebias of the point tensor y_ref.
-    Returns (dW, g, s0, s1) and, with coef_bn=(gamma, count), the lazy-operand coefficients [3,Nb] of the NEXT BatchNorm backward as a fifth
-    result.  dW's split sum is deferred like gemm_tn(defer=True): valid after flush_tn(); out / beta: dW = beta*out + sum (accumulated in place)."""
+      dW [Na,Nb] = dy^T . lrelu(pre*scale + shift),   g = (dy . W + bias + rowadd) * lrelu'(pre*scale + shift),   s0 = sum g,  s1 = sum g*xhat
+    dy: Affine2 (lazy BatchNorm backward), ActOperand (an activation formed on load) or a dense [M,Na] tensor; W [Na,Nb] the layer's weight
+    as stored; pre = y_ref [M,Nb], or with edge=(idx, ebias) the per-edge difference y_ref[idx[e]] - y_ref[e // k] + ebias of the point
+    tensor y_ref; bias [Nb] / rowadd [M,Nb]: optional addends of the input gradient in front of the mask.
+    Returns (dW, g, s0, s1) [+ coef [3,Nb] with coef_bn=(gamma, count): the lazy-operand coefficients of the NEXT BatchNorm backward]
+    [+ colsum(dy) [Na] with with_colsum].  dW's (and the column sums') split sum is deferred like gemm_tn(defer=True): valid after
+    flush_tn(); out / beta: dW = beta*out + sum (accumulated in place)."""
     a2 = dy if isinstance(dy, Affine2) else None
-    A = a2.g if a2 is not None else dy
+    act = dy if isinstance(dy, ActOperand) else None
+    A = a2.g if a2 is not None else (act.x if act is not None else dy)
     _rowmajor2d(A, "dy"); _rowmajor2d(W, "W"); _rowmajor2d(y_ref, "y_ref")
     M_, Na = A.shape
     Nb = W.shape[1]
@@ -675,16 +692,20 @@ def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: 
         raise ValueError("W must be [Na, Nb] with Na = columns of dy")
     lib = _lib.load()
     ek = 0 if edge is None else int(edge[0].shape[1])
-    wgs = lib.spgan_gemm_dual_wgs(M_, Na, Nb, ek)
-    if not wgs:
+    runs = lib.spgan_gemm_dual_wgs(M_, Na, Nb, ek)
+    if not runs:
         raise ValueError("gemm_dual: unsupported shape M=%d Na=%d Nb=%d k=%d (see gemm_dual_ok)" % (M_, Na, Nb, ek))
-    rows_wg = lib.spgan_gemm_dual_rows_per_wg(M_)
+    rows_wg = lib.spgan_gemm_dual_rows_per_wg(M_, Na, Nb)
     a = GemmDualArgs()
     a.A = _p(A); a.lda = _ld(A)
     if a2 is not None:
         _rowmajor2d(a2.y, "dy.y")
+        a.a_mode = 1
         a.A2 = _p(a2.y); a.lda2 = _ld(a2.y)
         a.p = _p(_vec(a2.p, Na, "p")); a.q = _p(_vec(a2.q, Na, "q")); a.r = _p(_vec(a2.r, Na, "r"))
+    elif act is not None:
+        a.a_mode = 2; a.a_slope = act.slope
+        a.p = _p(_vec(act.scale, Na, "scale")); a.r = _p(_vec(act.shift, Na, "shift"))
     a.W = _p(W); a.ldw = _ld(W)
     a.B = _p(y_ref); a.ldb = _ld(y_ref)
     if edge is not None:
@@ -697,34 +718,49 @@ def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: 
         raise ValueError("dy and y_ref disagree on the rows: %d vs %d" % (M_, y_ref.shape[0]))
     a.b_scale = _p(_vec(scale, Nb, "scale")); a.b_shift = _p(_vec(shift, Nb, "shift"))
     a.b_mean = _p(_vec(mean, Nb, "mean")); a.b_invstd = _p(_vec(invstd, Nb, "invstd")); a.slope = float(slope)
+    if bias is not None:
+        a.bias = _p(_vec(bias, Nb, "bias"))
+    if rowadd is not None:
+        _rowmajor2d(rowadd, "rowadd")
+        if tuple(rowadd.shape) != (M_, Nb):
+            raise ValueError("rowadd must be [M,Nb]")
+        a.rowadd = _p(rowadd); a.ld_rowadd = _ld(rowadd)
     g = torch.empty((M_, Nb), dtype=torch.float32, device=A.device)
-    part = torch.empty((wgs, Nb, 2), dtype=torch.float32, device=A.device)
-    ws = torch.empty((wgs, Na, Nb), dtype=torch.float32, device=A.device)
+    part = torch.empty((runs, Nb, 2), dtype=torch.float32, device=A.device)
+    ws = torch.empty((runs, Na, Nb), dtype=torch.float32, device=A.device)
     if out is None:
         dW, beta = torch.empty((Na, Nb), dtype=torch.float32, device=A.device), 0.0
     else:
         dW = _rowmajor2d(out, "out")
         if tuple(out.shape) != (Na, Nb):
             raise ValueError("out must be [Na, Nb]")
+    cs_ws = cs_out = None
+    if with_colsum:
+        cs_ws = torch.empty((runs, Na), dtype=torch.float32, device=A.device)
+        cs_out = torch.empty((Na,), dtype=torch.float32, device=A.device)
+        a.colsum_ws = _p(cs_ws)
     a.G = _p(g); a.ldg = Nb; a.stats = _p(part); a.ws = _p(ws)
     a.M, a.Na, a.Nb = M_, Na, Nb
     done = launch_timer("gemm_dual", a) if launch_timer is not None else None
     check(lib.spgan_gemm_dual(C.byref(a), _s()), "gemm_dual", M=M_, Na=Na, Nb=Nb, k=ek)
     if done is not None:
         done()
-    _PENDING_TN.append((ws, dW, wgs, Na, Nb, _ld(dW), float(beta)))
+    _PENDING_TN.append((ws, dW, runs, Na, Nb, _ld(dW), float(beta)))
+    if cs_ws is not None:
+        _PENDING_TN.append((cs_ws, cs_out, runs, 1, Na, Na, 0.0))           # [runs][1 x Na] partials: one more entry of the multi-reduce
     if not defer:
         flush_tn()
+    extra = () if cs_out is None else (cs_out,)
     if coef_bn is not None:
         gamma, count = coef_bn
-        out = torch.empty((2, Nb), dtype=torch.float32, device=A.device)
+        fin = torch.empty((2, Nb), dtype=torch.float32, device=A.device)
         coef = torch.empty((3, Nb), dtype=torch.float32, device=A.device)
-        check(lib.spgan_colstats_finalize_bnbwd(_p(part), wgs, Nb, M_, rows_wg, _p(_vec(mean, Nb, "mean")), _p(_vec(invstd, Nb, "invstd")),
-                                                _p(None if gamma is None else _vec(gamma, Nb, "gamma")), float(count), _p(out[0]), _p(out[1]), _p(coef), _s()),
+        check(lib.spgan_colstats_finalize_bnbwd(_p(part), runs, Nb, M_, rows_wg, _p(_vec(mean, Nb, "mean")), _p(_vec(invstd, Nb, "invstd")),
+                                                _p(None if gamma is None else _vec(gamma, Nb, "gamma")), float(count), _p(fin[0]), _p(fin[1]), _p(coef), _s()),
               "colstats_finalize_bnbwd", N=Nb, M=M_)
-        return dW, g, out[0], out[1], coef
-    s0, s1 = _finalize(part, 1, wgs, Nb, M_, 1, rows_wg)
-    return dW, g, s0[0], s1[0]
+        return (dW, g, fin[0], fin[1], coef) + extra
+    s0, s1 = _finalize(part, 1, runs, Nb, M_, 1, rows_wg)
+    return (dW, g, s0[0], s1[0]) + extra
 
 
 _PENDING_TN: list = []      # deferred split-K reductions: (ws, out, splits, Na, Nb, ldc, beta); see gemm_tn(defer=True) / flush_tn()

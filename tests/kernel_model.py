@@ -731,21 +731,35 @@ def capturing():
 GEMM_DUAL = [True]
 
 
+class ActOperand:
+    def __init__(self, x, scale, shift, slope):
+        self.x, self.scale, self.shift, self.slope = x, scale, shift, float(slope)
+        self.shape, self.device = x.shape, x.device
+
+    def dense(self):
+        return _lrelu(self.x * self.scale + self.shift, self.slope)
+
+
 def gemm_dual_ok(dy, W, y_ref, edge=None):
-    g = dy.g if isinstance(dy, Affine2) else dy
+    g = dy.g if isinstance(dy, Affine2) else (dy.x if isinstance(dy, ActOperand) else dy)
     ek = 0 if edge is None else int(edge[0].shape[1])
+    shape = (W.shape[0], W.shape[1])
     # (the HIP kernel wants M >= 8192; the model takes the small sizes of the CPU host-composition tests too, so that they run the fused route)
-    return bool(GEMM_DUAL[0] and W.shape[0] == 128 and W.shape[1] == 64 and g.shape[0] % 32 == 0 and ek in (0, 10))
+    return bool(GEMM_DUAL[0] and g.shape[0] % 32 == 0 and ((shape == (128, 64) and ek in (0, 10)) or (shape in ((256, 128), (256, 256)) and ek == 0)))
 
 
-def gemm_dual(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=None, coef_bn=None, defer=True, out=None, beta=0.0):
+def gemm_dual(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=None, coef_bn=None, defer=True, out=None, beta=0.0, bias=None, rowadd=None,
+              with_colsum=False):
     """= gemm_tn(dy, y_ref, pro / edge) and gemm_nt_bnbwd(dy, W^T, y_ref, ...) of the same operands."""
-    dW = gemm_tn(dy, y_ref, pro=(scale, shift, slope), edge=edge)
+    d = dy.dense() if isinstance(dy, ActOperand) else dy
+    dW = gemm_tn(d, y_ref, pro=(scale, shift, slope), edge=edge)
     if out is not None:
         out.copy_(beta * out + dW)
         dW = out
-    res = gemm_nt_bnbwd(dy, W.t().contiguous(), y_ref, scale, shift, mean, invstd, slope, edge=edge, **({} if coef_bn is None else dict(coef_bn=coef_bn)))
-    return (dW,) + tuple(res)
+    res = gemm_nt_bnbwd(d, W.t().contiguous(), y_ref, scale, shift, mean, invstd, slope, edge=edge, bias=bias, rowadd=rowadd,
+                        **({} if coef_bn is None else dict(coef_bn=coef_bn)))
+    extra = (_dense(d).sum(0),) if with_colsum else ()
+    return (dW,) + tuple(res) + extra
 
 
 def wt_diag_w(W, alpha, beta=None, bias=None):

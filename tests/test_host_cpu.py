@@ -35,6 +35,7 @@ def spgan_cpu(monkeypatch):
         monkeypatch.setattr(ops, name, fn)
     monkeypatch.setattr(ops, "SparseAffine", km.SparseAffine)          # isinstance checks in nets.py select the collapsed paths
     monkeypatch.setattr(ops, "Affine2", km.Affine2)
+    monkeypatch.setattr(ops, "ActOperand", km.ActOperand)
     monkeypatch.setattr(modules, "_require_gpu", lambda t, what: None)
     return types.SimpleNamespace(ops=ops, modules=modules)
 

@@ -596,3 +596,59 @@ def test_gemm_dual_edge(ops):
     close(dW, ref.float(), rtol=2e-5, atol=2e-5 * float(ref.abs().max()), what="edge weight gradient vs float64")
     r64 = (d64 @ W2.double()) * torch.where(z > 0, 1.0, 0.01)
     close(g1, r64.float(), rtol=1e-5, atol=1e-5 * float(r64.abs().max()), what="edge input gradient vs float64")
+
+
+@pytest.mark.parametrize("M,Nb,mode", [(16384, 128, "lazy"), (65536, 128, "dense"), (16384, 256, "act"), (65536, 256, "act")])
+def test_gemm_dual_wide(ops, M, Nb, mode):
+    """The 256-column geometry of ops.gemm_dual (512 threads, 2 / 4 column parts per row run): the Discriminator's mlps.6 backward
+    (lazy / dense dy, Nb = 128) and the collapsed fc2.0 (dy := a3 = lrelu(bn3(y3)) formed on load, W := a symmetric K x K matrix, pre := y3
+    itself, bias + dense row addend in front of the mask, colsum(a3) as a by-product; Nb = 256) -- against float64 and the launches it replaces."""
+    Na = 256
+    sc, sh = rnd("gdw.sc%d" % Nb, (Nb,)), rnd("gdw.sh%d" % Nb, (Nb,), 0.3)
+    mu, iv = rnd("gdw.mu%d" % Nb, (Nb,), 0.2), rnd("gdw.iv%d" % Nb, (Nb,)).abs() + 0.5
+    if mode == "act":
+        y3 = rnd("gdw.y3.%d" % M, (M, Na), 1.5)
+        dy = ops.ActOperand(y3, sc, sh, 0.01)
+        dense, prev = dy.dense(), y3
+        Wm = rnd("gdw.G", (Na, Na), 0.05); Wm = (Wm + Wm.t()).contiguous()
+        bias, radd = rnd("gdw.cv", (Nb,), 0.2), rnd("gdw.E%d" % M, (M, Nb), 0.3)
+        kw = dict(bias=bias, rowadd=radd, with_colsum=True)
+    else:
+        g, y = rnd("gdw.g%d" % M, (M, Na)), rnd("gdw.y%d" % M, (M, Na), 2.0) + 0.3
+        mean, inv = y.mean(0), 1.0 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+        gamma = rnd("gdw.ga", (Na,)).abs() + 0.5
+        sums = torch.cat([g.sum(0), (g * ((y - mean) * inv)).sum(0)])
+        dy = ops.bn_bwd_lazy(g, y, mean, inv, gamma, sums, M) if mode == "lazy" else ops.bn_bwd_apply(g, y, mean, inv, gamma, sums, M)
+        dense = dy.dense() if mode == "lazy" else dy
+        prev = rnd("gdw.prev%d" % M, (M, Nb), 1.5)
+        Wm = rnd("gdw.W", (Na, Nb), 0.1)
+        bias = radd = None
+        kw = {}
+    assert ops.gemm_dual_ok(dy, Wm, prev)
+    res = ops.gemm_dual(dy, Wm, prev, sc, sh, mu, iv, 0.01, defer=False, **kw)
+    dW, gz, s0, s1 = res[:4]
+    d64, p64 = dense.double(), prev.double()
+    z = p64 * sc.double() + sh.double()
+    a64 = torch.where(z > 0, z, z * 0.01)
+    ref = d64.t() @ a64
+    close(dW, ref.float(), rtol=2e-5, atol=2e-5 * float(ref.abs().max()), what="weight gradient vs float64")
+    acc = d64 @ Wm.double()
+    if bias is not None:
+        acc = acc + bias.double() + radd.double()
+    g64 = acc * torch.where(z > 0, 1.0, 0.01)
+    xh = (p64 - mu.double()) * iv.double()
+    close(gz, g64.float(), rtol=1e-5, atol=1e-5 * float(g64.abs().max()), what="input gradient vs float64")
+    close(s0, g64.sum(0).float(), rtol=1e-5, atol=3e-5 * float(g64.abs().sum(0).max()), what="sum g")
+    close(s1, (g64 * xh).sum(0).float(), rtol=1e-5, atol=3e-5 * float((g64 * xh).abs().sum(0).max()), what="sum g*xhat")
+    if mode == "act":
+        close(res[4], d64.sum(0).float(), rtol=1e-5, atol=3e-5 * float(d64.abs().sum(0).max()), what="colsum(a3)")
+        g2, t0, t1 = ops.gemm_nt_bnbwd(prev, Wm, prev, sc, sh, mu, iv, 0.01, pro=(sc, sh, 0.01), bias=bias, rowadd=radd)
+        gram, cs = ops.gemm_tn(prev, prev, a_pro=(sc, sh, 0.01), pro=(sc, sh, 0.01), with_colsum=True)
+        close(dW, gram, rtol=1e-5, atol=1e-5 * float(gram.abs().max()), what="vs gemm_tn (Gram)")
+        close(res[4], cs, rtol=1e-5, atol=1e-5 * float(cs.abs().max()), what="colsum vs gemm_tn by-product")
+    else:
+        g2, t0, t1 = ops.gemm_nt_bnbwd(dy, Wm.t().contiguous(), prev, sc, sh, mu, iv, 0.01)
+        close(dW, ops.gemm_tn(dy, prev, pro=(sc, sh, 0.01)), rtol=1e-5, atol=1e-5 * float(dW.abs().max()), what="vs gemm_tn")
+    close(gz, g2, rtol=3e-6, atol=3e-6 * float(g2.abs().max()), what="vs gemm_nt_bnbwd")
+    res2 = ops.gemm_dual(dy, Wm, prev, sc, sh, mu, iv, 0.01, defer=False, **kw)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(res, res2)), "not deterministic"

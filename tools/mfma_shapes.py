@@ -21,7 +21,7 @@ class Shapes(bench.MfmaAccounting):
             elif kind == "gemm_tn":
                 key = ("tn", a.M, a.Na, a.Nb, "b%d%s%s" % (a.b_mode, " sparseA" if a.a_scale else "", " defer" if a.defer_reduce else ""))
             elif kind == "gemm_dual":
-                key = ("dual", a.M, a.Na, a.Nb, "dgrad+wgrad%s%s" % (" lazyA" if a.A2 else "", " edge" if a.e_idx else ""))
+                key = ("dual", a.M, a.Na, a.Nb, "dgrad+wgrad%s%s" % ({0: "", 1: " lazyA", 2: " actA"}.get(int(a.a_mode), ""), " edge" if a.e_idx else ""))
             else:
                 key = ("knn", a.B * a.N, a.N, a.C, "k%d" % a.k)
             self.rec[-1] = self.rec[-1] + (key,)
