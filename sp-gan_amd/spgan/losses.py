@@ -189,6 +189,20 @@ class GradientPenalty:
         v = ops.gp_penalty_bwd(g, norms, float(self.gamma), float(self.lambdaGP), None)
         return loss, grads, v.view_as(grads)
 
+    def with_grads_pm(self, netD, x_hat_pm, pre, B: int):
+        """with_grads for TrainStep's point-major route: x_hat_pm [B*N,3] = interpolates (already evaluated by
+        netD.forward_stacks_grouped(..., pm_shape=(B,N)) as `pre`); the input gradient comes back point-major, the penalty's per-shape norm
+        runs over the same 3N values of a shape in either layout."""
+        x_hat_pm = x_hat_pm.requires_grad_(True)
+        with input_grad_only():
+            disc = netD(x_hat_pm, pre=pre)
+            grads = torch.autograd.grad(outputs=disc, inputs=x_hat_pm, grad_outputs=_ones_like(disc), create_graph=True, retain_graph=True,
+                                        only_inputs=True)[0]
+        g = grads.detach().contiguous().view(B, -1)
+        loss, norms = ops.gp_penalty_fwd(g, float(self.gamma), float(self.lambdaGP))
+        v = ops.gp_penalty_bwd(g, norms, float(self.gamma), float(self.lambdaGP), None)
+        return loss, grads, v.view_as(grads)
+
     def interpolate(self, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False):
         """x_hat [B,3,N] (detached): the points the penalty is evaluated at."""
         B = real_data.size(0)

@@ -291,7 +291,7 @@ class Generator(nn.Module, _BNCounts):
         hz = ops.concat2(x.reshape(B * N, 3), z.reshape(B * N, -1))
         return self._mlp2(self.head, hz)
 
-    def _body(self, x, style):
+    def _body(self, x, style, pm_out: bool = False):
         B, N, _ = x.shape
         pc = x.reshape(B * N, 3).contiguous()
         feat = self._mlp2(self.pc_head, pc) if self.use_head else pc
@@ -374,12 +374,16 @@ class Generator(nn.Module, _BNCounts):
             out = Fn.MLPFn.apply(th, feat, *self._params_of(Fn.GT_NAMES[len(Fn.GF_NAMES):]))
         else:
             out = Fn.GlobalTailFn.apply(h, x2, *self._params_of(Fn.GT_NAMES))
+        if pm_out and not self.off:
+            return out                              # [B*N,3] point-major: TrainStep's internal route hands it to the Discriminator as it is
         out = Fn.PmToCm.apply(out, B, N)
         return x.transpose(2, 1) + out if self.off else out
 
-    def forward(self, x, z):
+    def forward(self, x, z, pm_out: bool = False):
+        """pm_out=True (TrainStep's internal route; not with --off): return the cloud point-major [B*N,3], i.e. without the final layout
+        change to the reference's [B,3,N] -- Discriminator.forward_stacks_grouped / forward(..., pm_shape=(B,N)) take it as it is."""
         _require_gpu(x, "Generator")
-        return self._body(x, self._style(x, z))
+        return self._body(x, self._style(x, z), pm_out=pm_out)
 
     def inject_graph2(self, graphs) -> None:
         """EdgeConv2's neighbour graph for the next len(graphs) forwards, consumed in order (see _body).  None = build it."""
@@ -424,7 +428,7 @@ class Discriminator(nn.Module, _BNCounts):
         h = _Holder(names=names, buffers=_buffers(self), training=self.training, pre=pre)
         return Fn.DiscriminatorFn.apply(h, x.contiguous(), *params)
 
-    def forward_stack_after_stats_pass(self, stats_x, x):
+    def forward_stack_after_stats_pass(self, stats_x, x, pm_shape=None):
         """The side effect of a train-mode D(stats_x) whose result nobody reads (`advance_running_stats`) followed by the conv stack of
         D(x), the shared first three layers of the two passes as one batch (nets.d_forward_after_stats_pass): the G step's
         D(real); D(G(z)).  Returns the entry to hand to `forward(x, pre=...)`."""
@@ -435,9 +439,9 @@ class Discriminator(nn.Module, _BNCounts):
         names, params = _named(self)
         with torch.no_grad():
             P = dict(zip(names, [nets.owned(p) for p in params]))
-            return nets.d_forward_after_stats_pass(P, _buffers(self), stats_x.detach(), x.detach())
+            return nets.d_forward_after_stats_pass(P, _buffers(self), stats_x.detach(), x.detach(), pm_shape=pm_shape)
 
-    def forward_stacks_grouped(self, xs):
+    def forward_stacks_grouped(self, xs, pm_shape=None):
         """The conv stacks of several train-mode passes as ONE batch (nets.d_forward_groups): one GEMM and one finalize launch per layer
         for all of them, per-pass BatchNorm statistics, running statistics advanced in list order -- bit-identical to separate calls.
         Returns one opaque entry per input, to be handed to `forward(x, pre=...)` or `forward_stack(x, pre=...)` of the same input."""
@@ -449,7 +453,7 @@ class Discriminator(nn.Module, _BNCounts):
         names, params = _named(self)
         with torch.no_grad():
             P = dict(zip(names, [nets.owned(p) for p in params]))
-            return nets.d_forward_groups(P, _buffers(self), [x.detach() for x in xs])
+            return nets.d_forward_groups(P, _buffers(self), [x.detach() for x in xs], pm_shape=pm_shape)
 
 
 def _discriminator_forward_many(self, *xs):

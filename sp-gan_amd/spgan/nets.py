@@ -268,7 +268,7 @@ def d_forward(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], x_cm: Ten
     return logits, ctx
 
 
-def d_forward_groups(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], xs_cm, update_running: bool = True):
+def d_forward_groups(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], xs_cm, update_running: bool = True, pm_shape=None):
     """The conv stacks of several train-mode passes D(x_0), D(x_1), ... as ONE batch: every layer is a single GEMM over the rows of all
     passes (ops.gemm_bn_groups), every pass keeps its own BatchNorm batch statistics, and the running statistics (and call counts)
     advance pass after pass in list order -- the activations, statistics and buffers are those of separate d_forward(head=False) calls
@@ -276,11 +276,20 @@ def d_forward_groups(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], xs
     Returns [(pooled_g [B,C4], ctx_g)]: the contexts are VIEWS of the batched tensors, laid out exactly like d_forward's, so d_backward /
     d_double_backward run per pass unchanged.  Needs equal shapes and N % 128 == 0."""
     G = len(xs_cm)
-    B, _, N = xs_cm[0].shape
-    M = B * N
-    if any(tuple(x.shape) != (B, 3, N) for x in xs_cm) or N % ops.ROW_TILE:
-        raise ValueError("d_forward_groups needs equally shaped inputs [B,3,N] with N %% %d == 0" % ops.ROW_TILE)
-    x_pm = ops.cm_to_pm(torch.cat([x.contiguous() for x in xs_cm], dim=0))            # [G*M, 3]
+    if pm_shape is not None:
+        # pm_shape = (B, N): the inputs are POINT-major [B*N, 3] already (TrainStep's internal route: the generator's output before its
+        # layout change, the real cloud as the loader delivers it) -- no [B,3,N] round trip; d_backward then returns dx point-major too
+        B, N = pm_shape
+        M = B * N
+        if any(tuple(x.shape) != (M, 3) for x in xs_cm) or N % ops.ROW_TILE:
+            raise ValueError("d_forward_groups(pm_shape=(B,N)) needs inputs [B*N,3] with N %% %d == 0" % ops.ROW_TILE)
+        x_pm = torch.cat([x.contiguous() for x in xs_cm], dim=0)
+    else:
+        B, _, N = xs_cm[0].shape
+        M = B * N
+        if any(tuple(x.shape) != (B, 3, N) for x in xs_cm) or N % ops.ROW_TILE:
+            raise ValueError("d_forward_groups needs equally shaped inputs [B,3,N] with N %% %d == 0" % ops.ROW_TILE)
+        x_pm = ops.cm_to_pm(torch.cat([x.contiguous() for x in xs_cm], dim=0))            # [G*M, 3]
     ys_all, outs = [], []
     a, pro = x_pm, None
     for li, (conv, bn) in enumerate(D_LAYERS):
@@ -305,22 +314,30 @@ def d_forward_groups(P: Dict[str, Tensor], bufs: Optional[Dict[str, Tensor]], xs
         ys = [None if y is None else y[g * M:(g + 1) * M] for y in ys_all]
         bns = [(o[0, g], o[1, g], o[2, g], o[3, g]) for o in outs]
         sl = slice(g * B, (g + 1) * B)
-        ctx = dict(B=B, N=N, x_pm=x_pm[g * M:(g + 1) * M], ys=ys, bns=bns, pooled=pooled[sl], argmax=argmax[sl], yarg=yarg[sl], hs=None, training=True)
+        ctx = dict(B=B, N=N, x_pm=x_pm[g * M:(g + 1) * M], ys=ys, bns=bns, pooled=pooled[sl], argmax=argmax[sl], yarg=yarg[sl], hs=None, training=True,
+                   pm_io=pm_shape is not None)
         res.append((pooled[sl], ctx))
     return res
 
 
-def d_forward_after_stats_pass(P: Dict[str, Tensor], bufs: Dict[str, Tensor], stats_cm: Tensor, x_cm: Tensor):
+def d_forward_after_stats_pass(P: Dict[str, Tensor], bufs: Dict[str, Tensor], stats_cm: Tensor, x_cm: Tensor, pm_shape=None):
     """d_advance_running_stats(stats_cm) followed by d_forward(x_cm, head=False) -- the G step's D(real) side effect and D(G(z)) -- with
     the first three layers of the two passes evaluated as ONE batch (per-pass BatchNorm, running statistics real first): three GEMM and
     three finalize launches instead of six and six.  The 1024-wide layer stays separate: the statistics pass replaces it by the
     covariance form (d_advance_running_stats), the real pass runs it with the pooling epilogue.  Bit-identical to the two calls.
     Returns (pooled, ctx) of x_cm."""
-    B, _, N = x_cm.shape
-    M = B * N
-    if tuple(stats_cm.shape) != (B, 3, N) or N % ops.ROW_TILE:
-        raise ValueError("d_forward_after_stats_pass needs equally shaped inputs [B,3,N] with N %% %d == 0" % ops.ROW_TILE)
-    x_pm = ops.cm_to_pm(torch.cat([stats_cm.contiguous(), x_cm.contiguous()], dim=0))
+    if pm_shape is not None:               # point-major inputs [B*N,3] (see d_forward_groups)
+        B, N = pm_shape
+        M = B * N
+        if tuple(stats_cm.shape) != (M, 3) or tuple(x_cm.shape) != (M, 3) or N % ops.ROW_TILE:
+            raise ValueError("d_forward_after_stats_pass(pm_shape=(B,N)) needs inputs [B*N,3] with N %% %d == 0" % ops.ROW_TILE)
+        x_pm = torch.cat([stats_cm.contiguous(), x_cm.contiguous()], dim=0)
+    else:
+        B, _, N = x_cm.shape
+        M = B * N
+        if tuple(stats_cm.shape) != (B, 3, N) or N % ops.ROW_TILE:
+            raise ValueError("d_forward_after_stats_pass needs equally shaped inputs [B,3,N] with N %% %d == 0" % ops.ROW_TILE)
+        x_pm = ops.cm_to_pm(torch.cat([stats_cm.contiguous(), x_cm.contiguous()], dim=0))
     ys_all, outs = [], []
     a, pro = x_pm, None
     for conv, bn in D_LAYERS[:3]:
@@ -342,7 +359,7 @@ def d_forward_after_stats_pass(P: Dict[str, Tensor], bufs: Dict[str, Tensor], st
     _count_bn_call(bufs, bn)
     ys = [y[M:] for y in ys_all] + [None]
     bns = [(o[0, 1], o[1, 1], o[2, 1], o[3, 1]) for o in outs] + [(sc, sh, inv, mu)]
-    ctx = dict(B=B, N=N, x_pm=x_pm[M:], ys=ys, bns=bns, pooled=pooled, argmax=argmax, yarg=yarg, hs=None, training=True)
+    ctx = dict(B=B, N=N, x_pm=x_pm[M:], ys=ys, bns=bns, pooled=pooled, argmax=argmax, yarg=yarg, hs=None, training=True, pm_io=pm_shape is not None)
     return pooled, ctx
 
 
@@ -485,7 +502,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
     dx_cm = None
     if need_dx:
         dx_pm = ops.gemm_nt(dy, _t(_w2(P["mlps.0.weight"])))
-        dx_cm = ops.pm_to_cm(dx_pm, B, N)
+        dx_cm = dx_pm if ctx.get("pm_io") else ops.pm_to_cm(dx_pm, B, N)        # the layout the input came in
     saved = None
     if keep_for_double:
         saved = dict(dout=dout, dhs=dhs, gval=gval, dys=dys, gs=gs, sums=sums_all)
@@ -571,7 +588,7 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
     dys, gs, sums_all = saved["dys"], saved["gs"], saved["sums"]
     grads: Dict[str, Tensor] = {}
     rM = 1.0 / M
-    q = ops.cm_to_pm(v_dx_cm.contiguous())                       # adjoint of ga_0 [M,3]
+    q = v_dx_cm.contiguous() if ctx.get("pm_io") else ops.cm_to_pm(v_dx_cm.contiguous())     # adjoint of ga_0 [M,3]
     xbarA: List[Optional[Tensor]] = [None] * 4                   # phase-A adjoint on xhat_l
     coeffs: List[Optional[Tensor]] = [None] * 4                  # per-channel phase-A results [4,C] (see ops.bn_dbl_coeffs)
     # ---------------------------------------------------------------- phase A
@@ -644,7 +661,8 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         else:
             ops.gemm_tn(ybar, ctx["x_pm"], out=gA, beta=1.0)
             if need_dx:
-                dx = ops.pm_to_cm(ops.gemm_nt(ybar, _t(W)), B, N)
+                dx = ops.gemm_nt(ybar, _t(W))
+                dx = dx if ctx.get("pm_io") else ops.pm_to_cm(dx, B, N)
         grads[conv + ".weight"] = gA.view_as(P[conv + ".weight"])
         grads[conv + ".bias"] = ZERO_GRAD
     return grads, dx
@@ -662,7 +680,7 @@ def d_double_backward_eval(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False
     ys, bns, hs, pooled, argmax = ctx["ys"], ctx["bns"], ctx["hs"], ctx["pooled"], ctx["argmax"]
     dys, gs = saved["dys"], saved["gs"]
     grads: Dict[str, Tensor] = {}
-    q = ops.cm_to_pm(v_dx_cm.contiguous())
+    q = v_dx_cm.contiguous() if ctx.get("pm_io") else ops.cm_to_pm(v_dx_cm.contiguous())
     for li in range(4):
         conv, bn = D_LAYERS[li]
         W = _w2(P[conv + ".weight"])
@@ -685,7 +703,7 @@ def d_double_backward_eval(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False
         grads[name + ".bias"] = ZERO_GRAD
         if li < 3:
             t = ops.gemm_nt_maskout(t, P[name + ".weight"], hs[li], NEG)
-    dx = torch.zeros((B, 3, N), dtype=torch.float32, device=q.device) if need_dx else None
+    dx = torch.zeros((B * N, 3) if ctx.get("pm_io") else (B, 3, N), dtype=torch.float32, device=q.device) if need_dx else None
     return grads, dx
 
 

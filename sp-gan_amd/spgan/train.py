@@ -183,7 +183,7 @@ class TrainStep:
                     g_fake = None
                     if self.overlap_g_forward:          # replayed while D's all-reduce is in flight
                         with torch.cuda.graph(gf, pool=g1.pool(), capture_error_mode="thread_local"):
-                            g_fake = self._seg_gfwd(sx, szg)
+                            g_fake = self._seg_gfwd(sx, szg, pm=isinstance(real_t, tuple))
                     with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
                         self._seg_g(sx, real_t, szg, w, False, info, g_fake=g_fake)
                     with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode="thread_local"):
@@ -264,11 +264,38 @@ class TrainStep:
         B, N, _ = real.shape
         requires_grad(G, False); requires_grad(D, True)
         self.optD.zero_grad()
+        # Point-major internal route: the batched conv stacks take the generator's output [B*N,3] as it leaves its last GEMM and the real
+        # cloud as the loader delivers it ([B,N,3] IS point-major) -- no [B,3,N] round trips (layout kernels, cat + transpose, and their
+        # adjoints in the penalty's double backward); bit-identical to the [B,3,N] route (same values into the same kernels).
+        pm = self.batch_d_forwards and D.training and N % ops.ROW_TILE == 0 and not getattr(G, "off", False) and tuple(x.shape) == tuple(real.shape)
         G.twin_forward = "first" if self.twin_g_forwards else None
         try:
-            fake = G(x, z_d).detach()
+            fake = G(x, z_d, pm_out=True).detach() if pm else G(x, z_d).detach()
         finally:
             G.twin_forward = None
+        if pm:
+            M = B * N
+            real_pm = real.reshape(M, 3).contiguous()
+            ins = [real_pm, fake]
+            x_hat = None
+            if self.use_gp:
+                a_ = alpha if alpha is not None else torch.rand(B, 1, 1, device=real.device)      # gradient_penalty.py:24
+                x_hat = ops.lerp_rows(real_pm.view(B, N * 3), fake.view(B, N * 3), a_.reshape(B)).view(M, 3)     # real + alpha*(fake - real)
+                ins.append(x_hat)
+            pre = D.forward_stacks_grouped(ins, pm_shape=(B, N))
+            d_real, d_fake = D.forward_heads([D.forward_stack(real_pm, pre=pre[0]), D.forward_stack(fake, pre=pre[1])])
+            out5, g_real, g_fake = dis_loss_with_grads(d_real, d_fake, self.gan, self.flip_d)
+            roots, seeds = [d_real, d_fake], [g_real, g_fake]
+            loss_d = out5[0]
+            if self.use_gp:
+                pen, gx, v = self.gp.with_grads_pm(D, x_hat, pre[2], B)
+                roots.append(gx); seeds.append(v)
+                loss_d = loss_d + pen[0]
+            torch.autograd.backward(roots, seeds)
+            if keep_grads:
+                info["fake_d"] = ops.pm_to_cm(fake, B, N)
+            info.update(loss_d=loss_d.detach(), real_acc=out5[3], fake_acc=out5[4])
+            return ("pm", real_pm, B, N)
         real_t = ops.pm_to_cm(real.reshape(B * N, 3), B, N)                      # real_points.transpose(2,1)
         pre_hat = x_hat = None
         if self.batch_d_forwards and D.training and N % ops.ROW_TILE == 0 and tuple(fake.shape) == tuple(real_t.shape):
@@ -300,7 +327,7 @@ class TrainStep:
         info.update(loss_d=loss_d.detach(), real_acc=out5[3], fake_acc=out5[4])
         return real_t
 
-    def _seg_gfwd(self, x, z_g):
+    def _seg_gfwd(self, x, z_g, pm: bool = False):
         """The generator's forward of the G step (model.py:264-271 without D's half of the requires_grad toggle).  It reads neither
         D's weights nor D's gradients, so the data-parallel schedule issues it BEFORE optimizerD.step() (model.py:260), while D's
         gradient all-reduce is in flight; every tensor it produces is what the reference's order produces (G is untouched by D's
@@ -311,7 +338,7 @@ class TrainStep:
         G.twin_forward = "second" if self.twin_g_forwards else None
         try:
             with fused_grad_accumulation():
-                return G(x, z_g)
+                return G(x, z_g, pm_out=True) if pm else G(x, z_g)
         finally:
             G.twin_forward = None
 
@@ -327,8 +354,18 @@ class TrainStep:
             info["d_grads"] = {n: p.grad.detach().clone() * scale_d for n, p in D.named_parameters()}
         self.optD.step(scale_d)
         requires_grad(G, True); requires_grad(D, False)
+        pm = isinstance(real_t, tuple)                      # ("pm", real_pm, B, N): the D step ran the point-major route
         if g_fake is None:
-            g_fake = self._seg_gfwd(x, z_g)
+            g_fake = self._seg_gfwd(x, z_g, pm=pm)
+        if pm:
+            _, real_pm, B_, N_ = real_t
+            g_fake_logit = D(g_fake, pre=D.forward_stack_after_stats_pass(real_pm, g_fake, pm_shape=(B_, N_)))
+            out5, seed = gen_loss_with_grads(g_fake_logit, self.gan, self.flip_g)
+            torch.autograd.backward([g_fake_logit], [seed])
+            if keep_grads:
+                info["fake_g"] = ops.pm_to_cm(g_fake.detach(), B_, N_)
+            info["loss_g"] = out5[0]
+            return
         # model.py:272-274: d_real = D(real) is computed but gen_loss ignores it (loss_utils.py:727-802) -- what lasts of that call
         # are D's BatchNorm running statistics, advanced here without the 1024-wide layer, the pool and the head
         g_real_logit = None
@@ -361,7 +398,7 @@ class TrainStep:
             # data parallel: the generator's forward of the G step is issued under D's gradient all-reduce (it depends on neither)
             self.dpD.allreduce_grads_begin()
             if self.overlap_g_forward:
-                g_fake = self._seg_gfwd(x, z_g)
+                g_fake = self._seg_gfwd(x, z_g, pm=isinstance(real_t, tuple))
             scale = self.dpD.allreduce_grads_end()
         self._seg_g(x, real_t, z_g, scale, keep_grads, info, g_fake=g_fake)
         scale = self.dpG.allreduce_grads() if self.dpG is not None else 1.0
