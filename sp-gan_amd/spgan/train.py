@@ -74,6 +74,7 @@ class TrainStep:
         # The generator's two forwards of a step (D step, G step) see the same sphere prior and the same weights: EdgeConv1, which
         # depends on nothing else, is evaluated once and its BatchNorm running statistics are advanced twice (Generator.twin_forward).
         self.twin_g_forwards = not reference_schedule      # attribute = test hook
+        self.point_major = True                            # test hook: False keeps the [B,3,N] layout between the networks (same results up to the penalty norm's summation order)
         # Data parallel: the generator's forward of the G step does not depend on D's update, so it is issued while D's gradient
         # all-reduce is in flight (SPGAN_DP_OVERLAP=0: the strictly sequential schedule, for A/B measurements on a node).
         self.overlap_g_forward = distributed and os.environ.get("SPGAN_DP_OVERLAP", "1") != "0"
@@ -266,8 +267,10 @@ class TrainStep:
         self.optD.zero_grad()
         # Point-major internal route: the batched conv stacks take the generator's output [B*N,3] as it leaves its last GEMM and the real
         # cloud as the loader delivers it ([B,N,3] IS point-major) -- no [B,3,N] round trips (layout kernels, cat + transpose, and their
-        # adjoints in the penalty's double backward); bit-identical to the [B,3,N] route (same values into the same kernels).
-        pm = self.batch_d_forwards and D.training and N % ops.ROW_TILE == 0 and not getattr(G, "off", False) and tuple(x.shape) == tuple(real.shape)
+        # adjoints in the penalty's double backward); the same values into the same kernels (only the penalty's per-shape norm sums its
+        # 3N squares in the other memory order: last-bit differences).
+        pm = (self.point_major and self.batch_d_forwards and D.training and N % ops.ROW_TILE == 0 and not getattr(G, "off", False)
+              and tuple(x.shape) == tuple(real.shape))
         G.twin_forward = "first" if self.twin_g_forwards else None
         try:
             fake = G(x, z_d, pm_out=True).detach() if pm else G(x, z_d).detach()

@@ -350,3 +350,34 @@ def test_native_rccl_allreduce_flat_one_rank_and_in_a_graph(sp):
     finally:
         os.environ.pop("SPGAN_DP_COLLECTIVE", None)
         dist.destroy_process_group()
+
+
+def test_point_major_route_equals_the_channel_major_one():
+    """TrainStep's internal point-major route (generator output and real cloud handed to the Discriminator as [B*N,3], no [B,3,N] round trips)
+    feeds the same values into the same kernels; the one difference is the gradient penalty's per-shape norm, whose 3N squares are summed in
+    the other memory order (a last-bit difference that reaches D's update).  First-step losses of the D step are bit-identical, everything
+    after two steps agrees to rounding; mixing factors drawn from the same generator state (alpha=None)."""
+    import spgan
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    out = []
+    for pm in (True, False):
+        o = Opts()
+        G = _load(spgan.Generator(o), fr.init_params(orc.generator_shapes(), salt=31))
+        D = _load(spgan.Discriminator(o), fr.init_params(orc.discriminator_shapes(), salt=31))
+        tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True)
+        tr.point_major = pm
+        torch.manual_seed(1234)
+        losses = []
+        for s in range(2):
+            info = tr.step(x, fr.synthetic_real(B, N, seed=40 + s).cuda(), fr.latent(B, N, seed=50 + s).cuda(), fr.latent(B, N, seed=60 + s).cuda())
+            losses.append((info["loss_d"].item(), info["loss_g"].item()))
+        torch.cuda.synchronize()
+        G.flush_bn_counts(); D.flush_bn_counts()
+        out.append((losses, {k: v.clone() for k, v in list(G.state_dict().items()) + [("D." + k, v) for k, v in D.state_dict().items()]}))
+    assert out[0][0][0][0] == out[1][0][0][0], "the first D loss (forward passes only) must be bit-identical"
+    for (da, ga), (db, gb) in zip(out[0][0], out[1][0]):
+        assert abs(da - db) <= 1e-5 * abs(db) and abs(ga - gb) <= 1e-5 * max(abs(gb), 1e-3), (out[0][0], out[1][0])
+    for k in out[0][1]:
+        a, b = out[0][1][k].double(), out[1][1][k].double()
+        assert (a - b).abs().max().item() <= 1e-6 + 1e-5 * b.abs().max().item(), k      # an Adam step is <= lr = 1e-4
