@@ -53,3 +53,15 @@ def test_bench_eight_ranks():
 def test_bench_refuses_a_mismatched_world():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("cfg", ["c4", "c5"])
+def test_bench_config_switch(cfg):
+    """`--config c4 / c5` (the per-GPU shapes of BASELINE configs[3] / configs[4]) are accepted, named in the line, and the default (the
+    driver's command) stays c2; an unknown config is refused before anything runs."""
+    r = _run(["--config", cfg, "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_lines(r.stdout)[0]
+    assert line["bench_config"] == cfg and line["selftest"] is True
+    assert line["gf_per_shape_step_reference"] == (67.3 if cfg == "c4" else 32.6)
+    assert _run(["--config", "c9"]).returncode != 0
