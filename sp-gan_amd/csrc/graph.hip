@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void knn_mfma3_kernel(const float* __restrict_
   constexpr int SL = CP / 32;           // float4 staging slots per thread (32 rows x CP/4 float4 / 256 threads)
   __shared__ __attribute__((aligned(16))) float cand[2][32 * LDC];
   __shared__ __attribute__((aligned(16))) float cn[2][32];
+  __shared__ float dsc[4][16 * 64];     // per wave: the tile's 16 distances of every lane, [r][lane]
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -390,7 +391,11 @@ __global__ __launch_bounds__(256) void knn_mfma3_kernel(const float* __restrict_
     // nearly always has one among its 16 -- running the insertion under a per-candidate branch would execute it almost
     // every time.  Instead: 16 compares build a per-lane bit mask of the survivors, and a per-lane loop pops them in
     // index order (the wave iterates max-over-lanes(#survivors) times, typically 1-2 instead of ~12).
-    float d[16];
+    // Round 4 (PMC: the kernel is VALU-issue-bound -- 612 VALU instructions per tile and wave, 69 % of a SIMD's cycles, of which ~3.8
+    // trips x 89 were this loop): the 16 distances go to an LDS scratch [r][lane] (conflict-free 4-byte stores), so that a trip reads
+    // its candidate by address instead of a 15-deep select chain on a per-lane register index, and the sorted insertion is one
+    // v_med3_f32 per slot -- new[t] = median(dv, old[t-1], old[t]) -- with the indices following through two selects.
+    float* sc = &dsc[wave][lane];
     unsigned live = 0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -400,27 +405,34 @@ __global__ __launch_bounds__(256) void knn_mfma3_kernel(const float* __restrict_
       for (int u = 0; u < 4; ++u) {
         const int r = 4 * g + u;
         const float dot = acc0[r] + acc1[r];
-        d[r] = (-2.f * dot + qn) + nn[u];
-        if (j0 + 8 * g + 4 * lh + u >= N) d[r] = INFINITY;
-        live |= (d[r] < bd[KP - 1]) ? (1u << r) : 0u;
+        float dr = (-2.f * dot + qn) + nn[u];
+        if (j0 + 8 * g + 4 * lh + u >= N) dr = INFINITY;
+        sc[r * 64] = dr;
+        live |= (dr < bd[KP - 1]) ? (1u << r) : 0u;
       }
     }
+    int rn = live ? __ffs(live) - 1 : 0;
+    float dn = sc[rn * 64];             // this lane's own store: no barrier needed
     while (live) {
-      const int r = __ffs(live) - 1;
+      const int r = rn;
+      const float dv = dn;
       live &= live - 1;
-      float dv = d[0];
-#pragma unroll
-      for (int u = 1; u < 16; ++u) dv = (r == u) ? d[u] : dv;
+      rn = live ? __ffs(live) - 1 : 0;  // the next candidate's LDS read is in flight during this one's insertion
+      dn = sc[rn * 64];
       if (dv < bd[KP - 1]) {  // the threshold may have tightened since the mask was built
-        bd[KP - 1] = dv;
-        bi[KP - 1] = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int iv = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        // sorted insertion, equal distances keep the lower (earlier) index first: with c[t] = dv < old[t] (c[KP-1] holds),
+        //   new_d[t] = median(dv, old_d[t-1], old_d[t]),  new_i[t] = c[t-1] ? old_i[t-1] : (c[t] ? iv : old_i[t])
+        bool ct = true;
 #pragma unroll
         for (int t = KP - 1; t > 0; --t) {
-          if (bd[t] < bd[t - 1]) {  // strict: equal distances keep the lower (earlier) index first
-            const float td = bd[t]; bd[t] = bd[t - 1]; bd[t - 1] = td;
-            const int ti = bi[t]; bi[t] = bi[t - 1]; bi[t - 1] = ti;
-          }
+          const bool cl = dv < bd[t - 1];
+          bi[t] = cl ? bi[t - 1] : (ct ? iv : bi[t]);
+          bd[t] = __builtin_amdgcn_fmed3f(dv, bd[t - 1], bd[t]);
+          ct = cl;
         }
+        bi[0] = ct ? iv : bi[0];
+        bd[0] = fminf(bd[0], dv);
       }
     }
     if (tile + 1 < ntiles) commit(buf ^ 1);  // its last readers passed the previous barrier
