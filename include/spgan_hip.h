@@ -50,6 +50,13 @@ const char* spgan_arch(void);
  * positionally (modules.py:703), ties go to the lower index (stable sort).  k <= 32, k+1 <= N. */
 int spgan_knn(const float* x_pm, int B, int N, int C, int k, int mode, int32_t* idx, spgan_stream_t s);
 
+/* The same selection with a caller-provided scratch buffer (csrc/knn_pipe.hip): for 16 < C <= 64, k <= 10, mode 0 a pre-pass writes every
+ * 32-row tile once as three bfloat16 planes + squared norms into `ws`, and the scan is software-pipelined over those images; identical
+ * indices, ~0.6x the time.  spgan_knn_ws_bytes returns the scratch size that route needs (16-byte aligned buffer), or 0 when the shape
+ * is served by spgan_knn's kernels -- spgan_knn_ws then forwards to spgan_knn and ignores ws. */
+size_t spgan_knn_ws_bytes(int B, int N, int C, int k, int mode);
+int spgan_knn_ws(const float* x_pm, int B, int N, int C, int k, int mode, int32_t* idx, void* ws, size_t ws_bytes, spgan_stream_t s);
+
 /* In-edge lists of the kNN graph (for deterministic gather-style backward instead of float
  * atomics; replaces the atomicAdd scatter of metrics/pointops/src/grouping/grouping_cuda_kernel.cu:28-45).
  * rowptr [M+1], src [M*k]: src[rowptr[j] .. rowptr[j+1]) = ascending edge ids e with idx[e] == j. */

@@ -118,6 +118,8 @@ SIGNATURES = {
     "spgan_version": (I, []),
     "spgan_arch": (C.c_char_p, []),
     "spgan_knn": (I, [P, I, I, I, I, I, P, P]),
+    "spgan_knn_ws_bytes": (SZ, [I, I, I, I, I]),
+    "spgan_knn_ws": (I, [P, I, I, I, I, I, P, P, SZ, P]),
     "spgan_csr_build": (I, [P, I, I, I, P, P, P]),
     "spgan_edge_features_cm": (I, [P, P, I, I, I, I, P, P]),
     "spgan_idx_to_local64": (I, [P, I, I, I, P, P]),

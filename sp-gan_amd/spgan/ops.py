@@ -177,6 +177,9 @@ class _KnnInfo:
 
 
 # ----------------------------------------------------------------------------- graph
+KNN_PIPELINED = [True]  # test / A-B hook: False keeps every shape on spgan_knn's single-launch kernels
+
+
 def knn(x_pm: Tensor, B: int, N: int, k: int, mode: int = 0) -> Tensor:
     """x_pm [B*N, C] -> idx int32 [B*N, k] (global rows), sorted ascending, rank 0 dropped.
     mode 1 = fp64 direct differences (coordinate inputs, C<=4)."""
@@ -185,7 +188,13 @@ def knn(x_pm: Tensor, B: int, N: int, k: int, mode: int = 0) -> Tensor:
         raise ValueError("x_pm must be contiguous [B*N, C]")
     idx = torch.empty((B * N, k), dtype=torch.int32, device=x_pm.device)
     done = launch_timer("knn", _KnnInfo(B, N, x_pm.shape[1], k, mode)) if launch_timer is not None else None
-    check(_lib.load().spgan_knn(_p(x_pm), B, N, x_pm.shape[1], k, mode, _p(idx), _s()), "knn", B=B, N=N, C=x_pm.shape[1], k=k)
+    lib, C = _lib.load(), x_pm.shape[1]
+    ws_bytes = lib.spgan_knn_ws_bytes(B, N, C, k, mode) if KNN_PIPELINED[0] else 0
+    if ws_bytes:  # the tile images of csrc/knn_pipe.hip (freed with the call; inside a capture they live in the graph's pool)
+        ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=x_pm.device)
+        check(lib.spgan_knn_ws(_p(x_pm), B, N, C, k, mode, _p(idx), _p(ws), ws_bytes, _s()), "knn", B=B, N=N, C=C, k=k)
+    else:
+        check(lib.spgan_knn(_p(x_pm), B, N, C, k, mode, _p(idx), _s()), "knn", B=B, N=N, C=C, k=k)
     if done is not None:
         done()
     return idx
