@@ -4,7 +4,7 @@
 // VALU issue, not by the matrix pipe -- 513 VALU instructions per 32-candidate tile and wave (612 before the selection loop's LDS
 // extraction + median-of-three insertion), MFMA pipe ~20 % busy -- and the two do not overlap: a wave issues its 24 MFMAs back to back
 // and only then starts on the distances.  ~110 of those instructions converted the candidate tile to its three bfloat16 planes, in
-// each of the 16 workgroups that scan the same shape.  Here (316 VALU instructions per tile and wave, 213 -> 174 us with the pre-pass)
+// each of the 16 workgroups that scan the same shape.  Here (285 VALU instructions per tile and wave, 213 -> 172 us with the pre-pass)
 //   * a pre-pass (knn_split_kernel) writes every 32-row tile once as the exact LDS image the main kernel wants: three bf16 planes per
 //     row at the conflict-free row pitch, then the 32 squared norms (+inf for rows past N, which removes the bounds test from the
 //     distance loop).  12.9 KB per tile, 26 MB at B=32, N=2048: one 10 us launch;
@@ -12,10 +12,14 @@
 //     fragments straight from the images;
 //   * the tile loop is software-pipelined inside a wave: the MFMAs of tile t+1 are issued between the distance instructions of
 //     tile t (two accumulator sets, alternating), so the matrix pipe runs under the VALU work instead of before it;
-//   * the survivor mask is built from sign bits (v_sub + v_alignbit per candidate instead of cmp + cndmask + or).
+//   * the survivor mask is built from sign bits (v_sub + v_alignbit per candidate instead of cmp + cndmask + or), and the selection
+//     loop runs once per tile pair (32 candidates per lane): fewer max-over-lanes trips.
+// What is left (same PMC file): VALU issue 58 % of a SIMD's cycles, matrix pipe 31 %, ~29 % of a wave's life in s_waitcnt/s_barrier --
+// the four waves of a workgroup meet once per tile and wait for the one with the most survivors.
 // Distances, norms and the selection are the arithmetic of knn_mfma3_kernel, operation for operation: the indices are identical
 // (tools/knn_ab.py prints the same checksum for both).
 #include <math.h>
+#include <type_traits>
 #include "common.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void knn_pipe_kernel(const float* __restrict__ img, int N, int tiles, int k, int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* cand = smem;               // [3][IMGW]
-  float* dsc = smem + 3 * IMGW;     // [4][16*64]: per wave, the tile's 16 distances of every lane, [r][lane]
+  float* dsc = smem + 3 * IMGW;     // [4][32*64]: per wave, the 2 x 16 distances of a tile pair of every lane, [r][lane]
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -142,19 +146,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     bd[t] = INFINITY;
     bi[t] = 0x7fffffff;
   }
-  float* sc = dsc + wave * (16 * 64) + lane;
+  float* sc = dsc + wave * (32 * 64) + lane;
+  unsigned live = 0;  // survivor bits of the current tile pair: bit 16*h + r = candidate r of the pair's tile h
 
-  // One phase: distances + selection of tile `tile` (accumulators c0/c1, image in ring slot s0) while the matrix pipe works on tile+1
-  // (ring slot s1 -> n0/n1), the image of tile+2 (registers `cm`, loaded last phase) goes to ring slot s2 and the load of tile+3 into `ld`
-  // starts.  Past the last tile the same work runs on a clamped tile index and its results are dropped (no divergent control flow
-  // around the MFMAs).
-  auto phase = [&](int tile, int s0, int s1, int s2, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1, float4& la, float4& lb, float4& lc, float4& ld,
-                   const float4& ca, const float4& cb, const float4& cc, const float4& cd) {
+  // One phase: distances of tile `tile` (accumulators c0/c1, image in ring slot s0) while the matrix pipe works on tile+1 (ring slot s1 ->
+  // n0/n1), the image of tile+2 (registers c*, loaded last phase) goes to ring slot s2 and the load of tile+3 into l* starts.  Past the
+  // last tile the same work runs on a clamped tile index and its results are dropped (no divergent control flow around the MFMAs).
+  // The selection runs once per tile PAIR (H = 1, or the last tile): a wave iterates max-over-lanes(#survivors) times, and that maximum
+  // over 32 candidates per lane is well below twice the one over 16 (PMC: 3.8 trips per tile before).  The pair's survivors are
+  // popped in candidate order, so the lists see the same sequence of insertions as with a selection per tile -- the mask of the
+  // pair's first tile is merely tested against an older (larger) threshold, and the insertion re-tests.
+  auto phase = [&](auto half, int tile, int s0, int s1, int s2, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1, float4& la, float4& lb, float4& lc,
+                   float4& ld, const float4& ca, const float4& cb, const float4& cc, const float4& cd) {
+    constexpr int H = decltype(half)::value;
     gload(min(tile + 3, ntiles - 1), la, lb, lc, ld);
     mfma_tile(s1, n0, n1);
     const float* cn = cand + s0 * IMGW + 32 * LDC + 4 * lh;
     const float thr = bd[KP - 1];
-    unsigned live = 0;
+    unsigned m = 0;
 #pragma unroll
     for (int g = 3; g >= 0; --g) {
       const float4 nrm = *reinterpret_cast<const float4*>(cn + 8 * g);
@@ -164,35 +173,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int r = 4 * g + u;
         const float dot = c0[r] + c1[r];
         const float dr = (-2.f * dot + qn) + nn[u];  // +inf for a row past N (its norm)
-        sc[r * 64] = dr;
+        sc[(16 * H + r) * 64] = dr;
         // bit r = (dr < thr): the sign of dr - thr, shifted in from the right -- r runs downwards, so the last one lands on bit 0.
         // (inf - inf is a NaN of either sign: a false survivor costs one trip, the insertion test below decides.)
-        live = __builtin_amdgcn_alignbit(live, __float_as_uint(dr - thr), 31);
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(dr - thr), 31);
       }
     }
-    const int j0 = tile * 32 + 4 * lh;
-    int rn = live ? __ffs(live) - 1 : 0;
-    float dn = sc[rn * 64];  // this lane's own store: no barrier needed
-    while (live) {
-      const int r = rn;
-      const float dv = dn;
-      live &= live - 1;
-      rn = live ? __ffs(live) - 1 : 0;  // the next candidate's LDS read is in flight during this one's insertion
-      dn = sc[rn * 64];
-      if (dv < bd[KP - 1]) {  // the threshold may have tightened since the mask was built
-        const int iv = j0 + (r & 3) + 8 * (r >> 2);
-        // sorted insertion, equal distances keep the lower (earlier) index first: with c[t] = dv < old[t] (c[KP-1] holds),
-        //   new_d[t] = median(dv, old_d[t-1], old_d[t]),  new_i[t] = c[t-1] ? old_i[t-1] : (c[t] ? iv : old_i[t])
-        bool ct = true;
+    live = H ? (live | (m << 16)) : m;
+    if (H == 1 || tile == ntiles - 1) {
+      const int j0 = (tile - H) * 32 + 4 * lh;
+      int rn = live ? __ffs(live) - 1 : 0;
+      float dn = sc[rn * 64];  // this lane's own store: no barrier needed
+      while (live) {
+        const int r = rn;
+        const float dv = dn;
+        live &= live - 1;
+        rn = live ? __ffs(live) - 1 : 0;  // the next candidate's LDS read is in flight during this one's insertion
+        dn = sc[rn * 64];
+        if (dv < bd[KP - 1]) {  // the threshold may have tightened since the mask was built
+          const int iv = j0 + (r & 3) + 8 * ((r >> 2) & 3) + 2 * (r & 16);
+          // sorted insertion, equal distances keep the lower (earlier) index first: with c[t] = dv < old[t] (c[KP-1] holds),
+          //   new_d[t] = median(dv, old_d[t-1], old_d[t]),  new_i[t] = c[t-1] ? old_i[t-1] : (c[t] ? iv : old_i[t])
+          bool ct = true;
 #pragma unroll
-        for (int t = KP - 1; t > 0; --t) {
-          const bool cl = dv < bd[t - 1];
-          bi[t] = cl ? bi[t - 1] : (ct ? iv : bi[t]);
-          bd[t] = __builtin_amdgcn_fmed3f(dv, bd[t - 1], bd[t]);
-          ct = cl;
+          for (int t = KP - 1; t > 0; --t) {
+            const bool cl = dv < bd[t - 1];
+            bi[t] = cl ? bi[t - 1] : (ct ? iv : bi[t]);
+            bd[t] = __builtin_amdgcn_fmed3f(dv, bd[t - 1], bd[t]);
+            ct = cl;
+          }
+          bi[0] = ct ? iv : bi[0];
+          bd[0] = fminf(bd[0], dv);
         }
-        bi[0] = ct ? iv : bi[0];
-        bd[0] = fminf(bd[0], dv);
       }
     }
     commit(s2, ca, cb, cc, cd);  // slot s2 held tile-1: its last readers (this wave's norms, last phase) are behind the previous barrier
@@ -210,8 +222,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   for (int tile = 0; tile < ntiles; tile += 2) {
     const int s = tile % 3;  // ring slots of tile, tile+1, tile+2
     const int s1 = s == 2 ? 0 : s + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-    phase(tile, s, s1, s2, a0, a1, b0, b1, xa, xb4, xc, xd, ya, yb, yc, yd);
-    if (tile + 1 < ntiles) phase(tile + 1, s1, s2, s, b0, b1, a0, a1, ya, yb, yc, yd, xa, xb4, xc, xd);
+    phase(std::integral_constant<int, 0>{}, tile, s, s1, s2, a0, a1, b0, b1, xa, xb4, xc, xd, ya, yb, yc, yd);
+    if (tile + 1 < ntiles) phase(std::integral_constant<int, 1>{}, tile + 1, s1, s2, s, b0, b1, a0, a1, ya, yb, yc, yd, xa, xb4, xc, xd);
   }
 
   // merge the two half-lists of a query into lane lh == 0 by (distance, index)
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 }
 
 inline int tiles_of(int N) { return 4 * cdiv(N, 128); }  // whole query groups: the tiles past N hold zero rows with +inf norms
-constexpr size_t PIPE_LDS = (size_t)(3 * IMGW + 4 * 16 * 64) * sizeof(float);  // 55,168 bytes: two workgroups per CU
+constexpr size_t PIPE_LDS = (size_t)(3 * IMGW + 4 * 32 * 64) * sizeof(float);  // 71,552 bytes: two workgroups per CU
 
 }  // namespace
 
@@ -260,6 +272,11 @@ int spgan_knn_ws(const float* x_pm, int B, int N, int C, int k, int mode, int32_
   hipStream_t s = static_cast<hipStream_t>(s_);
   const int tiles = tiles_of(N);
   float* img = static_cast<float*>(ws);
+  static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(knn_split_kernel, dim3(tiles, B), dim3(256), 0, s, x_pm, N, C, tiles, img);
   hipLaunchKernelGGL(knn_pipe_kernel, dim3(cdiv(N, 128), B), dim3(256), PIPE_LDS, s, img, N, tiles, k, idx);
   return spgan_launch_status();
