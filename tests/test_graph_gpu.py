@@ -355,8 +355,10 @@ def test_native_rccl_allreduce_flat_one_rank_and_in_a_graph(sp):
 def test_point_major_route_equals_the_channel_major_one():
     """TrainStep's internal point-major route (generator output and real cloud handed to the Discriminator as [B*N,3], no [B,3,N] round trips)
     feeds the same values into the same kernels; the one difference is the gradient penalty's per-shape norm, whose 3N squares are summed in
-    the other memory order (a last-bit difference that reaches D's update).  First-step losses of the D step are bit-identical, everything
-    after two steps agrees to rounding; mixing factors drawn from the same generator state (alpha=None)."""
+    the other memory order (a last-bit difference that reaches D's gradients).  Compared on what the routes compute -- losses, every
+    gradient of both networks, the generated clouds -- at rounding level relative to each tensor's own scale.  (Not on the weights after
+    Adam: its first updates are +-lr * sign-like for entries whose gradient is itself rounding noise, e.g. the columns of tail.0.weight
+    that only see the penalty's last bits -- tools/exp/pm_route_diff.py shows up to 0.4 lr there on equal gradients.)"""
     import spgan
     B, N = 4, 256
     x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
@@ -368,16 +370,16 @@ def test_point_major_route_equals_the_channel_major_one():
         tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True)
         tr.point_major = pm
         torch.manual_seed(1234)
-        losses = []
-        for s in range(2):
-            info = tr.step(x, fr.synthetic_real(B, N, seed=40 + s).cuda(), fr.latent(B, N, seed=50 + s).cuda(), fr.latent(B, N, seed=60 + s).cuda())
-            losses.append((info["loss_d"].item(), info["loss_g"].item()))
+        info = tr.step(x, fr.synthetic_real(B, N, seed=40).cuda(), fr.latent(B, N, seed=50).cuda(), fr.latent(B, N, seed=60).cuda(), keep_grads=True)
         torch.cuda.synchronize()
-        G.flush_bn_counts(); D.flush_bn_counts()
-        out.append((losses, {k: v.clone() for k, v in list(G.state_dict().items()) + [("D." + k, v) for k, v in D.state_dict().items()]}))
-    assert out[0][0][0][0] == out[1][0][0][0], "the first D loss (forward passes only) must be bit-identical"
-    for (da, ga), (db, gb) in zip(out[0][0], out[1][0]):
-        assert abs(da - db) <= 1e-5 * abs(db) and abs(ga - gb) <= 1e-5 * max(abs(gb), 1e-3), (out[0][0], out[1][0])
-    for k in out[0][1]:
-        a, b = out[0][1][k].double(), out[1][1][k].double()
-        assert (a - b).abs().max().item() <= 1e-6 + 1e-5 * b.abs().max().item(), k      # an Adam step is <= lr = 1e-4
+        out.append(info)
+    a, b = out
+    assert a["loss_d"].item() == pytest.approx(b["loss_d"].item(), rel=1e-6) and a["loss_g"].item() == pytest.approx(b["loss_g"].item(), rel=1e-6)
+    assert torch.equal(a["fake_d"], b["fake_d"]), "the D step's generated clouds come from the same kernels"
+    for which in ("d_grads", "g_grads"):
+        assert a[which].keys() == b[which].keys()
+        for k in a[which]:
+            ga, gb = a[which][k].double(), b[which][k].double()
+            # G's gradients are taken through the UPDATED discriminator (model.py:259-277), so they carry D's Adam amplification: 1e-3
+            tol = 1e-5 if which == "d_grads" else 1e-3
+            assert (ga - gb).abs().max().item() <= tol * gb.abs().max().item() + 1e-12, (which, k)
