@@ -311,8 +311,9 @@ int spgan_sparse_rows_tn(const float* val, const int32_t* arg, int B, int rows, 
 /* out[m,c] = lrelu(X[m,c]*scale[c] + shift[c], slope)   (train-mode BatchNorm + LeakyReLU output, Discriminator.py:57-64) */
 int spgan_affine_act(const float* X, int ldx, size_t M, int C, const float* scale, const float* shift, float slope, float* out, spgan_stream_t s);
 /* out[r,c] = a[r]*X[r,c] + (a[r]*b[r] + d[r])*v[c]   (v == NULL: first term only); weight-shaped [R,C] tensors */
+/* accumulate != 0: out += that (the terms of a weight gradient summed in place instead of by axpby launches) */
 int spgan_rowscale_outer(const float* X, int ldx, int R, int C, const float* a, const float* b, const float* d, const float* v, float* out,
-                         int ldo, spgan_stream_t s);
+                         int ldo, int accumulate, spgan_stream_t s);
 
 /* Column reductions over row groups (group = G consecutive rows; M % G == 0).  Partials are
  * [groups * ceil(G/128)][C][2] floats: one (a, b) pair per 128-row tile and column -- the format
@@ -380,7 +381,12 @@ int spgan_maxpool(const float* y, int ld, int B, int N, int C, const float* scal
  *   conv_w.0(x_j - x_i) = (P_j - P_i) + b1,  conv_x.0([x_i, x_j-x_i]) = (R_i + Q_j) + bx,
  *   PQR[M, H+2F] = x . Wcat^T,  Wcat = [W1; Wd; Wc-Wd],  Wx = [Wc | Wd],  H = F/2.
  * ---------------------------------------------------------------------------------------- */
-int spgan_edge_wcat(const float* Ww0 /*[H,C]*/, const float* Wx /*[F,2C]*/, int H, int F, int C, float* Wcat, spgan_stream_t s);
+/* WcatT (nullable) [C, H+2F] = Wcat^T from the same launch: the operand of the block's input-gradient GEMM (dx = dPQR . Wcat). */
+int spgan_edge_wcat(const float* Ww0 /*[H,C]*/, const float* Wx /*[F,2C]*/, int H, int F, int C, float* Wcat, float* WcatT, spgan_stream_t s);
+/* conv_out.weight [F,F,1,k] (Generator.py:70: Conv2d(F, F, [1,k])) in the two layouts the point-major EdgeBlock multiplies with:
+ * Wo [F, k*F] with K index r*F + c (the order of the per-point feature row T[m, r*F + c]) for the forward product, and WoT (nullable)
+ * [k*F, F] = Wo^T for the input gradient dT = dout . Wo -- one launch instead of a permuted copy now and a transpose in the backward. */
+int spgan_conv_out_weight_pm(const float* w, int F, int k, float* Wo, float* WoT, spgan_stream_t s);
 int spgan_edge_wcat_bwd(const float* dWcat, int H, int F, int C, float* dWw0, float* dWx, spgan_stream_t s);
 /* BatchNorm2d statistics over the M*k edges of both per-edge pre-activations (Generator.py:58,67):
  * partials [ceil(M/32)][H+F][2] in the finalize-mode-0 format with tile_rows = spgan_edge_stats_tile_rows(k). */
@@ -547,6 +553,17 @@ typedef struct spgan_multi_add_args {
   int n[SPGAN_MULTI_MAX];
 } spgan_multi_add_args;
 int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s);
+/* The same for pairs that are 3-D strided views of one shape [n0, n1, n2] (n = n0*n1*n2; strides in elements):
+ * dst[i0*ds[0] + i1*ds[1] + i2*ds[2]] += src[i0*ss[0] + i1*ss[1] + i2*ss[2]].  A permuted source (the conv_out weight gradient is computed
+ * as [F,k,F] and accumulated into [F,F,1,k]) or a column block of the destination; n1 = n2 = 1 is the plain contiguous pair. */
+typedef struct spgan_multi_add3_args {
+  int count;
+  float* dst[SPGAN_MULTI_MAX];
+  const float* src[SPGAN_MULTI_MAX];
+  int n[SPGAN_MULTI_MAX], n1[SPGAN_MULTI_MAX], n2[SPGAN_MULTI_MAX];
+  long ds[3][SPGAN_MULTI_MAX], ss[3][SPGAN_MULTI_MAX];
+} spgan_multi_add3_args;
+int spgan_multi_add3(const spgan_multi_add3_args* a, spgan_stream_t s);
 /* The local step of a ONE-HOP all-reduce of a flat gradient buffer over W ranks (on a fully connected xGMI node an
  * all-to-all is one hop per pair, so reduce-scatter = all-to-all + this sum, all-gather = one more hop; 2 hops instead of a ring's
  * 2(W-1) steps for the 2.3 / 3.9 MB latency-bound messages).  recv [parts, n] holds this rank's chunk as received from every rank

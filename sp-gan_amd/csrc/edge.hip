@@ -16,7 +16,8 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ weights
-__global__ void edge_wcat_kernel(const float* __restrict__ Ww0, const float* __restrict__ Wx, int H, int F, int C, float* __restrict__ Wcat) {
+__global__ void edge_wcat_kernel(const float* __restrict__ Ww0, const float* __restrict__ Wx, int H, int F, int C, float* __restrict__ Wcat,
+                                 float* __restrict__ WcatT) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (H + 2 * F) * C) return;
   const int row = t / C, c = t % C;
@@ -25,6 +26,16 @@ __global__ void edge_wcat_kernel(const float* __restrict__ Ww0, const float* __r
   else if (row < H + F) v = Wx[(row - H) * 2 * C + C + c];                       // Wd
   else v = Wx[(row - H - F) * 2 * C + c] - Wx[(row - H - F) * 2 * C + C + c];     // Wc - Wd
   Wcat[t] = v;
+  if (WcatT) WcatT[c * (H + 2 * F) + row] = v;
+}
+// conv_out.weight [F,F,1,k] -> Wo [F, k*F] (K index r*F + c) and Wo^T
+__global__ void conv_out_weight_pm_kernel(const float* __restrict__ w, int F, int k, float* __restrict__ Wo, float* __restrict__ WoT) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= F * F * k) return;
+  const int o = t / (k * F), q = t % (k * F), r = q / F, c = q % F;      // Wo[o, r*F + c] = w[o, c, 0, r]
+  const float v = w[((size_t)o * F + c) * k + r];
+  Wo[t] = v;
+  if (WoT) WoT[(size_t)q * F + o] = v;
 }
 __global__ void edge_wcat_bwd_kernel(const float* __restrict__ dWcat, int H, int F, int C, float* __restrict__ dWw0, float* __restrict__ dWx) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -568,9 +579,14 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
 
 }  // namespace
 
-extern "C" int spgan_edge_wcat(const float* Ww0, const float* Wx, int H, int F, int C, float* Wcat, spgan_stream_t s_) {
+extern "C" int spgan_edge_wcat(const float* Ww0, const float* Wx, int H, int F, int C, float* Wcat, float* WcatT, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(Ww0 && Wx && Wcat && H > 0 && F > 0 && C > 0);
-  hipLaunchKernelGGL(edge_wcat_kernel, dim3(cdiv((H + 2 * F) * C, 256)), dim3(256), 0, (hipStream_t)s_, Ww0, Wx, H, F, C, Wcat);
+  hipLaunchKernelGGL(edge_wcat_kernel, dim3(cdiv((H + 2 * F) * C, 256)), dim3(256), 0, (hipStream_t)s_, Ww0, Wx, H, F, C, Wcat, WcatT);
+  return spgan_launch_status();
+}
+extern "C" int spgan_conv_out_weight_pm(const float* w, int F, int k, float* Wo, float* WoT, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(w && Wo && F > 0 && k > 0);
+  hipLaunchKernelGGL(conv_out_weight_pm_kernel, dim3(cdiv((long)F * F * k, 256)), dim3(256), 0, (hipStream_t)s_, w, F, k, Wo, WoT);
   return spgan_launch_status();
 }
 extern "C" int spgan_edge_wcat_bwd(const float* dWcat, int H, int F, int C, float* dWw0, float* dWx, spgan_stream_t s_) {

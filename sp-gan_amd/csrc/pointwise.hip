@@ -367,13 +367,14 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
 
 // out[r,c] = a[r]*X[r,c] + (a[r]*b[r] + d[r])*v[c]   (v == NULL: first term only).  Small [R,C] weight-shaped tensors.
 __global__ void rowscale_outer_kernel(const float* __restrict__ X, int ldx, int R, int C, const float* __restrict__ a, const float* __restrict__ b,
-                                      const float* __restrict__ d, const float* __restrict__ v, float* __restrict__ out, int ldo) {
+                                      const float* __restrict__ d, const float* __restrict__ v, float* __restrict__ out, int ldo, int accumulate) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= R * C) return;
   const int r = t / C, c = t % C;
   float o = a[r] * X[(size_t)r * ldx + c];
   if (v) o = fmaf(fmaf(a[r], b[r], d[r]), v[c], o);
-  out[(size_t)r * ldo + c] = o;
+  float* q = out + (size_t)r * ldo + c;
+  *q = accumulate ? *q + o : o;
 }
 
 __global__ void axpby_kernel(float a, const float* __restrict__ x, float b, float* __restrict__ y, size_t n) {
@@ -603,6 +604,38 @@ extern "C" int spgan_multi_copy(const spgan_multi_add_args* a, spgan_stream_t s_
   return spgan_launch_status();
 }
 
+// The same accumulation for pairs that are 3-D strided views of each other's shape [n0, n1, n2]: a permuted source (the conv_out weight
+// gradient leaves its GEMM as [F, k, F] and belongs into [F, F, 1, k]), a column slice of the destination (a weight whose gradient is
+// computed in two column blocks).  Plain pairs have n1 = n2 = 1.
+__global__ void multi_add3_kernel(const spgan_multi_add3_args a) {
+  const int t = blockIdx.y;
+  const int n = a.n[t], n1 = a.n1[t], n2 = a.n2[t];
+  float* __restrict__ d = a.dst[t];
+  const float* __restrict__ s = a.src[t];
+  if (n1 == 1 && n2 == 1) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] += s[i];
+    return;
+  }
+  const long ds0 = a.ds[0][t], ds1 = a.ds[1][t], ds2 = a.ds[2][t], ss0 = a.ss[0][t], ss1 = a.ss[1][t], ss2 = a.ss[2][t];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int i2 = i % n2, r = i / n2, i1 = r % n1, i0 = r / n1;
+    d[i0 * ds0 + i1 * ds1 + i2 * ds2] += s[i0 * ss0 + i1 * ss1 + i2 * ss2];
+  }
+}
+
+extern "C" int spgan_multi_add3(const spgan_multi_add3_args* a, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && a->count > 0 && a->count <= SPGAN_MULTI_MAX);
+  int nmax = 0;
+  for (int t = 0; t < a->count; ++t) {
+    SPGAN_CHECK_ARG(a->dst[t] && a->src[t] && a->n[t] > 0 && a->n1[t] > 0 && a->n2[t] > 0 && a->n[t] % (a->n1[t] * a->n2[t]) == 0);
+    nmax = a->n[t] > nmax ? a->n[t] : nmax;
+  }
+  int bx = cdiv(nmax, 256 * 4);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(multi_add3_kernel, dim3(bx, a->count), dim3(256), 0, (hipStream_t)s_, *a);
+  return spgan_launch_status();
+}
+
 extern "C" int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a && a->count > 0 && a->count <= SPGAN_MULTI_MAX);
   int nmax = 0;
@@ -627,9 +660,9 @@ extern "C" int spgan_affine_act(const float* X, int ldx, size_t M, int C, const 
 }
 
 extern "C" int spgan_rowscale_outer(const float* X, int ldx, int R, int C, const float* a, const float* b, const float* d, const float* v,
-                                    float* out, int ldo, spgan_stream_t s_) {
+                                    float* out, int ldo, int accumulate, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(X && a && out && R > 0 && C > 0 && ldx >= C && ldo >= C && (!v || (b && d)));
-  hipLaunchKernelGGL(rowscale_outer_kernel, dim3(cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)s_, X, ldx, R, C, a, b, d, v, out, ldo);
+  hipLaunchKernelGGL(rowscale_outer_kernel, dim3(cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)s_, X, ldx, R, C, a, b, d, v, out, ldo, accumulate);
   return spgan_launch_status();
 }
 

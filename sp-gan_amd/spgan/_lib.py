@@ -98,6 +98,11 @@ class MultiAddArgs(C.Structure):
     _fields_ = [("count", C.c_int), ("dst", C.c_void_p * MULTI_MAX), ("src", C.c_void_p * MULTI_MAX), ("n", C.c_int * MULTI_MAX)]
 
 
+class MultiAdd3Args(C.Structure):
+    _fields_ = [("count", C.c_int), ("dst", C.c_void_p * MULTI_MAX), ("src", C.c_void_p * MULTI_MAX), ("n", C.c_int * MULTI_MAX),
+                ("n1", C.c_int * MULTI_MAX), ("n2", C.c_int * MULTI_MAX), ("ds", (C.c_long * MULTI_MAX) * 3), ("ss", (C.c_long * MULTI_MAX) * 3)]
+
+
 class MultiTransposeArgs(C.Structure):
     _fields_ = [("count", C.c_int), ("src", C.c_void_p * MULTI_MAX), ("dst", C.c_void_p * MULTI_MAX),
                 ("rows", C.c_int * MULTI_MAX), ("cols", C.c_int * MULTI_MAX), ("ld", C.c_int * MULTI_MAX),
@@ -137,7 +142,7 @@ SIGNATURES = {
     "spgan_sparse_rows_nt": (I, [P, P, I, I, I, P, I, I, P, I, P]),
     "spgan_sparse_rows_tn": (I, [P, P, I, I, I, P, I, I, P, P, F, P, I, P]),
     "spgan_affine_act": (I, [P, I, SZ, I, P, P, F, P, P]),
-    "spgan_rowscale_outer": (I, [P, I, I, I, P, P, P, P, P, I, P]),
+    "spgan_rowscale_outer": (I, [P, I, I, I, P, P, P, P, P, I, I, P]),
     "spgan_colreduce_ws_bytes": (SZ, [I, I, I]),
     "spgan_colstats_finalize": (I, [P, I, I, I, I, I, I, P, P, P]),
     "spgan_colstats_finalize_bn": (I, [P, I, I, I, I, P, P, F, F, P, P, P, P, P, P, P]),
@@ -149,7 +154,8 @@ SIGNATURES = {
     "spgan_bn_bwd_apply": (I, [P, P, I, I, I, P, P, P, P, I, P, P]),
     "spgan_bn_bwd_apply2": (I, [P, P, P, P, I, I, P, P, P, P, I, P, P]),
     "spgan_maxpool": (I, [P, I, I, I, I, P, P, F, P, P, P]),
-    "spgan_edge_wcat": (I, [P, P, I, I, I, P, P]),
+    "spgan_edge_wcat": (I, [P, P, I, I, I, P, P, P]),
+    "spgan_conv_out_weight_pm": (I, [P, I, I, P, P, P]),
     "spgan_edge_wcat_bwd": (I, [P, I, I, I, P, P, P]),
     "spgan_edge_stats_tile_rows": (I, [I]),
     "spgan_edge_stats": (I, [P, I, P, I, I, I, I, P, P, P, P]),
@@ -214,6 +220,7 @@ SIGNATURES = {
     "spgan_scale_residual_bwd_ws_bytes": (SZ, [SZ]),
     "spgan_scale_residual_bwd": (I, [P, P, P, P, P, P, SZ, SZ, P]),
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
+    "spgan_multi_add3": (I, [C.POINTER(MultiAdd3Args), P]),
     "spgan_reduce_chunks": (I, [P, I, C.c_size_t, P, P]),
     "spgan_bn_bwd_coeffs": (I, [P, P, P, P, I, F, P, P]),
     "spgan_colstats_finalize_bnbwd": (I, [P, I, I, I, I, P, P, P, F, P, P, P, P]),

@@ -102,11 +102,22 @@ def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool], f
             continue
         zero = isinstance(g, int)
         if fused and p.is_leaf and p.grad is not None and p.grad.is_contiguous() and (zero or p.grad.numel() == g.numel()):
-            if not zero:
+            if zero:
+                continue
+            if isinstance(g, nets.CatCols):      # column blocks of one weight: each goes straight into its slice of .grad
+                flat, c0 = p.grad.view(g.rows, -1), 0
+                for part in g.parts:
+                    pairs.append((flat[:, c0:c0 + part.shape[1]], part))
+                    c0 += part.shape[1]
+            elif g.is_contiguous() or g.shape == p.grad.shape:
+                pairs.append((p.grad, g))        # a strided view of the parameter's shape is added through its strides
+            else:
                 pairs.append((p.grad, g.contiguous()))
         elif zero:
             out[i] = torch.zeros_like(p)
         else:
+            if isinstance(g, nets.CatCols):
+                g = g.cat()
             out[i] = g.view_as(p) if g.shape != p.shape else g
     if pairs:
         ops.multi_add([d for d, _ in pairs], [s_ for _, s_ in pairs])
@@ -461,7 +472,7 @@ class HeadFn(Function):
         if need_p:
             gz = ops.gemm_tn(drb, zb.contiguous())                                       # [128, nz]
             ops.flush_tn()
-            grads = [torch.cat([g["head.0.weight.part"], gz], dim=1).view_as(w0), ops.colsum(drb)[0], g["head.2.weight"], g["head.2.bias"]]
+            grads = [nets.CatCols([g["head.0.weight.part"], gz]), ops.colsum(drb)[0], g["head.2.weight"], g["head.2.bias"]]
         return (None, dx, dz) + _deliver(params, grads, ctx.needs_input_grad[3:], ctx.fused)
 
 
@@ -550,5 +561,5 @@ class GlobalTailFn(Function):
         gg = nets.global_backward(P, ctx.gctx, Wt0[:, :ctx.Cg], drb, da2)
         g.update({k: v for k, v in gg.items() if k != "tail.0.weight.global"})
         ops.flush_tn()                 # the per-point half of tail.0's weight gradient was deferred
-        g["tail.0.weight"] = torch.cat([gg["tail.0.weight.global"], g.pop("tail.0.weight.part")], dim=1).view_as(P["tail.0.weight"])
+        g["tail.0.weight"] = nets.CatCols([gg["tail.0.weight.global"], g.pop("tail.0.weight.part")])
         return (None, da2 if ctx.needs_input_grad[1] else None) + _deliver(params, [g[n] for n in GT_NAMES], ctx.needs_input_grad[2:], ctx.fused)

@@ -568,10 +568,12 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
     else:
         gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)            # a3^T a3 and colsum(a3) from one launch
         abar_g = ops.gemm_nt_bnbwd(ys[2], G2, ys[2], psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part)
-    gw = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), c2, b4, c3, cs3)
-    gw = ops.axpby(1.0, ops.gemm_nt(Wc1, _t(top["Qqa"]), exact=True), 1.0, gw)             # + diag(c1).W.(q3^T a3)
-    ops.sparse_rows_tn(spB, argmax, N, ys[2], gw, pro=pro3)
-    grads[conv + ".weight"] = ops.axpby(1.0, gw, 1.0, grads[conv + ".weight"]).view_as(P[conv + ".weight"])
+    # the four terms are summed in place into phase A's part of the gradient (accumulating epilogues instead of axpby launches)
+    dW = grads[conv + ".weight"]
+    ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), c2, b4, c3, cs3, out=dW, accumulate=True)
+    ops.gemm_nt(Wc1, _t(top["Qqa"]), rowbias=dW, rows_per_group=1, out=dW, exact=True)     # + diag(c1).W.(q3^T a3)
+    ops.sparse_rows_tn(spB, argmax, N, ys[2], dW, pro=pro3)
+    grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
     grads[conv + ".bias"] = ZERO_GRAD
     return abar_g
 
@@ -713,20 +715,36 @@ def d_double_backward_eval(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False
 _WO_CACHE: Dict[int, tuple] = {}      # data_ptr -> (stamp, permuted weight, weakref to the owning Parameter)
 
 
-def conv_out_weight_pm(w: Tensor) -> Tensor:
-    """conv_out.weight [F,F,1,k] -> [F, k*F] with K index r*F + c (matches T's layout).  For a Parameter the copy is kept until the
-    weights change (both generator forwards of a train step see the same weights: nets._t's staleness rule)."""
-    F_, _, _, k = w.shape
+def conv_out_weight_pm(w: Tensor) -> Tuple[Tensor, Tensor]:
+    """conv_out.weight [F,F,1,k] -> (Wo [F, k*F] with K index r*F + c (matches T's layout), Wo^T) from one launch
+    (ops.conv_out_weight_pm): the forward product's operand and the one of the input gradient dT = dout . Wo.  For a Parameter the pair
+    is kept until the weights change (both generator forwards of a train step see the same weights: nets._t's staleness rule)."""
     owner = _owner(w)
     if owner is None:
-        return w[:, :, 0, :].permute(0, 2, 1).reshape(F_, k * F_).contiguous()
+        return ops.conv_out_weight_pm(w.contiguous())
     stamp = (ops.weights_epoch_of(owner), owner._version)          # this network's own optimiser steps, not the other's
     hit = _WO_CACHE.get(w.data_ptr())
     if hit is not None and hit[0] == stamp and hit[2]() is owner:
         return hit[1]
-    out = w.detach()[:, :, 0, :].permute(0, 2, 1).reshape(F_, k * F_).contiguous()
+    out = ops.conv_out_weight_pm(w.detach().contiguous())
     _WO_CACHE[w.data_ptr()] = (stamp, out, weakref.ref(owner))
     return out
+
+
+class CatCols:
+    """A weight gradient computed as column blocks [rows, c_i] of one [rows, sum c_i] matrix, not yet concatenated:
+    functions._deliver adds every block into its column range of the parameter's .grad (one fused launch for all gradients of the
+    pass) instead of a torch.cat launch followed by the accumulation; cat() materialises it for autograd's own accumulation."""
+
+    def __init__(self, parts):
+        self.parts = [p_ if p_.dim() == 2 else p_.reshape(p_.shape[0], -1) for p_ in parts]
+        self.rows = self.parts[0].shape[0]
+
+    def numel(self) -> int:
+        return sum(p_.numel() for p_ in self.parts)
+
+    def cat(self) -> Tensor:
+        return torch.cat(self.parts, dim=1)
 
 
 def drop_weight_caches() -> None:
@@ -740,7 +758,9 @@ def drop_weight_caches() -> None:
 
 
 def conv_out_weight_grad_from_pm(g: Tensor, F_: int, k: int) -> Tensor:
-    return g.view(F_, k, F_).permute(0, 2, 1).reshape(F_, F_, 1, k).contiguous()
+    """[F, k*F] (the GEMM's layout) -> the parameter's [F,F,1,k] as a permuted VIEW: functions._deliver adds it into .grad through its
+    strides (ops.multi_add), autograd's own accumulation takes it as it is -- no copy launch."""
+    return g.view(F_, k, F_).permute(0, 2, 1).unsqueeze(2)
 
 
 def edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int, training: bool = True, update_running: bool = True,
@@ -768,7 +788,7 @@ def _edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int
     Ww0 = P[pre + ".conv_w.0.weight"]; Wx = P[pre + ".conv_x.0.weight"]
     H, F_ = Ww0.shape[0], Wx.shape[0]
     b1, bx = P[pre + ".conv_w.0.bias"], P[pre + ".conv_x.0.bias"]
-    Wcat = ops.edge_wcat(_w2(Ww0), _w2(Wx))
+    Wcat, WcatT = ops.edge_wcat(_w2(Ww0), _w2(Wx), transposed=True)               # Wcat^T: the input gradient's operand, same launch
     PQR = ops.gemm_nt(x, Wcat)                                                   # [M, H+2F]
     E = M * k
     if training:
@@ -788,9 +808,9 @@ def _edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int
     h2pre, bn2 = _gemm_bn(PQR[:, :H], W2, b2, P, bufs, pre + ".conv_w.4", E, training, update_running, pro=(bn1[0], bn1[1], NEG), edge=(idx, b1),
                           **({"count_rep": count_rep} if training and count_rep > 1 else {}), **({"out_half": True} if s16 else {}))
     T = ops.edge_attend_fwd(h2pre, bn2[0], bn2[1], PQR, idx, bx, bnx[0], bnx[1], NEG, half=s16)
-    Wo = conv_out_weight_pm(P[pre + ".conv_out.weight"])
+    Wo, WoT = conv_out_weight_pm(P[pre + ".conv_out.weight"])
     out = ops.gemm_nt(T, Wo, P[pre + ".conv_out.bias"])
-    ctx = dict(x=x, idx=idx, B=B, N=N, PQR=PQR, Wcat=Wcat, bn1=bn1, bnx=bnx, bn2=bn2, h2pre=h2pre, T=T, Wo=Wo, H=H, F=F_, k=k, training=training)
+    ctx = dict(x=x, idx=idx, B=B, N=N, PQR=PQR, Wcat=Wcat, WcatT=WcatT, WoT=WoT, bn1=bn1, bnx=bnx, bn2=bn2, h2pre=h2pre, T=T, Wo=Wo, H=H, F=F_, k=k, training=training)
     return out, ctx
 
 
@@ -806,7 +826,7 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     # conv_out
     gwo, g[pre + ".conv_out.bias"] = ops.gemm_tn(dout, ctx["T"], with_colsum=True)      # the bias gradient rides along (column sums of dout)
     g[pre + ".conv_out.weight"] = conv_out_weight_grad_from_pm(gwo, F_, k)
-    dT = ops.gemm_nt(dout, _t(ctx["Wo"]), out_bf16=ctx["T"].dtype == torch.float16)     # [M, k*F]
+    dT = ops.gemm_nt(dout, ctx["WoT"], out_bf16=ctx["T"].dtype == torch.float16)     # [M, k*F]
     # softmax * conv_x product, both LeakyReLUs
     g2, gy, sums2, sumsy = ops.edge_attend_bwd(dT, ctx["h2pre"], bn2[0], bn2[1], bn2[3], bn2[2], PQR, idx, bx, bnx[0], bnx[1], bnx[3], bnx[2], NEG)
     g[pre + ".conv_w.4.weight"] = sums2[F_:]; g[pre + ".conv_w.4.bias"] = sums2[:F_]
@@ -837,7 +857,7 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     # biases in front of a train-mode BatchNorm: mathematically zero gradient
     g[pre + ".conv_w.0.bias"] = ZERO_GRAD
     g[pre + ".conv_x.0.bias"] = ZERO_GRAD
-    dx = ops.gemm_nt(dPQR, _t(ctx["Wcat"])) if need_dx else None
+    dx = ops.gemm_nt(dPQR, ctx["WcatT"]) if need_dx else None
     return dx, g
 
 

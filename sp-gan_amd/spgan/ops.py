@@ -964,15 +964,24 @@ def affine_act(X: Tensor, scale: Tensor, shift: Tensor, slope: float) -> Tensor:
     return out
 
 
-def rowscale_outer(X: Tensor, a: Tensor, b: Optional[Tensor] = None, d: Optional[Tensor] = None, v: Optional[Tensor] = None) -> Tensor:
-    """out[r,c] = a[r]*X[r,c] + (a[r]*b[r] + d[r])*v[c]   (v None: first term only)."""
+def rowscale_outer(X: Tensor, a: Tensor, b: Optional[Tensor] = None, d: Optional[Tensor] = None, v: Optional[Tensor] = None,
+                   out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """out[r,c] (+)= a[r]*X[r,c] + (a[r]*b[r] + d[r])*v[c]   (v None: first term only).  out: destination [R,C] with unit column stride;
+    accumulate=True adds into it (a term of a weight gradient summed in place)."""
     _rowmajor2d(X, "X")
     R, Cn = X.shape
-    out = torch.empty((R, Cn), dtype=torch.float32, device=X.device)
+    if out is None:
+        if accumulate:
+            raise ValueError("rowscale_outer(accumulate=True) needs out")
+        out = torch.empty((R, Cn), dtype=torch.float32, device=X.device)
+    else:
+        _rowmajor2d(out, "out")
+        if tuple(out.shape) != (R, Cn):
+            raise ValueError("rowscale_outer: out must be [%d,%d]" % (R, Cn))
     vb = vd = vv = None
     if v is not None:
         vb, vd, vv = _vec(b, R, "b"), _vec(d, R, "d"), _vec(v, Cn, "v")
-    check(_lib.load().spgan_rowscale_outer(_p(X), _ld(X), R, Cn, _p(_vec(a, R, "a")), _p(vb), _p(vd), _p(vv), _p(out), Cn, _s()),
+    check(_lib.load().spgan_rowscale_outer(_p(X), _ld(X), R, Cn, _p(_vec(a, R, "a")), _p(vb), _p(vd), _p(vv), _p(out), _ld(out), int(accumulate), _s()),
           "rowscale_outer", R=R, C=Cn)
     return out
 
@@ -1200,16 +1209,30 @@ def gemm_bn_groups(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, groups: int
 
 
 # ----------------------------------------------------------------------------- EdgeBlock gather-side ops
-def edge_wcat(Ww0: Tensor, Wx: Tensor) -> Tensor:
-    """[W1; Wd; Wc-Wd] from conv_w.0.weight [H,C] and conv_x.0.weight [F,2C] = [Wc|Wd] -> [H+2F, C]."""
+def edge_wcat(Ww0: Tensor, Wx: Tensor, transposed: bool = False):
+    """[W1; Wd; Wc-Wd] from conv_w.0.weight [H,C] and conv_x.0.weight [F,2C] = [Wc|Wd] -> [H+2F, C].
+    transposed=True: -> (Wcat, Wcat^T [C, H+2F]) from the same launch (the operand of the block's input-gradient GEMM)."""
     _f32(Ww0, "Ww0", 2); _f32(Wx, "Wx", 2)
     H, Cc = Ww0.shape
     F_ = Wx.shape[0]
     if not (Ww0.is_contiguous() and Wx.is_contiguous()) or Wx.shape[1] != 2 * Cc:
         raise ValueError("expected contiguous Ww0 [H,C] and Wx [F,2C]")
     out = torch.empty((H + 2 * F_, Cc), dtype=torch.float32, device=Ww0.device)
-    check(_lib.load().spgan_edge_wcat(_p(Ww0), _p(Wx), H, F_, Cc, _p(out), _s()), "edge_wcat")
-    return out
+    out_t = torch.empty((Cc, H + 2 * F_), dtype=torch.float32, device=Ww0.device) if transposed else None
+    check(_lib.load().spgan_edge_wcat(_p(Ww0), _p(Wx), H, F_, Cc, _p(out), _p(out_t), _s()), "edge_wcat")
+    return (out, out_t) if transposed else out
+
+
+def conv_out_weight_pm(w: Tensor) -> Tuple[Tensor, Tensor]:
+    """conv_out.weight [F,F,1,k] -> (Wo [F, k*F] with K index r*F + c, Wo^T [k*F, F]) in one launch."""
+    _f32(w, "w", 4)
+    F_, F2, one, k = w.shape
+    if F2 != F_ or one != 1 or not w.is_contiguous():
+        raise ValueError("conv_out.weight must be contiguous [F,F,1,k]")
+    wo = torch.empty((F_, k * F_), dtype=torch.float32, device=w.device)
+    wot = torch.empty((k * F_, F_), dtype=torch.float32, device=w.device)
+    check(_lib.load().spgan_conv_out_weight_pm(_p(w), F_, k, _p(wo), _p(wot), _s()), "conv_out_weight_pm", F=F_, k=k)
+    return wo, wot
 
 
 def edge_wcat_bwd(dWcat: Tensor, H: int, F_: int) -> Tuple[Tensor, Tensor]:
@@ -1620,22 +1643,60 @@ def scale_residual_bwd(dy: Tensor, o: Tensor, gamma: Tensor):
     return d_o, dgamma
 
 
+def _strided3(d: Tensor, s: Tensor):
+    """(n1, n2, dst strides, src strides) of a pair with one common shape, as 3-D strided views (size-1 dimensions dropped); None when
+    both are contiguous (the plain pair).  Raises for pairs that need more than three strided dimensions."""
+    if d.is_contiguous() and s.is_contiguous():
+        return None
+    dims = [(n, ds_, ss_) for n, ds_, ss_ in zip(d.shape, d.stride(), s.stride()) if n != 1]
+    merged = []
+    for n, ds_, ss_ in dims:      # merge neighbours that are contiguous in BOTH views
+        if merged and merged[-1][1] == n * ds_ and merged[-1][2] == n * ss_:
+            pn, _, _ = merged[-1]
+            merged[-1] = (pn * n, ds_, ss_)
+        else:
+            merged.append((n, ds_, ss_))
+    if len(merged) > 3:
+        raise ValueError("multi_add: a pair needs more than three strided dimensions")
+    while len(merged) < 3:
+        merged.insert(0, (1, 0, 0))
+    return merged[1][0], merged[2][0], [m[1] for m in merged], [m[2] for m in merged]
+
+
 def multi_add(dsts, srcs) -> None:
-    """dst[t] += src[t] for a list of tensor pairs (contiguous fp32, equal sizes) in ceil(T/64) launches."""
-    from ._lib import MULTI_MAX, MultiAddArgs
+    """dst[t] += src[t] for a list of fp32 tensor pairs of equal shape in ceil(T/64) launches.  Contiguous pairs of equal size may differ
+    in shape; a pair of equal SHAPE may consist of strided views (<= 3 strided dimensions: a permuted source, a column block of the
+    destination) -- spgan_multi_add3."""
+    from ._lib import MULTI_MAX, MultiAddArgs, MultiAdd3Args
     lib = _lib.load()
     pairs = [(d, s) for d, s in zip(dsts, srcs)]
     for i0 in range(0, len(pairs), MULTI_MAX):
         chunk = pairs[i0:i0 + MULTI_MAX]
-        a = MultiAddArgs()
-        a.count = len(chunk)
+        views = []
         for t, (d, s) in enumerate(chunk):
-            if not (d.is_contiguous() and s.is_contiguous()) or d.numel() != s.numel() or d.dtype != torch.float32 or s.dtype != torch.float32:
-                raise ValueError("multi_add: pair %d is not a contiguous fp32 pair of equal size" % (i0 + t))
+            if d.numel() != s.numel() or d.dtype != torch.float32 or s.dtype != torch.float32:
+                raise ValueError("multi_add: pair %d is not an fp32 pair of equal size" % (i0 + t))
             if not (d.is_cuda and s.is_cuda):
                 raise RuntimeError("multi_add needs GPU tensors")
-            a.dst[t] = d.data_ptr(); a.src[t] = s.data_ptr(); a.n[t] = d.numel()
-        check(lib.spgan_multi_add(C.byref(a), _s()), "multi_add", count=len(chunk))
+            if not (d.is_contiguous() and s.is_contiguous()) and d.shape != s.shape:
+                raise ValueError("multi_add: strided pair %d must have one common shape" % (i0 + t))
+            views.append(_strided3(d, s))
+        if all(v is None for v in views):
+            a = MultiAddArgs()
+            a.count = len(chunk)
+            for t, (d, s) in enumerate(chunk):
+                a.dst[t] = d.data_ptr(); a.src[t] = s.data_ptr(); a.n[t] = d.numel()
+            check(lib.spgan_multi_add(C.byref(a), _s()), "multi_add", count=len(chunk))
+            continue
+        a3 = MultiAdd3Args()
+        a3.count = len(chunk)
+        for t, ((d, s), v) in enumerate(zip(chunk, views)):
+            a3.dst[t] = d.data_ptr(); a3.src[t] = s.data_ptr(); a3.n[t] = d.numel()
+            a3.n1[t], a3.n2[t] = (1, 1) if v is None else (v[0], v[1])
+            for ax in range(3):
+                a3.ds[ax][t] = 0 if v is None else v[2][ax]
+                a3.ss[ax][t] = 0 if v is None else v[3][ax]
+        check(lib.spgan_multi_add3(C.byref(a3), _s()), "multi_add3", count=len(chunk))
 
 
 def reduce_chunks(recv: Tensor, out: Optional[Tensor] = None) -> Tensor:

@@ -302,11 +302,14 @@ def affine_act(X, scale, shift, slope):
     return _lrelu(X * scale + shift, slope).contiguous()
 
 
-def rowscale_outer(X, a, b=None, d=None, v=None):
-    out = a[:, None] * X
+def rowscale_outer(X, a, b=None, d=None, v=None, out=None, accumulate=False):
+    o = a[:, None] * X
     if v is not None:
-        out = out + (a * b + d)[:, None] * v[None, :]
-    return out.contiguous()
+        o = o + (a * b + d)[:, None] * v[None, :]
+    if out is None:
+        return o.contiguous()
+    out.copy_(out + o if accumulate else o)
+    return out
 
 
 def flush_tn():
@@ -382,9 +385,16 @@ def maxpool(y, B, N, scale=None, shift=None, slope=1.0):
 
 
 # ----------------------------------------------------------------------------- EdgeBlock gather-side ops
-def edge_wcat(Ww0, Wx):
+def edge_wcat(Ww0, Wx, transposed=False):
     C = Ww0.shape[1]
-    return torch.cat([Ww0, Wx[:, C:], Wx[:, :C] - Wx[:, C:]], dim=0).contiguous()
+    out = torch.cat([Ww0, Wx[:, C:], Wx[:, :C] - Wx[:, C:]], dim=0).contiguous()
+    return (out, out.t().contiguous()) if transposed else out
+
+
+def conv_out_weight_pm(w):
+    F_, _, _, k = w.shape
+    wo = w[:, :, 0, :].permute(0, 2, 1).reshape(F_, k * F_).contiguous()
+    return wo, wo.t().contiguous()
 
 
 def edge_wcat_bwd(dWcat, H, F_):
@@ -720,7 +730,7 @@ def reduce_chunks(recv, out=None):
 
 def multi_add(dsts, srcs):
     for d, s in zip(dsts, srcs):
-        d.add_(s.reshape(d.shape))
+        d.add_(s if s.shape == d.shape else s.reshape(d.shape))
 
 
 def capturing():

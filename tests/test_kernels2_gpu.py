@@ -28,9 +28,46 @@ def _graph(ops, B, N, k, tag):
 def test_edge_wcat(ops, H, F_, C):
     Ww0, Wx = rnd("wc.a", (H, C)), rnd("wc.b", (F_, 2 * C))
     assert torch.equal(ops.edge_wcat(Ww0, Wx), km.edge_wcat(Ww0, Wx))
+    w, wt = ops.edge_wcat(Ww0, Wx, transposed=True)
+    assert torch.equal(w, km.edge_wcat(Ww0, Wx)) and torch.equal(wt, w.t().contiguous())
     d = rnd("wc.d", (H + 2 * F_, C))
     for a, b in zip(ops.edge_wcat_bwd(d, H, F_), km.edge_wcat_bwd(d, H, F_)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("F_,k", [(64, 20), (128, 10), (24, 3)])
+def test_conv_out_weight_pm(ops, F_, k):
+    """conv_out.weight [F,F,1,k] -> Wo [F, k*F] (K index r*F + c) and its transpose, one launch."""
+    w = rnd("cow.%d.%d" % (F_, k), (F_, F_, 1, k))
+    wo, wot = ops.conv_out_weight_pm(w)
+    ref, ref_t = km.conv_out_weight_pm(w)
+    assert torch.equal(wo, ref) and torch.equal(wot, ref_t)
+
+
+def test_multi_add_strided_pairs(ops):
+    """spgan_multi_add3: a permuted source (conv_out gradient [F,k,F] into [F,F,1,k]), column blocks of one destination, a plain pair
+    with differing shapes -- all in one launch, against torch's own accumulation."""
+    F_, k = 64, 10
+    dst_w = rnd("ma3.w", (F_, F_, 1, k)); g = rnd("ma3.g", (F_, k * F_))
+    dst_cat = rnd("ma3.c", (128, 192, 1)); a, b = rnd("ma3.a", (128, 64)), rnd("ma3.b", (128, 128))
+    dst_p = rnd("ma3.p", (37, 5)); c = rnd("ma3.pp", (185,))
+    want_w = dst_w + g.view(F_, k, F_).permute(0, 2, 1).unsqueeze(2)
+    want_cat = dst_cat + torch.cat([a, b], dim=1).unsqueeze(2)
+    want_p = dst_p + c.view(37, 5)
+    flat = dst_cat.view(128, 192)
+    ops.multi_add([dst_w, flat[:, :64], flat[:, 64:], dst_p], [g.view(F_, k, F_).permute(0, 2, 1).unsqueeze(2), a, b, c])
+    assert torch.equal(dst_w, want_w) and torch.equal(dst_cat, want_cat) and torch.equal(dst_p, want_p)
+    with pytest.raises(ValueError):
+        ops.multi_add([dst_p], [rnd("ma3.bad", (5, 37)).t()[:, :4]])
+
+
+def test_rowscale_outer_accumulates_in_place(ops):
+    X, a, b, d, v = rnd("rso.x", (96, 40)), rnd("rso.a", (96,)), rnd("rso.b", (96,)), rnd("rso.d", (96,)), rnd("rso.v", (40,))
+    base = rnd("rso.base", (96, 40))
+    want = base + km.rowscale_outer(X, a, b, d, v)
+    out = ops.rowscale_outer(X, a, b, d, v, out=base.clone(), accumulate=True)
+    close(out, want, rtol=1e-6, atol=1e-6)
+    assert torch.equal(ops.rowscale_outer(X, a, out=torch.empty_like(X)), ops.rowscale_outer(X, a))
 
 
 @pytest.mark.parametrize("B,N,k,H,F_", [(2, 200, 10, 32, 64), (2, 130, 10, 64, 128), (1, 77, 5, 16, 32)])
