@@ -555,12 +555,16 @@ int launch_knn(const float* x, int B, int N, int C, int k, int mode, int32_t* id
 // One workgroup per shape (edges never cross shapes, and each shape has exactly N*k edges, so its
 // segment of `src` starts at b*N*k).  Degree count and slot assignment use LDS integer atomics
 // (order-independent results after the per-segment sort).
+// LDS_SEG: the segments are filled and sorted in LDS as 16-bit local edge ids (E <= 65536) and leave with one coalesced store --
+// the per-point insertion sort is a chain of dependent accesses, ~10x shorter on LDS than on L2 (67 -> 2x us at B=32, N=2048).
+template <bool LDS_SEG>
 __global__ __launch_bounds__(1024) void csr_kernel(const int32_t* __restrict__ idx, int N, int k,
                                                    int32_t* __restrict__ rowptr, int32_t* __restrict__ src) {
   extern __shared__ int ism[];
   int* deg = ism;          // [N]
   int* start = ism + N;    // [N]   exclusive scan of deg
   int* wsum = ism + 2 * N; // [32]
+  unsigned short* lseg = reinterpret_cast<unsigned short*>(ism + 2 * N + 32);   // [E]  (LDS_SEG)
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int E = N * k;
   const int32_t* ib = idx + (size_t)b * E;
@@ -604,25 +608,49 @@ __global__ __launch_bounds__(1024) void csr_kernel(const int32_t* __restrict__ i
   }
   if (b == gridDim.x - 1 && tid == 0) rowptr[(size_t)gridDim.x * N] = gridDim.x * E;
   __syncthreads();
-  for (int e = tid; e < E; e += nt) {
-    const int j = ib[e] - b * N;
-    const int slot = atomicAdd(&deg[j], 1);
-    src[(size_t)b * E + start[j] + slot] = b * E + e;
-  }
-  __threadfence_block();
-  __syncthreads();
-  // sort each segment ascending (deterministic summation order downstream)
-  for (int i = tid; i < N; i += nt) {
-    int32_t* seg = src + (size_t)b * E + start[i];
-    const int n = deg[i];
-    for (int a = 1; a < n; ++a) {
-      const int v = seg[a];
-      int c = a - 1;
-      while (c >= 0 && seg[c] > v) {
-        seg[c + 1] = seg[c];
-        --c;
+  if constexpr (LDS_SEG) {
+    for (int e = tid; e < E; e += nt) {
+      const int j = ib[e] - b * N;
+      const int slot = atomicAdd(&deg[j], 1);
+      lseg[start[j] + slot] = (unsigned short)e;
+    }
+    __syncthreads();
+    // sort each segment ascending (deterministic summation order downstream)
+    for (int i = tid; i < N; i += nt) {
+      unsigned short* seg = lseg + start[i];
+      const int n = deg[i];
+      for (int a = 1; a < n; ++a) {
+        const unsigned short v = seg[a];
+        int c = a - 1;
+        while (c >= 0 && seg[c] > v) {
+          seg[c + 1] = seg[c];
+          --c;
+        }
+        seg[c + 1] = v;
       }
-      seg[c + 1] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += nt) src[(size_t)b * E + e] = b * E + (int)lseg[e];
+  } else {
+    for (int e = tid; e < E; e += nt) {
+      const int j = ib[e] - b * N;
+      const int slot = atomicAdd(&deg[j], 1);
+      src[(size_t)b * E + start[j] + slot] = b * E + e;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < N; i += nt) {
+      int32_t* seg = src + (size_t)b * E + start[i];
+      const int n = deg[i];
+      for (int a = 1; a < n; ++a) {
+        const int v = seg[a];
+        int c = a - 1;
+        while (c >= 0 && seg[c] > v) {
+          seg[c + 1] = seg[c];
+          --c;
+        }
+        seg[c + 1] = v;
+      }
     }
   }
 }
@@ -743,7 +771,17 @@ extern "C" int spgan_csr_build(const int32_t* idx, int B, int N, int k, int32_t*
   hipStream_t s = (hipStream_t)s_;
   SPGAN_CHECK_ARG(idx && rowptr && src && B > 0 && N > 0 && k > 0 && N <= 16384);
   const size_t sh = (size_t)(2 * N + 32) * sizeof(int);
-  hipLaunchKernelGGL(csr_kernel, dim3(B), dim3(1024), sh, s, idx, N, k, rowptr, src);
+  const size_t E = (size_t)N * k, sh_seg = sh + ((E * sizeof(unsigned short) + 15) & ~(size_t)15);
+  if (E <= 65536 && sh_seg <= 160 * 1024) {
+    static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(csr_kernel<true>, dim3(B), dim3(1024), sh_seg, s, idx, N, k, rowptr, src);
+  } else {
+    hipLaunchKernelGGL(csr_kernel<false>, dim3(B), dim3(1024), sh, s, idx, N, k, rowptr, src);
+  }
   return spgan_launch_status();
 }
 

@@ -85,11 +85,26 @@ def test_knn_features(ops, B, N, C, k):
         assert (gaps[~rows] < 1e-4).all(), "a non-tie row disagrees with the reference"
 
 
-def test_csr(ops):
-    B, N, k = 3, 300, 10
-    x = rnd("csr.x", (B * N, 3))
+@pytest.mark.parametrize("B,N,k", [(3, 300, 10), (2, 2048, 10), (2, 4096, 10), (1, 4096, 20), (2, 77, 32)])
+def test_csr(ops, B, N, k):
+    """In-edge lists: the LDS-segment route (N*k <= 65536 local edge ids, 16 bits each) and the in-place one behind it (4096 x 20)."""
+    x = rnd("csr.x.%d" % N, (B * N, 3))
     idx = ops.knn(x, B, N, k, mode=1)
     rowptr, src = ops.csr_build(idx, B, N)
+    rp, sr = km.csr_build(idx, B, N)
+    assert torch.equal(rowptr.cpu(), rp.cpu()) and torch.equal(src.cpu(), sr.cpu())
+
+
+def test_csr_hub_point(ops):
+    """One point that is everybody's neighbour (a segment of N entries) next to empty segments."""
+    B, N, k = 2, 512, 4
+    idx = torch.zeros((B * N, k), dtype=torch.int32, device="cuda")
+    ar = torch.arange(B * N, device="cuda", dtype=torch.int32)
+    base = (ar // N) * N
+    idx[:, 0] = base                                   # every point -> point 0 of its shape
+    for r in range(1, k):
+        idx[:, r] = base + (ar - base + r) % N
+    rowptr, src = ops.csr_build(idx.contiguous(), B, N)
     rp, sr = km.csr_build(idx, B, N)
     assert torch.equal(rowptr.cpu(), rp.cpu()) and torch.equal(src.cpu(), sr.cpu())
 
