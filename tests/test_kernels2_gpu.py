@@ -689,3 +689,21 @@ def test_gemm_dual_wide(ops, M, Nb, mode):
     close(gz, g2, rtol=3e-6, atol=3e-6 * float(g2.abs().max()), what="vs gemm_nt_bnbwd")
     res2 = ops.gemm_dual(dy, Wm, prev, sc, sh, mu, iv, 0.01, defer=False, **kw)
     assert all(torch.equal(a_, b_) for a_, b_ in zip(res, res2)), "not deterministic"
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 256, 256), (512, 96, 64), (96, 32, 32), (2048, 64, 128), (1024, 256, 224)])
+def test_gemm_nt_small_row_products(ops, M, N, K):
+    """csrc/gemm_mid.hip: weight-by-weight products (few rows, K <= 256) on 32 x 32 tiles with K staged once -- bias, per-row addend
+    (rows_per_group = 1: a full [M,N] tensor, also in place), activation; against float64."""
+    A, W, b = rnd("mid.a.%d.%d" % (M, K), (M, K)), rnd("mid.w.%d.%d" % (N, K), (N, K), 0.2), rnd("mid.b.%d" % N, (N,))
+    ref = A.double() @ W.double().t()
+    close(ops.gemm_nt(A, W, exact=True), ref, rtol=2e-6, atol=2e-5)
+    close(ops.gemm_nt(A, W, b, act=ops.ACT_LRELU, slope=0.2, exact=True), torch.nn.functional.leaky_relu(ref + b.double(), 0.2), rtol=2e-6, atol=2e-5)
+    add = rnd("mid.add.%d.%d" % (M, N), (M, N))
+    want = ref + add.double()
+    out = add.clone()
+    got = ops.gemm_nt(A, W, rowbias=out, rows_per_group=1, out=out, exact=True)      # accumulate in place
+    assert got.data_ptr() == out.data_ptr()
+    close(out, want, rtol=2e-6, atol=2e-5)
+    grp = rnd("mid.grp.%d" % N, (M // 32, N))
+    close(ops.gemm_nt(A, W, rowbias=grp, rows_per_group=32, exact=True), ref + grp.double().repeat_interleave(32, dim=0), rtol=2e-6, atol=2e-5)
