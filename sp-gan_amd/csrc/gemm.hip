@@ -26,7 +26,6 @@
 
 #include "common.hpp"
 #include "gemm_wide.hpp"
-#include "gemm_mid.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -1262,9 +1261,6 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
   }
   if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE2 && EPI != SPGAN_EPI_EDGE_BNBWD) {
     if (spgan_nt_wide_selected(a)) return spgan_launch_nt_wide(a, s);  // large aligned products: 256 x 256 tiles (gemm_wide.hip)
-  }
-  if constexpr (AMODE == SPGAN_A_PLAIN && EPI == SPGAN_EPI_LINEAR) {
-    if (spgan_nt_mid_selected(a)) return spgan_launch_nt_mid(a, s);    // few rows, K <= 256: 32 x 32 tiles, K staged once (gemm_mid.hip)
   }
   if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE_SPARSE && AMODE != A_AFFINE2 && EPI != SPGAN_EPI_EDGE_BNBWD) {
     if (a.M <= 64 && fast && !a.sp_val && a.batch <= 1 && !a.pool_val) {

@@ -693,8 +693,8 @@ def test_gemm_dual_wide(ops, M, Nb, mode):
 
 @pytest.mark.parametrize("M,N,K", [(1024, 256, 256), (512, 96, 64), (96, 32, 32), (2048, 64, 128), (1024, 256, 224)])
 def test_gemm_nt_small_row_products(ops, M, N, K):
-    """csrc/gemm_mid.hip: weight-by-weight products (few rows, K <= 256) on 32 x 32 tiles with K staged once -- bias, per-row addend
-    (rows_per_group = 1: a full [M,N] tensor, also in place), activation; against float64."""
+    """Weight-by-weight products (few rows, K <= 256): bias, per-row addend (rows_per_group = 1: a full [M,N] tensor, also in place --
+    how fc2.0's double-backward weight gradient sums its terms), activation; against float64."""
     A, W, b = rnd("mid.a.%d.%d" % (M, K), (M, K)), rnd("mid.w.%d.%d" % (N, K), (N, K), 0.2), rnd("mid.b.%d" % N, (N,))
     ref = A.double() @ W.double().t()
     close(ops.gemm_nt(A, W, exact=True), ref, rtol=2e-6, atol=2e-5)

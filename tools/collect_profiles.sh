@@ -30,6 +30,5 @@ bash $R/tools/profile_f16.sh $TAG > /dev/null 2>&1      # kernel table of the "f
 python $R/tools/exp/wide_k_sweep.py > $O/${TAG}_wide_k_sweep.txt 2>/dev/null
 python $R/tools/exp/mid_k_sweep.py > $O/${TAG}_mid_k_sweep.txt 2>/dev/null
 bash $R/tools/knn_pmc.sh > $O/${TAG}_knn_pmc.txt 2>&1                      # PMC passes over the kNN launches (both routes)
-python $R/tools/exp/mid_gemm_ab.py > $O/${TAG}_mid_gemm_ab.txt 2>/dev/null
 python $R/tools/torch_ops_in_step.py > $O/${TAG}_torch_ops_in_step.txt 2>/dev/null
 echo collected; ls -la $O | tail -20

@@ -1,3 +1,10 @@
+// KEPT NEGATIVE RESULT (round 4), not compiled into libspgan_hip.so.  It was routed from launch_nt for plain / LINEAR problems with
+// few rows and K <= 256.  Back to back it is faster than the 128 x 64-tile kernel (13.4 -> 9.7 us at 1024 x 256 x 256, 8.0 -> 6.0 at
+// 2048 x 64 x 128; tools/exp/mid_gemm_ab.py of commit 68a6d64), but inside the replayed train step the six launches it served went
+// 15.6 -> 14.5 us only (cold operands: the chain is one HBM round trip either way), and its summation order (K split over the four
+// waves, tree sum) differs from the 128-row kernels' single chain: at the small golden size (B=4, N=256, where activations also
+// have ~1000 rows) the 1e-7 changes flipped a near-tie of D's max-pool arg-max and moved the D-step gradients by 2-5 % -- outside the
+// reference-golden tolerances that hold when the arg-max agrees (tools/exp/op_trace.py found the flip).  6 us per step was not worth that.
 // gemm_nt for the weight-by-weight products of the train step: a few hundred to a few thousand rows, K <= 256 -- the Gram-matrix
 // forms of D's collapsed 256 -> 1024 layer (Discriminator.py:77-81: W [1024,256] times [256,256] sums over the points, six per step)
 // and their relatives.  The 128-row kernels of gemm.hip give such a problem 16-32 workgroups that each walk K in 32-wide steps:
@@ -8,6 +15,7 @@
 //     and the four partial tiles are summed in a fixed order through LDS -- fp32 operands, deterministic.
 // Plain operands and the LINEAR epilogue (bias, row addend, activation) only; everything else stays with gemm.hip.
 #include <math.h>
+#include <stdlib.h>
 #include "gemm_mid.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -88,6 +96,8 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 }  // namespace
 
 bool spgan_nt_mid_selected(const spgan_gemm_nt_args& a) {
+  static const bool off = getenv("SPGAN_NT_MID") && atoi(getenv("SPGAN_NT_MID")) == 0;   // A/B measurements of whole programs
+  if (off) return false;
   if (a.a_mode != SPGAN_A_PLAIN || a.epi_mode != SPGAN_EPI_LINEAR || a.stats || a.pool_val || a.batch > 1 || a.tail.enabled || a.mfma_f16 != 0 ||
       a.a_half || a.y_bf16 || a.y_half || a.A2 || a.sp_val || a.tile_hint != 0 || !a.Y)
     return false;
