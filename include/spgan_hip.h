@@ -304,6 +304,19 @@ int spgan_gemm_dual(const spgan_gemm_dual_args* a, spgan_stream_t s);
  * C % 256 == 0, K % 32 == 0; deterministic (fixed-order sums). */
 int spgan_wt_diag_w(const float* W, int ldw, int C, int K, const float* alpha, const float* beta, const float* bias, float* G, int ldg,
                     float* cvec, spgan_stream_t s);
+/* Both of the above's launches for one collapsed backward pass -- spgan_wt_diag_w (nprob = 1 or 2 problems on the same W: the double backward needs
+ * W^T diag(c1) W and W^T diag(c2) W) and spgan_sparse_rows_nt (E [B*rows, K] = S.W, Cs = C) -- as ONE launch: the weight-only part is latency-bound on
+ * a fraction of the chip and finishes under the part that streams E out.  Results bit-identical to the separate launches.  cvec[p] / beta[p] /
+ * bias[p] NULL: no cvec for problem p. */
+typedef struct spgan_collapse_prep_args {
+  const float* W; int ldw, C, K;
+  int nprob;
+  const float* alpha[2]; const float* beta[2]; const float* bias[2];
+  float* G[2]; int ldg; float* cvec[2];
+  const float* sp_val; const int32_t* sp_arg; int B, rows;
+  float* E; int lde;
+} spgan_collapse_prep_args;
+int spgan_collapse_prep(const spgan_collapse_prep_args* a, spgan_stream_t s);
 int spgan_sparse_rows_nt(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* W, int ldw, int N, float* E, int lde,
                          spgan_stream_t s);
 int spgan_sparse_rows_tn(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* Bm, int ldb, int Nb,

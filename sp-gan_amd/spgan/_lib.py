@@ -103,6 +103,13 @@ class MultiAdd3Args(C.Structure):
                 ("n1", C.c_int * MULTI_MAX), ("n2", C.c_int * MULTI_MAX), ("ds", (C.c_long * MULTI_MAX) * 3), ("ss", (C.c_long * MULTI_MAX) * 3)]
 
 
+class CollapsePrepArgs(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("ldw", C.c_int), ("C", C.c_int), ("K", C.c_int), ("nprob", C.c_int),
+                ("alpha", C.c_void_p * 2), ("beta", C.c_void_p * 2), ("bias", C.c_void_p * 2), ("G", C.c_void_p * 2), ("ldg", C.c_int),
+                ("cvec", C.c_void_p * 2), ("sp_val", C.c_void_p), ("sp_arg", C.c_void_p), ("B", C.c_int), ("rows", C.c_int),
+                ("E", C.c_void_p), ("lde", C.c_int)]
+
+
 class MultiTransposeArgs(C.Structure):
     _fields_ = [("count", C.c_int), ("src", C.c_void_p * MULTI_MAX), ("dst", C.c_void_p * MULTI_MAX),
                 ("rows", C.c_int * MULTI_MAX), ("cols", C.c_int * MULTI_MAX), ("ld", C.c_int * MULTI_MAX),
@@ -198,6 +205,7 @@ SIGNATURES = {
     "spgan_knn_point": (I, [I, P, P, I, I, I, I, P, P]),
     "spgan_group_concat": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
     "spgan_wt_diag_w": (I, [P, I, I, I, P, P, P, P, I, P, P]),
+    "spgan_collapse_prep": (I, [C.POINTER(CollapsePrepArgs), P]),
     "spgan_gemm_dual_wgs": (I, [I, I, I, I]),
     "spgan_gemm_dual_rows_per_wg": (I, [I, I, I]),
     "spgan_gemm_dual": (I, [C.POINTER(GemmDualArgs), P]),

@@ -443,11 +443,12 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             # sides of the Gram product, whose launch also yields colsum(a3); the sparse rows; the input-gradient GEMM)
             pro3 = (sc, sh, NEG)
             if W.shape[0] % 256 == 0 and W.shape[1] % 32 == 0:
-                G4, cvec = ops.wt_diag_w(W, alpha, beta, b4)                      # W^T diag(alpha) W and (alpha*b4 + beta).W in one launch
+                # W^T diag(alpha) W, (alpha*b4 + beta).W and S.W (dense rows) in one launch: the weight-only part finishes under the streaming one
+                ((G4, cvec),), E = ops.collapse_prep(W, [(alpha, beta, b4)], dy.sp_val, dy.sp_arg, N)
             else:
                 G4 = ops.gemm_tn(W, ops.rowscale_outer(W, alpha))                     # W^T diag(alpha) W
                 cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(alpha, beta, 1.0), exact=True)[0]  # (alpha*b4 + beta).W
-            E = ops.sparse_rows_nt(dy.sp_val, dy.sp_arg, N, W)                    # S.W, dense rows
+                E = ops.sparse_rows_nt(dy.sp_val, dy.sp_arg, N, W)                # S.W, dense rows
             lazy = _lazy_ok(M, sc.numel())
             cb = dict(coef_bn=(P[D_LAYERS[2][1] + ".weight"], M)) if lazy else {}     # the finalize launch also emits the lazy operand's coefficients
             a3 = ops.ActOperand(ys[2], sc, sh, NEG)
@@ -554,12 +555,13 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
     Wc1 = ops.rowscale_outer(W, c1)
     psc, psh, pinv, pmu = bns[2]
     if W.shape[0] % 256 == 0 and W.shape[1] % 32 == 0:
-        G1 = ops.wt_diag_w(W, c1)                                                  # W^T diag(c1) W
-        G2, cvec = ops.wt_diag_w(W, c2, c3, b4)                                    # W^T diag(c2) W, (c2*b4 + c3).W
+        # W^T diag(c1) W;  W^T diag(c2) W, (c2*b4 + c3).W;  spB.W -- one launch (ops.collapse_prep)
+        (G1, (G2, cvec)), EB = ops.collapse_prep(W, [(c1, None, None), (c2, c3, b4)], spB, argmax, N)
     else:
         G1, G2 = ops.gemm_tn(W, Wc1), ops.gemm_tn(W, ops.rowscale_outer(W, c2))
         cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(c2, c3, 1.0), exact=True)[0]
-    part = ops.gemm_nt(q3, G1, rowbias=ops.sparse_rows_nt(spB, argmax, N, W), rows_per_group=1)
+        EB = ops.sparse_rows_nt(spB, argmax, N, W)
+    part = ops.gemm_nt(q3, G1, rowbias=EB, rows_per_group=1)
     a3 = ops.ActOperand(ys[2], pro3[0], pro3[1], NEG)
     if ops.gemm_dual_ok(a3, G2, ys[2]):
         # a3^T a3, colsum(a3) and the outgoing adjoint a3.G2 (+ addends, layer 3's mask / sums epilogue) from one staging of the y3 tile

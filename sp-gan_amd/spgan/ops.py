@@ -926,6 +926,33 @@ def wt_diag_w(W: Tensor, alpha: Tensor, beta: Optional[Tensor] = None, bias: Opt
     return G if cvec is None else (G, cvec)
 
 
+def collapse_prep(W: Tensor, problems, val: Tensor, arg: Tensor, rows: int):
+    """What the collapsed backward of the layer in front of the max-pool needs before its big launch, in ONE launch:
+    problems = one or two (alpha, beta | None, bias | None) -> wt_diag_w(W, alpha, beta, bias) each, and E = sparse_rows_nt(val, arg, rows, W).
+    -> ([G or (G, cvec), ...], E); bit-identical to the separate launches (the weight-only part, latency-bound on a fraction of the chip,
+    finishes under the part that streams E out)."""
+    from ._lib import CollapsePrepArgs
+    _rowmajor2d(W, "W"); _f32(val, "val", 2)
+    Cn, K = W.shape
+    B, Cs = val.shape
+    if Cn % 256 or K % 32 or Cs != Cn or not 1 <= len(problems) <= 2:
+        raise ValueError("collapse_prep: W [C,K] with C % 256 == 0, K % 32 == 0, val [B,C], one or two problems")
+    a = CollapsePrepArgs()
+    a.W = _p(W); a.ldw = _ld(W); a.C = Cn; a.K = K; a.nprob = len(problems); a.ldg = K
+    outs, keep = [], [val.contiguous(), _i32(arg, "arg")]
+    for i, (alpha, beta, bias) in enumerate(problems):
+        G = torch.empty((K, K), dtype=torch.float32, device=W.device)
+        cvec = torch.empty((K,), dtype=torch.float32, device=W.device) if beta is not None else None
+        va = _vec(alpha, Cn, "alpha"); vb = None if beta is None else _vec(beta, Cn, "beta"); vc = None if beta is None else _vec(bias, Cn, "bias")
+        keep += [va, vb, vc]
+        a.alpha[i] = _p(va); a.beta[i] = _p(vb); a.bias[i] = _p(vc); a.G[i] = _p(G); a.cvec[i] = _p(cvec)
+        outs.append(G if cvec is None else (G, cvec))
+    E = torch.empty((B * rows, K), dtype=torch.float32, device=W.device)
+    a.sp_val = _p(keep[0]); a.sp_arg = _p(keep[1]); a.B = B; a.rows = rows; a.E = _p(E); a.lde = K
+    check(_lib.load().spgan_collapse_prep(C.byref(a), _s()), "collapse_prep", C=Cn, K=K, B=B, rows=rows)
+    return outs, E
+
+
 def sparse_rows_nt(val: Tensor, arg: Tensor, rows: int, W: Tensor) -> Tensor:
     """E[m,:] = sum_{c: arg[b,c]==m} val[b,c] * W[c,:]  (b = m // rows): the row-sparse product S @ W, written densely [B*rows, N]."""
     _f32(val, "val", 2); _rowmajor2d(W, "W")

@@ -241,6 +241,11 @@ def _sparse_dense(val, arg, rows):
     return S
 
 
+def collapse_prep(W, problems, val, arg, rows):
+    outs = [wt_diag_w(W, al) if be is None else wt_diag_w(W, al, be, bi) for al, be, bi in problems]
+    return outs, sparse_rows_nt(val, arg, rows, W)
+
+
 def sparse_rows_nt(val, arg, rows, W):
     return (_sparse_dense(val, arg, rows) @ W).contiguous()
 

@@ -144,3 +144,24 @@ def test_wt_diag_w(C, K):
     close(G, ops.gemm_tn(W, ops.rowscale_outer(W, alpha)), rtol=3e-6, atol=3e-6 * float(ref.abs().max()), what="G vs gemm_tn")
     G2 = ops.wt_diag_w(W, alpha)
     assert torch.equal(G, G2) and torch.equal(ops.wt_diag_w(W, alpha, beta, b)[1], cvec)
+
+
+@pytest.mark.parametrize("C,K,B,rows", [(1024, 256, 4, 256), (512, 64, 3, 96), (1024, 256, 32, 2048)])
+def test_collapse_prep_equals_its_parts(C, K, B, rows):
+    """ops.collapse_prep: one or two wt_diag_w problems and the sparse-row product S.W from ONE launch -- bit-identical to the separate launches
+    (the same device functions), for one problem with cvec, and for two (the double backward: no cvec / cvec)."""
+    from spgan import ops
+    from test_kernels_gpu import rnd
+    W = rnd("cp.W%d" % C, (C, K), 0.1)
+    a1, a2, beta, b = rnd("cp.a1%d" % C, (C,)), rnd("cp.a2%d" % C, (C,)), rnd("cp.b%d" % C, (C,), 0.3), rnd("cp.c%d" % C, (C,), 0.2)
+    val = rnd("cp.val%d.%d" % (C, B), (B, C))
+    g = torch.Generator().manual_seed(C + rows)
+    local = torch.randint(0, rows, (B, C), generator=g)
+    local[:, : C // 4] = 7 % rows                                   # a hub row: a quarter of the channels share one arg-max
+    arg = (local + torch.arange(B)[:, None] * rows).to(torch.int32).cuda()
+    E_ref = ops.sparse_rows_nt(val, arg, rows, W)
+    G_ref, c_ref = ops.wt_diag_w(W, a2, beta, b)
+    ((G, cv),), E = ops.collapse_prep(W, [(a2, beta, b)], val, arg, rows)
+    assert torch.equal(G, G_ref) and torch.equal(cv, c_ref) and torch.equal(E, E_ref)
+    (G1, (G2, cv2)), E2 = ops.collapse_prep(W, [(a1, None, None), (a2, beta, b)], val, arg, rows)
+    assert torch.equal(G1, ops.wt_diag_w(W, a1)) and torch.equal(G2, G_ref) and torch.equal(cv2, c_ref) and torch.equal(E2, E_ref)
