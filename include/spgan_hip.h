@@ -317,6 +317,24 @@ typedef struct spgan_collapse_prep_args {
   float* E; int lde;
 } spgan_collapse_prep_args;
 int spgan_collapse_prep(const spgan_collapse_prep_args* a, spgan_stream_t s);
+/* The weight gradient of the collapsed layer, all of its terms in one launch (csrc/collapse.hip):
+ *   out[a,n] (+)= a1[a] * sum_k W[a,k]*X1[n,k]  +  (a1[a]*b1[a] + d1[a]) * v1[n]  +  a2[a] * sum_k W[a,k]*X2[n,k]
+ *                 +  sum_b sp_val[b,a] * pro(Bm)[sp_arg[b,a], n]          (pro = lrelu(x*p_scale[n] + p_shift[n], p_slope), or identity)
+ * W [C,K], X1 [N,K] (a Gram matrix / q^T a of the double backward), K <= 256, C, N, K multiples of 32, 16-byte aligned rows.  Optional: the rank-1 term
+ * (v1, b1, d1), the second product (X2 [N,K], or [K,N] with x2_t = 1: used transposed; a2), the sparse term (sp_val / sp_arg [B,C], global rows of
+ * Bm [B*rows, N]; B <= 64; shapes in ascending order), T [C,N] = the raw first product, accumulate != 0: out += .  Replaces spgan_gemm_nt +
+ * spgan_rowscale_outer + spgan_sparse_rows_tn (and, in the double backward, a transpose, a second product and two axpby). */
+typedef struct spgan_wgrad_collapse_args {
+  const float* W; int ldw, C, K;
+  const float* X1; int ldx1;
+  const float* a1; const float* b1; const float* d1; const float* v1;
+  const float* X2; int ldx2, x2_t; const float* a2;
+  const float* sp_val; const int32_t* sp_arg; int B, rows;
+  const float* Bm; int ldb; const float* p_scale; const float* p_shift; float p_slope;
+  float* T; int ldt;
+  float* out; int ldo, N, accumulate;
+} spgan_wgrad_collapse_args;
+int spgan_wgrad_collapse(const spgan_wgrad_collapse_args* a, spgan_stream_t s);
 int spgan_sparse_rows_nt(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* W, int ldw, int N, float* E, int lde,
                          spgan_stream_t s);
 int spgan_sparse_rows_tn(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* Bm, int ldb, int Nb,

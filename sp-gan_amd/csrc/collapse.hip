@@ -116,7 +116,213 @@ __global__ __launch_bounds__(256) void collapse_prep_kernel(const spgan_collapse
   sparse_rows_nt_body(id % chunks, id / chunks, reinterpret_cast<unsigned*>(dyn), a.sp_val, a.sp_arg, a.rows, a.C, a.W, a.ldw, a.K, a.E, a.lde, RB);
 }
 
+// spgan_wgrad_collapse: the weight gradient of the collapsed layer, all of its terms in ONE launch
+//   out[a, n] (+)= a1[a] * sum_k W[a,k] X1[n,k]  +  (a1[a]*b1[a] + d1[a]) * v1[n]  +  a2[a] * sum_k W[a,k] X2[n,k]
+//                 + sum_b val[b,a] * pro(Bm)[arg[b,a], n]
+// (before: gemm_nt on 32 workgroups, rowscale_outer, a transpose + a second gemm_nt + axpby in the double backward, tn_sparse_rows: three to six
+// launches of 5-15 us each).  One workgroup per 32 x 32 output tile (256 for [1024, 256]); the W tile and the X tiles [32, K <= 256] are staged
+// once -- every load of the launch, the arg-max indices of the sparse term included, is in flight together --, the four waves split K
+// (v_mfma_f32_32x32x2_f32, fp32 operands), their partial tiles are summed in wave order through LDS, and the epilogue's gathers (one B row
+// segment per shape and output row, shapes ascending: deterministic) are issued eight shapes at a time.
+constexpr int WG_KMAX = 256, WG_BMAX = 64;
+// LDS floats in front of the sparse term's index / value tables: the operand tiles, later overlaid by the waves' partial tiles (4096 per product)
+constexpr int wgrad_front(int K, int nx) { return (1 + nx) * 32 * (K + 4) > nx * 4096 ? (1 + nx) * 32 * (K + 4) : nx * 4096; }
+constexpr size_t wgrad_lds_bytes(int K, int nx) { return (size_t)(wgrad_front(K, nx) + 2 * 32 * WG_BMAX) * sizeof(float); }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_collapse_kernel(const spgan_wgrad_collapse_args p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  const int K = p.K, LDK = K + 4, K4 = K / 4;
+  const bool two = p.X2 != nullptr;
+  float* Ws = dyn;                                   // [32][LDK]
+  float* X1s = Ws + 32 * LDK;                        // [32][LDK]
+  float* X2s = X1s + 32 * LDK;                       // [32][LDK] (two terms)
+  int* sarg = reinterpret_cast<int*>(dyn + wgrad_front(K, two ? 2 : 1));  // [B][32]
+  float* sval = reinterpret_cast<float*>(sarg + 32 * WG_BMAX);          // [B][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int a0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  // ---- stage.  K == 256 (the layer this kernel exists for): every load of the launch is issued before the first LDS store, the sparse
+  // term's index / value tables first (the gathers of the epilogue wait for them); other K: tile by tile
+  const bool x2_rows = two && !p.x2_t;
+  const int nsp = p.sp_val ? 32 * p.B : 0;                 // <= 2048 table entries: <= 8 per thread
+  if (K == WG_KMAX) {
+    int si[8];
+    float sv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = min(tid + 256 * i, max(nsp - 1, 0));
+      const size_t off = (size_t)(e >> 5) * p.C + a0 + (e & 31);
+      si[i] = nsp ? p.sp_arg[off] : -1;
+      sv[i] = nsp ? p.sp_val[off] : 0.f;
+    }
+    float4 vw[8], vx[8], vy[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i, r = e >> 6, c = (e & 63) * 4;
+      vw[i] = *reinterpret_cast<const float4*>(p.W + (size_t)(a0 + r) * p.ldw + c);
+      vx[i] = *reinterpret_cast<const float4*>(p.X1 + (size_t)(n0 + r) * p.ldx1 + c);
+      if (x2_rows) vy[i] = *reinterpret_cast<const float4*>(p.X2 + (size_t)(n0 + r) * p.ldx2 + c);
+      else if (two) vy[i] = *reinterpret_cast<const float4*>(p.X2 + (size_t)(e >> 3) * p.ldx2 + n0 + (e & 7) * 4);   // X2 [K,N]: row k = e >> 3, 4 of the tile's columns
+      else vy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      if (e < nsp) {
+        sarg[e] = (si[i] >= 0 && si[i] < p.B * p.rows) ? si[i] : -1;
+        sval[e] = sv[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i, r = e >> 6, c = (e & 63) * 4;
+      *reinterpret_cast<float4*>(Ws + r * LDK + c) = vw[i];
+      *reinterpret_cast<float4*>(X1s + r * LDK + c) = vx[i];
+    }
+    if (x2_rows) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i, r = e >> 6, c = (e & 63) * 4;
+        *reinterpret_cast<float4*>(X2s + r * LDK + c) = vy[i];
+      }
+    } else if (two) {   // transposed into the tile: X2s[n][k]
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i, k = e >> 3, c4 = (e & 7) * 4;
+        X2s[(c4 + 0) * LDK + k] = vy[i].x; X2s[(c4 + 1) * LDK + k] = vy[i].y; X2s[(c4 + 2) * LDK + k] = vy[i].z; X2s[(c4 + 3) * LDK + k] = vy[i].w;
+      }
+    }
+  } else {
+    for (int e = tid; e < nsp; e += 256) {
+      const int r = p.sp_arg[(size_t)(e >> 5) * p.C + a0 + (e & 31)];
+      sarg[e] = (r >= 0 && r < p.B * p.rows) ? r : -1;
+      sval[e] = p.sp_val[(size_t)(e >> 5) * p.C + a0 + (e & 31)];
+    }
+    for (int e = tid; e < 32 * K4; e += 256) {
+      const int r = e / K4, c = (e % K4) * 4;
+      *reinterpret_cast<float4*>(Ws + r * LDK + c) = *reinterpret_cast<const float4*>(p.W + (size_t)(a0 + r) * p.ldw + c);
+      *reinterpret_cast<float4*>(X1s + r * LDK + c) = *reinterpret_cast<const float4*>(p.X1 + (size_t)(n0 + r) * p.ldx1 + c);
+      if (x2_rows) *reinterpret_cast<float4*>(X2s + r * LDK + c) = *reinterpret_cast<const float4*>(p.X2 + (size_t)(n0 + r) * p.ldx2 + c);
+    }
+    if (two && p.x2_t) {   // X2 given as [K, N]: rows k, the tile's 32 columns n0.. -> LDS transposed
+      for (int e = tid; e < K * 8; e += 256) {
+        const int k = e >> 3, c = (e & 7) * 4;
+        const float4 q = *reinterpret_cast<const float4*>(p.X2 + (size_t)k * p.ldx2 + n0 + c);
+        X2s[(c + 0) * LDK + k] = q.x; X2s[(c + 1) * LDK + k] = q.y; X2s[(c + 2) * LDK + k] = q.z; X2s[(c + 3) * LDK + k] = q.w;
+      }
+    }
+  }
+  __syncthreads();
+  // this thread's four output rows (accumulator registers 4w .. 4w+3 of the tile: row = (r & 3) + 8*(r >> 2) + 4*lh) and its column
+  const int col = n0 + l31;
+  int rl[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) rl[u] = ((4 * wave + u) & 3) + 8 * ((4 * wave + u) >> 2) + 4 * lh;
+  // the sparse term's gathers, GS shapes x 4 rows per round, the first round in flight under the MFMA phase (one workgroup per CU: the
+  // memory-level parallelism has to come from the loads a thread keeps in flight)
+  constexpr int GS = 16;
+  float gv[GS][4];
+  int gr[GS][4];
+#define WG_GATHER(b0_)                                                                         \
+  _Pragma("unroll") for (int j = 0; j < GS; ++j) _Pragma("unroll") for (int u = 0; u < 4; ++u) { \
+    gr[j][u] = ((b0_) + j < p.B) ? sarg[((b0_) + j) * 32 + rl[u]] : -1;                           \
+    gv[j][u] = gr[j][u] >= 0 ? p.Bm[(size_t)gr[j][u] * p.ldb + col] : 0.f;                        \
+  }
+  if (p.sp_val) { WG_GATHER(0) }
+  // ---- wave w: k in [w*K/4, (w+1)*K/4); a 16-byte read at k + 4*lh feeds four MFMA steps
+  f32x16 acc1, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = 0.f;
+  const int ks = wave * (K / 4), ke = ks + K / 4;
+  const float* wp = Ws + l31 * LDK + 4 * lh;
+  const float* x1p = X1s + l31 * LDK + 4 * lh;
+  const float* x2p = X2s + l31 * LDK + 4 * lh;
+  for (int k = ks; k < ke; k += 8) {
+    const float4 a = *reinterpret_cast<const float4*>(wp + k), x = *reinterpret_cast<const float4*>(x1p + k);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, x.x, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, x.y, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, x.z, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, x.w, acc1, 0, 0, 0);
+    if (two) {
+      const float4 y = *reinterpret_cast<const float4*>(x2p + k);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, y.x, acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, y.y, acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, y.z, acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, y.w, acc2, 0, 0, 0);
+    }
+  }
+  __syncthreads();           // the operand tiles are dead: their LDS holds the partial tiles [term][wave][r][lane] (wgrad_front covers them)
+  float* red = dyn;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    red[(wave * 16 + r) * 64 + lane] = acc1[r];
+    if (two) red[4096 + (wave * 16 + r) * 64 + lane] = acc2[r];
+  }
+  __syncthreads();
+  // ---- epilogue
+  const float vcol = p.v1 ? p.v1[col] : 0.f;
+  float sc = 1.f, sh = 0.f;
+  if (p.p_scale) { sc = p.p_scale[col]; sh = p.p_shift[col]; }
+  float o[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = 4 * wave + u;
+    const int row = a0 + rl[u];
+    const float s1 = (red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + (red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane]);
+    if (p.T) p.T[(size_t)row * p.ldt + col] = s1;
+    const float al = p.a1[row];
+    float v = al * s1;
+    if (p.v1) v = fmaf(fmaf(al, p.b1[row], p.d1[row]), vcol, v);
+    if (two) {
+      const float s2 = (red[4096 + (0 * 16 + r) * 64 + lane] + red[4096 + (1 * 16 + r) * 64 + lane]) +
+                       (red[4096 + (2 * 16 + r) * 64 + lane] + red[4096 + (3 * 16 + r) * 64 + lane]);
+      v = fmaf(p.a2[row], s2, v);
+    }
+    o[u] = v;
+  }
+  if (p.sp_val) {
+    float add[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < p.B; b0 += GS) {
+      if (b0) { WG_GATHER(b0) }
+#pragma unroll
+      for (int j = 0; j < GS; ++j)       // shapes ascending: a fixed summation order
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float x = gv[j][u];
+          if (p.p_scale) x = lrelu_f(fmaf(x, sc, sh), p.p_slope);
+          if (gr[j][u] >= 0) add[u] = fmaf(sval[(b0 + j) * 32 + rl[u]], x, add[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] += add[u];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    float* q = p.out + (size_t)(a0 + rl[u]) * p.ldo + col;
+    *q = p.accumulate ? *q + o[u] : o[u];
+  }
+}
+
+#undef WG_GATHER
+
 }  // namespace
+
+extern "C" int spgan_wgrad_collapse(const spgan_wgrad_collapse_args* a, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && a->W && a->X1 && a->a1 && a->out && a->C > 0 && a->N > 0 && a->K >= 32 && a->K <= WG_KMAX);
+  SPGAN_CHECK_ARG(a->C % 32 == 0 && a->N % 32 == 0 && a->K % 32 == 0 && a->ldw >= a->K && a->ldx1 >= a->K && a->ldo >= a->N);
+  SPGAN_CHECK_ARG((a->ldw % 4 == 0) && (a->ldx1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(a->W) | reinterpret_cast<uintptr_t>(a->X1)) & 15) == 0);
+  SPGAN_CHECK_ARG(!a->v1 || (a->b1 && a->d1));
+  SPGAN_CHECK_ARG(!a->X2 || (a->a2 && (a->ldx2 % 4 == 0) && (reinterpret_cast<uintptr_t>(a->X2) & 15) == 0 && a->ldx2 >= (a->x2_t ? a->N : a->K)));
+  SPGAN_CHECK_ARG(!a->sp_val || (a->sp_arg && a->Bm && a->B > 0 && a->B <= WG_BMAX && a->rows > 0 && a->ldb >= a->N && (!a->p_scale == !a->p_shift)));
+  SPGAN_CHECK_ARG(!a->T || a->ldt >= a->N);
+  static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_collapse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes(WG_KMAX, 2));
+    attr_set = true;
+  }
+  const size_t lds = wgrad_lds_bytes(a->K, a->X2 ? 2 : 1);
+  hipLaunchKernelGGL(wgrad_collapse_kernel, dim3(a->C / 32, a->N / 32), dim3(256), lds, (hipStream_t)s_, *a);
+  return spgan_launch_status();
+}
 
 extern "C" int spgan_collapse_prep(const spgan_collapse_prep_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a && a->W && a->C > 0 && a->K > 0 && a->C % 256 == 0 && a->K % 32 == 0 && a->ldw >= a->K && a->ldg >= a->K && a->C <= 8192);

@@ -110,6 +110,15 @@ class CollapsePrepArgs(C.Structure):
                 ("E", C.c_void_p), ("lde", C.c_int)]
 
 
+class WgradCollapseArgs(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("ldw", C.c_int), ("C", C.c_int), ("K", C.c_int), ("X1", C.c_void_p), ("ldx1", C.c_int),
+                ("a1", C.c_void_p), ("b1", C.c_void_p), ("d1", C.c_void_p), ("v1", C.c_void_p),
+                ("X2", C.c_void_p), ("ldx2", C.c_int), ("x2_t", C.c_int), ("a2", C.c_void_p),
+                ("sp_val", C.c_void_p), ("sp_arg", C.c_void_p), ("B", C.c_int), ("rows", C.c_int),
+                ("Bm", C.c_void_p), ("ldb", C.c_int), ("p_scale", C.c_void_p), ("p_shift", C.c_void_p), ("p_slope", C.c_float),
+                ("T", C.c_void_p), ("ldt", C.c_int), ("out", C.c_void_p), ("ldo", C.c_int), ("N", C.c_int), ("accumulate", C.c_int)]
+
+
 class MultiTransposeArgs(C.Structure):
     _fields_ = [("count", C.c_int), ("src", C.c_void_p * MULTI_MAX), ("dst", C.c_void_p * MULTI_MAX),
                 ("rows", C.c_int * MULTI_MAX), ("cols", C.c_int * MULTI_MAX), ("ld", C.c_int * MULTI_MAX),
@@ -206,6 +215,7 @@ SIGNATURES = {
     "spgan_group_concat": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
     "spgan_wt_diag_w": (I, [P, I, I, I, P, P, P, P, I, P, P]),
     "spgan_collapse_prep": (I, [C.POINTER(CollapsePrepArgs), P]),
+    "spgan_wgrad_collapse": (I, [C.POINTER(WgradCollapseArgs), P]),
     "spgan_gemm_dual_wgs": (I, [I, I, I, I]),
     "spgan_gemm_dual_rows_per_wg": (I, [I, I, I]),
     "spgan_gemm_dual": (I, [C.POINTER(GemmDualArgs), P]),

@@ -462,8 +462,12 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
                     gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)      # a3^T a3 [256,256], colsum(a3)
                 g, s0, s1, *coef = ops.gemm_nt_bnbwd(ys[2], G4, ys[2], sc, sh, mu, inv, NEG, pro=pro3, bias=cvec, rowadd=E, **cb)
             if need_dparams:
-                dW = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), alpha, b4, beta, cs3)     # gram: a sum over B*N points
-                ops.sparse_rows_tn(dy.sp_val, dy.sp_arg, N, ys[2], dW, pro=pro3)
+                if ops.wgrad_collapse_ok(W, gram, B):
+                    # diag(alpha).W.(a3^T a3) + (alpha*b4 + beta) (x) colsum(a3) + S^T.a3 in one launch
+                    dW = ops.wgrad_collapse(W, gram, alpha, b4, beta, cs3, sparse=(dy.sp_val, dy.sp_arg, N, ys[2], pro3))
+                else:
+                    dW = ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), alpha, b4, beta, cs3)     # gram: a sum over B*N points
+                    ops.sparse_rows_tn(dy.sp_val, dy.sp_arg, N, ys[2], dW, pro=pro3)
                 grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
                 grads[conv + ".bias"] = ZERO_GRAD
             if need_dparams:
@@ -528,9 +532,13 @@ def _d_double_top_phase_a(P, ctx, saved, q3: Tensor, grads) -> dict:
     pro3 = (bns[2][0], bns[2][1], NEG)                                           # a3 = lrelu(bn3(y3)), applied to y3 on the operand loads
     Qqa = ops.gemm_tn(q3, ys[2], pro=pro3)                                       # q3^T a3 [256,256]
     cq = ops.colsum(q3)[0]
-    T = ops.gemm_nt(W, Qqa, exact=True)                                          # W.(a3^T q3) [1024,256]; Qqa: a sum over B*N points
-    dW = ops.rowscale_outer(T, dz.alpha, b4, dz.beta, cq)
-    ops.sparse_rows_tn(dz.sp_val, dz.sp_arg, N, q3, dW)
+    if ops.wgrad_collapse_ok(W, Qqa, B):
+        # T = W.(a3^T q3) and dW = diag(alpha).T + (alpha*b4 + beta) (x) colsum(q3) + S^T q3 from one launch
+        dW, T = ops.wgrad_collapse(W, Qqa, dz.alpha, b4, dz.beta, cq, sparse=(dz.sp_val, dz.sp_arg, N, q3, None), want_T=True)
+    else:
+        T = ops.gemm_nt(W, Qqa, exact=True)                                      # W.(a3^T q3) [1024,256]; Qqa: a sum over B*N points
+        dW = ops.rowscale_outer(T, dz.alpha, b4, dz.beta, cq)
+        ops.sparse_rows_tn(dz.sp_val, dz.sp_arg, N, q3, dW)
     grads[conv + ".weight"] = dW
     U0 = ops.gemm_nt(cq.view(1, -1), W, exact=True)[0]
     quad = ops.rowdot(W, T)                                                      # w_c^T (q3^T a3) w_c
@@ -552,13 +560,12 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
     dgamma, c1, c2, c3 = c4[0], c4[1], c4[2], c4[3]
     grads[bn + ".weight"] = dgamma
     grads[bn + ".bias"] = ZERO_GRAD
-    Wc1 = ops.rowscale_outer(W, c1)
     psc, psh, pinv, pmu = bns[2]
     if W.shape[0] % 256 == 0 and W.shape[1] % 32 == 0:
         # W^T diag(c1) W;  W^T diag(c2) W, (c2*b4 + c3).W;  spB.W -- one launch (ops.collapse_prep)
         (G1, (G2, cvec)), EB = ops.collapse_prep(W, [(c1, None, None), (c2, c3, b4)], spB, argmax, N)
     else:
-        G1, G2 = ops.gemm_tn(W, Wc1), ops.gemm_tn(W, ops.rowscale_outer(W, c2))
+        G1, G2 = ops.gemm_tn(W, ops.rowscale_outer(W, c1)), ops.gemm_tn(W, ops.rowscale_outer(W, c2))
         cvec = ops.gemm_nt(b4.view(1, -1), _t(W), pro=(c2, c3, 1.0), exact=True)[0]
         EB = ops.sparse_rows_nt(spB, argmax, N, W)
     part = ops.gemm_nt(q3, G1, rowbias=EB, rows_per_group=1)
@@ -570,11 +577,15 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
     else:
         gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)            # a3^T a3 and colsum(a3) from one launch
         abar_g = ops.gemm_nt_bnbwd(ys[2], G2, ys[2], psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part)
-    # the four terms are summed in place into phase A's part of the gradient (accumulating epilogues instead of axpby launches)
+    # the four terms are summed into phase A's part of the gradient
     dW = grads[conv + ".weight"]
-    ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), c2, b4, c3, cs3, out=dW, accumulate=True)
-    ops.gemm_nt(Wc1, _t(top["Qqa"]), rowbias=dW, rows_per_group=1, out=dW, exact=True)     # + diag(c1).W.(q3^T a3)
-    ops.sparse_rows_tn(spB, argmax, N, ys[2], dW, pro=pro3)
+    if ops.wgrad_collapse_ok(W, gram, B):
+        # diag(c2).W.(a3^T a3) + (c2*b4 + c3) (x) colsum(a3) + diag(c1).W.(q3^T a3) + spB^T a3, accumulated in one launch (q3^T a3 is used transposed)
+        ops.wgrad_collapse(W, gram, c2, b4, c3, cs3, X2=top["Qqa"], x2_t=True, a2=c1, sparse=(spB, argmax, N, ys[2], pro3), out=dW, accumulate=True)
+    else:
+        ops.rowscale_outer(ops.gemm_nt(W, gram, exact=True), c2, b4, c3, cs3, out=dW, accumulate=True)
+        ops.gemm_nt(ops.rowscale_outer(W, c1), _t(top["Qqa"]), rowbias=dW, rows_per_group=1, out=dW, exact=True)     # + diag(c1).W.(q3^T a3)
+        ops.sparse_rows_tn(spB, argmax, N, ys[2], dW, pro=pro3)
     grads[conv + ".weight"] = dW.view_as(P[conv + ".weight"])
     grads[conv + ".bias"] = ZERO_GRAD
     return abar_g

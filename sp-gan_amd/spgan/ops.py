@@ -953,6 +953,66 @@ def collapse_prep(W: Tensor, problems, val: Tensor, arg: Tensor, rows: int):
     return outs, E
 
 
+WGRAD_COLLAPSE = [True]   # test / A-B hook: False keeps the collapsed layer's weight gradient on its separate launches
+
+
+def wgrad_collapse_ok(W: Tensor, X1: Tensor, B: int = 0) -> bool:
+    """Does spgan_wgrad_collapse take this problem (W [C,K], X1 [N,K]; B shapes in the sparse term)?"""
+    Cn, K = W.shape
+    return (WGRAD_COLLAPSE[0] and W.is_cuda and Cn % 32 == 0 and X1.shape[0] % 32 == 0 and K % 32 == 0 and 32 <= K <= 256 and X1.shape[1] == K and B <= 64
+            and W.stride(0) % 4 == 0 and X1.stride(0) % 4 == 0 and W.data_ptr() % 16 == 0 and X1.data_ptr() % 16 == 0)
+
+
+def wgrad_collapse(W: Tensor, X1: Tensor, a1: Tensor, b1: Optional[Tensor] = None, d1: Optional[Tensor] = None, v1: Optional[Tensor] = None, *,
+                   X2: Optional[Tensor] = None, x2_t: bool = False, a2: Optional[Tensor] = None, sparse=None, out: Optional[Tensor] = None,
+                   accumulate: bool = False, want_T: bool = False):
+    """The collapsed layer's weight gradient, all terms in one launch (spgan_wgrad_collapse):
+      out[a,n] (+)= a1[a]*(W . X1^T)[a,n] + (a1*b1 + d1)[a]*v1[n] + a2[a]*(W . X2^T)[a,n] + sum_b val[b,a]*pro(Bm)[arg[b,a], n]
+    W [C,K], X1 [N,K]; X2 [N,K] or, with x2_t, [K,N]; sparse = (val [B,C], arg int32 [B,C] global rows, rows, Bm [B*rows,N], pro | None) with
+    pro = (scale[N], shift[N], slope).  -> out, or (out, T) with want_T (T = W . X1^T)."""
+    from ._lib import WgradCollapseArgs
+    _rowmajor2d(W, "W"); _rowmajor2d(X1, "X1")
+    Cn, K = W.shape
+    N = X1.shape[0]
+    if out is None:
+        if accumulate:
+            raise ValueError("wgrad_collapse(accumulate=True) needs out")
+        out = torch.empty((Cn, N), dtype=torch.float32, device=W.device)
+    else:
+        _rowmajor2d(out, "out")
+        if tuple(out.shape) != (Cn, N):
+            raise ValueError("wgrad_collapse: out must be [%d,%d]" % (Cn, N))
+    a = WgradCollapseArgs()
+    a.W = _p(W); a.ldw = _ld(W); a.C = Cn; a.K = K; a.X1 = _p(X1); a.ldx1 = _ld(X1); a.N = N
+    keep = [_vec(a1, Cn, "a1")]
+    a.a1 = _p(keep[0])
+    if v1 is not None:
+        keep += [_vec(b1, Cn, "b1"), _vec(d1, Cn, "d1"), _vec(v1, N, "v1")]
+        a.b1, a.d1, a.v1 = _p(keep[1]), _p(keep[2]), _p(keep[3])
+    if X2 is not None:
+        _rowmajor2d(X2, "X2")
+        if tuple(X2.shape) != ((K, N) if x2_t else (N, K)):
+            raise ValueError("wgrad_collapse: X2 must be [N,K] (or [K,N] with x2_t)")
+        keep.append(_vec(a2, Cn, "a2"))
+        a.X2 = _p(X2); a.ldx2 = _ld(X2); a.x2_t = int(x2_t); a.a2 = _p(keep[-1])
+    if sparse is not None:
+        val, arg, rows, Bm, pro = sparse
+        _f32(val, "val", 2); _rowmajor2d(Bm, "Bm")
+        B = val.shape[0]
+        if val.shape[1] != Cn or Bm.shape[0] != B * rows or Bm.shape[1] != N:
+            raise ValueError("wgrad_collapse: sparse term shapes")
+        keep += [val.contiguous(), _i32(arg, "arg")]
+        a.sp_val = _p(keep[-2]); a.sp_arg = _p(keep[-1]); a.B = B; a.rows = rows; a.Bm = _p(Bm); a.ldb = _ld(Bm)
+        if pro is not None:
+            keep += [_vec(pro[0], N, "pro.scale"), _vec(pro[1], N, "pro.shift")]
+            a.p_scale = _p(keep[-2]); a.p_shift = _p(keep[-1]); a.p_slope = float(pro[2])
+    T = torch.empty((Cn, N), dtype=torch.float32, device=W.device) if want_T else None
+    a.T = _p(T); a.ldt = N
+    a.out = _p(out); a.ldo = _ld(out); a.accumulate = int(accumulate)
+    check(_lib.load().spgan_wgrad_collapse(C.byref(a), _s()), "wgrad_collapse", C=Cn, N=N, K=K)
+    return (out, T) if want_T else out
+
+
 def sparse_rows_nt(val: Tensor, arg: Tensor, rows: int, W: Tensor) -> Tensor:
     """E[m,:] = sum_{c: arg[b,c]==m} val[b,c] * W[c,:]  (b = m // rows): the row-sparse product S @ W, written densely [B*rows, N]."""
     _f32(val, "val", 2); _rowmajor2d(W, "W")

@@ -241,6 +241,29 @@ def _sparse_dense(val, arg, rows):
     return S
 
 
+def wgrad_collapse_ok(W, X1, B=0):
+    return W.shape[0] % 32 == 0 and X1.shape[0] % 32 == 0 and W.shape[1] % 32 == 0 and 32 <= W.shape[1] <= 256 and B <= 64
+
+
+def wgrad_collapse(W, X1, a1, b1=None, d1=None, v1=None, *, X2=None, x2_t=False, a2=None, sparse=None, out=None, accumulate=False, want_T=False):
+    T = W @ X1.t()
+    o = a1[:, None] * T
+    if v1 is not None:
+        o = o + (a1 * b1 + d1)[:, None] * v1[None, :]
+    if X2 is not None:
+        o = o + a2[:, None] * (W @ (X2 if x2_t else X2.t()))
+    if sparse is not None:
+        val, arg, rows, Bm, pro = sparse
+        add = torch.zeros_like(o)
+        sparse_rows_tn(val, arg, rows, Bm, add, pro=pro)
+        o = o + add
+    if out is None:
+        out = o.contiguous()
+    else:
+        out.copy_(out + o if accumulate else o)
+    return (out, T.contiguous()) if want_T else out
+
+
 def collapse_prep(W, problems, val, arg, rows):
     outs = [wt_diag_w(W, al) if be is None else wt_diag_w(W, al, be, bi) for al, be, bi in problems]
     return outs, sparse_rows_nt(val, arg, rows, W)

@@ -165,3 +165,43 @@ def test_collapse_prep_equals_its_parts(C, K, B, rows):
     assert torch.equal(G, G_ref) and torch.equal(cv, c_ref) and torch.equal(E, E_ref)
     (G1, (G2, cv2)), E2 = ops.collapse_prep(W, [(a1, None, None), (a2, beta, b)], val, arg, rows)
     assert torch.equal(G1, ops.wt_diag_w(W, a1)) and torch.equal(G2, G_ref) and torch.equal(cv2, c_ref) and torch.equal(E2, E_ref)
+
+
+@pytest.mark.parametrize("C,N,K,B,rows", [(1024, 256, 256, 32, 2048), (512, 64, 96, 3, 64), (256, 32, 32, 1, 40)])
+def test_wgrad_collapse_all_terms(C, N, K, B, rows):
+    """ops.wgrad_collapse: scaled product + rank-1 term + second (transposed-operand) product + sparse gather term, plain / accumulating, with the
+    raw product as a by-product -- against float64 and against the launches it replaces."""
+    import kernel_model as km
+    from spgan import ops
+    from test_kernels_gpu import close, rnd
+    W, X1, X2 = rnd("wg.W%d" % C, (C, K), 0.1), rnd("wg.X1%d" % N, (N, K)), rnd("wg.X2%d" % N, (K, N))
+    a1, b1, d1, a2 = rnd("wg.a%d" % C, (C,)), rnd("wg.b%d" % C, (C,)), rnd("wg.d%d" % C, (C,)), rnd("wg.e%d" % C, (C,))
+    v1 = rnd("wg.v%d" % N, (N,))
+    val = rnd("wg.val%d" % C, (B, C))
+    g = torch.Generator().manual_seed(C + N)
+    arg = (torch.randint(0, rows, (B, C), generator=g) + torch.arange(B)[:, None] * rows).to(torch.int32).cuda()
+    Bm = rnd("wg.Bm%d" % N, (B * rows, N))
+    pro = (rnd("wg.ps%d" % N, (N,)).abs() + 0.5, rnd("wg.ph%d" % N, (N,), 0.2), 0.01)
+    def ref64(x2, sparse, base=None):
+        o = a1.double()[:, None] * (W.double() @ X1.double().t()) + (a1.double() * b1.double() + d1.double())[:, None] * v1.double()[None, :]
+        if x2:
+            o = o + a2.double()[:, None] * (W.double() @ X2.double())
+        if sparse:
+            add = torch.zeros((C, N), dtype=torch.float64, device=W.device)
+            km.sparse_rows_tn(val.double(), arg, rows, Bm.double(), add, pro=(pro[0].double(), pro[1].double(), pro[2]))
+            o = o + add
+        return o if base is None else o + base.double()
+    tol = dict(rtol=3e-6, atol=3e-5)
+    close(ops.wgrad_collapse(W, X1, a1, b1, d1, v1), ref64(False, False), **tol)
+    out, T = ops.wgrad_collapse(W, X1, a1, b1, d1, v1, sparse=(val, arg, rows, Bm, pro), want_T=True)
+    close(out, ref64(False, True), **tol); close(T, W.double() @ X1.double().t(), **tol)
+    base = rnd("wg.base%d" % C, (C, N))
+    acc = base.clone()
+    ops.wgrad_collapse(W, X1, a1, b1, d1, v1, X2=X2, x2_t=True, a2=a2, sparse=(val, arg, rows, Bm, pro), out=acc, accumulate=True)
+    close(acc, ref64(True, True, base), **tol)
+    close(ops.wgrad_collapse(W, X1, a1, X2=X2.t().contiguous(), a2=a2), a1.double()[:, None] * (W.double() @ X1.double().t()) + a2.double()[:, None] * (W.double() @ X2.double()), **tol)
+    # against the launches it replaces (same fp32 data, other summation order)
+    old = ops.rowscale_outer(ops.gemm_nt(W, X1, exact=True), a1, b1, d1, v1)
+    ops.sparse_rows_tn(val, arg, rows, Bm, old, pro=pro)
+    close(ops.wgrad_collapse(W, X1, a1, b1, d1, v1, sparse=(val, arg, rows, Bm, pro)), old, rtol=3e-6, atol=3e-5)
+    assert torch.equal(ops.wgrad_collapse(W, X1, a1, b1, d1, v1, sparse=(val, arg, rows, Bm, pro)), out), "not deterministic"
