@@ -559,6 +559,10 @@ int spgan_bn_dbl_coeffs(const float* U0, const float* U1, const float* Ugz, cons
                         const float* invstd, int C, int count, float* out4C, spgan_stream_t s);
 int spgan_bn_dbl_phaseb(const float* coeffs4C, const float* gamma, const float* invstd, const float* s0, const float* s1, int C,
                         float* sums2C, float* dgamma, spgan_stream_t s);
+/* spgan_bn_dbl_coeffs followed by spgan_bn_dbl_phaseb in one launch (same arithmetic, the [4,C] coefficient block is not stored) */
+int spgan_bn_dbl_phaseb_sums(const float* U0, const float* U1, const float* Ugz, const float* S0, const float* S1, const float* gamma,
+                             const float* invstd, const float* s0, const float* s1, int C, int count, float* sums2C, float* dgamma,
+                             spgan_stream_t s);
 /* Collapsed double backward of the layer in front of the max-pool (Discriminator.py:74-81,104): the dense [M,C]
  * tensors of the generic path are only needed as per-channel sums and at the B*C arg-max positions.
  * spgan_gather_rowdot: out[b,c] = Q[arg[b,c], :] . W[c, :]          (u = q.W^T at the arg-max rows)

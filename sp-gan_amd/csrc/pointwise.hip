@@ -246,6 +246,19 @@ __global__ void bn_dbl_phaseb_kernel(const float* coeffs, const float* gamma, co
   sums[C + c] = coeffs[3 * C + c] + gamma[c] * a1 + inv[c] * coeffs[C + c];
   dgamma[c] = coeffs[c] + a1;
 }
+// the two above in one launch: phase B's sums straight from phase A's per-channel sums (the coefficient vectors are not stored)
+__global__ void bn_dbl_phaseb_sums_kernel(const float* U0, const float* U1, const float* Ugz, const float* S0, const float* S1, const float* gamma,
+                                          const float* inv, const float* s0, const float* s1, int C, float rM, float* sums, float* dgamma) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float core = Ugz[c] - (U0[c] * S0[c] + U1[c] * S1[c]) * rM;
+  const float gsM = gamma[c] * inv[c] * rM;
+  const float k0 = inv[c] * core, k1 = gamma[c] * core, k2 = -gsM * (U0[c] * S1[c] + S0[c] * U1[c]), k3 = -2.0f * gsM * (U1[c] * S1[c]);
+  const float a0 = s0 ? s0[c] : 0.f, a1 = s1 ? s1[c] : 0.f;
+  sums[c] = k2 + gamma[c] * a0;
+  sums[C + c] = k3 + gamma[c] * a1 + inv[c] * k1;
+  dgamma[c] = k0 + a1;
+}
 // ---- collapsed double backward of the layer in front of the max-pool: everything that used to need the dense
 // [M,C] tensors u = q.W^T, y, gz and q_out is only needed (a) as per-channel sums and (b) at the B*C arg-max positions.
 // out[b,c] = Q[arg[b,c], :] . W[c, :]     (u at the arg-max rows); 16 lanes per (b,c), fixed shuffle tree
@@ -534,6 +547,14 @@ extern "C" int spgan_bn_dbl_phaseb(const float* coeffs4C, const float* gamma, co
                                    float* sums2C, float* dgamma, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(coeffs4C && gamma && invstd && sums2C && dgamma && C > 0 && ((s0 == nullptr) == (s1 == nullptr)));
   hipLaunchKernelGGL(bn_dbl_phaseb_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s_, coeffs4C, gamma, invstd, s0, s1, C, sums2C, dgamma);
+  return spgan_launch_status();
+}
+extern "C" int spgan_bn_dbl_phaseb_sums(const float* U0, const float* U1, const float* Ugz, const float* S0, const float* S1, const float* gamma,
+                                        const float* invstd, const float* s0, const float* s1, int C, int count, float* sums2C, float* dgamma,
+                                        spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(U0 && U1 && Ugz && S0 && S1 && gamma && invstd && sums2C && dgamma && C > 0 && count > 0 && ((s0 == nullptr) == (s1 == nullptr)));
+  hipLaunchKernelGGL(bn_dbl_phaseb_sums_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s_, U0, U1, Ugz, S0, S1, gamma, invstd, s0, s1, C,
+                     1.0f / (float)count, sums2C, dgamma);
   return spgan_launch_status();
 }
 extern "C" int spgan_gather_rowdot(const float* Q, int ldq, const int32_t* arg, const float* W, int ldw, int B, int C, int K, float* out,

@@ -198,6 +198,7 @@ SIGNATURES = {
     "spgan_bn_dbl_apply": (I, [P, P, P, I, I, P, P, P, P, F, P, P, P, P, P, P, P]),
     "spgan_bn_dbl_coeffs": (I, [P, P, P, P, P, P, P, I, I, P, P]),
     "spgan_bn_dbl_phaseb": (I, [P, P, P, P, P, I, P, P, P]),
+    "spgan_bn_dbl_phaseb_sums": (I, [P, P, P, P, P, P, P, P, P, I, I, P, P, P]),
     "spgan_gather_rowdot": (I, [P, I, P, P, I, I, I, I, P, P]),
     "spgan_rowdot": (I, [P, I, P, I, I, I, P, P]),
     "spgan_bn_dbl_pool": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P]),

@@ -605,7 +605,7 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
     rM = 1.0 / M
     q = v_dx_cm.contiguous() if ctx.get("pm_io") else ops.cm_to_pm(v_dx_cm.contiguous())     # adjoint of ga_0 [M,3]
     xbarA: List[Optional[Tensor]] = [None] * 4                   # phase-A adjoint on xhat_l
-    coeffs: List[Optional[Tensor]] = [None] * 4                  # per-channel phase-A results [4,C] (see ops.bn_dbl_coeffs)
+    coeffs: list = [None] * 4                                    # per-channel phase-A sums (see ops.bn_dbl_coeffs / bn_dbl_phaseb)
     # ---------------------------------------------------------------- phase A
     for li in range(4):
         conv, bn = D_LAYERS[li]
@@ -627,7 +627,7 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
             gz = gs[li]
         S0, S1 = sums_all[li][:C], sums_all[li][C:]
         U0, U1, Ugz = ops.bn_dbl_stats(u, ys[li], gz, mu, inv)
-        coeffs[li] = ops.bn_dbl_coeffs(U0, U1, Ugz, S0, S1, gamma, inv, M)       # [dgammaA | sbarA | sum xbarA | sum xbarA*xhat]
+        coeffs[li] = (U0, U1, Ugz, S0, S1, M)       # -> [dgammaA | sbarA | sum xbarA | sum xbarA*xhat], formed by phase B's own launch (ops.bn_dbl_phaseb)
         q, xbarA[li] = ops.bn_dbl_apply(u, ys[li], gz, mu, inv, sc, sh, NEG, gamma, S1, U0, U1, M)
     else:
         top = None

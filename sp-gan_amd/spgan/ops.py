@@ -552,11 +552,19 @@ def bn_dbl_coeffs(U0, U1, Ugz, S0, S1, gamma, invstd, count: int) -> Tensor:
     return out
 
 
-def bn_dbl_phaseb(coeffs: Tensor, gamma: Tensor, invstd: Tensor, s0: Optional[Tensor], s1: Optional[Tensor]):
-    """-> (sums [2C] for bn_bwd_apply, dgamma [C]) (phase B of the double backward, per channel)."""
+def bn_dbl_phaseb(coeffs, gamma: Tensor, invstd: Tensor, s0: Optional[Tensor], s1: Optional[Tensor]):
+    """-> (sums [2C] for bn_bwd_apply, dgamma [C]) (phase B of the double backward, per channel).
+    coeffs: the [4,C] block of bn_dbl_coeffs, or the tuple (U0, U1, Ugz, S0, S1, count) it would be computed from -- then both steps run as one launch."""
     Cn = gamma.numel()
     sums = torch.empty((2 * Cn,), dtype=torch.float32, device=gamma.device)
     dg = torch.empty((Cn,), dtype=torch.float32, device=gamma.device)
+    if isinstance(coeffs, tuple):
+        U0, U1, Ugz, S0, S1, count = coeffs
+        v = lambda t, n: _p(_vec(t.contiguous(), Cn, n))
+        check(_lib.load().spgan_bn_dbl_phaseb_sums(v(U0, "U0"), v(U1, "U1"), v(Ugz, "Ugz"), v(S0, "S0"), v(S1, "S1"), v(gamma, "gamma"), v(invstd, "invstd"),
+                                                   _p(None if s0 is None else s0.contiguous()), _p(None if s1 is None else s1.contiguous()), Cn, int(count),
+                                                   _p(sums), _p(dg), _s()), "bn_dbl_phaseb_sums")
+        return sums, dg
     check(_lib.load().spgan_bn_dbl_phaseb(_p(coeffs), _p(_vec(gamma.contiguous(), Cn, "gamma")), _p(_vec(invstd.contiguous(), Cn, "invstd")),
                                           _p(None if s0 is None else s0.contiguous()), _p(None if s1 is None else s1.contiguous()), Cn, _p(sums), _p(dg), _s()),
           "bn_dbl_phaseb")

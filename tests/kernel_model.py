@@ -176,6 +176,9 @@ def bn_dbl_coeffs(U0, U1, Ugz, S0, S1, gamma, invstd, count):
 
 
 def bn_dbl_phaseb(coeffs, gamma, invstd, s0, s1):
+    if isinstance(coeffs, tuple):
+        U0, U1, Ugz, S0, S1, count = coeffs
+        coeffs = bn_dbl_coeffs(U0, U1, Ugz, S0, S1, gamma, invstd, count)
     a0 = s0 if s0 is not None else torch.zeros_like(gamma)
     a1 = s1 if s1 is not None else torch.zeros_like(gamma)
     return torch.cat([coeffs[2] + gamma * a0, coeffs[3] + gamma * a1 + invstd * coeffs[1]]), coeffs[0] + a1

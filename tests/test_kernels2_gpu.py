@@ -227,6 +227,9 @@ def test_fused_bn_finalize_and_small_kernels(ops):
         close(a, c, rtol=1e-5, atol=1e-6, what="bn_dbl_phaseb")
     for a, c in zip(ops.bn_dbl_phaseb(co2.contiguous(), vec[5], vec[6], None, None), km.bn_dbl_phaseb(co2, vec[5], vec[6], None, None)):
         close(a, c, rtol=1e-5, atol=1e-6, what="bn_dbl_phaseb.none")
+    for sa, sb in ((s0, s1), (None, None)):      # both steps as one launch: the same values as the two-launch route
+        for a, c in zip(ops.bn_dbl_phaseb(tuple(vec[:5]) + (640,), vec[5], vec[6], sa, sb), ops.bn_dbl_phaseb(co, vec[5], vec[6], sa, sb)):
+            close(a, c, rtol=1e-6, atol=1e-7, what="bn_dbl_phaseb from sums")
     dsts = [rnd("fb.d%d" % i, (n,)) for i, n in enumerate((5, 1000, 70001, 3))]
     srcs = [rnd("fb.s%d" % i, (n,)) for i, n in enumerate((5, 1000, 70001, 3))]
     ref = [d + s for d, s in zip(dsts, srcs)]
