@@ -594,12 +594,35 @@ extern "C" int spgan_col_scale_add(const float* a, const float* b, const float* 
 
 // dst[t][i] += src[t][i] for up to SPGAN_MULTI_MAX tensors in one launch (parameter-gradient accumulation into the
 // flat gradient buffer: replaces one elementwise launch per parameter tensor).
+// (16-byte accesses when both pointers and the length allow, two of them in flight per thread: the launch lasts as long as its LARGEST
+// pair -- 0.5 M elements for D's first head layer -- and a thread's trips are a chain of load latencies)
+__device__ __forceinline__ void add_span(float* __restrict__ d, const float* __restrict__ s, int n, int gtid, int gthreads) {
+  if ((((uintptr_t)d | (uintptr_t)s) & 15) == 0 && (n & 3) == 0) {
+    float4* d4 = reinterpret_cast<float4*>(d);
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    const int n4 = n >> 2;
+    int i = gtid;
+    for (; i + gthreads < n4; i += 2 * gthreads) {
+      float4 x0 = d4[i], x1 = d4[i + gthreads];
+      const float4 y0 = s4[i], y1 = s4[i + gthreads];
+      x0.x += y0.x; x0.y += y0.y; x0.z += y0.z; x0.w += y0.w;
+      x1.x += y1.x; x1.y += y1.y; x1.z += y1.z; x1.w += y1.w;
+      d4[i] = x0; d4[i + gthreads] = x1;
+    }
+    if (i < n4) {
+      float4 x0 = d4[i];
+      const float4 y0 = s4[i];
+      x0.x += y0.x; x0.y += y0.y; x0.z += y0.z; x0.w += y0.w;
+      d4[i] = x0;
+    }
+    return;
+  }
+  for (int i = gtid; i < n; i += gthreads) d[i] += s[i];
+}
+
 __global__ void multi_add_kernel(const spgan_multi_add_args a) {
   const int t = blockIdx.y;
-  const int n = a.n[t];
-  float* __restrict__ d = a.dst[t];
-  const float* __restrict__ s = a.src[t];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] += s[i];
+  add_span(a.dst[t], a.src[t], a.n[t], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // dst[t][i] = src[t][i]: the same argument block, assignment instead of accumulation (a train step's input tensors copied into the
@@ -634,7 +657,7 @@ __global__ void multi_add3_kernel(const spgan_multi_add3_args a) {
   float* __restrict__ d = a.dst[t];
   const float* __restrict__ s = a.src[t];
   if (n1 == 1 && n2 == 1) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] += s[i];
+    add_span(d, s, n, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     return;
   }
   const long ds0 = a.ds[0][t], ds1 = a.ds[1][t], ds2 = a.ds[2][t], ss0 = a.ss[0][t], ss1 = a.ss[1][t], ss2 = a.ss[2][t];
@@ -652,7 +675,7 @@ extern "C" int spgan_multi_add3(const spgan_multi_add3_args* a, spgan_stream_t s
     nmax = a->n[t] > nmax ? a->n[t] : nmax;
   }
   int bx = cdiv(nmax, 256 * 4);
-  if (bx > 64) bx = 64;
+  if (bx > 128) bx = 128;
   hipLaunchKernelGGL(multi_add3_kernel, dim3(bx, a->count), dim3(256), 0, (hipStream_t)s_, *a);
   return spgan_launch_status();
 }
@@ -665,7 +688,7 @@ extern "C" int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s_)
     nmax = a->n[t] > nmax ? a->n[t] : nmax;
   }
   int bx = cdiv(nmax, 256 * 4);
-  if (bx > 64) bx = 64;
+  if (bx > 128) bx = 128;
   hipLaunchKernelGGL(multi_add_kernel, dim3(bx, a->count), dim3(256), 0, (hipStream_t)s_, *a);
   return spgan_launch_status();
 }
