@@ -11,9 +11,23 @@
 // "scatter" to neighbours is a gather over the CSR in-edge lists (deterministic; no float atomics).
 //
 // Thread mapping everywhere: one wave per point, lanes along channels.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
+
+// XCD-aware workgroup order for the gather kernels: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own
+// 4 MB L2.  In launch order, neighbouring point chunks -- which gather the same rows of the [B*N, H+2F] point tensor, 2.6 MB per shape at
+// F = 128 -- would sit on eight different L2s and every shape's rows would be fetched eight times.  Logical block xcd * per + t runs on XCD
+// xcd: an XCD works through a CONTIGUOUS eighth of the points (4 shapes at B = 32), whose rows it fetches once.  Grids are rounded up to a
+// multiple of 8; logical blocks past the end find no points.
+// Measured in the replayed step (profiles/r04_step_sequence.txt): edge_stats 65 -> 43-51 us, edge_attend_bwd 280 -> 272, edge_scatter 237 -> 228
+// (9.24 -> 9.18-9.20 ms/step on one box); the same order changed nothing for the kNN scan and the per-edge-operand GEMM (not kept there).
+__device__ __forceinline__ int xcd_block() {
+  const int per = gridDim.x >> 3;
+  return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+}
+inline int grid8(long n) { return (int)((n + 7) / 8 * 8); }
 
 // ------------------------------------------------------------------------------------------ weights
 __global__ void edge_wcat_kernel(const float* __restrict__ Ww0, const float* __restrict__ Wx, int H, int F, int C, float* __restrict__ Wcat,
@@ -69,7 +83,9 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
   const int k = KT > 0 ? KT : k_;
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int p0 = blockIdx.x * ES_PT;
+  const int bxid = xcd_block();
+  const int p0 = bxid * ES_PT;
+  if (p0 >= M) return;
   const int np = min(ES_PT, M - p0);
   const int CH = H + F;
   const float cnt = (float)(np * k);
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
     if (w == 0 && ok) {
       const float t1 = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
       const float t2 = (red2[0][lane] + red2[1][lane]) + (red2[2][lane] + red2[3][lane]);
-      float* o = part + ((size_t)blockIdx.x * CH + c) * 2;
+      float* o = part + ((size_t)bxid * CH + c) * 2;
       o[0] = fmaf(cnt, v0, t1);
       o[1] = fmaxf(t2 - t1 * t1 / cnt, 0.f);
     }
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(256) void edge_attend_fwd_k_kernel(const float* __r
                                                                 const float* __restrict__ scx, const float* __restrict__ shx, float slope,
                                                                 float* __restrict__ T) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
+  const int i = __builtin_amdgcn_readfirstlane(xcd_block() * 4 + w);
   if (i >= M) return;
   int nb[K];
 #pragma unroll
@@ -358,6 +374,8 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
   // EB_PT points per workgroup (4 waves x EB_PT/4 points) so the partial format matches the generic kernel
   __shared__ float red[4][4][64 * VEC];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int bxid = xcd_block();
+  if (bxid * EB_PT >= M) return;
   for (int f0 = 0; f0 < F; f0 += 64 * VEC) {
     const int f = f0 + lane * VEC;
     const bool ok = f < F;
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
       ldv<VEC>(sc2 + f, a2); ldv<VEC>(sh2 + f, c2); ldv<VEC>(scx + f, ax); ldv<VEC>(shx + f, cx); ldv<VEC>(bx + f, bb);
       ldv<VEC>(mean2 + f, m2); ldv<VEC>(inv2 + f, i2); ldv<VEC>(meanx + f, mxm); ldv<VEC>(invx + f, ixv);
       for (int pp = 0; pp < EB_PT / 4; ++pp) {
-        const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * EB_PT + pp * 4 + w);
+        const int i = __builtin_amdgcn_readfirstlane(bxid * EB_PT + pp * 4 + w);
         if (i >= M) break;
         float Ri[VEC];
         ldv<VEC>(PQR + (size_t)i * ld + H + F + f, Ri);
@@ -440,7 +458,7 @@ __global__ __launch_bounds__(256) void edge_attend_bwd_k_kernel(
     for (int c = threadIdx.x; c < 64 * VEC; c += 256) {
       const int ff = f0 + c;
       if (ff < F) {
-        float* o = part + (size_t)blockIdx.x * (2 * F) * 2;
+        float* o = part + (size_t)bxid * (2 * F) * 2;
         o[(size_t)ff * 2 + 0] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
         o[(size_t)ff * 2 + 1] = (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]);
         o[(size_t)(F + ff) * 2 + 0] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
@@ -478,7 +496,7 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(
   constexpr int KU = KT > 0 ? KT : 1;
   const int k = KT > 0 ? KT : k_;
   const int lane = threadIdx.x & 63;
-  const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // wave-uniform: scalar index loads
+  const int j = __builtin_amdgcn_readfirstlane(xcd_block() * 4 + (threadIdx.x >> 6));  // wave-uniform: scalar index loads
   if (j >= M) return;
   auto ldgy = [&](size_t off) -> float {   // GB: gy lies in memory as bfloat16 (written by spgan_edge_attend_bwd_b)
     return GB ? (float)reinterpret_cast<const __bf16*>(gy)[off] : gy[off];
@@ -601,8 +619,8 @@ extern "C" int spgan_edge_attend_bwd_tile_points(void) { return EB_PT; }
 extern "C" int spgan_edge_stats(const float* PQR, int ld, const int32_t* idx, int M, int k, int H, int F, const float* b1, const float* bx,
                                 float* partials, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(PQR && idx && b1 && bx && partials && M > 0 && k > 0 && H > 0 && F > 0 && ld >= H + 2 * F);
-  if (k == 10) hipLaunchKernelGGL(edge_stats_kernel<10>, dim3(cdiv(M, ES_PT)), dim3(256), 0, (hipStream_t)s_, PQR, ld, idx, M, k, H, F, b1, bx, partials);
-  else hipLaunchKernelGGL(edge_stats_kernel<0>, dim3(cdiv(M, ES_PT)), dim3(256), 0, (hipStream_t)s_, PQR, ld, idx, M, k, H, F, b1, bx, partials);
+  if (k == 10) hipLaunchKernelGGL(edge_stats_kernel<10>, dim3(grid8(cdiv(M, ES_PT))), dim3(256), 0, (hipStream_t)s_, PQR, ld, idx, M, k, H, F, b1, bx, partials);
+  else hipLaunchKernelGGL(edge_stats_kernel<0>, dim3(grid8(cdiv(M, ES_PT))), dim3(256), 0, (hipStream_t)s_, PQR, ld, idx, M, k, H, F, b1, bx, partials);
   return spgan_launch_status();
 }
 
@@ -612,10 +630,10 @@ extern "C" int spgan_edge_attend_fwd(const float* h2pre, const float* sc2, const
   SPGAN_CHECK_ARG(h2pre && sc2 && sh2 && PQR && idx && bx && scx && shx && T && M > 0 && k > 0 && ld >= H + 2 * F);
   const bool al = ((ld | H | F) % 2 == 0);
   if (k == 10 && al && F % 128 == 0)
-    hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 2>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, bx,
+    hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 2>), dim3(grid8(cdiv(M, 4))), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, bx,
                        scx, shx, slope, T);
   else if (k == 10)
-    hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, bx,
+    hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 1>), dim3(grid8(cdiv(M, 4))), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, bx,
                        scx, shx, slope, T);
   else
     hipLaunchKernelGGL(edge_attend_fwd_kernel, dim3(cdiv(M, EA_PT)), dim3(256), 0, (hipStream_t)s_, h2pre, sc2, sh2, PQR, ld, H, F, idx, M, k,
@@ -630,7 +648,7 @@ extern "C" int spgan_edge_attend_fwd_h(const void* h2pre, int h2_half, const flo
   SPGAN_CHECK_ARG(k == 10 && F % 4 == 0);   // the k = 10 kernels only; rows of T stay 8-byte aligned for the consumers' loads
   const float* h2 = reinterpret_cast<const float*>(h2pre);
   float* T = reinterpret_cast<float*>(T_f16);
-  const dim3 g(cdiv(M, 4)), b(256);
+  const dim3 g(grid8(cdiv(M, 4))), b(256);
   hipStream_t s = (hipStream_t)s_;
   const bool v2 = ((ld | H) % 2 == 0) && F % 128 == 0;
   if (v2 && h2_half) hipLaunchKernelGGL((edge_attend_fwd_k_kernel<10, 2, 1, 1>), g, b, 0, s, h2, sc2, sh2, PQR, ld, H, F, idx, M, bx, scx, shx, slope, T);
@@ -650,7 +668,7 @@ extern "C" int spgan_edge_attend_bwd_b(const uint16_t* dT_bf16, const void* h2pr
   const float* h2 = reinterpret_cast<const float*>(h2pre);
   float* g2 = reinterpret_cast<float*>(g2_bf16);
   float* gy = reinterpret_cast<float*>(gy_bf16);
-  const dim3 g(cdiv(M, EB_PT)), b(256);
+  const dim3 g(grid8(cdiv(M, EB_PT))), b(256);
   hipStream_t s = (hipStream_t)s_;
   const bool v2 = ((ld | H) % 2 == 0) && F % 128 == 0;
 #define SPGAN_ATT_BWD(V, HHV)                                                                                                               \
@@ -672,10 +690,10 @@ extern "C" int spgan_edge_attend_bwd(const float* dT, const float* h2pre, const 
   SPGAN_CHECK_ARG(M > 0 && k > 0 && ld >= H + 2 * F);
   const bool al = ((ld | H | F) % 2 == 0);
   if (k == 10 && al && F % 128 == 0)
-    hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 2>), dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR,
+    hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 2>), dim3(grid8(cdiv(M, EB_PT))), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR,
                        ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
   else if (k == 10)
-    hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 1>), dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR,
+    hipLaunchKernelGGL((edge_attend_bwd_k_kernel<10, 1>), dim3(grid8(cdiv(M, EB_PT))), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR,
                        ld, H, F, idx, M, bx, scx, shx, meanx, invx, slope, g2, gy, partials);
   else
     hipLaunchKernelGGL(edge_attend_bwd_kernel, dim3(cdiv(M, EB_PT)), dim3(256), 0, (hipStream_t)s_, dT, h2pre, sc2, sh2, mean2, inv2, PQR, ld,
@@ -689,7 +707,7 @@ extern "C" int spgan_edge_scatter_b(const float* g1, const uint16_t* gy_bf16, co
                                     const float* invx, const float* gamx, const float* sumsx, float* dPQR, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(g1 && gy_bf16 && PQR && idx && rowptr && src && b1 && mean1 && inv1 && gam1 && sums1 && bx && meanx && invx && gamx && sumsx && dPQR);
   SPGAN_CHECK_ARG(M > 0 && k == 10 && ld >= H + 2 * F);
-  hipLaunchKernelGGL((edge_scatter_kernel<10, 1>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, reinterpret_cast<const float*>(gy_bf16), PQR, ld,
+  hipLaunchKernelGGL((edge_scatter_kernel<10, 1>), dim3(grid8(cdiv(M, 4))), dim3(256), 0, (hipStream_t)s_, g1, reinterpret_cast<const float*>(gy_bf16), PQR, ld,
                      H, F, idx, rowptr, src, M, k, b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
   return spgan_launch_status();
 }
@@ -701,10 +719,10 @@ extern "C" int spgan_edge_scatter(const float* g1, const float* gy, const float*
   SPGAN_CHECK_ARG(g1 && gy && PQR && idx && rowptr && src && b1 && mean1 && inv1 && gam1 && sums1 && bx && meanx && invx && gamx && sumsx && dPQR);
   SPGAN_CHECK_ARG(M > 0 && k > 0 && ld >= H + 2 * F);
   if (k == 10)
-    hipLaunchKernelGGL(edge_scatter_kernel<10>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, gy, PQR, ld, H, F, idx, rowptr, src, M, k,
+    hipLaunchKernelGGL(edge_scatter_kernel<10>, dim3(grid8(cdiv(M, 4))), dim3(256), 0, (hipStream_t)s_, g1, gy, PQR, ld, H, F, idx, rowptr, src, M, k,
                        b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
   else
-    hipLaunchKernelGGL(edge_scatter_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)s_, g1, gy, PQR, ld, H, F, idx, rowptr, src, M, k,
+    hipLaunchKernelGGL(edge_scatter_kernel<0>, dim3(grid8(cdiv(M, 4))), dim3(256), 0, (hipStream_t)s_, g1, gy, PQR, ld, H, F, idx, rowptr, src, M, k,
                        b1, mean1, inv1, gam1, sums1, bx, meanx, invx, gamx, sumsx, 1.0f / ((float)M * (float)k), dPQR);
   return spgan_launch_status();
 }
