@@ -250,6 +250,11 @@ typedef struct spgan_gemm_tn_args {
  * the finalize launch behind a BNBWD-epilogue GEMM hands the lazy operand to the next products without a launch of its own. */
 int spgan_colstats_finalize_bnbwd(const float* partials, int tiles, int C, int G, int tile_rows, const float* mean, const float* invstd,
                                   const float* gamma, float count, float* s0, float* s1, float* coef, spgan_stream_t s);
+/* spgan_colstats_finalize (mode 1, one group) that ALSO runs phase B of the BatchNorm double backward on the sums it just merged
+ * (spgan_bn_dbl_phaseb_sums with s0 / s1 := the merged sums): -> s0, s1 [C], sums2C, dgamma */
+int spgan_colstats_finalize_phaseb(const float* partials, int tiles, int C, int G, int tile_rows, const float* U0, const float* U1, const float* Ugz,
+                                   const float* S0, const float* S1, const float* gamma, const float* invstd, int count, float* s0, float* s1,
+                                   float* sums2C, float* dgamma, spgan_stream_t s);
 int spgan_bn_bwd_coeffs(const float* sums, const float* mean, const float* invstd, const float* gamma, int C, float count, float* coef, spgan_stream_t s);
 
 size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb);

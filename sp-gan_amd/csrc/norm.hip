@@ -97,6 +97,10 @@ struct BnTail {
   // mode 1 (plain sums S0 = out0, S1 = out1): also emit the BatchNorm-backward coefficient vectors coef[3,C] = [p | q | r] of
   // dy = p*g + q*y + r (spgan_bn_bwd_coeffs) -- the finalize of a BNBWD-epilogue GEMM hands the lazy operand to its consumers
   float* bwd_coef; const float* bwd_mean; const float* bwd_invstd; const float* bwd_gamma; float bwd_rcount;
+  // mode 1: also phase B of the BatchNorm double backward (the arithmetic of spgan_bn_dbl_phaseb_sums) from the sums this launch merges:
+  // s0 = out0, s1 = out1 -- the finalize behind the double backward's fused layer launch needs no per-channel launch after it
+  const float* pb_U0; const float* pb_U1; const float* pb_Ugz; const float* pb_S0; const float* pb_S1; const float* pb_gamma; const float* pb_inv;
+  float pb_rM; float* pb_sums; float* pb_dgamma;
 };
 
 template <int FS, int FC>
@@ -177,6 +181,15 @@ __global__ __launch_bounds__(256) void colfinalize_t_kernel(const float* __restr
       bn.bwd_coef[c] = pc;
       bn.bwd_coef[C + c] = qc;
       bn.bwd_coef[2 * C + c] = rc;
+    }
+    if (bn.pb_sums) {  // single group, mode 1: the arithmetic of bn_dbl_phaseb_sums_kernel
+      const float U0 = bn.pb_U0[c], U1 = bn.pb_U1[c], S0 = bn.pb_S0[c], S1 = bn.pb_S1[c], ga = bn.pb_gamma[c], iv = bn.pb_inv[c];
+      const float core = bn.pb_Ugz[c] - (U0 * S0 + U1 * S1) * bn.pb_rM;
+      const float gsM = ga * iv * bn.pb_rM;
+      const float k0 = iv * core, k1 = ga * core, k2 = -gsM * (U0 * S1 + S0 * U1), k3 = -2.0f * gsM * (U1 * S1);
+      bn.pb_sums[c] = k2 + ga * a;
+      bn.pb_sums[C + c] = k3 + ga * b + iv * k1;
+      bn.pb_dgamma[c] = k0 + b;
     }
     if (bn.scale) {  // single group, mode 0: same arithmetic as bn_prepare_kernel
       const bool second = bn.split > 0 && c >= bn.split;
@@ -525,6 +538,20 @@ extern "C" int spgan_colstats_finalize_bnbwd(const float* partials, int tiles, i
   SPGAN_CHECK_ARG(partials && s0 && s1 && coef && mean && invstd && tiles > 0 && C > 0 && G > 0 && count > 0.f && tiles == cdiv(G, tile_rows));
   BnTail bn{};
   bn.bwd_coef = coef; bn.bwd_mean = mean; bn.bwd_invstd = invstd; bn.bwd_gamma = gamma; bn.bwd_rcount = 1.0f / count;
+  launch_colfinalize(s, partials, 1, tiles, C, G, 1, tile_rows, s0, s1, bn);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_colstats_finalize_phaseb(const float* partials, int tiles, int C, int G, int tile_rows, const float* U0, const float* U1,
+                                              const float* Ugz, const float* S0, const float* S1, const float* gamma, const float* invstd, int count,
+                                              float* s0, float* s1, float* sums2C, float* dgamma, spgan_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (tile_rows <= 0) tile_rows = RT;
+  SPGAN_CHECK_ARG(partials && s0 && s1 && U0 && U1 && Ugz && S0 && S1 && gamma && invstd && sums2C && dgamma);
+  SPGAN_CHECK_ARG(tiles > 0 && C > 0 && G > 0 && count > 0 && tiles == cdiv(G, tile_rows));
+  BnTail bn{};
+  bn.pb_U0 = U0; bn.pb_U1 = U1; bn.pb_Ugz = Ugz; bn.pb_S0 = S0; bn.pb_S1 = S1; bn.pb_gamma = gamma; bn.pb_inv = invstd;
+  bn.pb_rM = 1.0f / (float)count; bn.pb_sums = sums2C; bn.pb_dgamma = dgamma;
   launch_colfinalize(s, partials, 1, tiles, C, G, 1, tile_rows, s0, s1, bn);
   return spgan_launch_status();
 }

@@ -243,6 +243,7 @@ SIGNATURES = {
     "spgan_reduce_chunks": (I, [P, I, C.c_size_t, P, P]),
     "spgan_bn_bwd_coeffs": (I, [P, P, P, P, I, F, P, P]),
     "spgan_colstats_finalize_bnbwd": (I, [P, I, I, I, I, P, P, P, F, P, P, P, P]),
+    "spgan_colstats_finalize_phaseb": (I, [P, I, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P]),
     "spgan_comm_available": (I, []),
     "spgan_comm_last_error": (I, [C.c_void_p]),
     "spgan_comm_unique_id": (I, [P]),

@@ -548,7 +548,7 @@ def _d_double_top_phase_a(P, ctx, saved, q3: Tensor, grads) -> dict:
     return dict(t=t, spB=spB, c4=c4, pro3=pro3, q3=q3, Qqa=Qqa)
 
 
-def _d_double_top_phase_b(P, ctx, top: dict, grads):
+def _d_double_top_phase_b(P, ctx, top: dict, grads, phaseb=None):
     """Phase B at the same layer: ybar = c1*u + c2*y4 + c3 + scatter(spB) (never formed) ->
       ybar^T a3 = diag(c1).W.(q3^T a3) + diag(c2).W.(a3^T a3) + (c2*b4 + c3) (x) colsum(a3) + spB^T a3
       ybar.W    = q3.(W^T diag(c1) W) + a3.(W^T diag(c2) W) + (c2*b4 + c3).W + spB.W      (then layer 3's mask / sums epilogue)"""
@@ -572,8 +572,10 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads):
     a3 = ops.ActOperand(ys[2], pro3[0], pro3[1], NEG)
     if ops.gemm_dual_ok(a3, G2, ys[2]):
         # a3^T a3, colsum(a3) and the outgoing adjoint a3.G2 (+ addends, layer 3's mask / sums epilogue) from one staging of the y3 tile
-        gram, *abar, cs3 = ops.gemm_dual(a3, G2, ys[2], psc, psh, pmu, pinv, NEG, bias=cvec, rowadd=part, with_colsum=True, defer=False)
-        abar_g = tuple(abar)
+        # (phaseb: layer 2's phase-B sums come out of this launch's finalize)
+        gram, g_, s0_, s1_, cs3, *pb = ops.gemm_dual(a3, G2, ys[2], psc, psh, pmu, pinv, NEG, bias=cvec, rowadd=part, with_colsum=True, defer=False,
+                                                     phaseb=phaseb)
+        abar_g = (g_, s0_, s1_) + tuple(pb)
     else:
         gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)            # a3^T a3 and colsum(a3) from one launch
         abar_g = ops.gemm_nt_bnbwd(ys[2], G2, ys[2], psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part)
@@ -650,17 +652,22 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         sc, sh, inv, mu = bns[li]
         gamma = P[bn + ".weight"]
         C = W.shape[0]
+        # the finalize of the launch that produces layer l's adjoint also runs layer l's phase-B sums (ops.gemm_dual(phaseb=...))
+        pb_below = (coeffs[li - 1], P[D_LAYERS[li - 1][1] + ".weight"], bns[li - 1][2]) if li > 0 and isinstance(coeffs[li - 1], tuple) else None
         if li == 3 and top is not None:
-            abar_g = _d_double_top_phase_b(P, ctx, top, grads)
+            abar_g = _d_double_top_phase_b(P, ctx, top, grads, phaseb=pb_below)
             continue
         add = None
         if abar_g is None:
             sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, None, None)
             grads[bn + ".bias"] = ZERO_GRAD
         else:
-            g, s0, s1 = abar_g
+            g, s0, s1 = abar_g[:3]
             add = (g, gamma)                                                     # X = xbarA + gamma*g, formed inside bn_bwd_apply
-            sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, s0, s1)
+            if len(abar_g) == 5:
+                sums, grads[bn + ".weight"] = abar_g[3], abar_g[4]
+            else:
+                sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, s0, s1)
             grads[bn + ".bias"] = s0
         ybar = ops.bn_bwd_apply(xbarA[li], ys[li], mu, inv, None, sums, M, add=add)
         # phase B's weight-gradient term is accumulated onto phase A's by the split-K reduction itself (beta = 1): no separate add
@@ -668,7 +675,7 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         if li > 0:
             psc, psh, pinv, pmu = bns[li - 1]
             if ops.gemm_dual_ok(ybar, W, ys[li - 1]):
-                _, *abar = ops.gemm_dual(ybar, W, ys[li - 1], psc, psh, pmu, pinv, NEG, out=gA, beta=1.0)      # both products of this layer in one launch
+                _, *abar = ops.gemm_dual(ybar, W, ys[li - 1], psc, psh, pmu, pinv, NEG, out=gA, beta=1.0, phaseb=pb_below)      # both products of this layer in one launch
                 abar_g = tuple(abar)
             else:
                 ops.gemm_tn(ybar, ys[li - 1], pro=(psc, psh, NEG), out=gA, beta=1.0)

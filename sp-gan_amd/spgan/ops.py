@@ -690,7 +690,7 @@ GEMM_DUAL = [True]      # test hook: False sends every layer backward through th
 
 def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float, edge=None, coef_bn=None,
               defer: bool = True, out: Optional[Tensor] = None, beta: float = 0.0, bias: Optional[Tensor] = None, rowadd: Optional[Tensor] = None,
-              with_colsum: bool = False):
+              with_colsum: bool = False, phaseb=None):
     """The weight-gradient AND the masked input-gradient product of one conv layer behind BatchNorm + LeakyReLU in one launch:
       dW [Na,Nb] = dy^T . lrelu(pre*scale + shift),   g = (dy . W + bias + rowadd) * lrelu'(pre*scale + shift),   s0 = sum g,  s1 = sum g*xhat
     dy: Affine2 (lazy BatchNorm backward), ActOperand (an activation formed on load) or a dense [M,Na] tensor; W [Na,Nb] the layer's weight
@@ -698,7 +698,9 @@ def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: 
     tensor y_ref; bias [Nb] / rowadd [M,Nb]: optional addends of the input gradient in front of the mask.
     Returns (dW, g, s0, s1) [+ coef [3,Nb] with coef_bn=(gamma, count): the lazy-operand coefficients of the NEXT BatchNorm backward]
     [+ colsum(dy) [Na] with with_colsum].  dW's (and the column sums') split sum is deferred like gemm_tn(defer=True): valid after
-    flush_tn(); out / beta: dW = beta*out + sum (accumulated in place)."""
+    flush_tn(); out / beta: dW = beta*out + sum (accumulated in place).
+    phaseb = ((U0, U1, Ugz, S0, S1, count), gamma, invstd) of the layer BELOW (the double backward): the finalize launch also runs
+    bn_dbl_phaseb on the sums it merges -> the return tuple ends with (sums [2Nb], dgamma [Nb])."""
     a2 = dy if isinstance(dy, Affine2) else None
     act = dy if isinstance(dy, ActOperand) else None
     A = a2.g if a2 is not None else (act.x if act is not None else dy)
@@ -776,6 +778,16 @@ def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: 
                                                 _p(None if gamma is None else _vec(gamma, Nb, "gamma")), float(count), _p(fin[0]), _p(fin[1]), _p(coef), _s()),
               "colstats_finalize_bnbwd", N=Nb, M=M_)
         return (dW, g, fin[0], fin[1], coef) + extra
+    if phaseb is not None:
+        (U0, U1, Ugz, S0, S1, count), pg, pinv = phaseb
+        fin = torch.empty((2, Nb), dtype=torch.float32, device=A.device)
+        sums = torch.empty((2 * Nb,), dtype=torch.float32, device=A.device)
+        dg = torch.empty((Nb,), dtype=torch.float32, device=A.device)
+        v = lambda t, n: _p(_vec(t.contiguous(), Nb, n))
+        check(lib.spgan_colstats_finalize_phaseb(_p(part), runs, Nb, M_, rows_wg, v(U0, "U0"), v(U1, "U1"), v(Ugz, "Ugz"), v(S0, "S0"), v(S1, "S1"),
+                                                 v(pg, "gamma"), v(pinv, "invstd"), int(count), _p(fin[0]), _p(fin[1]), _p(sums), _p(dg), _s()),
+              "colstats_finalize_phaseb", N=Nb, M=M_)
+        return (dW, g, fin[0], fin[1]) + extra + (sums, dg)
     s0, s1 = _finalize(part, 1, runs, Nb, M_, 1, rows_wg)
     return (dW, g, s0[0], s1[0]) + extra
 

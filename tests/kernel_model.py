@@ -790,7 +790,7 @@ def gemm_dual_ok(dy, W, y_ref, edge=None):
 
 
 def gemm_dual(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=None, coef_bn=None, defer=True, out=None, beta=0.0, bias=None, rowadd=None,
-              with_colsum=False):
+              with_colsum=False, phaseb=None):
     """= gemm_tn(dy, y_ref, pro / edge) and gemm_nt_bnbwd(dy, W^T, y_ref, ...) of the same operands."""
     d = dy.dense() if isinstance(dy, ActOperand) else dy
     dW = gemm_tn(d, y_ref, pro=(scale, shift, slope), edge=edge)
@@ -800,6 +800,9 @@ def gemm_dual(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=None, coef_b
     res = gemm_nt_bnbwd(d, W.t().contiguous(), y_ref, scale, shift, mean, invstd, slope, edge=edge, bias=bias, rowadd=rowadd,
                         **({} if coef_bn is None else dict(coef_bn=coef_bn)))
     extra = (_dense(d).sum(0),) if with_colsum else ()
+    if phaseb is not None:
+        co, pg, pinv = phaseb
+        extra = extra + tuple(bn_dbl_phaseb(co, pg, pinv, res[1], res[2]))
     return (dW,) + tuple(res) + extra
 
 

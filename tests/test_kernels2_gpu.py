@@ -596,6 +596,12 @@ def test_gemm_dual_plain(ops, M, lazy):
     # deterministic; accumulation into an existing gradient by the (deferred) split reduction
     dWb, gzb, s0b, s1b = ops.gemm_dual(dy, W, prev, sc, sh, mu, iv, 0.01, defer=False)
     assert torch.equal(dW, dWb) and torch.equal(gz, gzb) and torch.equal(s0, s0b) and torch.equal(s1, s1b)
+    # phase B of the double backward from the finalize launch: the same values as the per-channel launch on the returned sums
+    pbv = [rnd("gd.pb%d" % i, (Nb,)) for i in range(5)]
+    dWp, gzp, s0p, s1p, psums, pdg = ops.gemm_dual(dy, W, prev, sc, sh, mu, iv, 0.01, defer=False, phaseb=(tuple(pbv) + (M,), gam2, iv))
+    assert torch.equal(dWp, dW) and torch.equal(gzp, gz) and torch.equal(s0p, s0) and torch.equal(s1p, s1)
+    rs, rd = ops.bn_dbl_phaseb(tuple(pbv) + (M,), gam2, iv, s0, s1)
+    close(psums, rs, rtol=1e-6, atol=1e-7, what="phase-B sums from the finalize launch"); close(pdg, rd, rtol=1e-6, atol=1e-7, what="phase-B dgamma")
     acc = rnd("gd.acc", (Na, Nb))
     out = acc.clone()
     ops.gemm_dual(dy, W, prev, sc, sh, mu, iv, 0.01, out=out, beta=1.0)
