@@ -575,6 +575,10 @@ int spgan_bn_dbl_phaseb_sums(const float* U0, const float* U1, const float* Ugz,
  * spgan_bn_dbl_pool:   per channel: U1, Ugz, the phase-A coefficients; t [B,C] = adjoint of the pooled gradient;
  *                      out4C = [dgamma | c1 | c2 | c3], spB [B,C]: phase B's ybar = c1*u + c2*y + c3 + scatter(spB). */
 int spgan_gather_rowdot(const float* Q, int ldq, const int32_t* arg, const float* W, int ldw, int B, int C, int K, float* out, spgan_stream_t s);
+/* spgan_gather_rowdot (uarg [B,C] = Q[arg[b,c],:] . W[c,:]), spgan_rowdot (quad [C] = W[c,:] . T[c,:]) and U0 [C] = W[c,:] . cq in ONE launch:
+ * the three independent per-channel dot products of the collapsed double backward's phase A (Discriminator.py:77-81 behind the max-pool). */
+int spgan_dbl_top_dots(const float* Q, int ldq, const int32_t* arg, const float* W, int ldw, const float* T, int ldt, const float* cq, int B, int C,
+                       int K, float* uarg, float* quad, float* U0, spgan_stream_t s);
 int spgan_rowdot(const float* X, int ldx, const float* Y, int ldy, int R, int K, float* out, spgan_stream_t s);
 int spgan_bn_dbl_pool(const float* uarg, const float* gval, const float* yarg, const float* pooled, const float* U0, const float* quad,
                       const float* bias, const float* mean, const float* invstd, const float* gamma, const float* S0, const float* S1,

@@ -286,6 +286,38 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
   for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
   if (r < R && l == 0) out[r] = s;
 }
+// The three independent dot-product launches of the collapsed double backward's phase A in one grid: quad[c] = W[c,:].T[c,:] and
+// U0[c] = W[c,:].cq (the first C/16 workgroups, 16 lanes per row) and uarg[b,c] = Q[arg[b,c],:].W[c,:] (gather_rowdot_kernel's arithmetic)
+__global__ __launch_bounds__(256) void dbl_top_dots_kernel(const float* __restrict__ Q, int ldq, const int32_t* __restrict__ arg,
+                                                           const float* __restrict__ W, int ldw, const float* __restrict__ T, int ldt,
+                                                           const float* __restrict__ cq, int BC, int C, int K, int row_blocks,
+                                                           float* __restrict__ uarg, float* __restrict__ quad, float* __restrict__ U0) {
+  const int l = threadIdx.x & 15;
+  if ((int)blockIdx.x < row_blocks) {
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
+    float s = 0.f, u = 0.f;
+    if (r < C)
+      for (int k = l; k < K; k += 16) {
+        const float w = W[(size_t)r * ldw + k];
+        s = fmaf(w, T[(size_t)r * ldt + k], s);
+        u = fmaf(w, cq[k], u);
+      }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); u += __shfl_xor(u, o); }
+    if (r < C && l == 0) { quad[r] = s; U0[r] = u; }
+    return;
+  }
+  const int pair = ((int)blockIdx.x - row_blocks) * 16 + (threadIdx.x >> 4);
+  float s = 0.f;
+  if (pair < BC) {
+    const float* q = Q + (size_t)arg[pair] * ldq;
+    const float* w = W + (size_t)(pair % C) * ldw;
+    for (int k = l; k < K; k += 16) s = fmaf(q[k], w[k], s);
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+  if (pair < BC && l == 0) uarg[pair] = s;
+}
 // One thread per channel, loop over the B shapes.  With u = q.W^T, xhat = (y-mean)*inv, gz = scatter(gval):
 //   U0 = sum_m u (given), U1 = sum_m u*xhat = inv*(quad + (bias-mean)*U0)   (quad[c] = w_c^T (q^T a) w_c), Ugz = sum_b gval*uarg
 //   phase A coefficients as bn_dbl_coeffs; top adjoint t[b,c] = gamma*inv*(uarg - U0/M - xhat_arg*U1/M)*lrelu'(pooled)
@@ -561,6 +593,14 @@ extern "C" int spgan_gather_rowdot(const float* Q, int ldq, const int32_t* arg, 
                                    spgan_stream_t s_) {
   SPGAN_CHECK_ARG(Q && arg && W && out && B > 0 && C > 0 && K > 0 && ldq >= K && ldw >= K);
   hipLaunchKernelGGL(gather_rowdot_kernel, dim3(cdiv(B * C, 16)), dim3(256), 0, (hipStream_t)s_, Q, ldq, arg, W, ldw, B * C, C, K, out);
+  return spgan_launch_status();
+}
+extern "C" int spgan_dbl_top_dots(const float* Q, int ldq, const int32_t* arg, const float* W, int ldw, const float* T, int ldt, const float* cq,
+                                  int B, int C, int K, float* uarg, float* quad, float* U0, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(Q && arg && W && T && cq && uarg && quad && U0 && B > 0 && C > 0 && K > 0 && ldq >= K && ldw >= K && ldt >= K);
+  const int row_blocks = cdiv(C, 16);
+  hipLaunchKernelGGL(dbl_top_dots_kernel, dim3(row_blocks + cdiv(B * C, 16)), dim3(256), 0, (hipStream_t)s_, Q, ldq, arg, W, ldw, T, ldt, cq, B * C, C, K,
+                     row_blocks, uarg, quad, U0);
   return spgan_launch_status();
 }
 extern "C" int spgan_rowdot(const float* X, int ldx, const float* Y, int ldy, int R, int K, float* out, spgan_stream_t s_) {

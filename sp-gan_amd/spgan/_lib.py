@@ -201,6 +201,7 @@ SIGNATURES = {
     "spgan_bn_dbl_phaseb_sums": (I, [P, P, P, P, P, P, P, P, P, I, I, P, P, P]),
     "spgan_gather_rowdot": (I, [P, I, P, P, I, I, I, I, P, P]),
     "spgan_rowdot": (I, [P, I, P, I, I, I, P, P]),
+    "spgan_dbl_top_dots": (I, [P, I, P, P, I, P, I, P, I, I, I, P, P, P, P]),
     "spgan_bn_dbl_pool": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P]),
     "spgan_sparse_bn_prep": (I, [P, P, P, P, P, I, I, I, P, P, P, P]),
     "spgan_col_scale_add": (I, [P, P, P, I, I, P, P]),

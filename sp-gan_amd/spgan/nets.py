@@ -540,9 +540,8 @@ def _d_double_top_phase_a(P, ctx, saved, q3: Tensor, grads) -> dict:
         dW = ops.rowscale_outer(T, dz.alpha, b4, dz.beta, cq)
         ops.sparse_rows_tn(dz.sp_val, dz.sp_arg, N, q3, dW)
     grads[conv + ".weight"] = dW
-    U0 = ops.gemm_nt(cq.view(1, -1), W, exact=True)[0]
-    quad = ops.rowdot(W, T)                                                      # w_c^T (q3^T a3) w_c
-    uarg = ops.gather_rowdot(q3, argmax, W)                                      # u at the arg-max rows [B,1024]
+    # u at the arg-max rows [B,1024], w_c^T (q3^T a3) w_c and U0 = colsum(q3).W^T: three independent dot-product launches as one
+    uarg, quad, U0 = ops.dbl_top_dots(q3, argmax, W, T, cq)
     yarg = ctx["yarg"] if ctx.get("yarg") is not None else ops.gather_rows(ys[3], argmax)
     t, spB, c4 = ops.bn_dbl_pool(uarg, saved["gval"], yarg, pooled, U0, quad, b4, mu, inv, gamma, S0, S1, M, NEG)
     return dict(t=t, spB=spB, c4=c4, pro3=pro3, q3=q3, Qqa=Qqa)

@@ -1105,6 +1105,21 @@ def gather_rowdot(Q: Tensor, arg: Tensor, W: Tensor) -> Tensor:
     return out
 
 
+def dbl_top_dots(Q: Tensor, arg: Tensor, W: Tensor, T: Tensor, cq: Tensor):
+    """-> (uarg [B,C] = Q[arg[b,c],:] . W[c,:],  quad [C] = W[c,:] . T[c,:],  U0 [C] = W[c,:] . cq): gather_rowdot, rowdot and a matrix-vector
+    product -- three independent launches of the collapsed double backward's phase A -- as one."""
+    _rowmajor2d(Q, "Q"); _rowmajor2d(W, "W"); _rowmajor2d(T, "T"); _i32(arg, "arg")
+    B, Cn = arg.shape
+    K = W.shape[1]
+    if W.shape[0] != Cn or Q.shape[1] != K or tuple(T.shape) != (Cn, K):
+        raise ValueError("shape mismatch in dbl_top_dots")
+    uarg = torch.empty((B, Cn), dtype=torch.float32, device=Q.device)
+    qu = torch.empty((2, Cn), dtype=torch.float32, device=Q.device)
+    check(_lib.load().spgan_dbl_top_dots(_p(Q), _ld(Q), _p(arg), _p(W), _ld(W), _p(T), _ld(T), _p(_vec(cq, K, "cq")), B, Cn, K, _p(uarg), _p(qu[0]),
+                                         _p(qu[1]), _s()), "dbl_top_dots", B=B, C=Cn, K=K)
+    return uarg, qu[0], qu[1]
+
+
 def rowdot(X: Tensor, Y: Tensor) -> Tensor:
     """out[r] = X[r,:] . Y[r,:]"""
     _rowmajor2d(X, "X"); _rowmajor2d(Y, "Y")

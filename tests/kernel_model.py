@@ -287,6 +287,10 @@ def gather_rowdot(Q, arg, W):
     return (Q[arg.long().reshape(-1)] * W.repeat(B, 1)).sum(1).view(B, C).contiguous()
 
 
+def dbl_top_dots(Q, arg, W, T, cq):
+    return gather_rowdot(Q, arg, W), rowdot(W, T), W @ cq
+
+
 def rowdot(X, Y):
     return (X * Y).sum(1)
 

@@ -205,3 +205,17 @@ def test_wgrad_collapse_all_terms(C, N, K, B, rows):
     ops.sparse_rows_tn(val, arg, rows, Bm, old, pro=pro)
     close(ops.wgrad_collapse(W, X1, a1, b1, d1, v1, sparse=(val, arg, rows, Bm, pro)), old, rtol=3e-6, atol=3e-5)
     assert torch.equal(ops.wgrad_collapse(W, X1, a1, b1, d1, v1, sparse=(val, arg, rows, Bm, pro)), out), "not deterministic"
+
+
+def test_dbl_top_dots_equals_its_three_launches():
+    """ops.dbl_top_dots: gather_rowdot, rowdot and W.cq from one grid -- the first two bit-identical to their own kernels (same arithmetic), the
+    matrix-vector product against float64."""
+    from spgan import ops
+    from test_kernels_gpu import close, rnd
+    B, rows, C, K = 5, 96, 1024, 256
+    Q, W, T, cq = rnd("dtd.Q", (B * rows, K)), rnd("dtd.W", (C, K), 0.1), rnd("dtd.T", (C, K)), rnd("dtd.cq", (K,))
+    g = torch.Generator().manual_seed(11)
+    arg = (torch.randint(0, rows, (B, C), generator=g) + torch.arange(B)[:, None] * rows).to(torch.int32).cuda()
+    uarg, quad, U0 = ops.dbl_top_dots(Q, arg, W, T, cq)
+    assert torch.equal(uarg, ops.gather_rowdot(Q, arg, W)) and torch.equal(quad, ops.rowdot(W, T))
+    close(U0, W.double() @ cq.double(), rtol=3e-6, atol=3e-6)
