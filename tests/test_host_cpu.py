@@ -334,3 +334,22 @@ def test_discriminator_forward_many_equals_separate_calls(spgan_cpu):
         _cmp("forward_many grad " + n, res[1][4][n], res[0][4][n], 2e-6, atol=1e-7)
     for k in res[0][5]:
         assert torch.allclose(res[1][5][k].float(), res[0][5][k].float(), rtol=1e-6, atol=1e-7), k
+
+
+def test_multi_add_stride_merging_is_host_logic():
+    """ops._strided3: how a pair of equal-shape views becomes the <= 3 strided dimensions of spgan_multi_add3 (pure host code: runs on CPU tensors)."""
+    from spgan import ops as real_ops
+    import importlib
+    o = importlib.reload(real_ops) if not hasattr(real_ops, "_strided3") else real_ops
+    F_, k = 8, 5
+    dst = torch.zeros(F_, F_, 1, k)
+    g = torch.arange(F_ * k * F_, dtype=torch.float32).view(F_, k * F_)
+    src = g.view(F_, k, F_).permute(0, 2, 1).unsqueeze(2)                       # the conv_out gradient as a view of the parameter's shape
+    n1, n2, ds, ss = o._strided3(dst, src)
+    assert (n1, n2) == (F_, k) and ds == [F_ * k, k, 1] and ss == [k * F_, 1, F_]
+    assert o._strided3(dst, dst.clone()) is None                                # contiguous pair: the plain kernel
+    full = torch.zeros(6, 10, 1)
+    n1, n2, ds, ss = o._strided3(full.view(6, 10)[:, 4:], torch.ones(6, 6))     # a column block of the destination
+    assert (n1, n2) == (6, 6) and ds[1:] == [10, 1] and ss[1:] == [6, 1]
+    with pytest.raises(ValueError):
+        o._strided3(torch.zeros(2, 3, 4, 5).permute(3, 2, 1, 0), torch.zeros(5, 4, 3, 2))
