@@ -36,6 +36,9 @@ def test_knn_mfma_duplicates_and_ties(ops):
 def test_knn_tile_images_route_returns_the_same_indices(ops, B, N, C, k):
     """csrc/knn_pipe.hip (pre-split tile images, software-pipelined scan) keeps the arithmetic of the single-launch kernel:
     identical indices on ragged N (tiles past N carry +inf norms), C < 64 (zero-padded channels), one-tile shapes and k < 10."""
+    import os
+    if os.environ.get("SPGAN_KNN_BF16X3") == "0":
+        pytest.skip("the A/B switch puts the single-launch route on the fp32-MFMA kernel: other rounding, near-ties may resolve differently")
     x = rnd("knnp.%d.%d.%d" % (B, N, C), (B * N, C), 0.5)
     from spgan import _lib
     assert _lib.load().spgan_knn_ws_bytes(B, N, C, k, 0) > 0
