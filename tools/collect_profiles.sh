@@ -18,6 +18,8 @@ python $R/tools/gap_analysis.py $DB 0.35 0.7 > $O/${TAG}_bench_graph_replay_wind
 python $R/tools/step_sequence.py $DB -8 > $O/${TAG}_step_sequence.txt
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do rm -rf /tmp/p_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/p_$c -o r -- python $R/tools/pmc_step.py > /tmp/log_$c 2>&1; done
 python $R/tools/pmc_step_total.py $(find /tmp/p_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/p_WRITE_SIZE -name "*.db" | head -1) $(find /tmp/p_MfmaUtil -name "*.db" | head -1) > $O/${TAG}_pmc_step.json
+for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do rm -rf /tmp/p4_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/p4_$c -o r -- python $R/tools/pmc_step.py --config c4 > /tmp/log4_$c 2>&1; done     # the same at the C4 per-GPU shape
+python $R/tools/pmc_step_total.py $(find /tmp/p4_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/p4_WRITE_SIZE -name "*.db" | head -1) $(find /tmp/p4_MfmaUtil -name "*.db" | head -1) > $O/${TAG}_pmc_step_c4.json
 for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/g_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/g_$c -o r -- python $R/tools/pmc_gemm.py > /tmp/glog_$c 2>&1; python $R/tools/pmc_summary.py $(find /tmp/g_$c -name "*.db" | head -1) gemm_nt > $O/${TAG}_pmc_gemm_$c.txt; done
 python $R/tools/pmc_gemm_json.py $O/${TAG}_pmc_gemm_FETCH_SIZE.txt $O/${TAG}_pmc_gemm_WRITE_SIZE.txt ${TAG} > $O/${TAG}_pmc_gemm_nt.json
 python $R/tools/mfma_shapes.py > $O/${TAG}_mfma_shapes.txt 2>/dev/null
