@@ -224,6 +224,20 @@ class DStackFn(Function):
         return (None, dx) + _deliver(params, [grads.get(n) for n in names], ctx.needs_input_grad[2:], ctx.fused)
 
 
+class JoinRowsFn(Function):
+    """cat(parts, dim=0) for the pooled features of passes that one grouped launch wrote as consecutive row blocks of ONE buffer: then the result
+    is a view of that buffer (ops.stacked_rows: no copy launch); backward hands every part its row block of the gradient (views)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        ctx.sizes = [p_.shape[0] for p_ in parts]
+        return ops.stacked_rows([p_.detach() for p_ in parts])
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.sizes, dim=0))
+
+
 class DHeadFn(Function):
     """logits [B',1] = mlp(pooled [B',C4]) -- the head of one or several stacked passes as one batch.  inputs: holder(names), pooled, *params."""
 
@@ -252,7 +266,7 @@ class DHeadFn(Function):
             dout = douts[0]
         else:
             sizes = ctx.holder.sizes
-            dout = torch.cat([d if d is not None else pooled.new_zeros((n, 1)) for d, n in zip(douts, sizes)], dim=0)
+            dout = ops.stacked_rows([d if d is not None else pooled.new_zeros((n, 1)) for d, n in zip(douts, sizes)])   # the loss kernel's seeds: one buffer
         gpool, grads, _ = nets.d_head_backward(P, pooled, ctx.hs, dout.detach().contiguous(), need_dp)
         gp = gpool if ctx.needs_input_grad[1] else None
         if not need_dp:

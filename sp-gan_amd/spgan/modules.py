@@ -478,7 +478,8 @@ def _discriminator_forward_heads(self, pooled):
     """The per-shape MLP head of several forward_stack() results as one batch -> one logits tensor per pass."""
     hn, hp = _named(self.mlp, "mlp.")
     pooled = list(pooled)
-    outs = Fn.DHeadFn.apply(_Holder(names=hn, sizes=[p.shape[0] for p in pooled]), torch.cat(pooled, dim=0), *hp)
+    joined = pooled[0] if len(pooled) == 1 else Fn.JoinRowsFn.apply(*pooled)       # a view when one grouped launch produced the passes
+    outs = Fn.DHeadFn.apply(_Holder(names=hn, sizes=[p.shape[0] for p in pooled]), joined, *hp)
     return list(outs)
 
 

@@ -368,7 +368,7 @@ def _advance_top_running_stats(P, bufs, y3: Tensor, sc3: Tensor, sh3: Tensor, M:
     conv, bn = D_LAYERS[3]
     W, b4 = _w2(P[conv + ".weight"]), P[conv + ".bias"]
     a3 = ops.affine_act(y3, sc3, sh3, NEG)
-    mu_a = ops.colsum(a3)[0] * (1.0 / M)
+    mu_a = ops.colstats(a3, M)[0][0]                    # the column means (one group of M rows), no separate scaling launch
     neg_ones, neg_inv_m = _const_vec(mu_a.numel(), -1.0, mu_a.device), _const_vec(mu_a.numel(), -1.0 / M, mu_a.device)
     cov = ops.rowscale_outer(ops.gemm_tn(a3, a3, pro=(neg_ones, mu_a, 1.0)), neg_inv_m)
     mean4 = ops.gemm_nt(mu_a.view(1, -1), W, b4, exact=True)[0]

@@ -1655,6 +1655,26 @@ def col_scale_add(a: Tensor, b: Tensor, gamma: Tensor) -> Tensor:
 GAN_MODES = {"ls": 0, "wgan": 1, "hinge": 2, "gan": 3}
 
 
+def stacked_rows(parts) -> Tensor:
+    """torch.cat(parts, dim=0) -- without a launch when the parts are consecutive row blocks of ONE buffer (contiguous, same storage, each starting
+    where the previous ends): then the result is a view of that buffer."""
+    parts = list(parts)
+    first = parts[0]
+    ok = all(isinstance(p_, torch.Tensor) and p_.is_contiguous() and p_.dtype == first.dtype and p_.shape[1:] == first.shape[1:] for p_ in parts)
+    if ok and len(parts) > 1:
+        st = first.untyped_storage().data_ptr()
+        end = first.data_ptr() + first.numel() * first.element_size()
+        for p_ in parts[1:]:
+            if p_.untyped_storage().data_ptr() != st or p_.data_ptr() != end:
+                ok = False
+                break
+            end += p_.numel() * p_.element_size()
+    if ok and len(parts) > 1:
+        rows = sum(p_.shape[0] for p_ in parts)
+        return first.as_strided((rows,) + tuple(first.shape[1:]), first.stride(), first.storage_offset())
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+
+
 def gan_loss(mode: int, which: int, d_real: Optional[Tensor], d_fake: Tensor, real_label: Optional[Tensor] = None,
              fake_label: Optional[Tensor] = None):
     """-> (out5 = [loss, fake term, real term, real_acc, fake_acc], g_real [B,1] | None, g_fake [B,1])."""
@@ -1663,8 +1683,13 @@ def gan_loss(mode: int, which: int, d_real: Optional[Tensor], d_fake: Tensor, re
     if d_real is not None:
         d_real = _f32(d_real, "d_real").contiguous()
     out5 = torch.empty((5,), dtype=torch.float32, device=d_fake.device)
-    g_fake = torch.empty_like(d_fake)
-    g_real = torch.empty_like(d_real) if d_real is not None else None
+    if d_real is not None and d_real.shape == d_fake.shape:
+        # one buffer, real rows first: a consumer that wants the two seeds stacked (the batched head's backward) takes the buffer as it is
+        both = torch.empty((2 * B,) + tuple(d_fake.shape[1:]), dtype=torch.float32, device=d_fake.device)
+        g_real, g_fake = both[:B], both[B:]
+    else:
+        g_fake = torch.empty_like(d_fake)
+        g_real = torch.empty_like(d_real) if d_real is not None else None
     check(_lib.load().spgan_gan_loss(mode, which, _p(d_real), _p(d_fake), _p(_vec(real_label, B, "real_label")), _p(_vec(fake_label, B, "fake_label")),
                                      B, _p(out5), _p(g_real), _p(g_fake), _s()), "gan_loss", mode=mode, which=which, B=B)
     return out5, g_real, g_fake

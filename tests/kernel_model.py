@@ -617,6 +617,11 @@ def tanh_bwd(dy, y):
     return (dy * (1 - y * y)).contiguous()
 
 
+def stacked_rows(parts):
+    parts = list(parts)
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+
+
 def multi_copy(dsts, srcs):
     for d, s in zip(dsts, srcs):
         d.copy_(s)

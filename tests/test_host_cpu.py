@@ -353,3 +353,24 @@ def test_multi_add_stride_merging_is_host_logic():
     assert (n1, n2) == (6, 6) and ds[1:] == [10, 1] and ss[1:] == [6, 1]
     with pytest.raises(ValueError):
         o._strided3(torch.zeros(2, 3, 4, 5).permute(3, 2, 1, 0), torch.zeros(5, 4, 3, 2))
+
+
+def test_stacked_rows_is_a_view_only_for_adjacent_blocks():
+    """ops.stacked_rows (host logic): consecutive row blocks of one buffer come back as a view of it, anything else through torch.cat."""
+    import importlib
+    real_ops = importlib.import_module("spgan.ops")
+    import inspect
+    src = inspect.getsource(real_ops)                      # the fixture swaps the public ops for their models: take the real helper from source
+    ns = {"torch": torch, "Tensor": torch.Tensor}
+    start = src.index("def stacked_rows(")
+    exec(src[start:src.index("\ndef ", start + 10)], ns)
+    stacked = ns["stacked_rows"]
+    base = torch.arange(24.0).view(6, 4)
+    a, b = base[:2], base[2:5]
+    v = stacked([a, b])
+    assert v.data_ptr() == base.data_ptr() and torch.equal(v, base[:5])
+    w = stacked([b, a])                                    # not adjacent in this order: a copy
+    assert w.data_ptr() != base.data_ptr() and torch.equal(w, torch.cat([b, a]))
+    assert stacked([a]).data_ptr() == a.data_ptr()
+    c = torch.zeros(3, 4)
+    assert torch.equal(stacked([a, c]), torch.cat([a, c]))
