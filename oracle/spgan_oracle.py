@@ -373,16 +373,19 @@ class AdamState:
 
 def train_step(gp_, gbuf, dp_, dbuf, optG: AdamState, optD: AdamState, sphere: Tensor, real: Tensor,
                z_d: Tensor, z_g: Tensor, gan: str = "ls", use_gp: bool = False,
-               alpha: Optional[Tensor] = None, lambda_gp: float = 10.0, k: int = 10, lr: float = 1e-4):
+               alpha: Optional[Tensor] = None, lambda_gp: float = 10.0, k: int = 10, lr: float = 1e-4, graphs=None):
     """One iteration of the reference loop body (Generation/model.py:239-279):
     D-step (G frozen, no graph through G) then G-step (D frozen: input grads only).
     `real` is [B,N,3]; sphere [B,N,3]; z_* [B,N,nz].  With use_gp the D loss is
     dis_loss(gan) + GradientPenalty(lambda_gp, gamma=1).
-    Params are leaf tensors with requires_grad=True; returns dict of scalars + grads."""
+    Params are leaf tensors with requires_grad=True; returns dict of scalars + grads.
+    graphs = (idx2 of the D step's generator forward, idx2 of the G step's): EdgeConv2's neighbour graphs [B,N*k] handed in instead of
+    built (tie-aware protocol of the multi-step golden G19)."""
     out = {}
+    g_d, g_g = graphs if graphs is not None else (None, None)
     # ---- D step (model.py:240-260) ----
     with torch.no_grad():
-        fake = generator_forward(gp_, sphere, z_d, k=k, training=True, buffers=gbuf)
+        fake = generator_forward(gp_, sphere, z_d, k=k, training=True, buffers=gbuf, idx2=g_d)
     real_t = real.transpose(2, 1).contiguous()
     d_real = discriminator_forward(dp_, real_t, True, dbuf)
     d_fake = discriminator_forward(dp_, fake, True, dbuf)
@@ -395,7 +398,7 @@ def train_step(gp_, gbuf, dp_, dbuf, optG: AdamState, optD: AdamState, sphere: T
     optD.apply(dp_, dgrads, lr)
     out.update(loss_d=loss_d.detach(), d_grads=dgrads, fake_d=fake)
     # ---- G step (model.py:264-279) ----
-    fake_g = generator_forward(gp_, sphere, z_g, k=k, training=True, buffers=gbuf)
+    fake_g = generator_forward(gp_, sphere, z_g, k=k, training=True, buffers=gbuf, idx2=g_g)
     with torch.no_grad():
         d_real_g = discriminator_forward(dp_, real_t, True, dbuf)   # unused by the loss, but it
     #                                                                 advances D's BN running stats

@@ -314,11 +314,8 @@ extern "C" int spgan_wgrad_collapse(const spgan_wgrad_collapse_args* a, spgan_st
   SPGAN_CHECK_ARG(!a->X2 || (a->a2 && (a->ldx2 % 4 == 0) && (reinterpret_cast<uintptr_t>(a->X2) & 15) == 0 && a->ldx2 >= (a->x2_t ? a->N : a->K)));
   SPGAN_CHECK_ARG(!a->sp_val || (a->sp_arg && a->Bm && a->B > 0 && a->B <= WG_BMAX && a->rows > 0 && a->ldb >= a->N && (!a->p_scale == !a->p_shift)));
   SPGAN_CHECK_ARG(!a->T || a->ldt >= a->N);
-  static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_collapse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_lds_bytes(WG_KMAX, 2));
-    attr_set = true;
-  }
+  static LdsOptIn opt;  // > 64 KB of dynamic LDS: once per kernel and device
+  opt.ensure(reinterpret_cast<const void*>(&wgrad_collapse_kernel), (int)wgrad_lds_bytes(WG_KMAX, 2));
   const size_t lds = wgrad_lds_bytes(a->K, a->X2 ? 2 : 1);
   hipLaunchKernelGGL(wgrad_collapse_kernel, dim3(a->C / 32, a->N / 32), dim3(256), lds, (hipStream_t)s_, *a);
   return spgan_launch_status();

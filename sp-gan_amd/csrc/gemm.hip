@@ -1000,11 +1000,8 @@ template <int AMODE, int EPI, int CFG, int DB, int FAST, int F16 = 0, int AH = 0
 void launch_nt_cfg(const spgan_gemm_nt_args& a, hipStream_t s) {
   constexpr int BN = Geo<CFG>::WGN * Geo<CFG>::TJ * 32;
   constexpr size_t lds = nt_lds_bytes<CFG, DB, F16>();
-  static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16, AH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static LdsOptIn opt;  // > 64 KB of dynamic LDS: once per kernel and device
+  if (lds > 64 * 1024) opt.ensure(reinterpret_cast<const void*>(&gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16, AH>), (int)lds);
   const int tm8 = cdiv(cdiv(a.M, BM), 8) * 8;
   const int batch = (AMODE == SPGAN_A_PLAIN && EPI == SPGAN_EPI_LINEAR && a.batch > 1) ? a.batch : 1;
   hipLaunchKernelGGL((gemm_nt_kernel<AMODE, EPI, CFG, DB, FAST, F16, AH>), dim3(tm8 * cdiv(a.N, BN), batch), dim3(256), lds, s, a);

@@ -374,11 +374,8 @@ __global__ __launch_bounds__(WTHREADS, 2) void gemm_nt_wide_kernel(const spgan_g
 template <int AMODE, int EPI, int F16>
 int launch_op(const spgan_gemm_nt_args& a, hipStream_t s) {
   constexpr size_t lds = wide_lds<F16>();
-  static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_wide_kernel<AMODE, EPI, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static LdsOptIn opt;  // > 64 KB of dynamic LDS: once per kernel and device
+  opt.ensure(reinterpret_cast<const void*>(&gemm_nt_wide_kernel<AMODE, EPI, F16>), (int)lds);
   const int tm8 = cdiv(a.M / WM, 8) * 8;
   hipLaunchKernelGGL((gemm_nt_wide_kernel<AMODE, EPI, F16>), dim3(tm8 * (a.N / WN)), dim3(WTHREADS), lds, s, a);
   return spgan_launch_status();

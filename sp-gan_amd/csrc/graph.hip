@@ -773,11 +773,8 @@ extern "C" int spgan_csr_build(const int32_t* idx, int B, int N, int k, int32_t*
   const size_t sh = (size_t)(2 * N + 32) * sizeof(int);
   const size_t E = (size_t)N * k, sh_seg = sh + ((E * sizeof(unsigned short) + 15) & ~(size_t)15);
   if (E <= 65536 && sh_seg <= 160 * 1024) {
-    static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+    static LdsOptIn opt;  // > 64 KB of dynamic LDS: once per kernel and device
+    opt.ensure(reinterpret_cast<const void*>(&csr_kernel<true>), 160 * 1024);
     hipLaunchKernelGGL(csr_kernel<true>, dim3(B), dim3(1024), sh_seg, s, idx, N, k, rowptr, src);
   } else {
     hipLaunchKernelGGL(csr_kernel<false>, dim3(B), dim3(1024), sh, s, idx, N, k, rowptr, src);

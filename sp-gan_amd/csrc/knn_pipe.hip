@@ -272,11 +272,8 @@ int spgan_knn_ws(const float* x_pm, int B, int N, int C, int k, int mode, int32_
   hipStream_t s = static_cast<hipStream_t>(s_);
   const int tiles = tiles_of(N);
   float* img = static_cast<float*>(ws);
-  static bool attr_set = false;  // > 64 KB of dynamic LDS must be opted into once per kernel
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS);
-    attr_set = true;
-  }
+  static LdsOptIn opt;  // > 64 KB of dynamic LDS: once per kernel and device
+  opt.ensure(reinterpret_cast<const void*>(&knn_pipe_kernel), (int)PIPE_LDS);
   hipLaunchKernelGGL(knn_split_kernel, dim3(tiles, B), dim3(256), 0, s, x_pm, N, C, tiles, img);
   hipLaunchKernelGGL(knn_pipe_kernel, dim3(cdiv(N, 128), B), dim3(256), PIPE_LDS, s, img, N, tiles, k, idx);
   return spgan_launch_status();

@@ -330,11 +330,8 @@ extern "C" int spgan_chamfer_bwd(const float* xa, const float* xb, int B, int Na
 extern "C" int spgan_chamfer_pairs(const float* A, const float* Bc, int S, int R, int N, int M, float* out, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(A && Bc && out && S > 0 && R > 0 && N > 0 && M > 0 && N <= 4096 && M <= 4096 && (long)S * R < (1L << 31));
   const size_t lds = (size_t)(N + M) * sizeof(float4);
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chamfer_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
+  static LdsOptIn opt;  // > 64 KB of dynamic LDS: once per kernel and device
+  if (lds > 64 * 1024) opt.ensure(reinterpret_cast<const void*>(&chamfer_pairs_kernel), 128 * 1024);
   hipLaunchKernelGGL(chamfer_pairs_kernel, dim3(S * R), dim3(256), lds, (hipStream_t)s_, A, Bc, N, M, R, out);
   return spgan_launch_status();
 }

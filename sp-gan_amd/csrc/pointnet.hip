@@ -375,7 +375,9 @@ extern "C" int spgan_group_concat(const float* xyz, const float* center, const f
  * point); bad (optional, one int, zeroed by the caller) is set when an index lies outside [0, N). */
 extern "C" int spgan_gather_csr(const int64_t* idx, int B, int S, int N, int32_t* rowptr, int32_t* src, int32_t* bad, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(idx && rowptr && src && B > 0 && S > 0 && N > 0 && N <= 16384 && (size_t)B * S < 2147483647u);
-  const size_t sh = (size_t)(2 * N + 32) * sizeof(int);
+  const size_t sh = (size_t)(2 * N + 32) * sizeof(int);      // N <= 16384: <= 128.1 KB of the CU's 160 KB
+  static LdsOptIn opt;  // > 64 KB of dynamic LDS (N >= 8177): once per kernel and device
+  if (sh > 64 * 1024) opt.ensure(reinterpret_cast<const void*>(&gather_csr_kernel), 160 * 1024);
   hipLaunchKernelGGL(gather_csr_kernel, dim3(B), dim3(1024), sh, (hipStream_t)s_, idx, S, N, rowptr, src, (int*)bad);
   return spgan_launch_status();
 }

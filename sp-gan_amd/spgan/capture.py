@@ -99,8 +99,11 @@ class CapturedBody:
                 # the modules cached structure derived from this buffer and the captured graph does not re-derive it: compare on the
                 # device (one host sync, off the steady-state path); a real change goes through torch's copy_, whose version bump
                 # invalidates the modules' cache entries
-                if self._graph is None or not bool(torch.equal(st, a)):
-                    structure_changed = True        # (without a graph: assumed changed -- no comparison, the next call is eager anyway)
+                # -- with or without a captured graph: a caller that re-creates an IDENTICAL prior on every call (x = sphere.cuda() inside
+                # the loop) must not be taken for one whose prior changes, or the warm-up would restart forever and no graph would ever
+                # be captured (round-4 advisor finding); equal content needs no copy and leaves the modules' cache entries valid
+                if not bool(torch.equal(st, a)):
+                    structure_changed = True
                     st.copy_(a)
                 continue
             if a.is_cuda and a.is_contiguous() and a.dtype == torch.float32:
@@ -131,8 +134,7 @@ class CapturedBody:
             # The prior changed: a captured graph holds the OLD prior's kNN graph, CSR and dedup decision (the modules cache them per
             # tensor and version, so the capture contains no kNN launch), and a capture that found its cache entry stale would have to
             # rebuild it with a host sync.  Drop the graph, run this call eagerly (rebuilds the caches), capture again on the next one.
-            if self._graph is not None or self._captured_once:
-                self._recaptures += 1
+            self._recaptures += 1                    # also before the first capture: a prior that really changes on every call must reach the eager verdict
             self._graph = None
             if self._recaptures > 3:
                 warnings.warn("CapturedBody: an argument the modules derive cached graph structure from (the sphere prior) keeps changing "

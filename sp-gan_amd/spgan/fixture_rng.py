@@ -65,6 +65,28 @@ def init_params(shapes: Dict[str, Tuple[int, ...]], salt: int = 0, perturb_bn: b
     return out
 
 
+def mid_training_state(shapes: Dict[str, Tuple[int, ...]], buffer_names, salt: int = 0, scale: float = 1e-2, step: int = 7,
+                       batches: int = 21) -> Dict[str, object]:
+    """A reproducible state "in the middle of training" for the state-carry fixtures (golden G20): Adam moments of the magnitude the
+    networks' gradients have (exp_avg ~ N(0, scale), exp_avg_sq = (U(0.5, 1.5)*scale)^2), an optimiser step count, and non-trivial
+    BatchNorm running statistics (mean ~ N(0, 0.1), var ~ U(0.5, 1.5), `batches` calls tracked) -- loaded into the reference AND into the
+    build before ONE step, so that Adam at step > 1 and a running-statistics update from non-initial buffers are compared at one-step
+    tolerances instead of across a chaotic multi-step trajectory.  -> {"m": {name: t}, "v": {name: t}, "step": int, "buffers": {name: t}}."""
+    m = {n: normal("mid.m." + n, shp, scale, 0.0, salt) for n, shp in shapes.items()}
+    v = {n: (uniform("mid.v." + n, shp, 0.5, 1.5, salt) * scale) ** 2 for n, shp in shapes.items()}
+    bufs = {}
+    for n in buffer_names:
+        base = n.rsplit(".", 1)[0]
+        c = shapes[base + ".weight"]
+        if n.endswith("running_mean"):
+            bufs[n] = normal("mid.rm." + n, c, 0.1, 0.0, salt)
+        elif n.endswith("running_var"):
+            bufs[n] = uniform("mid.rv." + n, c, 0.5, 1.5, salt)
+        elif n.endswith("num_batches_tracked"):
+            bufs[n] = torch.tensor(batches, dtype=torch.long)
+    return {"m": m, "v": v, "step": step, "buffers": bufs}
+
+
 _BALLS = None
 
 

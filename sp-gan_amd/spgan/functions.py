@@ -69,12 +69,14 @@ def _engine_needs(ctx, pos: int, tpos: int) -> bool:
 
 
 # Parameter gradients are handed back to autograd (AccumulateGrad, hooks, torch.autograd.grad all behave as usual) unless the
-# caller opted into the fused route with `fused_grad_accumulation()` -- spgan.TrainStep does, around its two backward() calls.
+# caller opted into the fused route with `fused_grad_accumulation()` -- spgan.TrainStep does, around each of its segments (the mode is
+# recorded per graph when a Function's FORWARD runs: the context must enclose the forward pass, wrapping only backward() selects nothing).
 class fused_grad_accumulation(_Mode):
     """Context: the nodes of forward passes evaluated inside it add their parameter gradients straight into the pre-bound flat `.grad`
     buffers (spgan.optim.flatten_module) with one fused launch per Function and return None to autograd.  Only for callers that read
     gradients from `.grad` afterwards and use no parameter hooks (TrainStep wraps its segments in it, CapturedBody the caller's body on
-    request); everything else gets normal autograd semantics."""
+    request); everything else gets normal autograd semantics.  The mode is recorded at FORWARD time (`_record_modes`): enclose the forward
+    pass -- a context around backward() alone has no effect on graphs built outside it."""
     name = "fused"
 
 

@@ -231,10 +231,26 @@ def edge_features_cm_bwd(dE: Tensor, idx_local: Tensor, k: int) -> Tensor:
     idx_local = idx_local.contiguous()
     rowptr = torch.empty((B * N, 2), dtype=torch.int32, device=dE.device)
     src = torch.empty((B * N * k,), dtype=torch.int32, device=dE.device)
-    check(lib.spgan_gather_csr(_p(idx_local), B, N * k, N, _p(rowptr), _p(src), None, _s()), "gather_csr", B=B, S=N * k, N=N)
+    bad = index_check_flag(dE.device)
+    check(lib.spgan_gather_csr(_p(idx_local), B, N * k, N, _p(rowptr), _p(src), None if bad is None else _p(bad), _s()), "gather_csr", B=B, S=N * k, N=N)
+    index_check_raise(bad, "edge_features backward: a neighbour index lies outside [0, %d)" % N)
     dx = torch.empty((B, C2 // 2, N), dtype=torch.float32, device=dE.device)
     check(lib.spgan_edge_features_cm_bwd(_p(dE), _p(rowptr), _p(src), B, C2 // 2, N, k, _p(dx), _s()), "edge_features_cm_bwd", B=B, C=C2 // 2, N=N, k=k)
     return dx
+
+
+def index_check_flag(device) -> Optional[Tensor]:
+    """The gather adjoints drop out-of-range indices silently (the forward gather would already have read out of bounds).  With
+    SPGAN_CHECK_INDICES=1 the CSR builder reports them through a device flag that `index_check_raise` reads back -- one host
+    synchronisation per backward, so it is a debugging switch, not the default."""
+    if os.environ.get("SPGAN_CHECK_INDICES", "0") != "1" or capturing():
+        return None
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def index_check_raise(bad: Optional[Tensor], msg: str) -> None:
+    if bad is not None and int(bad.item()) != 0:
+        raise IndexError(msg)
 
 
 def idx_to_local64(idx: Tensor, B: int, N: int) -> Tensor:

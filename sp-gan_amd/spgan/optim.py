@@ -79,6 +79,16 @@ class Adam:
         self.zero_grad_in_step = bool(zero_grad_in_step and capturable)
         self._grad_clean = False
 
+    def invalidate_grads(self) -> None:
+        """Restore "the flat gradient buffer is zero" after anything OUTSIDE the owner's zero_grad() .. step() window wrote into the
+        parameters' `.grad` (a diagnostic backward between two steps, a regulariser of the caller's): zero_grad_in_step skips the
+        fill on the host flag alone, and a captured step records no fill at all, so such a write would be added to the next step's
+        gradients.  Zeroes the buffer now (one fill launch) and forgets the flag.  Contract of zero_grad_in_step otherwise: `p.grad`
+        reads as zero after step()."""
+        self._grad_clean = False
+        self.fp.zero_grad()
+        self._grad_clean = self.zero_grad_in_step
+
     def zero_grad(self, set_to_none: bool = False):
         if self._grad_clean:
             self._grad_clean = False         # the previous step() zeroed the buffer; the parameters' .grad views are bound to it

@@ -21,6 +21,7 @@ import torch
 
 from . import _lib
 from ._lib import check
+from . import ops
 from .ops import _f32, _p, _s
 
 Tensor = torch.Tensor
@@ -46,7 +47,9 @@ def gather_csr(idx: Tensor, N: int):
     S = idx.numel() // B
     rowptr = torch.empty((B * N, 2), dtype=torch.int32, device=idx.device)
     src = torch.empty((B * S,), dtype=torch.int32, device=idx.device)
-    check(_lib.load().spgan_gather_csr(_p(idx), B, S, N, _p(rowptr), _p(src), None, _s()), "gather_csr", B=B, S=S, N=N)
+    bad = ops.index_check_flag(idx.device)
+    check(_lib.load().spgan_gather_csr(_p(idx), B, S, N, _p(rowptr), _p(src), None if bad is None else _p(bad), _s()), "gather_csr", B=B, S=S, N=N)
+    ops.index_check_raise(bad, "gather_csr: an index lies outside [0, %d)" % N)
     return rowptr, src
 
 

@@ -205,6 +205,9 @@ class TrainStep:
                 self.optG.t, self.optD.t = tG, tD
                 if self.optG.capturable:
                     self.optG.dev_state[:1].view(torch.int32).fill_(tG); self.optD.dev_state[:1].view(torch.int32).fill_(tD)
+                # the aborted capture recorded Adam launches that never ran: their "the step left the gradient buffer zeroed" flags are
+                # false, and whatever the warm-up steps left in the buffers is unknown to the host -- fill them
+                self.optG.invalidate_grads(); self.optD.invalidate_grads()
                 self.use_graph = False
                 torch.cuda.synchronize()
                 # cache entries created during the aborted capture carry current stamps but live in the aborted graph's pool and were
@@ -269,8 +272,10 @@ class TrainStep:
         # cloud as the loader delivers it ([B,N,3] IS point-major) -- no [B,3,N] round trips (layout kernels, cat + transpose, and their
         # adjoints in the penalty's double backward); the same values into the same kernels (only the penalty's per-shape norm sums its
         # 3N squares in the other memory order: last-bit differences).
+        # (the route builds x_hat itself as real + alpha*(fake - real), gradient_penalty.py:24-25: only for the penalty's "common" mixing
+        # rule -- a GradientPenalty(mix="loss_utils") keeps the [B,3,N] route, which calls GradientPenalty.interpolate)
         pm = (self.point_major and self.batch_d_forwards and D.training and N % ops.ROW_TILE == 0 and not getattr(G, "off", False)
-              and tuple(x.shape) == tuple(real.shape))
+              and tuple(x.shape) == tuple(real.shape) and (not self.use_gp or self.gp.mix == "common"))
         G.twin_forward = "first" if self.twin_g_forwards else None
         try:
             fake = G(x, z_d, pm_out=True).detach() if pm else G(x, z_d).detach()

@@ -1008,8 +1008,229 @@ def g18():
     save("g18_step_noise_c2.npz", d)
 
 
+# ---------------------------------------------------------------- G19: THREE consecutive reference steps (state carry)
+def _g19_inputs(tag, B, N, k):
+    """Inputs of step k (fresh real batch, fresh latents, fresh mixing factors: every step sees other data, as in model.py:239-279)."""
+    return (fr.synthetic_real(B, N, seed=1900 + 10 * k), fr.latent(B, N, seed=1901 + 10 * k), fr.latent(B, N, seed=1902 + 10 * k),
+            fr.uniform("g19.%s.alpha.%d" % (tag, k), (B, 1, 1), 0.0, 1.0))
+
+
+class _NP64:
+    """numpy with float32 -> float64: the reference's LS losses build their labels with `.astype(np.float32)` (loss_utils.py:902-903),
+    which a float64 run of the same functions cannot take."""
+    def __getattr__(self, k):
+        return np.float64 if k == "float32" else getattr(np, k)
+
+
+LU64 = extract_functions(os.path.join(REF, "Common/loss_utils.py"),
+                         ["dis_loss", "gen_loss", "BCEloss", "BCEfakeloss", "smooth_labels", "noisy_labels"],
+                         dict(torch=torch, nn=nn, F=F, np=_NP64(), functools=functools, Variable=Variable))
+
+
+def _ref_three_steps(tag, gan, use_gp, B, N, salt, dtype, graphs=None):
+    """Three consecutive iterations of the imported reference in `dtype`; graphs = per step (idx2_d, idx2_g) to inject into EdgeConv2
+    (None: built, and returned).  Returns per-step records and the final state."""
+    import Generation.Generator as GG
+    lu = LU64 if dtype == torch.float64 else LU
+
+    class O(Opts):
+        np = N
+    G = load_into(Generator(O), fr.init_params(orc.generator_shapes(), salt=salt)).train().to(dtype)
+    D = load_into(Discriminator(O, num_point=N), fr.init_params(orc.discriminator_shapes(), salt=salt)).train().to(dtype)
+    init = {"g": {n: p.detach().clone() for n, p in G.named_parameters()}, "d": {n: p.detach().clone() for n, p in D.named_parameters()}}
+    optG = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.99))
+    optD = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.99))
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).to(dtype)
+    stages = {}
+    hook = G.adain1.register_forward_hook(lambda m, i, o: stages.__setitem__("x1", o.detach().clone()))
+    orig_gef, calls, inject = GG.get_edge_features, [0], [None]
+
+    def patched(x_, k_, num=-1, idx=None, return_idx=False):
+        calls[0] += 1
+        return orig_gef(x_, k_, num, inject[0] if (calls[0] % 2 == 0 and inject[0] is not None) else idx, return_idx)
+
+    def req(m, f):
+        for p in m.parameters():
+            p.requires_grad = f
+    GG.get_edge_features = patched
+    orig_rand = torch.rand
+    torch.set_default_dtype(dtype)                              # gradient_penalty.py:32 builds its seed with torch.ones(...)
+    steps = []
+    try:
+        for k in range(3):
+            real, z_d, z_g, alpha = (t.to(dtype) for t in _g19_inputs(tag, B, N, k))
+            rec = {}
+            # D step (model.py:240-260)
+            req(G, False); req(D, True); optD.zero_grad()
+            inject[0] = None if graphs is None else graphs[k][0]
+            fake = G(x, z_d).detach()
+            rec["idx2_d"] = orig_gef(stages["x1"], 10, return_idx=True)[1] if graphs is None else graphs[k][0]
+            real_t = real.transpose(2, 1).contiguous()
+            lossD, _ = lu.dis_loss(D(real_t), D(fake), gan=gan)
+            if use_gp:
+                torch.rand = lambda *a, **kw: alpha.clone().requires_grad_(kw.get("requires_grad", False))
+                try:
+                    gpv = GradientPenalty(10.0, gamma=1)(D, real_t, fake)
+                finally:
+                    torch.rand = orig_rand
+                rec["gp"] = gpv.detach()
+                lossD = lossD + gpv
+            lossD.backward()
+            rec["dgrad"] = {n: p.grad.detach().clone() for n, p in D.named_parameters()}
+            optD.step()
+            # G step (model.py:264-279)
+            req(G, True); req(D, False); optG.zero_grad()
+            inject[0] = None if graphs is None else graphs[k][1]
+            g_fake = G(x, z_g)
+            rec["idx2_g"] = orig_gef(stages["x1"], 10, return_idx=True)[1] if graphs is None else graphs[k][1]
+            g_real_logit = D(real_t)
+            lossG, _ = lu.gen_loss(g_real_logit, D(g_fake), gan=gan)
+            lossG.backward()
+            rec["ggrad"] = {n: p.grad.detach().clone() for n, p in G.named_parameters()}
+            optG.step()
+            rec.update(lossD=lossD.detach(), lossG=lossG.detach(), alpha=alpha, fake_g=g_fake.detach())
+            steps.append(rec)
+            print("g19 %s %s: step %d lossD %.6f lossG %.6f" % (tag, str(dtype)[6:], k, float(lossD.detach()), float(lossG.detach())), flush=True)
+    finally:
+        GG.get_edge_features = orig_gef
+        torch.rand = orig_rand
+        torch.set_default_dtype(torch.float32)
+        hook.remove()
+    final = {}
+    for kind, net, opt in (("d", D, optD), ("g", G, optG)):
+        final[kind] = dict(param={n: p.detach() for n, p in net.named_parameters()},
+                           upd={n: p.detach() - init[kind][n] for n, p in net.named_parameters()},
+                           m={n: opt.state[p]["exp_avg"] for n, p in net.named_parameters()},
+                           v={n: opt.state[p]["exp_avg_sq"] for n, p in net.named_parameters()},
+                           buf={n: b.detach().clone() for n, b in net.named_buffers()})
+        assert all(int(opt.state[p]["step"]) == 3 for p in net.parameters())
+    return steps, final
+
+
+def g19():
+    """Round-4 review item 2(b): state carry across steps against the REFERENCE.  Three consecutive D-step + G-step iterations of the
+    imported reference (model.py:239-279 with torch.optim.Adam(lr=1e-4, betas=(0.5, 0.99)), model.py:94-97) at C1 (B=4, N=512, LS)
+    and at C2 (B=32, N=2048, WGAN-GP), from fixture weights, fresh inputs every step.  Stored per step: both EdgeConv2 graphs (the
+    GPU test injects them), losses, every D / G gradient (summaries); after step 3: parameters, the UPDATE param - init (what Adam
+    did -- the parameters themselves move by <= 3e-4 and pin nothing), Adam's exp_avg / exp_avg_sq, every BatchNorm buffer incl.
+    num_batches_tracked (G's 8 layers are advanced by both G forwards of a step, D's 4 by all four / five D forwards).
+
+    A multi-step trajectory is NOT reproducible to rounding by anybody: Adam's first updates are +-lr whatever the gradient's size, so
+    every element whose gradient is rounding noise moves with a sign that depends on the summation order, and D's kinks amplify the
+    difference from step to step.  The bounds of the tests are therefore DERIVED, as for G18: the same three steps are run once more in
+    float64 on the float32 run's graphs, and `noise|...` holds how far the reference's own float32 trajectory is from it (per step:
+    losses, cloud, every gradient tensor, each gradient's rms element difference; at the end: moments, buffers)."""
+    for tag, gan, use_gp, B, N, salt in (("c1_ls", "ls", False, 4, 512, 19), ("c2_wgangp", "wgan", True, 32, 2048, 20)):
+        d = {}
+        steps, final = _ref_three_steps(tag, gan, use_gp, B, N, salt, torch.float32)
+        graphs = [(r["idx2_d"], r["idx2_g"]) for r in steps]
+        s64, f64 = _ref_three_steps(tag, gan, use_gp, B, N, salt, torch.float64, graphs=graphs)
+        for k, (r, r64) in enumerate(zip(steps, s64)):
+            pre = "s%d|" % k
+            d[pre + "idx2_d"] = r["idx2_d"].view(B, N, 10).numpy().astype(np.int16)
+            d[pre + "idx2_g"] = r["idx2_g"].view(B, N, 10).numpy().astype(np.int16)
+            d[pre + "lossD"] = r["lossD"].numpy(); d[pre + "lossG"] = r["lossG"].numpy(); d[pre + "alpha"] = r["alpha"].numpy()
+            if use_gp:
+                d[pre + "gp"] = r["gp"].numpy()
+            put(d, pre + "fake_g", r["fake_g"], nsamp=4096)
+            for kind in ("dgrad", "ggrad"):
+                for n, g in r[kind].items():
+                    put(d, pre + kind + "|" + n, g)
+                    d["noise|" + pre + kind + "|" + n] = np.float64(_rel(g, r64[kind][n]))
+                    d["noise_rms|" + pre + kind + "|" + n] = np.float64((g.double() - r64[kind][n]).pow(2).mean().sqrt())
+            d["noise|" + pre + "lossD"] = np.float64(abs(float(r["lossD"]) - float(r64["lossD"])) / abs(float(r64["lossD"])))
+            d["noise|" + pre + "lossG"] = np.float64(abs(float(r["lossG"]) - float(r64["lossG"])) / abs(float(r64["lossG"])))
+            d["noise|" + pre + "fake_g"] = np.float64(_rel(r["fake_g"], r64["fake_g"]))
+            print("g19 %s step %d: float32 vs float64: lossD %.2e lossG %.2e cloud %.2e worst D grad %.2e worst G grad %.2e" % (
+                tag, k, d["noise|" + pre + "lossD"], d["noise|" + pre + "lossG"], d["noise|" + pre + "fake_g"],
+                max(_rel(g, r64["dgrad"][n]) for n, g in r["dgrad"].items() if not n.endswith(ZERO_GRAD_BIASES)),
+                max(_rel(g, r64["ggrad"][n]) for n, g in r["ggrad"].items() if not n.endswith(ZERO_GRAD_BIASES))), flush=True)
+        for kind in ("d", "g"):
+            for what in ("param", "upd", "m", "v"):
+                for n, t in final[kind][what].items():
+                    put(d, "%s%s|%s" % (kind, what, n), t)
+                    if what != "param":
+                        d["noise|%s%s|%s" % (kind, what, n)] = np.float64(_rel(t, f64[kind][what][n]))
+            for n, b in final[kind]["buf"].items():
+                d["%sbuf|%s" % (kind, n)] = b.numpy().copy()
+                d["%sbuf64|%s" % (kind, n)] = f64[kind]["buf"][n].numpy().copy()
+        save("g19_three_steps_%s.npz" % tag, d)
+
+
+# ---------------------------------------------------------------- G20: ONE step from a mid-training state (tight state-carry pin)
+def g20():
+    """The tight half of round-4 review item 2(b).  G19's free-running trajectory is chaos-limited (the reference's own float32 and
+    float64 runs are tens of per cent apart in the gradients after three steps), so it cannot pin "Adam at step >= 2" or "the n-th
+    running-statistics update" to better than that.  Here the state that such a step STARTS from is a fixture both sides can build
+    (spgan.fixture_rng.mid_training_state: Adam exp_avg / exp_avg_sq of the gradients' magnitude at step 7, non-trivial BatchNorm
+    running statistics with 21 / 14 tracked batches), loaded into the imported reference's torch.optim.Adam and modules, and ONE
+    iteration of model.py:239-279 is run from it: C1 (B=4, N=512, LS) and C2 (B=32, N=2048, WGAN-GP).  Stored: both EdgeConv2 graphs,
+    losses, gradients, and after the step the parameters, Adam's moments (step 8: bias corrections 1-0.5^8, 1-0.99^8) and every
+    BatchNorm buffer incl. num_batches_tracked -- all at one-step noise."""
+    for tag, gan, use_gp, B, N, salt in (("c1_ls", "ls", False, 4, 512, 21), ("c2_wgangp", "wgan", True, 32, 2048, 22)):
+        class O(Opts):
+            np = N
+        d = {}
+        G = load_into(Generator(O), fr.init_params(orc.generator_shapes(), salt=salt)).train()
+        D = load_into(Discriminator(O, num_point=N), fr.init_params(orc.discriminator_shapes(), salt=salt)).train()
+        optG = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.99))
+        optD = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.99))
+        for net, opt, shapes, batches in ((D, optD, orc.discriminator_shapes(), 21), (G, optG, orc.generator_shapes(), 14)):
+            st = fr.mid_training_state(shapes, [n for n, _ in net.named_buffers()], salt=salt, batches=batches)
+            for n, p in net.named_parameters():
+                opt.state[p] = {"step": torch.tensor(float(st["step"])), "exp_avg": st["m"][n].clone(), "exp_avg_sq": st["v"][n].clone()}
+            net.load_state_dict({**net.state_dict(), **st["buffers"]})
+        x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+        real, z_d, z_g = fr.synthetic_real(B, N, seed=2001), fr.latent(B, N, seed=2002), fr.latent(B, N, seed=2003)
+        alpha = fr.uniform("g20.%s.alpha" % tag, (B, 1, 1), 0.0, 1.0)
+        stages = {}
+        hook = G.adain1.register_forward_hook(lambda m, i, o: stages.__setitem__("x1", o.detach().clone()))
+
+        def req(m, f):
+            for p in m.parameters():
+                p.requires_grad = f
+        req(G, False); req(D, True); optD.zero_grad()
+        fake = G(x, z_d).detach()
+        d["idx2_d"] = get_edge_features(stages["x1"], 10, return_idx=True)[1].view(B, N, 10).numpy().astype(np.int16)
+        real_t = real.transpose(2, 1).contiguous()
+        lossD, _ = LU.dis_loss(D(real_t), D(fake), gan=gan)
+        if use_gp:
+            orig = torch.rand
+            torch.rand = lambda *a, **kw: alpha.clone().requires_grad_(kw.get("requires_grad", False))
+            try:
+                lossD = lossD + GradientPenalty(10.0, gamma=1)(D, real_t, fake)
+            finally:
+                torch.rand = orig
+        lossD.backward()
+        for n, p in D.named_parameters():
+            put(d, "dgrad|" + n, p.grad)
+        optD.step()
+        req(G, True); req(D, False); optG.zero_grad()
+        g_fake = G(x, z_g)
+        d["idx2_g"] = get_edge_features(stages["x1"], 10, return_idx=True)[1].view(B, N, 10).numpy().astype(np.int16)
+        hook.remove()
+        g_real_logit = D(real_t)
+        lossG, _ = LU.gen_loss(g_real_logit, D(g_fake), gan=gan)
+        lossG.backward()
+        for n, p in G.named_parameters():
+            put(d, "ggrad|" + n, p.grad)
+        optG.step()
+        d["lossD"] = lossD.detach().numpy(); d["lossG"] = lossG.detach().numpy(); d["alpha"] = alpha.numpy()
+        put(d, "fake_d", fake, nsamp=4096); put(d, "fake_g", g_fake, nsamp=4096)
+        for kind, net, opt in (("d", D, optD), ("g", G, optG)):
+            for n, p in net.named_parameters():
+                put(d, kind + "param|" + n, p)
+                st = opt.state[p]
+                assert int(st["step"]) == 8
+                put(d, kind + "m|" + n, st["exp_avg"]); put(d, kind + "v|" + n, st["exp_avg_sq"])
+            for n, b in net.named_buffers():
+                d[kind + "buf|" + n] = b.numpy().copy()
+        print("g20 %s: lossD %.6f lossG %.6f" % (tag, float(lossD.detach()), float(lossG.detach())), flush=True)
+        save("g20_mid_state_step_%s.npz" % tag, d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4_g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     for name in which:
         globals()[name]()

@@ -78,8 +78,6 @@ def _single_process_reference(world, gan, use_gp):
     """The same step on the concatenated batch in ONE process: W replicas from rank 0's weights, shard r on replica r (per-replica
     BatchNorm statistics), gradient buffers summed by hand, every replica's Adam applies sum/W."""
     import spgan
-    from helpers import install_kernel_models
-    install_kernel_models()
     nthreads = torch.get_num_threads()
     torch.set_num_threads(2)                                    # same CPU reduction orders as the workers
     reps = []
@@ -125,7 +123,9 @@ def test_n_rank_step_equals_single_process_on_concatenated_batch(tmp_path, world
         assert torch.equal(ranks[0]["flatD"], r["flatD"]) and torch.equal(ranks[0]["flatG"], r["flatG"]), "ranks diverged after one step"
         assert torch.equal(ranks[0]["gD"], r["gD"]) and torch.equal(ranks[0]["gG"], r["gG"])
     _setup_paths()
-    ref = _single_process_reference(world, gan, use_gp)
+    from helpers import kernel_models
+    with kernel_models():                  # the CPU doubles for this block only: the patch must not outlive the test (order independence)
+        ref = _single_process_reference(world, gan, use_gp)
     a = ranks[0]
     # the all-reduced gradient is the mean of the per-shard gradients (sum order of gloo's reduction may differ for W > 2)
     assert _rel(a["gD"], ref["gD"]) <= 1e-6, _rel(a["gD"], ref["gD"])

@@ -383,3 +383,55 @@ def test_point_major_route_equals_the_channel_major_one():
             # G's gradients are taken through the UPDATED discriminator (model.py:259-277), so they carry D's Adam amplification: 1e-3
             tol = 1e-5 if which == "d_grads" else 1e-3
             assert (ga - gb).abs().max().item() <= tol * gb.abs().max().item() + 1e-12, (which, k)
+
+
+def test_gradients_dirtied_between_replays_need_invalidate_grads(sp):
+    """Advisor (round 4): with zero_grad folded into the Adam kernel a captured step records no gradient fill, so anything written into
+    the flat `.grad` buffers between two replays (a diagnostic backward on D, a caller's regulariser) is added to the next step.  The
+    contract: p.grad reads as zero after step(); whoever writes there calls `optimizer.invalidate_grads()` before the next step -- then
+    the trajectory is the undisturbed one, bit for bit."""
+    steps = 6
+    Ge, De, tre, le = _run(sp, True, steps)
+    B, N = 4, 256
+    o = Opts()
+    G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(), salt=8))
+    D = _load(sp.Discriminator(o), fr.init_params(orc.discriminator_shapes(), salt=8))
+    tr = sp.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, graph=True, graph_warmup=2)
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    real = [fr.synthetic_real(B, N, seed=90 + i).cuda() for i in range(2)]
+    zs = [fr.latent(B, N, seed=70 + i).cuda() for i in range(3)]
+    alpha = fr.uniform("graph.alpha", (B, 1, 1), 0.0, 1.0).cuda()
+    losses = []
+    for i in range(steps):
+        if i == 4:                                            # between two replays
+            assert not tr.optD.fp.grad.any().item() and not tr.optG.fp.grad.any().item(), "p.grad must read as zero after step()"
+            tr.optD.fp.grad.add_(1.0); tr.optG.fp.grad.add_(-1.0)
+            tr.optD.invalidate_grads(); tr.optG.invalidate_grads()
+        info = tr.step(x, real[i % 2], zs[i % 3], zs[(i + 1) % 3], alpha=alpha)
+        losses.append((info["loss_d"].item(), info["loss_g"].item()))
+    assert tr._graph is not None and losses == le
+    for (n, a), (_, b) in zip(list(Ge.state_dict().items()) + list(De.state_dict().items()), list(G.state_dict().items()) + list(D.state_dict().items())):
+        assert torch.equal(a, b), n
+
+
+def test_point_major_route_is_only_taken_for_the_common_mixing_rule(sp):
+    """Advisor (round 4): TrainStep's point-major D step builds x_hat itself as real + alpha*(fake - real) (gradient_penalty.py:24-25); a
+    GradientPenalty with mix="loss_utils" (alpha*real + (1-alpha)*fake, loss_utils.py:1108) must keep the route that calls its
+    interpolate(): the same TrainStep with either flag setting then penalises the same points."""
+    B, N = 4, 256
+    res = []
+    for pm in (True, False):
+        o = Opts()
+        G = _load(sp.Generator(o), fr.init_params(orc.generator_shapes(), salt=8))
+        D = _load(sp.Discriminator(o), fr.init_params(orc.discriminator_shapes(), salt=8))
+        tr = sp.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0)
+        tr.gp = sp.GradientPenalty(10.0, gamma=1, mix="loss_utils")
+        tr.point_major = pm
+        x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+        alpha = fr.uniform("graph.alpha", (B, 1, 1), 0.0, 1.0).cuda()
+        info = tr.step(x, fr.synthetic_real(B, N, seed=90).cuda(), fr.latent(B, N, seed=70).cuda(), fr.latent(B, N, seed=71).cuda(), alpha=alpha,
+                       keep_grads=True)
+        res.append(info)
+    assert res[0]["loss_d"].item() == res[1]["loss_d"].item()
+    for n in res[0]["d_grads"]:
+        assert torch.equal(res[0]["d_grads"][n], res[1]["d_grads"][n]), n

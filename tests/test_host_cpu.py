@@ -42,7 +42,7 @@ def spgan_cpu(monkeypatch):
 
 def test_every_op_has_a_model():
     import spgan.ops as ops
-    settings = {"set_mfma_operands", "get_mfma_operands", "bump_weights_epoch", "weights_epoch_of"}   # switches / host bookkeeping, not arithmetic
+    settings = {"set_mfma_operands", "get_mfma_operands", "bump_weights_epoch", "weights_epoch_of", "index_check_flag", "index_check_raise"}   # switches / host bookkeeping, not arithmetic
     public = [n for n, f in inspect.getmembers(ops, inspect.isfunction)
               if not n.startswith("_") and f.__module__ == ops.__name__ and n not in settings]
     missing = [n for n in public if not hasattr(km, n)]

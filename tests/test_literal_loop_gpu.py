@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import StepNoise, check, check_step_gradients_bounded, check_whole_gradient_bounded, golden
+from helpers import StepNoise, check, check_adam_updates, check_step_gradients_bounded, check_whole_gradient_bounded, golden, measured_grad_errors
 from oracle import spgan_oracle as orc
 from spgan import fixture_rng as fr
 
@@ -56,7 +56,7 @@ def _setup(sp, salt, N, capturable=False):
     return G, D, optimizerG, optimizerD, LoopState
 
 
-def _compare_with_golden(d, G, D, lossD, lossG, keep, loose_fake=6e-5, dgrad_rtol=4e-3, lossg_atol=0.0, ggrad_rtol=2.5e-2, buf_tol=(2e-3, 2e-4), own_graph_rows=None):
+def _compare_with_golden(d, G, D, lossD, lossG, keep, salt, loose_fake=6e-5, dgrad_rtol=4e-3, lossg_atol=0.0, ggrad_rtol=2.5e-2, buf_tol=(2e-3, 2e-4), own_graph_rows=None):
     np.testing.assert_allclose(lossD.item(), float(d["lossD"]), rtol=3e-3)
     np.testing.assert_allclose(lossG.item(), float(d["lossG"]), rtol=5e-3, atol=max(lossg_atol, 1e-6))
     check(d, "fake_d", keep["fake_d"], rtol=loose_fake)
@@ -71,12 +71,11 @@ def _compare_with_golden(d, G, D, lossD, lossG, keep, loose_fake=6e-5, dgrad_rto
             check(d, "dgrad|" + n, g, rtol=dgrad_rtol, atol=_atol(n))
         for n, g in keep["g_grads"].items():
             check(d, "ggrad|" + n, g, rtol=ggrad_rtol, atol=_atol(n))
-    for n, p in D.named_parameters():
-        if not n.endswith(ZERO_GRAD_BIASES):
-            check(d, "dparam|" + n, p, rtol=1e-3, atol=2.5e-4)
-    for n, p in G.named_parameters():
-        if not n.endswith(ZERO_GRAD_BIASES):
-            check(d, "gparam|" + n, p, rtol=1e-3, atol=2.5e-4)
+    # post-Adam parameters (here: torch.optim.Adam over OUR gradients) as UPDATES p - p0 on above-noise elements (helpers.check_adam_updates)
+    for kind, net, shapes in (("d", D, orc.discriminator_shapes()), ("g", G, orc.generator_shapes())):
+        check_adam_updates(d, kind, net.named_parameters(), fr.init_params(shapes, salt=salt), [kind + "grad|"],
+                           measured_grad_errors(d, kind + "grad|", keep[kind + "_grads"], skip=ZERO_GRAD_BIASES), skip=ZERO_GRAD_BIASES,
+                           min_selected=0.2 if (own_graph_rows is None or kind == "d") else 0.0)      # own graphs: see test_train_step_benchsize_golden[False]
     dbuf = dict(D.named_buffers())
     for n, b in [(k, v) for k, v in D.state_dict().items() if k in dbuf]:
         np.testing.assert_allclose(b.cpu().numpy(), d["dbuf|" + n], rtol=buf_tol[0], atol=buf_tol[1], err_msg=n)
@@ -109,7 +108,7 @@ def test_literal_reference_loop_matches_reference_step(sp, tag, gan, use_gp, B, 
     # "caller": x_hat = real + alpha*(fake - real) by torch ops instead of the fused lerp kernel -- a last-bit difference that puts one
     # LeakyReLU / arg-max element of this small case on the other side of its kink: the D gradients move by exactly the 2.785e-2 the
     # CPU kernel-model run of the same step shows (tests/test_train_cpu.py tolerates 3e-2 for the same reason)
-    _compare_with_golden(d, G, D, lossD, lossG, s.keep, dgrad_rtol=3e-2 if gp_impl == "caller" else 4e-3,
+    _compare_with_golden(d, G, D, lossD, lossG, s.keep, 8, dgrad_rtol=3e-2 if gp_impl == "caller" else 4e-3,
                          ggrad_rtol=1.5e-1 if gp_impl == "caller" else 2.5e-2)      # the CPU twin's tolerances for the same kink
 
 
@@ -131,7 +130,7 @@ def test_literal_reference_loop_at_the_benchmarked_size(sp):
     own = sp.ops.idx_to_local64(G.EdgeConv2.last_idx, B, N).view(B * N, 10).cpu()
     n_diff = int((own != torch.from_numpy(d["idx2_g"].astype(np.int64)).view(B * N, 10)).any(dim=1).sum().item())
     assert n_diff <= 0.01 * B * N
-    _compare_with_golden(d, G, D, lossD, lossG, s.keep, loose_fake=3e-2, lossg_atol=2e-2 * float(np.abs(d["d_gfake"]).max()),
+    _compare_with_golden(d, G, D, lossD, lossG, s.keep, 18, loose_fake=3e-2, lossg_atol=2e-2 * float(np.abs(d["d_gfake"]).max()),
                          buf_tol=(2e-2, 2e-3), own_graph_rows=max(n_diff, 1))
 
 
@@ -208,3 +207,23 @@ def test_captured_body_notices_a_changed_prior(sp):
             xa = x0 if i % 2 == 0 else x1
             assert torch.equal(body(xa, z), want0 if i % 2 == 0 else want1)
     assert body.eager
+
+
+def test_captured_body_with_an_identical_prior_recreated_on_every_call(sp):
+    """Advisor (round 4): a caller that builds the same sphere prior anew on every iteration (x = sphere.cuda() inside the loop) passes a
+    new tensor OBJECT with equal CONTENT each time.  Before a graph exists that used to count as a change and restart the warm-up on
+    every call -- the body ran eagerly forever without a warning.  Now equal content is recognised in every state: the capture happens
+    after the warm-up, later calls replay it."""
+    B, N = 4, 256
+    G = _load(sp.Generator(_opts(N)), fr.init_params(orc.generator_shapes(), salt=8)).eval()
+
+    def fn(x_, z_):
+        with torch.no_grad():
+            return G(x_, z_)
+    body = sp.CapturedBody(fn, modules=(G,), warmup=2)
+    host = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    z = fr.latent(B, N, seed=3).cuda()
+    want = fn(host.cuda(), z).clone()
+    for i in range(6):
+        assert torch.equal(body(host.cuda(), z), want)          # a fresh device tensor per call
+    assert body._graph is not None and not body.eager and body._recaptures == 0

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check, golden
+from helpers import check, check_adam_updates, golden, load_mid_state, measured_grad_errors
 from oracle import spgan_oracle as orc
 from spgan import fixture_rng as fr
 from test_host_cpu import Opts, ZERO_GRAD_BIASES, spgan_cpu, _load   # noqa: F401  (fixture import)
@@ -68,12 +68,10 @@ def test_train_step_golden(spgan_cpu, tag, gan, use_gp, B, N):
     for n, g in info["g_grads"].items():
         # after D's Adam step (+-lr per element) and through D's kinks: loose by nature
         check(d, "ggrad|" + n, g, rtol=1.5e-1, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
-    for n, p in D.named_parameters():
-        if not n.endswith(ZERO_GRAD_BIASES):
-            check(d, "dparam|" + n, p, rtol=1e-3, atol=2.5e-4)      # one Adam step moves an element by <= lr; sign noise => 2*lr
-    for n, p in G.named_parameters():
-        if not n.endswith(ZERO_GRAD_BIASES):
-            check(d, "gparam|" + n, p, rtol=1e-3, atol=2.5e-4)      # one Adam step moves an element by <= lr; sign noise => 2*lr
+    # post-Adam parameters as UPDATES p - p0 on above-noise elements (helpers.check_adam_updates)
+    for kind, net, shapes in (("d", D, orc.discriminator_shapes()), ("g", G, orc.generator_shapes())):
+        check_adam_updates(d, kind, net.named_parameters(), fr.init_params(shapes, salt=8), [kind + "grad|"],
+                           measured_grad_errors(d, kind + "grad|", info[kind + "_grads"], skip=ZERO_GRAD_BIASES), skip=ZERO_GRAD_BIASES, what=tag)
     for n, b in [(k, v) for k, v in G.state_dict().items() if k in dict(G.named_buffers())]:
         np.testing.assert_allclose(b.numpy(), d["gbuf|" + n], rtol=2e-3, atol=2e-4)
     for n, b in [(k, v) for k, v in D.state_dict().items() if k in dict(D.named_buffers())]:
@@ -214,8 +212,45 @@ def test_literal_reference_loop_body_golden(spgan_cpu, tag, gan, use_gp, B, N):
     check(d, "fake_d", s.keep["fake_d"], rtol=2e-4)
     for n, g in s.keep["d_grads"].items():
         check(d, "dgrad|" + n, g, rtol=3e-2, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
-    for n, p in list(D.named_parameters()) + list(G.named_parameters()):
-        if not n.endswith(ZERO_GRAD_BIASES):
-            check(d, ("dparam|" if p in set(D.parameters()) else "gparam|") + n, p, rtol=1e-3, atol=2.5e-4)
+    for kind, net, shapes in (("d", D, orc.discriminator_shapes()), ("g", G, orc.generator_shapes())):
+        check_adam_updates(d, kind, net.named_parameters(), fr.init_params(shapes, salt=8), [kind + "grad|"],
+                           measured_grad_errors(d, kind + "grad|", s.keep[kind + "_grads"], skip=ZERO_GRAD_BIASES), skip=ZERO_GRAD_BIASES)
     for n, b in [(k, v) for k, v in D.state_dict().items() if k in dict(D.named_buffers())]:
         np.testing.assert_allclose(b.numpy(), d["dbuf|" + n], rtol=2e-3, atol=2e-4)
+
+
+def test_step_from_mid_training_state_g20(spgan_cpu):
+    """CPU twin of tests/test_multistep_golden_gpu.py::test_one_step_from_a_mid_training_state (C1): the host side of state carry --
+    BatchNorm buffers and call counts loaded through load_state_dict, spgan.optim.Adam.load_state_dict, one TrainStep from there --
+    over the kernel models, against the reference started from the same fixture state (golden G20)."""
+    import spgan
+    tag, B, N, salt = "c1_ls", 4, 512, 21
+    d = golden("g20_mid_state_step_%s.npz" % tag)
+
+    class O(Opts):
+        np = N
+    init_g, init_d = fr.init_params(orc.generator_shapes(), salt=salt), fr.init_params(orc.discriminator_shapes(), salt=salt)
+    G = _load(spgan.Generator(O), init_g)
+    D = _load(spgan.Discriminator(O, num_point=N), init_d)
+    tr = spgan.TrainStep(G, D, gan="ls", use_gp=False)
+    load_mid_state(D, tr.optD, orc.discriminator_shapes(), salt, 21)
+    load_mid_state(G, tr.optG, orc.generator_shapes(), salt, 14)
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    G.inject_graph2([torch.from_numpy(d[w].astype(np.int64)).view(B, N * 10) for w in ("idx2_d", "idx2_g")])
+    info = tr.step(x, fr.synthetic_real(B, N, seed=2001), fr.latent(B, N, seed=2002), fr.latent(B, N, seed=2003), keep_grads=True)
+    np.testing.assert_allclose(info["loss_d"].item(), float(d["lossD"]), rtol=1e-4)
+    np.testing.assert_allclose(info["loss_g"].item(), float(d["lossG"]), rtol=2e-3)
+    check(d, "fake_g", info["fake_g"], rtol=2e-4)
+    for n, g in info["d_grads"].items():
+        check(d, "dgrad|" + n, g, rtol=3e-2, atol=2e-3 if n.endswith(ZERO_GRAD_BIASES) else 1e-7)
+    assert tr.optD.t == 8 and tr.optG.t == 8
+    for kind, net, init in (("d", D, init_d), ("g", G, init_g)):
+        check_adam_updates(d, kind, net.named_parameters(), init, [], None, skip=ZERO_GRAD_BIASES, select_by_gradient=False, atol=2e-6,
+                           min_selected=0.5, what="kernel models, step 8")
+    for kind, net, calls in (("d", D, 25), ("g", G, 16)):
+        names = dict(net.named_buffers())
+        for n, b in [(k_, v_) for k_, v_ in net.state_dict().items() if k_ in names]:
+            if n.endswith("num_batches_tracked"):
+                assert int(b.item()) == int(d["%sbuf|%s" % (kind, n)]) == calls, n
+            else:
+                np.testing.assert_allclose(b.numpy(), d["%sbuf|%s" % (kind, n)], rtol=2e-3, atol=2e-4, err_msg=n)
