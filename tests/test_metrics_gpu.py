@@ -143,3 +143,24 @@ def test_emd_metric_drivers():
     allm = M.compute_all_metrics(smp_g, ref_g)
     for key in ("lgan_mmd-CD", "lgan_cov-CD", "lgan_mmd_smp-CD", "lgan_mmd-EMD", "lgan_cov-EMD", "lgan_mmd_smp-EMD", "1-NN-CD-acc", "1-NN-EMD-acc"):
         assert key in allm and np.isfinite(allm[key].item()), key
+
+
+def test_emd_auction_against_the_cuda_kernel_emulation():
+    """Golden G21 (tests/golden/make_emd_trace.py: emd_cuda.cu:93-236 emulated sequentially, its GetMax race resolved by a fixed thread
+    order): the HIP auction equals it row for row in rounds 1-3 under every variant, through round 10 under the lowest-bidder order,
+    and differs later by less than the emulation's own two thread orders differ from each other; matching costs within 0.5 %
+    (tests/test_oracle_golden.py::emd_trace_statement)."""
+    from test_oracle_golden import emd_trace_statement
+    from spgan import metrics as M
+
+    def hip(a, b, eps, T):
+        dist, asg = M.emdModule()(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), eps, T)
+        return dist.cpu().numpy(), asg.cpu().numpy()
+    emd_trace_statement(hip, "HIP auction")
+    # and the kernel equals the numpy restatement on the trace inputs too (bit for bit, as on the small sets above)
+    import make_emd_trace as mt
+    a, b = mt.trace_inputs()
+    for T in (3, 50):
+        dist, asg = hip(a, b, 0.005, T)
+        od, oa = orc.emd_auction(a, b, 0.005, T)
+        assert np.array_equal(asg, oa) and np.array_equal(dist, od)

@@ -1,5 +1,8 @@
 """CPU: the oracle (oracle/spgan_oracle.py) against the vectors captured from the real
 reference (tests/golden/make_golden.py).  This is what pins the oracle."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -541,3 +544,55 @@ def test_step_noise_tables_g18():
             assert np.isfinite([b0, b20, b100]).all() and b0 > 0 and b20 >= b0 * 0.999, (kind, n, b0, b20, b100)
     w = [sn.whole_g_bound(n, 1.0) for n in (0, 1, 5, 20, 100)]
     assert w[0] < 0.05 and w[0] < w[2] < w[4] < 0.5, w          # float32 noise 1.4e-2; 20 flipped ties move the whole G gradient by 0.18
+
+
+# ---------------------------------------------------------------- G21: the auction against a sequential emulation of emd_cuda.cu
+def emd_trace_statement(assign_fn, what):
+    """Shared by the CPU (oracle) and the GPU (HIP kernel) test.  assign_fn(a, b, eps, T) -> (dist [B,n], assignment [B,n]) numpy.
+    Fixture: tests/golden/make_emd_trace.py -- the reference's CUDA kernels (metrics/emd/emd_cuda.cu:93-236) emulated sequentially in
+    the file's own arithmetic, its one data race (GetMax: the last writer among bidders within 1e-6 of the maximum keeps the object)
+    resolved by a fixed thread order, ascending and descending, with and without nvcc's fma contraction.  The statement, round by round:
+      * rounds 1-3: the assignment equals the emulation's in EVERY variant, row for row;
+      * rounds <= 10: it equals the variant in which the lowest near-tied bidder wins (= the build's rule: exact maximum, lowest index);
+      * later: the rows that differ from the nearest variant are fewer than 1.5 x the rows the emulation's own two thread orders differ
+        in (0.5 % at 20 rounds, 8 % at 50, 41 % at 100, 71 % at 1000: the reference's assignment IS its race), and the matching cost lies
+        within 0.5 % of the variants' own range at every round count; the exact optimum bounds it as in test_emd_auction_against_optimal_assignment."""
+    sys_path_golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if sys_path_golden not in sys.path:
+        sys.path.insert(0, sys_path_golden)
+    import make_emd_trace as mt
+    d = golden("g21_emd_trace.npz")
+    a, b = mt.trace_inputs()
+    eps = float(d["eps"])
+    report = []
+    for T in [int(t) for t in d["iters"]]:
+        dist, asg = assign_fn(a, b, eps, T)
+        cost = np.sqrt(np.asarray(dist, dtype=np.float64)).sum(1)
+        diff = {v: float((np.asarray(asg) != d["assign|%s|%s|%d" % (v + (T,))]).mean()) for v in mt.VARIANTS}
+        own = float((d["assign|ascending|fma|%d" % T] != d["assign|descending|fma|%d" % T]).mean())
+        report.append((T, min(diff.values()), own))
+        if T <= 3:
+            assert max(diff.values()) == 0.0, (what, T, diff)
+        if T <= 10:
+            assert diff[("descending", "fma")] == 0.0 and diff[("descending", "none")] == 0.0, (what, T, diff)
+        assert min(diff.values()) <= max(1.5 * own, 0.003), (what, T, diff, own)
+        refs = np.stack([d["cost|%s|%s|%d" % (v + (T,))] for v in mt.VARIANTS])            # the variants themselves are up to 0.8 % apart (300 rounds)
+        assert np.all(cost >= refs.min(0) * (1 - 5e-3)) and np.all(cost <= refs.max(0) * (1 + 5e-3)), (what, T, cost, refs)
+    return report
+
+
+def test_emd_trace_fixture_is_what_the_script_produces():
+    import os as _os, sys as _sys
+    _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden"))
+    import make_emd_trace as mt
+    d = golden("g21_emd_trace.npz")
+    a, b = mt.trace_inputs()
+    for order, contract, T in (("ascending", "fma", 5), ("descending", "none", 20)):
+        for i in range(a.shape[0]):
+            _, asg, _ = mt.emulate_emd_cuda(a[i], b[i], float(d["eps"]), T, order, contract)
+            assert np.array_equal(asg.astype(np.int16), d["assign|%s|%s|%d" % (order, contract, T)][i])
+
+
+def test_emd_trace_oracle_against_cuda_emulation():
+    rep = emd_trace_statement(lambda a, b, eps, T: orc.emd_auction(a, b, eps, T), "oracle")
+    assert rep[0][1] == 0.0
