@@ -342,6 +342,94 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+class _Watchdog:
+    """First contact with a multi-GPU node must yield a line, not a hang (round-4 review item 7).  A phase that can block forever (the first
+    collective, the first steps of a schedule RCCL has never carried) is armed with a deadline; when it passes, rank 0 prints the line
+    `fallback()` returns (the last completed measurement plus a "dp_fallback" key naming the phase) and every rank leaves with os._exit --
+    the main thread may be parked inside a HIP / RCCL call that never returns."""
+
+    def __init__(self, rank):
+        self.rank, self.timer, self.fallback = rank, None, None
+
+    def arm(self, phase, seconds):
+        import threading
+        self.disarm()
+        self.phase = phase
+
+        def fire():
+            line = self.fallback(phase) if self.fallback is not None else None
+            if self.rank == 0:
+                if line is None:
+                    line = {"metric": "G+D train-step shapes/sec", "value": None, "unit": "shapes/s", "higher_is_better": True}
+                    line["dp_fallback"] = "no measurement: '%s' did not complete within %.0f s" % (phase, seconds)
+                print(json.dumps(line), flush=True)
+            os._exit(0 if line is not None and line.get("value") else 3)
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
+def _param_checksum(nets):
+    """Order-independent exact checksum of the parameters' BITS (int32 views summed in int64): equal on two ranks / two schedules iff --
+    up to a 2^-64 accident -- the parameters are bit-identical."""
+    tot = torch.zeros((), dtype=torch.int64, device=next(nets[0].parameters()).device)
+    for net in nets:
+        for p_ in net.parameters():
+            tot = tot + p_.detach().contiguous().view(torch.int32).to(torch.int64).sum()
+    return tot
+
+
+def first_contact(dev, rank, world, variant, wd, seconds):
+    """Before anything is timed on N > 1 ranks: (1) one all-reduce of ones under the watchdog -> the ranks RCCL really connects;
+    (2) ONE eager step under the strictly sequential schedule and ONE under the overlapped default (the generator's forward of the G step
+    issued under D's gradient all-reduce, train.py) from identical state on identical inputs: parameters must be BIT-EQUAL across the two
+    schedules and across all ranks (checksums all-gathered).  Returns the report that goes into the JSON line; "overlap_ok" False makes
+    main() run the sequential schedule (the SPGAN_DP_OVERLAP=0 behaviour) and say so under "dp_fallback"."""
+    import spgan
+    rep = {"overlap_ok": True}
+    wd.arm("first collective (all-reduce of one float per rank)", seconds)
+    ones = torch.ones(1, device=dev)
+    torch.distributed.all_reduce(ones)
+    rep["rccl_ranks_seen"] = int(round(ones.item()))
+    wd.arm("equivalence probe: one sequential and one overlapped eager step", seconds)
+    sums = []
+    try:
+        for overlap in (False, True):
+            G, D = build_models(dev, variant)
+            tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, distributed=True, graph=False)
+            tr.overlap_g_forward = overlap
+            x, real, zs, alpha = make_inputs(dev, rank, PER_GPU_BATCH)
+            tr.step(x, real, zs[0], zs[1], alpha=alpha)
+            if overlap and os.environ.get("SPGAN_BENCH_TEST_BREAK", "") == "overlap":      # test hook: a schedule that computes something else
+                with torch.no_grad():
+                    next(G.parameters()).add_(1e-3)
+            sums.append(_param_checksum((G, D)))
+            if rep.get("native_comm_world") is None and getattr(tr.dpD, "_comm", None) is not None:
+                from spgan import _lib
+                rep["native_comm_world"] = int(_lib.load().spgan_comm_world(tr.dpD._comm))
+            del tr, G, D
+        both = torch.stack(sums)
+        gathered = [torch.zeros_like(both) for _ in range(world)]
+        torch.distributed.all_gather(gathered, both)
+        allsums = torch.stack(gathered).cpu()                     # [world, 2]
+        rep["schedules_bit_equal"] = bool((allsums[:, 0] == allsums[:, 1]).all())
+        rep["ranks_bit_equal"] = bool((allsums == allsums[0:1]).all())
+        if not (rep["schedules_bit_equal"] and rep["ranks_bit_equal"]):
+            rep["overlap_ok"] = False
+            rep["dp_fallback"] = "sequential schedule: the overlapped step's parameters are not bit-equal to the sequential step's%s" % (
+                "" if rep["ranks_bit_equal"] else " / not equal on all ranks")
+    except Exception as e:                                   # noqa: BLE001
+        rep["overlap_ok"] = False
+        rep["dp_fallback"] = "sequential schedule: the equivalence probe raised %s: %s" % (type(e).__name__, str(e)[:200])
+    wd.disarm()
+    return rep
+
+
 def time_steps(tr, step_fn, steps, dist_on, dev):
     if dist_on:
         torch.distributed.barrier()
@@ -424,28 +512,77 @@ def main():
         raise SystemExit("process group has %d ranks, --gpus asked for %d" % (world_seen, args.gpus))
 
     spgan.ops.set_mfma_operands(args.mfma)
-    G, D = build_models(dev, variant)
     # The step is captured once into a hipGraph and replayed (TrainStep(graph=True)): issuing its launches from Python takes
     # as long as the GPU needs to run them.  Data-parallel runs capture three graphs (D step | Adam(D) + G step | Adam(G)) and issue
     # the two RCCL all-reduces eagerly between them; SPGAN_GRAPH=0 / --no-graph fall back to eager issue.
     use_graph = not args.no_graph and os.environ.get("SPGAN_GRAPH", "1") != "0" and not SELFTEST
     graph_warmup = 3
-    tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=dist_on, graph=use_graph,
-                         graph_warmup=graph_warmup, reference_schedule=args.reference_schedule)
     x, real, zs, alpha = make_inputs(dev, rank, PER_GPU_BATCH)
 
-    def one_step(i):
-        tr.step(x, real, zs[(2 * i) % 4], zs[(2 * i + 1) % 4], alpha=alpha)
+    def measure(overlap=None):
+        """Fresh models (same initialisation), prime + capture, W warm-up steps, K timed steps.  overlap: None = TrainStep's default."""
+        G_, D_ = build_models(dev, variant)
+        tr_ = spgan.TrainStep(G_, D_, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=dist_on, graph=use_graph,
+                              graph_warmup=graph_warmup, reference_schedule=args.reference_schedule)
+        if overlap is not None:
+            tr_.overlap_g_forward = bool(overlap)
+        step_ = lambda i: tr_.step(x, real, zs[(2 * i) % 4], zs[(2 * i + 1) % 4], alpha=alpha)
+        if use_graph:
+            for i in range(graph_warmup + 1):     # eager priming steps + the capture, before the W warm-up steps
+                step_(i)
+        for i in range(args.warmup):
+            step_(i)
+        if overlap and os.environ.get("SPGAN_BENCH_TEST_HANG", "") == "overlap":      # test hook: the overlapped schedule never returns
+            time.sleep(1e6)
+        dt_, t_issue_ = time_steps(tr_, step_, args.steps, dist_on, dev)
+        return G_, D_, tr_, dt_, t_issue_
 
-    if use_graph:
-        for i in range(graph_warmup + 1):     # eager priming steps + the capture, before the W warm-up steps
-            one_step(i)
-    for i in range(args.warmup):
-        one_step(i)
     peak = FP32_MATRIX_PEAK_TFLOPS if args.mfma == "f32" else FP16_MATRIX_PEAK_TFLOPS
     acct = MfmaAccounting(PER_GPU_BATCH * N_POINTS, peak, args.mfma) if (rank == 0 and not SELFTEST) else None
-    dt, t_issue = time_steps(tr, one_step, args.steps, dist_on, dev)
+    contact, dp_seq, wd = None, None, None
 
+    def basic_line(m, schedule, why):
+        """The measured line a watchdog prints when a LATER phase hangs on a multi-GPU node (the complete line is assembled at the end)."""
+        return {"metric": "G+D train-step shapes/sec @%d pts, bs=%d per GPU (WGAN-GP)" % (N_POINTS, PER_GPU_BATCH), "value": m["shapes_per_s"],
+                "unit": "shapes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
+                "config": {"workload": "BASELINE %s per-GPU shape, data parallel" % args.config, "global_batch": PER_GPU_BATCH * world,
+                           "n_points": N_POINTS, "parallelism": "dp%d" % world},
+                "world_size_observed": world_seen, "hipgraph_replay": bool(use_graph),
+                "first_contact": {k: v for k, v in (contact or {}).items() if k != "overlap_ok"}, "dp_schedule": schedule, "dp_fallback": why}
+
+    if dist_on and world > 1:
+        # First contact with a multi-GPU node (no such node exists in this build's loop): never hang, always leave a line.  Order = risk:
+        # the first collective, the strictly SEQUENTIAL schedule measured in full, the equivalence probe, and only then the OVERLAPPED
+        # default -- each under a deadline after which rank 0 prints what has been measured so far with a "dp_fallback" key.
+        seconds = float(os.environ.get("SPGAN_BENCH_WATCHDOG_S", "300"))
+        wd = _Watchdog(rank)
+        contact = first_contact(dev, rank, world, variant, wd, seconds)
+        wd.arm("sequential schedule: capture, warm-up and the timed steps", seconds)
+        G, D, tr, dt, t_issue = measure(overlap=False)
+        wd.disarm()
+        dp_seq = {"ms_per_step": round(dt / args.steps * 1e3, 3), "shapes_per_s": round(PER_GPU_BATCH * world * args.steps / dt, 2)}
+        if contact["overlap_ok"] and os.environ.get("SPGAN_DP_OVERLAP", "1") != "0":
+            wd.fallback = lambda phase: basic_line(dp_seq, "sequential", "sequential schedule measured in full; '%s' did not complete within %.0f s" % (phase, seconds))
+            wd.arm("overlapped schedule (generator forward under D's all-reduce): capture, warm-up and the timed steps", seconds)
+            G2_, D2_, tr2_, dt2_, ti2_ = measure(overlap=True)
+            wd.disarm()
+            wd.fallback = None
+            del G, D, tr
+            G, D, tr, dt, t_issue = G2_, D2_, tr2_, dt2_, ti2_
+            dp_schedule = "overlapped"
+        else:
+            dp_schedule = "sequential"
+            if "dp_fallback" not in contact and os.environ.get("SPGAN_DP_OVERLAP", "1") == "0":
+                contact["dp_fallback"] = "sequential schedule: SPGAN_DP_OVERLAP=0"
+    else:
+        G, D, tr, dt, t_issue = measure()
+
+    if wd is not None:
+        # the phases after the timed region (eager accounting steps with their own collectives) run under the deadline too: what is measured is kept
+        final_m = {"ms_per_step": round(dt / args.steps * 1e3, 3), "shapes_per_s": round(PER_GPU_BATCH * world * args.steps / dt, 2)}
+        wd.fallback = lambda phase: basic_line(final_m, dp_schedule, "timed region complete; '%s' did not complete within %.0f s" % (phase, seconds))
+        wd.arm("accounting steps after the timed region", seconds)
     ACCT_STEPS = 4
     if not SELFTEST:
         # a replayed graph offers no per-launch hook: the matrix-core launches are bracketed with HIP events over a few eager steps
@@ -460,7 +597,9 @@ def main():
         spgan.ops.launch_timer = None
 
     drop_in = None
-    if not SELFTEST and not args.no_extra_legs and not variant:
+    if wd is not None:
+        wd.disarm()
+    if not SELFTEST and not args.no_extra_legs and not variant and world == 1:      # comparison legs: single-GPU runs only (nothing after the timed region may cost a multi-GPU line)
         # The same step as an unmodified reference loop would drive it (model.py:246-248,272-273): z tiled to [B,N,nz], the G step's
         # unused D(real) forward evaluated, EdgeConv1 on every copy of the tiled sphere.  Fresh models (same initialisation), its own
         # captured graph; every rank takes part.
@@ -531,6 +670,13 @@ def main():
             "step_tflops_algorithmic": round(shapes_s * GF_PER_SHAPE_STEP / 1e3, 2),
             "step_frac_of_fp32_matrix_peak_reference_flops": round(shapes_s * GF_PER_SHAPE_STEP / 1e3 / (FP32_MATRIX_PEAK_TFLOPS * world), 4),
         }
+        if contact is not None:
+            line["first_contact"] = {k: v for k, v in contact.items() if k not in ("overlap_ok", "dp_fallback")}
+            line["rccl_ranks_seen"] = contact.get("rccl_ranks_seen")
+            line["dp_schedule"] = dp_schedule
+            line["dp_sequential_schedule"] = dp_seq
+            if "dp_fallback" in contact:
+                line["dp_fallback"] = contact["dp_fallback"]
         if EXPERIMENT_BATCH is not None and not SELFTEST:
             line["experiment"] = "per-GPU batch %d instead of BASELINE's 32" % PER_GPU_BATCH
         if dist_on and not SELFTEST and backend != "nccl":

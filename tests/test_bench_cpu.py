@@ -65,3 +65,31 @@ def test_bench_config_switch(cfg):
     assert line["bench_config"] == cfg and line["selftest"] is True
     assert line["gf_per_shape_step_reference"] == (67.3 if cfg == "c4" else 32.6)
     assert _run(["--config", "c9"]).returncode != 0
+
+
+def test_bench_first_contact_report_and_fallbacks():
+    """Round-4 review item 7: on N > 1 ranks bench.py (1) all-reduces one float per rank under a watchdog and reports the ranks seen,
+    (2) runs one sequential and one overlapped eager step from identical state and requires bit-equal parameters across schedules and
+    ranks, (3) measures the sequential schedule in full BEFORE the overlapped default, so that a hang of the latter still leaves a
+    measured line with a "dp_fallback" key (here: a simulated hang and a simulated wrong result of the overlapped schedule)."""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_lines(r.stdout)[0]
+    fc = line["first_contact"]
+    assert line["rccl_ranks_seen"] == 2 and fc["schedules_bit_equal"] is True and fc["ranks_bit_equal"] is True
+    assert line["dp_schedule"] == "overlapped" and "dp_fallback" not in line and line["dp_sequential_schedule"]["shapes_per_s"] > 0
+    # the overlapped schedule hangs: the watchdog prints the sequential measurement and every rank leaves with status 0
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"SPGAN_BENCH_TEST_HANG": "overlap", "SPGAN_BENCH_WATCHDOG_S": "20"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["dp_schedule"] == "sequential" and "did not complete" in lines[0]["dp_fallback"] and lines[0]["value"] > 0
+    assert lines[0]["n_gpus"] == 2 and lines[0]["first_contact"]["rccl_ranks_seen"] == 2
+    # the overlapped schedule computes something else: the sequential one is what gets timed, and the line says why
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"SPGAN_BENCH_TEST_BREAK": "overlap"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_lines(r.stdout)[0]
+    assert line["dp_schedule"] == "sequential" and "not bit-equal" in line["dp_fallback"] and line["first_contact"]["schedules_bit_equal"] is False
+    # SPGAN_DP_OVERLAP=0: the sequential schedule by request
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"SPGAN_DP_OVERLAP": "0"})
+    line = _json_lines(r.stdout)[0]
+    assert r.returncode == 0 and line["dp_schedule"] == "sequential" and "SPGAN_DP_OVERLAP=0" in line["dp_fallback"]

@@ -29,3 +29,8 @@ def test_two_rank_schedule_on_one_gpu():
     assert line["hipgraph_replay"] is True, "the captured data-parallel schedule must not have fallen back to eager issue"
     assert "rehearsal" in line and line["value"] > 0 and line["steps"] == 2
     assert "falling back to eager" not in r.stderr
+    # first contact (round-4 review item 7): both ranks seen by the first collective, the overlapped default bit-equal to the sequential
+    # schedule on the HIP kernels and on both ranks, the sequential schedule measured first, no fallback taken
+    fc = line["first_contact"]
+    assert line["rccl_ranks_seen"] == 2 and fc["schedules_bit_equal"] is True and fc["ranks_bit_equal"] is True
+    assert line["dp_schedule"] == "overlapped" and "dp_fallback" not in line and line["dp_sequential_schedule"]["ms_per_step"] > 0
