@@ -668,6 +668,13 @@ int spgan_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
 int spgan_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                         float* state, float grad_scale, int zero_grad, spgan_stream_t s);
 
+/* Measurement plumbing (bench.py's `roofline` entry): device timestamps that survive a hipGraph capture, where HIP events
+ * cannot be queried.  spgan_stamp_begin stores the constant-rate wall clock in *slot; spgan_stamp_end adds (now - *slot) to acc2[0] and 1
+ * to acc2[1]; launched on the kernel's stream directly in front of / behind it.  spgan_wall_clock_khz: ticks per millisecond (0: unknown). */
+int spgan_stamp_begin(uint64_t* slot, spgan_stream_t s);
+int spgan_stamp_end(const uint64_t* slot, uint64_t* acc2, spgan_stream_t s);
+int spgan_wall_clock_khz(void);
+
 /* ------------------------------------------------------------------------------------------
  * Evaluation metrics: Chamfer distance.
  * ---------------------------------------------------------------------------------------- */

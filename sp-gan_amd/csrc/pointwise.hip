@@ -466,7 +466,38 @@ __global__ void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, fl
   p[t] -= (lr / bc1) * (mm / denom);
 }
 
+// Device timestamps INSIDE a replayed hipGraph (HIP events cannot be queried there): a one-thread launch in front of the kernel under
+// measurement stores the constant-rate wall clock (s_memrealtime; hipDeviceAttributeWallClockRate), a one-thread launch behind it adds
+// the elapsed ticks to an accumulator.  Stream order makes the pair bracket exactly that kernel (plus two launch boundaries: an EMPTY
+// pair in the same graph measures those).  Measurement plumbing of bench.py's `roofline` entry -- no product path calls it.
+__global__ void stamp_begin_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+__global__ void stamp_end_kernel(const unsigned long long* slot, unsigned long long* acc) {
+  const unsigned long long t = wall_clock64();
+  acc[0] += t - *slot;
+  acc[1] += 1ull;
+}
+
 }  // namespace
+
+extern "C" int spgan_stamp_begin(uint64_t* slot, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(slot);
+  hipLaunchKernelGGL(stamp_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)s_, reinterpret_cast<unsigned long long*>(slot));
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_stamp_end(const uint64_t* slot, uint64_t* acc2, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(slot && acc2);
+  hipLaunchKernelGGL(stamp_end_kernel, dim3(1), dim3(1), 0, (hipStream_t)s_, reinterpret_cast<const unsigned long long*>(slot),
+                     reinterpret_cast<unsigned long long*>(acc2));
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_wall_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+  return khz;
+}
 
 extern "C" int spgan_adain_fwd(const float* x, int M, int C, int N, float slope, const float* imean, const float* ivar, float eps,
                                const float* gb, float* out, spgan_stream_t s_) {

@@ -231,6 +231,9 @@ SIGNATURES = {
     "spgan_occupancy_counts": (I, [P, I, I, I, P, P, P]),
     "spgan_mmd_cov": (I, [P, I, I, P, P, P]),
     "spgan_two_sample_knn": (I, [P, P, P, I, I, I, I, P, P, P]),
+    "spgan_stamp_begin": (I, [P, P]),
+    "spgan_stamp_end": (I, [P, P, P]),
+    "spgan_wall_clock_khz": (I, []),
     "spgan_emd_ws_bytes": (SZ, [I, I]),
     "spgan_emd_forward": (I, [P, P, I, I, F, I, P, P, P, SZ, P]),
     "spgan_emd_backward": (I, [P, P, I, I, P, P, P, P]),

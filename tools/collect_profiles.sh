@@ -13,7 +13,8 @@ python $R/bench.py --config c4 --no-cpu-baseline --no-extra-legs > $O/${TAG}_ben
 python $R/bench.py --mfma bf16x3 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_bf16x3.json 2>> $O/${TAG}_bench.err
 rm -rf /tmp/prof_s; rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/bench_s.log 2>&1
 DB=$(find /tmp/prof_s -name "*.db" | head -1)
-python $R/tools/rocprof_summary.py $DB 31 > $O/${TAG}_bench_kernel_stats.txt      # 31 steps: 4 priming + 3 warm-up + 20 timed + 4 eager accounting steps (+ the keep-busy launches: the Cijk_ row)
+python $R/tools/rocprof_summary.py $DB 31 > $O/${TAG}_bench_kernel_stats.txt
+python $R/tools/roofline_same_process.py /tmp/bench_s.log $DB > $O/${TAG}_roofline_same_process.json 2>> $O/${TAG}_bench.err      # stamps / events / rocprof of ONE process      # 31 steps: 4 priming + 3 warm-up + 20 timed + 4 eager accounting steps (+ the keep-busy launches: the Cijk_ row)
 python $R/tools/gap_analysis.py $DB 0.35 0.7 > $O/${TAG}_bench_graph_replay_window.txt
 python $R/tools/step_sequence.py $DB -8 > $O/${TAG}_step_sequence.txt
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do rm -rf /tmp/p_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/p_$c -o r -- python $R/tools/pmc_step.py > /tmp/log_$c 2>&1; done
