@@ -1,0 +1,468 @@
+// GENERATED from sp-gan_amd/csrc/gemm_dual.hip (round-5 kernel) with runtime ablation switches; measurement only
+// spgan_gemm_dual: the backward of one 1x1-conv layer behind a train-mode BatchNorm + LeakyReLU as ONE launch -- the input-gradient
+// product AND the weight-gradient product from ONE staging of the incoming gradient tile (round-3 review item 1).  The layers:
+// conv_w.3 of an EdgeBlock (Generation/Generator.py:56-63,78), mlps.3 and mlps.6 of the Discriminator
+// (Generation/Discriminator.py:55-65) and the collapsed form of its fc2.0 (Discriminator.py:77-81,104; DESIGN.md "collapsed backward").
+//
+//   dy[m, :]   = p*A[m, :] + q*A2[m, :] + r                 the layer's output gradient as the lazy BatchNorm-backward operand, or
+//              = lrelu(p*A[m, :] + r, a_slope)               an activation formed on load (the collapsed layer: dy := a3), or A itself
+//   a[m, :]    = lrelu(sc*pre[m, :] + sh)                    the layer's INPUT: the previous layer's BatchNorm + LeakyReLU applied on load;
+//                                                            pre[m] = B[m] (plain) or B[idx[m]] - B[m / k] + e_bias (per-edge operand)
+//   dW[Na,Nb]  = sum_m dy[m, :]^T a[m, :]                    weight gradient (split over row runs, partials summed in fixed order)
+//   G[m, :]    = (dy[m, :] . W + bias + rowadd[m, :]) * lrelu'(sc*pre[m, :] + sh)      gradient w.r.t. the previous BatchNorm's output
+//   stats      = (sum_m G, sum_m G * xhat),  xhat = (pre - mean)*invstd               the previous BatchNorm's backward sums
+//   colsum     = sum_m dy[m, :]                              (optional by-product: the collapsed layer's colsum(a3))
+//
+// Before, gemm_tn (dW) and gemm_nt with the BNBWD / EDGE_BNBWD epilogue (G, stats) each read A, A2 and pre: at the EdgeBlock's size
+// (655,360 edges x 128 channels) 2 x 840 MB; both launches ran at 32-39 % of the fp32 matrix peak, bound by that traffic.  Here a
+// workgroup owns a contiguous run of 32-row chunks and ONE 64-column part of the Nb output columns; per chunk the dy tile [32 x Na] and
+// the pre tile [32 x 64] are staged ONCE into LDS and feed both products:
+//   input gradient  [32 x 64]  = dy [32 x Na] . W [Na x 64]        v_mfma_f32_32x32x2_f32: two 32 x 32 tiles, each split over Na / 64 waves
+//                                                                  along K (64-deep slices); the slice partials meet through LDS and every
+//                                                                  wave finalises 16 / (Na / 64) rows-of-elements of its tile.  Both
+//                                                                  fragments of TWO consecutive MFMAs come from one 8-byte LDS read each
+//                                                                  (dy: the K order inside a group of four is permuted so that the pair is
+//                                                                  contiguous; W: stored in LDS as [k / 2][column][k % 2]).  Round 4 issued
+//                                                                  this product as 16x16x4 MFMAs fed by two conflicted ds_read_b32 per
+//                                                                  32 matrix-pipe cycles -- the LDS pipe was 100 % busy and the loop ran at
+//                                                                  half the matrix rate (tools/exp/run_dual_abl.py, profiles/r05_dual_abl.txt)
+//   weight gradient [Na x 64] += dy^T [Na x 32] . a [32 x 64]      v_mfma_f32_32x32x2_f32, 2 tiles per wave, accumulated over all chunks
+// with Na / 32 waves (Na = 128: 256 threads, two workgroups per CU; Na = 256: 512 threads, one per CU): 2048 + 2048 matrix-pipe cycles per
+// wave and chunk in both geometries.  Nb = 128 / 256 run as 2 / 4 column parts (workgroups next to each other on one XCD: the dy tile of a
+// run comes from HBM once and from that XCD's L2 for the other parts).  The next chunk's global loads are in flight under the MFMAs (raw
+// values in registers; the affine maps are applied at the LDS store, csrc/gemm.hip "prologues run at the LDS store"), the per-edge
+// neighbour indices are fetched one chunk further ahead.  The masked input-gradient tile goes through LDS (pre-loaded with the row addend
+// when there is one) so that it leaves as 16-byte stores of full rows.
+// Bank maths: dy pitch Na + 2 (8-byte aligned rows; the b64 A-fragment read of 32 rows x 2 k-pairs touches every bank pair four times:
+// full rate; the weight gradient's A fragment is 32 consecutive floats of one row), W [k / 2][64][2]: a b64 B-fragment read is 32
+// consecutive 8-byte words per k-pair, pre / G pitch 68 (the epilogue's two rows 4 apart x 32 columns: 2-way, the floor for 64 lanes).
+// Deterministic: fixed chunk -> workgroup assignment, fixed-order sums, no atomics.  fp32 operands only (the "f16" operand mode keeps the
+// two-launch route with its 16-bit storage).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int R = 32;      // rows per chunk
+constexpr int NBW = 64;    // output columns per workgroup (one part of Nb)
+constexpr int LDP = 68, LDG = 68;
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// A-operand modes (spgan_gemm_dual_args.a_mode)
+constexpr int A_DENSE = 0, A_LAZY2 = 1, A_ACT = 2;
+
+template <int EK, int NA>   // EK: 0 plain pre tensor, > 0 per-edge operand with EK edges per point (NA = 128 only); NA: columns of dy
+__global__ __launch_bounds__(2 * NA, NA == 128 ? 2 : 1) void gemm_dual_kernel(const spgan_gemm_dual_args p, int chunks_per_wg, int runs, int parts,
+                                                                               int a_mode, int abl) {
+  constexpr int T = 2 * NA;            // threads
+  constexpr int W_ = NA / 32;          // waves
+  constexpr int KS = W_ / 2;           // K slices of the input-gradient product: two 32 x 32 tiles, W_ / 2 waves each, 64 k-values per wave
+  constexpr int NE = 16 / KS;          // input-gradient accumulator elements a lane finalises per chunk
+  constexpr int PS = 512 / T;          // float4 staging slots per thread of a 32 x 64 tile
+  constexpr int LDY = NA + 2;
+  // exchange buffer of the K-slice partials: KS = 2: [tile][sender][8 elements][lane]; KS = 4: [tile][owner][sender][4 elements][lane]
+  constexpr int SM_DY = R * LDY, SM_PRE = R * LDP, SM_G = R * LDG, SM_X = (KS == 2 ? 2 * 2 * 8 : 2 * 4 * 4 * 4) * 64;
+  // the dy and pre tiles are DOUBLE-BUFFERED: chunk c+1 is staged while chunk c is being multiplied (W lives in registers, see below)
+  __shared__ __attribute__((aligned(16))) float sm[2 * SM_DY + 2 * SM_PRE + SM_G + SM_X];
+  float* dys0 = sm;
+  float* pres0 = sm + 2 * SM_DY;
+  float* gzs = sm + 2 * SM_DY + 2 * SM_PRE;      // the masked input-gradient tile [32 x 64] on its way to coalesced 16-byte stores
+  float* xch = sm + 2 * SM_DY + 2 * SM_PRE + SM_G;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;     // 32x32x2 fragment coordinates
+  const int chunks = p.M / R;
+  // XCD-aware: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs; logical workgroup xcd*per + t goes to XCD xcd, so
+  // that an XCD works on CONSECUTIVE row runs and all column parts of a run: the per-edge operand's neighbour rows of one shape (0.5 MB
+  // of the point tensor) are gathered through ONE L2, and a run's dy tile is fetched from HBM once for all its parts
+  const int per_xcd = gridDim.x >> 3;
+  const int L = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (L >= runs * parts) return;
+  const int wg = L / parts, part = L - wg * parts;
+  const int c0 = wg * chunks_per_wg;
+  const int c1 = min(chunks, c0 + chunks_per_wg);
+  const int col0 = part * NBW;                   // this workgroup's columns of pre / W / G
+  const bool do_cs = p.colsum_ws != nullptr && part == 0;
+
+  // ---- input gradient geometry: tile tc (columns 32 tc + l31), K slice ks = [64 ks, 64 ks + 64).  The wave's W fragments (64 x 32 values
+  // = 32 VGPRs per lane) are loaded from global memory ONCE, in the order the MFMAs consume them: group jj covers k = 64 ks + 4 jj .. + 3;
+  // its first MFMA takes k = .. + 2 lh, its second k = .. + 2 lh + 1 (the dy fragment of both is ONE 8-byte LDS read)
+  const int tc = w & 1, ks = w >> 1;
+  float wf[32];
+  {
+    const float* wp = p.W + (size_t)(64 * ks + 2 * lh) * p.ldw + col0 + 32 * tc + l31;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      wf[2 * jj] = wp[(size_t)(4 * jj) * p.ldw];
+      wf[2 * jj + 1] = wp[(size_t)(4 * jj + 1) * p.ldw];
+    }
+  }
+  // Na = 256 (eight waves, two per SIMD, ONE workgroup per CU): the waves of the upper half stage the next chunk BEFORE their input-gradient
+  // MFMAs, those of the lower half BETWEEN their two MFMA phases -- while one wave of a SIMD writes LDS, its partner keeps the matrix pipe
+  // busy.  Na = 128: the two resident workgroups of a CU are out of phase by themselves.
+  const bool early = W_ == 8 && w >= 4;
+
+  // ---- per-thread constants
+  // staging slots: dy tile 32 x NA -> 4 float4 per thread and tensor (column quad fixed per thread); 32 x 64 tiles -> PS per thread
+  const int ycol = (tid % (NA / 4)) * 4, yrow0 = tid / (NA / 4);      // rows yrow0 + 8 i
+  const int pcol = (tid & 15) * 4, prow0 = tid >> 4;                    // rows prow0 + (T / 16) i
+  float4 cp = make_float4(1.f, 1.f, 1.f, 1.f), cq = make_float4(0.f, 0.f, 0.f, 0.f), cr = cq, eb = cq;
+  if (a_mode != A_DENSE) {
+    cp = ldg4(p.p + ycol); cr = ldg4(p.r + ycol);
+    if (a_mode == A_LAZY2) cq = ldg4(p.q + ycol);
+  }
+  const float a_slope = p.a_slope;
+  if (EK > 0) eb = ldg4(p.e_bias + pcol);
+  // weight-gradient B fragments: columns 32 cj + l31 of the pre tile
+  float sc_w[2], sh_w[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    sc_w[j] = p.b_scale[col0 + 32 * j + l31]; sh_w[j] = p.b_shift[col0 + 32 * j + l31];
+  }
+  const int cd = col0 + 32 * tc + l31;
+  const float sc_d = p.b_scale[cd], sh_d = p.b_shift[cd], mu_d = p.b_mean[cd], iv_d = p.b_invstd[cd];
+  const float bi_d = p.bias ? p.bias[cd] : 0.f;
+  const float slope = p.slope;
+  const bool radd = p.rowadd != nullptr;
+
+  f32x16 accw[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+  float s0 = 0.f, s1 = 0.f;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);      // column sums of dy over this thread's rows (ascending: deterministic)
+
+  float4 ra[4], ra2[4], rb[PS], rb2[PS], re[PS];
+  int nidx[PS];      // neighbour rows of the chunk AFTER the one whose values are being loaded
+#pragma unroll
+  for (int i = 0; i < PS; ++i) nidx[i] = 0;
+
+  // global addressing: a uniform base per chunk (scalar registers) + a 32-bit per-thread element offset (the rows of a chunk are less
+  // than 2^31 elements apart)
+  const unsigned offA = (unsigned)yrow0 * (unsigned)p.lda + (unsigned)ycol, stepA = 8u * (unsigned)p.lda;
+  const unsigned offA2 = (unsigned)yrow0 * (unsigned)p.lda2 + (unsigned)ycol, stepA2 = 8u * (unsigned)p.lda2;
+  const unsigned offB = (unsigned)prow0 * (unsigned)p.ldb + (unsigned)(col0 + pcol), stepB = (unsigned)(T / 16) * (unsigned)p.ldb;
+  const unsigned offE = (unsigned)prow0 * (unsigned)p.ld_rowadd + (unsigned)(col0 + pcol), stepE = (unsigned)(T / 16) * (unsigned)p.ld_rowadd;
+  const unsigned offG = (unsigned)prow0 * (unsigned)p.ldg + (unsigned)(col0 + pcol), stepG = (unsigned)(T / 16) * (unsigned)p.ldg;
+  auto iload = [&](int c) {  // neighbour indices of chunk c (clamped: a chunk past the end is never stored)
+    if (EK > 0) {
+      const int m0 = min(c, chunks - 1) * R;
+#pragma unroll
+      for (int i = 0; i < PS; ++i) nidx[i] = p.e_idx[m0 + prow0 + (T / 16) * i];
+    }
+  };
+  auto gload = [&](int c) {
+    const float* Ab = p.A + (size_t)c * R * p.lda;
+    const float* A2b = p.A2 + (size_t)c * R * p.lda2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = ldg4(Ab + (offA + i * stepA));
+      if (a_mode == A_LAZY2) ra2[i] = ldg4(A2b + (offA2 + i * stepA2));
+    }
+    if (EK > 0) {
+      const unsigned m0 = (unsigned)c * R + (unsigned)prow0;
+#pragma unroll
+      for (int i = 0; i < PS; ++i) {
+        rb[i] = ldg4(p.B + ((unsigned)nidx[i] * (unsigned)p.ldb + (unsigned)pcol));
+        rb2[i] = ldg4(p.B + (((m0 + (unsigned)(T / 16) * i) / (unsigned)(EK > 0 ? EK : 1)) * (unsigned)p.ldb + (unsigned)pcol));
+      }
+    } else {
+      const float* Bb = p.B + (size_t)c * R * p.ldb;
+#pragma unroll
+      for (int i = 0; i < PS; ++i) rb[i] = ldg4(Bb + (offB + i * stepB));
+    }
+  };
+  auto eload = [&](int c) {      // the row addend travels separately: its LDS slots (the gradient tile) are free one barrier later than the tiles
+    if (radd) {
+      const float* Eb = p.rowadd + (size_t)c * R * p.ld_rowadd;
+#pragma unroll
+      for (int i = 0; i < PS; ++i) re[i] = ldg4(Eb + (offE + i * stepE));
+    }
+  };
+  auto estore = [&]() {          // the row addend of the next chunk waits in the gradient tile's LDS slot: the epilogue adds it where it writes its own value
+    if (radd) {
+#pragma unroll
+      for (int i = 0; i < PS; ++i) *reinterpret_cast<float4*>(&gzs[(prow0 + (T / 16) * i) * LDG + pcol]) = re[i];
+    }
+  };
+  auto sstore = [&](float* dys, float* pres) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = ra[i];
+      if (a_mode == A_LAZY2) {
+        v.x = fmaf(v.x, cp.x, fmaf(ra2[i].x, cq.x, cr.x));
+        v.y = fmaf(v.y, cp.y, fmaf(ra2[i].y, cq.y, cr.y));
+        v.z = fmaf(v.z, cp.z, fmaf(ra2[i].z, cq.z, cr.z));
+        v.w = fmaf(v.w, cp.w, fmaf(ra2[i].w, cq.w, cr.w));
+      } else if (a_mode == A_ACT) {
+        v.x = lrelu_f(fmaf(v.x, cp.x, cr.x), a_slope);
+        v.y = lrelu_f(fmaf(v.y, cp.y, cr.y), a_slope);
+        v.z = lrelu_f(fmaf(v.z, cp.z, cr.z), a_slope);
+        v.w = lrelu_f(fmaf(v.w, cp.w, cr.w), a_slope);
+      }
+      if (do_cs) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
+      float* d = &dys[(yrow0 + 8 * i) * LDY + ycol];      // pitch NA + 2 floats: 8-byte aligned rows
+      *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+    }
+#pragma unroll
+    for (int i = 0; i < PS; ++i) {
+      float4 v = rb[i];
+      if (EK > 0) {
+        v.x = (v.x - rb2[i].x) + eb.x;
+        v.y = (v.y - rb2[i].y) + eb.y;
+        v.z = (v.z - rb2[i].z) + eb.z;
+        v.w = (v.w - rb2[i].w) + eb.w;
+      }
+      *reinterpret_cast<float4*>(&pres[(prow0 + (T / 16) * i) * LDP + pcol]) = v;
+    }
+  };
+
+  // Pipeline: while chunk c is multiplied out of tile buffer c & 1, chunk c+1 goes from registers to the other buffer and the loads of chunk
+  // c+2 are issued right behind (they fly for a whole chunk).  Two barriers per chunk: B1 after the input-gradient MFMAs (the K-slice partials
+  // are in LDS), B2 after the weight-gradient MFMAs (every read of buffer c & 1 is done, buffer (c+1) & 1 is complete, the gradient tile is complete).
+  if (c0 < c1) {
+    iload(c0);
+    gload(c0); eload(c0);
+    iload(c0 + 1);
+    sstore(dys0, pres0); estore();
+    if (c0 + 1 < c1) {
+      gload(c0 + 1); eload(c0 + 1);
+      iload(c0 + 2);
+    }
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+      const bool more = c + 1 < c1;
+      const int cur = (c - c0) & 1;
+      const float* dys = dys0 + cur * SM_DY;
+      const float* pres = pres0 + cur * SM_PRE;
+      float* dys_n = dys0 + (cur ^ 1) * SM_DY;
+      float* pres_n = pres0 + (cur ^ 1) * SM_PRE;
+      if (early && more) {
+        if (!(abl & 16)) sstore(dys_n, pres_n);
+        if (c + 2 < c1 && !(abl & 2)) {
+          gload(c + 2);              // uses the indices fetched one iteration ago
+          iload(c + 3);
+        }
+      }
+      // ---- input gradient: [32 x 64] = dy [32 x NA] . W [NA x 64]; this wave: tile tc (columns 32 tc .. +32), K slice [64 ks, 64 ks + 64):
+      // 32 MFMAs in two independent accumulator chains, ONE 8-byte LDS read per operand and MFMA pair.  Group jj covers k = 64 ks + 4 jj .. + 3;
+      // its first MFMA takes k = .. + 2 lh, its second k = .. + 2 lh + 1 on both operands.
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+      if (!(abl & 4)) {
+        const float* ap = dys + l31 * LDY + 64 * ks + 2 * lh;
+#pragma unroll
+        for (int jj = 0; jj < 16; jj += 2) {
+          const float2 a0 = *reinterpret_cast<const float2*>(ap + 4 * jj);
+          const float2 a1 = *reinterpret_cast<const float2*>(ap + 4 * jj + 4);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf[2 * jj], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf[2 * jj + 2], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf[2 * jj + 1], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf[2 * jj + 3], acc1, 0, 0, 0);
+        }
+      }
+      f32x16 accd;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accd[r] = acc0[r] + acc1[r];      // even groups + odd groups: fixed order
+      // ---- the K slices of a tile meet: wave ks finalises accumulator elements NE ks .. NE ks + NE - 1 (rows 2 NE ks .. of the tile, see
+      // the epilogue) and hands the others to their owners through LDS; the owner sums the slices in slice order
+      float fin[NE];
+      if (abl & 32) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) fin[e] = accd[e];
+      } else if (KS == 2) {
+        float* xo = xch + ((tc * 2 + ks) * 8) * 64 + lane;
+        if (ks == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xo[e * 64] = accd[8 + e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xo[e * 64] = accd[e];
+        }
+        __syncthreads();
+        const float* xi = xch + ((tc * 2 + (1 - ks)) * 8) * 64 + lane;
+        if (ks == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fin[e] = accd[e] + xi[e * 64];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fin[e] = xi[e * 64] + accd[8 + e];
+        }
+      } else {
+        // [tile][owner][sender][element][lane]: every wave writes all four quarters (its own included: no register indexed by ks)
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xch[((((tc * 4 + o) * 4 + ks) * 4) + e) * 64 + lane] = accd[4 * o + e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* xi = xch + ((((tc * 4 + ks) * 4) * 4) + e) * 64 + lane;
+          fin[e % NE] = ((xi[0] + xi[4 * 64]) + xi[8 * 64]) + xi[12 * 64];      // slices 0, 1, 2, 3
+        }
+      }
+      if (!early && more) {          // the lower half of the waves (and every wave at Na = 128) stages the next chunk between its two MFMA phases
+        if (!(abl & 16)) sstore(dys_n, pres_n);
+        if (c + 2 < c1 && !(abl & 2)) {
+          gload(c + 2);              // uses the indices fetched one iteration ago
+          iload(c + 3);
+        }
+      }
+      // ---- weight gradient: [NA x 64] += dy^T [NA x 32] . a [32 x 64]; this wave: dy columns 32 w .. +32, both column halves of a.
+      // The epilogue of the input gradient (bias / row addend, LeakyReLU mask of the previous layer, BatchNorm-backward sums, tile -> LDS)
+      // is interleaved, one accumulator element behind every (16 / NE)-th k-step: its VALU work issues while the matrix pipe works off
+      // the MFMAs before it.
+      if (!(abl & 8)) {
+        const float* ap = dys + lh * LDY + 32 * w + l31;
+        const float* bp = pres + lh * LDP + l31;
+        // accumulator element NE ks + e of the 32 x 32 tile sits in row (e & 3) + 8 (e >> 2) + 2 NE ks + 4 lh, column l31
+        const float* ep = pres + (2 * NE * ks + 4 * lh) * LDP + 32 * tc + l31;
+        float* gp = gzs + (2 * NE * ks + 4 * lh) * LDG + 32 * tc + l31;
+#pragma unroll
+        for (int kq = 0; kq < R / 2; ++kq) {
+          const float af = ap[2 * kq * LDY];
+          float b0 = fmaf(bp[2 * kq * LDP], sc_w[0], sh_w[0]);
+          float b1 = fmaf(bp[2 * kq * LDP + 32], sc_w[1], sh_w[1]);
+          b0 = b0 > 0.f ? b0 : b0 * slope;
+          b1 = b1 > 0.f ? b1 : b1 * slope;
+          accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, b0, accw[0], 0, 0, 0);
+          accw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, b1, accw[1], 0, 0, 0);
+          if ((kq + 1) % (16 / NE) == 0) {
+            const int e = kq / (16 / NE), ro = (e & 3) + 8 * (e >> 2);      // compile-time after unrolling
+            const float pre = ep[ro * LDP];
+            const float z = fmaf(pre, sc_d, sh_d);
+            float acc = fin[e] + bi_d;
+            if (radd) acc += gp[ro * LDG];
+            const float g = acc * (z > 0.f ? 1.f : slope);
+            const float xh = (pre - mu_d) * iv_d;
+            s0 += g;
+            s1 = fmaf(g, xh, s1);
+            gp[ro * LDG] = g;
+          }
+        }
+      }
+      __syncthreads();      // B2: every read of this chunk's tiles is done, the next chunk's tiles and this chunk's gradient tile are complete
+      if (!(abl & 1)) {
+        float* gout = p.G + (size_t)c * R * p.ldg;
+#pragma unroll
+        for (int i = 0; i < PS; ++i)
+          *reinterpret_cast<float4*>(gout + (offG + i * stepG)) = *reinterpret_cast<const float4*>(&gzs[(prow0 + (T / 16) * i) * LDG + pcol]);
+      }
+      if (more) {
+        estore();                    // the same thread re-fills the gradient-tile slots it just stored from; B1 of the next chunk orders it before the epilogue's reads
+        if (c + 2 < c1) eload(c + 2);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- statistics: a lane holds the sums of ONE column (32 tc + l31) over the rows it finalised; the two lane halves, then the KS waves
+  // that share the tile, in slice order
+  float* red = dys0;        // the tiles are dead (barrier above)
+  {
+    float a = s0, b = s1;
+    a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+    if (lh == 0) {
+      red[(w * 32 + l31) * 2] = a;
+      red[(w * 32 + l31) * 2 + 1] = b;
+    }
+  }
+  __syncthreads();
+  if (tid < NBW) {
+    const int tcc = tid >> 5, cc = tid & 31;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < KS; ++k2) {
+      a += red[((2 * k2 + tcc) * 32 + cc) * 2];          // wave (tc = tcc, ks = k2)
+      b += red[((2 * k2 + tcc) * 32 + cc) * 2 + 1];
+    }
+    float* st = p.stats + ((size_t)wg * p.Nb + col0 + tid) * 2;
+    st[0] = a; st[1] = b;
+  }
+  // ---- column sums of dy over this run (8 row groups per column quad -> one value per column), part 0 only
+  if (do_cs) {
+    float* cred = dys0 + SM_DY;       // [8][NA]: the second tile buffer (dead; the statistics scratch sits in the first)
+    *reinterpret_cast<float4*>(&cred[yrow0 * NA + ycol]) = cs;
+    __syncthreads();
+    if (tid < NA) {
+      float t = 0.f;
+#pragma unroll
+      for (int g8 = 0; g8 < 8; ++g8) t += cred[g8 * NA + tid];
+      p.colsum_ws[(size_t)wg * NA + tid] = t;
+    }
+  }
+  // ---- weight-gradient partial of this workgroup -> ws[run][NA][Nb], columns col0 .. col0+63
+  float* out = p.ws + (size_t)wg * NA * p.Nb + (size_t)(32 * w + 4 * lh) * p.Nb + col0 + l31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2)) * p.Nb + 32 * j] = accw[j][r];
+}
+
+// row run -> workgroup plan.  Na = 128: two workgroups per CU resident (LDS) -> 512 slots; Na = 256: one -> 256 slots; the slots are shared
+// by the column parts of a run; at least 4 chunks per run to amortise the W load and the partial store
+inline void dual_plan(int M, int Na, int Nb, int* runs, int* cpw) {
+  const int chunks = M / R, parts = Nb / NBW;
+  const int slots = (Na == 128 ? 512 : 256) / parts;
+  int per = (chunks + slots - 1) / slots;
+  if (per < 4) per = 4;
+  *cpw = per;
+  *runs = (chunks + per - 1) / per;
+}
+
+inline bool dual_shape_ok(int M, int Na, int Nb, int e_k) {
+  if (M < 8192 || M % R) return false;
+  if (Na == 128 && Nb == 64) return e_k == 0 || e_k == 10;
+  if (Na == 256 && (Nb == 128 || Nb == 256)) return e_k == 0;
+  return false;
+}
+
+}  // namespace
+
+extern "C" int abl_gemm_dual_wgs(int M, int Na, int Nb, int e_k) {
+  if (!dual_shape_ok(M, Na, Nb, e_k)) return 0;
+  int runs, cpw;
+  dual_plan(M, Na, Nb, &runs, &cpw);
+  return runs;
+}
+
+extern "C" int abl_gemm_dual_rows_per_wg(int M, int Na, int Nb) {
+  if (M < R || !(Na == 128 || Na == 256) || Nb < NBW || Nb % NBW) return 0;
+  int runs, cpw;
+  dual_plan(M, Na, Nb, &runs, &cpw);
+  return cpw * R;
+}
+
+extern "C" int abl_gemm_dual(const spgan_gemm_dual_args* a, int abl, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && a->A && a->W && a->B && a->G && a->stats && a->ws && a->b_scale && a->b_shift && a->b_mean && a->b_invstd);
+  const int ek = a->e_idx ? a->e_k : 0;
+  SPGAN_CHECK_ARG(dual_shape_ok(a->M, a->Na, a->Nb, ek));
+  SPGAN_CHECK_ARG(a->a_mode == A_DENSE || a->a_mode == A_LAZY2 || a->a_mode == A_ACT);
+  SPGAN_CHECK_ARG(a->a_mode == A_DENSE || (a->p && a->r));
+  SPGAN_CHECK_ARG(a->a_mode != A_LAZY2 || (a->A2 && a->q));
+  SPGAN_CHECK_ARG(!a->e_idx || a->e_bias);
+  // 16-byte aligned rows everywhere (float4 loads / stores)
+  auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0; };
+  SPGAN_CHECK_ARG(al(a->A, a->lda) && (a->a_mode != A_LAZY2 || al(a->A2, a->lda2)) && al(a->W, a->ldw) && al(a->B, a->ldb) && al(a->G, a->ldg));
+  SPGAN_CHECK_ARG(a->lda >= a->Na && (a->a_mode != A_LAZY2 || a->lda2 >= a->Na) && a->ldw >= a->Nb && a->ldg >= a->Nb && (ek > 0 ? a->ldb >= NBW : a->ldb >= a->Nb));
+  SPGAN_CHECK_ARG(a->a_mode == A_DENSE || (al(a->p, 4) && al(a->r, 4) && (a->a_mode != A_LAZY2 || al(a->q, 4))));
+  SPGAN_CHECK_ARG(!a->e_idx || al(a->e_bias, 4));
+  SPGAN_CHECK_ARG(!a->rowadd || (al(a->rowadd, a->ld_rowadd) && a->ld_rowadd >= a->Nb));
+  int runs, cpw;
+  dual_plan(a->M, a->Na, a->Nb, &runs, &cpw);
+  const int parts = a->Nb / NBW;
+  const int grid = ((runs * parts + 7) / 8) * 8;
+  hipStream_t s = (hipStream_t)s_;
+  if (a->Na == 128) {
+    if (ek == 0) hipLaunchKernelGGL((gemm_dual_kernel<0, 128>), dim3(grid), dim3(256), 0, s, *a, cpw, runs, parts, a->a_mode, abl);
+    else hipLaunchKernelGGL((gemm_dual_kernel<10, 128>), dim3(grid), dim3(256), 0, s, *a, cpw, runs, parts, a->a_mode, abl);
+  } else {
+    hipLaunchKernelGGL((gemm_dual_kernel<0, 256>), dim3(grid), dim3(512), 0, s, *a, cpw, runs, parts, a->a_mode, abl);
+  }
+  return spgan_launch_status();
+}
