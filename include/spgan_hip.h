@@ -259,6 +259,10 @@ int spgan_bn_bwd_coeffs(const float* sums, const float* mean, const float* invst
 
 size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb);
 int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s);
+/* `count` (<= 4) streaming products with a narrow B (Nb <= 4: the weight gradient of D's first conv against the three input coordinates) of ONE
+ * shape as one launch, partials only (defer_reduce != 0 required; summed by spgan_splitk_reduce_multi): real / fake / double-backward pass of a
+ * grouped D step.  A plain or two-tensor (A2) A operand. */
+int spgan_gemm_tn_skinny_multi(const spgan_gemm_tn_args* a, int count, spgan_stream_t s);
 
 /* The backward of one 1x1-conv layer behind a train-mode BatchNorm + LeakyReLU as ONE launch (csrc/gemm_dual.hip): the weight-gradient
  * product and the input-gradient product from ONE staging of the incoming gradient tile -- what autograd does with two convolution
@@ -295,6 +299,35 @@ typedef struct spgan_gemm_dual_args {
 int spgan_gemm_dual_wgs(int M, int Na, int Nb, int e_k);
 int spgan_gemm_dual_rows_per_wg(int M, int Na, int Nb);   /* rows per run = the `tile_rows` of the statistics partials (tiles = runs = ceil(M / rows)) */
 int spgan_gemm_dual(const spgan_gemm_dual_args* a, spgan_stream_t s);
+/* Grouped launch: `count` (<= SPGAN_GROUP_MAX) independent spgan_gemm_dual problems of ONE geometry (equal M, Na, Nb; plain pre tensors) as a
+ * single grid, problem g on the workgroups [g*grid1, (g+1)*grid1): every problem's results are bit-identical to its stand-alone launch.
+ * The D step issues each Discriminator layer's backward for the real pass, the fake pass and phase B of the penalty's double backward
+ * (Generation/Discriminator.py:97-115 called three times per D step, Common/gradient_penalty.py:19-37); count == 1 is spgan_gemm_dual. */
+#define SPGAN_GROUP_MAX 4
+int spgan_gemm_dual_multi(const spgan_gemm_dual_args* a, int count, spgan_stream_t s);
+/* The launches around a grouped spgan_gemm_dual_multi, grouped the same way (every problem runs the body of its stand-alone kernel:
+ * bit-identical results).
+ * spgan_colstats_finalize_multi: `count` mode-1 finalize launches (plain sums s0/s1 of [tiles, C, 2] records) with per-problem tail --
+ *   kind 0: none;  kind 1: spgan_colstats_finalize_bnbwd's coefficients (mean, invstd, gamma | NULL, count -> coef [3,C]);
+ *   kind 2: spgan_colstats_finalize_phaseb (U0, U1, Ugz, S0, S1, gamma, invstd, count -> sums [2C], dgamma [C]).  tiles < 2048. */
+typedef struct spgan_colfinalize_args {
+  const float* partials; int tiles, C, G, tile_rows;
+  float* s0; float* s1;
+  int kind;
+  const float* mean; const float* invstd; const float* gamma; float count;
+  float* coef;
+  const float* U0; const float* U1; const float* Ugz; const float* S0; const float* S1;
+  float* sums; float* dgamma;
+} spgan_colfinalize_args;
+int spgan_colstats_finalize_multi(const spgan_colfinalize_args* a, int count, spgan_stream_t s);
+/* spgan_pool_bwd_stats_prep for `count` passes (the real and the fake pass behind one grouped forward) as one launch. */
+typedef struct spgan_pool_bwd_args {
+  const float* gpool; const float* pooled; const int32_t* argmax; const float* y; int ld;
+  const float* mean; const float* invstd; float slope; int B, C;
+  const float* gamma; int count;
+  float* gval; float* sums; float* alpha; float* beta; float* cg;
+} spgan_pool_bwd_args;
+int spgan_pool_bwd_stats_prep_multi(const spgan_pool_bwd_args* a, int count, spgan_stream_t s);
 
 /* Row-sparse products with the max-pool gradient pattern S (Discriminator.py:104 backward): one (value, row) pair per
  * shape b and channel c, val/arg [B, Cs], arg = global row (b*rows + local).  They let the backward of the layer in front
@@ -309,17 +342,18 @@ int spgan_gemm_dual(const spgan_gemm_dual_args* a, spgan_stream_t s);
  * C % 256 == 0, K % 32 == 0; deterministic (fixed-order sums). */
 int spgan_wt_diag_w(const float* W, int ldw, int C, int K, const float* alpha, const float* beta, const float* bias, float* G, int ldg,
                     float* cvec, spgan_stream_t s);
-/* Both of the above's launches for one collapsed backward pass -- spgan_wt_diag_w (nprob = 1 or 2 problems on the same W: the double backward needs
- * W^T diag(c1) W and W^T diag(c2) W) and spgan_sparse_rows_nt (E [B*rows, K] = S.W, Cs = C) -- as ONE launch: the weight-only part is latency-bound on
+/* Both of the above's launches for one collapsed backward pass -- spgan_wt_diag_w (nprob = 1 .. 4 problems on the same W: the double backward needs
+ * W^T diag(c1) W and W^T diag(c2) W; the grouped D step adds the real and the fake pass) and nsparse x spgan_sparse_rows_nt (E [B*rows, K] = S.W, Cs = C) -- as ONE launch: the weight-only part is latency-bound on
  * a fraction of the chip and finishes under the part that streams E out.  Results bit-identical to the separate launches.  cvec[p] / beta[p] /
  * bias[p] NULL: no cvec for problem p. */
 typedef struct spgan_collapse_prep_args {
   const float* W; int ldw, C, K;
-  int nprob;
-  const float* alpha[2]; const float* beta[2]; const float* bias[2];
-  float* G[2]; int ldg; float* cvec[2];
-  const float* sp_val; const int32_t* sp_arg; int B, rows;
-  float* E; int lde;
+  int nprob;                                            /* 1 .. SPGAN_GROUP_MAX weight problems on the same W */
+  const float* alpha[SPGAN_GROUP_MAX]; const float* beta[SPGAN_GROUP_MAX]; const float* bias[SPGAN_GROUP_MAX];
+  float* G[SPGAN_GROUP_MAX]; int ldg; float* cvec[SPGAN_GROUP_MAX];
+  int nsparse;                                          /* 1 .. SPGAN_GROUP_MAX sparse-row products E[q] = S[q].W, equal B and rows */
+  const float* sp_val[SPGAN_GROUP_MAX]; const int32_t* sp_arg[SPGAN_GROUP_MAX]; int B, rows;
+  float* E[SPGAN_GROUP_MAX]; int lde;
 } spgan_collapse_prep_args;
 int spgan_collapse_prep(const spgan_collapse_prep_args* a, spgan_stream_t s);
 /* The weight gradient of the collapsed layer, all of its terms in one launch (csrc/collapse.hip):
@@ -340,6 +374,8 @@ typedef struct spgan_wgrad_collapse_args {
   float* out; int ldo, N, accumulate;
 } spgan_wgrad_collapse_args;
 int spgan_wgrad_collapse(const spgan_wgrad_collapse_args* a, spgan_stream_t s);
+/* `count` (<= SPGAN_GROUP_MAX) problems with equal C, N, K as one launch (count == 1: spgan_wgrad_collapse) */
+int spgan_wgrad_collapse_multi(const spgan_wgrad_collapse_args* a, int count, spgan_stream_t s);
 int spgan_sparse_rows_nt(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* W, int ldw, int N, float* E, int lde,
                          spgan_stream_t s);
 int spgan_sparse_rows_tn(const float* val, const int32_t* arg, int B, int rows, int Cs, const float* Bm, int ldb, int Nb,
@@ -597,6 +633,17 @@ typedef struct spgan_multi_add_args {
   int n[SPGAN_MULTI_MAX];
 } spgan_multi_add_args;
 int spgan_multi_add(const spgan_multi_add_args* a, spgan_stream_t s);
+/* dst[t] = ((dst[t] + src[0][t]) + src[1][t]) + src[2][t] with nsrc[t] in 1..3 sources: the per-pass parameter gradients of a grouped backward
+ * accumulated in one launch, element for element the sums of nsrc successive spgan_multi_add calls. */
+#define SPGAN_MULTI_ADDN_MAX 32
+typedef struct spgan_multi_addn_args {
+  int count;
+  float* dst[SPGAN_MULTI_ADDN_MAX];
+  const float* src[3][SPGAN_MULTI_ADDN_MAX];
+  int nsrc[SPGAN_MULTI_ADDN_MAX];
+  int n[SPGAN_MULTI_ADDN_MAX];
+} spgan_multi_addn_args;
+int spgan_multi_addn(const spgan_multi_addn_args* a, spgan_stream_t s);
 /* The same for pairs that are 3-D strided views of one shape [n0, n1, n2] (n = n0*n1*n2; strides in elements):
  * dst[i0*ds[0] + i1*ds[1] + i2*ds[2]] += src[i0*ss[0] + i1*ss[1] + i2*ss[2]].  A permuted source (the conv_out weight gradient is computed
  * as [F,k,F] and accumulated into [F,F,1,k]) or a column block of the destination; n1 = n2 = 1 is the plain contiguous pair. */

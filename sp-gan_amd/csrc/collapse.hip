@@ -95,25 +95,29 @@ __global__ __launch_bounds__(256) void wt_diag_w_kernel(const float* __restrict_
   wt_diag_w_body(blockIdx.x, blockIdx.y, gridDim.y, lds, W, ldw, C, K, alpha, beta, bias, G, ldg, cvec);
 }
 
-// spgan_collapse_prep: everything the collapsed backward needs before its big launch, in ONE launch -- one or two W^T diag(alpha) W problems
-// (72 or 64 workgroups each, latency-bound on the cold weight matrix: 29 us alone) and the sparse-row product S.W (2048 workgroups that
-// stream 67 MB out: 33 us alone).  The weight workgroups come first in the grid, so they are resident from the start and finish under the
+// spgan_collapse_prep: everything the collapsed backward needs before its big launch, in ONE launch -- one to four W^T diag(alpha) W problems
+// (72 or 64 workgroups each, latency-bound on the cold weight matrix: 29 us alone) and one to four sparse-row products S.W (2048 workgroups
+// each that stream 67 MB out: 33 us alone); several passes over the same W (the grouped D step: real, fake, the double backward) share it.  The weight workgroups come first in the grid, so they are resident from the start and finish under the
 // streaming ones.  Both parts run the device functions of their stand-alone kernels: bit-identical results.
-__global__ __launch_bounds__(256) void collapse_prep_kernel(const spgan_collapse_prep_args a, int wgs_per_prob0, int wgs_per_prob1, int chunks, int RB) {
+__global__ __launch_bounds__(256) void collapse_prep_kernel(const spgan_collapse_prep_args a, int chunks, int RB) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   int id = blockIdx.x;
   const int kx = a.K / 32;
-  if (id < wgs_per_prob0) {
-    wt_diag_w_body(id % kx, id / kx, wgs_per_prob0 / kx, dyn, a.W, a.ldw, a.C, a.K, a.alpha[0], a.beta[0], a.bias[0], a.G[0], a.ldg, a.cvec[0]);
-    return;
+  // weight problems first (nprob <= SPGAN_GROUP_MAX: the real / fake passes and the double backward's two of a grouped D step)
+  for (int q = 0; q < a.nprob; ++q) {
+    const int wgs = kx * (kx + (a.cvec[q] ? 1 : 0));
+    if (id < wgs) {
+      wt_diag_w_body(id % kx, id / kx, wgs / kx, dyn, a.W, a.ldw, a.C, a.K, a.alpha[q], a.beta[q], a.bias[q], a.G[q], a.ldg, a.cvec[q]);
+      return;
+    }
+    id -= wgs;
   }
-  id -= wgs_per_prob0;
-  if (id < wgs_per_prob1) {
-    wt_diag_w_body(id % kx, id / kx, wgs_per_prob1 / kx, dyn, a.W, a.ldw, a.C, a.K, a.alpha[1], a.beta[1], a.bias[1], a.G[1], a.ldg, a.cvec[1]);
-    return;
-  }
-  id -= wgs_per_prob1;
-  sparse_rows_nt_body(id % chunks, id / chunks, reinterpret_cast<unsigned*>(dyn), a.sp_val, a.sp_arg, a.rows, a.C, a.W, a.ldw, a.K, a.E, a.lde, RB);
+  // then the sparse-row products, set after set (each: chunks x B workgroups)
+  const int per_set = chunks * a.B;
+  const int set = id / per_set;
+  id -= set * per_set;
+  sparse_rows_nt_body(id % chunks, id / chunks, reinterpret_cast<unsigned*>(dyn), a.sp_val[set], a.sp_arg[set], a.rows, a.C, a.W, a.ldw, a.K, a.E[set], a.lde,
+                      RB);
 }
 
 // spgan_wgrad_collapse: the weight gradient of the collapsed layer, all of its terms in ONE launch
@@ -129,8 +133,7 @@ constexpr int WG_KMAX = 256, WG_BMAX = 64;
 constexpr int wgrad_front(int K, int nx) { return (1 + nx) * 32 * (K + 4) > nx * 4096 ? (1 + nx) * 32 * (K + 4) : nx * 4096; }
 constexpr size_t wgrad_lds_bytes(int K, int nx) { return (size_t)(wgrad_front(K, nx) + 2 * 32 * WG_BMAX) * sizeof(float); }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_collapse_kernel(const spgan_wgrad_collapse_args p) {
-  extern __shared__ __attribute__((aligned(16))) float dyn[];
+__device__ __forceinline__ void wgrad_collapse_body(const spgan_wgrad_collapse_args& p, float* dyn, int bx, int by) {
   const int K = p.K, LDK = K + 4, K4 = K / 4;
   const bool two = p.X2 != nullptr;
   float* Ws = dyn;                                   // [32][LDK]
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int* sarg = reinterpret_cast<int*>(dyn + wgrad_front(K, two ? 2 : 1));  // [B][32]
   float* sval = reinterpret_cast<float*>(sarg + 32 * WG_BMAX);          // [B][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int a0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int a0 = bx * 32, n0 = by * 32;
   // ---- stage.  K == 256 (the layer this kernel exists for): every load of the launch is issued before the first LDS store, the sparse
   // term's index / value tables first (the gathers of the epilogue wait for them); other K: tile by tile
   const bool x2_rows = two && !p.x2_t;
@@ -304,9 +307,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 #undef WG_GATHER
 
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_collapse_kernel(const spgan_wgrad_collapse_args p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  wgrad_collapse_body(p, dyn, blockIdx.x, blockIdx.y);
+}
+
+// spgan_wgrad_collapse_multi: the same layer's weight gradient for several passes (blockIdx.z; equal C, N, K -- the real and the fake pass and
+// phase B of the double backward of a grouped D step) as one launch; every pass runs the stand-alone kernel's body: bit-identical results.
+struct WgradMulti {
+  spgan_wgrad_collapse_args a[SPGAN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad_collapse_multi_kernel(const WgradMulti m) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  wgrad_collapse_body(m.a[blockIdx.z], dyn, blockIdx.x, blockIdx.y);
+}
+
 }  // namespace
 
-extern "C" int spgan_wgrad_collapse(const spgan_wgrad_collapse_args* a, spgan_stream_t s_) {
+static int wgrad_check(const spgan_wgrad_collapse_args* a) {
   SPGAN_CHECK_ARG(a && a->W && a->X1 && a->a1 && a->out && a->C > 0 && a->N > 0 && a->K >= 32 && a->K <= WG_KMAX);
   SPGAN_CHECK_ARG(a->C % 32 == 0 && a->N % 32 == 0 && a->K % 32 == 0 && a->ldw >= a->K && a->ldx1 >= a->K && a->ldo >= a->N);
   SPGAN_CHECK_ARG((a->ldw % 4 == 0) && (a->ldx1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(a->W) | reinterpret_cast<uintptr_t>(a->X1)) & 15) == 0);
@@ -314,6 +332,12 @@ extern "C" int spgan_wgrad_collapse(const spgan_wgrad_collapse_args* a, spgan_st
   SPGAN_CHECK_ARG(!a->X2 || (a->a2 && (a->ldx2 % 4 == 0) && (reinterpret_cast<uintptr_t>(a->X2) & 15) == 0 && a->ldx2 >= (a->x2_t ? a->N : a->K)));
   SPGAN_CHECK_ARG(!a->sp_val || (a->sp_arg && a->Bm && a->B > 0 && a->B <= WG_BMAX && a->rows > 0 && a->ldb >= a->N && (!a->p_scale == !a->p_shift)));
   SPGAN_CHECK_ARG(!a->T || a->ldt >= a->N);
+  return SPGAN_OK;
+}
+
+extern "C" int spgan_wgrad_collapse(const spgan_wgrad_collapse_args* a, spgan_stream_t s_) {
+  const int rc = wgrad_check(a);
+  if (rc != SPGAN_OK) return rc;
   static LdsOptIn opt;  // > 64 KB of dynamic LDS: once per kernel and device
   opt.ensure(reinterpret_cast<const void*>(&wgrad_collapse_kernel), (int)wgrad_lds_bytes(WG_KMAX, 2));
   const size_t lds = wgrad_lds_bytes(a->K, a->X2 ? 2 : 1);
@@ -321,19 +345,40 @@ extern "C" int spgan_wgrad_collapse(const spgan_wgrad_collapse_args* a, spgan_st
   return spgan_launch_status();
 }
 
+extern "C" int spgan_wgrad_collapse_multi(const spgan_wgrad_collapse_args* a, int count, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && count >= 1 && count <= SPGAN_GROUP_MAX);
+  if (count == 1) return spgan_wgrad_collapse(a, s_);
+  WgradMulti m;
+  bool two = false;
+  for (int g = 0; g < count; ++g) {
+    const int rc = wgrad_check(a + g);
+    if (rc != SPGAN_OK) return rc;
+    SPGAN_CHECK_ARG(a[g].C == a[0].C && a[g].N == a[0].N && a[g].K == a[0].K);
+    m.a[g] = a[g];
+    two = two || a[g].X2 != nullptr;
+  }
+  static LdsOptIn opt;
+  opt.ensure(reinterpret_cast<const void*>(&wgrad_collapse_multi_kernel), (int)wgrad_lds_bytes(WG_KMAX, 2));
+  const size_t lds = wgrad_lds_bytes(a->K, two ? 2 : 1);
+  hipLaunchKernelGGL(wgrad_collapse_multi_kernel, dim3(a->C / 32, a->N / 32, count), dim3(256), lds, (hipStream_t)s_, m);
+  return spgan_launch_status();
+}
+
 extern "C" int spgan_collapse_prep(const spgan_collapse_prep_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a && a->W && a->C > 0 && a->K > 0 && a->C % 256 == 0 && a->K % 32 == 0 && a->ldw >= a->K && a->ldg >= a->K && a->C <= 8192);
-  SPGAN_CHECK_ARG(a->nprob >= 1 && a->nprob <= 2 && a->sp_val && a->sp_arg && a->E && a->B > 0 && a->rows > 0 && a->lde >= a->K);
-  int wgs[2] = {0, 0};
+  SPGAN_CHECK_ARG(a->nprob >= 1 && a->nprob <= SPGAN_GROUP_MAX && a->nsparse >= 1 && a->nsparse <= SPGAN_GROUP_MAX && a->B > 0 && a->rows > 0 &&
+                  a->lde >= a->K);
+  int wgs = 0;
   for (int p = 0; p < a->nprob; ++p) {
     SPGAN_CHECK_ARG(a->alpha[p] && a->G[p] && (!a->cvec[p] || (a->beta[p] && a->bias[p])));
-    wgs[p] = (a->K / 32) * (a->K / 32 + (a->cvec[p] ? 1 : 0));
+    wgs += (a->K / 32) * (a->K / 32 + (a->cvec[p] ? 1 : 0));
   }
+  for (int q = 0; q < a->nsparse; ++q) SPGAN_CHECK_ARG(a->sp_val[q] && a->sp_arg[q] && a->E[q]);
   const int RB = sparse_rows_nt_rb(a->rows, a->C);
   const int chunks = cdiv(a->rows, RB);
   size_t lds = sparse_rows_nt_lds(RB, a->C);
   if (lds < WDW_LDS_FLOATS * sizeof(float)) lds = WDW_LDS_FLOATS * sizeof(float);
-  hipLaunchKernelGGL(collapse_prep_kernel, dim3(wgs[0] + wgs[1] + chunks * a->B), dim3(256), lds, (hipStream_t)s_, *a, wgs[0], wgs[1], chunks, RB);
+  hipLaunchKernelGGL(collapse_prep_kernel, dim3(wgs + chunks * a->B * a->nsparse), dim3(256), lds, (hipStream_t)s_, *a, chunks, RB);
   return spgan_launch_status();
 }
 

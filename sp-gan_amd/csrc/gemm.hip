@@ -1905,16 +1905,15 @@ inline void tn_plan(int M, int Na, int Nb, int* splits, int* rows) {
 // out[split][Na][Nb] partials of A^T B when A or B has <= 4 columns: 64 columns of the wide operand x 4 row-lanes per workgroup,
 // the narrow operand's row is a broadcast load; the four row-lanes are summed in a fixed order.
 template <bool NARROW_B>
-__global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(const spgan_gemm_tn_args p, int rows_per_split) {
+__device__ __forceinline__ void gemm_tn_skinny_body(const spgan_gemm_tn_args& p, int rows_per_split, int bx, int split) {
   __shared__ float red[4][4][64];
-  const int split = blockIdx.y;
   const int mbeg = split * rows_per_split, mend = min(p.M, mbeg + rows_per_split);
   const float* __restrict__ Lm = NARROW_B ? p.A : p.B;
   const float* __restrict__ Sm = NARROW_B ? p.B : p.A;
   const int ldl = NARROW_B ? p.lda : p.ldb, lds_ = NARROW_B ? p.ldb : p.lda;
   const int Ln = NARROW_B ? p.Na : p.Nb, Sn = NARROW_B ? p.Nb : p.Na;
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int l = blockIdx.x * 64 + cl;
+  const int l = bx * 64 + cl;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   // two-tensor A operand (spgan_gemm_tn_args.A2) on the wide side: a = A*a_scale[l] + A2*a_scale2[l] + a_shift[l], column l fixed per thread
   const bool a2 = NARROW_B && p.A2 != nullptr;
@@ -1959,6 +1958,19 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(const spgan_gemm_tn
         else out[(size_t)q * p.Nb + l] = v;
       }
   }
+}
+
+template <bool NARROW_B>
+__global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(const spgan_gemm_tn_args p, int rows_per_split) {
+  gemm_tn_skinny_body<NARROW_B>(p, rows_per_split, blockIdx.x, blockIdx.y);
+}
+
+// spgan_gemm_tn_skinny_multi: the 3-column weight gradient of D's first conv for several passes (blockIdx.z) as one launch
+struct TnSkinnyMulti {
+  spgan_gemm_tn_args a[SPGAN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void gemm_tn_skinny_multi_kernel(const TnSkinnyMulti m, int rows_per_split) {
+  gemm_tn_skinny_body<true>(m.a[blockIdx.z], rows_per_split, blockIdx.x, blockIdx.y);
 }
 
 inline void launch_reduce(const spgan_gemm_tn_args& a, int splits, hipStream_t s) {
@@ -2156,6 +2168,27 @@ extern "C" int spgan_splitk_reduce_multi(const spgan_splitk_multi_args* a, spgan
     SPGAN_CHECK_ARG(a->block_start[e + 1] - a->block_start[e] == reduce_blocks(a->splits[e], (long)a->Na[e] * a->Nb[e]));
   }
   hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(a->block_start[a->count]), dim3(256), 0, (hipStream_t)s_, *a);
+  return spgan_launch_status();
+}
+
+// `count` streaming weight-gradient products A^T B with a narrow B (Nb <= 4: the three input coordinates) of ONE shape as one launch; partials only
+// (defer_reduce: the caller sums them with spgan_splitk_reduce_multi, splits = spgan_gemm_tn_splits): the stand-alone kernel's body per problem.
+extern "C" int spgan_gemm_tn_skinny_multi(const spgan_gemm_tn_args* a, int count, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && count >= 1 && count <= SPGAN_GROUP_MAX);
+  TnSkinnyMulti m;
+  for (int g = 0; g < count; ++g) {
+    const spgan_gemm_tn_args& q = a[g];
+    SPGAN_CHECK_ARG(q.A && q.B && q.ws && q.M > 0 && q.M < (1 << 24) && q.Na > 0 && q.Nb > 0 && q.Nb <= 4 && tn_skinny(q.Na, q.Nb));
+    SPGAN_CHECK_ARG(q.M == a[0].M && q.Na == a[0].Na && q.Nb == a[0].Nb && q.lda >= q.Na && q.ldb >= q.Nb);
+    SPGAN_CHECK_ARG(q.b_mode == SPGAN_A_PLAIN && q.defer_reduce && !q.a_colsum_ws && !q.b_half && !q.a_half && !q.a_lrelu && !q.a_sp_val);
+    SPGAN_CHECK_ARG(q.ws_bytes >= spgan_gemm_tn_ws_bytes(q.M, q.Na, q.Nb));
+    if (q.A2) SPGAN_CHECK_ARG(q.a_scale && q.a_scale2 && q.a_shift && q.lda2 >= q.Na);
+    else SPGAN_CHECK_ARG(!q.a_scale);
+    m.a[g] = q;
+  }
+  int splits, rows;
+  tn_plan(a->M, a->Na, a->Nb, &splits, &rows);
+  hipLaunchKernelGGL(gemm_tn_skinny_multi_kernel, dim3(cdiv(a->Na, 64), splits, count), dim3(256), 0, (hipStream_t)s_, m, rows);
   return spgan_launch_status();
 }
 

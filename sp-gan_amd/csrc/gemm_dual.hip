@@ -44,9 +44,10 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 // A-operand modes (spgan_gemm_dual_args.a_mode)
 constexpr int A_DENSE = 0, A_LAZY2 = 1, A_ACT = 2;
 
+// The body of one workgroup: `bid` of `nblk` workgroups of ONE problem (the stand-alone kernel passes blockIdx.x / gridDim.x; the grouped
+// kernel the workgroup's position inside its problem's block range).
 template <int EK, int NA>   // EK: 0 plain pre tensor, > 0 per-edge operand with EK edges per point (NA = 128 only); NA: columns of dy
-__global__ __launch_bounds__(2 * NA, NA == 128 ? 2 : 1) void gemm_dual_kernel(const spgan_gemm_dual_args p, int chunks_per_wg, int runs, int parts,
-                                                                               int a_mode) {
+__device__ __forceinline__ void gemm_dual_body(const spgan_gemm_dual_args& p, int chunks_per_wg, int runs, int parts, int a_mode, int bid, int nblk) {
   constexpr int T = 2 * NA;            // threads
   constexpr int W_ = NA / 32;          // waves
   constexpr int TPW = 8 / W_;          // 16 x 16 input-gradient tiles per wave (8 tiles: 2 row halves x 4 column sixteenths)
@@ -67,8 +68,8 @@ __global__ __launch_bounds__(2 * NA, NA == 128 ? 2 : 1) void gemm_dual_kernel(co
   // XCD-aware: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs; logical workgroup xcd*per + t goes to XCD xcd, so
   // that an XCD works on CONSECUTIVE row runs and all column parts of a run: the per-edge operand's neighbour rows of one shape (0.5 MB
   // of the point tensor) are gathered through ONE L2, and a run's dy tile is fetched from HBM once for all its parts
-  const int per_xcd = gridDim.x >> 3;
-  const int L = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int per_xcd = nblk >> 3;
+  const int L = (bid & 7) * per_xcd + (bid >> 3);
   if (L >= runs * parts) return;
   const int wg = L / parts, part = L - wg * parts;
   const int c0 = wg * chunks_per_wg;
@@ -320,6 +321,28 @@ __global__ __launch_bounds__(2 * NA, NA == 128 ? 2 : 1) void gemm_dual_kernel(co
     for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2)) * p.Nb + 32 * j] = accw[j][r];
 }
 
+template <int EK, int NA>
+__global__ __launch_bounds__(2 * NA, NA == 128 ? 2 : 1) void gemm_dual_kernel(const spgan_gemm_dual_args p, int chunks_per_wg, int runs, int parts,
+                                                                               int a_mode) {
+  gemm_dual_body<EK, NA>(p, chunks_per_wg, runs, parts, a_mode, blockIdx.x, gridDim.x);
+}
+
+// Grouped launch (spgan_gemm_dual_multi): `count` independent problems of ONE geometry (M, Na, Nb equal; operands, modes, addends and outputs
+// per problem) as one grid -- problem g owns the workgroups [g*grid1, (g+1)*grid1) and runs exactly the stand-alone kernel's body there
+// (grid1 is a multiple of 8: a workgroup's XCD is the same as in the stand-alone launch).  The D step's real / fake backward passes and
+// phase B of the penalty's double backward issue the same layer's launch three times with different operands (Discriminator.py:97-115,
+// gradient_penalty.py:19-37): one launch, the tail of one problem under the head of the next, results bit-identical to the separate ones.
+struct DualMulti {
+  spgan_gemm_dual_args a[SPGAN_GROUP_MAX];
+};
+
+template <int NA>
+__global__ __launch_bounds__(2 * NA, NA == 128 ? 2 : 1) void gemm_dual_multi_kernel(const DualMulti m, int chunks_per_wg, int runs, int parts, int grid1) {
+  const int g = blockIdx.x / grid1;
+  const spgan_gemm_dual_args& p = m.a[g];
+  gemm_dual_body<0, NA>(p, chunks_per_wg, runs, parts, p.a_mode, blockIdx.x - g * grid1, grid1);
+}
+
 // row run -> workgroup plan.  Na = 128: two workgroups per CU resident (LDS) -> 512 slots; Na = 256: one -> 256 slots; the slots are shared
 // by the column parts of a run; at least 4 chunks per run to amortise the W load and the partial store
 inline void dual_plan(int M, int Na, int Nb, int* runs, int* cpw) {
@@ -354,7 +377,7 @@ extern "C" int spgan_gemm_dual_rows_per_wg(int M, int Na, int Nb) {
   return cpw * R;
 }
 
-extern "C" int spgan_gemm_dual(const spgan_gemm_dual_args* a, spgan_stream_t s_) {
+static int dual_check(const spgan_gemm_dual_args* a) {
   SPGAN_CHECK_ARG(a && a->A && a->W && a->B && a->G && a->stats && a->ws && a->b_scale && a->b_shift && a->b_mean && a->b_invstd);
   const int ek = a->e_idx ? a->e_k : 0;
   SPGAN_CHECK_ARG(dual_shape_ok(a->M, a->Na, a->Nb, ek));
@@ -369,6 +392,13 @@ extern "C" int spgan_gemm_dual(const spgan_gemm_dual_args* a, spgan_stream_t s_)
   SPGAN_CHECK_ARG(a->a_mode == A_DENSE || (al(a->p, 4) && al(a->r, 4) && (a->a_mode != A_LAZY2 || al(a->q, 4))));
   SPGAN_CHECK_ARG(!a->e_idx || al(a->e_bias, 4));
   SPGAN_CHECK_ARG(!a->rowadd || (al(a->rowadd, a->ld_rowadd) && a->ld_rowadd >= a->Nb));
+  return SPGAN_OK;
+}
+
+extern "C" int spgan_gemm_dual(const spgan_gemm_dual_args* a, spgan_stream_t s_) {
+  const int rc = dual_check(a);
+  if (rc != SPGAN_OK) return rc;
+  const int ek = a->e_idx ? a->e_k : 0;
   int runs, cpw;
   dual_plan(a->M, a->Na, a->Nb, &runs, &cpw);
   const int parts = a->Nb / NBW;
@@ -380,5 +410,25 @@ extern "C" int spgan_gemm_dual(const spgan_gemm_dual_args* a, spgan_stream_t s_)
   } else {
     hipLaunchKernelGGL((gemm_dual_kernel<0, 256>), dim3(grid), dim3(512), 0, s, *a, cpw, runs, parts, a->a_mode);
   }
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_gemm_dual_multi(const spgan_gemm_dual_args* a, int count, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && count >= 1 && count <= SPGAN_GROUP_MAX);
+  if (count == 1) return spgan_gemm_dual(a, s_);
+  DualMulti m;
+  for (int g = 0; g < count; ++g) {
+    const int rc = dual_check(a + g);
+    if (rc != SPGAN_OK) return rc;
+    SPGAN_CHECK_ARG(!a[g].e_idx && a[g].M == a[0].M && a[g].Na == a[0].Na && a[g].Nb == a[0].Nb);   // one geometry, plain pre tensors
+    m.a[g] = a[g];
+  }
+  int runs, cpw;
+  dual_plan(a->M, a->Na, a->Nb, &runs, &cpw);
+  const int parts = a->Nb / NBW;
+  const int grid1 = ((runs * parts + 7) / 8) * 8;
+  hipStream_t s = (hipStream_t)s_;
+  if (a->Na == 128) hipLaunchKernelGGL((gemm_dual_multi_kernel<128>), dim3(grid1 * count), dim3(256), 0, s, m, cpw, runs, parts, grid1);
+  else hipLaunchKernelGGL((gemm_dual_multi_kernel<256>), dim3(grid1 * count), dim3(512), 0, s, m, cpw, runs, parts, grid1);
   return spgan_launch_status();
 }

@@ -103,16 +103,17 @@ struct BnTail {
   float pb_rM; float* pb_sums; float* pb_dgamma;
 };
 
+// workgroup (bx, by) of a (ceil(C / FC), groups) grid
 template <int FS, int FC>
-__global__ __launch_bounds__(256) void colfinalize_t_kernel(const float* __restrict__ part, int tiles_per_group, int C, int G, int mode,
-                                                            int tile_rows, float* __restrict__ out0, float* __restrict__ out1, const BnTail bn) {
+__device__ __forceinline__ void colfinalize_body(const float* __restrict__ part, int tiles_per_group, int C, int G, int mode, int tile_rows,
+                                                 float* __restrict__ out0, float* __restrict__ out1, const BnTail& bn, int bx, int by) {
   static_assert(FS * FC == 256, "one thread per (slice, column)");
   __shared__ float sn[FS][FC], sa[FS][FC], sb[FS][FC];
   const int cl = threadIdx.x & (FC - 1), sl = threadIdx.x / FC;
-  const int c = blockIdx.x * FC + cl;
+  const int c = bx * FC + cl;
   const bool cok = c < C;
-  const int g_end = bn.seq_groups > 1 ? bn.seq_groups : (int)blockIdx.y + 1;
-  for (int g = bn.seq_groups > 1 ? 0 : (int)blockIdx.y; g < g_end; ++g) {
+  const int g_end = bn.seq_groups > 1 ? bn.seq_groups : by + 1;
+  for (int g = bn.seq_groups > 1 ? 0 : by; g < g_end; ++g) {
   const size_t goff = bn.seq_groups > 1 ? (size_t)g * bn.group_stride : 0;
   if (g > 0 && bn.seq_groups > 1) __syncthreads();  // the LDS exchange of the previous group is done
   float n = 0.f, a = 0.f, b = 0.f;  // mode 0: (count, mean, M2); mode 1: (-, s0, s1)
@@ -214,6 +215,29 @@ __global__ __launch_bounds__(256) void colfinalize_t_kernel(const float* __restr
     }
   }
   }
+}
+
+template <int FS, int FC>
+__global__ __launch_bounds__(256) void colfinalize_t_kernel(const float* __restrict__ part, int tiles_per_group, int C, int G, int mode,
+                                                            int tile_rows, float* __restrict__ out0, float* __restrict__ out1, const BnTail bn) {
+  colfinalize_body<FS, FC>(part, tiles_per_group, C, G, mode, tile_rows, out0, out1, bn, blockIdx.x, blockIdx.y);
+}
+
+// spgan_colstats_finalize_multi: the mode-1 finalize launches (plain sums, optionally with the BatchNorm-backward coefficients or phase B of
+// the double backward as tail) behind the `count` problems of a grouped GEMM launch, as ONE launch: problem blockIdx.y runs the stand-alone
+// kernel's body on its own record set -- bit-identical results.
+struct FinMulti {
+  const float* part[SPGAN_GROUP_MAX];
+  int tiles[SPGAN_GROUP_MAX], C[SPGAN_GROUP_MAX], G[SPGAN_GROUP_MAX], tile_rows[SPGAN_GROUP_MAX];
+  float* out0[SPGAN_GROUP_MAX];
+  float* out1[SPGAN_GROUP_MAX];
+  BnTail bn[SPGAN_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256) void colfinalize_multi_kernel(const FinMulti m) {
+  const int g = blockIdx.y;
+  if ((int)blockIdx.x * 8 >= m.C[g]) return;
+  colfinalize_body<32, 8>(m.part[g], m.tiles[g], m.C[g], m.G[g], 1, m.tile_rows[g], m.out0[g], m.out1[g], m.bn[g], blockIdx.x, 0);
 }
 
 // The grouped BatchNorm finalize (spgan_colstats_finalize_bn_groups) for a handful of groups: the record loads of ALL groups are in
@@ -553,6 +577,31 @@ extern "C" int spgan_colstats_finalize_phaseb(const float* partials, int tiles, 
   bn.pb_U0 = U0; bn.pb_U1 = U1; bn.pb_Ugz = Ugz; bn.pb_S0 = S0; bn.pb_S1 = S1; bn.pb_gamma = gamma; bn.pb_inv = invstd;
   bn.pb_rM = 1.0f / (float)count; bn.pb_sums = sums2C; bn.pb_dgamma = dgamma;
   launch_colfinalize(s, partials, 1, tiles, C, G, 1, tile_rows, s0, s1, bn);
+  return spgan_launch_status();
+}
+
+extern "C" int spgan_colstats_finalize_multi(const spgan_colfinalize_args* a, int count, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && count >= 1 && count <= SPGAN_GROUP_MAX);
+  FinMulti m{};
+  int cmax = 0;
+  for (int g = 0; g < count; ++g) {
+    const spgan_colfinalize_args& q = a[g];
+    const int tr = q.tile_rows > 0 ? q.tile_rows : RT;
+    SPGAN_CHECK_ARG(q.partials && q.s0 && q.s1 && q.tiles > 0 && q.tiles < 2048 && q.C > 0 && q.G > 0 && q.tiles == cdiv(q.G, tr));
+    SPGAN_CHECK_ARG(q.kind >= 0 && q.kind <= 2);
+    m.part[g] = q.partials; m.tiles[g] = q.tiles; m.C[g] = q.C; m.G[g] = q.G; m.tile_rows[g] = tr; m.out0[g] = q.s0; m.out1[g] = q.s1;
+    BnTail& bn = m.bn[g];
+    if (q.kind == 1) {
+      SPGAN_CHECK_ARG(q.coef && q.mean && q.invstd && q.count > 0.f);
+      bn.bwd_coef = q.coef; bn.bwd_mean = q.mean; bn.bwd_invstd = q.invstd; bn.bwd_gamma = q.gamma; bn.bwd_rcount = 1.0f / q.count;
+    } else if (q.kind == 2) {
+      SPGAN_CHECK_ARG(q.U0 && q.U1 && q.Ugz && q.S0 && q.S1 && q.gamma && q.invstd && q.sums && q.dgamma && q.count > 0.f);
+      bn.pb_U0 = q.U0; bn.pb_U1 = q.U1; bn.pb_Ugz = q.Ugz; bn.pb_S0 = q.S0; bn.pb_S1 = q.S1; bn.pb_gamma = q.gamma; bn.pb_inv = q.invstd;
+      bn.pb_rM = 1.0f / q.count; bn.pb_sums = q.sums; bn.pb_dgamma = q.dgamma;
+    }
+    if (q.C > cmax) cmax = q.C;
+  }
+  hipLaunchKernelGGL(colfinalize_multi_kernel, dim3(cdiv(cmax, 8), count), dim3(256), 0, (hipStream_t)s_, m);
   return spgan_launch_status();
 }
 

@@ -75,15 +75,15 @@ __global__ void adain_bwd2_kernel(const float* __restrict__ dout, const float* _
 // 64 channels x 4 shape-lanes per workgroup: the B gathers of a channel are independent loads spread over four threads
 // (one thread per channel walked the shapes one dependent-latency at a time: 25 us for 32 x 1024 values); the four partial
 // sums are combined in a fixed order.
-__global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __restrict__ gpool, const float* __restrict__ pooled,
-                                                             const int32_t* __restrict__ argmax, const float* __restrict__ y, int ld,
-                                                             const float* __restrict__ mean, const float* __restrict__ invstd, float slope, int B,
-                                                             int C, float* __restrict__ gval, float* __restrict__ sums,
-                                                             const float* __restrict__ gamma = nullptr, float rM = 0.f, float* __restrict__ alpha = nullptr,
-                                                             float* __restrict__ beta = nullptr, float* __restrict__ cg = nullptr) {
+__device__ __forceinline__ void pool_bwd_stats_body(int bx, const float* __restrict__ gpool, const float* __restrict__ pooled,
+                                                    const int32_t* __restrict__ argmax, const float* __restrict__ y, int ld,
+                                                    const float* __restrict__ mean, const float* __restrict__ invstd, float slope, int B,
+                                                    int C, float* __restrict__ gval, float* __restrict__ sums,
+                                                    const float* __restrict__ gamma, float rM, float* __restrict__ alpha,
+                                                    float* __restrict__ beta, float* __restrict__ cg) {
   __shared__ float r0[4][64], r1[4][64];
   const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int c = bx * 64 + cl;
   float s0 = 0.f, s1 = 0.f;
   if (c < C) {
     const float mu = mean[c], iv = invstd[c];
@@ -115,6 +115,26 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __rest
     }
     for (int b = bl; b < B; b += 4) cg[(size_t)b * C + c] = gval[(size_t)b * C + c] * coef;   // this thread wrote gval[b,c] itself
   }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __restrict__ gpool, const float* __restrict__ pooled,
+                                                             const int32_t* __restrict__ argmax, const float* __restrict__ y, int ld,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, float slope, int B,
+                                                             int C, float* __restrict__ gval, float* __restrict__ sums,
+                                                             const float* __restrict__ gamma = nullptr, float rM = 0.f, float* __restrict__ alpha = nullptr,
+                                                             float* __restrict__ beta = nullptr, float* __restrict__ cg = nullptr) {
+  pool_bwd_stats_body(blockIdx.x, gpool, pooled, argmax, y, ld, mean, invstd, slope, B, C, gval, sums, gamma, rM, alpha, beta, cg);
+}
+
+// spgan_pool_bwd_stats_prep for several passes (blockIdx.y) as one launch: the stand-alone kernel's body per pass
+struct PoolBwdMulti {
+  spgan_pool_bwd_args a[SPGAN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void pool_bwd_stats_multi_kernel(const PoolBwdMulti m) {
+  const spgan_pool_bwd_args& q = m.a[blockIdx.y];
+  if ((int)blockIdx.x * 64 >= q.C) return;
+  pool_bwd_stats_body(blockIdx.x, q.gpool, q.pooled, q.argmax, q.y, q.ld, q.mean, q.invstd, q.slope, q.B, q.C, q.gval, q.sums, q.gamma,
+                      1.0f / (float)q.count, q.alpha, q.beta, q.cg);
 }
 
 // dy[m,c] = gamma*invstd*( (argmax[b,c]==m ? gval[b,c] : 0) - sums[c]/count - xhat*sums[C+c]/count )
@@ -543,6 +563,21 @@ extern "C" int spgan_pool_bwd_stats_prep(const float* gpool, const float* pooled
   return spgan_launch_status();
 }
 
+extern "C" int spgan_pool_bwd_stats_prep_multi(const spgan_pool_bwd_args* a, int count, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && count >= 1 && count <= SPGAN_GROUP_MAX);
+  PoolBwdMulti m;
+  int cmax = 0;
+  for (int g = 0; g < count; ++g) {
+    const spgan_pool_bwd_args& q = a[g];
+    SPGAN_CHECK_ARG(q.gpool && q.pooled && q.argmax && q.y && q.mean && q.invstd && q.gval && q.sums && q.gamma && q.alpha && q.beta && q.cg &&
+                    q.B > 0 && q.C > 0 && q.ld >= q.C && q.count > 0);
+    m.a[g] = q;
+    if (q.C > cmax) cmax = q.C;
+  }
+  hipLaunchKernelGGL(pool_bwd_stats_multi_kernel, dim3(cdiv(cmax, 64), count), dim3(256), 0, (hipStream_t)s_, m);
+  return spgan_launch_status();
+}
+
 extern "C" int spgan_bn_bwd_apply_sparse(const float* gval, const int32_t* argmax, const float* y, int ld, int M, int C, int N,
                                          const float* mean, const float* invstd, const float* gamma, const float* sums, int count, float* dy,
                                          spgan_stream_t s_) {
@@ -748,6 +783,56 @@ extern "C" int spgan_multi_add3(const spgan_multi_add3_args* a, spgan_stream_t s
   int bx = cdiv(nmax, 256 * 4);
   if (bx > 128) bx = 128;
   hipLaunchKernelGGL(multi_add3_kernel, dim3(bx, a->count), dim3(256), 0, (hipStream_t)s_, *a);
+  return spgan_launch_status();
+}
+
+// dst[t] = ((dst[t] + src[0][t]) + src[1][t]) + src[2][t] (nsrc[t] of them, in this order): the parameter gradients of several passes that one grouped
+// backward produced separately, accumulated in ONE launch with the sums of as many successive spgan_multi_add launches (same order per element)
+__global__ void multi_addn_kernel(const spgan_multi_addn_args a) {
+  const int t = blockIdx.y;
+  const int n = a.n[t], ns = a.nsrc[t];
+  float* __restrict__ d = a.dst[t];
+  const float* __restrict__ s0 = a.src[0][t];
+  const float* __restrict__ s1 = a.src[1][t];
+  const float* __restrict__ s2 = a.src[2][t];
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gthreads = gridDim.x * blockDim.x;
+  bool al = (((uintptr_t)d | (uintptr_t)s0) & 15) == 0 && (n & 3) == 0;
+  if (ns > 1) al = al && ((uintptr_t)s1 & 15) == 0;
+  if (ns > 2) al = al && ((uintptr_t)s2 & 15) == 0;
+  if (al) {
+    float4* d4 = reinterpret_cast<float4*>(d);
+    for (int i = gtid; i < (n >> 2); i += gthreads) {
+      float4 x = d4[i];
+      const float4 y0 = reinterpret_cast<const float4*>(s0)[i];
+      float4 y1 = make_float4(0.f, 0.f, 0.f, 0.f), y2 = y1;
+      if (ns > 1) y1 = reinterpret_cast<const float4*>(s1)[i];
+      if (ns > 2) y2 = reinterpret_cast<const float4*>(s2)[i];
+      x.x += y0.x; x.y += y0.y; x.z += y0.z; x.w += y0.w;
+      if (ns > 1) { x.x += y1.x; x.y += y1.y; x.z += y1.z; x.w += y1.w; }
+      if (ns > 2) { x.x += y2.x; x.y += y2.y; x.z += y2.z; x.w += y2.w; }
+      d4[i] = x;
+    }
+    return;
+  }
+  for (int i = gtid; i < n; i += gthreads) {
+    float x = d[i] + s0[i];
+    if (ns > 1) x += s1[i];
+    if (ns > 2) x += s2[i];
+    d[i] = x;
+  }
+}
+
+extern "C" int spgan_multi_addn(const spgan_multi_addn_args* a, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(a && a->count > 0 && a->count <= SPGAN_MULTI_ADDN_MAX);
+  int nmax = 0;
+  for (int t = 0; t < a->count; ++t) {
+    SPGAN_CHECK_ARG(a->dst[t] && a->n[t] > 0 && a->nsrc[t] >= 1 && a->nsrc[t] <= 3);
+    for (int j = 0; j < a->nsrc[t]; ++j) SPGAN_CHECK_ARG(a->src[j][t]);
+    nmax = a->n[t] > nmax ? a->n[t] : nmax;
+  }
+  int bx = cdiv(nmax, 256 * 4);
+  if (bx > 128) bx = 128;
+  hipLaunchKernelGGL(multi_addn_kernel, dim3(bx, a->count), dim3(256), 0, (hipStream_t)s_, *a);
   return spgan_launch_status();
 }
 

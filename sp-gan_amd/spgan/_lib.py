@@ -103,11 +103,37 @@ class MultiAdd3Args(C.Structure):
                 ("n1", C.c_int * MULTI_MAX), ("n2", C.c_int * MULTI_MAX), ("ds", (C.c_long * MULTI_MAX) * 3), ("ss", (C.c_long * MULTI_MAX) * 3)]
 
 
+GROUP_MAX = 4           # SPGAN_GROUP_MAX: problems per grouped launch
+
+
 class CollapsePrepArgs(C.Structure):
     _fields_ = [("W", C.c_void_p), ("ldw", C.c_int), ("C", C.c_int), ("K", C.c_int), ("nprob", C.c_int),
-                ("alpha", C.c_void_p * 2), ("beta", C.c_void_p * 2), ("bias", C.c_void_p * 2), ("G", C.c_void_p * 2), ("ldg", C.c_int),
-                ("cvec", C.c_void_p * 2), ("sp_val", C.c_void_p), ("sp_arg", C.c_void_p), ("B", C.c_int), ("rows", C.c_int),
-                ("E", C.c_void_p), ("lde", C.c_int)]
+                ("alpha", C.c_void_p * GROUP_MAX), ("beta", C.c_void_p * GROUP_MAX), ("bias", C.c_void_p * GROUP_MAX), ("G", C.c_void_p * GROUP_MAX),
+                ("ldg", C.c_int), ("cvec", C.c_void_p * GROUP_MAX), ("nsparse", C.c_int), ("sp_val", C.c_void_p * GROUP_MAX),
+                ("sp_arg", C.c_void_p * GROUP_MAX), ("B", C.c_int), ("rows", C.c_int), ("E", C.c_void_p * GROUP_MAX), ("lde", C.c_int)]
+
+
+class ColFinalizeArgs(C.Structure):
+    _fields_ = [("partials", C.c_void_p), ("tiles", C.c_int), ("C", C.c_int), ("G", C.c_int), ("tile_rows", C.c_int),
+                ("s0", C.c_void_p), ("s1", C.c_void_p), ("kind", C.c_int),
+                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p), ("count", C.c_float), ("coef", C.c_void_p),
+                ("U0", C.c_void_p), ("U1", C.c_void_p), ("Ugz", C.c_void_p), ("S0", C.c_void_p), ("S1", C.c_void_p),
+                ("sums", C.c_void_p), ("dgamma", C.c_void_p)]
+
+
+class PoolBwdArgs(C.Structure):
+    _fields_ = [("gpool", C.c_void_p), ("pooled", C.c_void_p), ("argmax", C.c_void_p), ("y", C.c_void_p), ("ld", C.c_int),
+                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("slope", C.c_float), ("B", C.c_int), ("C", C.c_int),
+                ("gamma", C.c_void_p), ("count", C.c_int),
+                ("gval", C.c_void_p), ("sums", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p), ("cg", C.c_void_p)]
+
+
+MULTI_ADDN_MAX = 32
+
+
+class MultiAddNArgs(C.Structure):
+    _fields_ = [("count", C.c_int), ("dst", C.c_void_p * MULTI_ADDN_MAX), ("src", (C.c_void_p * MULTI_ADDN_MAX) * 3),
+                ("nsrc", C.c_int * MULTI_ADDN_MAX), ("n", C.c_int * MULTI_ADDN_MAX)]
 
 
 class WgradCollapseArgs(C.Structure):
@@ -155,6 +181,7 @@ SIGNATURES = {
     "spgan_pool_finalize_groups": (I, [P, P, I, I, I, P, P, I, I, F, P, P, P, I, P]),
     "spgan_gemm_tn_ws_bytes": (SZ, [I, I, I]),
     "spgan_gemm_tn": (I, [C.POINTER(GemmTNArgs), P]),
+    "spgan_gemm_tn_skinny_multi": (I, [C.POINTER(GemmTNArgs), I, P]),
     "spgan_sparse_rows_nt": (I, [P, P, I, I, I, P, I, I, P, I, P]),
     "spgan_sparse_rows_tn": (I, [P, P, I, I, I, P, I, I, P, P, F, P, I, P]),
     "spgan_affine_act": (I, [P, I, SZ, I, P, P, F, P, P]),
@@ -218,9 +245,13 @@ SIGNATURES = {
     "spgan_wt_diag_w": (I, [P, I, I, I, P, P, P, P, I, P, P]),
     "spgan_collapse_prep": (I, [C.POINTER(CollapsePrepArgs), P]),
     "spgan_wgrad_collapse": (I, [C.POINTER(WgradCollapseArgs), P]),
+    "spgan_wgrad_collapse_multi": (I, [C.POINTER(WgradCollapseArgs), I, P]),
     "spgan_gemm_dual_wgs": (I, [I, I, I, I]),
     "spgan_gemm_dual_rows_per_wg": (I, [I, I, I]),
     "spgan_gemm_dual": (I, [C.POINTER(GemmDualArgs), P]),
+    "spgan_gemm_dual_multi": (I, [C.POINTER(GemmDualArgs), I, P]),
+    "spgan_colstats_finalize_multi": (I, [C.POINTER(ColFinalizeArgs), I, P]),
+    "spgan_pool_bwd_stats_prep_multi": (I, [C.POINTER(PoolBwdArgs), I, P]),
     "spgan_gather_csr": (I, [P, I, I, I, P, P, P, P]),
     "spgan_scatter_slots": (I, [P, I, I, I, P, P, I, P, P]),
     "spgan_group_center_bwd": (I, [P, I, I, I, I, P, P]),
@@ -243,6 +274,7 @@ SIGNATURES = {
     "spgan_scale_residual_bwd_ws_bytes": (SZ, [SZ]),
     "spgan_scale_residual_bwd": (I, [P, P, P, P, P, P, SZ, SZ, P]),
     "spgan_multi_add": (I, [C.POINTER(MultiAddArgs), P]),
+    "spgan_multi_addn": (I, [C.POINTER(MultiAddNArgs), P]),
     "spgan_multi_add3": (I, [C.POINTER(MultiAdd3Args), P]),
     "spgan_reduce_chunks": (I, [P, I, C.c_size_t, P, P]),
     "spgan_bn_bwd_coeffs": (I, [P, P, P, P, I, F, P, P]),

@@ -226,6 +226,64 @@ class DStackFn(Function):
         return (None, dx) + _deliver(params, [grads.get(n) for n in names], ctx.needs_input_grad[2:], ctx.fused)
 
 
+class DStacksJointFn(Function):
+    """The conv stacks of the D step's passes behind ONE node, so that their backward work runs in lock step (nets.d_backward_joint):
+    outputs = (pooled of every first-order pass ..., gx) with gx = d sum(D(x_hat)) / d x_hat of the `hat` pass (WGAN-GP,
+    Common/gradient_penalty.py:28-33; its head and first-order backward run inside this forward).  The backward receives the pooled
+    gradients of the first-order passes (from DHeadFn) and the penalty's seed on gx -- the double backward -- together: every layer's
+    launch is issued once for all of them.  inputs: holder(names, firsts=[(pooled, dctx)], hat=(pooled, dctx) | None), *all D params."""
+
+    @staticmethod
+    def forward(ctx, holder, *params):
+        _record_modes(ctx, holder)
+        outs = [pooled for pooled, _ in holder.firsts]
+        ctx.saved_hat = None
+        if holder.hat is not None:
+            P = dict(zip(holder.names, params))
+            pooled_h, dctx_h = holder.hat
+            logits, dctx_h["hs"] = nets.d_head_forward(P, pooled_h)
+            dx, _, ctx.saved_hat = nets.d_backward(P, dctx_h, torch.ones_like(logits), True, False, keep_for_double=True)
+            outs.append(dx)
+        ctx.holder = holder
+        ctx.save_for_backward(*params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        params = ctx.saved_tensors
+        h = ctx.holder
+        names = h.names
+        P = dict(zip(names, [nets.owned(p) for p in params]))
+        nf = len(h.firsts)
+        firsts = [(dctx, g.detach()) for (_, dctx), g in zip(h.firsts, gouts[:nf]) if g is not None]
+        dbl = None
+        if h.hat is not None and gouts[nf] is not None:
+            dbl = (h.hat[1], ctx.saved_hat, gouts[nf].detach())
+        fg, hg = nets.d_backward_joint(P, firsts, dbl)
+        chains = list(fg) + ([hg] if hg is not None else [])
+        ops.flush_tn()
+        needs = ctx.needs_input_grad[1:]
+        fused = ctx.fused and not torch.is_grad_enabled()
+        out: List[Optional[Tensor]] = [None] * len(params)
+        dsts, srcs = [], []
+        for i, (n, p_, need) in enumerate(zip(names, params, needs)):
+            if not need:
+                continue
+            gs = [c[n] for c in chains if n in c and not isinstance(c[n], int)]
+            if not gs:
+                continue
+            if fused and p_.is_leaf and p_.grad is not None and p_.grad.is_contiguous() and all(g.numel() == p_.grad.numel() for g in gs):
+                dsts.append(p_.grad); srcs.append(gs)
+            else:
+                tot = gs[0]
+                for g in gs[1:]:
+                    tot = tot + g
+                out[i] = tot.view_as(p_)
+        if dsts:
+            ops.multi_addn(dsts, srcs)      # one launch: ((grad + real) + fake) + double backward, per parameter
+        return (None,) + tuple(out)
+
+
 class JoinRowsFn(Function):
     """cat(parts, dim=0) for the pooled features of passes that one grouped launch wrote as consecutive row blocks of ONE buffer: then the result
     is a view of that buffer (ops.stacked_rows: no copy launch); backward hands every part its row block of the gradient (views)."""

@@ -203,6 +203,14 @@ class GradientPenalty:
         v = ops.gp_penalty_bwd(g, norms, float(self.gamma), float(self.lambdaGP), None)
         return loss, grads, v.view_as(grads)
 
+    def from_input_gradient(self, grads: torch.Tensor, B: int):
+        """(penalty [1], seed) for an input gradient that is already there (TrainStep's joint D-step node, Discriminator.stacks_joint): the
+        penalty of gradient_penalty.py:31-35 and v = d penalty / d grads, the seed of the double backward."""
+        g = grads.detach().contiguous().view(B, -1)
+        loss, norms = ops.gp_penalty_fwd(g, float(self.gamma), float(self.lambdaGP))
+        v = ops.gp_penalty_bwd(g, norms, float(self.gamma), float(self.lambdaGP), None)
+        return loss, v.view_as(grads)
+
     def interpolate(self, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False):
         """x_hat [B,3,N] (detached): the points the penalty is evaluated at."""
         B = real_data.size(0)

@@ -483,6 +483,24 @@ def _discriminator_forward_heads(self, pooled):
     return list(outs)
 
 
+def _discriminator_stacks_joint(self, firsts, hat=None):
+    """The D step's passes behind one autograd node (Fn.DStacksJointFn): firsts / hat are entries of forward_stacks_grouped(...).
+    -> [pooled of every first-order pass ..., gx] with gx = d sum(D(x_hat)) / d x_hat of the `hat` entry (differentiable once more: its
+    backward is the penalty's double backward).  The backward work of all these passes then runs in lock step, every layer's launch issued
+    once (nets.d_backward_joint) -- results as from forward_stack(pre=...) per pass and the WGAN-GP route of forward(pre=...)."""
+    names, params = _named(self)
+    h = _Holder(names=names, firsts=list(firsts), hat=hat)
+    return list(Fn.DStacksJointFn.apply(h, *params))
+
+
+def _discriminator_joint_ok(self, entries) -> bool:
+    from . import nets
+    names, params = _named(self)
+    return nets.d_joint_ok(dict(zip(names, params)), [c for _, c in entries])
+
+
+Discriminator.stacks_joint = _discriminator_stacks_joint
+Discriminator.joint_ok = _discriminator_joint_ok
 Discriminator.forward_many = _discriminator_forward_many
 Discriminator.forward_stack = _discriminator_forward_stack
 Discriminator.forward_heads = _discriminator_forward_heads

@@ -598,12 +598,17 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
     Phase A walks the first-order backward graph in reverse (layer 1 -> top), phase B is an ordinary
     backward sweep of the adjoints that phase A deposits on the forward activations (derivation in
     DESIGN.md).  Returns ({name: grad}, dR/dx [B,3,N] | None)."""
+    grads, top, coeffs, xbarA = _d_double_phase_a(P, ctx, saved, v_dx_cm)
+    return _d_double_phase_b(P, ctx, grads, top, coeffs, xbarA, need_dx)
+
+
+def _d_double_phase_a(P, ctx, saved, v_dx_cm: Tensor):
+    """Phase A of d_double_backward (the first-order backward graph in reverse, layer 1 -> top -> MLP head) -> (grads so far, top, coeffs, xbarA)."""
     B, N = ctx["B"], ctx["N"]
     M = B * N
     ys, bns, hs, pooled, argmax = ctx["ys"], ctx["bns"], ctx["hs"], ctx["pooled"], ctx["argmax"]
     dys, gs, sums_all = saved["dys"], saved["gs"], saved["sums"]
     grads: Dict[str, Tensor] = {}
-    rM = 1.0 / M
     q = v_dx_cm.contiguous() if ctx.get("pm_io") else ops.cm_to_pm(v_dx_cm.contiguous())     # adjoint of ga_0 [M,3]
     xbarA: List[Optional[Tensor]] = [None] * 4                   # phase-A adjoint on xhat_l
     coeffs: list = [None] * 4                                    # per-channel phase-A sums (see ops.bn_dbl_coeffs / bn_dbl_phaseb)
@@ -642,6 +647,14 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         grads[name + ".bias"] = ZERO_GRAD
         if li < 3:
             t = ops.gemm_nt_maskout(t, P[name + ".weight"], hs[li], NEG)
+    return grads, top, coeffs, xbarA
+
+
+def _d_double_phase_b(P, ctx, grads, top, coeffs, xbarA, need_dx: bool):
+    """Phase B of d_double_backward: an ordinary backward sweep of the adjoints phase A deposited on the forward activations."""
+    B, N = ctx["B"], ctx["N"]
+    M = B * N
+    ys, bns = ctx["ys"], ctx["bns"]
     # ---------------------------------------------------------------- phase B
     abar_g = None      # (abar_l * mask_l) and its column sums, produced by the dgrad epilogue of layer l+1
     dx = None
@@ -687,6 +700,143 @@ def d_double_backward(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):
         grads[conv + ".weight"] = gA.view_as(P[conv + ".weight"])
         grads[conv + ".bias"] = ZERO_GRAD
     return grads, dx
+
+
+def d_joint_ok(P, ctxs) -> bool:
+    """Can d_backward_joint run these passes in lock step?  Train-mode contexts of one shape from the grouped forward (the 1024-wide layer
+    collapsed: no stored y4), every layer on its fused launch (ops.gemm_dual / wgrad_collapse / the lazy BatchNorm-backward operand)."""
+    if not ctxs or not ops.GROUPED[0]:
+        return False
+    c0 = ctxs[0]
+    B, N = c0["B"], c0["N"]
+    M = B * N
+    for c in ctxs:
+        if not c["training"] or (c["B"], c["N"]) != (B, N) or c["ys"][3] is not None or c.get("yarg") is None:
+            return False
+    W4 = _w2(P[D_LAYERS[3][0] + ".weight"])
+    if W4.shape[0] % 256 or W4.shape[1] % 32 or W4.shape[1] > 256 or B > 64:
+        return False
+    ys = c0["ys"]
+    sc3, sh3 = c0["bns"][2][0], c0["bns"][2][1]
+    if not ops.gemm_dual_ok(ops.ActOperand(ys[2], sc3, sh3, NEG), W4[:W4.shape[1]], ys[2]):       # the collapsed layer: dy := a3, W := a [K,K] matrix
+        return False
+    for li in (2, 1):
+        W = _w2(P[D_LAYERS[li][0] + ".weight"])
+        if not (_lazy_ok(M, W.shape[0]) and ops.gemm_dual_ok(ys[li], W, ys[li - 1])):
+            return False
+    return _lazy_ok(M, ys[0].shape[1]) and ys[2].shape[1] % 32 == 0
+
+
+def d_backward_joint(P, firsts, dbl=None):
+    """The D step's backward work on the conv stack in LOCK STEP (Generation/Discriminator.py:97-115 is called three times per D step,
+    Common/gradient_penalty.py:19-37 differentiates the third call twice): `firsts` = [(ctx, gpool), ...] first-order passes that need parameter
+    gradients (the real and the fake pass: d_backward(P, ctx, None, False, True, gpool=gpool)), `dbl` = (ctx, saved, v) the penalty's double
+    backward (d_double_backward(P, ctx, saved, v)).  Phase A of the double backward runs first; then every layer's launch is issued ONCE for all
+    passes (ops.*_multi: the passes' problems on consecutive workgroup ranges of one grid; the first-order passes meet phase B of the double
+    backward at the collapsed 1024-wide layer and walk down together).  Every pass computes exactly what its separate call computes -- the
+    results are bit-identical (tests/test_parity_gpu.py::test_d_backward_joint_equals_separate_calls).
+    -> ([grads of each first-order pass], grads of the double backward | None)."""
+    nf = len(firsts)
+    ctxs = [c for c, _ in firsts] + ([dbl[0]] if dbl is not None else [])
+    c0 = ctxs[0]
+    B, N = c0["B"], c0["N"]
+    M = B * N
+    conv4, bn4 = D_LAYERS[3]
+    W4, b4 = _w2(P[conv4 + ".weight"]), P[conv4 + ".bias"]
+    C4 = W4.shape[0]
+    G: List[Dict[str, Tensor]] = [dict() for _ in ctxs]
+    hot = None
+    if dbl is not None:
+        hctx, hsaved, v = dbl
+        hg, top, coeffs, xbarA = _d_double_phase_a(P, hctx, hsaved, v)
+        if top is None:
+            raise RuntimeError("d_backward_joint: the double backward's context is not the collapsed one (see d_joint_ok)")
+        G[nf] = hg
+        c4 = top["c4"]
+        hg[bn4 + ".weight"] = c4[0]; hg[bn4 + ".bias"] = ZERO_GRAD
+        hot = dict(c1=c4[1], c2=c4[2], c3=c4[3], spB=top["spB"], q3=top["q3"], Qqa=top["Qqa"])
+    # ---- max-pool + BN4 of the first-order passes (sparse incoming gradient), one launch
+    dys = []
+    if nf:
+        outs = ops.pool_bwd_stats_multi([dict(gpool=gp.contiguous(), pooled=c["pooled"], argmax=c["argmax"], y=c["yarg"], mean=c["bns"][3][3],
+                                              invstd=c["bns"][3][2], slope=NEG, prep=(P[bn4 + ".weight"], M, None, N)) for c, gp in firsts])
+        for i, (gval, sums4, dy) in enumerate(outs):
+            G[i][bn4 + ".weight"] = sums4[C4:]; G[i][bn4 + ".bias"] = sums4[:C4]
+            dys.append(dy)
+    # ---- the collapsed 256 -> 1024 layer (see d_backward / _d_double_top_phase_b): its weight-only operands and sparse-row products, one launch
+    problems = [(dy.alpha, dy.beta, b4) for dy in dys]
+    vals, args_ = [dy.sp_val for dy in dys], [dy.sp_arg for dy in dys]
+    if hot is not None:
+        problems += [(hot["c1"], None, None), (hot["c2"], hot["c3"], b4)]
+        vals.append(hot["spB"]); args_.append(hctx["argmax"])
+    outs, Es = ops.collapse_prep(W4, problems, vals, args_, N)
+    bn3 = D_LAYERS[2][1]
+    specs = []
+    for i, (c, _) in enumerate(firsts):
+        sc, sh, inv, mu = c["bns"][2]
+        G4, cvec = outs[i]
+        specs.append(dict(dy=ops.ActOperand(c["ys"][2], sc, sh, NEG), W=G4, y_ref=c["ys"][2], scale=sc, shift=sh, mean=mu, invstd=inv, slope=NEG,
+                          bias=cvec, rowadd=Es[i], with_colsum=True, coef_bn=(P[bn3 + ".weight"], M)))
+    if hot is not None:
+        psc, psh, pinv, pmu = hctx["bns"][2]
+        G1, (G2, cvec) = outs[nf], outs[nf + 1]
+        part = ops.gemm_nt(hot["q3"], G1, rowbias=Es[nf], rows_per_group=1)
+        specs.append(dict(dy=ops.ActOperand(hctx["ys"][2], psc, psh, NEG), W=G2, y_ref=hctx["ys"][2], scale=psc, shift=psh, mean=pmu, invstd=pinv,
+                          slope=NEG, bias=cvec, rowadd=part, with_colsum=True, phaseb=((coeffs[2], P[bn3 + ".weight"], pinv))))
+    res = ops.gemm_dual_multi(specs, defer=False)
+    wspecs, lazies, abar_g = [], [], None
+    for i, (c, _) in enumerate(firsts):
+        gram, g, s0, s1, coef, cs3 = res[i]
+        sc, sh = c["bns"][2][0], c["bns"][2][1]
+        wspecs.append(dict(W=W4, X1=gram, a1=dys[i].alpha, b1=b4, d1=dys[i].beta, v1=cs3, sparse=(dys[i].sp_val, dys[i].sp_arg, N, c["ys"][2], (sc, sh, NEG))))
+        G[i][bn3 + ".weight"] = s1; G[i][bn3 + ".bias"] = s0
+        lazies.append(ops.Affine2(g, c["ys"][2], coef))
+    if hot is not None:
+        gram, g_, s0_, s1_, cs3, sums_, dg_ = res[nf]
+        abar_g = (g_, s0_, s1_, sums_, dg_)
+        wspecs.append(dict(W=W4, X1=gram, a1=hot["c2"], b1=b4, d1=hot["c3"], v1=cs3, X2=hot["Qqa"], x2_t=True, a2=hot["c1"],
+                           sparse=(hot["spB"], hctx["argmax"], N, hctx["ys"][2], (psc, psh, NEG)), out=G[nf][conv4 + ".weight"], accumulate=True))
+    dWs = ops.wgrad_collapse_multi(wspecs)
+    for i in range(len(ctxs)):
+        G[i][conv4 + ".weight"] = dWs[i].view_as(P[conv4 + ".weight"]); G[i][conv4 + ".bias"] = ZERO_GRAD
+    # ---- mlps.6 <- mlps.3 <- mlps.0
+    for li in (2, 1, 0):
+        conv, bn = D_LAYERS[li]
+        W = _w2(P[conv + ".weight"])
+        ybar = None
+        if hot is not None:
+            # phase B of layer li: the adjoint X = xbarA + gamma*g through the BatchNorm backward (sums from the finalize launch above)
+            sc, sh, inv, mu = hctx["bns"][li]
+            g, s0, s1, sums, dgam = abar_g
+            G[nf][bn + ".weight"] = dgam; G[nf][bn + ".bias"] = s0
+            ybar = ops.bn_bwd_apply(xbarA[li], hctx["ys"][li], mu, inv, None, sums, M, add=(g, P[bn + ".weight"]))
+        if li == 0:
+            tsp = [dict(A=lazies[i], Bm=c["x_pm"]) for i, (c, _) in enumerate(firsts)]
+            if hot is not None:
+                tsp.append(dict(A=ybar, Bm=hctx["x_pm"], out=G[nf][conv + ".weight"], beta=1.0))
+            for i, dW in enumerate(ops.gemm_tn_narrow_multi(tsp)):
+                G[i][conv + ".weight"] = dW.view_as(P[conv + ".weight"]); G[i][conv + ".bias"] = ZERO_GRAD
+            break
+        pbn = D_LAYERS[li - 1][1]
+        specs = []
+        for i, (c, _) in enumerate(firsts):
+            sc, sh, inv, mu = c["bns"][li - 1]
+            specs.append(dict(dy=lazies[i], W=W, y_ref=c["ys"][li - 1], scale=sc, shift=sh, mean=mu, invstd=inv, slope=NEG, coef_bn=(P[pbn + ".weight"], M)))
+        if hot is not None:
+            psc, psh, pinv, pmu = hctx["bns"][li - 1]
+            specs.append(dict(dy=ybar, W=W, y_ref=hctx["ys"][li - 1], scale=psc, shift=psh, mean=pmu, invstd=pinv, slope=NEG, out=G[nf][conv + ".weight"],
+                              beta=1.0, phaseb=(coeffs[li - 1], P[pbn + ".weight"], pinv)))
+        res = ops.gemm_dual_multi(specs)
+        for i, (c, _) in enumerate(firsts):
+            dW, g, s0, s1, coef = res[i]
+            G[i][conv + ".weight"] = dW.view_as(P[conv + ".weight"]); G[i][conv + ".bias"] = ZERO_GRAD
+            G[i][pbn + ".weight"] = s1; G[i][pbn + ".bias"] = s0
+            lazies[i] = ops.Affine2(g, c["ys"][li - 1], coef)
+        if hot is not None:
+            dW, *abar = res[nf]
+            abar_g = tuple(abar)
+            G[nf][conv + ".weight"] = dW.view_as(P[conv + ".weight"]); G[nf][conv + ".bias"] = ZERO_GRAD
+    return G[:nf], (G[nf] if dbl is not None else None)
 
 
 def d_double_backward_eval(P, ctx, saved, v_dx_cm: Tensor, need_dx: bool = False):

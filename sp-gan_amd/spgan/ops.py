@@ -717,6 +717,45 @@ def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: 
     flush_tn(); out / beta: dW = beta*out + sum (accumulated in place).
     phaseb = ((U0, U1, Ugz, S0, S1, count), gamma, invstd) of the layer BELOW (the double backward): the finalize launch also runs
     bn_dbl_phaseb on the sums it merges -> the return tuple ends with (sums [2Nb], dgamma [Nb])."""
+    b = _gemm_dual_build(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=edge, out=out, beta=beta, bias=bias, rowadd=rowadd, with_colsum=with_colsum)
+    a = b["a"]
+    done = launch_timer("gemm_dual", a) if launch_timer is not None else None
+    check(_lib.load().spgan_gemm_dual(C.byref(a), _s()), "gemm_dual", M=b["M"], Na=b["Na"], Nb=b["Nb"], k=b["ek"])
+    if done is not None:
+        done()
+    _gemm_dual_pending(b)
+    if not defer:
+        flush_tn()
+    lib = _lib.load()
+    M_, Nb, runs, rows_wg, part = b["M"], b["Nb"], b["runs"], b["rows_wg"], b["part"]
+    dW, g = b["dW"], b["g"]
+    extra = () if b["cs_out"] is None else (b["cs_out"],)
+    if coef_bn is not None:
+        gamma, count = coef_bn
+        fin = torch.empty((2, Nb), dtype=torch.float32, device=g.device)
+        coef = torch.empty((3, Nb), dtype=torch.float32, device=g.device)
+        check(lib.spgan_colstats_finalize_bnbwd(_p(part), runs, Nb, M_, rows_wg, _p(_vec(mean, Nb, "mean")), _p(_vec(invstd, Nb, "invstd")),
+                                                _p(None if gamma is None else _vec(gamma, Nb, "gamma")), float(count), _p(fin[0]), _p(fin[1]), _p(coef), _s()),
+              "colstats_finalize_bnbwd", N=Nb, M=M_)
+        return (dW, g, fin[0], fin[1], coef) + extra
+    if phaseb is not None:
+        (U0, U1, Ugz, S0, S1, count), pg, pinv = phaseb
+        fin = torch.empty((2, Nb), dtype=torch.float32, device=g.device)
+        sums = torch.empty((2 * Nb,), dtype=torch.float32, device=g.device)
+        dg = torch.empty((Nb,), dtype=torch.float32, device=g.device)
+        v = lambda t, n: _p(_vec(t.contiguous(), Nb, n))
+        check(lib.spgan_colstats_finalize_phaseb(_p(part), runs, Nb, M_, rows_wg, v(U0, "U0"), v(U1, "U1"), v(Ugz, "Ugz"), v(S0, "S0"), v(S1, "S1"),
+                                                 v(pg, "gamma"), v(pinv, "invstd"), int(count), _p(fin[0]), _p(fin[1]), _p(sums), _p(dg), _s()),
+              "colstats_finalize_phaseb", N=Nb, M=M_)
+        return (dW, g, fin[0], fin[1]) + extra + (sums, dg)
+    s0, s1 = _finalize(part, 1, runs, Nb, M_, 1, rows_wg)
+    return (dW, g, s0[0], s1[0]) + extra
+
+
+def _gemm_dual_build(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float, edge=None,
+                     out: Optional[Tensor] = None, beta: float = 0.0, bias: Optional[Tensor] = None, rowadd: Optional[Tensor] = None,
+                     with_colsum: bool = False) -> dict:
+    """The argument block and the output / workspace tensors of one spgan_gemm_dual problem (shared by the stand-alone and the grouped launch)."""
     a2 = dy if isinstance(dy, Affine2) else None
     act = dy if isinstance(dy, ActOperand) else None
     A = a2.g if a2 is not None else (act.x if act is not None else dy)
@@ -776,36 +815,70 @@ def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: 
         a.colsum_ws = _p(cs_ws)
     a.G = _p(g); a.ldg = Nb; a.stats = _p(part); a.ws = _p(ws)
     a.M, a.Na, a.Nb = M_, Na, Nb
-    done = launch_timer("gemm_dual", a) if launch_timer is not None else None
-    check(lib.spgan_gemm_dual(C.byref(a), _s()), "gemm_dual", M=M_, Na=Na, Nb=Nb, k=ek)
-    if done is not None:
-        done()
-    _PENDING_TN.append((ws, dW, runs, Na, Nb, _ld(dW), float(beta)))
-    if cs_ws is not None:
-        _PENDING_TN.append((cs_ws, cs_out, runs, 1, Na, Na, 0.0))           # [runs][1 x Na] partials: one more entry of the multi-reduce
+    return dict(a=a, M=M_, Na=Na, Nb=Nb, ek=ek, runs=runs, rows_wg=rows_wg, g=g, part=part, ws=ws, dW=dW, beta=float(beta), cs_ws=cs_ws, cs_out=cs_out,
+                mean=mean, invstd=invstd)
+
+
+def _gemm_dual_pending(b: dict) -> None:
+    _PENDING_TN.append((b["ws"], b["dW"], b["runs"], b["Na"], b["Nb"], _ld(b["dW"]), b["beta"]))
+    if b["cs_ws"] is not None:
+        _PENDING_TN.append((b["cs_ws"], b["cs_out"], b["runs"], 1, b["Na"], b["Na"], 0.0))           # [runs][1 x Na] partials: one more entry of the multi-reduce
+
+
+GROUPED = [os.environ.get("SPGAN_GROUPED", "1") != "0"]      # test / A-B hook: False issues every problem of a grouped call as its stand-alone launch
+
+
+def gemm_dual_multi(specs, defer: bool = True):
+    """Several gemm_dual problems of ONE geometry (equal M, Na, Nb, no per-edge operand) as one launch (spgan_gemm_dual_multi), followed by ONE
+    finalize launch for all of them (spgan_colstats_finalize_multi): the same layer's backward of the D step's real pass, fake pass and of
+    phase B of the penalty's double backward.  specs: one dict of gemm_dual's arguments per problem (dy, W, y_ref, scale, shift, mean, invstd,
+    slope [, coef_bn | phaseb, out, beta, bias, rowadd, with_colsum]); -> the list of gemm_dual's return tuples, bit-identical to separate calls.
+    defer=False: the weight-gradient sums (and column sums) of all problems are finished by one flush_tn()."""
+    if len(specs) == 1 or not GROUPED[0]:
+        return [gemm_dual(defer=defer, **sp) for sp in specs]
+    from ._lib import ColFinalizeArgs, GROUP_MAX
+    if len(specs) > GROUP_MAX:
+        raise ValueError("gemm_dual_multi: at most %d problems per launch" % GROUP_MAX)
+    tails = [(sp.get("coef_bn"), sp.get("phaseb")) for sp in specs]
+    bs = [_gemm_dual_build(**{k: v for k, v in sp.items() if k not in ("coef_bn", "phaseb")}) for sp in specs]
+    if any(b["ek"] for b in bs) or len({(b["M"], b["Na"], b["Nb"]) for b in bs}) != 1:
+        raise ValueError("gemm_dual_multi: one geometry (M, Na, Nb), plain pre tensors")
+    lib = _lib.load()
+    n = len(bs)
+    arr = (GemmDualArgs * n)(*[b["a"] for b in bs])
+    check(lib.spgan_gemm_dual_multi(arr, n, _s()), "gemm_dual_multi", M=bs[0]["M"], Na=bs[0]["Na"], Nb=bs[0]["Nb"], count=n)
+    for b in bs:
+        _gemm_dual_pending(b)
     if not defer:
         flush_tn()
-    extra = () if cs_out is None else (cs_out,)
-    if coef_bn is not None:
-        gamma, count = coef_bn
-        fin = torch.empty((2, Nb), dtype=torch.float32, device=A.device)
-        coef = torch.empty((3, Nb), dtype=torch.float32, device=A.device)
-        check(lib.spgan_colstats_finalize_bnbwd(_p(part), runs, Nb, M_, rows_wg, _p(_vec(mean, Nb, "mean")), _p(_vec(invstd, Nb, "invstd")),
-                                                _p(None if gamma is None else _vec(gamma, Nb, "gamma")), float(count), _p(fin[0]), _p(fin[1]), _p(coef), _s()),
-              "colstats_finalize_bnbwd", N=Nb, M=M_)
-        return (dW, g, fin[0], fin[1], coef) + extra
-    if phaseb is not None:
-        (U0, U1, Ugz, S0, S1, count), pg, pinv = phaseb
-        fin = torch.empty((2, Nb), dtype=torch.float32, device=A.device)
-        sums = torch.empty((2 * Nb,), dtype=torch.float32, device=A.device)
-        dg = torch.empty((Nb,), dtype=torch.float32, device=A.device)
-        v = lambda t, n: _p(_vec(t.contiguous(), Nb, n))
-        check(lib.spgan_colstats_finalize_phaseb(_p(part), runs, Nb, M_, rows_wg, v(U0, "U0"), v(U1, "U1"), v(Ugz, "Ugz"), v(S0, "S0"), v(S1, "S1"),
-                                                 v(pg, "gamma"), v(pinv, "invstd"), int(count), _p(fin[0]), _p(fin[1]), _p(sums), _p(dg), _s()),
-              "colstats_finalize_phaseb", N=Nb, M=M_)
-        return (dW, g, fin[0], fin[1]) + extra + (sums, dg)
-    s0, s1 = _finalize(part, 1, runs, Nb, M_, 1, rows_wg)
-    return (dW, g, s0[0], s1[0]) + extra
+    fa = (ColFinalizeArgs * n)()
+    res, keep = [], []
+    for i, (b, (coef_bn, phaseb)) in enumerate(zip(bs, tails)):
+        Nb, dev = b["Nb"], b["g"].device
+        f = fa[i]
+        fin = torch.empty((2, Nb), dtype=torch.float32, device=dev)
+        f.partials = _p(b["part"]); f.tiles = b["runs"]; f.C = Nb; f.G = b["M"]; f.tile_rows = b["rows_wg"]; f.s0 = _p(fin[0]); f.s1 = _p(fin[1])
+        extra = () if b["cs_out"] is None else (b["cs_out"],)
+        if coef_bn is not None:
+            gamma, count = coef_bn
+            coef = torch.empty((3, Nb), dtype=torch.float32, device=dev)
+            f.kind = 1; f.mean = _p(_vec(b["mean"], Nb, "mean")); f.invstd = _p(_vec(b["invstd"], Nb, "invstd"))
+            f.gamma = _p(None if gamma is None else _vec(gamma, Nb, "gamma")); f.count = float(count); f.coef = _p(coef)
+            res.append((b["dW"], b["g"], fin[0], fin[1], coef) + extra)
+        elif phaseb is not None:
+            (U0, U1, Ugz, S0, S1, count), pg, pinv = phaseb
+            sums = torch.empty((2 * Nb,), dtype=torch.float32, device=dev)
+            dg = torch.empty((Nb,), dtype=torch.float32, device=dev)
+            vs = [_vec(t.contiguous(), Nb, nm) for t, nm in ((U0, "U0"), (U1, "U1"), (Ugz, "Ugz"), (S0, "S0"), (S1, "S1"), (pg, "gamma"), (pinv, "invstd"))]
+            keep.append(vs)
+            f.kind = 2; f.U0, f.U1, f.Ugz, f.S0, f.S1, f.gamma, f.invstd = [_p(t) for t in vs]
+            f.count = float(count); f.sums = _p(sums); f.dgamma = _p(dg)
+            res.append((b["dW"], b["g"], fin[0], fin[1]) + extra + (sums, dg))
+        else:
+            f.kind = 0
+            res.append((b["dW"], b["g"], fin[0], fin[1]) + extra)
+    check(lib.spgan_colstats_finalize_multi(fa, n, _s()), "colstats_finalize_multi", count=n)
+    return res
 
 
 _PENDING_TN: list = []      # deferred split-K reductions: (ws, out, splits, Na, Nb, ldc, beta); see gemm_tn(defer=True) / flush_tn()
@@ -947,6 +1020,73 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     return out, cs_out
 
 
+def gemm_tn_narrow_multi(specs):
+    """Several deferred gemm_tn(A, Bm, out=, beta=, defer=True) products with a narrow Bm (<= 4 columns: D's first conv against the three input
+    coordinates) of one shape as ONE launch (spgan_gemm_tn_skinny_multi); A: Affine2 or a dense tensor.  specs: dicts(A, Bm[, out, beta]);
+    -> the list of result tensors (valid after flush_tn(), like gemm_tn(defer=True)), bit-identical to the separate calls."""
+    if len(specs) == 1 or not GROUPED[0] or _MFMA_F16[0] == 1:
+        return [gemm_tn(sp["A"], sp["Bm"], out=sp.get("out"), beta=sp.get("beta", 0.0), defer=True) for sp in specs]
+    lib = _lib.load()
+    n = len(specs)
+    arr = (GemmTNArgs * n)()
+    res, keep, pend = [], [], []
+    for i, sp in enumerate(specs):
+        A, Bm, out, beta = sp["A"], sp["Bm"], sp.get("out"), float(sp.get("beta", 0.0))
+        a2 = A if isinstance(A, Affine2) else None
+        if a2 is not None:
+            if a2.half:
+                raise ValueError("gemm_tn_narrow_multi: fp32 operands")
+            A = a2.g
+        _rowmajor2d(A, "A"); _rowmajor2d(Bm, "B")
+        M_, Na = A.shape
+        Nb = Bm.shape[1]
+        if Bm.shape[0] != M_ or Nb > 4:
+            raise ValueError("gemm_tn_narrow_multi: Bm [M, <= 4]")
+        a = arr[i]
+        if a2 is not None:
+            a.a_scale = _p(_vec(a2.p, Na, "p")); a.a_shift = _p(_vec(a2.r, Na, "r"))
+            a.A2 = _p(a2.y); a.lda2 = _ld(a2.y); a.a_scale2 = _p(_vec(a2.q, Na, "q"))
+        if out is None:
+            out, beta = torch.empty((Na, Nb), dtype=torch.float32, device=A.device), 0.0
+        else:
+            _rowmajor2d(out, "out")
+        wsb = lib.spgan_gemm_tn_ws_bytes(M_, Na, Nb)
+        ws = torch.empty((wsb // 4,), dtype=torch.float32, device=A.device)
+        a.A = _p(A); a.lda = _ld(A); a.B = _p(Bm); a.ldb = _ld(Bm); a.C = _p(out); a.ldc = _ld(out)
+        a.M, a.Na, a.Nb = M_, Na, Nb
+        a.beta = beta; a.ws = _p(ws); a.ws_bytes = wsb; a.defer_reduce = 1; a.b_mode = A_PLAIN
+        pend.append((ws, out, lib.spgan_gemm_tn_splits(M_, Na, Nb), Na, Nb, _ld(out), beta))
+        res.append(out)
+    check(lib.spgan_gemm_tn_skinny_multi(arr, n, _s()), "gemm_tn_skinny_multi", count=n)
+    _PENDING_TN.extend(pend)
+    return res
+
+
+def multi_addn(dsts, srcs_per_dst) -> None:
+    """dsts[t] = ((dsts[t] + s0) + s1) + s2 for the one to three contiguous sources srcs_per_dst[t] of every destination, in ONE launch: the per-pass
+    parameter gradients of a grouped backward into the flat .grad buffers -- the sums of as many successive multi_add calls."""
+    from ._lib import MULTI_ADDN_MAX, MultiAddNArgs
+    lib = _lib.load()
+    items = [(d, [x for x in ss]) for d, ss in zip(dsts, srcs_per_dst) if len(ss)]
+    for i0 in range(0, len(items), MULTI_ADDN_MAX):
+        chunk = items[i0:i0 + MULTI_ADDN_MAX]
+        a = MultiAddNArgs()
+        a.count = len(chunk)
+        keep = []
+        for t, (d, ss) in enumerate(chunk):
+            if not (d.is_cuda and d.is_contiguous() and d.dtype == torch.float32) or not 1 <= len(ss) <= 3:
+                raise ValueError("multi_addn: contiguous float32 GPU destinations, one to three sources each")
+            a.dst[t] = d.data_ptr(); a.n[t] = d.numel(); a.nsrc[t] = len(ss)
+            for j, x in enumerate(ss):
+                x = _f32(x, "src")
+                if x.numel() != d.numel():
+                    raise ValueError("multi_addn: source and destination sizes differ")
+                x = x.contiguous()
+                keep.append(x)
+                a.src[j][t] = x.data_ptr()
+        check(lib.spgan_multi_addn(C.byref(a), _s()), "multi_addn", count=len(chunk))
+
+
 # ----------------------------------------------------------------------------- reductions / norms
 def wt_diag_w(W: Tensor, alpha: Tensor, beta: Optional[Tensor] = None, bias: Optional[Tensor] = None):
     """G = W^T diag(alpha) W [K,K] and (with beta, bias) cvec = (alpha*bias + beta) . W [K] of W [C,K] in one launch: the weight-only operands
@@ -962,20 +1102,38 @@ def wt_diag_w(W: Tensor, alpha: Tensor, beta: Optional[Tensor] = None, bias: Opt
     return G if cvec is None else (G, cvec)
 
 
-def collapse_prep(W: Tensor, problems, val: Tensor, arg: Tensor, rows: int):
+def collapse_prep(W: Tensor, problems, val, arg, rows: int):
     """What the collapsed backward of the layer in front of the max-pool needs before its big launch, in ONE launch:
-    problems = one or two (alpha, beta | None, bias | None) -> wt_diag_w(W, alpha, beta, bias) each, and E = sparse_rows_nt(val, arg, rows, W).
+    problems = one to four (alpha, beta | None, bias | None) -> wt_diag_w(W, alpha, beta, bias) each, and E = sparse_rows_nt(val, arg, rows, W).
     -> ([G or (G, cvec), ...], E); bit-identical to the separate launches (the weight-only part, latency-bound on a fraction of the chip,
-    finishes under the part that streams E out)."""
-    from ._lib import CollapsePrepArgs
-    _rowmajor2d(W, "W"); _f32(val, "val", 2)
+    finishes under the part that streams E out).  val / arg may be LISTS of equally shaped sets (the passes of a grouped D step share W):
+    then E is the list of their products."""
+    from ._lib import CollapsePrepArgs, GROUP_MAX
+    many = isinstance(val, (list, tuple))
+    vals, args_ = (list(val), list(arg)) if many else ([val], [arg])
+    _rowmajor2d(W, "W")
+    for v in vals:
+        _f32(v, "val", 2)
     Cn, K = W.shape
-    B, Cs = val.shape
-    if Cn % 256 or K % 32 or Cs != Cn or not 1 <= len(problems) <= 2:
-        raise ValueError("collapse_prep: W [C,K] with C % 256 == 0, K % 32 == 0, val [B,C], one or two problems")
+    B, Cs = vals[0].shape
+    if (Cn % 256 or K % 32 or Cs != Cn or not 1 <= len(problems) <= GROUP_MAX or not 1 <= len(vals) <= GROUP_MAX or len(vals) != len(args_)
+            or any(tuple(v.shape) != (B, Cs) for v in vals)):
+        raise ValueError("collapse_prep: W [C,K] with C % 256 == 0, K % 32 == 0, val [B,C] (up to four equally shaped sets), one to four problems")
+    if not GROUPED[0] and (len(problems) > 2 or many):       # A/B hook: the launches of the ungrouped route
+        outs, Es = [], []
+        for q in range(max(len(vals), (len(problems) + 1) // 2)):
+            pr = problems[2 * q:2 * q + 2]
+            if q < len(vals) and pr:
+                o, E = collapse_prep(W, pr, vals[q], args_[q], rows)
+                outs += o; Es.append(E)
+            elif pr:
+                outs += [wt_diag_w(W, *p3) for p3 in pr]
+            else:
+                Es.append(sparse_rows_nt(vals[q], args_[q], rows, W))
+        return outs, (Es if many else Es[0])
     a = CollapsePrepArgs()
     a.W = _p(W); a.ldw = _ld(W); a.C = Cn; a.K = K; a.nprob = len(problems); a.ldg = K
-    outs, keep = [], [val.contiguous(), _i32(arg, "arg")]
+    outs, keep = [], []
     for i, (alpha, beta, bias) in enumerate(problems):
         G = torch.empty((K, K), dtype=torch.float32, device=W.device)
         cvec = torch.empty((K,), dtype=torch.float32, device=W.device) if beta is not None else None
@@ -983,10 +1141,16 @@ def collapse_prep(W: Tensor, problems, val: Tensor, arg: Tensor, rows: int):
         keep += [va, vb, vc]
         a.alpha[i] = _p(va); a.beta[i] = _p(vb); a.bias[i] = _p(vc); a.G[i] = _p(G); a.cvec[i] = _p(cvec)
         outs.append(G if cvec is None else (G, cvec))
-    E = torch.empty((B * rows, K), dtype=torch.float32, device=W.device)
-    a.sp_val = _p(keep[0]); a.sp_arg = _p(keep[1]); a.B = B; a.rows = rows; a.E = _p(E); a.lde = K
+    Es = []
+    a.nsparse = len(vals); a.B = B; a.rows = rows; a.lde = K
+    for q, (v, ar) in enumerate(zip(vals, args_)):
+        vc_, ac_ = v.contiguous(), _i32(ar, "arg")
+        keep += [vc_, ac_]
+        E = torch.empty((B * rows, K), dtype=torch.float32, device=W.device)
+        a.sp_val[q] = _p(vc_); a.sp_arg[q] = _p(ac_); a.E[q] = _p(E)
+        Es.append(E)
     check(_lib.load().spgan_collapse_prep(C.byref(a), _s()), "collapse_prep", C=Cn, K=K, B=B, rows=rows)
-    return outs, E
+    return outs, (Es if many else Es[0])
 
 
 WGRAD_COLLAPSE = [True]   # test / A-B hook: False keeps the collapsed layer's weight gradient on its separate launches
@@ -1006,6 +1170,27 @@ def wgrad_collapse(W: Tensor, X1: Tensor, a1: Tensor, b1: Optional[Tensor] = Non
       out[a,n] (+)= a1[a]*(W . X1^T)[a,n] + (a1*b1 + d1)[a]*v1[n] + a2[a]*(W . X2^T)[a,n] + sum_b val[b,a]*pro(Bm)[arg[b,a], n]
     W [C,K], X1 [N,K]; X2 [N,K] or, with x2_t, [K,N]; sparse = (val [B,C], arg int32 [B,C] global rows, rows, Bm [B*rows,N], pro | None) with
     pro = (scale[N], shift[N], slope).  -> out, or (out, T) with want_T (T = W . X1^T)."""
+    a, res, _keep = _wgrad_collapse_build(W, X1, a1, b1, d1, v1, X2=X2, x2_t=x2_t, a2=a2, sparse=sparse, out=out, accumulate=accumulate, want_T=want_T)
+    check(_lib.load().spgan_wgrad_collapse(C.byref(a), _s()), "wgrad_collapse", C=a.C, N=a.N, K=a.K)
+    return res
+
+
+def wgrad_collapse_multi(specs):
+    """Several wgrad_collapse problems with equal shapes (the passes of a grouped D step) as one launch; specs: dicts of wgrad_collapse's
+    arguments; -> the list of its results, bit-identical to separate calls."""
+    if len(specs) == 1 or not GROUPED[0]:
+        return [wgrad_collapse(**sp) for sp in specs]
+    from ._lib import WgradCollapseArgs
+    builds = [_wgrad_collapse_build(**sp) for sp in specs]
+    n = len(builds)
+    arr = (WgradCollapseArgs * n)(*[b[0] for b in builds])
+    check(_lib.load().spgan_wgrad_collapse_multi(arr, n, _s()), "wgrad_collapse_multi", count=n)
+    return [b[1] for b in builds]
+
+
+def _wgrad_collapse_build(W: Tensor, X1: Tensor, a1: Tensor, b1: Optional[Tensor] = None, d1: Optional[Tensor] = None, v1: Optional[Tensor] = None, *,
+                          X2: Optional[Tensor] = None, x2_t: bool = False, a2: Optional[Tensor] = None, sparse=None, out: Optional[Tensor] = None,
+                          accumulate: bool = False, want_T: bool = False):
     from ._lib import WgradCollapseArgs
     _rowmajor2d(W, "W"); _rowmajor2d(X1, "X1")
     Cn, K = W.shape
@@ -1045,8 +1230,7 @@ def wgrad_collapse(W: Tensor, X1: Tensor, a1: Tensor, b1: Optional[Tensor] = Non
     T = torch.empty((Cn, N), dtype=torch.float32, device=W.device) if want_T else None
     a.T = _p(T); a.ldt = N
     a.out = _p(out); a.ldo = _ld(out); a.accumulate = int(accumulate)
-    check(_lib.load().spgan_wgrad_collapse(C.byref(a), _s()), "wgrad_collapse", C=Cn, N=N, K=K)
-    return (out, T) if want_T else out
+    return a, ((out, T) if want_T else out), keep
 
 
 def sparse_rows_nt(val: Tensor, arg: Tensor, rows: int, W: Tensor) -> Tensor:
@@ -1579,6 +1763,38 @@ def pool_bwd_stats(gpool: Tensor, pooled: Tensor, argmax: Tensor, y: Tensor, mea
                                                 _p(_vec(invstd, Cn, "invstd")), float(slope), B, Cn, _p(_vec(gamma, Cn, "gamma")), int(count), _p(gval),
                                                 _p(sums), _p(ab[0]), _p(ab[1]), _p(cg), _s()), "pool_bwd_stats_prep")
     return gval, sums, SparseAffine(y_full, ab[0], ab[1], cg, real_arg, rows)
+
+
+def pool_bwd_stats_multi(specs):
+    """pool_bwd_stats(..., prep=...) for several passes as one launch; specs: dicts of its arguments (prep required); -> list of its results."""
+    if len(specs) == 1 or not GROUPED[0]:
+        return [pool_bwd_stats(**sp) for sp in specs]
+    from ._lib import PoolBwdArgs
+    n = len(specs)
+    arr = (PoolBwdArgs * n)()
+    res, keep = [], []
+    for i, sp in enumerate(specs):
+        gpool, pooled, argmax, y, mean, invstd, slope = (sp[k] for k in ("gpool", "pooled", "argmax", "y", "mean", "invstd", "slope"))
+        gamma, count, y_full, rows = sp["prep"]
+        _f32(gpool, "gpool", 2); _rowmajor2d(y, "y")
+        B, Cn = gpool.shape
+        real_arg = argmax
+        if y.shape[0] == B:
+            argmax = _rowids(B, Cn, y.device)
+        gpool = gpool.contiguous()
+        gval = torch.empty_like(gpool)
+        sums = torch.empty((2 * Cn,), dtype=torch.float32, device=y.device)
+        ab = torch.empty((2, Cn), dtype=torch.float32, device=y.device)
+        cg = torch.empty_like(gval)
+        q = arr[i]
+        ks = [gpool, pooled.contiguous(), _i32(argmax, "argmax"), _vec(mean, Cn, "mean"), _vec(invstd, Cn, "invstd"), _vec(gamma, Cn, "gamma")]
+        keep.append(ks)
+        q.gpool = _p(ks[0]); q.pooled = _p(ks[1]); q.argmax = _p(ks[2]); q.y = _p(y); q.ld = _ld(y); q.mean = _p(ks[3]); q.invstd = _p(ks[4])
+        q.slope = float(slope); q.B = B; q.C = Cn; q.gamma = _p(ks[5]); q.count = int(count)
+        q.gval = _p(gval); q.sums = _p(sums); q.alpha = _p(ab[0]); q.beta = _p(ab[1]); q.cg = _p(cg)
+        res.append((gval, sums, SparseAffine(y_full, ab[0], ab[1], cg, real_arg, rows)))
+    check(_lib.load().spgan_pool_bwd_stats_prep_multi(arr, n, _s()), "pool_bwd_stats_prep_multi", count=n)
+    return res
 
 
 def bn_bwd_apply_sparse(gval: Tensor, argmax: Tensor, y: Tensor, N: int, mean, invstd, gamma, sums, count: int) -> Tensor:

@@ -74,6 +74,7 @@ class TrainStep:
         # The generator's two forwards of a step (D step, G step) see the same sphere prior and the same weights: EdgeConv1, which
         # depends on nothing else, is evaluated once and its BatchNorm running statistics are advanced twice (Generator.twin_forward).
         self.twin_g_forwards = not reference_schedule      # attribute = test hook
+        self.joint_d_backward = os.environ.get("SPGAN_JOINT_D", "1") != "0"      # test / A-B hook: False keeps one autograd node (and one chain of launches) per D pass
         self.point_major = True                            # test hook: False keeps the [B,3,N] layout between the networks (same results up to the penalty norm's summation order)
         # Data parallel: the generator's forward of the G step does not depend on D's update, so it is issued while D's gradient
         # all-reduce is in flight (SPGAN_DP_OVERLAP=0: the strictly sequential schedule, for A/B measurements on a node).
@@ -291,14 +292,27 @@ class TrainStep:
                 x_hat = ops.lerp_rows(real_pm.view(B, N * 3), fake.view(B, N * 3), a_.reshape(B)).view(M, 3)     # real + alpha*(fake - real)
                 ins.append(x_hat)
             pre = D.forward_stacks_grouped(ins, pm_shape=(B, N))
-            d_real, d_fake = D.forward_heads([D.forward_stack(real_pm, pre=pre[0]), D.forward_stack(fake, pre=pre[1])])
-            out5, g_real, g_fake = dis_loss_with_grads(d_real, d_fake, self.gan, self.flip_d)
-            roots, seeds = [d_real, d_fake], [g_real, g_fake]
-            loss_d = out5[0]
-            if self.use_gp:
-                pen, gx, v = self.gp.with_grads_pm(D, x_hat, pre[2], B)
-                roots.append(gx); seeds.append(v)
-                loss_d = loss_d + pen[0]
+            if self.joint_d_backward and hasattr(D, "stacks_joint") and D.joint_ok(pre):
+                # one node for the conv stacks of all passes: their backward work (real, fake, the penalty's double backward) runs in lock
+                # step, every layer's launch issued once for the three of them (nets.d_backward_joint)
+                outs = D.stacks_joint(pre[:2], pre[2] if self.use_gp else None)
+                d_real, d_fake = D.forward_heads(outs[:2])
+                out5, g_real, g_fake = dis_loss_with_grads(d_real, d_fake, self.gan, self.flip_d)
+                roots, seeds = [d_real, d_fake], [g_real, g_fake]
+                loss_d = out5[0]
+                if self.use_gp:
+                    pen, v = self.gp.from_input_gradient(outs[2], B)
+                    roots.append(outs[2]); seeds.append(v)
+                    loss_d = loss_d + pen[0]
+            else:
+                d_real, d_fake = D.forward_heads([D.forward_stack(real_pm, pre=pre[0]), D.forward_stack(fake, pre=pre[1])])
+                out5, g_real, g_fake = dis_loss_with_grads(d_real, d_fake, self.gan, self.flip_d)
+                roots, seeds = [d_real, d_fake], [g_real, g_fake]
+                loss_d = out5[0]
+                if self.use_gp:
+                    pen, gx, v = self.gp.with_grads_pm(D, x_hat, pre[2], B)
+                    roots.append(gx); seeds.append(v)
+                    loss_d = loss_d + pen[0]
             torch.autograd.backward(roots, seeds)
             if keep_grads:
                 info["fake_d"] = ops.pm_to_cm(fake, B, N)

@@ -269,6 +269,8 @@ def wgrad_collapse(W, X1, a1, b1=None, d1=None, v1=None, *, X2=None, x2_t=False,
 
 def collapse_prep(W, problems, val, arg, rows):
     outs = [wt_diag_w(W, al) if be is None else wt_diag_w(W, al, be, bi) for al, be, bi in problems]
+    if isinstance(val, (list, tuple)):
+        return outs, [sparse_rows_nt(v, a, rows, W) for v, a in zip(val, arg)]
     return outs, sparse_rows_nt(val, arg, rows, W)
 
 
@@ -820,3 +822,29 @@ def wt_diag_w(W, alpha, beta=None, bias=None):
     if beta is None:
         return G.contiguous()
     return G.contiguous(), ((alpha * bias + beta) @ W).contiguous()
+
+
+# ----------------------------------------------------------------------------- grouped launches (spgan.ops.*_multi): the same problems, one after the other
+GROUPED = [True]
+
+
+def gemm_dual_multi(specs, defer=True):
+    return [gemm_dual(defer=defer, **sp) for sp in specs]
+
+
+def wgrad_collapse_multi(specs):
+    return [wgrad_collapse(**sp) for sp in specs]
+
+
+def pool_bwd_stats_multi(specs):
+    return [pool_bwd_stats(**sp) for sp in specs]
+
+
+def gemm_tn_narrow_multi(specs):
+    return [gemm_tn(sp["A"], sp["Bm"], out=sp.get("out"), beta=sp.get("beta", 0.0), defer=True) for sp in specs]
+
+
+def multi_addn(dsts, srcs_per_dst):
+    for d, ss in zip(dsts, srcs_per_dst):
+        for s in ss:
+            d.add_(s.reshape(d.shape))

@@ -129,7 +129,9 @@ def test_n_rank_step_equals_single_process_on_concatenated_batch(tmp_path, world
     a = ranks[0]
     # the all-reduced gradient is the mean of the per-shard gradients (sum order of gloo's reduction may differ for W > 2)
     assert _rel(a["gD"], ref["gD"]) <= 1e-6, _rel(a["gD"], ref["gD"])
-    assert _rel(a["gG"], ref["gG"]) <= 1e-6, _rel(a["gG"], ref["gG"])
+    # G's gradient is taken through the UPDATED D: for W > 2 the other summation order of D's all-reduce flips the +-lr first Adam step of D's
+    # noise-level gradient elements (see below), which G's gradient then sees -- a few 1e-6 of its norm (1.5e-6 observed); W = 2 is bit-identical
+    assert _rel(a["gG"], ref["gG"]) <= (1e-6 if world == 2 else 1e-5), _rel(a["gG"], ref["gG"])
     if world == 2:
         assert torch.equal(a["gD"], ref["gD"]) and torch.equal(a["gG"], ref["gG"])          # a + b in both runs: bit-identical
         assert torch.equal(a["flatD"], ref["flatD"]) and torch.equal(a["flatG"], ref["flatG"])

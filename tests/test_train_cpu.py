@@ -254,3 +254,36 @@ def test_step_from_mid_training_state_g20(spgan_cpu):
                 assert int(b.item()) == int(d["%sbuf|%s" % (kind, n)]) == calls, n
             else:
                 np.testing.assert_allclose(b.numpy(), d["%sbuf|%s" % (kind, n)], rtol=2e-3, atol=2e-4, err_msg=n)
+
+
+@pytest.mark.parametrize("gan,use_gp,B,N", [("ls", False, 4, 256), ("wgan", True, 4, 256), ("hinge", True, 2, 512)])
+def test_joint_d_backward_equals_one_node_per_pass(spgan_cpu, monkeypatch, gan, use_gp, B, N):
+    """TrainStep's D step with the conv stacks of all passes behind ONE autograd node (Discriminator.stacks_joint -> nets.d_backward_joint: the
+    backward work of the real pass, the fake pass and the penalty's double backward in lock step) against one node per pass: same losses,
+    same gradients (the per-parameter sums are formed in another order: 1e-6), and the joint route is the one that ran."""
+    import spgan
+    from spgan import nets
+    calls = []
+    real_joint = nets.d_backward_joint
+    monkeypatch.setattr(nets, "d_backward_joint", lambda P, firsts, dbl=None: (calls.append((len(firsts), dbl is not None)), real_joint(P, firsts, dbl))[1])
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    real = fr.synthetic_real(B, N, seed=91)
+    z_d, z_g = fr.latent(B, N, seed=92), fr.latent(B, N, seed=93)
+    alpha = fr.uniform("joint.alpha", (B, 1, 1), 0.0, 1.0)
+    outs = []
+    for joint in (True, False):
+        G = _load(spgan.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=9))
+        D = _load(spgan.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=9))
+        tr = spgan.TrainStep(G, D, gan=gan, use_gp=use_gp, lambda_gp=10.0)
+        tr.joint_d_backward = joint
+        outs.append((tr.step(x, real, z_d, z_g, alpha=alpha, keep_grads=True), {k: v.clone() for k, v in D.state_dict().items()}))
+    assert calls == [(2, use_gp)], calls
+    (a, sa), (b, sb) = outs
+    np.testing.assert_allclose(a["loss_d"].item(), b["loss_d"].item(), rtol=1e-6)
+    np.testing.assert_allclose(a["loss_g"].item(), b["loss_g"].item(), rtol=1e-5)
+    for n in a["d_grads"]:
+        ga, gb = a["d_grads"][n], b["d_grads"][n]
+        assert (ga - gb).norm().item() <= 1e-6 * gb.norm().item() + 1e-12, n
+    for k in sa:      # (the G step's D passes run on the UPDATED weights, which carry the other summation order: not bit-equal)
+        if "running" in k or "num_batches" in k:
+            assert torch.allclose(sa[k].float(), sb[k].float(), rtol=1e-5, atol=1e-6), k
