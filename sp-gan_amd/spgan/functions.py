@@ -242,7 +242,8 @@ class DStacksJointFn(Function):
             P = dict(zip(holder.names, params))
             pooled_h, dctx_h = holder.hat
             logits, dctx_h["hs"] = nets.d_head_forward(P, pooled_h)
-            dx, _, ctx.saved_hat = nets.d_backward(P, dctx_h, torch.ones_like(logits), True, False, keep_for_double=True)
+            ones = nets._const_vec(logits.numel(), 1.0, logits.device).view_as(logits)          # grad_outputs = ones (gradient_penalty.py:29), a cached constant
+            dx, _, ctx.saved_hat = nets.d_backward(P, dctx_h, ones, True, False, keep_for_double=True)
             outs.append(dx)
         ctx.holder = holder
         ctx.save_for_backward(*params)
