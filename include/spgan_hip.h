@@ -295,6 +295,9 @@ typedef struct spgan_gemm_dual_args {
   int a_mode; float a_slope;
   const float* bias; const float* rowadd; int ld_rowadd;
   float* colsum_ws;
+  /* optional: the stored tile is gout_add[m, :] + gout_scale[:] * G[m, :] (statistics: of G).  The double backward's phase B: the adjoint
+   * X = xbarA + gamma*g that the next BatchNorm backward consumes leaves this launch, not a pass of its own. */
+  const float* gout_add; int ld_gout_add; const float* gout_scale;
 } spgan_gemm_dual_args;
 int spgan_gemm_dual_wgs(int M, int Na, int Nb, int e_k);
 int spgan_gemm_dual_rows_per_wg(int M, int Na, int Nb);   /* rows per run = the `tile_rows` of the statistics partials (tiles = runs = ceil(M / rows)) */
@@ -318,6 +321,7 @@ typedef struct spgan_colfinalize_args {
   float* coef;
   const float* U0; const float* U1; const float* Ugz; const float* S0; const float* S1;
   float* sums; float* dgamma;
+  float* pb_coef;          /* kind 2, optional (needs mean): coef [3,C] of the lazy operand p*X + q*y + r = the BatchNorm backward (gamma = 1) with `sums` */
 } spgan_colfinalize_args;
 int spgan_colstats_finalize_multi(const spgan_colfinalize_args* a, int count, spgan_stream_t s);
 /* spgan_pool_bwd_stats_prep for `count` passes (the real and the fake pass behind one grouped forward) as one launch. */

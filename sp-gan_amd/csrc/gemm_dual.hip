@@ -10,6 +10,8 @@
 //   dW[Na,Nb]  = sum_m dy[m, :]^T a[m, :]                    weight gradient (split over row runs, partials summed in fixed order)
 //   G[m, :]    = (dy[m, :] . W + bias + rowadd[m, :]) * lrelu'(sc*pre[m, :] + sh)      gradient w.r.t. the previous BatchNorm's output
 //   stats      = (sum_m G, sum_m G * xhat),  xhat = (pre - mean)*invstd               the previous BatchNorm's backward sums
+//   (optional: the STORED tile is gout_add[m, :] + gout_scale * G[m, :] -- phase B of the double backward hands X = xbarA + gamma*g to the next
+//    layer's lazy BatchNorm-backward operand; the statistics stay those of G)
 //   colsum     = sum_m dy[m, :]                              (optional by-product: the collapsed layer's colsum(a3))
 //
 // Before, gemm_tn (dW) and gemm_nt with the BNBWD / EDGE_BNBWD epilogue (G, stats) each read A, A2 and pre: at the EdgeBlock's size
@@ -122,6 +124,10 @@ __device__ __forceinline__ void gemm_dual_body(const spgan_gemm_dual_args& p, in
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);      // column sums of dy over this thread's rows (ascending: deterministic)
 
   float4 ra[4], ra2[4], rb[PS], rb2[PS], re[PS];
+  float4 rx[PS];     // post-mask addend of the gradient tile (gout_add) of the chunk that is stored NEXT
+  const bool gadd = p.gout_add != nullptr;
+  float4 gsc = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (gadd) gsc = ldg4(p.gout_scale + col0 + pcol);
   int nidx[PS];      // neighbour rows of the chunk AFTER the one whose values are being loaded
 #pragma unroll
   for (int i = 0; i < PS; ++i) nidx[i] = 0;
@@ -133,6 +139,14 @@ __device__ __forceinline__ void gemm_dual_body(const spgan_gemm_dual_args& p, in
   const unsigned offB = (unsigned)prow0 * (unsigned)p.ldb + (unsigned)(col0 + pcol), stepB = (unsigned)(T / 16) * (unsigned)p.ldb;
   const unsigned offE = (unsigned)prow0 * (unsigned)p.ld_rowadd + (unsigned)(col0 + pcol), stepE = (unsigned)(T / 16) * (unsigned)p.ld_rowadd;
   const unsigned offG = (unsigned)prow0 * (unsigned)p.ldg + (unsigned)(col0 + pcol), stepG = (unsigned)(T / 16) * (unsigned)p.ldg;
+  const unsigned offX = (unsigned)prow0 * (unsigned)p.ld_gout_add + (unsigned)(col0 + pcol), stepX = (unsigned)(T / 16) * (unsigned)p.ld_gout_add;
+  auto xload = [&](int c) {  // the stored tile's addend of chunk c: in flight under chunk c's MFMA phases
+    if (gadd) {
+      const float* Xb = p.gout_add + (size_t)c * R * p.ld_gout_add;
+#pragma unroll
+      for (int i = 0; i < PS; ++i) rx[i] = ldg4(Xb + (offX + i * stepX));
+    }
+  };
   auto iload = [&](int c) {  // neighbour indices of chunk c (clamped: a chunk past the end is never stored)
     if (EK > 0) {
       const int m0 = min(c, chunks - 1) * R;
@@ -209,6 +223,7 @@ __device__ __forceinline__ void gemm_dual_body(const spgan_gemm_dual_args& p, in
     gload(c0);
     iload(c0 + 1);
     sstore();
+    xload(c0);
     if (c0 + 1 < c1) {
       gload(c0 + 1);
       iload(c0 + 2);
@@ -266,10 +281,16 @@ __device__ __forceinline__ void gemm_dual_body(const spgan_gemm_dual_args& p, in
       {
         float* gout = p.G + (size_t)c * R * p.ldg;
 #pragma unroll
-        for (int i = 0; i < PS; ++i)
-          *reinterpret_cast<float4*>(gout + (offG + i * stepG)) = *reinterpret_cast<const float4*>(&gzs[(prow0 + (T / 16) * i) * LDG + pcol]);
+        for (int i = 0; i < PS; ++i) {
+          float4 gq = *reinterpret_cast<const float4*>(&gzs[(prow0 + (T / 16) * i) * LDG + pcol]);
+          if (gadd) {   // G = gout_add + gout_scale * g (the statistics above are those of g)
+            gq.x = fmaf(gsc.x, gq.x, rx[i].x); gq.y = fmaf(gsc.y, gq.y, rx[i].y); gq.z = fmaf(gsc.z, gq.z, rx[i].z); gq.w = fmaf(gsc.w, gq.w, rx[i].w);
+          }
+          *reinterpret_cast<float4*>(gout + (offG + i * stepG)) = gq;
+        }
       }
       if (more) {
+        xload(c + 1);
         sstore();                    // chunk c+1: registers -> LDS (the same thread re-fills the gradient-tile slots it just stored from)
         if (c + 2 < c1) {
           gload(c + 2);              // uses the indices fetched one iteration ago
@@ -392,6 +413,7 @@ static int dual_check(const spgan_gemm_dual_args* a) {
   SPGAN_CHECK_ARG(a->a_mode == A_DENSE || (al(a->p, 4) && al(a->r, 4) && (a->a_mode != A_LAZY2 || al(a->q, 4))));
   SPGAN_CHECK_ARG(!a->e_idx || al(a->e_bias, 4));
   SPGAN_CHECK_ARG(!a->rowadd || (al(a->rowadd, a->ld_rowadd) && a->ld_rowadd >= a->Nb));
+  SPGAN_CHECK_ARG(!a->gout_add || (a->gout_scale && al(a->gout_add, a->ld_gout_add) && a->ld_gout_add >= a->Nb && al(a->gout_scale, 4)));
   return SPGAN_OK;
 }
 

@@ -101,6 +101,9 @@ struct BnTail {
   // s0 = out0, s1 = out1 -- the finalize behind the double backward's fused layer launch needs no per-channel launch after it
   const float* pb_U0; const float* pb_U1; const float* pb_Ugz; const float* pb_S0; const float* pb_S1; const float* pb_gamma; const float* pb_inv;
   float pb_rM; float* pb_sums; float* pb_dgamma;
+  // ... and, from those phase-B sums (S0', S1'), the coefficients [p | q | r] of the lazy operand p*X + q*y + r = invstd*(X - S0'/M - xhat*S1'/M):
+  // the BatchNorm backward (gamma = 1) of the adjoint X = xbarA + gamma*g, consumed on the next layer's operand loads (bn_bwd_coeffs_kernel's arithmetic)
+  float* pb_coef; const float* pb_mean;
 };
 
 // workgroup (bx, by) of a (ceil(C / FC), groups) grid
@@ -188,9 +191,17 @@ __device__ __forceinline__ void colfinalize_body(const float* __restrict__ part,
       const float core = bn.pb_Ugz[c] - (U0 * S0 + U1 * S1) * bn.pb_rM;
       const float gsM = ga * iv * bn.pb_rM;
       const float k0 = iv * core, k1 = ga * core, k2 = -gsM * (U0 * S1 + S0 * U1), k3 = -2.0f * gsM * (U1 * S1);
-      bn.pb_sums[c] = k2 + ga * a;
-      bn.pb_sums[C + c] = k3 + ga * b + iv * k1;
+      const float S0n = k2 + ga * a, S1n = k3 + ga * b + iv * k1;
+      bn.pb_sums[c] = S0n;
+      bn.pb_sums[C + c] = S1n;
       bn.pb_dgamma[c] = k0 + b;
+      if (bn.pb_coef) {
+        const float pc = iv;
+        const float qc = -(pc * iv) * (S1n * bn.pb_rM);
+        bn.pb_coef[c] = pc;
+        bn.pb_coef[C + c] = qc;
+        bn.pb_coef[2 * C + c] = -(pc * (S0n * bn.pb_rM)) - qc * bn.pb_mean[c];
+      }
     }
     if (bn.scale) {  // single group, mode 0: same arithmetic as bn_prepare_kernel
       const bool second = bn.split > 0 && c >= bn.split;
@@ -598,6 +609,8 @@ extern "C" int spgan_colstats_finalize_multi(const spgan_colfinalize_args* a, in
       SPGAN_CHECK_ARG(q.U0 && q.U1 && q.Ugz && q.S0 && q.S1 && q.gamma && q.invstd && q.sums && q.dgamma && q.count > 0.f);
       bn.pb_U0 = q.U0; bn.pb_U1 = q.U1; bn.pb_Ugz = q.Ugz; bn.pb_S0 = q.S0; bn.pb_S1 = q.S1; bn.pb_gamma = q.gamma; bn.pb_inv = q.invstd;
       bn.pb_rM = 1.0f / q.count; bn.pb_sums = q.sums; bn.pb_dgamma = q.dgamma;
+      SPGAN_CHECK_ARG(!q.pb_coef || q.mean);
+      bn.pb_coef = q.pb_coef; bn.pb_mean = q.mean;
     }
     if (q.C > cmax) cmax = q.C;
   }

@@ -88,6 +88,7 @@ class GemmDualArgs(C.Structure):
         ("a_mode", C.c_int), ("a_slope", C.c_float),
         ("bias", c_f32p), ("rowadd", c_f32p), ("ld_rowadd", C.c_int),
         ("colsum_ws", c_f32p),
+        ("gout_add", c_f32p), ("ld_gout_add", C.c_int), ("gout_scale", c_f32p),
     ]
 
 
@@ -118,7 +119,7 @@ class ColFinalizeArgs(C.Structure):
                 ("s0", C.c_void_p), ("s1", C.c_void_p), ("kind", C.c_int),
                 ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p), ("count", C.c_float), ("coef", C.c_void_p),
                 ("U0", C.c_void_p), ("U1", C.c_void_p), ("Ugz", C.c_void_p), ("S0", C.c_void_p), ("S1", C.c_void_p),
-                ("sums", C.c_void_p), ("dgamma", C.c_void_p)]
+                ("sums", C.c_void_p), ("dgamma", C.c_void_p), ("pb_coef", C.c_void_p)]
 
 
 class PoolBwdArgs(C.Structure):

@@ -547,7 +547,7 @@ def _d_double_top_phase_a(P, ctx, saved, q3: Tensor, grads) -> dict:
     return dict(t=t, spB=spB, c4=c4, pro3=pro3, q3=q3, Qqa=Qqa)
 
 
-def _d_double_top_phase_b(P, ctx, top: dict, grads, phaseb=None):
+def _d_double_top_phase_b(P, ctx, top: dict, grads, phaseb=None, gout=None):
     """Phase B at the same layer: ybar = c1*u + c2*y4 + c3 + scatter(spB) (never formed) ->
       ybar^T a3 = diag(c1).W.(q3^T a3) + diag(c2).W.(a3^T a3) + (c2*b4 + c3) (x) colsum(a3) + spB^T a3
       ybar.W    = q3.(W^T diag(c1) W) + a3.(W^T diag(c2) W) + (c2*b4 + c3).W + spB.W      (then layer 3's mask / sums epilogue)"""
@@ -573,7 +573,7 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads, phaseb=None):
         # a3^T a3, colsum(a3) and the outgoing adjoint a3.G2 (+ addends, layer 3's mask / sums epilogue) from one staging of the y3 tile
         # (phaseb: layer 2's phase-B sums come out of this launch's finalize)
         gram, g_, s0_, s1_, cs3, *pb = ops.gemm_dual(a3, G2, ys[2], psc, psh, pmu, pinv, NEG, bias=cvec, rowadd=part, with_colsum=True, defer=False,
-                                                     phaseb=phaseb)
+                                                     phaseb=phaseb, gout=gout)
         abar_g = (g_, s0_, s1_) + tuple(pb)
     else:
         gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)            # a3^T a3 and colsum(a3) from one launch
@@ -650,6 +650,21 @@ def _d_double_phase_a(P, ctx, saved, v_dx_cm: Tensor):
     return grads, top, coeffs, xbarA
 
 
+LAZY_PHASE_B = [True]     # test / A-B hook: False keeps phase B's BatchNorm backward as a pass of its own (ops.bn_bwd_apply) in front of every layer's launch
+
+
+def _phaseb_below(P, bns, coeffs, xbarA, li: int, M: int):
+    """What the launch that produces layer li-1's adjoint carries for that layer: the phase-B sums' inputs (+ the layer's mean: the finalize then
+    also emits the lazy BatchNorm-backward coefficients) and the stored-tile addend X = xbarA + gamma*g.  -> (phaseb, gout) or (None, None)."""
+    if li == 0 or not isinstance(coeffs[li - 1], tuple):
+        return None, None
+    gam = P[D_LAYERS[li - 1][1] + ".weight"]
+    sc, sh, inv, mu = bns[li - 1]
+    if LAZY_PHASE_B[0] and xbarA[li - 1] is not None and _lazy_ok(M, gam.numel()):
+        return (coeffs[li - 1], gam, inv, mu), (xbarA[li - 1], gam)
+    return (coeffs[li - 1], gam, inv), None
+
+
 def _d_double_phase_b(P, ctx, grads, top, coeffs, xbarA, need_dx: bool):
     """Phase B of d_double_backward: an ordinary backward sweep of the adjoints phase A deposited on the forward activations."""
     B, N = ctx["B"], ctx["N"]
@@ -664,30 +679,36 @@ def _d_double_phase_b(P, ctx, grads, top, coeffs, xbarA, need_dx: bool):
         sc, sh, inv, mu = bns[li]
         gamma = P[bn + ".weight"]
         C = W.shape[0]
-        # the finalize of the launch that produces layer l's adjoint also runs layer l's phase-B sums (ops.gemm_dual(phaseb=...))
-        pb_below = (coeffs[li - 1], P[D_LAYERS[li - 1][1] + ".weight"], bns[li - 1][2]) if li > 0 and isinstance(coeffs[li - 1], tuple) else None
+        # the finalize of the launch that produces layer l's adjoint also runs layer l's phase-B sums (ops.gemm_dual(phaseb=...)) and the lazy
+        # BatchNorm-backward coefficients that go with them, and the launch itself stores X = xbarA + gamma*g (gout): no pass of its own
+        pb_below, gout_below = _phaseb_below(P, bns, coeffs, xbarA, li, M)
         if li == 3 and top is not None:
-            abar_g = _d_double_top_phase_b(P, ctx, top, grads, phaseb=pb_below)
+            abar_g = _d_double_top_phase_b(P, ctx, top, grads, phaseb=pb_below, gout=gout_below)
             continue
         add = None
-        if abar_g is None:
-            sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, None, None)
-            grads[bn + ".bias"] = ZERO_GRAD
-        else:
-            g, s0, s1 = abar_g[:3]
-            add = (g, gamma)                                                     # X = xbarA + gamma*g, formed inside bn_bwd_apply
-            if len(abar_g) == 5:
-                sums, grads[bn + ".weight"] = abar_g[3], abar_g[4]
-            else:
-                sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, s0, s1)
+        if abar_g is not None and len(abar_g) == 6:
+            X, s0, s1, sums, grads[bn + ".weight"], coefB = abar_g
             grads[bn + ".bias"] = s0
-        ybar = ops.bn_bwd_apply(xbarA[li], ys[li], mu, inv, None, sums, M, add=add)
+            ybar = ops.Affine2(X, ys[li], coefB)                                 # inv*(X - S0/M - xhat*S1/M), evaluated on the operand loads
+        else:
+            if abar_g is None:
+                sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, None, None)
+                grads[bn + ".bias"] = ZERO_GRAD
+            else:
+                g, s0, s1 = abar_g[:3]
+                add = (g, gamma)                                                     # X = xbarA + gamma*g, formed inside bn_bwd_apply
+                if len(abar_g) == 5:
+                    sums, grads[bn + ".weight"] = abar_g[3], abar_g[4]
+                else:
+                    sums, grads[bn + ".weight"] = ops.bn_dbl_phaseb(coeffs[li], gamma, inv, s0, s1)
+                grads[bn + ".bias"] = s0
+            ybar = ops.bn_bwd_apply(xbarA[li], ys[li], mu, inv, None, sums, M, add=add)
         # phase B's weight-gradient term is accumulated onto phase A's by the split-K reduction itself (beta = 1): no separate add
         gA = grads[conv + ".weight"]
         if li > 0:
             psc, psh, pinv, pmu = bns[li - 1]
             if ops.gemm_dual_ok(ybar, W, ys[li - 1]):
-                _, *abar = ops.gemm_dual(ybar, W, ys[li - 1], psc, psh, pmu, pinv, NEG, out=gA, beta=1.0, phaseb=pb_below)      # both products of this layer in one launch
+                _, *abar = ops.gemm_dual(ybar, W, ys[li - 1], psc, psh, pmu, pinv, NEG, out=gA, beta=1.0, phaseb=pb_below, gout=gout_below)      # both products of this layer in one launch
                 abar_g = tuple(abar)
             else:
                 ops.gemm_tn(ybar, ys[li - 1], pro=(psc, psh, NEG), out=gA, beta=1.0)
@@ -695,7 +716,7 @@ def _d_double_phase_b(P, ctx, grads, top, coeffs, xbarA, need_dx: bool):
         else:
             ops.gemm_tn(ybar, ctx["x_pm"], out=gA, beta=1.0)
             if need_dx:
-                dx = ops.gemm_nt(ybar, _t(W))
+                dx = ops.gemm_nt(_dense(ybar), _t(W))
                 dx = dx if ctx.get("pm_io") else ops.pm_to_cm(dx, B, N)
         grads[conv + ".weight"] = gA.view_as(P[conv + ".weight"])
         grads[conv + ".bias"] = ZERO_GRAD
@@ -781,8 +802,9 @@ def d_backward_joint(P, firsts, dbl=None):
         psc, psh, pinv, pmu = hctx["bns"][2]
         G1, (G2, cvec) = outs[nf], outs[nf + 1]
         part = ops.gemm_nt(hot["q3"], G1, rowbias=Es[nf], rows_per_group=1)
+        pb, gout = _phaseb_below(P, hctx["bns"], coeffs, xbarA, 3, M)
         specs.append(dict(dy=ops.ActOperand(hctx["ys"][2], psc, psh, NEG), W=G2, y_ref=hctx["ys"][2], scale=psc, shift=psh, mean=pmu, invstd=pinv,
-                          slope=NEG, bias=cvec, rowadd=part, with_colsum=True, phaseb=((coeffs[2], P[bn3 + ".weight"], pinv))))
+                          slope=NEG, bias=cvec, rowadd=part, with_colsum=True, phaseb=pb, gout=gout))
     res = ops.gemm_dual_multi(specs, defer=False)
     wspecs, lazies, abar_g = [], [], None
     for i, (c, _) in enumerate(firsts):
@@ -792,8 +814,8 @@ def d_backward_joint(P, firsts, dbl=None):
         G[i][bn3 + ".weight"] = s1; G[i][bn3 + ".bias"] = s0
         lazies.append(ops.Affine2(g, c["ys"][2], coef))
     if hot is not None:
-        gram, g_, s0_, s1_, cs3, sums_, dg_ = res[nf]
-        abar_g = (g_, s0_, s1_, sums_, dg_)
+        gram, g_, s0_, s1_, cs3, *pbr = res[nf]
+        abar_g = (g_, s0_, s1_) + tuple(pbr)
         wspecs.append(dict(W=W4, X1=gram, a1=hot["c2"], b1=b4, d1=hot["c3"], v1=cs3, X2=hot["Qqa"], x2_t=True, a2=hot["c1"],
                            sparse=(hot["spB"], hctx["argmax"], N, hctx["ys"][2], (psc, psh, NEG)), out=G[nf][conv4 + ".weight"], accumulate=True))
     dWs = ops.wgrad_collapse_multi(wspecs)
@@ -807,9 +829,12 @@ def d_backward_joint(P, firsts, dbl=None):
         if hot is not None:
             # phase B of layer li: the adjoint X = xbarA + gamma*g through the BatchNorm backward (sums from the finalize launch above)
             sc, sh, inv, mu = hctx["bns"][li]
-            g, s0, s1, sums, dgam = abar_g
+            g, s0, s1, sums, dgam = abar_g[:5]
             G[nf][bn + ".weight"] = dgam; G[nf][bn + ".bias"] = s0
-            ybar = ops.bn_bwd_apply(xbarA[li], hctx["ys"][li], mu, inv, None, sums, M, add=(g, P[bn + ".weight"]))
+            if len(abar_g) == 6:      # g is X = xbarA + gamma*g already; its BatchNorm backward is a lazy operand
+                ybar = ops.Affine2(g, hctx["ys"][li], abar_g[5])
+            else:
+                ybar = ops.bn_bwd_apply(xbarA[li], hctx["ys"][li], mu, inv, None, sums, M, add=(g, P[bn + ".weight"]))
         if li == 0:
             tsp = [dict(A=lazies[i], Bm=c["x_pm"]) for i, (c, _) in enumerate(firsts)]
             if hot is not None:
@@ -824,8 +849,9 @@ def d_backward_joint(P, firsts, dbl=None):
             specs.append(dict(dy=lazies[i], W=W, y_ref=c["ys"][li - 1], scale=sc, shift=sh, mean=mu, invstd=inv, slope=NEG, coef_bn=(P[pbn + ".weight"], M)))
         if hot is not None:
             psc, psh, pinv, pmu = hctx["bns"][li - 1]
+            pb, gout = _phaseb_below(P, hctx["bns"], coeffs, xbarA, li, M)
             specs.append(dict(dy=ybar, W=W, y_ref=hctx["ys"][li - 1], scale=psc, shift=psh, mean=pmu, invstd=pinv, slope=NEG, out=G[nf][conv + ".weight"],
-                              beta=1.0, phaseb=(coeffs[li - 1], P[pbn + ".weight"], pinv)))
+                              beta=1.0, phaseb=pb, gout=gout))
         res = ops.gemm_dual_multi(specs)
         for i, (c, _) in enumerate(firsts):
             dW, g, s0, s1, coef = res[i]

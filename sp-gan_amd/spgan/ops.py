@@ -706,7 +706,7 @@ GEMM_DUAL = [True]      # test hook: False sends every layer backward through th
 
 def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float, edge=None, coef_bn=None,
               defer: bool = True, out: Optional[Tensor] = None, beta: float = 0.0, bias: Optional[Tensor] = None, rowadd: Optional[Tensor] = None,
-              with_colsum: bool = False, phaseb=None):
+              with_colsum: bool = False, phaseb=None, gout=None):
     """The weight-gradient AND the masked input-gradient product of one conv layer behind BatchNorm + LeakyReLU in one launch:
       dW [Na,Nb] = dy^T . lrelu(pre*scale + shift),   g = (dy . W + bias + rowadd) * lrelu'(pre*scale + shift),   s0 = sum g,  s1 = sum g*xhat
     dy: Affine2 (lazy BatchNorm backward), ActOperand (an activation formed on load) or a dense [M,Na] tensor; W [Na,Nb] the layer's weight
@@ -716,8 +716,15 @@ def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: 
     [+ colsum(dy) [Na] with with_colsum].  dW's (and the column sums') split sum is deferred like gemm_tn(defer=True): valid after
     flush_tn(); out / beta: dW = beta*out + sum (accumulated in place).
     phaseb = ((U0, U1, Ugz, S0, S1, count), gamma, invstd) of the layer BELOW (the double backward): the finalize launch also runs
-    bn_dbl_phaseb on the sums it merges -> the return tuple ends with (sums [2Nb], dgamma [Nb])."""
-    b = _gemm_dual_build(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=edge, out=out, beta=beta, bias=bias, rowadd=rowadd, with_colsum=with_colsum)
+    bn_dbl_phaseb on the sums it merges -> the return tuple ends with (sums [2Nb], dgamma [Nb]); with a fourth element `mean` (of that layer)
+    also the coefficients coef [3,Nb] of the lazy operand p*X + q*y + r = bn_bwd_apply(X, y, mean, invstd, None, sums, count) -> (..., sums, dgamma, coef).
+    gout = (add [M,Nb], scale [Nb]): the returned g tensor holds add + scale*g instead of g (s0, s1 stay the sums of g): phase B's adjoint
+    X = xbarA + gamma*g leaves this launch."""
+    if phaseb is not None and len(phaseb) == 4:
+        return gemm_dual_multi([dict(dy=dy, W=W, y_ref=y_ref, scale=scale, shift=shift, mean=mean, invstd=invstd, slope=slope, out=out, beta=beta, bias=bias,
+                                     rowadd=rowadd, with_colsum=with_colsum, phaseb=phaseb, gout=gout)], defer=defer, _force=True)[0]
+    b = _gemm_dual_build(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=edge, out=out, beta=beta, bias=bias, rowadd=rowadd, with_colsum=with_colsum,
+                         gout=gout)
     a = b["a"]
     done = launch_timer("gemm_dual", a) if launch_timer is not None else None
     check(_lib.load().spgan_gemm_dual(C.byref(a), _s()), "gemm_dual", M=b["M"], Na=b["Na"], Nb=b["Nb"], k=b["ek"])
@@ -754,7 +761,7 @@ def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: 
 
 def _gemm_dual_build(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float, edge=None,
                      out: Optional[Tensor] = None, beta: float = 0.0, bias: Optional[Tensor] = None, rowadd: Optional[Tensor] = None,
-                     with_colsum: bool = False) -> dict:
+                     with_colsum: bool = False, gout=None) -> dict:
     """The argument block and the output / workspace tensors of one spgan_gemm_dual problem (shared by the stand-alone and the grouped launch)."""
     a2 = dy if isinstance(dy, Affine2) else None
     act = dy if isinstance(dy, ActOperand) else None
@@ -799,6 +806,12 @@ def _gemm_dual_build(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor,
         if tuple(rowadd.shape) != (M_, Nb):
             raise ValueError("rowadd must be [M,Nb]")
         a.rowadd = _p(rowadd); a.ld_rowadd = _ld(rowadd)
+    if gout is not None:
+        gadd, gscale = gout
+        _rowmajor2d(gadd, "gout.add")
+        if tuple(gadd.shape) != (M_, Nb):
+            raise ValueError("gout: add must be [M,Nb]")
+        a.gout_add = _p(gadd); a.ld_gout_add = _ld(gadd); a.gout_scale = _p(_vec(gscale, Nb, "gout.scale"))
     g = torch.empty((M_, Nb), dtype=torch.float32, device=A.device)
     part = torch.empty((runs, Nb, 2), dtype=torch.float32, device=A.device)
     ws = torch.empty((runs, Na, Nb), dtype=torch.float32, device=A.device)
@@ -828,13 +841,13 @@ def _gemm_dual_pending(b: dict) -> None:
 GROUPED = [os.environ.get("SPGAN_GROUPED", "1") != "0"]      # test / A-B hook: False issues every problem of a grouped call as its stand-alone launch
 
 
-def gemm_dual_multi(specs, defer: bool = True):
+def gemm_dual_multi(specs, defer: bool = True, _force: bool = False):
     """Several gemm_dual problems of ONE geometry (equal M, Na, Nb, no per-edge operand) as one launch (spgan_gemm_dual_multi), followed by ONE
     finalize launch for all of them (spgan_colstats_finalize_multi): the same layer's backward of the D step's real pass, fake pass and of
     phase B of the penalty's double backward.  specs: one dict of gemm_dual's arguments per problem (dy, W, y_ref, scale, shift, mean, invstd,
     slope [, coef_bn | phaseb, out, beta, bias, rowadd, with_colsum]); -> the list of gemm_dual's return tuples, bit-identical to separate calls.
     defer=False: the weight-gradient sums (and column sums) of all problems are finished by one flush_tn()."""
-    if len(specs) == 1 or not GROUPED[0]:
+    if (len(specs) == 1 or not GROUPED[0]) and not _force:
         return [gemm_dual(defer=defer, **sp) for sp in specs]
     from ._lib import ColFinalizeArgs, GROUP_MAX
     if len(specs) > GROUP_MAX:
@@ -866,14 +879,21 @@ def gemm_dual_multi(specs, defer: bool = True):
             f.gamma = _p(None if gamma is None else _vec(gamma, Nb, "gamma")); f.count = float(count); f.coef = _p(coef)
             res.append((b["dW"], b["g"], fin[0], fin[1], coef) + extra)
         elif phaseb is not None:
-            (U0, U1, Ugz, S0, S1, count), pg, pinv = phaseb
+            (U0, U1, Ugz, S0, S1, count), pg, pinv = phaseb[:3]
             sums = torch.empty((2 * Nb,), dtype=torch.float32, device=dev)
             dg = torch.empty((Nb,), dtype=torch.float32, device=dev)
             vs = [_vec(t.contiguous(), Nb, nm) for t, nm in ((U0, "U0"), (U1, "U1"), (Ugz, "Ugz"), (S0, "S0"), (S1, "S1"), (pg, "gamma"), (pinv, "invstd"))]
             keep.append(vs)
             f.kind = 2; f.U0, f.U1, f.Ugz, f.S0, f.S1, f.gamma, f.invstd = [_p(t) for t in vs]
             f.count = float(count); f.sums = _p(sums); f.dgamma = _p(dg)
-            res.append((b["dW"], b["g"], fin[0], fin[1]) + extra + (sums, dg))
+            tail = (sums, dg)
+            if len(phaseb) == 4:      # + the lazy-operand coefficients of the BatchNorm backward these sums belong to
+                pmean = _vec(phaseb[3].contiguous(), Nb, "mean")
+                keep.append(pmean)
+                coefB = torch.empty((3, Nb), dtype=torch.float32, device=dev)
+                f.mean = _p(pmean); f.pb_coef = _p(coefB)
+                tail = (sums, dg, coefB)
+            res.append((b["dW"], b["g"], fin[0], fin[1]) + extra + tail)
         else:
             f.kind = 0
             res.append((b["dW"], b["g"], fin[0], fin[1]) + extra)

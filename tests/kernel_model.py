@@ -801,7 +801,7 @@ def gemm_dual_ok(dy, W, y_ref, edge=None):
 
 
 def gemm_dual(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=None, coef_bn=None, defer=True, out=None, beta=0.0, bias=None, rowadd=None,
-              with_colsum=False, phaseb=None):
+              with_colsum=False, phaseb=None, gout=None):
     """= gemm_tn(dy, y_ref, pro / edge) and gemm_nt_bnbwd(dy, W^T, y_ref, ...) of the same operands."""
     d = dy.dense() if isinstance(dy, ActOperand) else dy
     dW = gemm_tn(d, y_ref, pro=(scale, shift, slope), edge=edge)
@@ -812,8 +812,16 @@ def gemm_dual(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=None, coef_b
                         **({} if coef_bn is None else dict(coef_bn=coef_bn)))
     extra = (_dense(d).sum(0),) if with_colsum else ()
     if phaseb is not None:
-        co, pg, pinv = phaseb
-        extra = extra + tuple(bn_dbl_phaseb(co, pg, pinv, res[1], res[2]))
+        co, pg, pinv = phaseb[:3]
+        sums, dgam = bn_dbl_phaseb(co, pg, pinv, res[1], res[2])
+        extra = extra + (sums, dgam)
+        if len(phaseb) == 4:       # coefficients of p*X + q*y + r = pinv*(X - S0/M - xhat*S1/M)
+            C_, rM = pinv.numel(), 1.0 / co[5]
+            q_ = -(pinv * pinv) * (sums[C_:] * rM)
+            extra = extra + (torch.stack([pinv, q_, -(pinv * (sums[:C_] * rM)) - q_ * phaseb[3]]),)
+    res = list(res)
+    if gout is not None:
+        res[0] = gout[0] + gout[1] * res[0]
     return (dW,) + tuple(res) + extra
 
 

@@ -45,6 +45,29 @@ def _dual_spec(ops, tag, M, Nb, mode, tail):
     return sp
 
 
+@pytest.mark.parametrize("M,Nb,mode", [(16384, 256, "act"), (16384, 128, "dense"), (8192, 64, "lazy")])
+def test_gemm_dual_stored_adjoint_and_phase_b_coefficients(ops, M, Nb, mode):
+    """gout = (add, scale): the stored tile is add + scale*g with the statistics of g; a 4-element phaseb also yields the coefficients of the lazy
+    operand p*X + q*y + r that equals bn_bwd_apply(add, y, mean, invstd, None, sums, M, add=(g, scale)) -- phase B of the double backward without
+    its BatchNorm-backward pass (nets._phaseb_below)."""
+    sp = _dual_spec(ops, "gsa%d.%d" % (Nb, M), M, Nb, mode, "phaseb")
+    sp.pop("out", None); sp.pop("beta", None)
+    plain = ops.gemm_dual(defer=False, **sp)
+    g, s0, s1 = plain[1], plain[2], plain[3]
+    sums, dg = plain[-2], plain[-1]
+    add, scale = rnd("gsa.add%d" % Nb, (M, Nb)), rnd("gsa.scale%d" % Nb, (Nb,)).abs() + 0.5
+    ymean = rnd("gsa.ymean%d" % Nb, (Nb,), 0.2)
+    sp2 = dict(sp, phaseb=tuple(sp["phaseb"]) + (ymean,), gout=(add, scale))
+    res = ops.gemm_dual(defer=False, **sp2)
+    X, coef = res[1], res[-1]
+    assert torch.equal(res[0], plain[0]) and torch.equal(res[2], s0) and torch.equal(res[3], s1) and torch.equal(res[-3], sums) and torch.equal(res[-2], dg)
+    close(X, add.double() + scale.double() * g.double(), rtol=1e-6, atol=1e-6, what="stored adjoint")
+    y = sp["y_ref"]
+    inv = sp["phaseb"][2]
+    ref = ops.bn_bwd_apply(add, y, ymean, inv, None, sums, M, add=(g, scale))
+    close(ops.Affine2(X, y, coef).dense(), ref, rtol=2e-6, atol=2e-6 * float(ref.abs().max()), what="lazy phase-B operand vs bn_bwd_apply")
+
+
 @pytest.mark.parametrize("M,Nb,modes", [(16384, 256, ("act", "act", "act")), (65536, 128, ("lazy", "lazy", "dense")), (16384, 64, ("lazy", "lazy", "dense")),
                                         (8192, 128, ("lazy", "dense"))])
 def test_gemm_dual_multi_equals_separate_launches(ops, M, Nb, modes):
@@ -52,6 +75,9 @@ def test_gemm_dual_multi_equals_separate_launches(ops, M, Nb, modes):
     coef / coef / phase B), mlps.6 and mlps.3 (two lazy operands and phase B's dense one with beta = 1 accumulation)."""
     tails = ["coef"] * (len(modes) - 1) + ["phaseb"]
     specs = [_dual_spec(ops, "gdm%d.%d.%d" % (Nb, M, i), M, Nb, m, t) for i, (m, t) in enumerate(zip(modes, tails))]
+    if M == 65536:     # the last problem as the double backward issues it: stored adjoint + lazy coefficients
+        specs[-1]["phaseb"] = tuple(specs[-1]["phaseb"]) + (rnd("gdm.ymean", (Nb,), 0.2),)
+        specs[-1]["gout"] = (rnd("gdm.add", (M, Nb)), rnd("gdm.gscale", (Nb,)).abs() + 0.5)
     acc0 = [sp["out"].clone() if "out" in sp else None for sp in specs]
     got = ops.gemm_dual_multi(specs, defer=False)
     got = [tuple(t.clone() for t in r) for r in got]
