@@ -566,6 +566,10 @@ int spgan_lerp_rows(const float* real, const float* fake, const float* alpha, in
 int spgan_gp_penalty_fwd(const float* g, int B, size_t L, float gamma, float lambda, float* norms, float* loss, spgan_stream_t s);
 int spgan_gp_penalty_bwd(const float* g, const float* norms, int B, size_t L, float gamma, float lambda, const float* upstream,
                          float* v, spgan_stream_t s);
+/* spgan_gp_penalty_fwd and spgan_gp_penalty_bwd (upstream = 1) as two launches instead of three: row norms, then v and the penalty together;
+ * optional loss_total[0] = loss_add[0] + penalty (the D step's reported loss).  Values bit-identical to the separate calls. */
+int spgan_gp_penalty_fwd_bwd(const float* g, int B, size_t L, float gamma, float lambda, float* norms, float* loss, const float* loss_add,
+                             float* loss_total, float* v, spgan_stream_t s);
 /* ------------------------------------------------------------------------------------------
  * Ball-query / grouping family (Common/pointnet_util.py, Common/pointconv_util.py; orphans in the reference,
  * named by the north star).  xyz/new_xyz/points are [B,N,C] row-major like the reference; indices are int64.

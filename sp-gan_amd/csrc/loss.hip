@@ -140,7 +140,44 @@ __global__ void gp_bwd_kernel(const float* __restrict__ g, const float* __restri
   v[t] = c * g[t];
 }
 
+// gp_bwd_kernel and gp_value_kernel as ONE launch: every workgroup writes its part of v; workgroup 0 also forms the penalty (the arithmetic and
+// summation order of gp_value_kernel) and, with loss_add, total[0] = loss_add[0] + penalty (the D step's reported loss: no add launch)
+__global__ __launch_bounds__(256) void gp_value_bwd_kernel(const float* __restrict__ g, const float* __restrict__ norms, size_t L, size_t total, int B,
+                                                           float gamma, float lambda, float* __restrict__ loss, const float* __restrict__ loss_add,
+                                                           float* __restrict__ loss_total, float* __restrict__ v) {
+  __shared__ float red[4];
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < total) {
+    const float n = norms[t / L];
+    const float c = (n > 0.f) ? 1.f * lambda * (2.f / (float)B) * ((n - gamma) / (gamma * gamma)) / n : 0.f;
+    v[t] = c * g[t];
+  }
+  if (blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+      const float d = (norms[i] - gamma) / gamma;
+      s = fmaf(d, d, s);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+      const float pen = lambda * s / (float)B;
+      loss[0] = pen;
+      if (loss_total) loss_total[0] = loss_add[0] + pen;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int spgan_gp_penalty_fwd_bwd(const float* g, int B, size_t L, float gamma, float lambda, float* norms, float* loss, const float* loss_add,
+                                        float* loss_total, float* v, spgan_stream_t s_) {
+  SPGAN_CHECK_ARG(g && norms && loss && v && B > 0 && L > 0 && gamma != 0.f && (!loss_total == !loss_add));
+  const size_t total = (size_t)B * L;
+  hipLaunchKernelGGL(row_norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)s_, g, L, norms);
+  hipLaunchKernelGGL(gp_value_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)s_, g, norms, L, total, B, gamma, lambda, loss, loss_add,
+                     loss_total, v);
+  return spgan_launch_status();
+}
 
 extern "C" int spgan_gan_loss(int mode, int which, const float* d_real, const float* d_fake, const float* real_label, const float* fake_label,
                               int B, float* out5, float* g_real, float* g_fake, spgan_stream_t s_) {

@@ -237,6 +237,7 @@ SIGNATURES = {
     "spgan_lerp_rows": (I, [P, P, P, I, SZ, P, P]),
     "spgan_gp_penalty_fwd": (I, [P, I, SZ, F, F, P, P, P]),
     "spgan_gp_penalty_bwd": (I, [P, P, I, SZ, F, F, P, P, P]),
+    "spgan_gp_penalty_fwd_bwd": (I, [P, I, SZ, F, F, P, P, P, P, P, P]),
     "spgan_square_distance": (I, [P, P, I, I, I, I, P, P]),
     "spgan_index_points": (I, [P, P, I, I, I, I, P, P]),
     "spgan_farthest_point_sample": (I, [P, I, I, I, P, P, P, P]),

@@ -203,13 +203,13 @@ class GradientPenalty:
         v = ops.gp_penalty_bwd(g, norms, float(self.gamma), float(self.lambdaGP), None)
         return loss, grads, v.view_as(grads)
 
-    def from_input_gradient(self, grads: torch.Tensor, B: int):
-        """(penalty [1], seed) for an input gradient that is already there (TrainStep's joint D-step node, Discriminator.stacks_joint): the
-        penalty of gradient_penalty.py:31-35 and v = d penalty / d grads, the seed of the double backward."""
+    def from_input_gradient(self, grads: torch.Tensor, B: int, loss_add: Optional[torch.Tensor] = None):
+        """(penalty [1], seed, total) for an input gradient that is already there (TrainStep's joint D-step node, Discriminator.stacks_joint): the
+        penalty of gradient_penalty.py:31-35, v = d penalty / d grads (the seed of the double backward) and, with loss_add [1], total = loss_add +
+        penalty from the same launch (else None)."""
         g = grads.detach().contiguous().view(B, -1)
-        loss, norms = ops.gp_penalty_fwd(g, float(self.gamma), float(self.lambdaGP))
-        v = ops.gp_penalty_bwd(g, norms, float(self.gamma), float(self.lambdaGP), None)
-        return loss, v.view_as(grads)
+        loss, _norms, v, total = ops.gp_penalty_fwd_bwd(g, float(self.gamma), float(self.lambdaGP), loss_add)
+        return loss, v.view_as(grads), total
 
     def interpolate(self, real_data, fake_data, alpha: Optional[torch.Tensor] = None, mapping: bool = False):
         """x_hat [B,3,N] (detached): the points the penalty is evaluated at."""

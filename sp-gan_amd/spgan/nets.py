@@ -530,8 +530,10 @@ def _d_double_top_phase_a(P, ctx, saved, q3: Tensor, grads) -> dict:
     dz = saved["dys"][3]
     S0, S1 = saved["sums"][3][:C], saved["sums"][3][C:]
     pro3 = (bns[2][0], bns[2][1], NEG)                                           # a3 = lrelu(bn3(y3)), applied to y3 on the operand loads
-    Qqa = ops.gemm_tn(q3, ys[2], pro=pro3)                                       # q3^T a3 [256,256]
-    cq = ops.colsum(q3)[0]
+    # q3^T a3 [256,256] and colsum(q3) from one launch; their split sums -- and those of phase A's weight gradients below this layer, deferred
+    # by _d_double_phase_a -- are finished by ONE reduction launch
+    Qqa, cq = ops.gemm_tn(q3, ys[2], pro=pro3, with_colsum=True, defer=True)
+    ops.flush_tn()
     if ops.wgrad_collapse_ok(W, Qqa, B):
         # T = W.(a3^T q3) and dW = diag(alpha).T + (alpha*b4 + beta) (x) colsum(q3) + S^T q3 from one launch
         dW, T = ops.wgrad_collapse(W, Qqa, dz.alpha, b4, dz.beta, cq, sparse=(dz.sp_val, dz.sp_arg, N, q3, None), want_T=True)
@@ -625,7 +627,8 @@ def _d_double_phase_a(P, ctx, saved, v_dx_cm: Tensor):
             # tensor is formed in either phase.
             top = _d_double_top_phase_a(P, ctx, saved, q, grads)
             break
-        grads[conv + ".weight"] = ops.gemm_tn(dys[li], q)                       # gy_l^T q_{l-1}
+        # gy_l^T q_{l-1}; with the collapsed top layer ahead its split sum waits for that layer's reduction launch (_d_double_top_phase_a)
+        grads[conv + ".weight"] = ops.gemm_tn(dys[li], q, defer=isinstance(dys[3], ops.SparseAffine))
         u = ops.gemm_nt(q, W)                                                    # adjoint of gy_l
         if li == 3:
             gz = ops.scatter_rows(saved["gval"], argmax, M)

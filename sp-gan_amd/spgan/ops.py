@@ -1966,6 +1966,23 @@ def gp_penalty_fwd(g: Tensor, gamma: float, lam: float):
     return loss, norms
 
 
+def gp_penalty_fwd_bwd(g: Tensor, gamma: float, lam: float, loss_add: Optional[Tensor] = None):
+    """gp_penalty_fwd and gp_penalty_bwd(upstream = None) with one launch less: -> (loss [1], norms [B], v, total | None); with loss_add [1]:
+    total [1] = loss_add + loss from the same launch (the D step's reported loss).  The values of the separate calls, bit for bit."""
+    g = _f32(g, "g").contiguous()
+    B = g.shape[0]
+    norms = torch.empty((B,), dtype=torch.float32, device=g.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=g.device)
+    v = torch.empty_like(g)
+    total = la = None
+    if loss_add is not None:
+        la = _f32(loss_add, "loss_add").reshape(1)
+        total = torch.empty((1,), dtype=torch.float32, device=g.device)
+    check(_lib.load().spgan_gp_penalty_fwd_bwd(_p(g), B, g.numel() // B, float(gamma), float(lam), _p(norms), _p(loss), _p(la), _p(total), _p(v), _s()),
+          "gp_penalty_fwd_bwd")
+    return loss, norms, v, total
+
+
 def gp_penalty_bwd(g: Tensor, norms: Tensor, gamma: float, lam: float, upstream: Optional[Tensor]) -> Tensor:
     g = g.contiguous()
     B = g.shape[0]

@@ -301,9 +301,9 @@ class TrainStep:
                 roots, seeds = [d_real, d_fake], [g_real, g_fake]
                 loss_d = out5[0]
                 if self.use_gp:
-                    pen, v = self.gp.from_input_gradient(outs[2], B)
+                    pen, v, tot = self.gp.from_input_gradient(outs[2], B, loss_add=out5[0:1])
                     roots.append(outs[2]); seeds.append(v)
-                    loss_d = loss_d + pen[0]
+                    loss_d = tot[0]
             else:
                 d_real, d_fake = D.forward_heads([D.forward_stack(real_pm, pre=pre[0]), D.forward_stack(fake, pre=pre[1])])
                 out5, g_real, g_fake = dis_loss_with_grads(d_real, d_fake, self.gan, self.flip_d)

@@ -760,6 +760,12 @@ def gp_penalty_bwd(g, norms, gamma, lam, upstream):
     return (c.reshape(B, *([1] * (g.dim() - 1))) * g).contiguous()
 
 
+def gp_penalty_fwd_bwd(g, gamma, lam, loss_add=None):
+    loss, norms = gp_penalty_fwd(g, gamma, lam)
+    v = gp_penalty_bwd(g, norms, gamma, lam, None)
+    return loss, norms, v, (None if loss_add is None else loss_add.reshape(1) + loss)
+
+
 def reduce_chunks(recv, out=None):
     s = recv[0].clone()
     for j in range(1, recv.shape[0]):

@@ -259,3 +259,14 @@ def test_train_step_joint_d_backward_equals_one_node_per_pass(ops, gan, use_gp):
     for n in a["d_grads"]:
         ga, gb = a["d_grads"][n], b["d_grads"][n]
         assert (ga - gb).norm().item() <= 2e-6 * gb.norm().item() + 1e-12, (n, (ga - gb).norm().item(), gb.norm().item())
+
+
+def test_gp_penalty_fwd_bwd_equals_separate_calls(ops):
+    B, L = 32, 3 * 2048
+    g = rnd("gpf.g", (B, L), 1e-3)
+    la = rnd("gpf.la", (1,))
+    loss, norms = ops.gp_penalty_fwd(g, 1.0, 10.0)
+    v = ops.gp_penalty_bwd(g, norms, 1.0, 10.0, None)
+    l2, n2, v2, tot = ops.gp_penalty_fwd_bwd(g, 1.0, 10.0, la)
+    assert torch.equal(loss, l2) and torch.equal(norms, n2) and torch.equal(v, v2) and torch.equal(tot, la + loss)
+    assert ops.gp_penalty_fwd_bwd(g, 1.0, 10.0)[3] is None
