@@ -859,7 +859,14 @@ def gemm_dual_multi(specs, defer: bool = True, _force: bool = False):
     lib = _lib.load()
     n = len(bs)
     arr = (GemmDualArgs * n)(*[b["a"] for b in bs])
+    done = None
+    if launch_timer is not None:            # measurement hook: one record for the grouped launch, rows = the rows of all its problems
+        agg = GemmDualArgs()
+        agg.M, agg.Na, agg.Nb = n * bs[0]["M"], bs[0]["Na"], bs[0]["Nb"]
+        done = launch_timer("gemm_dual", agg)
     check(lib.spgan_gemm_dual_multi(arr, n, _s()), "gemm_dual_multi", M=bs[0]["M"], Na=bs[0]["Na"], Nb=bs[0]["Nb"], count=n)
+    if done is not None:
+        done()
     for b in bs:
         _gemm_dual_pending(b)
     if not defer:
