@@ -63,7 +63,7 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense p
 FP16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (never the 2:1-sparsity figure)
 # algorithmic FLOPs per shape per step, reference formulation: WGAN-GP at N=2048
 GF_PER_SHAPE_STEP = 67.3 if CONFIG == "c4" else 32.6     # 2 F_Gf + 4N*779,520 + 15 F_Df at N = 4096 / 2048
-PMC_FILES = ("r04_pmc_gemm_nt.json", "r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json")
+PMC_FILES = ("r05_pmc_gemm_nt.json", "r04_pmc_gemm_nt.json", "r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json")
 PMC_STEP_FILES = ("r04_pmc_step.json", "r03_pmc_step.json", "r02_pmc_step.json")
 ALGORITHMIC_HBM_GB_PER_STEP = 3.5      # ~110 MB per shape per step x 32 shapes
 

@@ -71,6 +71,50 @@ def _engine_needs(ctx, pos: int, tpos: int) -> bool:
 # Parameter gradients are handed back to autograd (AccumulateGrad, hooks, torch.autograd.grad all behave as usual) unless the
 # caller opted into the fused route with `fused_grad_accumulation()` -- spgan.TrainStep does, around each of its segments (the mode is
 # recorded per graph when a Function's FORWARD runs: the context must enclose the forward pass, wrapping only backward() selects nothing).
+class DeliverySink:
+    """Where the nodes of ONE backward pass leave their parameter gradients when the caller accumulates them itself (TrainStep, one sink per
+    network): every fused `_deliver` appends its (destination, source) pairs instead of launching its own split-sum reduction and accumulation,
+    and `flush()` -- called by the owner when backward() has returned, on the same stream -- finishes ALL deferred split sums with one
+    reduction launch and adds every gradient with one launch (two when a parameter received more than one gradient: those go through
+    spgan_multi_addn in arrival order).  The same sums as the per-node launches (a parameter's gradients are added in the order the nodes ran)."""
+
+    def __init__(self):
+        self._pairs = []
+        self._lock = threading.Lock()
+
+    def add(self, pairs) -> None:
+        with self._lock:
+            self._pairs.extend(pairs)
+
+    def flush(self) -> None:
+        with self._lock:
+            pairs, self._pairs = self._pairs, []
+        ops.flush_tn()
+        if not pairs:
+            return
+        by_dst, order = {}, []
+        for d, s_ in pairs:
+            key = (d.data_ptr(), tuple(d.shape), tuple(d.stride()))
+            if key not in by_dst:
+                by_dst[key] = (d, [])
+                order.append(key)
+            by_dst[key][1].append(s_)
+        single = [(by_dst[k][0], by_dst[k][1][0]) for k in order if len(by_dst[k][1]) == 1]
+        multi = [by_dst[k] for k in order if len(by_dst[k][1]) > 1]
+        rest = []
+        for d, ss in multi:      # more than three gradients for one parameter, or strided ones: further rounds of plain adds
+            if len(ss) > 3 or not d.is_contiguous() or any(not x.is_contiguous() for x in ss):
+                rest.append((d, ss))
+        multi = [m for m in multi if not any(m[0] is r[0] for r in rest)]
+        if single:
+            ops.multi_add([d for d, _ in single], [s_ for _, s_ in single])
+        if multi:
+            ops.multi_addn([d for d, _ in multi], [ss for _, ss in multi])
+        for d, ss in rest:
+            for x in ss:
+                ops.multi_add([d], [x])
+
+
 class fused_grad_accumulation(_Mode):
     """Context: the nodes of forward passes evaluated inside it add their parameter gradients straight into the pre-bound flat `.grad`
     buffers (spgan.optim.flatten_module) with one fused launch per Function and return None to autograd.  Only for callers that read
@@ -79,10 +123,23 @@ class fused_grad_accumulation(_Mode):
     pass -- a context around backward() alone has no effect on graphs built outside it."""
     name = "fused"
 
+    def __init__(self, sink: Optional[DeliverySink] = None):
+        """sink: the graphs built inside leave their parameter gradients there (DeliverySink) and the caller flushes it after backward()."""
+        self.sink = sink
+
+    def __enter__(self):
+        super().__enter__()
+        self._prev = getattr(_TLS, "sink", None)
+        _TLS.sink = self.sink
+
+    def __exit__(self, *exc):
+        _TLS.sink = self._prev
+        super().__exit__(*exc)
+
 
 def _record_modes(ctx, holder=None) -> None:
     """Called in every Function.forward (on the caller's thread): remember the backward modes selected for this graph."""
-    ctx.fused = _mode("fused")
+    ctx.fused = (getattr(_TLS, "sink", None) or True) if _mode("fused") else False      # True, or the DeliverySink the gradients go to
     ctx.input_only = _mode("input_only")
     if holder is not None:                       # nodes created later INSIDE this node's backward (the double-backward node) inherit them
         holder.fused, holder.input_only = ctx.fused, ctx.input_only
@@ -95,8 +152,11 @@ def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool], f
     elementwise launch per parameter tensor (and on the launch stream, which keeps the step capturable as a hipGraph).  Non-leaf
     "parameters" (the scaled weights of equalised-LR layers) get their gradient returned.  Exact-zero gradients (nets.ZERO_GRAD)
     cost nothing on the fused path."""
-    ops.flush_tn()                     # weight gradients whose split-K sums were deferred (ops.gemm_tn(defer=True)) become valid here
-    fused = fused and not torch.is_grad_enabled()
+    sink = fused if isinstance(fused, DeliverySink) else None
+    fused = bool(fused) and not torch.is_grad_enabled()
+    if sink is None or not fused:
+        ops.flush_tn()                 # weight gradients whose split-K sums were deferred (ops.gemm_tn(defer=True)) become valid here
+        sink = None                    # (with a sink the owner's flush() finishes them, together with those of every other node)
     out: List[Optional[Tensor]] = [None] * len(params)
     pairs = []
     for i, (p, g, need) in enumerate(zip(params, grads, needs)):
@@ -121,8 +181,13 @@ def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool], f
             if isinstance(g, nets.CatCols):
                 g = g.cat()
             out[i] = g.view_as(p) if g.shape != p.shape else g
+    if sink is not None and any(o is not None for o in out):
+        ops.flush_tn()                 # a gradient handed back to autograd must be complete now
     if pairs:
-        ops.multi_add([d for d, _ in pairs], [s_ for _, s_ in pairs])
+        if sink is not None:
+            sink.add(pairs)
+        else:
+            ops.multi_add([d for d, _ in pairs], [s_ for _, s_ in pairs])
     return tuple(out)
 
 
@@ -262,9 +327,11 @@ class DStacksJointFn(Function):
             dbl = (h.hat[1], ctx.saved_hat, gouts[nf].detach())
         fg, hg = nets.d_backward_joint(P, firsts, dbl)
         chains = list(fg) + ([hg] if hg is not None else [])
-        ops.flush_tn()
         needs = ctx.needs_input_grad[1:]
-        fused = ctx.fused and not torch.is_grad_enabled()
+        fused = bool(ctx.fused) and not torch.is_grad_enabled()
+        sink = ctx.fused if (fused and isinstance(ctx.fused, DeliverySink)) else None
+        if sink is None:
+            ops.flush_tn()
         out: List[Optional[Tensor]] = [None] * len(params)
         dsts, srcs = [], []
         for i, (n, p_, need) in enumerate(zip(names, params, needs)):
@@ -280,7 +347,11 @@ class DStacksJointFn(Function):
                 for g in gs[1:]:
                     tot = tot + g
                 out[i] = tot.view_as(p_)
-        if dsts:
+        if sink is not None and any(o is not None for o in out):
+            ops.flush_tn()
+        if dsts and sink is not None:
+            sink.add([(d, g) for d, gs in zip(dsts, srcs) for g in gs])      # the owner adds them (arrival order) with everything else of this backward
+        elif dsts:
             ops.multi_addn(dsts, srcs)      # one launch: ((grad + real) + fake) + double backward, per parameter
         return (None,) + tuple(out)
 

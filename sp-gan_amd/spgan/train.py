@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .functions import fused_grad_accumulation
+from .functions import DeliverySink, fused_grad_accumulation
 from .losses import GradientPenalty, dis_loss_with_grads, gen_loss_with_grads
 from .optim import Adam
 from .parallel import DataParallel
@@ -74,6 +74,7 @@ class TrainStep:
         # The generator's two forwards of a step (D step, G step) see the same sphere prior and the same weights: EdgeConv1, which
         # depends on nothing else, is evaluated once and its BatchNorm running statistics are advanced twice (Generator.twin_forward).
         self.twin_g_forwards = not reference_schedule      # attribute = test hook
+        self._sinkD, self._sinkG = DeliverySink(), DeliverySink()      # where the backward nodes of the D / G step leave their parameter gradients
         self.joint_d_backward = os.environ.get("SPGAN_JOINT_D", "1") != "0"      # test / A-B hook: False keeps one autograd node (and one chain of launches) per D pass
         self.point_major = True                            # test hook: False keeps the [B,3,N] layout between the networks (same results up to the penalty norm's summation order)
         # Data parallel: the generator's forward of the G step does not depend on D's update, so it is issued while D's gradient
@@ -261,8 +262,12 @@ class TrainStep:
     # The iteration in three segments, split where the data-parallel all-reduces sit (they stay outside the captured graphs).
     def _seg_d(self, x, real, z_d, alpha, keep_grads, info):
         """D step up to lossD.backward() (model.py:240-258)."""
-        with fused_grad_accumulation():      # the nodes built here add their parameter gradients straight into the flat .grad buffers
-            return self._seg_d_body(x, real, z_d, alpha, keep_grads, info)
+        # the nodes built here add their parameter gradients straight into the flat .grad buffers -- through the step's sink: one split-sum
+        # reduction and one accumulation launch for the whole backward instead of a pair per node
+        with fused_grad_accumulation(self._sinkD):
+            out = self._seg_d_body(x, real, z_d, alpha, keep_grads, info)
+        self._sinkD.flush()
+        return out
 
     def _seg_d_body(self, x, real, z_d, alpha, keep_grads, info):
         G, D = self.G, self.D
@@ -359,7 +364,7 @@ class TrainStep:
         self.optG.zero_grad()
         G.twin_forward = "second" if self.twin_g_forwards else None
         try:
-            with fused_grad_accumulation():
+            with fused_grad_accumulation(self._sinkG):
                 return G(x, z_g, pm_out=True) if pm else G(x, z_g)
         finally:
             G.twin_forward = None
@@ -367,8 +372,9 @@ class TrainStep:
     def _seg_g(self, x, real_t, z_g, scale_d, keep_grads, info, g_fake=None):
         """optimizerD.step(), then the G step up to lossG.backward() (model.py:259-277).  g_fake: the generator's forward when the
         caller already issued it (_seg_gfwd)."""
-        with fused_grad_accumulation():
+        with fused_grad_accumulation(self._sinkG):
             self._seg_g_body(x, real_t, z_g, scale_d, keep_grads, info, g_fake)
+        self._sinkG.flush()
 
     def _seg_g_body(self, x, real_t, z_g, scale_d, keep_grads, info, g_fake=None):
         G, D = self.G, self.D
