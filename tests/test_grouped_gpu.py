@@ -231,15 +231,16 @@ def test_d_backward_joint_equals_separate_calls(ops, B, N, with_dbl):
             assert torch.equal(ga[n].reshape(-1), gb[n].reshape(-1)), "pass %d, %s: max diff %.3e" % (ci, n, (ga[n].reshape(-1) - gb[n].reshape(-1)).abs().max().item())
 
 
-@pytest.mark.parametrize("gan,use_gp", [("wgan", True), ("ls", False)])
-def test_train_step_joint_d_backward_equals_one_node_per_pass(ops, gan, use_gp):
+@pytest.mark.parametrize("gan,use_gp,small_d", [("wgan", True, False), ("ls", False, False), ("hinge", True, True)])
+def test_train_step_joint_d_backward_equals_one_node_per_pass(ops, gan, use_gp, small_d):
     """TrainStep with the joint D-step node (default) against one autograd node per pass: D's gradients differ only by the order in which the
     three per-pass gradients are added into .grad (1e-6 of each tensor), losses agree."""
     import spgan
     from oracle import spgan_oracle as orc
 
     class O:
-        np = 2048; nk = 20; nz = 128; softmax = True; off = False; attn = False; use_head = False; eql = False; z_norm = False; small_d = False
+        np = 2048; nk = 20; nz = 128; softmax = True; off = False; attn = False; use_head = False; eql = False; z_norm = False
+    O.small_d = small_d            # --small_d: a 512-wide top layer (Discriminator.py:52)
     B, N = 8, 2048
     x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
     real = fr.synthetic_real(B, N, seed=71).cuda()
@@ -249,10 +250,29 @@ def test_train_step_joint_d_backward_equals_one_node_per_pass(ops, gan, use_gp):
     for joint in (True, False):
         G, D = spgan.Generator(O), spgan.Discriminator(O)
         G.load_state_dict({**G.state_dict(), **fr.init_params(orc.generator_shapes(), salt=7)})
-        D.load_state_dict({**D.state_dict(), **fr.init_params(orc.discriminator_shapes(), salt=7)})
+        if not small_d:
+            D.load_state_dict({**D.state_dict(), **fr.init_params(orc.discriminator_shapes(), salt=7)})
+        else:
+            torch.manual_seed(5)
+            D.load_state_dict({k: (torch.randn_like(v) * 0.05 if v.dtype.is_floating_point and "running" not in k else v) for k, v in D.state_dict().items()})
+            with torch.no_grad():
+                for k, v in D.named_parameters():
+                    if k.endswith("1.weight") or k.endswith("4.weight") or k.endswith("7.weight"):      # BatchNorm scales around one
+                        v.add_(1.0)
         G.cuda().train(); D.cuda().train()
         tr = spgan.TrainStep(G, D, gan=gan, use_gp=use_gp)
         tr.joint_d_backward = joint
+        if joint:
+            calls = []
+            from spgan import nets
+            real_joint = nets.d_backward_joint
+            nets.d_backward_joint = lambda P, firsts, dbl=None: (calls.append(len(firsts)), real_joint(P, firsts, dbl))[1]
+            try:
+                outs.append(tr.step(x, real, z_d, z_g, alpha=alpha, keep_grads=True))
+            finally:
+                nets.d_backward_joint = real_joint
+            assert calls == [2], "the joint route did not run"
+            continue
         outs.append(tr.step(x, real, z_d, z_g, alpha=alpha, keep_grads=True))
     a, b = outs
     assert abs(a["loss_d"].item() - b["loss_d"].item()) <= 1e-6 * abs(b["loss_d"].item()) + 1e-7
