@@ -292,31 +292,22 @@ class DStackFn(Function):
 
 
 class DStacksJointFn(Function):
-    """The D step's passes behind ONE node, so that their backward work runs in lock step (nets.d_backward_joint):
-    outputs = (logits of every first-order pass ..., gx) with gx = d sum(D(x_hat)) / d x_hat of the `hat` pass (WGAN-GP,
-    Common/gradient_penalty.py:28-33; its first-order backward runs inside this forward).  The per-shape MLP head of ALL passes is one batch
-    (it has no BatchNorm: rows are independent).  The backward receives the loss kernel's seeds on the logits and the penalty's seed on gx --
-    the double backward -- together: the head backward of the first-order passes, then every conv-stack layer's launch once for all passes.
-    inputs: holder(names, firsts=[(pooled, dctx)], hat=(pooled, dctx) | None), *all D params."""
+    """The conv stacks of the D step's passes behind ONE node, so that their backward work runs in lock step (nets.d_backward_joint):
+    outputs = (pooled of every first-order pass ..., gx) with gx = d sum(D(x_hat)) / d x_hat of the `hat` pass (WGAN-GP,
+    Common/gradient_penalty.py:28-33; its head and first-order backward run inside this forward).  The backward receives the pooled
+    gradients of the first-order passes (from DHeadFn) and the penalty's seed on gx -- the double backward -- together: every layer's
+    launch is issued once for all of them.  inputs: holder(names, firsts=[(pooled, dctx)], hat=(pooled, dctx) | None), *all D params."""
 
     @staticmethod
     def forward(ctx, holder, *params):
         _record_modes(ctx, holder)
-        P = dict(zip(holder.names, params))
-        parts = [pooled for pooled, _ in holder.firsts] + ([holder.hat[0]] if holder.hat is not None else [])
-        sizes = [p_.shape[0] for p_ in parts]
-        pooled_all = ops.stacked_rows([p_.detach() for p_ in parts])          # a view when one grouped launch produced the passes
-        logits_all, hs_all = nets.d_head_forward(P, pooled_all)
-        nf = sum(sizes[:len(holder.firsts)])
-        ctx.pooled_f, ctx.hs_f = pooled_all[:nf], [h[:nf] for h in hs_all]
-        ctx.sizes_f = sizes[:len(holder.firsts)]
-        outs = list(logits_all[:nf].split(ctx.sizes_f, dim=0)) if holder.firsts else []
+        outs = [pooled for pooled, _ in holder.firsts]
         ctx.saved_hat = None
         if holder.hat is not None:
-            _, dctx_h = holder.hat
-            dctx_h["hs"] = [h[nf:] for h in hs_all]
-            logits_h = logits_all[nf:]
-            ones = nets._const_vec(logits_h.numel(), 1.0, logits_h.device).view_as(logits_h)          # grad_outputs = ones (gradient_penalty.py:29), a cached constant
+            P = dict(zip(holder.names, params))
+            pooled_h, dctx_h = holder.hat
+            logits, dctx_h["hs"] = nets.d_head_forward(P, pooled_h)
+            ones = nets._const_vec(logits.numel(), 1.0, logits.device).view_as(logits)          # grad_outputs = ones (gradient_penalty.py:29), a cached constant
             dx, _, ctx.saved_hat = nets.d_backward(P, dctx_h, ones, True, False, keep_for_double=True)
             outs.append(dx)
         ctx.holder = holder
@@ -330,19 +321,12 @@ class DStacksJointFn(Function):
         names = h.names
         P = dict(zip(names, [nets.owned(p) for p in params]))
         nf = len(h.firsts)
-        chains = []
-        firsts = []
-        if nf:
-            # the head of the first-order passes as one batch (a pass the loss does not depend on contributes a zero seed)
-            dout = ops.stacked_rows([g.detach() if g is not None else ctx.pooled_f.new_zeros((n, 1)) for g, n in zip(gouts[:nf], ctx.sizes_f)])
-            gpool, hgrads, _ = nets.d_head_backward(P, ctx.pooled_f, ctx.hs_f, dout.contiguous(), True)
-            chains.append(hgrads)
-            firsts = [(dctx, gp) for (_, dctx), gp in zip(h.firsts, gpool.split(ctx.sizes_f, dim=0))]
+        firsts = [(dctx, g.detach()) for (_, dctx), g in zip(h.firsts, gouts[:nf]) if g is not None]
         dbl = None
         if h.hat is not None and gouts[nf] is not None:
             dbl = (h.hat[1], ctx.saved_hat, gouts[nf].detach())
         fg, hg = nets.d_backward_joint(P, firsts, dbl)
-        chains += list(fg) + ([hg] if hg is not None else [])
+        chains = list(fg) + ([hg] if hg is not None else [])
         needs = ctx.needs_input_grad[1:]
         fused = bool(ctx.fused) and not torch.is_grad_enabled()
         sink = ctx.fused if (fused and isinstance(ctx.fused, DeliverySink)) else None
@@ -368,9 +352,7 @@ class DStacksJointFn(Function):
         if dsts and sink is not None:
             sink.add([(d, g) for d, gs in zip(dsts, srcs) for g in gs])      # the owner adds them (arrival order) with everything else of this backward
         elif dsts:
-            for j in range(max(len(gs) for gs in srcs)):                     # rounds of plain adds (a parameter has at most four sources here)
-                pr = [(d, gs[j]) for d, gs in zip(dsts, srcs) if len(gs) > j]
-                ops.multi_add([d for d, _ in pr], [g for _, g in pr])
+            ops.multi_addn(dsts, srcs)      # one launch: ((grad + real) + fake) + double backward, per parameter
         return (None,) + tuple(out)
 
 

@@ -485,9 +485,9 @@ def _discriminator_forward_heads(self, pooled):
 
 def _discriminator_stacks_joint(self, firsts, hat=None):
     """The D step's passes behind one autograd node (Fn.DStacksJointFn): firsts / hat are entries of forward_stacks_grouped(...).
-    -> [logits [B,1] of every first-order pass ..., gx] with gx = d sum(D(x_hat)) / d x_hat of the `hat` entry (differentiable once more: its
-    backward is the penalty's double backward).  The head of all passes is one batch; the backward work of all these passes runs in lock
-    step, every layer's launch issued once (nets.d_backward_joint) -- results as from forward(x, pre=...) per pass and its WGAN-GP route."""
+    -> [pooled of every first-order pass ..., gx] with gx = d sum(D(x_hat)) / d x_hat of the `hat` entry (differentiable once more: its
+    backward is the penalty's double backward).  The backward work of all these passes then runs in lock step, every layer's launch issued
+    once (nets.d_backward_joint) -- results as from forward_stack(pre=...) per pass and the WGAN-GP route of forward(pre=...)."""
     names, params = _named(self)
     h = _Holder(names=names, firsts=list(firsts), hat=hat)
     return list(Fn.DStacksJointFn.apply(h, *params))

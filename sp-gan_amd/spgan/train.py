@@ -301,7 +301,7 @@ class TrainStep:
                 # one node for the conv stacks of all passes: their backward work (real, fake, the penalty's double backward) runs in lock
                 # step, every layer's launch issued once for the three of them (nets.d_backward_joint)
                 outs = D.stacks_joint(pre[:2], pre[2] if self.use_gp else None)
-                d_real, d_fake = outs[0], outs[1]
+                d_real, d_fake = D.forward_heads(outs[:2])
                 out5, g_real, g_fake = dis_loss_with_grads(d_real, d_fake, self.gan, self.flip_d)
                 roots, seeds = [d_real, d_fake], [g_real, g_fake]
                 loss_d = out5[0]
