@@ -41,6 +41,18 @@ def test_argument_validation_without_gpu():
     assert lib.spgan_gemm_tn_ws_bytes(0, 4, 4) == 0
     with pytest.raises(RuntimeError):
         _lib.check(-22, "knn", B=1)
+    # the grouped launches (round 5): count outside 1 .. SPGAN_GROUP_MAX, problems of different geometry, missing pointers
+    one = (_lib.GemmDualArgs * 1)()
+    assert lib.spgan_gemm_dual_multi(one, 0, None) == -22 and lib.spgan_gemm_dual_multi(one, 5, None) == -22
+    assert lib.spgan_gemm_dual_multi(one, 1, None) == -22                 # an empty argument block
+    assert lib.spgan_colstats_finalize_multi((_lib.ColFinalizeArgs * 1)(), 1, None) == -22
+    assert lib.spgan_pool_bwd_stats_prep_multi((_lib.PoolBwdArgs * 1)(), 1, None) == -22
+    assert lib.spgan_wgrad_collapse_multi((_lib.WgradCollapseArgs * 2)(), 2, None) == -22
+    assert lib.spgan_gemm_tn_skinny_multi((_lib.GemmTNArgs * 1)(), 1, None) == -22
+    assert lib.spgan_multi_addn(_lib.MultiAddNArgs(), None) == -22
+    assert lib.spgan_collapse_prep(_lib.CollapsePrepArgs(), None) == -22
+    assert lib.spgan_gp_penalty_fwd_bwd(None, 1, 1, 1.0, 1.0, None, None, None, None, None, None) == -22
+    assert _lib.GROUP_MAX == 4 and _lib.MULTI_ADDN_MAX == 32
 
 
 def test_cpu_tensors_are_refused():
