@@ -495,15 +495,17 @@ class RepeatRowsFn(Function):
     batch); backward sums the B row blocks (deterministic column reduction)."""
 
     @staticmethod
-    def forward(ctx, x, B):
+    def forward(ctx, x, B, reuse=None):
         ctx.B = B
+        if reuse is not None:                   # the rows were written by an earlier evaluation (nets.g_pair_forward)
+            return reuse.view_as(reuse)
         return x.repeat(B, 1)
 
     @staticmethod
     def backward(ctx, g):
         B = ctx.B
         M, Cn = g.shape
-        return ops.colsum(g.contiguous().view(B, (M // B) * Cn))[0].view(M // B, Cn), None
+        return ops.colsum(g.contiguous().view(B, (M // B) * Cn))[0].view(M // B, Cn), None, None
 
 
 class AdaINFn(Function):
@@ -513,7 +515,12 @@ class AdaINFn(Function):
     def forward(ctx, holder, x, style, w, b):
         _record_modes(ctx, holder)
         P = {holder.prefix + ".style.weight": w, holder.prefix + ".style.bias": b}
-        out, actx = nets.adain_forward(P, holder.prefix, x.contiguous(), style.contiguous(), holder.N, holder.slope)
+        reuse = getattr(holder, "reuse", None)
+        if reuse is not None:                   # evaluated by nets.g_pair_forward: adopt the rows and the saved context of this pass
+            out, actx = reuse
+            out = out.view_as(out)
+        else:
+            out, actx = nets.adain_forward(P, holder.prefix, x.contiguous(), style.contiguous(), holder.N, holder.slope)
         ctx.holder, ctx.actx = holder, actx
         ctx.save_for_backward(w, b)
         return out
@@ -596,10 +603,15 @@ class HeadFn(Function):
         _record_modes(ctx, holder)
         W0 = nets._w2(w0)
         c = x_pm.shape[1]
-        rb = ops.gemm_nt(zb.contiguous(), W0[:, c:], b0)                               # [B,128]
-        P = {"head.0.weight": w0, "head.0.bias": b0, "head.2.weight": w2, "head.2.bias": b2}
-        out, mctx = nets.mlp_forward(P, ["head.0", "head.2"], [ops.ACT_LRELU, ops.ACT_LRELU], x_pm.contiguous(), nets.NEG,
-                                     rowbias=rb, N=holder.N, first_weight=W0[:, :c])
+        reuse = getattr(holder, "reuse", None)
+        if reuse is not None:                   # evaluated by nets.g_pair_forward
+            out, mctx = reuse
+            out = out.view_as(out)
+        else:
+            rb = ops.gemm_nt(zb.contiguous(), W0[:, c:], b0)                               # [B,128]
+            P = {"head.0.weight": w0, "head.0.bias": b0, "head.2.weight": w2, "head.2.bias": b2}
+            out, mctx = nets.mlp_forward(P, ["head.0", "head.2"], [ops.ACT_LRELU, ops.ACT_LRELU], x_pm.contiguous(), nets.NEG,
+                                         rowbias=rb, N=holder.N, first_weight=W0[:, :c])
         ctx.mctx, ctx.c = mctx, c
         ctx.save_for_backward(zb, w0, b0, w2, b2)
         return out
@@ -686,13 +698,19 @@ class GlobalTailFn(Function):
         P = dict(zip(GT_NAMES, params))
         a2 = a2.contiguous()
         B, N = holder.B, holder.N
-        gctx = nets.global_forward(P, holder.buffers, a2, B, N, holder.training, True)
-        Wt0 = P["tail.0.weight"].view(P["tail.0.weight"].shape[0], -1)
-        Cg = gctx["y3"].shape[1]
-        W_g, W_x = Wt0[:, :Cg], Wt0[:, Cg:]
-        rb = ops.gemm_nt(gctx["y3"], W_g, P["tail.0.bias"], pro=(gctx["bn3"][0], gctx["bn3"][1], nets.NEG))     # [B,256]
-        out, mctx = nets.mlp_forward(P, ["tail.0", "tail.2", "tail.4"], [ops.ACT_LRELU, ops.ACT_LRELU, ops.ACT_TANH], a2, nets.NEG,
-                                     rowbias=rb, N=N, first_weight=W_x)
+        reuse = getattr(holder, "reuse", None)
+        if reuse is not None:                   # evaluated by nets.g_pair_forward
+            out, gctx, mctx = reuse
+            out = out.view_as(out)
+            Cg = gctx["y3"].shape[1]
+        else:
+            gctx = nets.global_forward(P, holder.buffers, a2, B, N, holder.training, True)
+            Wt0 = P["tail.0.weight"].view(P["tail.0.weight"].shape[0], -1)
+            Cg = gctx["y3"].shape[1]
+            W_g, W_x = Wt0[:, :Cg], Wt0[:, Cg:]
+            rb = ops.gemm_nt(gctx["y3"], W_g, P["tail.0.bias"], pro=(gctx["bn3"][0], gctx["bn3"][1], nets.NEG))     # [B,256]
+            out, mctx = nets.mlp_forward(P, ["tail.0", "tail.2", "tail.4"], [ops.ACT_LRELU, ops.ACT_LRELU, ops.ACT_TANH], a2, nets.NEG,
+                                         rowbias=rb, N=N, first_weight=W_x)
         ctx.holder, ctx.gctx, ctx.mctx, ctx.Cg = holder, gctx, mctx, Cg
         ctx.save_for_backward(*params)
         return out

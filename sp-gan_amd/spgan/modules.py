@@ -178,10 +178,12 @@ class AdaptivePointNorm(nn.Module):
             self.style.bias.zero_()
             self.style.bias[:in_channel] = 1
 
-    def forward_pm(self, x_pm, style_pm, N: int, slope: float = 1.0, style_chain=None):
+    def forward_pm(self, x_pm, style_pm, N: int, slope: float = 1.0, style_chain=None, reuse=None):
         """style_chain = (dict, role): two AdaIN layers fed by the SAME style tensor (the generator's adain1 / adain2) hand the style
-        gradient along instead of leaving its sum to autograd -- see Fn.AdaINFn.backward."""
-        return Fn.AdaINFn.apply(_Holder(prefix="a", N=N, slope=slope, style_chain=style_chain), x_pm, style_pm, self.style.weight, self.style.bias)
+        gradient along instead of leaving its sum to autograd -- see Fn.AdaINFn.backward.  reuse = (out, ctx): already evaluated
+        (nets.g_pair_forward), only the autograd node is built."""
+        return Fn.AdaINFn.apply(_Holder(prefix="a", N=N, slope=slope, style_chain=style_chain, reuse=reuse), x_pm, style_pm, self.style.weight,
+                                self.style.bias)
 
     def forward(self, input, style):
         _require_gpu(input, "AdaptivePointNorm")
@@ -291,6 +293,91 @@ class Generator(nn.Module, _BNCounts):
         hz = ops.concat2(x.reshape(B * N, 3), z.reshape(B * N, -1))
         return self._mlp2(self.head, hz)
 
+    def _sphere_entry(self, x):
+        """The cache entry of the sphere prior x [B,N,3]: its kNN graph, the CSR of its in-edges and whether every shape carries the same prior."""
+        B = x.shape[0]
+        # a few entries (most recent first): the training prior stays cached while an occasional call with another tensor -- a
+        # sample dump with its own batch size, an eval forward -- comes and goes (building an entry costs a host sync, which a
+        # stream capture that finds its entry evicted could not afford)
+        sgs = self.__dict__.setdefault("_sphere_graphs", [])
+        key = (x._version, tuple(x.shape), self.nk)
+        sg = next((e for e in sgs if e["ref"]() is x and e["key"] == key), None)        # same tensor OBJECT (not just address), unmodified
+        if sg is None:
+            # Does every shape of the batch carry the SAME prior (sphere_generator(static=True) tiles one template,
+            # model.py:169-171)?  Checked once per (tensor, version) -- one host sync when the cache entry is built.
+            shared = B > 1 and getattr(self, "dedup_sphere", True) and bool(torch.equal(x, x[:1].expand_as(x)))
+            sg = {"ref": weakref.ref(x), "key": key, "idx": None, "csr": None, "shared": shared, "idx_full": None}
+            sgs[:] = [e for e in sgs if e["ref"]() is not None and e["ref"]() is not x][:3]
+        else:
+            sgs[:] = [e for e in sgs if e is not sg]
+        sgs.insert(0, sg)
+        self.__dict__["_sphere_graph"] = sg
+        return sg
+
+    def pair_ok(self, x, z_d, z_g) -> bool:
+        """Can forward_pair evaluate G(x, z_d) and G(x, z_g) as one pipeline?  The default generator in train mode, one latent per shape
+        ([B,1,nz]), every shape carrying the same prior (its cache entry exists or can be built: not inside a stream capture)."""
+        if (self.use_head or self.use_attn or self.off or not self.training or bool(getattr(self.opts, "eql", False))
+                or x.dim() != 3 or z_d.shape != z_g.shape or z_d.dim() != 3 or z_d.shape[1] != 1 or x.shape[1] <= 1):
+            return False
+        return bool(self._sphere_entry(x)["shared"])
+
+    def forward_pair(self, x, z_d, z_g):
+        """(G(x, z_d).detach(), G(x, z_g)), both point-major [B*N,3]: the two generator forwards of one train step (model.py:246-248 and
+        264-271) as ONE pipeline over the rows of both passes (nets.g_pair_forward) -- same prior, same weights, and the second depends on
+        nothing the D step in between produces.  EdgeConv1 is evaluated once for one copy of the prior (as in the twin protocol of _body),
+        the per-point / per-shape stages run once on 2B shapes, the BatchNorm stages per pass in the reference's order; the autograd graph of
+        the second forward is built from the saved contexts of its rows only.  Values, running statistics and call counts are those of the
+        two separate calls."""
+        B, N, _ = x.shape
+        M = B * N
+        cache = self._sphere_entry(x)
+        pc = x.reshape(M, 3).contiguous()
+        slope = nets.NEG_2
+        if self.opts.z_norm:
+            z_d = z_d / (z_d.norm(p=2, dim=-1, keepdim=True) + 1e-8)
+            z_g = z_g / (z_g.norm(p=2, dim=-1, keepdim=True) + 1e-8)
+        self.__dict__["_ec1_twin"] = None
+        x1_one = self.EdgeConv1.forward_pm(pc[:N], 1, N, knn_mode=1, graph_cache=cache, count_rep=B, bn_repeats=2)
+        if cache["idx_full"] is None:
+            off = (torch.arange(B, device=x.device, dtype=torch.int32) * N).view(B, 1, 1)
+            cache["idx_full"] = (cache["idx"].view(1, N, -1) + off).reshape(B * N, -1).contiguous()
+        self.EdgeConv1.last_idx = cache["idx_full"]
+        h0, h2 = self.head[0], self.head[2]
+        Ph = {"head.0.weight": h0.weight, "head.0.bias": h0.bias, "head.2.weight": h2.weight, "head.2.bias": h2.bias}
+        Pa1 = {"a.style.weight": self.adain1.style.weight, "a.style.bias": self.adain1.style.bias}
+        Pa2 = {"a.style.weight": self.adain2.style.weight, "a.style.bias": self.adain2.style.bias}
+        en, ep = _named(self.EdgeConv2, "e.")
+        gt_params = self._params_of(Fn.GT_NAMES)
+        q = self.__dict__.get("_graph2_queue")
+        idx2 = [q.pop(0) if q else None, q.pop(0) if q else None]
+        idx2 = [None if g is None else (g if g.dtype == torch.int32 else ops.idx_from_local64(g.to(torch.int64).reshape(B, -1), B, N, self.nk)) for g in idx2]
+        zg = z_g.reshape(B, -1)
+        with torch.no_grad():
+            pc2 = cache.get("pc2")                  # the prior's rows for both passes: constant, kept with the prior's cache entry
+            if pc2 is None:
+                pc2 = pc.repeat(2, 1)
+                if not ops.capturing():
+                    cache["pc2"] = pc2
+            zb2 = torch.cat([z_d.reshape(B, -1), zg], dim=0)
+            pre = nets.g_pair_forward({k_: nets.owned(v) for k_, v in Ph.items()}, {k_: nets.owned(v) for k_, v in Pa1.items()},
+                                      dict(zip(en, [nets.owned(p) for p in ep])), _buffers(self.EdgeConv2, "e."),
+                                      {k_: nets.owned(v) for k_, v in Pa2.items()}, dict(zip(Fn.GT_NAMES, [nets.owned(p) for p in gt_params])),
+                                      _buffers(self), pc2, zb2, x1_one.detach(), B, N, self.nk, slope, self.training, idx2=idx2)
+        # the autograd graph of the second forward: the usual nodes, adopting their rows and saved contexts
+        style = Fn.HeadFn.apply(_Holder(N=N, reuse=pre["head"]), pc, zg, h0.weight, h0.bias, h2.weight, h2.bias)
+        x1 = Fn.RepeatRowsFn.apply(x1_one, B, pre["x1"])
+        chain = {} if torch.is_grad_enabled() else None
+        a1 = self.adain1.forward_pm(x1, style, N, slope, style_chain=None if chain is None else (chain, "last"), reuse=pre["adain1"])
+        self.last_x1 = pre["x1_in"].detach()
+        x2 = self.EdgeConv2.forward_pm(a1, B, N, knn_mode=0, reuse=pre["ec2"])
+        a2 = self.adain2.forward_pm(x2, style, N, slope, style_chain=None if chain is None else (chain, "first"), reuse=pre["adain2"])
+        self.last_x2 = pre["a2"].detach()
+        h = _Holder(buffers=_buffers(self), B=B, N=N, training=self.training, reuse=pre["tail"])
+        out = Fn.GlobalTailFn.apply(h, a2, *gt_params)
+        self.__dict__["_pair_idx"] = pre["idx"]
+        return pre["fake_d"], out
+
     def _body(self, x, style, pm_out: bool = False):
         B, N, _ = x.shape
         pc = x.reshape(B * N, 3).contiguous()
@@ -299,25 +386,7 @@ class Generator(nn.Module, _BNCounts):
         # The sphere prior is the same tensor every step (Generation/model.py:231): its kNN graph (and the CSR of
         # its in-edges) is built once per (buffer, version, shape) and reused.  Any in-place write
         # to x bumps _version and invalidates the cache.
-        cache = None
-        if not self.use_head:
-            # a few entries (most recent first): the training prior stays cached while an occasional call with another tensor -- a
-            # sample dump with its own batch size, an eval forward -- comes and goes (building an entry costs a host sync, which a
-            # stream capture that finds its entry evicted could not afford)
-            sgs = self.__dict__.setdefault("_sphere_graphs", [])
-            key = (x._version, tuple(x.shape), self.nk)
-            sg = next((e for e in sgs if e["ref"]() is x and e["key"] == key), None)        # same tensor OBJECT (not just address), unmodified
-            if sg is None:
-                # Does every shape of the batch carry the SAME prior (sphere_generator(static=True) tiles one template,
-                # model.py:169-171)?  Checked once per (tensor, version) -- one host sync when the cache entry is built.
-                shared = B > 1 and getattr(self, "dedup_sphere", True) and bool(torch.equal(x, x[:1].expand_as(x)))
-                sg = {"ref": weakref.ref(x), "key": key, "idx": None, "csr": None, "shared": shared, "idx_full": None}
-                sgs[:] = [e for e in sgs if e["ref"]() is not None and e["ref"]() is not x][:3]
-            else:
-                sgs[:] = [e for e in sgs if e is not sg]
-            sgs.insert(0, sg)
-            self.__dict__["_sphere_graph"] = sg
-            cache = sg
+        cache = None if self.use_head else self._sphere_entry(x)
         if cache is not None and cache["shared"]:
             # EdgeConv1 sees the same N points in every shape: evaluate it for ONE copy (B times less work in forward and
             # backward; exact -- batch statistics of identical copies are those of one copy, and the backward is linear in the

@@ -962,22 +962,23 @@ def conv_out_weight_grad_from_pm(g: Tensor, F_: int, k: int) -> Tensor:
 
 
 def edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int, training: bool = True, update_running: bool = True,
-                      count_rep: int = 1, bn_repeats: int = 1):
+                      count_rep: int = 1, bn_repeats: int = 1, out: Optional[Tensor] = None):
+    """out: the [M,F] tensor (e.g. a row block of a larger buffer) the block's result is written into."""
     if bn_repeats > 1 and training:
         # this forward stands for bn_repeats identical ones (same input, same weights: the two generator forwards of a train step see
         # the same sphere prior): one evaluation, the running statistics advanced bn_repeats times with the same batch statistics
         with ops.bn_momentum(1.0 - (1.0 - ops.BN_MOMENTUM) ** bn_repeats):
-            out, ctx = edgeblock_forward(P, bufs, pre, x, idx, B, N, training, update_running, count_rep, 1)
+            out, ctx = edgeblock_forward(P, bufs, pre, x, idx, B, N, training, update_running, count_rep, 1, out=out)
         if bufs is not None and update_running:
             for _ in range(bn_repeats - 1):
                 for bn in (".conv_w.1", ".conv_x.1", ".conv_w.4"):
                     _count_bn_call(bufs, pre + bn)
         return out, ctx
-    return _edgeblock_forward(P, bufs, pre, x, idx, B, N, training, update_running, count_rep)
+    return _edgeblock_forward(P, bufs, pre, x, idx, B, N, training, update_running, count_rep, out=out)
 
 
 def _edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int, training: bool = True, update_running: bool = True,
-                       count_rep: int = 1):
+                       count_rep: int = 1, out: Optional[Tensor] = None):
     """x [M,C] (point-major), idx int32 [M,k] -> out [M,F] + ctx.
     count_rep > 1: x stands for count_rep identical copies of these M rows (the tiled sphere prior): batch statistics are those
     of one copy, only the unbiased-variance count of the running statistics is count_rep times larger."""
@@ -1007,7 +1008,7 @@ def _edgeblock_forward(P, bufs, pre: str, x: Tensor, idx: Tensor, B: int, N: int
                           **({"count_rep": count_rep} if training and count_rep > 1 else {}), **({"out_half": True} if s16 else {}))
     T = ops.edge_attend_fwd(h2pre, bn2[0], bn2[1], PQR, idx, bx, bnx[0], bnx[1], NEG, half=s16)
     Wo, WoT = conv_out_weight_pm(P[pre + ".conv_out.weight"])
-    out = ops.gemm_nt(T, Wo, P[pre + ".conv_out.bias"])
+    out = ops.gemm_nt(T, Wo, P[pre + ".conv_out.bias"], out=out)
     ctx = dict(x=x, idx=idx, B=B, N=N, PQR=PQR, Wcat=Wcat, WcatT=WcatT, WoT=WoT, bn1=bn1, bnx=bnx, bn2=bn2, h2pre=h2pre, T=T, Wo=Wo, H=H, F=F_, k=k, training=training)
     return out, ctx
 
@@ -1160,6 +1161,52 @@ def global_feat_backward(P, gctx, dfeat: Tensor):
     da2 = dfeat[:, Cg:].contiguous()
     dg = ops.colsum(dfeat[:, :Cg], N)                                                            # [B,512]: sum over the shape's points
     return da2, global_backward(P, gctx, None, dg, da2)
+
+
+def g_pair_forward(Ph, Pa1, Pe2, bufs_e2, Pa2, Pgt, bufs_g, x_pm2: Tensor, zb2: Tensor, x1_one: Tensor, B: int, N: int, k: int, slope: float,
+                   training: bool = True, idx2=None):
+    """The two generator forwards of one train step -- G(x, z_d) of the D step (model.py:246-248, no gradient) and G(x, z_g) of the G step
+    (model.py:264-271) -- behind their shared EdgeConv1 as ONE pipeline over the rows of both passes [2*B*N, C]: they see the same prior and
+    the same weights, and the second depends on nothing the D step produces.  Everything that acts per point or per shape (the style head,
+    both AdaIN layers, the tail) runs once on 2*B shapes; everything with BatchNorm batch statistics (EdgeConv2, global_conv) runs per pass
+    on its row block, pass 0 first (running statistics advance in the reference's order).  Every row's values are those of the separate
+    forwards.  x_pm2 [2M,3] the prior's rows twice, zb2 [2B,nz] = [z_d; z_g] (one latent per shape), x1_one [N,C1] EdgeConv1's output for ONE copy of the
+    prior; idx2: optional (graph of pass 0, graph of pass 1) for EdgeConv2.
+    -> dict(fake_d [M,3] (pass 0's cloud), and for pass 1 the (output, saved context) pairs the autograd Functions adopt:
+       head, x1, adain1, ec2, adain2, tail)."""
+    M = B * N
+    W0 = _w2(Ph["head.0.weight"])
+    c = x_pm2.shape[1]
+    rb = ops.gemm_nt(zb2.contiguous(), W0[:, c:], Ph["head.0.bias"])                                   # [2B,128]: the latent half of head.0
+    style, mh = mlp_forward(Ph, ["head.0", "head.2"], [ops.ACT_LRELU, ops.ACT_LRELU], x_pm2, NEG, rowbias=rb, N=N, first_weight=W0[:, :c])
+    x1 = x1_one.repeat(2 * B, 1)                                                                       # the same EdgeConv1 rows for every shape of both passes
+    a1, c1 = adain_forward(Pa1, "a", x1, style, N, slope)
+    F_ = _w2(Pe2["e.conv_x.0.weight"]).shape[0]
+    x2 = torch.empty((2 * M, F_), dtype=torch.float32, device=x_pm2.device)
+    ec = []
+    for p_ in (0, 1):                                                                                  # BatchNorm batch statistics: per pass
+        rows = slice(p_ * M, (p_ + 1) * M)
+        xin = a1[rows]
+        idx = idx2[p_] if (idx2 is not None and idx2[p_] is not None) else ops.knn(xin, B, N, k, 0)
+        ec.append(edgeblock_forward(Pe2, bufs_e2, "e", xin, idx, B, N, training, True, out=x2[rows]))
+    a2, c2 = adain_forward(Pa2, "a", x2, style, N, slope)
+    Wt0 = Pgt["tail.0.weight"].view(Pgt["tail.0.weight"].shape[0], -1)
+    gcs = [global_forward(Pgt, bufs_g, a2[p_ * M:(p_ + 1) * M], B, N, training, True) for p_ in (0, 1)]
+    Cg = gcs[0]["y3"].shape[1]
+    rb2 = torch.empty((2 * B, Wt0.shape[0]), dtype=torch.float32, device=x_pm2.device)
+    for p_ in (0, 1):
+        ops.gemm_nt(gcs[p_]["y3"], Wt0[:, :Cg], Pgt["tail.0.bias"], pro=(gcs[p_]["bn3"][0], gcs[p_]["bn3"][1], NEG), out=rb2[p_ * B:(p_ + 1) * B])
+    out, mt = mlp_forward(Pgt, ["tail.0", "tail.2", "tail.4"], [ops.ACT_LRELU, ops.ACT_LRELU, ops.ACT_TANH], a2, NEG, rowbias=rb2, N=N,
+                          first_weight=Wt0[:, Cg:])
+
+    def half_mlp(m):
+        return dict(m, x=m["x"][M:], hs=[h[M:] for h in m["hs"]])
+
+    def half_adain(cx):
+        return dict(cx, x=cx["x"][M:], style=cx["style"][M:], gb=cx["gb"][M:], imean=cx["imean"][B:], ivar=cx["ivar"][B:])
+    return dict(fake_d=out[:M], head=(style[M:], half_mlp(mh)), x1=x1[M:], adain1=(a1[M:], half_adain(c1)), ec2=ec[1],
+                adain2=(a2[M:], half_adain(c2)), tail=(out[M:], gcs[1], half_mlp(mt)), idx=(ec[0][1]["idx"], ec[1][1]["idx"]),
+                x1_in=a1[M:], a2=a2[M:])
 
 
 def attention_forward(P, pre: str, x: Tensor, B: int, N: int):

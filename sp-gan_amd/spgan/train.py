@@ -74,6 +74,8 @@ class TrainStep:
         # The generator's two forwards of a step (D step, G step) see the same sphere prior and the same weights: EdgeConv1, which
         # depends on nothing else, is evaluated once and its BatchNorm running statistics are advanced twice (Generator.twin_forward).
         self.twin_g_forwards = not reference_schedule      # attribute = test hook
+        self.pair_g_forwards = os.environ.get("SPGAN_PAIR_G", "1") != "0"      # test / A-B hook: False evaluates the step's two generator forwards separately
+        self._pair_gfake = None
         self._sinkD, self._sinkG = DeliverySink(), DeliverySink()      # where the backward nodes of the D / G step leave their parameter gradients
         self.joint_d_backward = os.environ.get("SPGAN_JOINT_D", "1") != "0"      # test / A-B hook: False keeps one autograd node (and one chain of launches) per D pass
         self.point_major = True                            # test hook: False keeps the [B,3,N] layout between the networks (same results up to the penalty norm's summation order)
@@ -260,20 +262,22 @@ class TrainStep:
         return self._eager_step(x, real, z_d, z_g, alpha, keep_grads)
 
     # The iteration in three segments, split where the data-parallel all-reduces sit (they stay outside the captured graphs).
-    def _seg_d(self, x, real, z_d, alpha, keep_grads, info):
-        """D step up to lossD.backward() (model.py:240-258)."""
+    def _seg_d(self, x, real, z_d, alpha, keep_grads, info, z_g=None):
+        """D step up to lossD.backward() (model.py:240-258).  z_g given (single process): the G step's generator forward is evaluated here,
+        together with the D step's (Generator.forward_pair), and waits in self._pair_gfake for _seg_g."""
         # the nodes built here add their parameter gradients straight into the flat .grad buffers -- through the step's sink: one split-sum
         # reduction and one accumulation launch for the whole backward instead of a pair per node
         with fused_grad_accumulation(self._sinkD):
-            out = self._seg_d_body(x, real, z_d, alpha, keep_grads, info)
+            out = self._seg_d_body(x, real, z_d, alpha, keep_grads, info, z_g)
         self._sinkD.flush()
         return out
 
-    def _seg_d_body(self, x, real, z_d, alpha, keep_grads, info):
+    def _seg_d_body(self, x, real, z_d, alpha, keep_grads, info, z_g=None):
         G, D = self.G, self.D
         B, N, _ = real.shape
         requires_grad(G, False); requires_grad(D, True)
         self.optD.zero_grad()
+        self._pair_gfake = None
         # Point-major internal route: the batched conv stacks take the generator's output [B*N,3] as it leaves its last GEMM and the real
         # cloud as the loader delivers it ([B,N,3] IS point-major) -- no [B,3,N] round trips (layout kernels, cat + transpose, and their
         # adjoints in the penalty's double backward); the same values into the same kernels (only the penalty's per-shape norm sums its
@@ -282,11 +286,21 @@ class TrainStep:
         # rule -- a GradientPenalty(mix="loss_utils") keeps the [B,3,N] route, which calls GradientPenalty.interpolate)
         pm = (self.point_major and self.batch_d_forwards and D.training and N % ops.ROW_TILE == 0 and not getattr(G, "off", False)
               and tuple(x.shape) == tuple(real.shape) and (not self.use_gp or self.gp.mix == "common"))
-        G.twin_forward = "first" if self.twin_g_forwards else None
-        try:
-            fake = G(x, z_d, pm_out=True).detach() if pm else G(x, z_d).detach()
-        finally:
-            G.twin_forward = None
+        pair = (pm and z_g is not None and self.pair_g_forwards and self.twin_g_forwards and self.dpD is None and hasattr(G, "forward_pair")
+                and G.pair_ok(x, z_d, z_g))
+        if pair:
+            # both generator forwards of the step as one pipeline (same prior, same weights; G(x, z_g) depends on nothing this D step produces):
+            # the per-point / per-shape stages run once on the rows of both passes.  Its autograd nodes leave their gradients in the G step's sink.
+            requires_grad(G, True)
+            self.optG.zero_grad()
+            with fused_grad_accumulation(self._sinkG):
+                fake, self._pair_gfake = G.forward_pair(x, z_d, z_g)
+        else:
+            G.twin_forward = "first" if self.twin_g_forwards else None
+            try:
+                fake = G(x, z_d, pm_out=True).detach() if pm else G(x, z_d).detach()
+            finally:
+                G.twin_forward = None
         if pm:
             M = B * N
             real_pm = real.reshape(M, 3).contiguous()
@@ -420,8 +434,9 @@ class TrainStep:
 
     def _eager_step(self, x, real, z_d, z_g, alpha=None, keep_grads: bool = False) -> Dict[str, torch.Tensor]:
         info: Dict[str, torch.Tensor] = {}
-        real_t = self._seg_d(x, real, z_d, alpha, keep_grads, info)
-        g_fake, scale = None, 1.0
+        real_t = self._seg_d(x, real, z_d, alpha, keep_grads, info, z_g=z_g if self.dpD is None else None)
+        g_fake, scale = self._pair_gfake, 1.0
+        self._pair_gfake = None
         if self.dpD is not None:
             # data parallel: the generator's forward of the G step is issued under D's gradient all-reduce (it depends on neither)
             self.dpD.allreduce_grads_begin()

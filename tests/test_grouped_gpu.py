@@ -290,3 +290,62 @@ def test_gp_penalty_fwd_bwd_equals_separate_calls(ops):
     l2, n2, v2, tot = ops.gp_penalty_fwd_bwd(g, 1.0, 10.0, la)
     assert torch.equal(loss, l2) and torch.equal(norms, n2) and torch.equal(v, v2) and torch.equal(tot, la + loss)
     assert ops.gp_penalty_fwd_bwd(g, 1.0, 10.0)[3] is None
+
+
+@pytest.mark.parametrize("gan,use_gp,graph", [("wgan", True, False), ("ls", False, False), ("wgan", True, True)])
+def test_paired_generator_forwards_equal_separate_forwards(ops, gan, use_gp, graph):
+    """TrainStep with the step's two generator forwards as ONE pipeline (Generator.forward_pair / nets.g_pair_forward) against two separate
+    forwards, eagerly and replayed as a hipGraph: the HIP kernels compute every row independently of the row count, so clouds, losses and
+    BatchNorm buffers of the first step agree to rounding of the kernels whose tile geometry depends on M, and the trajectories stay together."""
+    import spgan
+    from oracle import spgan_oracle as orc
+    from spgan import nets
+
+    class O:
+        np = 2048; nk = 20; nz = 128; softmax = True; off = False; attn = False; use_head = False; eql = False; z_norm = False; small_d = False
+    B, N = 8, 2048
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1).cuda()
+    outs, calls = [], []
+    real_pair = nets.g_pair_forward
+    nets.g_pair_forward = lambda *a, **k: (calls.append(1), real_pair(*a, **k))[1]
+    try:
+        for pair in (True, False):
+            G, D = spgan.Generator(O), spgan.Discriminator(O)
+            G.load_state_dict({**G.state_dict(), **fr.init_params(orc.generator_shapes(), salt=7)})
+            D.load_state_dict({**D.state_dict(), **fr.init_params(orc.discriminator_shapes(), salt=7)})
+            G.cuda().train(); D.cuda().train()
+            tr = spgan.TrainStep(G, D, gan=gan, use_gp=use_gp, graph=graph, graph_warmup=1)
+            tr.pair_g_forwards = pair
+            rec = []
+            for step in range(4 if graph else 2):
+                real = fr.synthetic_real(B, N, seed=81 + step).cuda()
+                z_d = fr.latent(B, N, seed=82 + 2 * step)[:, :1, :].contiguous().cuda()
+                z_g = fr.latent(B, N, seed=83 + 2 * step)[:, :1, :].contiguous().cuda()
+                alpha = fr.uniform("pairg.alpha.%d" % step, (B, 1, 1), 0.0, 1.0).cuda()
+                info = tr.step(x, real, z_d, z_g, alpha=alpha, keep_grads=not graph)
+                rec.append({k: v.detach().clone() if isinstance(v, torch.Tensor) else {n: g.clone() for n, g in v.items()} for k, v in info.items()})
+            outs.append((rec, {k: v.clone() for k, v in G.state_dict().items()}, {k: v.clone() for k, v in D.state_dict().items()}))
+    finally:
+        nets.g_pair_forward = real_pair
+    assert len(calls) >= 2, "the paired route did not run"
+    (ra, ga, da), (rb, gb, db) = outs
+    a, b = ra[0], rb[0]
+    assert abs(a["loss_d"].item() - b["loss_d"].item()) <= 2e-6 * abs(b["loss_d"].item()) + 1e-7
+    assert abs(a["loss_g"].item() - b["loss_g"].item()) <= 2e-5 * abs(b["loss_g"].item()) + 1e-6
+    if not graph:
+        close(a["fake_d"], b["fake_d"], rtol=1e-6, atol=1e-6, what="D-step cloud")
+        close(a["fake_g"], b["fake_g"], rtol=1e-6, atol=1e-6, what="G-step cloud")
+        for n in a["g_grads"]:
+            close(a["g_grads"][n], b["g_grads"][n], rtol=2e-4, atol=1e-9, what="G gradient " + n)
+        for n in a["d_grads"]:
+            close(a["d_grads"][n], b["d_grads"][n], rtol=2e-5, atol=1e-9, what="D gradient " + n)
+    for k in ga:       # after the last step: parameters within a few Adam steps' rounding, BatchNorm buffers and call counts together
+        if "num_batches" in k:
+            assert torch.equal(ga[k], gb[k]), k
+        else:
+            close(ga[k].float(), gb[k].float(), rtol=2e-3, atol=1e-3, what=k)
+    for k in da:
+        if "num_batches" in k:
+            assert torch.equal(da[k], db[k]), k
+        else:
+            close(da[k].float(), db[k].float(), rtol=2e-3, atol=1e-3, what=k)

@@ -287,3 +287,49 @@ def test_joint_d_backward_equals_one_node_per_pass(spgan_cpu, monkeypatch, gan, 
     for k in sa:      # (the G step's D passes run on the UPDATED weights, which carry the other summation order: not bit-equal)
         if "running" in k or "num_batches" in k:
             assert torch.allclose(sa[k].float(), sb[k].float(), rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.parametrize("gan,use_gp", [("wgan", True), ("ls", False)])
+def test_paired_generator_forwards_equal_separate_forwards(spgan_cpu, monkeypatch, gan, use_gp):
+    """TrainStep with the step's two generator forwards evaluated as ONE pipeline (Generator.forward_pair -> nets.g_pair_forward: the per-point /
+    per-shape stages once on the rows of both passes, the BatchNorm stages per pass) against two separate forwards: two steps, same losses,
+    gradients, parameters and BatchNorm buffers; and the paired route is the one that ran."""
+    import spgan
+    from spgan import nets
+    calls = []
+    real_pair = nets.g_pair_forward
+    monkeypatch.setattr(nets, "g_pair_forward", lambda *a, **k: (calls.append(1), real_pair(*a, **k))[1])
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    outs = []
+    for pair in (True, False):
+        G = _load(spgan.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=9))
+        D = _load(spgan.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=9))
+        tr = spgan.TrainStep(G, D, gan=gan, use_gp=use_gp, lambda_gp=10.0)
+        tr.pair_g_forwards = pair
+        infos = []
+        for step in range(2):
+            real = fr.synthetic_real(B, N, seed=61 + step)
+            z_d, z_g = fr.latent(B, N, seed=62 + 2 * step)[:, :1, :].contiguous(), fr.latent(B, N, seed=63 + 2 * step)[:, :1, :].contiguous()
+            alpha = fr.uniform("pair.alpha.%d" % step, (B, 1, 1), 0.0, 1.0)
+            infos.append(tr.step(x, real, z_d, z_g, alpha=alpha, keep_grads=True))
+        outs.append((infos, {k: v.clone() for k, v in G.state_dict().items()}, {k: v.clone() for k, v in D.state_dict().items()}))
+    assert len(calls) == 2, calls
+    (ia, ga, da), (ib, gb, db) = outs
+    for step, (a, b) in enumerate(zip(ia, ib)):
+        if step == 1:      # behind the first Adam step (+-lr on every element: the sign of a noise-level gradient element may differ): loose
+            np.testing.assert_allclose(a["fake_d"].numpy(), b["fake_d"].numpy(), rtol=1e-3, atol=1e-3)
+            np.testing.assert_allclose(a["loss_d"].item(), b["loss_d"].item(), rtol=2e-2, atol=1e-3)
+            continue
+        np.testing.assert_allclose(a["loss_d"].item(), b["loss_d"].item(), rtol=2e-3 if use_gp else 1e-5)     # the penalty is a function of a kink-limited gradient (SURVEY H1b)
+        np.testing.assert_allclose(a["loss_g"].item(), b["loss_g"].item(), rtol=2e-3, atol=1e-5)
+        # (the CPU doubles' matrix products block differently for M and 2M rows: last-bit differences per row, which reach the gradients through
+        # LeakyReLU / arg-max kinks; the GPU test compares the HIP kernels, whose rows are independent of the row count)
+        np.testing.assert_allclose(a["fake_d"].numpy(), b["fake_d"].numpy(), rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(a["fake_g"].numpy(), b["fake_g"].numpy(), rtol=1e-5, atol=5e-6)
+        for n in a["g_grads"]:
+            assert (a["g_grads"][n] - b["g_grads"][n]).norm().item() <= 2e-3 * b["g_grads"][n].norm().item() + 1e-9, n
+    for k in ga:       # parameters after two Adam steps move by <= 2e-4; buffers by the batch statistics' rounding
+        assert torch.allclose(ga[k].float(), gb[k].float(), rtol=1e-4, atol=4.1e-4 if "num_batches" not in k else 0), k
+    for k in da:
+        assert torch.allclose(da[k].float(), db[k].float(), rtol=1e-4, atol=4.1e-4 if "num_batches" not in k else 0), k
