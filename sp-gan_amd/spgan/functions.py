@@ -608,7 +608,7 @@ class HeadFn(Function):
             out, mctx = reuse
             out = out.view_as(out)
         else:
-            rb = ops.gemm_nt(zb.contiguous(), W0[:, c:], b0)                               # [B,128]
+            rb = ops.gemm_nt(zb.contiguous(), nets._cols_from(W0, c), b0)                  # [B,128]
             P = {"head.0.weight": w0, "head.0.bias": b0, "head.2.weight": w2, "head.2.bias": b2}
             out, mctx = nets.mlp_forward(P, ["head.0", "head.2"], [ops.ACT_LRELU, ops.ACT_LRELU], x_pm.contiguous(), nets.NEG,
                                          rowbias=rb, N=holder.N, first_weight=W0[:, :c])

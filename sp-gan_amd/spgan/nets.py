@@ -72,6 +72,26 @@ def _t(w: Tensor) -> Tensor:
     return t
 
 
+_COLS_CACHE: Dict[tuple, tuple] = {}
+
+
+def _cols_from(w: Tensor, c: int) -> Tensor:
+    """w[:, c:] as a contiguous (16-byte aligned) matrix.  For (views of) parameters the copy is kept until the weights change (the staleness
+    rule of _t): the latent half of head.0's weight, W0[:, 3:], starts 12 bytes into every 524-byte row -- as a strided view it sends a
+    [B,128] x [128,128] product to the unaligned path of the 128-row tile kernel (18 us for B = 32), as a copy to the small-row kernel (6 us)."""
+    owner = _owner(w)
+    if owner is None:
+        return w[:, c:].contiguous()
+    key = (w.data_ptr(), tuple(w.shape), c)
+    stamp = (ops.WEIGHTS_EPOCH[0], owner._version)
+    hit = _COLS_CACHE.get(key)
+    if hit is not None and hit[2]() is owner and hit[0] == stamp:
+        return hit[1]
+    t = w[:, c:].contiguous()
+    _COLS_CACHE[key] = (stamp, t, weakref.ref(owner))      # (an entry made inside a capture: the replay re-makes the copy, and the stamp changes with every optimiser step anyway)
+    return t
+
+
 def _refresh_transposes(trigger: Tensor) -> None:
     """Re-transpose the stale cached matrices of the network `trigger` belongs to (= the parameters that live in the same flat
     buffer, spgan.optim.flatten_module; an unflattened parameter is its own group) -- never another model's: a captured train
@@ -953,6 +973,7 @@ def drop_weight_caches() -> None:
     for key, (stamp, t, oref, view) in list(_T_CACHE.items()):
         _T_CACHE[key] = ((-1, -1), t, oref, view)          # stale, not forgotten: the capture's first use re-transposes the whole
     _WO_CACHE.clear()                                      # network's matrices in ONE launch (_refresh_transposes), as every step does
+    _COLS_CACHE.clear()
 
 
 def conv_out_weight_grad_from_pm(g: Tensor, F_: int, k: int) -> Tensor:
@@ -1177,7 +1198,7 @@ def g_pair_forward(Ph, Pa1, Pe2, bufs_e2, Pa2, Pgt, bufs_g, x_pm2: Tensor, zb2: 
     M = B * N
     W0 = _w2(Ph["head.0.weight"])
     c = x_pm2.shape[1]
-    rb = ops.gemm_nt(zb2.contiguous(), W0[:, c:], Ph["head.0.bias"])                                   # [2B,128]: the latent half of head.0
+    rb = ops.gemm_nt(zb2.contiguous(), _cols_from(W0, c), Ph["head.0.bias"])                           # [2B,128]: the latent half of head.0
     style, mh = mlp_forward(Ph, ["head.0", "head.2"], [ops.ACT_LRELU, ops.ACT_LRELU], x_pm2, NEG, rowbias=rb, N=N, first_weight=W0[:, :c])
     x1 = x1_one.repeat(2 * B, 1)                                                                       # the same EdgeConv1 rows for every shape of both passes
     a1, c1 = adain_forward(Pa1, "a", x1, style, N, slope)
