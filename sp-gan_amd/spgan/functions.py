@@ -154,6 +154,14 @@ def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool], f
     cost nothing on the fused path."""
     sink = fused if isinstance(fused, DeliverySink) else None
     fused = bool(fused) and not torch.is_grad_enabled()
+    def to_sink(p, g) -> bool:         # can this gradient wait for the sink's flush as it is (no copy, nothing handed back to autograd)?
+        if isinstance(g, int):
+            return True
+        if not (p.is_leaf and p.grad is not None and p.grad.is_contiguous() and p.grad.numel() == g.numel()):
+            return False
+        return isinstance(g, nets.CatCols) or g.is_contiguous() or g.shape == p.grad.shape
+    if sink is not None and fused and not all(to_sink(p, g) for p, g, need in zip(params, grads, needs) if need and g is not None):
+        ops.flush_tn()                 # a gradient that is copied or handed back to autograd below must be complete now
     if sink is None or not fused:
         ops.flush_tn()                 # weight gradients whose split-K sums were deferred (ops.gemm_tn(defer=True)) become valid here
         sink = None                    # (with a sink the owner's flush() finishes them, together with those of every other node)
@@ -181,8 +189,6 @@ def _deliver(params: Sequence[Tensor], grads: Sequence, needs: Sequence[bool], f
             if isinstance(g, nets.CatCols):
                 g = g.cat()
             out[i] = g.view_as(p) if g.shape != p.shape else g
-    if sink is not None and any(o is not None for o in out):
-        ops.flush_tn()                 # a gradient handed back to autograd must be complete now
     if pairs:
         if sink is not None:
             sink.add(pairs)
@@ -628,8 +634,7 @@ class HeadFn(Function):
         dz = ops.gemm_nt(drb, nets._t(W0[:, ctx.c:])) if ctx.needs_input_grad[2] else None
         grads = [None] * 4
         if need_p:
-            gz = ops.gemm_tn(drb, zb.contiguous())                                       # [128, nz]
-            ops.flush_tn()
+            gz = ops.gemm_tn(drb, zb.contiguous(), defer=True)                           # [128, nz]; finished with the other deferred sums (_deliver)
             grads = [nets.CatCols([g["head.0.weight.part"], gz]), ops.colsum(drb)[0], g["head.2.weight"], g["head.2.bias"]]
         return (None, dx, dz) + _deliver(params, grads, ctx.needs_input_grad[3:], ctx.fused)
 
@@ -724,6 +729,5 @@ class GlobalTailFn(Function):
         da2, g, drb = nets.mlp_backward(P, ctx.mctx, dout, True, True)
         gg = nets.global_backward(P, ctx.gctx, Wt0[:, :ctx.Cg], drb, da2)
         g.update({k: v for k, v in gg.items() if k != "tail.0.weight.global"})
-        ops.flush_tn()                 # the per-point half of tail.0's weight gradient was deferred
         g["tail.0.weight"] = nets.CatCols([gg["tail.0.weight.global"], g.pop("tail.0.weight.part")])
         return (None, da2 if ctx.needs_input_grad[1] else None) + _deliver(params, [g[n] for n in GT_NAMES], ctx.needs_input_grad[2:], ctx.fused)

@@ -1044,7 +1044,7 @@ def edgeblock_backward(P, pre: str, ctx, dout: Tensor, csr: Tuple[Tensor, Tensor
     g: Dict[str, Tensor] = {}
     dout = dout.contiguous()
     # conv_out
-    gwo, g[pre + ".conv_out.bias"] = ops.gemm_tn(dout, ctx["T"], with_colsum=True)      # the bias gradient rides along (column sums of dout)
+    gwo, g[pre + ".conv_out.bias"] = ops.gemm_tn(dout, ctx["T"], with_colsum=True, defer=True)      # the bias gradient rides along (column sums of dout); both split sums wait for the pass's one reduction launch
     g[pre + ".conv_out.weight"] = conv_out_weight_grad_from_pm(gwo, F_, k)
     dT = ops.gemm_nt(dout, ctx["WoT"], out_bf16=ctx["T"].dtype == torch.float16)     # [M, k*F]
     # softmax * conv_x product, both LeakyReLUs
@@ -1309,7 +1309,7 @@ def global_backward(P, gctx, W_g: Optional[Tensor], drb: Tensor, da2: Tensor):
     if W_g is None:
         Wg_t = _eye(y3.shape[1], y3.device)
     else:
-        g["tail.0.weight.global"] = ops.gemm_tn(drb, y3, pro=(bn3[0], bn3[1], NEG))
+        g["tail.0.weight.global"] = ops.gemm_tn(drb, y3, pro=(bn3[0], bn3[1], NEG), defer=True)
         g["tail.0.bias"] = ops.colsum(drb)[0]
         Wg_t = _t(W_g)
     g3, s0, s1 = ops.gemm_nt_bnbwd(drb, Wg_t, y3, bn3[0], bn3[1], bn3[3], bn3[2], NEG)
