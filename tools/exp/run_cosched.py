@@ -19,7 +19,7 @@ def t(f, reps=20):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / reps * 1e3
 for lds in (66 * 1024, 33 * 1024):
     for a_blocks in (512, 256):
-        iters = 6000 if a_blocks == 512 else 12000      # the same MFMA work in total
+        iters = int(os.environ.get("ITERS", "6000")) * (1 if a_blocks == 512 else 2)      # the same MFMA work in total
         for b_blocks in (2048, 8192):
             ta = t(lambda: lib.exp_cosched(out.data_ptr(), iters, a_blocks, src.data_ptr(), dst.data_ptr(), n, 0, lds, s))
             tb = t(lambda: lib.exp_stream(src.data_ptr(), dst.data_ptr(), n, b_blocks, s))
