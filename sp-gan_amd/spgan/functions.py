@@ -86,6 +86,11 @@ class DeliverySink:
         with self._lock:
             self._pairs.extend(pairs)
 
+    def clear(self) -> None:
+        """Forget what an aborted backward (an exception, a failed stream capture) left behind: its gradients must not reach the next step."""
+        with self._lock:
+            self._pairs = []
+
     def flush(self) -> None:
         with self._lock:
             pairs, self._pairs = self._pairs, []

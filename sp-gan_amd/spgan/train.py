@@ -212,6 +212,7 @@ class TrainStep:
                 # the aborted capture recorded Adam launches that never ran: their "the step left the gradient buffer zeroed" flags are
                 # false, and whatever the warm-up steps left in the buffers is unknown to the host -- fill them
                 self.optG.invalidate_grads(); self.optD.invalidate_grads()
+                self._sinkD.clear(); self._sinkG.clear(); self._pair_gfake = None
                 self.use_graph = False
                 torch.cuda.synchronize()
                 # cache entries created during the aborted capture carry current stamps but live in the aborted graph's pool and were
@@ -267,6 +268,7 @@ class TrainStep:
         together with the D step's (Generator.forward_pair), and waits in self._pair_gfake for _seg_g."""
         # the nodes built here add their parameter gradients straight into the flat .grad buffers -- through the step's sink: one split-sum
         # reduction and one accumulation launch for the whole backward instead of a pair per node
+        self._sinkD.clear(); self._sinkG.clear()      # a step starts here: nothing of an aborted earlier backward may be left
         with fused_grad_accumulation(self._sinkD):
             out = self._seg_d_body(x, real, z_d, alpha, keep_grads, info, z_g)
         self._sinkD.flush()

@@ -333,3 +333,34 @@ def test_paired_generator_forwards_equal_separate_forwards(spgan_cpu, monkeypatc
         assert torch.allclose(ga[k].float(), gb[k].float(), rtol=1e-4, atol=4.1e-4 if "num_batches" not in k else 0), k
     for k in da:
         assert torch.allclose(da[k].float(), db[k].float(), rtol=1e-4, atol=4.1e-4 if "num_batches" not in k else 0), k
+
+
+def test_delivery_sink_forgets_an_aborted_backward(spgan_cpu):
+    """A backward pass that raised leaves its gradients in the step's DeliverySink; the next step must not add them (TrainStep clears both sinks
+    where a step starts)."""
+    import spgan
+    from spgan.functions import DeliverySink
+    s = DeliverySink()
+    d, g = torch.zeros(8), torch.ones(8)
+    s.add([(d, g)])
+    s.clear()
+    s.flush()
+    assert float(d.sum()) == 0.0
+    s.add([(d, g), (d, 2 * g)])
+    s.flush()
+    assert torch.equal(d, torch.full((8,), 3.0))
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    outs = []
+    for dirty in (True, False):
+        G = _load(spgan.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=9))
+        D = _load(spgan.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=9))
+        tr = spgan.TrainStep(G, D, gan="ls", use_gp=False)
+        if dirty:      # what an aborted backward would have left
+            tr._sinkD.add([(tr.optD.fp.grad, torch.ones_like(tr.optD.fp.grad))])
+            tr._sinkG.add([(tr.optG.fp.grad, torch.ones_like(tr.optG.fp.grad))])
+        outs.append(tr.step(x, fr.synthetic_real(B, N, seed=3), fr.latent(B, N, seed=4)[:, :1].contiguous(), fr.latent(B, N, seed=5)[:, :1].contiguous(),
+                            keep_grads=True))
+    for kind in ("d_grads", "g_grads"):
+        for n in outs[0][kind]:
+            assert torch.equal(outs[0][kind][n], outs[1][kind][n]), (kind, n)
