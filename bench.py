@@ -25,6 +25,7 @@ The JSON line also carries
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -63,8 +64,20 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense p
 FP16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (never the 2:1-sparsity figure)
 # algorithmic FLOPs per shape per step, reference formulation: WGAN-GP at N=2048
 GF_PER_SHAPE_STEP = 67.3 if CONFIG == "c4" else 32.6     # 2 F_Gf + 4N*779,520 + 15 F_Df at N = 4096 / 2048
-PMC_FILES = ("r05_pmc_gemm_nt.json", "r04_pmc_gemm_nt.json", "r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json")
-PMC_STEP_FILES = ("r04_pmc_step.json", "r03_pmc_step.json", "r02_pmc_step.json")
+
+
+def _profiles_newest_first(suffix):
+    """profiles/rNN[a]_<suffix>, newest round first (so a new round's collection is picked up without editing this file)."""
+    import glob
+    names = [os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_" + suffix))]
+    names = [n for n in names if re.fullmatch(r"r\d\d[a-z]?_" + re.escape(suffix), n)]
+    return tuple(sorted(names, key=lambda n: (n[1:3], n[3] == "_"), reverse=True))     # r06_ before r06a_ before r05_ ...
+
+
+PMC_FILES = _profiles_newest_first("pmc_gemm_nt.json")
+# whole-step PMC passes per bench mode: (config, mfma) -> file suffix (tools/pmc_step.py --config / --mfma, tools/collect_profiles.sh)
+PMC_STEP_SUFFIX = {("c2", "f32"): "pmc_step.json", ("c4", "f32"): "pmc_step_c4.json", ("c2", "f16"): "pmc_step_f16.json",
+                   ("c2", "bf16x3"): "pmc_step_bf16x3.json"}
 ALGORITHMIC_HBM_GB_PER_STEP = 3.5      # SURVEY 8(d): ~110 MB per shape per step x 32 shapes
 
 
@@ -98,9 +111,11 @@ def make_inputs(dev, rank, b, tiled_z=False):
     return x, real, zs, alpha
 
 
-def _pmc_step_traffic():
-    """Whole-step HBM bytes from the committed rocprofv3 PMC passes of tools/pmc_step.py (FETCH_SIZE doubled + WRITE_SIZE)."""
-    for name in PMC_STEP_FILES:
+def _pmc_step_traffic(config="c2", mfma="f32"):
+    """Whole-step HBM bytes from the committed rocprofv3 PMC passes of tools/pmc_step.py (FETCH_SIZE doubled + WRITE_SIZE) for
+    this bench mode; None when no pass of this mode is committed."""
+    suffix = PMC_STEP_SUFFIX.get((config, mfma))
+    for name in (_profiles_newest_first(suffix) if suffix else ()):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -108,13 +123,13 @@ def _pmc_step_traffic():
             if gb:
                 return {"hbm_gb_per_step": round(float(gb), 2), "algorithmic_gb_per_step": ALGORITHMIC_HBM_GB_PER_STEP,
                         "ratio": round(float(gb) / ALGORITHMIC_HBM_GB_PER_STEP, 2), "source": "profiles/" + name,
-                        "note": "committed rocprofv3 --pmc passes over a replayed step (not sampled in this run; batch 32)"}
+                        "note": "committed rocprofv3 --pmc passes over a replayed step of this mode (not sampled in this run)"}
         except Exception:
             continue
     return None
 
 
-ROCPROF_STATS_FILES = ("r05_bench_kernel_stats.txt", "r04_bench_kernel_stats.txt")
+ROCPROF_STATS_FILES = _profiles_newest_first("bench_kernel_stats.txt")
 
 
 def _rocprof_reference(M):
@@ -818,8 +833,8 @@ def main():
                 # FLOPs the build really issues on the matrix cores / whole step time / peak (the reference-formulation fraction above
                 # divides FLOPs the build does not execute)
                 line["step_mfma_frac_issued"] = round(line["mfma"]["mfma_flops_issued_per_step"] / (ms * 1e-3) / 1e12 / (peak * 1.0), 4)
-            if PER_GPU_BATCH == 32 and args.config == "c2" and args.mfma == "f32":
-                line["hbm_traffic"] = _pmc_step_traffic()
+            if EXPERIMENT_BATCH is None and not variant:
+                line["hbm_traffic"] = _pmc_step_traffic("c4" if args.config == "c4" else "c2", args.mfma)
         if drop_in is not None:
             line["drop_in_caller"] = drop_in
         if literal is not None:

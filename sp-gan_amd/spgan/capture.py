@@ -49,6 +49,10 @@ def _bn_snapshot(mods):
 
 
 class CapturedBody:
+    # a change of the structure-bearing argument (the sphere prior) after this many undisturbed replays no longer counts towards the
+    # "keeps changing -> eager" verdict
+    RECAPTURE_FORGIVEN_AFTER = 8
+
     def __init__(self, fn: Callable, modules: Sequence[nn.Module], warmup: int = 3):
         self.fn, self.modules, self.warmup = fn, tuple(modules), warmup
         self._calls = 0
@@ -61,6 +65,7 @@ class CapturedBody:
         self.eager = False
         self._struct = set()         # positions of arguments the modules hold cached graph structure for (the sphere prior)
         self._recaptures = 0
+        self._quiet_replays = 0
         self._captured_once = False
 
     # ------------------------------------------------------------------ inputs
@@ -97,7 +102,8 @@ class CapturedBody:
             self._src[i] = (weakref.ref(a), a._version)
             if i in self._struct:
                 # the modules cached structure derived from this buffer and the captured graph does not re-derive it: compare on the
-                # device (one host sync, off the steady-state path); a real change goes through torch's copy_, whose version bump
+                # device (one host sync PER CALL for a caller that hands over a NEW tensor object every call -- `x = sphere.cuda()` inside
+                # the loop; a caller that reuses its tensor object unmodified never reaches this line); a real change goes through torch's copy_, whose version bump
                 # invalidates the modules' cache entries
                 # -- with or without a captured graph: a caller that re-creates an IDENTICAL prior on every call (x = sphere.cuda() inside
                 # the loop) must not be taken for one whose prior changes, or the warm-up would restart forever and no graph would ever
@@ -134,7 +140,11 @@ class CapturedBody:
             # The prior changed: a captured graph holds the OLD prior's kNN graph, CSR and dedup decision (the modules cache them per
             # tensor and version, so the capture contains no kNN launch), and a capture that found its cache entry stale would have to
             # rebuild it with a host sync.  Drop the graph, run this call eagerly (rebuilds the caches), capture again on the next one.
-            self._recaptures += 1                    # also before the first capture: a prior that really changes on every call must reach the eager verdict
+            # Counts changes in CLOSE succession (also before the first capture: a prior that really changes on every call must reach the
+            # eager verdict); a change after RECAPTURE_FORGIVEN_AFTER undisturbed replays starts from zero again -- a new sphere per epoch
+            # is re-captured every time, not demoted on the fourth epoch.
+            self._recaptures += 1
+            self._quiet_replays = 0
             self._graph = None
             if self._recaptures > 3:
                 warnings.warn("CapturedBody: an argument the modules derive cached graph structure from (the sphere prior) keeps changing "
@@ -192,6 +202,9 @@ class CapturedBody:
             self._captured_once = True
             self._struct = self._structure_args()
         self._graph.replay()
+        self._quiet_replays += 1
+        if self._quiet_replays >= self.RECAPTURE_FORGIVEN_AFTER:
+            self._recaptures = 0
         self._invalidate_weight_caches()
         for m, d in zip(mods, self._bn_delta):
             store = m.__dict__.setdefault("_bn_pending", {})

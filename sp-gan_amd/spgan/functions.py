@@ -104,6 +104,16 @@ class DeliverySink:
                 by_dst[key] = (d, [])
                 order.append(key)
             by_dst[key][1].append(s_)
+        # Two DIFFERENT destinations that share elements (a CatCols column block of a parameter's .grad from one node and the whole .grad
+        # from another) must not meet in one launch -- that would be an unordered read-modify-write.  They leave the grouped launches and
+        # are added one stream-ordered launch per gradient, in arrival order (what the per-node launches did).
+        clash = _overlapping_keys([by_dst[k][0] for k in order])
+        if clash:
+            hit = {order[i] for i in clash}
+            for d, s_ in pairs:
+                if (d.data_ptr(), tuple(d.shape), tuple(d.stride())) in hit:
+                    ops.multi_add([d], [s_ if s_.shape == d.shape or s_.is_contiguous() else s_.contiguous()])
+            order = [k for k in order if k not in hit]
         single = [(by_dst[k][0], by_dst[k][1][0]) for k in order if len(by_dst[k][1]) == 1]
         multi = [by_dst[k] for k in order if len(by_dst[k][1]) > 1]
         rest = []
@@ -118,6 +128,46 @@ class DeliverySink:
         for d, ss in rest:
             for x in ss:
                 ops.multi_add([d], [x])
+
+
+def _extent(t: Tensor):
+    """[lo, hi) byte range a (possibly strided) view touches."""
+    lo = t.data_ptr()
+    span = 1 + sum((n - 1) * st for n, st in zip(t.shape, t.stride()) if n > 0)
+    return lo, lo + span * t.element_size()
+
+
+def _share_elements(a: Tensor, b: Tensor) -> bool:
+    """Do two destination views share an element?  Exact for the shapes the sink sees (contiguous tensors; column blocks [rows, w] of one
+    row-major matrix: same row stride, unit column stride); conservative (True) for any other pair whose byte ranges intersect."""
+    if a.numel() == 0 or b.numel() == 0:
+        return False
+    (alo, ahi), (blo, bhi) = _extent(a), _extent(b)
+    if ahi <= blo or bhi <= alo:
+        return False
+    if a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) == b.stride(0) and a.shape[0] == b.shape[0] \
+            and a.element_size() == b.element_size():
+        ld, item = a.stride(0), a.element_size()
+        base = min(alo, blo)
+        ca, cb = (alo - base) // item, (blo - base) // item
+        if (alo - base) % item == 0 and (blo - base) % item == 0 and ca + a.shape[1] <= ld and cb + b.shape[1] <= ld:
+            return not (ca + a.shape[1] <= cb or cb + b.shape[1] <= ca)      # column intervals inside one row frame
+    return True
+
+
+def _overlapping_keys(dsts) -> set:
+    """Indices of the destinations that share elements with ANOTHER destination of the list (distinct views; O(n log n) sweep over byte
+    ranges, the exact test only for range-intersecting pairs)."""
+    ext = sorted((*_extent(d), i) for i, d in enumerate(dsts))
+    out, live = set(), []
+    for lo, hi, i in ext:
+        live = [(h, j) for h, j in live if h > lo]
+        for _, j in live:
+            if _share_elements(dsts[i], dsts[j]):
+                out.add(i)
+                out.add(j)
+        live.append((hi, i))
+    return out
 
 
 class fused_grad_accumulation(_Mode):
@@ -341,25 +391,27 @@ class DStacksJointFn(Function):
         needs = ctx.needs_input_grad[1:]
         fused = bool(ctx.fused) and not torch.is_grad_enabled()
         sink = ctx.fused if (fused and isinstance(ctx.fused, DeliverySink)) else None
-        if sink is None:
+        def to_grad(p_, gs) -> bool:      # added into the pre-bound .grad (by the sink's owner or by the launch below) instead of handed back
+            return fused and p_.is_leaf and p_.grad is not None and p_.grad.is_contiguous() and all(g.numel() == p_.grad.numel() for g in gs)
+        wanted = []
+        for i, (n, p_, need) in enumerate(zip(names, params, needs)):
+            gs = [c[n] for c in chains if n in c and not isinstance(c[n], int)] if need else []
+            if gs:
+                wanted.append((i, p_, gs))
+        # The per-pass weight gradients are deferred split-K sums (gemm_dual_multi(defer=True), gemm_tn_narrow_multi): only the sink's owner may
+        # leave them unreduced.  Anything summed here with torch adds and handed back to autograd has to be complete first.
+        if sink is None or any(not to_grad(p_, gs) for _, p_, gs in wanted):
             ops.flush_tn()
         out: List[Optional[Tensor]] = [None] * len(params)
         dsts, srcs = [], []
-        for i, (n, p_, need) in enumerate(zip(names, params, needs)):
-            if not need:
-                continue
-            gs = [c[n] for c in chains if n in c and not isinstance(c[n], int)]
-            if not gs:
-                continue
-            if fused and p_.is_leaf and p_.grad is not None and p_.grad.is_contiguous() and all(g.numel() == p_.grad.numel() for g in gs):
+        for i, p_, gs in wanted:
+            if to_grad(p_, gs):
                 dsts.append(p_.grad); srcs.append(gs)
             else:
                 tot = gs[0]
                 for g in gs[1:]:
                     tot = tot + g
                 out[i] = tot.view_as(p_)
-        if sink is not None and any(o is not None for o in out):
-            ops.flush_tn()
         if dsts and sink is not None:
             sink.add([(d, g) for d, gs in zip(dsts, srcs) for g in gs])      # the owner adds them (arrival order) with everything else of this backward
         elif dsts:

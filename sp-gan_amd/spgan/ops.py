@@ -721,6 +721,8 @@ def gemm_dual(dy, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: 
     gout = (add [M,Nb], scale [Nb]): the returned g tensor holds add + scale*g instead of g (s0, s1 stay the sums of g): phase B's adjoint
     X = xbarA + gamma*g leaves this launch."""
     if phaseb is not None and len(phaseb) == 4:
+        if edge is not None or coef_bn is not None:
+            raise ValueError("gemm_dual: the phase-B coefficient tail (4-tuple phaseb) takes neither a per-edge operand nor coef_bn")
         return gemm_dual_multi([dict(dy=dy, W=W, y_ref=y_ref, scale=scale, shift=shift, mean=mean, invstd=invstd, slope=slope, out=out, beta=beta, bias=bias,
                                      rowadd=rowadd, with_colsum=with_colsum, phaseb=phaseb, gout=gout)], defer=defer, _force=True)[0]
     b = _gemm_dual_build(dy, W, y_ref, scale, shift, mean, invstd, slope, edge=edge, out=out, beta=beta, bias=bias, rowadd=rowadd, with_colsum=with_colsum,

@@ -227,3 +227,25 @@ def test_captured_body_with_an_identical_prior_recreated_on_every_call(sp):
     for i in range(6):
         assert torch.equal(body(host.cuda(), z), want)          # a fresh device tensor per call
     assert body._graph is not None and not body.eager and body._recaptures == 0
+
+
+def test_captured_body_forgives_rare_prior_changes(sp):
+    """Advisor (round 5): prior changes separated by long runs of replays (a new sphere per epoch) are re-captured every time -- only changes in
+    close succession demote the body to eager issue."""
+    B, N = 4, 256
+    G = _load(sp.Generator(_opts(N)), fr.init_params(orc.generator_shapes(), salt=8)).eval()
+
+    def fn(x_, z_):
+        with torch.no_grad():
+            return G(x_, z_)
+    body = sp.CapturedBody(fn, modules=(G,), warmup=1)
+    rot = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    priors = [fr.sphere_template(N)[None].repeat(B, 1, 1).cuda(),
+              (fr.sphere_template(N) @ rot * torch.tensor([1.0, 0.8, 0.6]))[None].repeat(B, 1, 1).contiguous().cuda()]
+    z = fr.latent(B, N, seed=3).cuda()
+    wants = [fn(p, z).clone() for p in priors]
+    for epoch in range(6):                      # six changes: more than the demotion threshold of changes in a row
+        p, w = priors[epoch % 2], wants[epoch % 2]
+        for _ in range(sp.CapturedBody.RECAPTURE_FORGIVEN_AFTER + 3):
+            assert torch.equal(body(p, z), w)
+        assert body._graph is not None and not body.eager and body._recaptures == 0

@@ -155,13 +155,16 @@ def test_three_reference_steps(sp, tag, gan, use_gp, B, N, salt):
 MID = [("c1_ls", "ls", False, 4, 512, 21), ("c2_wgangp", "wgan", True, 32, 2048, 22)]
 
 
+@pytest.mark.parametrize("untiled", [False, True])
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("tag,gan,use_gp,B,N,salt", MID)
-def test_one_step_from_a_mid_training_state(sp, tag, gan, use_gp, B, N, salt, graph):
+def test_one_step_from_a_mid_training_state(sp, tag, gan, use_gp, B, N, salt, graph, untiled):
     """Golden G20: Adam at step 8 (moments and bias corrections of a run in progress) and BatchNorm running statistics advanced from
     non-initial buffers, inside the real train step, against the reference started from the SAME state -- one-step tolerances (the
     G8 / G17 ones).  graph=True: the same step issued by the capturable optimiser route the benchmark uses (device-side step count),
-    eagerly (keep_grads), so that the reference's graphs can be injected."""
+    eagerly (keep_grads), so that the reference's graphs can be injected.  untiled=True hands the latents over as [B,1,nz] (one row per
+    shape, what bench.py does): the step then takes Generator.forward_pair -- both generator forwards as one pipeline, the default
+    single-GPU route -- which is thereby pinned against the REFERENCE at one-step tolerances, not only against the separate forwards."""
     d = golden("g20_mid_state_step_%s.npz" % tag)
     o = _opts(N)
     init_g, init_d = fr.init_params(orc.generator_shapes(), salt=salt), fr.init_params(orc.discriminator_shapes(), salt=salt)
@@ -174,7 +177,12 @@ def test_one_step_from_a_mid_training_state(sp, tag, gan, use_gp, B, N, salt, gr
     real, z_d, z_g = fr.synthetic_real(B, N, seed=2001).cuda(), fr.latent(B, N, seed=2002).cuda(), fr.latent(B, N, seed=2003).cuda()
     alpha = torch.from_numpy(d["alpha"]).cuda()
     G.inject_graph2([torch.from_numpy(d["idx2_d"].astype(np.int64)).view(B, N * 10), torch.from_numpy(d["idx2_g"].astype(np.int64)).view(B, N * 10)])
+    if untiled:
+        assert torch.equal(z_d, z_d[:, :1].expand_as(z_d)) and torch.equal(z_g, z_g[:, :1].expand_as(z_g))      # the reference's np.tile of one latent per shape
+        z_d, z_g = z_d[:, :1].contiguous(), z_g[:, :1].contiguous()
+    G.__dict__["_pair_idx"] = None
     info = tr.step(x, real, z_d, z_g, alpha=alpha if use_gp else None, keep_grads=True)
+    assert (G.__dict__.get("_pair_idx") is not None) == (untiled and tr.pair_g_forwards), "the paired generator route did not run / ran unasked"
     fl = FLOOR[tag]
     np.testing.assert_allclose(info["loss_d"].item(), float(d["lossD"]), rtol=fl["loss"])
     np.testing.assert_allclose(info["loss_g"].item(), float(d["lossG"]), rtol=0, atol=2e-3 * max(abs(float(d["lossG"])), 0.5))

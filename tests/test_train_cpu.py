@@ -364,3 +364,37 @@ def test_delivery_sink_forgets_an_aborted_backward(spgan_cpu):
     for kind in ("d_grads", "g_grads"):
         for n in outs[0][kind]:
             assert torch.equal(outs[0][kind][n], outs[1][kind][n]), (kind, n)
+
+
+def test_delivery_sink_orders_overlapping_destinations(spgan_cpu):
+    """A CatCols column block of a parameter's .grad and the whole .grad of the SAME parameter (two nodes differentiating one generator
+    forward each) are different destinations sharing elements: they must not meet in one grouped launch (functions.DeliverySink.flush sends
+    them through stream-ordered single launches); disjoint column blocks of one matrix stay on the grouped path."""
+    from spgan import functions as F
+    from spgan import ops
+    grad = torch.zeros(6, 10)
+    left, right = grad.view(6, -1)[:, :4], grad.view(6, -1)[:, 4:]
+    assert not F._share_elements(left, right) and F._share_elements(left, grad) and F._share_elements(right, grad)
+    assert not F._share_elements(grad[:3], grad[3:]) and F._share_elements(grad[:4], grad[3:])
+    assert F._overlapping_keys([left, right]) == set() and F._overlapping_keys([left, right, grad]) == {0, 1, 2}
+    other = torch.zeros(7)
+    launches = []
+    real_add = ops.multi_add
+    def spy(dsts, srcs):
+        launches.append([d.data_ptr() for d in dsts])
+        return real_add(dsts, srcs)
+    ops.multi_add = spy
+    try:
+        s = F.DeliverySink()
+        a, b, w, o = torch.full((6, 4), 1.0), torch.full((6, 6), 2.0), torch.full((6, 10), 4.0), torch.full((7,), 8.0)
+        s.add([(left, a), (right, b), (other, o)])       # node 1: column blocks
+        s.add([(grad, w)])                               # node 2: the whole gradient of the same parameter
+        s.flush()
+    finally:
+        ops.multi_add = real_add
+    want = torch.cat([torch.full((6, 4), 5.0), torch.full((6, 6), 6.0)], 1)
+    assert torch.equal(grad, want) and torch.equal(other, torch.full((7,), 8.0))
+    clash_ptrs = {left.data_ptr(), right.data_ptr(), grad.data_ptr()}
+    for l in launches:       # no launch holds two of the clashing destinations
+        assert len([p for p in l if p in clash_ptrs]) <= 1 or l == [other.data_ptr()], l
+    assert [other.data_ptr()] in launches

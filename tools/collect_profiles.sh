@@ -21,6 +21,10 @@ for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do rm -rf /tmp/p_$c; rocprofv3 --pmc $c
 python $R/tools/pmc_step_total.py $(find /tmp/p_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/p_WRITE_SIZE -name "*.db" | head -1) $(find /tmp/p_MfmaUtil -name "*.db" | head -1) > $O/${TAG}_pmc_step.json
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do rm -rf /tmp/p4_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/p4_$c -o r -- python $R/tools/pmc_step.py --config c4 > /tmp/log4_$c 2>&1; done     # the same at the C4 per-GPU shape
 python $R/tools/pmc_step_total.py $(find /tmp/p4_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/p4_WRITE_SIZE -name "*.db" | head -1) $(find /tmp/p4_MfmaUtil -name "*.db" | head -1) > $O/${TAG}_pmc_step_c4.json
+for m in f16 bf16x3; do      # the same for the two 16-bit operand modes at C2
+for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do rm -rf /tmp/pm_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/pm_$c -o r -- python $R/tools/pmc_step.py --mfma $m > /tmp/logm_$c 2>&1; done
+python $R/tools/pmc_step_total.py $(find /tmp/pm_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pm_WRITE_SIZE -name "*.db" | head -1) $(find /tmp/pm_MfmaUtil -name "*.db" | head -1) > $O/${TAG}_pmc_step_$m.json
+done
 for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/g_$c; rocprofv3 --pmc $c --kernel-trace -d /tmp/g_$c -o r -- python $R/tools/pmc_gemm.py > /tmp/glog_$c 2>&1; python $R/tools/pmc_summary.py $(find /tmp/g_$c -name "*.db" | head -1) gemm_nt > $O/${TAG}_pmc_gemm_$c.txt; done
 python $R/tools/pmc_gemm_json.py $O/${TAG}_pmc_gemm_FETCH_SIZE.txt $O/${TAG}_pmc_gemm_WRITE_SIZE.txt ${TAG} > $O/${TAG}_pmc_gemm_nt.json
 python $R/tools/mfma_shapes.py > $O/${TAG}_mfma_shapes.txt 2>/dev/null

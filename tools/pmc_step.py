@@ -8,6 +8,8 @@ import torch
 import bench
 import spgan
 dev = torch.device("cuda", 0)
+MFMA = next((sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--mfma"), "f32")      # f32 | f16 | bf16x3 (bench.py --mfma)
+spgan.ops.set_mfma_operands(MFMA)
 G, D = bench.build_models(dev)
 tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4)
 x, real, zs, alpha = bench.make_inputs(dev, 0, bench.PER_GPU_BATCH)
