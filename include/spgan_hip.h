@@ -178,6 +178,10 @@ typedef struct spgan_gemm_nt_args {
    * a_half = 1 together with A2 (epi_mode EDGE_BNBWD): A points at bfloat16 values (g2 of spgan_edge_attend_bwd_b), A2 at fp16 values
    * (h2pre): the EdgeBlock's lazy BatchNorm-backward operand p*A + q*A2 + r with both tensors in 16-bit storage. */
   int y_half;
+  /* w_image != NULL (mfma_f16 == 2 only): the split-bf16 image of W written by spgan_split_bf16x3_image (same N, K): the 256-row-tile kernel
+   * copies W's three bf16 planes from it instead of splitting the fp32 rows of W again in every workgroup (weights: split once per optimiser
+   * step).  Kernels that do not use it ignore it; W must still be given. */
+  const void* w_image;
 } spgan_gemm_nt_args;
 /* 1 when spgan_gemm_nt will honour y_bf16 for this problem (it runs on the 256 x 256-tile kernel with fp16 operands) */
 int spgan_gemm_nt_y16_ok(const spgan_gemm_nt_args* a);
@@ -188,6 +192,14 @@ int spgan_gemm_nt_owns_columns(const spgan_gemm_nt_args* a);
 int spgan_gemm_nt_col_blocks(const spgan_gemm_nt_args* a);
 
 int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s);
+/* Split-bf16 image of a row-major fp32 matrix W [N,K] (N % 128 == 0, K % 16 == 0): every value as three bfloat16 terms hi + mid + lo (exact:
+ * round to nearest at each level, each residual representable), laid out as the LDS tiles of the split-bf16 gemm_nt read them:
+ * image[k / 16][plane][n][16 bf16], the two 16-byte halves of a row swapped where bit 3 of n is set, rows whose 32-row tile index is odd (bit 5 of
+ * n) negated (the kernel's sign checkerboard, csrc/gemm_wide3.hip).  spgan_split_bf16x3_image_bytes: 6*N*K. */
+size_t spgan_split_bf16x3_image_bytes(int N, int K);
+int spgan_split_bf16x3_image(const float* W, int ldw, int N, int K, void* image, spgan_stream_t s);
+/* 1 when spgan_gemm_nt would read a w_image for this problem (worth making one) */
+int spgan_gemm_nt_uses_w_image(const spgan_gemm_nt_args* a);
 /* pooled[b,c] = max_n lrelu(scale[c]*y[b*rows+n, c] + shift[c], slope) from the tile partials above (rows % 128 == 0, so
  * that no tile straddles two shapes): scale >= 0 takes the tile maxima, scale < 0 the minima.  argmax = global row,
  * yarg = the pre-BatchNorm value there.  Ties go to the lowest row of equal PRE-activation values; scale == 0 (all rows tie):

@@ -10,3 +10,11 @@ bool spgan_nt_wide_pays(const spgan_gemm_nt_args& a);      // ... and is expecte
 // SPGAN_NT_WIDE=0 (read once) turns the kernel off altogether (A/B measurements of whole programs)
 bool spgan_nt_wide_selected(const spgan_gemm_nt_args& a);
 int spgan_launch_nt_wide(const spgan_gemm_nt_args& a, hipStream_t s);
+
+// Split-bf16 operands (mfma_f16 == 2) on 256-row tiles (gemm_wide3.hip): 256 x 256 or 256 x 128 tiles.
+bool spgan_nt_wide3_eligible(const spgan_gemm_nt_args& a);
+int spgan_nt_wide3_config(const spgan_gemm_nt_args& a);     // waves (rows x columns, of 128 x 64 each) as WGM*10 + WGN: 24, 22 or 14
+int spgan_nt_wide3_tile_n(const spgan_gemm_nt_args& a);     // 256 or 128: the tile width an eligible problem runs with
+// tile_hint 1 -> never, 2 -> when eligible, 0 -> when eligible and large enough; SPGAN_NT_WIDE3=0 (read once) turns the kernel off
+bool spgan_nt_wide3_selected(const spgan_gemm_nt_args& a);
+int spgan_launch_nt_wide3(const spgan_gemm_nt_args& a, hipStream_t s);

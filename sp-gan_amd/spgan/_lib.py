@@ -50,6 +50,7 @@ class GemmNTArgs(C.Structure):
         ("p_group_rows", C.c_int),
         ("A2", c_f32p), ("lda2", C.c_int), ("p_scale2", c_f32p),
         ("a_half", C.c_int), ("y_bf16", C.c_int), ("y_half", C.c_int),
+        ("w_image", C.c_void_p),
     ]
 
 
@@ -177,6 +178,9 @@ SIGNATURES = {
     "spgan_concat2": (I, [P, I, P, I, I, P, P]),
     "spgan_gemm_nt": (I, [C.POINTER(GemmNTArgs), P]),
     "spgan_gemm_nt_col_blocks": (I, [C.POINTER(GemmNTArgs)]),
+    "spgan_split_bf16x3_image_bytes": (C.c_size_t, [I, I]),
+    "spgan_split_bf16x3_image": (I, [P, I, I, I, P, P]),
+    "spgan_gemm_nt_uses_w_image": (I, [C.POINTER(GemmNTArgs)]),
     "spgan_gemm_nt_owns_columns": (I, [C.POINTER(GemmNTArgs)]),
     "spgan_pool_finalize": (I, [P, P, I, I, I, P, P, F, P, P, P, P]),
     "spgan_pool_finalize_groups": (I, [P, P, I, I, I, P, P, I, I, F, P, P, P, I, P]),

@@ -127,6 +127,36 @@ def get_mfma_operands() -> str:
     return {v: k for k, v in _MFMA_KINDS.items()}[_MFMA_F16[0]]
 
 
+# Split-bf16 weight images ("bf16x3" operand mode): the 256-row-tile gemm_nt kernel copies W's three bf16 planes from a pre-split image of W
+# (split_image below: made once per weight and optimiser step) instead of splitting W's fp32 rows again in every workgroup.  ops does not
+# know which operands are weights and when they change -- the provider does (nets.w_image: parameters and their cached transposes, refreshed
+# when the weights' epoch / version moves, all stale images of a network in one launch); None, or a provider returning None: W is split
+# on the fly.  Signature: provider(W) -> uint8 image tensor | None.
+w_image_provider = None
+
+
+def split_image(W: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """The split-bf16 image of a row-major fp32 matrix W [N,K] (N % 128 == 0, K % 16 == 0; spgan_split_bf16x3_image): 6*N*K bytes."""
+    _rowmajor2d(W, "W")
+    N, K = W.shape
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((int(lib.spgan_split_bf16x3_image_bytes(N, K)),), dtype=torch.uint8, device=W.device)
+    check(lib.spgan_split_bf16x3_image(_p(W), _ld(W), N, K, _p(out), _s()), "split_bf16x3_image", N=N, K=K)
+    return out
+
+
+def _attach_w_image(a, W: Tensor):
+    """Called when the argument block is complete: hands the kernel W's pre-split image when the launch would read one.  Returns the image
+    (the caller keeps it alive across the launch)."""
+    if a.mfma_f16 != 2 or w_image_provider is None or not _lib.load().spgan_gemm_nt_uses_w_image(C.byref(a)):
+        return None
+    img = w_image_provider(W)
+    if img is not None:
+        a.w_image = _p(img)
+    return img
+
+
 # gemm_nt tile geometry (spgan_gemm_nt_args.tile_hint): 0 automatic, 1 the 128-row kernels only, 2 the 256 x 256-tile kernel
 # (csrc/gemm_wide.hip) whenever the problem is eligible.  1 / 2 are for tests and A/B measurements.
 _NT_TILE_HINT = [0]
@@ -416,6 +446,7 @@ def gemm_nt(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, *, pro=None, ed
         else:
             res = torch.empty((2, N), dtype=torch.float32, device=A.device)
             a.tail.enabled = 1; a.tail.mode = 0; a.tail.out0 = _p(res[0]); a.tail.out1 = _p(res[1])
+    _wimg = _attach_w_image(a, W)      # noqa: F841 (kept alive across the launch)
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt", M=M_, N=N, K=K, a_mode=a.a_mode)
     if done is not None:
@@ -491,6 +522,7 @@ def gemm_nt_maskout(A: Tensor, W: Tensor, ref: Tensor, slope: float, with_colsum
         res = torch.empty((2, N), dtype=torch.float32, device=A.device)
         a.stats = _p(part)
         a.tail.enabled = 1; a.tail.mode = 1; a.tail.out0 = _p(res[0]); a.tail.out1 = _p(res[1])
+    _wimg = _attach_w_image(a, W)      # noqa: F841 (kept alive across the launch)
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_maskout", M=M_, N=N, K=K)
     if done is not None:
@@ -653,6 +685,7 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
     if _owns_columns(lib, a):
         res = torch.empty((2, N), dtype=torch.float32, device=A.device)          # [sum g | sum g*xhat], contiguous (nets._cat2)
         a.tail.enabled = 1; a.tail.mode = 1; a.tail.out0 = _p(res[0]); a.tail.out1 = _p(res[1])
+    _wimg = _attach_w_image(a, W)      # noqa: F841 (kept alive across the launch)
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_bnbwd", M=M_, N=N, K=K)
     if done is not None:
@@ -1478,6 +1511,7 @@ def gemm_bn_pool(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, rows: int, sl
     lib = _lib.load()
     gamma, beta, rm, rv = bn
     st = torch.empty((4, N), dtype=torch.float32, device=dev)
+    _wimg = _attach_w_image(a, W)      # noqa: F841 (kept alive across the launch)
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_bn_pool", M=M_, N=N, K=K)
     if done is not None:
@@ -1542,6 +1576,7 @@ def gemm_bn_groups(A: Tensor, W: Tensor, bias: Optional[Tensor], bn, groups: int
     lib = _lib.load()
     gamma, beta, rm, rv = bn
     out = torch.empty((4, groups, N), dtype=torch.float32, device=dev)
+    _wimg = _attach_w_image(a, W)      # noqa: F841 (kept alive across the launch)
     done = launch_timer("gemm_nt", a) if launch_timer is not None else None
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_bn_groups", M=M_, N=N, K=K, groups=groups)
     if done is not None:

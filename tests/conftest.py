@@ -13,6 +13,37 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The reference-golden suites also run with the split-bf16 operand mode ("bf16x3": fp32-equivalent products on the bf16 matrix pipe) at
+# UNCHANGED tolerances: every test of these files is parametrised over the operand mode through the autouse fixture below.
+# SPGAN_TEST_MFMA=<mode> restricts these files to one mode (and extends it to nothing else).
+MFMA_PARITY_FILES = ("test_parity_gpu.py", "test_multistep_golden_gpu.py", "test_benchsize_golden_gpu.py", "test_literal_loop_gpu.py",
+                     "test_losses_gpu.py", "test_adam_gpu.py")
+
+
+def pytest_generate_tests(metafunc):
+    if "mfma_mode" in metafunc.fixturenames:
+        fname = os.path.basename(getattr(metafunc.module, "__file__", ""))
+        modes = ["f32"]
+        if fname in MFMA_PARITY_FILES:
+            env = os.environ.get("SPGAN_TEST_MFMA")
+            modes = [env] if env else ["f32", "bf16x3"]
+        metafunc.parametrize("mfma_mode", modes, indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def mfma_mode(request):
+    mode = getattr(request, "param", "f32")
+    if mode == "f32":
+        yield mode
+        return
+    from spgan import ops
+    ops.set_mfma_operands(mode)
+    try:
+        yield mode
+    finally:
+        ops.set_mfma_operands("f32")
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():

@@ -486,3 +486,121 @@ def test_networks_bf16x3_match_reference_goldens_at_fp32_tolerances(sp):
             check(d, "grad|" + n, p.grad, rtol=3e-4, atol=2e-3 if n.endswith(("mlps.0.bias", "mlps.3.bias", "mlps.6.bias", "fc2.0.bias")) else 1e-7, what="bf16x3")
     finally:
         sp.ops.set_mfma_operands("f32")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# split-bf16 operands on 256-row tiles (csrc/gemm_wide3.hip): configurations 24 (256 x 256 tiles), 22 (256 x 128), 14 (128 x 256, with W's
+# pre-split image) -- chosen by the library from the shape (spgan_nt_wide3_config); shapes below reach each of them
+WIDE3_SHAPES = [   # M, N, K, what it exercises
+    (16384, 1024, 256, "24: K > 128, tiles fill the chip"),
+    (1024, 128, 1280, "22: N % 256 != 0, long K"),
+    (2048, 256, 128, "22 / 14 with image: short K"),
+    (512, 384, 64, "22: N = 3 x 128, two k-pairs"),
+    (768, 512, 32, "the shortest k-loop (one pair of k-tiles)"),
+]
+
+
+def _images(ops):
+    """A provider without a cache: every call splits W anew (a cache keyed by address would hand a recycled temporary's image to its successor --
+    the staleness rules are the real provider's business, nets.w_image)."""
+    return lambda Wt: ops.split_image(Wt)
+
+
+@pytest.mark.parametrize("image", [False, True])
+@pytest.mark.parametrize("M,N,K,what", WIDE3_SHAPES)
+def test_gemm_nt_wide3(b3, M, N, K, what, image):
+    """Every prologue / epilogue of the 256-row-tile split-bf16 kernel against the float64 product and the fp32 models; with and without the
+    pre-split image of W (ops.split_image: the kernel copies W's planes instead of splitting its rows)."""
+    ops = b3
+    ops.w_image_provider = _images(ops) if image else None
+    try:
+        with ops.nt_tile_hint(2):
+            A, W, b = rnd("w3.A%d.%d" % (M, K), (M, K)), rnd("w3.W%d.%d" % (N, K), (N, K), 0.1), rnd("w3.b%d" % N, (N,))
+            ref = A.double() @ W.double().t() + b.double()
+            got = ops.gemm_nt(A, W, b)
+            e3 = ((got.double() - ref).norm() / ref.norm()).item()
+            m3 = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+            assert e3 <= 1e-6 and m3 <= 3e-6, (e3, m3)
+            with ops.nt_tile_hint(1):
+                narrow = ops.gemm_nt(A, W, b)          # the 128-row split kernel: same products, another summation order
+            close(got, narrow, rtol=2e-6, atol=2e-6, what="wide vs 128-row split kernel")
+            # activations in the epilogue, a dense / a per-group row addend
+            close(ops.gemm_nt(A, W, b, act=km.ACT_LRELU, slope=0.2), km.gemm_nt(A, W, b, act=km.ACT_LRELU, slope=0.2), rtol=2e-6, atol=2e-6, what="lrelu")
+            close(ops.gemm_nt(A, W, b, act=km.ACT_TANH), km.gemm_nt(A, W, b, act=km.ACT_TANH), rtol=2e-6, atol=2e-6, what="tanh")
+            rows = 256
+            rbg = rnd("w3.rbg%d.%d" % (M, N), (M // rows, N))
+            close(ops.gemm_nt(A, W, b, rowbias=rbg, rows_per_group=rows), km.gemm_nt(A, W, b, rowbias=rbg, rows_per_group=rows), rtol=2e-6, atol=2e-6, what="group bias")
+            # BatchNorm + LeakyReLU prologue (one vector pair, and one pair per group of rows), column statistics
+            sc, sh = rnd("w3.sc%d" % K, (K,)).abs() + 0.5, rnd("w3.sh%d" % K, (K,), 0.3)
+            for slope in (0.01, 0.2, 1.0, 0.0):
+                y, m, v = ops.gemm_nt(A, W, b, pro=(sc, sh, slope), stats=True)
+                y2, m2, v2 = km.gemm_nt(A, W, b, pro=(sc, sh, slope), stats=True)
+                close(y, y2, rtol=2e-6, atol=2e-6, what="affine %g" % slope); close(m, m2, rtol=1e-5, atol=1e-6); close(v, v2, rtol=2e-5)
+            # epilogues of the backward passes
+            refm = rnd("w3.ref%d.%d" % (M, N), (M, N))
+            close(ops.gemm_nt_maskout(A, W, refm, 0.01), km.gemm_nt_maskout(A, W, refm, 0.01), rtol=2e-6, atol=2e-6, what="maskout")
+            bsc, bsh, mu, inv = rnd("w3.bsc%d" % N, (N,)), rnd("w3.bsh%d" % N, (N,), 0.3), rnd("w3.mu%d" % N, (N,), 0.2), rnd("w3.inv%d" % N, (N,)).abs() + 0.5
+            radd = rnd("w3.radd%d.%d" % (M, N), (M, N))
+            for pro in (None, (sc, sh, 0.2)):
+                for a_, b_ in zip(ops.gemm_nt_bnbwd(A, W, refm, bsc, bsh, mu, inv, 0.01, pro=pro, bias=b, rowadd=radd),
+                                  km.gemm_nt_bnbwd(A, W, refm, bsc, bsh, mu, inv, 0.01, pro=pro, bias=b, rowadd=radd)):
+                    close(a_, b_, rtol=5e-6, atol=2e-5, what="bnbwd")
+            # BatchNorm + LeakyReLU + max-pool behind the product (the output is not stored)
+            if M % 256 == 0 and M >= 512:
+                gamma, beta = rnd("w3.g%d" % N, (N,)), rnd("w3.be%d" % N, (N,), 0.3)        # both signs: max and min records are read
+                for keep in (False, True):
+                    o = ops.gemm_bn_pool(A, W, b, (gamma, beta, None, None), 256, 0.2, pro=(sc, sh, 0.2), keep_y=keep)
+                    o2 = km.gemm_bn_pool(A, W, b, (gamma, beta, None, None), 256, 0.2, pro=(sc, sh, 0.2), keep_y=keep)
+                    close(o[2], o2[2], rtol=3e-5, atol=3e-5, what="pooled")
+                    for x_, y_ in zip(o[1], o2[1]):
+                        close(x_, y_, rtol=3e-5, atol=3e-6, what="bn vectors")
+                    same = (o[3] == o2[3]).float().mean().item()
+                    assert same >= 0.99, "arg-max rows differ on %.2f %% of the (shape, channel) pairs" % (100 * (1 - same))
+            # extreme magnitudes: the split keeps fp32's range
+            big = ops.gemm_nt(A * 1e18, W * 1e15)
+            assert torch.isfinite(big).all()
+            close(big, (A.double() * 1e18) @ (W.double() * 1e15).t(), rtol=1e-6, what="large magnitudes")
+            close(ops.gemm_nt(A * 1e-18, W * 1e-15), (A.double() * 1e-18) @ (W.double() * 1e-15).t(), rtol=1e-6, atol=0.0, what="small magnitudes")
+    finally:
+        ops.w_image_provider = None
+
+
+def test_gemm_nt_wide3_product_error_bound(b3):
+    """The dropped cross terms: every single product a*b is reproduced within 4 * 2^-24 |a*b| (the review's bound; the round-to-nearest split
+    keeps it at ~2^-26) -- on operands chosen to make the dropped terms as large as they can be (all three planes full: mantissas 0xffffff-like)
+    and a reduction in which nothing cancels (one non-zero term per output), over 40 binades of magnitude."""
+    ops = b3
+    M, N, K = 512, 256, 64
+    g = torch.Generator().manual_seed(7)
+    mant = lambda shape: 1.0 + (torch.randint(0, 2 ** 23, shape, generator=g).double() / 2 ** 23)      # [1, 2): random 24-bit significands
+    full = 2.0 - 2.0 ** -23                                                                             # 0x3fffffff: every plane saturated
+    A = torch.zeros(M, K, dtype=torch.float64); W = torch.zeros(N, K, dtype=torch.float64)
+    k_of_m = torch.arange(M) % K
+    A[torch.arange(M), k_of_m] = mant((M,)) * (2.0 ** torch.randint(-20, 20, (M,), generator=g).double())
+    A[::7, :] = 0; A[torch.arange(0, M, 7), k_of_m[::7]] = full
+    W[:] = mant((N, K)) * (2.0 ** torch.randint(-20, 20, (N, K), generator=g).double())
+    W[::5] = full * (2.0 ** torch.randint(-20, 20, (W[::5].shape[0], 1), generator=g).double())
+    Af, Wf = A.float().cuda(), W.float().cuda()
+    assert torch.equal(Af.double().cpu(), A) and torch.equal(Wf.double().cpu(), W)                      # exactly representable
+    ref = (Af.double() @ Wf.double().t())                                                                # one term per output: the exact product
+    for hint in (2, 1):
+        with ops.nt_tile_hint(hint):
+            got = ops.gemm_nt(Af, Wf)
+        rel = ((got.double() - ref).abs() / ref.abs()).max().item()
+        assert rel <= 4 * 2.0 ** -24, (hint, rel, rel / 2.0 ** -24)
+
+
+def test_split_image_layout(b3):
+    """ops.split_image: hi + mid + lo == +-W exactly, in the image layout [k/16][plane][n][16] with the 16-byte halves swapped where bit 3 of n is set and
+    the rows of odd 32-row tiles negated."""
+    ops = b3
+    N, K = 256, 96
+    W = rnd("w3.img", (N, K)) * torch.logspace(-12, 12, N, device="cuda")[:, None]
+    img = ops.split_image(W).view(torch.bfloat16).view(K // 16, 3, N, 2, 8).float().double()
+    n = torch.arange(N, device="cuda")
+    swap = ((n >> 3) & 1).bool()
+    img = torch.where(swap[None, None, :, None, None], img.flip(3), img)                 # undo the half swap
+    img = torch.where(((n >> 5) & 1).bool()[None, None, :, None, None], -img, img)       # ... and the sign checkerboard (odd 32-row tiles are stored negated)
+    planes = img.reshape(K // 16, 3, N, 16).permute(1, 2, 0, 3).reshape(3, N, K)
+    assert torch.equal(planes.sum(0), W.double()), "hi + mid + lo != W"
+    assert (planes[1].abs() <= planes[0].abs() * 2.0 ** -8 + 1e-300).all() and (planes[2].abs() <= planes[0].abs() * 2.0 ** -16 + 1e-300).all()
