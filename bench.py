@@ -62,6 +62,14 @@ NZ = 128
 K_NN = 10
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 FP16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (never the 2:1-sparsity figure)
+# "bf16x3": one fp32-equivalent product = six bf16 MFMA cross products (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) -> the ceiling of
+# that route in fp32-equivalent FLOPs is the dense bf16 peak / 6
+SPLIT_BF16_PEAK_TFLOPS = FP16_MATRIX_PEAK_TFLOPS / 6.0
+SPLIT_BF16_PEAK_NOTE = "2500 TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md) / 6 bf16 MFMAs per fp32-equivalent product = 416.7 TFLOP/s fp32-equivalent"
+PEAK_OF_MODE = {"f32": FP32_MATRIX_PEAK_TFLOPS, "f16": FP16_MATRIX_PEAK_TFLOPS, "bf16x3": SPLIT_BF16_PEAK_TFLOPS}
+DTYPE_OF_MODE = {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate/epilogues/weight-gradients",
+                 "bf16x3": "f32 storage and accumulation; gemm_nt products with every f32 operand split exactly into 3 bf16 terms (6 bf16 MFMA cross "
+                           "products: f32-equivalent, dropped terms <= 2^-26 relative); layer-backward pairs (gemm_dual) and weight gradients on the exact f32 MFMA"}
 # algorithmic FLOPs per shape per step, reference formulation: WGAN-GP at N=2048
 GF_PER_SHAPE_STEP = 67.3 if CONFIG == "c4" else 32.6     # 2 F_Gf + 4N*779,520 + 15 F_Df at N = 4096 / 2048
 
@@ -202,7 +210,7 @@ class MfmaAccounting:
             if small:
                 return None
             if self.f16 == "bf16x3" and a.N > 32 and a.mfma_f16:
-                bn = 64
+                bn = 128 if (a.N % 128 == 0 and a.M % 256 == 0 and a.K % 32 == 0) else 64      # 256-row tiles (gemm_wide3.hip) / the 128-row split kernel
             elif self.f16 == "f16" and a.N > 32 and a.mfma_f16:
                 bn = 128 if (a.N > 64 and a.K >= 512) else 64
             else:
@@ -258,7 +266,7 @@ class MfmaAccounting:
                             "subtracted; wall clock %d kHz" % (in_graph["empty_pair_us"], in_graph["wall_clock_khz"]))
         else:
             r["timing"] = "HIP events around eagerly issued launches after the timed region (no replayed graph in this run)"
-        ref = _rocprof_reference(self.M)
+        ref = _rocprof_reference(self.M) if self.f16 == "f32" else None      # the committed kernel-trace summary is of the fp32-operand run
         if ref is not None:
             r["frac_rocprof_ref"] = ref["frac"]; r["rocprof_ref"] = ref
         return r
@@ -277,11 +285,12 @@ class MfmaAccounting:
         rows_avg = sum(m for _, _, m in dom) / len(dom)
         t1, t1_file = _pmc_traffic() if self.f16 == "f32" else (None, None)       # the committed PMC passes measured the fp32-operand kernel
         ksym = {"f32": "gemm_nt_wide_kernel<1,0,0>", "f16": "gemm_nt_wide_kernel<1,0,1> (fp16 operands, v_mfma_f32_32x32x16_f16)",
-                "bf16x3": "gemm_nt_kernel<1,0,1,0,1,2> (split-bf16 operands, 128-row kernel)"}.get(self.f16, "gemm_nt")
+                "bf16x3": "gemm_nt_wide3_kernel<1,0,2,4,0> (split-bf16 operands, 256 x 256 tiles, v_mfma_f32_32x32x16_bf16 x 6 per k-step)"}.get(self.f16, "gemm_nt")
         return {"bound": "mfma", "kernel": "%s at D.fc2.0 (N=%d K=%d, BN+LeakyReLU prologue, column-statistics + max-pool epilogue, output not stored): "
                                            "per step one launch over the three D-step passes (M=%d) and one for the G step (M=%d)"
                                            % (ksym, DOMINANT["N"], DOMINANT["K"], 3 * self.M, self.M),
-                "achieved": round(achieved, 2), "peak": self.peak, "unit": "TFLOP/s", "frac": round(achieved / self.peak, 4),
+                "achieved": round(achieved, 2), "peak": round(self.peak, 1), "unit": "TFLOP/s", "frac": round(achieved / self.peak, 4),
+                **({"peak_derivation": SPLIT_BF16_PEAK_NOTE, "achieved_note": "fp32-equivalent FLOPs (2*M*N*K) per second; the bf16 pipe issues 6x as many"} if self.f16 == "bf16x3" else {}),
                 "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches_timed": len(dom), "per_shape": per_shape,
                 "traffic": None if t1 is None else int(t1 * rows_avg / self.M),
                 "traffic_note": ("HBM bytes per launch: measured for the one-pass launch (M=%d) in separate rocprofv3 --pmc passes (profiles/%s: %s B "
@@ -673,7 +682,7 @@ def main():
         dt_, t_issue_ = time_steps(tr_, step_, args.steps, dist_on, dev)
         return G_, D_, tr_, dt_, t_issue_
 
-    peak = FP32_MATRIX_PEAK_TFLOPS if args.mfma == "f32" else FP16_MATRIX_PEAK_TFLOPS
+    peak = PEAK_OF_MODE[args.mfma]
     acct = MfmaAccounting(PER_GPU_BATCH * N_POINTS, peak, args.mfma) if (rank == 0 and not SELFTEST) else None
     stamps = GraphStamps(acct, dev) if (acct is not None and use_graph and os.environ.get("SPGAN_BENCH_STAMPS", "1") != "0") else None
     contact, dp_seq, wd = None, None, None
@@ -786,14 +795,45 @@ def main():
                            "spgan.CapturedBody (hipGraph replay of the caller's own loop body); 10 steps each after warm-up"}
         del G3, D3, body, st3
 
+    split = None
+    if not SELFTEST and not args.no_extra_legs and not variant and world == 1 and args.mfma == "f32" and rank == 0:
+        # The SAME step with the split-bf16 products (`--mfma bf16x3`): fresh models (same initialisation), its own captured graph, 20 timed
+        # steps after priming, then the matrix-core accounting of that mode over 4 eager steps.  Reported beside the fp32 headline, not as it.
+        spgan.ops.set_mfma_operands("bf16x3")
+        try:
+            G4, D4 = build_models(dev, variant)
+            tr4 = spgan.TrainStep(G4, D4, gan="wgan", use_gp=True, lambda_gp=10.0, lr_g=1e-4, lr_d=1e-4, distributed=False, graph=use_graph,
+                                  graph_warmup=graph_warmup, reference_schedule=args.reference_schedule)
+            step4 = lambda i: tr4.step(x, real, zs[(2 * i) % 4], zs[(2 * i + 1) % 4], alpha=alpha)
+            for i in range((graph_warmup + 1 if use_graph else 0) + 3):
+                step4(i)
+            n4 = 20
+            dt4s, _ = time_steps(tr4, step4, n4, False, dev)
+            acct4 = MfmaAccounting(PER_GPU_BATCH * N_POINTS, SPLIT_BF16_PEAK_TFLOPS, "bf16x3")
+            busy4 = _KeepBusy(dev)
+            spgan.ops.launch_timer = acct4
+            for i in range(ACCT_STEPS):
+                busy4()
+                tr4._eager_step(x, real, zs[(2 * i) % 4], zs[(2 * i + 1) % 4], alpha=alpha)
+            torch.cuda.synchronize()
+            spgan.ops.launch_timer = None
+            ms4 = dt4s / n4 * 1e3
+            split = {"mfma": "bf16x3", "dtype": DTYPE_OF_MODE["bf16x3"], "ms_per_step": round(ms4, 3), "shapes_per_s": round(PER_GPU_BATCH * n4 / dt4s, 2),
+                     "steps": n4, "hipgraph_replay": bool(use_graph), "roofline": acct4.roofline(None), "mfma_accounting": acct4.summary(ACCT_STEPS, ms4),
+                     "note": "`python bench.py --mfma bf16x3` in this process: same models, inputs and schedule; every large gemm_nt product on the bf16 "
+                             "matrix pipe with exactly split operands (csrc/gemm_wide3.hip); not the headline (`value` above is the fp32-operand step)"}
+            del tr4, G4, D4
+        finally:
+            spgan.ops.launch_timer = None
+            spgan.ops.set_mfma_operands(args.mfma)
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         shapes_s = PER_GPU_BATCH * world * args.steps / dt
         line = {
             "metric": "G+D train-step shapes/sec @%d pts, bs=%d per GPU (WGAN-GP)" % (N_POINTS, PER_GPU_BATCH), "value": round(shapes_s, 2), "unit": "shapes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate/epilogues/weight-gradients",
-                                                                                  "bf16x3": "f32 operands split into 3 bf16 terms (6 bf16 MFMA cross products, f32 accumulate); weight gradients f32 MFMA"}[args.mfma],
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_OF_MODE[args.mfma],
             "data": "synthetic",
             "config": {"workload": "%s: Chair-shaped synthetic clouds, %d pts, per-GPU batch %d, WGAN + gradient penalty (lambda 10), "
                                    "1 D-step + 1 G-step, Adam(1e-4, (0.5,0.99)), k=10; one latent per shape (default noise_generator) handed over un-tiled [b,1,128]"
@@ -839,6 +879,8 @@ def main():
             line["drop_in_caller"] = drop_in
         if literal is not None:
             line["literal_loop"] = literal
+        if split is not None:
+            line["split_bf16"] = split
         if world == 1 and not args.no_cpu_baseline and not SELFTEST:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(shapes_s / line["cpu_baseline"]["value"], 1)

@@ -234,7 +234,10 @@ typedef struct spgan_gemm_tn_args {
   /* 1: both operands are rounded to bfloat16 (after the fp32 prologues) when they are staged into LDS and multiplied on the bf16
    * matrix pipe, fp32 accumulation / partials / reduction (BASELINE configs[4]; bf16 rather than fp16: per-point gradients of
    * magnitude 1e-8 must not flush).  Honoured for 16-byte aligned operands with Na, Nb, lda, ldb multiples of 4 outside the
-   * skinny (Na or Nb <= 4) path; ignored otherwise.  Default 0: exact fp32 products. */
+   * skinny (Na or Nb <= 4) path; ignored otherwise.  Default 0: exact fp32 products.
+   * 2: every fp32 operand value split exactly into three bfloat16 terms, the six leading cross products on the bf16 matrix pipe, fp32
+   * accumulation -- fp32-equivalent products (dropped terms <= 2^-26 relative), as spgan_gemm_nt_args.mfma_f16 == 2; same conditions
+   * (fp32-stored operands only). */
   int mfma_lp;
   /* A2 != NULL (needs a_scale, a_shift; not with a_sp_val): a = A*a_scale[c] + A2*a_scale2[c] + a_shift[c] -- the same two-tensor
    * operand as spgan_gemm_nt_args.A2, on the A side of the weight-gradient product. */

@@ -722,7 +722,9 @@ def gemm_dual_ok(dy, W: Tensor, y_ref: Tensor, edge=None) -> bool:
     """True when gemm_dual takes this layer backward (csrc/gemm_dual.hip: fp32 operands, (columns of dy, input channels) = (128, 64),
     (256, 128) or (256, 256), M % 32 == 0, M >= 8192, per-edge operand with k = 10 at (128, 64) only); otherwise the caller issues
     gemm_tn + gemm_nt_bnbwd."""
-    if _MFMA_F16[0] != 0 or _NT_TILE_HINT[0] != 0 or not GEMM_DUAL[0]:
+    # ("bf16x3" keeps this route: the split mode emulates exact fp32 products, so a layer whose two products leave ONE exact-fp32 launch is
+    #  inside its contract; the "f16" mode rounds operands and has its own 16-bit routes)
+    if _MFMA_F16[0] == 1 or _NT_TILE_HINT[0] != 0 or not GEMM_DUAL[0]:
         return False
     a2 = dy if isinstance(dy, Affine2) else None
     g = a2.g if a2 is not None else (dy.x if isinstance(dy, ActOperand) else dy)
@@ -978,6 +980,10 @@ def storage16(E: int, F_: int, k: int) -> bool:
     return STORAGE16[0] and _MFMA_F16[0] == 1 and k == 10 and F_ % 8 == 0 and F_ > 64 and E >= max(STORAGE16_MIN_EDGES[0], k * TN_LP_MIN_ROWS)    # F/2 > 32 columns: the fp16 128-row kernels; E/k points: conv_out's bf16 weight-gradient kernel
 
 
+# "bf16x3" operand mode: the weight gradients on the split-bf16 kernel (spgan_gemm_tn_args.mfma_lp == 2) instead of the exact-fp32 MFMA kernel.
+# Off: measured on MI355X (profiles/r06_mfma_shapes_bf16x3_tn_split.txt) the kernel transposes AND splits both operands in registers (176 VALU
+# per 48 MFMAs) and lands at the fp32 kernel's rate (65536 x 256 x 256: 97 vs 103 us; 128 x 1280: 236 vs 229; 320 x 64: 78 vs 55).  Kept for its tests.
+TN_SPLIT_BF16 = [False]
 TN_LP_MIN_ROWS = 8192     # "f16" operand mode: weight gradients reduce over >= this many points/edges on the bf16 matrix pipe
 
 
@@ -1054,7 +1060,9 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     defer = bool(defer) and sa is None
     a.defer_reduce = 1 if defer else 0
     a.mfma_lp = 1 if (_MFMA_F16[0] == 1 and not exact and M_ >= TN_LP_MIN_ROWS) else 0
-    if (b_half or a16) and not a.mfma_lp:
+    if _MFMA_F16[0] == 2 and TN_SPLIT_BF16[0] and not exact and M_ >= TN_LP_MIN_ROWS:
+        a.mfma_lp = 2                   # split-bf16 weight gradient (off by default, see TN_SPLIT_BF16)
+    if (b_half or a16) and a.mfma_lp != 1:
         raise ValueError("16-bit stored operands need the bf16 weight-gradient kernel ('f16' operand mode, M >= %d, exact=False)" % TN_LP_MIN_ROWS)
     a.a_half = 1 if a16 else 0
     splits = lib.spgan_gemm_tn_splits(M_, Na, Nb)

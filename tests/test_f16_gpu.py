@@ -604,3 +604,48 @@ def test_split_image_layout(b3):
     planes = img.reshape(K // 16, 3, N, 16).permute(1, 2, 0, 3).reshape(3, N, K)
     assert torch.equal(planes.sum(0), W.double()), "hi + mid + lo != W"
     assert (planes[1].abs() <= planes[0].abs() * 2.0 ** -8 + 1e-300).all() and (planes[2].abs() <= planes[0].abs() * 2.0 ** -16 + 1e-300).all()
+
+
+@pytest.mark.parametrize("M,Na,Nb", [(16384, 256, 256), (65536, 128, 1280), (20480, 128, 64), (9000, 64, 32), (8192, 320, 64), (12288, 132, 36)])
+def test_gemm_tn_bf16x3_is_fp32_equivalent(b3, M, Na, Nb):
+    """Weight gradients in the split-bf16 mode (spgan_gemm_tn_args.mfma_lp == 2): against the float64 product of the SAME fp32 operands the
+    result is as close as the exact-fp32-MFMA one; per-point gradients of magnitude 1e-7 survive; every A-side / B-side operand mode and
+    by-product of the bf16 kernel; short reductions and exact=True keep fp32 operands."""
+    ops = b3
+    ops.TN_SPLIT_BF16[0] = True
+    try:
+        _gemm_tn_bf16x3(ops, M, Na, Nb)
+    finally:
+        ops.TN_SPLIT_BF16[0] = False
+
+
+def _gemm_tn_bf16x3(ops, M, Na, Nb):
+    A, Bm = rnd("t3.A%d.%d" % (M, Na), (M, Na)) * 1e-7, rnd("t3.B%d.%d" % (M, Nb), (M, Nb))
+    sc, sh = rnd("t3.sc%d" % Nb, (Nb,)).abs() + 0.5, rnd("t3.sh%d" % Nb, (Nb,), 0.3)
+
+    def err(x, ref):
+        return ((x.double() - ref).norm() / ref.norm()).item()
+    for pro in (None, (sc, sh, 0.01)):
+        b = Bm if pro is None else torch.where(Bm * sc + sh > 0, Bm * sc + sh, (Bm * sc + sh) * 0.01)
+        ref = A.double().t() @ b.double()
+        got = ops.gemm_tn(A, Bm, pro=pro)
+        e3, e32 = err(got, ref), err(ops.gemm_tn(A, Bm, pro=pro, exact=True), ref)
+        assert e3 <= max(3.0 * e32, 3e-7) and e3 <= 2e-6, (e3, e32)
+        close(got, km.gemm_tn(A, Bm, pro=pro), rtol=2e-5, atol=1e-12, what="vs fp32 model")
+    out = rnd("t3.out%d.%d" % (Na, Nb), (Na, Nb)) * 1e-4
+    close(ops.gemm_tn(A, Bm, out=out.clone(), beta=0.5), (0.5 * out.double() + A.double().t() @ Bm.double()).float(), rtol=2e-6, atol=1e-12, what="beta accumulate")
+    o2, cs = ops.gemm_tn(A, Bm, with_colsum=True)
+    close(o2, (A.double().t() @ Bm.double()).float(), rtol=2e-6, atol=1e-12, what="with_colsum: product")
+    close(cs, A.double().sum(0).float(), rtol=3e-6, atol=1e-10, what="with_colsum: fp32 column sums (the sign of odd splits undone)")
+    if Na % 4 == 0:
+        y = rnd("t3.y%d.%d" % (M, Na), (M, Na)) * 1e-7
+        coef = torch.stack([rnd("t3.p%d" % Na, (Na,)).abs() + 0.5, rnd("t3.q%d" % Na, (Na,), 0.3), rnd("t3.r%d" % Na, (Na,), 1e-8)])
+        lazy = ops.Affine2(A, y, coef)
+        close(ops.gemm_tn(lazy, Bm), (lazy.dense().double().t() @ Bm.double()).float(), rtol=3e-6, atol=1e-12, what="lazy A operand (sign folded into the coefficients)")
+        asc, ash = rnd("t3.asc%d" % Na, (Na,)).abs() + 0.5, rnd("t3.ash%d" % Na, (Na,), 1e-8)
+        a_act = torch.where(A * asc + ash > 0, A * asc + ash, (A * asc + ash) * 0.01)
+        close(ops.gemm_tn(A, Bm, a_pro=(asc, ash, 0.01)), (a_act.double().t() @ Bm.double()).float(), rtol=3e-6, atol=1e-12, what="A-side LeakyReLU (sign by a multiply)")
+    close(ops.gemm_tn(A[:4096], Bm[:4096]), km.gemm_tn(A[:4096], Bm[:4096]), rtol=2e-5, atol=1e-12, what="short reduction stays fp32")
+    big = ops.gemm_tn(A * 1e25, Bm * 1e10)
+    assert torch.isfinite(big).all()
+    close(big, ((A.double() * 1e25).t() @ (Bm.double() * 1e10)).float(), rtol=2e-6, what="large magnitudes")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-shape table of the matrix-core launches of one train step (bench.py's MfmaAccounting with the shape kept): which GEMM
-shapes the step spends its MFMA time on and at what rate.  `python tools/mfma_shapes.py [--mfma f16] > gpurun_out/mfma_shapes.txt`"""
+shapes the step spends its MFMA time on and at what rate.  `python tools/mfma_shapes.py [--mfma f16|bf16x3] > gpurun_out/mfma_shapes.txt`"""
 import os
 import sys
 
@@ -29,15 +29,17 @@ class Shapes(bench.MfmaAccounting):
 
 
 def main():
-    f16 = "--mfma" in sys.argv and sys.argv[sys.argv.index("--mfma") + 1] == "f16"
+    mode = sys.argv[sys.argv.index("--mfma") + 1] if "--mfma" in sys.argv else "f32"      # f32 | f16 | bf16x3
+    f16 = mode == "f16"
     dev = torch.device("cuda", 0)
-    spgan.ops.set_mfma_operands("f16" if f16 else "f32")
+    spgan.ops.set_mfma_operands(mode)
     G, D = bench.build_models(dev)
     tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0, graph=False)
     x, real, zs, alpha = bench.make_inputs(dev, 0, bench.PER_GPU_BATCH)
     for i in range(3):
         tr.step(x, real, zs[0], zs[1], alpha=alpha)
-    acct = Shapes(bench.PER_GPU_BATCH * bench.N_POINTS, bench.FP16_MATRIX_PEAK_TFLOPS if f16 else bench.FP32_MATRIX_PEAK_TFLOPS, f16)
+    peak = {"f32": bench.FP32_MATRIX_PEAK_TFLOPS, "f16": bench.FP16_MATRIX_PEAK_TFLOPS, "bf16x3": bench.FP16_MATRIX_PEAK_TFLOPS / 6.0}[mode]   # bf16x3: six bf16 MFMAs per product
+    acct = Shapes(bench.PER_GPU_BATCH * bench.N_POINTS, peak, f16)
     busy = bench._KeepBusy(dev)
     steps = 4
     spgan.ops.launch_timer = acct
@@ -51,7 +53,7 @@ def main():
         d = agg.setdefault(r[-1], [0, 0.0, 0.0, 0.0])
         d[0] += 1; d[1] += r[3].elapsed_time(r[4]); d[2] += r[1]; d[3] += r[2]
     tot = sum(v[1] for v in agg.values()) / steps
-    print("# matrix-core launches of one WGAN-GP train step (B=32, N=2048, %s operands): %.3f ms/step in %d launches" % ("f16" if f16 else "f32", tot, len(acct.rec) // steps))
+    print("# matrix-core launches of one WGAN-GP train step (B=32, N=2048, %s operands; util = of %.1f TFLOP/s): %.3f ms/step in %d launches" % (mode, peak, tot, len(acct.rec) // steps))
     print("%-4s %8s %6s %6s  %-22s %5s %9s %9s %8s %7s" % ("kind", "M", "N/Na", "K/Nb", "flavour", "n/st", "avg_us", "us/step", "TF(use)", "util"))
     for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         n = v[0] / steps
