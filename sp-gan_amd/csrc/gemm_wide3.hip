@@ -100,10 +100,16 @@ __global__ __launch_bounds__((X3<WGM, WGN>::THREADS), 2) void gemm_nt_wide3_kern
   float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
   int4 spa = make_int4(-1, -1, -1, -1);
   float4 spv = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int lrow = tid >> 2, lc4 = (tid & 3) * 4;  // staging slot: row lrow + RPP*i, k offset lc4
+  // Staging slots.  A thread stages, per operand and k-tile, one float4 (k offset lc4) of SLOTS rows.  Slot i of thread row-index lrow = tid / 4
+  // takes tile row  slot_row(i) + 64 * (lrow / 32) + lrow % 32:  32-row tile 2*(lrow/32 + (RPP/32)*(i/2)) + (i & 1) -- every ODD slot stages rows of
+  // an odd 32-row tile, every even slot rows of an even one (what the sign checkerboard below keys on: a compile-time property of the slot).
+  const int lrow = tid >> 2, lc4 = (tid & 3) * 4;
+  const int lrow2 = 64 * (lrow >> 5) + (lrow & 31);
+  auto slot_row = [](int i) { return 32 * (i & 1) + 2 * RPP * (i >> 1); };
+  static_assert(AS % 2 == 0 && (BPRE || BS % 2 == 0), "slots come in (even tile, odd tile) pairs");
   // 32-bit element offsets (host: M*lda, N*ldw < 2^32): scalar base + 32-bit offset addressing
-  const unsigned oa = (unsigned)(m0 + lrow) * (unsigned)p.lda + (unsigned)lc4, sa = (unsigned)RPP * (unsigned)p.lda;
-  const unsigned ow = (unsigned)(n0 + lrow) * (unsigned)p.ldw + (unsigned)lc4, sw = (unsigned)RPP * (unsigned)p.ldw;
+  const unsigned oa = (unsigned)(m0 + lrow2) * (unsigned)p.lda + (unsigned)lc4, sa = (unsigned)p.lda;
+  const unsigned ow = (unsigned)(n0 + lrow2) * (unsigned)p.ldw + (unsigned)lc4, sw = (unsigned)p.ldw;
   const int sp_b = sparse ? m0 / p.sp_rows : 0;  // the whole tile lies in one shape (host: sp_rows % 256 == 0)
   const float* pPsc = p_.p_scale;
   const float* pPsh = p_.p_shift;
@@ -114,15 +120,15 @@ __global__ __launch_bounds__((X3<WGM, WGN>::THREADS), 2) void gemm_nt_wide3_kern
     }
   }
   // LDS word offset of this thread's 8-byte staging slot inside a plane (row lrow; RPP is a multiple of 16, so bit 3 of the row is the same for every slot)
-  const int st_off = lrow * PLW + 4 * ((lc4 >> 3) ^ ((lrow >> 3) & 1)) + ((lc4 >> 2) & 1) * 2;
+  const int st_off = lrow2 * PLW + 4 * ((lc4 >> 3) ^ ((lrow >> 3) & 1)) + ((lc4 >> 2) & 1) * 2;      // (slot_row(i) is a multiple of 16: bit 3 of the row is lrow's)
 
   // ---- staging, one float4 slot at a time ("piece"): global load -> (one k-tile later) prologue transform + split + three 8-byte LDS stores
-  auto load_a = [&](int i, int k0) { ra[i] = *reinterpret_cast<const float4*>(p.A + (oa + (unsigned)i * sa + (unsigned)k0)); };
+  auto load_a = [&](int i, int k0) { ra[i] = *reinterpret_cast<const float4*>(p.A + (oa + (unsigned)slot_row(i) * sa + (unsigned)k0)); };
   const float4* wimg = reinterpret_cast<const float4*>(p_.w_image) + (size_t)n0 * 2 + tid;      // 16-byte units: [k-tile][plane][N][2]
   const unsigned img_plane = (unsigned)p.N * 2u, img_ktile = 3u * img_plane;
   auto load_b = [&](int i, int k0) {
     if (BPRE) rb[i] = wimg[(unsigned)(k0 / XK) * img_ktile + (unsigned)(i / SPP) * img_plane + (unsigned)((i % SPP) * X::THREADS)];
-    else rb[i] = *reinterpret_cast<const float4*>(p.W + (ow + (unsigned)i * sw + (unsigned)k0));
+    else rb[i] = *reinterpret_cast<const float4*>(p.W + (ow + (unsigned)slot_row(i) * sw + (unsigned)k0));
   };
   auto load_pro = [&](int k0) {
     if (affine) {
@@ -144,11 +150,7 @@ __global__ __launch_bounds__((X3<WGM, WGN>::THREADS), 2) void gemm_nt_wide3_kern
   // and weight gradients SUM 10^5 of these outputs and the bias does not average out.  Rows (of A and of W) whose 32-row tile index is odd are
   // staged NEGATED (exact: the split of -v is minus the split of v), so accumulator tile (i, j) holds (-1)^(i+j) times its block and is negated
   // back in front of the epilogue: the bias alternates in sign from tile to tile, along the rows and along the columns, and cancels in sums.
-  const uint32_t sgn = ((uint32_t)(lrow >> 5) & 1u) << 31;   // RPP is a multiple of 64: the same for every slot of this thread, for A and for W
-  auto flip4 = [&](float4& v) {
-    v.x = __uint_as_float(__float_as_uint(v.x) ^ sgn); v.y = __uint_as_float(__float_as_uint(v.y) ^ sgn);
-    v.z = __uint_as_float(__float_as_uint(v.z) ^ sgn); v.w = __uint_as_float(__float_as_uint(v.w) ^ sgn);
-  };
+  auto neg4 = [](float4& v) { v = make_float4(-v.x, -v.y, -v.z, -v.w); };      // odd slots = rows of odd 32-row tiles (slot_row): a compile-time property
   auto piece_a = [&](int i, int buf) {
     float4 v = ra[i];
     if (affine) {
@@ -156,20 +158,20 @@ __global__ __launch_bounds__((X3<WGM, WGN>::THREADS), 2) void gemm_nt_wide3_kern
       v.x = fmaxf(v.x, v.x * sl); v.y = fmaxf(v.y, v.y * sl); v.z = fmaxf(v.z, v.z * sl); v.w = fmaxf(v.w, v.w * sl);
     }
     if (sparse) {
-      const int m = m0 + lrow + RPP * i;
+      const int m = m0 + lrow2 + slot_row(i);
       v.x += (spa.x == m) ? spv.x : 0.f;
       v.y += (spa.y == m) ? spv.y : 0.f;
       v.z += (spa.z == m) ? spv.z : 0.f;
       v.w += (spa.w == m) ? spv.w : 0.f;
     }
-    flip4(v);
-    st_split4(smem3 + buf * X::BUF + st_off + i * RPP * PLW, X::PLANE_A, v);
+    if (i & 1) neg4(v);
+    st_split4(smem3 + buf * X::BUF + st_off + slot_row(i) * PLW, X::PLANE_A, v);
   };
   auto piece_b = [&](int i, int buf) {
     float4 v = rb[i];
     if (BPRE) *reinterpret_cast<float4*>(smem3 + buf * X::BUF + 3 * X::PLANE_A + (i / SPP) * X::PLANE_B + ((i % SPP) * X::THREADS + tid) * 4) = v;   // (the image holds the signs)
-    else flip4(v);
-    if (!BPRE) st_split4(smem3 + buf * X::BUF + 3 * X::PLANE_A + st_off + i * RPP * PLW, X::PLANE_B, v);
+    else if (i & 1) neg4(v);
+    if (!BPRE) st_split4(smem3 + buf * X::BUF + 3 * X::PLANE_A + st_off + slot_row(i) * PLW, X::PLANE_B, v);
   };
 
   // ---- fragments: lane (l31, lh) reads the 16 bytes (row, k-half lh) of each plane; rows 32*i further have the same bit 3
