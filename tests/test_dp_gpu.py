@@ -143,3 +143,55 @@ def test_two_rank_step_on_hip_kernels_equals_single_process_on_concatenated_batc
                 assert torch.equal(v, ref[r][which][k]), (r, which, k)
     # and the shards really differ: each rank keeps the statistics of its own shard
     assert (ranks[0]["bufD"]["mlps.1.running_mean"] - ranks[1]["bufD"]["mlps.1.running_mean"]).abs().max().item() > 1e-6
+
+
+def _route_worker(rank, world, port, out):
+    """One data-parallel step at a size where the single-process step would take both of round 5's single-process routes (per-shape latents
+    handed over un-tiled: Generator.forward_pair; M >= 8192 rows per pass: the joint D-step node) -- counts which of them ran."""
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import spgan
+    from spgan import _lib, fixture_rng as fr
+    _lib.load()
+    torch.cuda.set_device(0)
+    assert spgan.init_process_group_from_env("gloo") == rank
+    n, b = 2048, 4
+    class O2(O):
+        np = n
+    from oracle import spgan_oracle as orc
+    G, D = spgan.Generator(O2), spgan.Discriminator(O2)
+    G.load_state_dict({**G.state_dict(), **fr.init_params(orc.generator_shapes(), salt=100)})
+    D.load_state_dict({**D.state_dict(), **fr.init_params(orc.discriminator_shapes(), salt=100)})
+    G, D = G.cuda(), D.cuda()
+    calls = dict(pair=0, joint=0)
+    pair0, joint0 = spgan.Generator.forward_pair, spgan.Discriminator.stacks_joint
+    def pair(self, *a, **k):
+        calls["pair"] += 1
+        return pair0(self, *a, **k)
+    def joint(self, *a, **k):
+        calls["joint"] += 1
+        return joint0(self, *a, **k)
+    spgan.Generator.forward_pair, spgan.Discriminator.stacks_joint = pair, joint
+    res = {}
+    for distributed in (True, False):
+        calls.update(pair=0, joint=0)
+        tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, distributed=distributed)
+        x = fr.sphere_template(n)[None].repeat(b, 1, 1).cuda()
+        z = lambda seed: fr.latent(b, n, seed=seed + rank)[:, :1].contiguous().cuda()       # one latent per shape, un-tiled [b,1,nz]
+        tr.step(x, fr.synthetic_real(b, n, seed=70 + rank).cuda(), z(80), z(90), alpha=fr.uniform("dpr.alpha.%d" % rank, (b, 1, 1), 0.0, 1.0).cuda())
+        torch.cuda.synchronize()
+        res[distributed] = dict(calls)
+    torch.save(res, os.path.join(out, "routes%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_keeps_the_joint_d_node_and_never_pairs_the_generator_forwards(tmp_path):
+    """Round-5 review item 8: `distributed=True` must not take Generator.forward_pair (the G step's forward is where D's all-reduce hides) and
+    still takes the joint D-step node (Discriminator.stacks_joint: a single-rank route below the all-reduce) -- asserted by counting the calls
+    of one real data-parallel step per rank next to a single-process step of the same TrainStep arguments in the same process."""
+    mp.spawn(_route_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(tmp_path / ("routes%d.pt" % r))
+        assert res[True]["pair"] == 0 and res[True]["joint"] >= 1, res
+        assert res[False]["pair"] == 1 and res[False]["joint"] >= 1, res            # the control: without DP both routes run at this size
