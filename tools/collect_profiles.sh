@@ -29,6 +29,19 @@ for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/g_$c; rocprofv3 --pmc $c --kernel
 python $R/tools/pmc_gemm_json.py $O/${TAG}_pmc_gemm_FETCH_SIZE.txt $O/${TAG}_pmc_gemm_WRITE_SIZE.txt ${TAG} > $O/${TAG}_pmc_gemm_nt.json
 python $R/tools/mfma_shapes.py > $O/${TAG}_mfma_shapes.txt 2>/dev/null
 python $R/tools/mfma_shapes.py --mfma f16 > $O/${TAG}_mfma_shapes_f16.txt 2>/dev/null
+python $R/tools/mfma_shapes.py --mfma bf16x3 > $O/${TAG}_mfma_shapes_bf16x3.txt 2>/dev/null
+# split-bf16 gemm_nt on 256-row tiles (csrc/gemm_wide3.hip): microbench against the other routes, K sweep (slope / intercept), kernel-only
+# durations, SQ counters, operand-data (power) probe, accuracy / bias probe, arg-max flip probe
+(cd /tmp && python $R/tools/nt3_bench.py) > $O/${TAG}_nt3_bench.txt 2>/dev/null
+python $R/tools/nt3_ksweep.py > $O/${TAG}_nt3_ksweep.txt 2>/dev/null
+bash $R/tools/nt3_trace.sh > $O/${TAG}_nt3_trace.txt 2>/dev/null
+bash $R/tools/nt3_pmc.sh > $O/${TAG}_nt3_pmc.txt 2>/dev/null
+python $R/tools/exp/nt3_power_probe.py > $O/${TAG}_nt3_power_probe.txt 2>/dev/null
+python $R/tools/exp/nt3_accuracy_probe.py > $O/${TAG}_nt3_accuracy_probe.txt 2>/dev/null
+python $R/tools/exp/argmax_flip_probe.py > $O/${TAG}_argmax_flip_probe.txt 2>/dev/null
+rm -rf /tmp/prof_b3; rocprofv3 --kernel-trace --stats -d /tmp/prof_b3 -o r -- python $R/bench.py --mfma bf16x3 --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/bench_b3.log 2>&1
+python $R/tools/rocprof_summary.py $(find /tmp/prof_b3 -name "*.db" | head -1) 31 > $O/${TAG}_bench_bf16x3_kernel_stats.txt
+python $R/tools/step_sequence.py $(find /tmp/prof_b3 -name "*.db" | head -1) -8 > $O/${TAG}_step_sequence_bf16x3.txt
 (python $R/tools/knn_ab.py 2048 32; python $R/tools/knn_ab.py 4096 16) > $O/${TAG}_knn_ab.txt 2>&1
 python $R/tools/dual_bench.py > $O/${TAG}_dual_bench.txt 2>/dev/null
 rm -rf /tmp/prof_c4; rocprofv3 --kernel-trace --stats -d /tmp/prof_c4 -o r -- python $R/bench.py --config c4 --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/bench_c4.log 2>&1
