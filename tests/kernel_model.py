@@ -862,3 +862,22 @@ def multi_addn(dsts, srcs_per_dst):
     for d, ss in zip(dsts, srcs_per_dst):
         for s in ss:
             d.add_(s.reshape(d.shape))
+
+
+def split_image(W, out=None):
+    """ops.split_image: the split-bf16 image of W [N,K] (spgan_split_bf16x3_image): hi + mid + lo = W exactly (round to nearest at each level),
+    laid out [K/16][plane][N][16 bf16], the two 16-byte halves of a row swapped where bit 3 of n is set, rows with bit 5 of n set negated."""
+    N, K = W.shape
+    assert N % 128 == 0 and K % 16 == 0
+    hi = W.bfloat16(); r1 = W - hi.float()
+    mid = r1.bfloat16(); r2 = r1 - mid.float()
+    planes = torch.stack([hi, mid, r2.bfloat16()])                                   # [3, N, K]
+    n = torch.arange(N, device=W.device)
+    planes = torch.where(((n >> 5) & 1).bool()[None, :, None], -planes, planes)
+    img = planes.view(3, N, K // 16, 2, 8).permute(2, 0, 1, 3, 4)                    # [K/16, 3, N, 2, 8]
+    img = torch.where(((n >> 3) & 1).bool()[None, None, :, None, None], img.flip(3), img).contiguous()
+    res = img.view(torch.uint8).reshape(-1)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res

@@ -603,6 +603,7 @@ def test_split_image_layout(b3):
     img = torch.where(((n >> 5) & 1).bool()[None, None, :, None, None], -img, img)       # ... and the sign checkerboard (odd 32-row tiles are stored negated)
     planes = img.reshape(K // 16, 3, N, 16).permute(1, 2, 0, 3).reshape(3, N, K)
     assert torch.equal(planes.sum(0), W.double()), "hi + mid + lo != W"
+    assert torch.equal(ops.split_image(W), km.split_image(W)), "image differs from its model (tests/kernel_model.py::split_image)"
     assert (planes[1].abs() <= planes[0].abs() * 2.0 ** -8 + 1e-300).all() and (planes[2].abs() <= planes[0].abs() * 2.0 ** -16 + 1e-300).all()
 
 
