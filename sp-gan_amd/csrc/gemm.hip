@@ -1272,6 +1272,7 @@ int launch_nt(const spgan_gemm_nt_args& a, hipStream_t s) {
     }
   }
   if constexpr (AMODE != SPGAN_A_EDGE && AMODE != A_AFFINE2 && EPI != SPGAN_EPI_EDGE_BNBWD) {
+    if (spgan_nt_wide16_selected(a)) return spgan_launch_nt_wide16(a, s);  // fp16 operands, large aligned products: row-pipelined 256-row tiles (gemm_wide16.hip)
     if (spgan_nt_wide_selected(a)) return spgan_launch_nt_wide(a, s);  // large aligned products: 256 x 256 tiles (gemm_wide.hip)
     if (spgan_nt_wide3_selected(a)) return spgan_launch_nt_wide3(a, s);  // ... with split-bf16 operands: 256-row tiles (gemm_wide3.hip)
   }
@@ -2148,6 +2149,7 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
 
 // N-tile width launch_nt picks for this problem (must mirror launch_nt)
 static int nt_tile_n(const spgan_gemm_nt_args& a) {
+  if (a.a_mode != SPGAN_A_EDGE && !a.A2 && a.epi_mode != SPGAN_EPI_EDGE_BNBWD && spgan_nt_wide16_selected(a)) return spgan_nt_wide16_tile_n(a);
   if (spgan_nt_wide_selected(a)) return 256;
   if (a.a_mode != SPGAN_A_EDGE && !a.A2 && a.epi_mode != SPGAN_EPI_EDGE_BNBWD && spgan_nt_wide3_selected(a)) return spgan_nt_wide3_tile_n(a);
   const bool fast = (a.K % 4 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) && al16(a.A) && al16(a.W);

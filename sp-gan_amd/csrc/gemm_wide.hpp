@@ -18,3 +18,10 @@ int spgan_nt_wide3_tile_n(const spgan_gemm_nt_args& a);     // 256 or 128: the t
 // tile_hint 1 -> never, 2 -> when eligible, 0 -> when eligible and large enough; SPGAN_NT_WIDE3=0 (read once) turns the kernel off
 bool spgan_nt_wide3_selected(const spgan_gemm_nt_args& a);
 int spgan_launch_nt_wide3(const spgan_gemm_nt_args& a, hipStream_t s);
+
+// fp16 operands (mfma_f16 == 1) on 256-row tiles in the row-pipelined form (gemm_wide16.hip): 256 x 256 or 256 x 128 tiles; preferred over
+// gemm_wide.hip's fp16 instantiation where eligible (K % 64 == 0, N % 128 == 0); SPGAN_NT_WIDE16=0 (read once) turns it off.
+bool spgan_nt_wide16_eligible(const spgan_gemm_nt_args& a);
+int spgan_nt_wide16_tile_n(const spgan_gemm_nt_args& a);
+bool spgan_nt_wide16_selected(const spgan_gemm_nt_args& a);
+int spgan_launch_nt_wide16(const spgan_gemm_nt_args& a, hipStream_t s);

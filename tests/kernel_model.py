@@ -869,11 +869,11 @@ def split_image(W, out=None):
     laid out [K/16][plane][N][16 bf16], the two 16-byte halves of a row swapped where bit 3 of n is set, rows with bit 5 of n set negated."""
     N, K = W.shape
     assert N % 128 == 0 and K % 16 == 0
+    n = torch.arange(N, device=W.device)
+    W = torch.where(((n >> 5) & 1).bool()[:, None], -W, W)                           # negated BEFORE the split, like the kernel (an exact-zero residual keeps +0)
     hi = W.bfloat16(); r1 = W - hi.float()
     mid = r1.bfloat16(); r2 = r1 - mid.float()
     planes = torch.stack([hi, mid, r2.bfloat16()])                                   # [3, N, K]
-    n = torch.arange(N, device=W.device)
-    planes = torch.where(((n >> 5) & 1).bool()[None, :, None], -planes, planes)
     img = planes.view(3, N, K // 16, 2, 8).permute(2, 0, 1, 3, 4)                    # [K/16, 3, N, 2, 8]
     img = torch.where(((n >> 3) & 1).bool()[None, None, :, None, None], img.flip(3), img).contiguous()
     res = img.view(torch.uint8).reshape(-1)
