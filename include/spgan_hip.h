@@ -236,8 +236,10 @@ typedef struct spgan_gemm_tn_args {
    * magnitude 1e-8 must not flush).  Honoured for 16-byte aligned operands with Na, Nb, lda, ldb multiples of 4 outside the
    * skinny (Na or Nb <= 4) path; ignored otherwise.  Default 0: exact fp32 products.
    * 2: every fp32 operand value split exactly into three bfloat16 terms, the six leading cross products on the bf16 matrix pipe, fp32
-   * accumulation -- fp32-equivalent products (dropped terms <= 2^-26 relative), as spgan_gemm_nt_args.mfma_f16 == 2; same conditions
-   * (fp32-stored operands only). */
+   * accumulation -- fp32-equivalent products (dropped terms <= 2^-26 relative), as spgan_gemm_nt_args.mfma_f16 == 2.  Honoured where the output
+   * tiles as 256 x 256, 256 x 128 or 128 x 256 (Na, Nb multiples of 128, not both odd multiples), M % 32 == 0, fp32-stored operands, b_mode PLAIN /
+   * AFFINE_LRELU with slopes in [0, 1]: csrc/gemm_tn_wide3.hip, with its own split plan (spgan_gemm_tn_splits_lp / _ws_bytes_lp below); every
+   * other problem runs the exact fp32 kernel on that plan. */
   int mfma_lp;
   /* A2 != NULL (needs a_scale, a_shift; not with a_sp_val): a = A*a_scale[c] + A2*a_scale2[c] + a_shift[c] -- the same two-tensor
    * operand as spgan_gemm_nt_args.A2, on the A side of the weight-gradient product. */
@@ -273,6 +275,10 @@ int spgan_colstats_finalize_phaseb(const float* partials, int tiles, int C, int 
 int spgan_bn_bwd_coeffs(const float* sums, const float* mean, const float* invstd, const float* gamma, int C, float count, float* coef, spgan_stream_t s);
 
 size_t spgan_gemm_tn_ws_bytes(int M, int Na, int Nb);
+/* The same, and the number of split partials, for a launch with spgan_gemm_tn_args.mfma_lp = mfma_lp: the split-bf16 kernel (mfma_lp == 2) works
+ * on larger output tiles and has its own split plan; for mfma_lp 0 / 1 these equal spgan_gemm_tn_ws_bytes / spgan_gemm_tn_splits. */
+size_t spgan_gemm_tn_ws_bytes_lp(int M, int Na, int Nb, int mfma_lp);
+int spgan_gemm_tn_splits_lp(int M, int Na, int Nb, int mfma_lp);
 int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s);
 /* `count` (<= 4) streaming products with a narrow B (Nb <= 4: the weight gradient of D's first conv against the three input coordinates) of ONE
  * shape as one launch, partials only (defer_reduce != 0 required; summed by spgan_splitk_reduce_multi): real / fake / double-backward pass of a

@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "gemm_wide.hpp"
+#include "gemm_tn_wide3.hpp"
 #include "sparse_rows.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1542,21 +1543,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const spgan_gemm_tn_args p
 // that block in registers and writes RP packed values per column: the LDS tiles are [column][32 m-values as bf16] with a row
 // stride of 20 words (16-byte aligned rows; 16 consecutive rows land on 16 distinct 4-bank groups: conflict-free b128 reads).
 // Same split plan, workspace layout, epilogue and reduction as gemm_tn_kernel.  Aligned operands only (the FAST path).
-// PL = 3 (spgan_gemm_tn_args.mfma_lp == 2, "bf16x3"): every fp32 operand value is split exactly into three bfloat16 terms (as in gemm_nt's
-// split mode, above) and the six leading cross products are evaluated: the fp32-equivalent weight gradient on the bf16 matrix pipe.  The LDS
-// tile holds the three planes of each operand ONCE (single-buffered: 60 KB, so that two workgroups share a CU and one's staging runs under
-// the other's MFMAs); the bf16 MFMA's accumulation bias (toward -infinity, see gemm_wide3.hip) alternates in sign from split to split: odd
-// splits stage the A operand negated and negate their partial tile before they store it, so the bias cancels in the split sum.
 constexpr int LDH = 20;  // words per LDS row: 32 bf16 = 16 words + 4 of padding
-template <int BMODE, int CFG, int PL = 1>
+template <int BMODE, int CFG>
 __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_args p, int rows_per_split) {
   using G = Geo<CFG>;
   constexpr int TI = G::TI, TJ = G::TJ;
   constexpr int TB = G::WGN * TJ * 32;
-  constexpr int NBUF = PL == 3 ? 1 : 2;
-  __shared__ __attribute__((aligned(16))) float smem[NBUF * PL * (TA + TB) * LDH];
-  float* As = smem;                           // [NBUF][PL][TA*LDH]
-  float* Bs = smem + NBUF * PL * TA * LDH;    // [NBUF][PL][TB*LDH]
+  __shared__ __attribute__((aligned(16))) float smem[2 * (TA + TB) * LDH];
+  float* As = smem;                 // [2][TA*LDH]
+  float* Bs = smem + 2 * TA * LDH;  // [2][TB*LDH]
 
   const int tilesB = (p.Nb + TB - 1) / TB;
   const int ta = blockIdx.x / tilesB, tb = blockIdx.x % tilesB;
@@ -1598,14 +1593,6 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
     asc = *reinterpret_cast<const float4*>(p.a_scale + a0 + ac);
     ash = *reinterpret_cast<const float4*>(p.a_shift + a0 + ac);
     if (a2) asc2 = *reinterpret_cast<const float4*>(p.a_scale2 + a0 + ac);
-  }
-  // PL = 3: the sign of this split's A operand: folded into the coefficient vectors where the A-side map is linear, a multiply otherwise
-  const float ssgn = (PL == 3 && (split & 1)) ? -1.f : 1.f;
-  const bool sgn_folded = PL == 3 && apro && (a2 || !p.a_lrelu);
-  if (sgn_folded) {
-    asc.x *= ssgn; asc.y *= ssgn; asc.z *= ssgn; asc.w *= ssgn;
-    ash.x *= ssgn; ash.y *= ssgn; ash.z *= ssgn; ash.w *= ssgn;
-    asc2.x *= ssgn; asc2.y *= ssgn; asc2.z *= ssgn; asc2.w *= ssgn;
   }
   float4 ra2[4];
   const bool a16 = p.a_half != 0;                          // A lies in memory as bfloat16, A2 (when given) as fp16: the EdgeBlock's 16-bit lazy operand
@@ -1670,23 +1657,12 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
         v.w = fmaf(v.w, asc.w, fmaf(ra2[i].w, asc2.w, ash.w));
       } else if (apro && ok) v = affine_lrelu4(v, asc, ash, p.a_lrelu ? p.a_slope : 1.0f);
       if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (PL == 3 && !sgn_folded) { v.x *= ssgn; v.y *= ssgn; v.z *= ssgn; v.w *= ssgn; }
-      if (acs) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }      // (PL = 3: signed like the operand; undone where the sums are stored)
+      if (acs) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
       va[i][0] = v.x; va[i][1] = v.y; va[i][2] = v.z; va[i][3] = v.w;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {  // column ac+q: m-rows ar..ar+3 as 4 bf16 = one 8-byte store (per plane)
+    for (int q = 0; q < 4; ++q) {  // column ac+q: m-rows ar..ar+3 as 4 bf16 = one 8-byte store
       f32x4v f = {va[0][q], va[1][q], va[2][q], va[3][q]};
-      if constexpr (PL == 3) {
-        const bf16x4 hi = __builtin_convertvector(f, bf16x4);
-        const f32x4v r1 = f - __builtin_convertvector(hi, f32x4v);
-        const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
-        const f32x4v r2 = r1 - __builtin_convertvector(mid, f32x4v);
-        __bf16* d = a + (ac + q) * (2 * LDH) + ar;
-        *reinterpret_cast<bf16x4*>(d) = hi;
-        *reinterpret_cast<bf16x4*>(d + TA * 2 * LDH) = mid;
-        *reinterpret_cast<bf16x4*>(d + 2 * TA * 2 * LDH) = __builtin_convertvector(r2, bf16x4);
-      } else
       *reinterpret_cast<bf16x4*>(a + (ac + q) * (2 * LDH) + ar) = __builtin_convertvector(f, bf16x4);
     }
     float vb[RP][4];
@@ -1714,30 +1690,7 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       __bf16* d = b + (bc + q) * (2 * LDH) + br;
-      if constexpr (PL == 3) {
-#pragma unroll
-        for (int i0 = 0; i0 < RP; i0 += (RP >= 4 ? 4 : RP)) {
-          if constexpr (RP >= 4) {
-            f32x4v f = {vb[i0][q], vb[i0 + 1][q], vb[i0 + 2][q], vb[i0 + 3][q]};
-            const bf16x4 hi = __builtin_convertvector(f, bf16x4);
-            const f32x4v r1 = f - __builtin_convertvector(hi, f32x4v);
-            const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
-            const f32x4v r2 = r1 - __builtin_convertvector(mid, f32x4v);
-            *reinterpret_cast<bf16x4*>(d + i0) = hi;
-            *reinterpret_cast<bf16x4*>(d + i0 + TB * 2 * LDH) = mid;
-            *reinterpret_cast<bf16x4*>(d + i0 + 2 * TB * 2 * LDH) = __builtin_convertvector(r2, bf16x4);
-          } else {
-#pragma unroll
-            for (int i = 0; i < RP; ++i) {
-              const float x = vb[i][q];
-              const __bf16 hi = (__bf16)x;
-              const float r1 = x - (float)hi;
-              const __bf16 mid = (__bf16)r1;
-              d[i] = hi; d[i + TB * 2 * LDH] = mid; d[i + 2 * TB * 2 * LDH] = (__bf16)(r1 - (float)mid);
-            }
-          }
-        }
-      } else if constexpr (RP == 4) {
+      if constexpr (RP == 4) {
         f32x4v f = {vb[0][q], vb[1][q], vb[2][q], vb[3][q]};
         *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(f, bf16x4);
       } else {
@@ -1747,62 +1700,7 @@ __global__ __launch_bounds__(256) void gemm_tn_lp_kernel(const spgan_gemm_tn_arg
     }
   };
 
-  if (PL == 3 && mbeg < mend) {
-    // single-buffered: store -> barrier -> (next tile's loads fly) -> 2 k-steps of TI*TJ*6 MFMAs -> barrier
-    gload(mbeg);
-    const __bf16* a = reinterpret_cast<const __bf16*>(As) + (wm * TI * 32 + l31) * (2 * LDH) + 8 * lh;
-    const __bf16* b = reinterpret_cast<const __bf16*>(Bs) + (wn * TJ * 32 + l31) * (2 * LDH) + 8 * lh;
-    for (int mb = mbeg; mb < mend; mb += TKM) {
-      sstore(0, mb);
-      __syncthreads();
-      if (mb + TKM < mend) gload(mb + TKM);
-#pragma unroll
-      for (int kk = 0; kk < TKM / 16; ++kk) {
-        bf16x8 ap[3][TI], bp[3][TJ];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-#pragma unroll
-          for (int i = 0; i < TI; ++i) ap[q][i] = *reinterpret_cast<const bf16x8*>(a + q * TA * 2 * LDH + i * 32 * (2 * LDH) + 16 * kk);
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) bp[q][j] = *reinterpret_cast<const bf16x8*>(b + q * TB * 2 * LDH + j * 32 * (2 * LDH) + 16 * kk);
-        }
-        // the six cross terms, small ones first; the accumulators alternate
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2][i], bp[0][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bp[2][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][i], bp[1][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1][i], bp[0][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bp[1][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bp[0][j], acc[i][j], 0, 0, 0);
-      }
-      __syncthreads();
-    }
-    if (split & 1) {   // undo this split's sign
-      cs = make_float4(-cs.x, -cs.y, -cs.z, -cs.w);
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = -acc[i][j];
-    }
-  }
-  if (PL != 3 && mbeg < mend) {
+  if (mbeg < mend) {
     gload(mbeg);
     sstore(0, mbeg);
     __syncthreads();
@@ -2100,10 +1998,26 @@ inline void launch_reduce(const spgan_gemm_tn_args& a, int splits, hipStream_t s
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, a.ws, splits, a.Na, a.Nb, a.C, a.ldc, a.beta);
 }
 
+// The plan of a launch with operand mode lp: the split-bf16 kernel (lp == 2, gemm_tn_wide3.hip) has larger output tiles, hence its own plan for
+// the shapes it takes (from the shape alone: a problem it then cannot run -- alignment -- runs the plan on the kernels below)
+inline void tn_plan_lp(int M, int Na, int Nb, int lp, int* splits, int* rows) {
+  if (lp == 2 && !tn_skinny(Na, Nb) && spgan_tn_wide3_config(M, Na, Nb)) spgan_tn_wide3_plan(M, Na, Nb, splits, rows);
+  else tn_plan(M, Na, Nb, splits, rows);
+}
+
 template <int BMODE>
 int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
   int splits, rows;
-  tn_plan(a.M, a.Na, a.Nb, &splits, &rows);
+  tn_plan_lp(a.M, a.Na, a.Nb, a.mfma_lp, &splits, &rows);
+  if constexpr (BMODE != SPGAN_A_EDGE) {
+    if (!tn_skinny(a.Na, a.Nb) && spgan_tn_wide3_eligible(a)) {   // split-bf16 operands: the fp32-equivalent product on the bf16 matrix pipe
+      const int rc = spgan_launch_tn_wide3(a, splits, rows, s);
+      if (rc != SPGAN_OK) return rc;
+      if (!a.defer_reduce) launch_reduce(a, splits, s);
+      if (a.a_sp_val) hipLaunchKernelGGL((tn_sparse_rows_kernel<BMODE>), dim3(a.Na), dim3(256), 0, s, a);
+      return spgan_launch_status();
+    }
+  }
   // the streaming kernels: no prologues -- except the two-tensor A operand on the wide side (a lazy BatchNorm-backward tensor against 3 input columns)
   if (BMODE == SPGAN_A_PLAIN && tn_skinny(a.Na, a.Nb) && !a.a_colsum_ws && !a.b_half &&
       (!a.a_scale || (a.A2 && a.Nb <= 4 && !a.a_lrelu && !a.a_sp_val))) {
@@ -2121,11 +2035,7 @@ int launch_tn(const spgan_gemm_tn_args& a, hipStream_t s) {
   const bool fast = (a.Na % 4 == 0) && (a.Nb % 4 == 0) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && al16(a.A) && al16(a.B) &&
                     (!a.A2 || (al16(a.A2) && a.lda2 % 4 == 0));
   if ((a.b_half || a.a_half) && !fast) return SPGAN_EINVAL;
-  if (fast && a.mfma_lp == 2 && !a.a_half && !a.b_half) {  // split-bf16 operands: the fp32-equivalent product on the bf16 matrix pipe
-    if (TB == 128) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 0, 3>), grid, dim3(256), 0, s, a, rows);
-    else if (TB == 64) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 1, 3>), grid, dim3(256), 0, s, a, rows);
-    else hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 2, 3>), grid, dim3(256), 0, s, a, rows);
-  } else if (fast && a.mfma_lp == 1) {  // bf16 operands (aligned problems only; others keep the fp32 kernel)
+  if (fast && a.mfma_lp == 1) {  // bf16 operands (aligned problems only; others keep the fp32 kernel)
     if (TB == 128) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 0>), grid, dim3(256), 0, s, a, rows);
     else if (TB == 64) hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 1>), grid, dim3(256), 0, s, a, rows);
     else hipLaunchKernelGGL((gemm_tn_lp_kernel<BMODE, 2>), grid, dim3(256), 0, s, a, rows);
@@ -2281,6 +2191,20 @@ extern "C" int spgan_gemm_tn_splits(int M, int Na, int Nb) {
   return splits;
 }
 
+extern "C" size_t spgan_gemm_tn_ws_bytes_lp(int M, int Na, int Nb, int mfma_lp) {
+  if (M <= 0 || Na <= 0 || Nb <= 0) return 0;
+  int splits, rows;
+  tn_plan_lp(M, Na, Nb, mfma_lp, &splits, &rows);
+  return (size_t)splits * Na * Nb * sizeof(float);
+}
+
+extern "C" int spgan_gemm_tn_splits_lp(int M, int Na, int Nb, int mfma_lp) {
+  if (M <= 0 || Na <= 0 || Nb <= 0) return 0;
+  int splits, rows;
+  tn_plan_lp(M, Na, Nb, mfma_lp, &splits, &rows);
+  return splits;
+}
+
 extern "C" int spgan_splitk_reduce_blocks(int splits, int Na, int Nb) {
   if (splits <= 0 || Na <= 0 || Nb <= 0) return 0;
   return reduce_blocks(splits, (long)Na * Nb);
@@ -2322,7 +2246,7 @@ extern "C" int spgan_gemm_tn(const spgan_gemm_tn_args* a, spgan_stream_t s_) {
   SPGAN_CHECK_ARG(a && !(a->defer_reduce && a->a_sp_val));
   SPGAN_CHECK_ARG(a && a->A && a->B && a->C && a->ws && a->M > 0 && a->Na > 0 && a->Nb > 0);
   SPGAN_CHECK_ARG(a->lda >= a->Na && a->ldb >= a->Nb && a->ldc >= a->Nb);
-  SPGAN_CHECK_ARG(a->ws_bytes >= spgan_gemm_tn_ws_bytes(a->M, a->Na, a->Nb));
+  SPGAN_CHECK_ARG(a->ws_bytes >= spgan_gemm_tn_ws_bytes_lp(a->M, a->Na, a->Nb, a->mfma_lp));
   if (a->b_mode != SPGAN_A_PLAIN) SPGAN_CHECK_ARG(a->p_scale && a->p_shift);
   if (a->a_scale) SPGAN_CHECK_ARG(a->a_shift && (!a->a_sp_val || (a->a_sp_arg && a->a_sp_rows > 0 && a->b_mode != SPGAN_A_EDGE)));
   if (a->A2) SPGAN_CHECK_ARG(a->a_scale && a->a_scale2 && !a->a_sp_val && a->lda2 >= a->Na);

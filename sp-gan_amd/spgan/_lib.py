@@ -185,6 +185,8 @@ SIGNATURES = {
     "spgan_pool_finalize": (I, [P, P, I, I, I, P, P, F, P, P, P, P]),
     "spgan_pool_finalize_groups": (I, [P, P, I, I, I, P, P, I, I, F, P, P, P, I, P]),
     "spgan_gemm_tn_ws_bytes": (SZ, [I, I, I]),
+    "spgan_gemm_tn_ws_bytes_lp": (SZ, [I, I, I, I]),
+    "spgan_gemm_tn_splits_lp": (I, [I, I, I, I]),
     "spgan_gemm_tn": (I, [C.POINTER(GemmTNArgs), P]),
     "spgan_gemm_tn_skinny_multi": (I, [C.POINTER(GemmTNArgs), I, P]),
     "spgan_sparse_rows_nt": (I, [P, P, I, I, I, P, I, I, P, I, P]),

@@ -980,10 +980,11 @@ def storage16(E: int, F_: int, k: int) -> bool:
     return STORAGE16[0] and _MFMA_F16[0] == 1 and k == 10 and F_ % 8 == 0 and F_ > 64 and E >= max(STORAGE16_MIN_EDGES[0], k * TN_LP_MIN_ROWS)    # F/2 > 32 columns: the fp16 128-row kernels; E/k points: conv_out's bf16 weight-gradient kernel
 
 
-# "bf16x3" operand mode: the weight gradients on the split-bf16 kernel (spgan_gemm_tn_args.mfma_lp == 2) instead of the exact-fp32 MFMA kernel.
-# Off: measured on MI355X (profiles/r06_mfma_shapes_bf16x3_tn_split.txt) the kernel transposes AND splits both operands in registers (176 VALU
-# per 48 MFMAs) and lands at the fp32 kernel's rate (65536 x 256 x 256: 97 vs 103 us; 128 x 1280: 236 vs 229; 320 x 64: 78 vs 55).  Kept for its tests.
-TN_SPLIT_BF16 = [False]
+# "bf16x3" operand mode: the weight gradients whose [Na, Nb] output tiles as 256 x 256, 256 x 128 or 128 x 256 run on the split-bf16 kernel
+# (spgan_gemm_tn_args.mfma_lp == 2, csrc/gemm_tn_wide3.hip: every staged value split once per 128..256 columns of the other operand); every other
+# shape keeps the exact-fp32 MFMA kernel.  Measured on MI355X (tools/tn3_bench.py, incl. the split-sum reduction): 65536 x 256 x 256: 112 -> 64 us,
+# 196608 x 256 x 256: 323 -> 154, 65536 x 128 x 1280: 263 -> 179, 65536 x 256 x 128: 59 -> 49.  SPGAN_TN_SPLIT=0 / TN_SPLIT_BF16[0] = False: A/B switch.
+TN_SPLIT_BF16 = [os.environ.get("SPGAN_TN_SPLIT", "1") != "0"]
 TN_LP_MIN_ROWS = 8192     # "f16" operand mode: weight gradients reduce over >= this many points/edges on the bf16 matrix pipe
 
 
@@ -1052,20 +1053,20 @@ def gemm_tn(A: Tensor, Bm: Tensor, *, pro=None, edge=None, out: Optional[Tensor]
     else:
         _rowmajor2d(out, "out")
     lib = _lib.load()
-    wsb = lib.spgan_gemm_tn_ws_bytes(M_, Na, Nb)
+    a.mfma_lp = 1 if (_MFMA_F16[0] == 1 and not exact and M_ >= TN_LP_MIN_ROWS) else 0
+    if _MFMA_F16[0] == 2 and TN_SPLIT_BF16[0] and not exact and M_ >= TN_LP_MIN_ROWS:
+        a.mfma_lp = 2                   # split-bf16 weight gradient (see TN_SPLIT_BF16)
+    if (b_half or a16) and a.mfma_lp != 1:
+        raise ValueError("16-bit stored operands need the bf16 weight-gradient kernel ('f16' operand mode, M >= %d, exact=False)" % TN_LP_MIN_ROWS)
+    wsb = lib.spgan_gemm_tn_ws_bytes_lp(M_, Na, Nb, a.mfma_lp)       # (the split-bf16 kernel has its own split plan)
     ws = torch.empty((wsb // 4,), dtype=torch.float32, device=A.device)
     a.A = _p(A); a.lda = _ld(A); a.B = _p(Bm); a.ldb = _ld(Bm); a.C = _p(out); a.ldc = _ld(out)
     a.M, a.Na, a.Nb = M_, Na, Nb
     a.beta = float(beta); a.ws = _p(ws); a.ws_bytes = wsb
     defer = bool(defer) and sa is None
     a.defer_reduce = 1 if defer else 0
-    a.mfma_lp = 1 if (_MFMA_F16[0] == 1 and not exact and M_ >= TN_LP_MIN_ROWS) else 0
-    if _MFMA_F16[0] == 2 and TN_SPLIT_BF16[0] and not exact and M_ >= TN_LP_MIN_ROWS:
-        a.mfma_lp = 2                   # split-bf16 weight gradient (off by default, see TN_SPLIT_BF16)
-    if (b_half or a16) and a.mfma_lp != 1:
-        raise ValueError("16-bit stored operands need the bf16 weight-gradient kernel ('f16' operand mode, M >= %d, exact=False)" % TN_LP_MIN_ROWS)
     a.a_half = 1 if a16 else 0
-    splits = lib.spgan_gemm_tn_splits(M_, Na, Nb)
+    splits = lib.spgan_gemm_tn_splits_lp(M_, Na, Nb, a.mfma_lp)
     cs_out = cs_ws = None
     streaming = (Na <= 4 or Nb <= 4) and Na <= 2048 and Nb <= 2048 and pro is None and edge is None and sa is None and a_pro is None and (a2 is None or Nb <= 4)   # 3-column layers: the streaming kernel + a colsum pass stay cheaper (mirrors launch_tn: a narrow-A two-tensor operand runs on the MFMA kernel)
     if with_colsum and sa is not None:

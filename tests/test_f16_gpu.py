@@ -607,11 +607,12 @@ def test_split_image_layout(b3):
     assert (planes[1].abs() <= planes[0].abs() * 2.0 ** -8 + 1e-300).all() and (planes[2].abs() <= planes[0].abs() * 2.0 ** -16 + 1e-300).all()
 
 
-@pytest.mark.parametrize("M,Na,Nb", [(16384, 256, 256), (65536, 128, 1280), (20480, 128, 64), (9000, 64, 32), (8192, 320, 64), (12288, 132, 36)])
+@pytest.mark.parametrize("M,Na,Nb", [(16384, 256, 256), (65536, 128, 1280), (65536, 256, 128), (32768, 128, 128), (20480, 128, 64), (9000, 64, 32), (8192, 320, 64), (12288, 132, 36)])
 def test_gemm_tn_bf16x3_is_fp32_equivalent(b3, M, Na, Nb):
-    """Weight gradients in the split-bf16 mode (spgan_gemm_tn_args.mfma_lp == 2): against the float64 product of the SAME fp32 operands the
-    result is as close as the exact-fp32-MFMA one; per-point gradients of magnitude 1e-7 survive; every A-side / B-side operand mode and
-    by-product of the bf16 kernel; short reductions and exact=True keep fp32 operands."""
+    """Weight gradients in the split-bf16 mode (spgan_gemm_tn_args.mfma_lp == 2; csrc/gemm_tn_wide3.hip for the shapes whose output tiles as
+    256 x 256 / 128 x 256 / 256 x 128 -- the first three here --, the exact-fp32 kernel on the split plan otherwise): against the float64 product of
+    the SAME fp32 operands the result is as close as the exact-fp32-MFMA one; per-point gradients of magnitude 1e-7 survive; every A-side /
+    B-side operand mode and by-product; short reductions and exact=True keep fp32 operands."""
     ops = b3
     ops.TN_SPLIT_BF16[0] = True
     try:

@@ -19,7 +19,7 @@ class Shapes(bench.MfmaAccounting):
             if kind == "gemm_nt":
                 key = ("nt", a.M, a.N, a.K, "a%d e%d%s%s%s" % (a.a_mode, a.epi_mode, " stats" if a.stats else "", " pool" if a.pool_val else "", " z%d" % a.batch if a.batch > 1 else ""))
             elif kind == "gemm_tn":
-                key = ("tn", a.M, a.Na, a.Nb, "b%d%s%s" % (a.b_mode, " sparseA" if a.a_scale else "", " defer" if a.defer_reduce else ""))
+                key = ("tn", a.M, a.Na, a.Nb, "b%d%s%s" % (a.b_mode, (" lazyA" if a.A2 else " affA") if a.a_scale else "", " defer" if a.defer_reduce else ""))
             elif kind == "gemm_dual":
                 key = ("dual", a.M, a.Na, a.Nb, "dgrad+wgrad%s%s" % ({0: "", 1: " lazyA", 2: " actA"}.get(int(a.a_mode), ""), " edge" if a.e_idx else ""))
             else:
