@@ -33,9 +33,11 @@ def main():
     ap.add_argument("--augment", action="store_true"); ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--out", default="runs/spgan"); ap.add_argument("--choice", default="chair")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mfma", choices=("f32", "f16", "bf16x3"), default="f32", help="operand mode of the matrix products (INTEGRATION.md section 4a)")
     ap.add_argument("--lr_decay", action="store_true", help="StepLR on both optimisers, stepped once per epoch (Generation/model.py:99-110,309-312)")
     ap.add_argument("--lr_decay_feq", type=int, default=40); ap.add_argument("--lr_decay_rate", type=float, default=0.7)
     a = ap.parse_args()
+    spgan.ops.set_mfma_operands(a.mfma)
 
     class Opts:                                                # the fields of Generation/config.py the modules read
         np = a.np; nk = a.nk; nz = a.nz; nv = a.nv; softmax = True; off = False; attn = False; use_head = False
