@@ -11,9 +11,9 @@
 // bf16 MFMA's accumulation bias (toward -infinity) alternates in sign from split to split (odd splits multiply A by -1 and negate their partial),
 // so it cancels in the split sum.
 //
-// Operand modes: B plain / BatchNorm + LeakyReLU per column; A plain / affine (+ LeakyReLU) (the kernel body also evaluates the two-tensor lazy
-// BatchNorm-backward operand, APRO = 2, but that form spills and is not dispatched); the fp32 column sums of the transformed A as a by-product.
-// Everything else (per-edge B, 16-bit storage, unaligned shapes) stays with gemm.hip.
+// Operand modes: B plain / BatchNorm + LeakyReLU per column; A plain / affine (+ LeakyReLU); the fp32 column sums of the transformed A as a
+// by-product.  Everything else (per-edge B, the two-tensor lazy A operand -- its second quad per slot on top of 128 accumulators spilled and
+// measured no faster than the fp32 kernel --, 16-bit storage, unaligned shapes) stays with gemm.hip.
 #include <type_traits>
 #include "gemm_tn_wide3.hpp"
 #include "split_bf16.hpp"
@@ -36,7 +36,7 @@ struct T3 {
   static constexpr size_t LDS = (size_t)2 * BUF * sizeof(uint32_t);
 };
 
-// APRO: 0 plain A, 1 a = A*a_scale + a_shift (a_lrelu: LeakyReLU behind it), 2 a = A*a_scale + A2*a_scale2 + a_shift
+// APRO: 0 plain A, 1 a = A*a_scale + a_shift (a_lrelu: LeakyReLU behind it)
 template <int BMODE, int APRO, int WGM, int WGN>
 __global__ __launch_bounds__((T3<WGM, WGN>::THREADS), 2) void gemm_tn_wide3_kernel(const spgan_gemm_tn_args p_, int rows_per_split) {
   using X = T3<WGM, WGN>;
@@ -62,15 +62,14 @@ __global__ __launch_bounds__((T3<WGM, WGN>::THREADS), 2) void gemm_tn_wide3_kern
 
   // staging: thread = (column cl + CPP*s, row-quad mq) of every pass s
   const int cl = tid >> 2, mq = tid & 3;
-  float4 ra[QA], ra2[APRO == 2 ? QA : 1], rb[QB];     // [slot] = the 4 m-rows of the quad
-  float asc[QA], ash[QA], asc2[APRO == 2 ? QA : 1], bsc[QB], bsh[QB], csum[QA];
+  float4 ra[QA], rb[QB];     // [slot] = the 4 m-rows of the quad
+  float asc[QA], ash[QA], bsc[QB], bsh[QB], csum[QA];
   const float ssgn = (split & 1) ? -1.f : 1.f;
 #pragma unroll
   for (int s = 0; s < QA; ++s) {
     const int c = a0 + cl + CPP * s;
     asc[s] = APRO ? p.a_scale[c] : 1.f;
     ash[s] = APRO ? p.a_shift[c] : 0.f;
-    if (APRO == 2) asc2[s] = p.a_scale2[c];
     csum[s] = 0.f;
   }
 #pragma unroll
@@ -83,17 +82,12 @@ __global__ __launch_bounds__((T3<WGM, WGN>::THREADS), 2) void gemm_tn_wide3_kern
   const float bsl = BMODE != SPGAN_A_PLAIN ? p.p_slope : 1.f;
   // element offsets of row-quad mq's four rows at column cl, relative to tile row 0 (32-bit: host checks M*ld < 2^32)
   const unsigned oa = (unsigned)(mbeg + 4 * mq) * (unsigned)p.lda + (unsigned)(a0 + cl);
-  const unsigned oa2 = APRO == 2 ? (unsigned)(mbeg + 4 * mq) * (unsigned)p.lda2 + (unsigned)(a0 + cl) : 0u;
   const unsigned ob = (unsigned)(mbeg + 4 * mq) * (unsigned)p.ldb + (unsigned)(b0 + cl);
-  const unsigned lda = (unsigned)p.lda, lda2 = (unsigned)p.lda2, ldb = (unsigned)p.ldb;
+  const unsigned lda = (unsigned)p.lda, ldb = (unsigned)p.ldb;
 
   auto load_a = [&](int s, int kt) {
     const unsigned o = oa + (unsigned)(kt * XK) * lda + (unsigned)(CPP * s);
     ra[s] = make_float4(p.A[o], p.A[o + lda], p.A[o + 2 * lda], p.A[o + 3 * lda]);
-    if (APRO == 2) {
-      const unsigned o2 = oa2 + (unsigned)(kt * XK) * lda2 + (unsigned)(CPP * s);
-      ra2[s] = make_float4(p.A2[o2], p.A2[o2 + lda2], p.A2[o2 + 2 * lda2], p.A2[o2 + 3 * lda2]);
-    }
   };
   auto load_b = [&](int s, int kt) {
     const unsigned o = ob + (unsigned)(kt * XK) * ldb + (unsigned)(CPP * s);
@@ -104,10 +98,7 @@ __global__ __launch_bounds__((T3<WGM, WGN>::THREADS), 2) void gemm_tn_wide3_kern
   auto pin4 = [](float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
   auto piece_a = [&](int s, int buf) {
     float4 v = ra[s];
-    if (APRO == 2) {
-      v.x = fmaf(v.x, asc[s], fmaf(ra2[s].x, asc2[s], ash[s])); v.y = fmaf(v.y, asc[s], fmaf(ra2[s].y, asc2[s], ash[s]));
-      v.z = fmaf(v.z, asc[s], fmaf(ra2[s].z, asc2[s], ash[s])); v.w = fmaf(v.w, asc[s], fmaf(ra2[s].w, asc2[s], ash[s]));
-    } else if (APRO == 1) {
+    if (APRO == 1) {
       v.x = fmaf(v.x, asc[s], ash[s]); v.y = fmaf(v.y, asc[s], ash[s]); v.z = fmaf(v.z, asc[s], ash[s]); v.w = fmaf(v.w, asc[s], ash[s]);
       v.x = fmaxf(v.x, v.x * asl); v.y = fmaxf(v.y, v.y * asl); v.z = fmaxf(v.z, v.z * asl); v.w = fmaxf(v.w, v.w * asl);
     }
@@ -128,7 +119,7 @@ __global__ __launch_bounds__((T3<WGM, WGN>::THREADS), 2) void gemm_tn_wide3_kern
   const int fa_off = (wm * 128 + l31) * PLW + 4 * (lh ^ ((l31 >> 3) & 1));
   const int fb_off = 3 * X::PLANE_A + (wn * 64 + l31) * PLW + 4 * (lh ^ ((l31 >> 3) & 1));
   bf16x8 aq[2][3];
-  constexpr bool XPF = X::THREADS == 512 && APRO != 2;   // the next k-tile's first fragments read across the barrier (one workgroup per CU; the two-tensor A operand needs the registers)
+  constexpr bool XPF = X::THREADS == 512;   // one workgroup per CU: the next k-tile's first fragments are read across the barrier, under tile row 3
   bf16x8 bq[XPF ? 2 : 1][3][TJ];
   auto read_a = [&](bf16x8 (&dst)[3], int buf, int i) {
 #pragma unroll
@@ -173,7 +164,7 @@ __global__ __launch_bounds__((T3<WGM, WGN>::THREADS), 2) void gemm_tn_wide3_kern
     constexpr int AH = QA / 2;
     // row 0
 #pragma unroll
-    for (int s = 0; s < AH; ++s) if (ST) { pin4(ra[s]); if (APRO == 2) pin4(ra2[s]); }
+    for (int s = 0; s < AH; ++s) if (ST) pin4(ra[s]);
     read_a(aq[1], buf, 1);
     mfma_row(0, aq[0], bq[C]);
 #pragma unroll
@@ -185,7 +176,7 @@ __global__ __launch_bounds__((T3<WGM, WGN>::THREADS), 2) void gemm_tn_wide3_kern
     __builtin_amdgcn_sched_barrier(0);
     // row 1
 #pragma unroll
-    for (int s = AH; s < QA; ++s) if (ST) { pin4(ra[s]); if (APRO == 2) pin4(ra2[s]); }
+    for (int s = AH; s < QA; ++s) if (ST) pin4(ra[s]);
     read_a(aq[0], buf, 2);
     mfma_row(1, aq[1], bq[C]);
 #pragma unroll
@@ -336,10 +327,10 @@ bool spgan_tn_wide3_eligible(const spgan_gemm_tn_args& a) {
   // the two-tensor lazy A operand doubles the A quads in flight (8 more registers per quad on top of 128 accumulators): the kernel spills and
   // measured no faster (65536 x 256 x 256: 112 us) or slower (256 x 128: 212 us against 63) than the fp32 kernel -- it keeps that one
   if (a.A2) return false;
-  if (!al4(a.A) || !al4(a.B) || (a.A2 && !al4(a.A2))) return false;
+  if (!al4(a.A) || !al4(a.B)) return false;
   if (a.b_mode != SPGAN_A_PLAIN && !(a.p_slope >= 0.f && a.p_slope <= 1.f)) return false;
   if (a.a_lrelu && !(a.a_slope >= 0.f && a.a_slope <= 1.f)) return false;
-  if ((double)a.M * a.lda >= 4294967296.0 || (double)a.M * a.ldb >= 4294967296.0 || (a.A2 && (double)a.M * a.lda2 >= 4294967296.0)) return false;
+  if ((double)a.M * a.lda >= 4294967296.0 || (double)a.M * a.ldb >= 4294967296.0) return false;
   return true;
 }
 

@@ -44,7 +44,6 @@ struct X3 {
 template <int AMODE, int EPI, int WGM, int WGN, int BPRE>
 __global__ __launch_bounds__((X3<WGM, WGN>::THREADS), 2) void gemm_nt_wide3_kernel(const spgan_gemm_nt_args p_) {
   using X = X3<WGM, WGN>;
-  constexpr int SCHED = 1;
   const spgan_gemm_nt_args& p = p_;  // stays in the kernarg segment (scalar loads)
   constexpr bool affine = AMODE != SPGAN_A_PLAIN;
   constexpr bool sparse = AMODE == SPGAN_WIDE_A_SPARSE;
@@ -181,7 +180,6 @@ __global__ __launch_bounds__((X3<WGM, WGN>::THREADS), 2) void gemm_nt_wide3_kern
   };
   // issue order inside one tile row (12 MFMAs): every MFMA gap carries `valu` VALU instructions and, every other gap, one LDS instruction
   auto row_schedule = [&](int valu) {
-    if (!SCHED) return;
 #pragma unroll
     for (int g = 0; g < 2 * 3 * TJ; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA

@@ -536,6 +536,9 @@ def test_gemm_nt_wide3(b3, M, N, K, what, image):
                 y, m, v = ops.gemm_nt(A, W, b, pro=(sc, sh, slope), stats=True)
                 y2, m2, v2 = km.gemm_nt(A, W, b, pro=(sc, sh, slope), stats=True)
                 close(y, y2, rtol=2e-6, atol=2e-6, what="affine %g" % slope); close(m, m2, rtol=1e-5, atol=1e-6); close(v, v2, rtol=2e-5)
+            # a LeakyReLU slope outside [0, 1] (max(v, v*slope) is not the activation there) leaves this kernel for the 128-row one: same answer
+            y = ops.gemm_nt(A, W, b, pro=(sc, sh, 1.5))
+            close(y, km.gemm_nt(A, W, b, pro=(sc, sh, 1.5)), rtol=2e-6, atol=2e-6, what="slope 1.5 (fallback)")
             # epilogues of the backward passes
             refm = rnd("w3.ref%d.%d" % (M, N), (M, N))
             close(ops.gemm_nt_maskout(A, W, refm, 0.01), km.gemm_nt_maskout(A, W, refm, 0.01), rtol=2e-6, atol=2e-6, what="maskout")

@@ -1,5 +1,7 @@
+"""EXPERIMENT: the split-bf16 gemm_nt launch (M = 65536, N = 1024, K = 1024, output stored) on operands of different DATA: N(0,1), zeros, ones, N(0,1)
+rounded to bf16 (mid = lo = 0) -- the bf16 matrix pipe is power-limited: DESIGN.md section 13.2."""
 import os, sys, torch
-sys.path[:0] = [os.path.join(os.environ["GRAFT_REPO_ROOT"], "sp-gan_amd")]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "sp-gan_amd")]
 from spgan import ops
 ops.set_mfma_operands("bf16x3")
 img = {}
