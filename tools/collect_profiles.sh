@@ -37,6 +37,7 @@ python $R/tools/nt3_ksweep.py > $O/${TAG}_nt3_ksweep.txt 2>/dev/null
 bash $R/tools/nt3_trace.sh > $O/${TAG}_nt3_trace.txt 2>/dev/null
 python $R/tools/tn3_bench.py > $O/${TAG}_tn3_bench.txt 2>/dev/null                   # split-bf16 weight gradients (csrc/gemm_tn_wide3.hip) against the fp32 kernel
 (cd /tmp && python $R/tools/nt16_bench.py) > $O/${TAG}_nt16_bench.txt 2>/dev/null     # fp16 operands: row-pipelined 256 x 256 tiles (csrc/gemm_wide16.hip) against gemm_wide.hip's
+python $R/bench.py --mfma bf16x3 --config c4 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_c4_bf16x3.json 2>/dev/null      # the C4 per-GPU shape in the split mode
 SPGAN_TN_SPLIT=0 python $R/bench.py --mfma bf16x3 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_bf16x3_tn_f32.json 2>/dev/null      # A/B: weight gradients on the fp32 kernel
 SPGAN_NT_WIDE16=0 python $R/bench.py --config c5 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_f16_operands_old_wide.json 2>/dev/null   # A/B: gemm_wide.hip's fp16 form
 bash $R/tools/nt3_pmc.sh > $O/${TAG}_nt3_pmc.txt 2>/dev/null
