@@ -182,6 +182,10 @@ typedef struct spgan_gemm_nt_args {
    * copies W's three bf16 planes from it instead of splitting the fp32 rows of W again in every workgroup (weights: split once per optimiser
    * step).  Kernels that do not use it ignore it; W must still be given. */
   const void* w_image;
+  /* gout_add != NULL (epi_mode BNBWD, a_mode AFFINE_LRELU, mfma_f16 == 2 on a problem its 256-row-tile kernel takes; SPGAN_EINVAL otherwise):
+   * the stored tile is gout_add[m, :] + gout_scale[:] * g[m, :] (the statistics stay those of g), as spgan_gemm_dual_args.gout_add: phase B of
+   * the double backward hands X = xbarA + gamma*g to the next BatchNorm backward. */
+  const float* gout_add; int ld_gout_add; const float* gout_scale;
 } spgan_gemm_nt_args;
 /* 1 when spgan_gemm_nt will honour y_bf16 for this problem (it runs on the 256 x 256-tile kernel with fp16 operands) */
 int spgan_gemm_nt_y16_ok(const spgan_gemm_nt_args* a);

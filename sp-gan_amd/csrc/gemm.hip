@@ -2113,6 +2113,9 @@ extern "C" int spgan_gemm_nt(const spgan_gemm_nt_args* a, spgan_stream_t s_) {
   if (a->batch > 1)
     SPGAN_CHECK_ARG(a->a_mode == SPGAN_A_PLAIN && a->epi_mode == SPGAN_EPI_LINEAR && a->Y && !a->stats && !a->rowbias && !a->pool_val &&
                     a->batch <= 65535 && a->batch_stride_a >= 0 && a->batch_stride_w >= 0 && a->batch_stride_y > 0);
+  if (a->gout_add)   // the stored tile gout_add + gout_scale * g: an epilogue of the split-bf16 256-row-tile kernel only (its one caller's route)
+    SPGAN_CHECK_ARG(a->epi_mode == SPGAN_EPI_BNBWD && a->gout_scale && a->ld_gout_add >= a->N && a->Y && spgan_nt_wide3_selected(*a) &&
+                    (uint64_t)a->M * (uint64_t)a->ld_gout_add < (1ull << 32));
   if (a->tail.enabled) {  // finished in the launch only where one workgroup owns its columns: the M <= 64 kernel
     const spgan_coltail& f = a->tail;
     SPGAN_CHECK_ARG(a->stats && a->M <= 64 && (f.mode == 0 || f.mode == 1));

@@ -324,7 +324,12 @@ int launch_epi(const spgan_gemm_nt_args& a, hipStream_t s) {
   switch (a.epi_mode) {
     case SPGAN_EPI_LINEAR: return launch<AMODE, SPGAN_EPI_LINEAR>(a, s);
     case SPGAN_EPI_MASK_OUT: return AMODE == SPGAN_A_PLAIN ? launch<SPGAN_A_PLAIN, SPGAN_EPI_MASK_OUT>(a, s) : SPGAN_EINVAL;
-    case SPGAN_EPI_BNBWD: return launch<AMODE, SPGAN_EPI_BNBWD>(a, s);
+    case SPGAN_EPI_BNBWD:
+      if (a.gout_add) {   // stored tile gout_add + gout_scale * g: the activation operand only (eligibility rule)
+        if constexpr (AMODE == SPGAN_A_AFFINE_LRELU) return launch<AMODE, SPGAN_WIDE_EPI_BNBWD_GOUT>(a, s);
+        return SPGAN_EINVAL;
+      }
+      return launch<AMODE, SPGAN_EPI_BNBWD>(a, s);
   }
   return SPGAN_EINVAL;
 }
@@ -380,6 +385,7 @@ bool spgan_nt_wide3_eligible(const spgan_gemm_nt_args& a) {
     if (a.epi_mode == SPGAN_EPI_BNBWD && a.rowbias && a.rows_per_group != 1) return false;
     if (a.epi_mode == SPGAN_EPI_MASK_OUT && (a.bias || a.rowbias)) return false;
   }
+  if (a.gout_add && (a.epi_mode != SPGAN_EPI_BNBWD || a.a_mode != SPGAN_A_AFFINE_LRELU || a.sp_val)) return false;
   return true;
 }
 

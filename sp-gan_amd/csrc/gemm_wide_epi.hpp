@@ -7,6 +7,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// internal epilogue id (template argument only, never in spgan_gemm_nt_args.epi_mode): BNBWD whose stored tile is gout_add + gout_scale * g.
+// Its own instantiation (gemm_wide3.hip), so that the BNBWD kernels keep their registers.
+constexpr int SPGAN_WIDE_EPI_BNBWD_GOUT = 8;
+
 #define ROFF(r) (((r) & 3) + 8 * ((r) >> 2))   // C/D layout of v_mfma_f32_32x32x*: register r of lane l holds row ROFF(r) + 4*(l >> 5), column l & 31
 
 // m0 / n0: first row / column of the workgroup's tile; wm / wn: the wave's position in the tile; H16: the 16-bit result storage modes
@@ -139,18 +143,23 @@ __device__ __forceinline__ void wide_epilogue(const spgan_gemm_nt_args& p, f32x1
 #pragma unroll
         for (int r = 0; r < 16; ++r) yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = acc[i][j][r] * lrelu_mask(rv[r], sl);
       }
-  } else {  // SPGAN_EPI_BNBWD
+  } else {  // SPGAN_EPI_BNBWD (/ SPGAN_WIDE_EPI_BNBWD_GOUT)
+    constexpr bool GOUT = EPI == SPGAN_WIDE_EPI_BNBWD_GOUT;
+    static_assert(EPI == SPGAN_EPI_BNBWD || GOUT, "unknown epilogue");
     const float* rb = p.ref + (size_t)rbase * p.ld_ref + cbase;
     float* yb = p.Y + (size_t)rbase * p.ldy + cbase;
     const unsigned ldr = (unsigned)p.ld_ref, ldy = (unsigned)p.ldy;
     const float sl = p.b_slope;
     const float* ab = p.rowbias ? p.rowbias + (size_t)rbase * p.ld_rowbias + cbase : nullptr;  // host: rows_per_group == 1 (dense addend)
     const unsigned ld2 = (unsigned)p.ld_rowbias;
+    const float* gx = GOUT ? p.gout_add + (size_t)rbase * p.ld_gout_add + cbase : nullptr;
+    const unsigned ldx = GOUT ? (unsigned)p.ld_gout_add : 0u;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
       const int col = cbase + j * 32;
       const float sc = p.b_scale[col], sh = p.b_shift[col], mu = p.b_mean[col], inv = p.b_invstd[col];
       const float bia = p.bias ? p.bias[col] : 0.f;
+      const float gs = GOUT ? p.gout_scale[col] : 1.f;
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
@@ -161,15 +170,31 @@ __device__ __forceinline__ void wide_epilogue(const spgan_gemm_nt_args& p, f32x1
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] += ab[(size_t)((unsigned)(i * 32 + ROFF(r)) * ld2 + (unsigned)(j * 32))];
         }
+        if constexpr (GOUT) {   // g into the accumulator, the statistics from it; then the stored value gout_add + gout_scale * g
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float y = yv[r];
-          const float z = fmaf(y, sc, sh);
-          const float g = (acc[i][j][r] + bia) * lrelu_mask(z, sl);
-          const float xh = (y - mu) * inv;
-          yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = g;
-          s0 += g;
-          s1 = fmaf(g, xh, s1);
+          for (int r = 0; r < 16; ++r) {
+            const float y = yv[r];
+            const float z = fmaf(y, sc, sh);
+            const float g = (acc[i][j][r] + bia) * lrelu_mask(z, sl);
+            acc[i][j][r] = g;
+            s0 += g;
+            s1 = fmaf(g, (y - mu) * inv, s1);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) yv[r] = gx[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldx + (unsigned)(j * 32))];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = fmaf(gs, acc[i][j][r], yv[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float y = yv[r];
+            const float z = fmaf(y, sc, sh);
+            const float g = (acc[i][j][r] + bia) * lrelu_mask(z, sl);
+            const float xh = (y - mu) * inv;
+            yb[(size_t)((unsigned)(i * 32 + ROFF(r)) * ldy + (unsigned)(j * 32))] = g;
+            s0 += g;
+            s1 = fmaf(g, xh, s1);
+          }
         }
       }
       if (p.stats) {

@@ -51,6 +51,7 @@ class GemmNTArgs(C.Structure):
         ("A2", c_f32p), ("lda2", C.c_int), ("p_scale2", c_f32p),
         ("a_half", C.c_int), ("y_bf16", C.c_int), ("y_half", C.c_int),
         ("w_image", C.c_void_p),
+        ("gout_add", c_f32p), ("ld_gout_add", C.c_int), ("gout_scale", c_f32p),
     ]
 
 

@@ -472,7 +472,7 @@ def d_backward(P, ctx, dout: Tensor, need_dx: bool, need_dparams: bool, keep_for
             lazy = _lazy_ok(M, sc.numel())
             cb = dict(coef_bn=(P[D_LAYERS[2][1] + ".weight"], M)) if lazy else {}     # the finalize launch also emits the lazy operand's coefficients
             a3 = ops.ActOperand(ys[2], sc, sh, NEG)
-            if need_dparams and ops.gemm_dual_ok(a3, G4, ys[2]):
+            if need_dparams and ops.gemm_dual_ok(a3, G4, ys[2]) and not ops.collapsed_pair_preferred(M, G4.shape[0]):
                 # the Gram matrix a3^T a3 (+ colsum(a3)) and the input-gradient product a3.G4 from ONE staging of the y3 tile (ops.gemm_dual
                 # with dy := a3, W := G4 -- symmetric --, pre := y3): both read the same tensor with the same BatchNorm + LeakyReLU on load
                 gram, g, s0, s1, *rest = ops.gemm_dual(a3, G4, ys[2], sc, sh, mu, inv, NEG, bias=cvec, rowadd=E, with_colsum=True, defer=False, **cb)
@@ -591,7 +591,12 @@ def _d_double_top_phase_b(P, ctx, top: dict, grads, phaseb=None, gout=None):
         EB = ops.sparse_rows_nt(spB, argmax, N, W)
     part = ops.gemm_nt(q3, G1, rowbias=EB, rows_per_group=1)
     a3 = ops.ActOperand(ys[2], pro3[0], pro3[1], NEG)
-    if ops.gemm_dual_ok(a3, G2, ys[2]):
+    pair = ops.collapsed_pair_preferred(B * N, G2.shape[0])
+    if pair:
+        # split-bf16 mode: the two products on the mode's own kernels; phase B's sums / the stored X = xbarA + gamma*g as in the fused launch
+        gram, cs3 = ops.gemm_tn(ys[2], ys[2], a_pro=pro3, pro=pro3, with_colsum=True)
+        abar_g = ops.gemm_nt_bnbwd(ys[2], G2, ys[2], psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part, phaseb=phaseb, gout=gout)
+    elif ops.gemm_dual_ok(a3, G2, ys[2]):
         # a3^T a3, colsum(a3) and the outgoing adjoint a3.G2 (+ addends, layer 3's mask / sums epilogue) from one staging of the y3 tile
         # (phaseb: layer 2's phase-B sums come out of this launch's finalize)
         gram, g_, s0_, s1_, cs3, *pb = ops.gemm_dual(a3, G2, ys[2], psc, psh, pmu, pinv, NEG, bias=cvec, rowadd=part, with_colsum=True, defer=False,
@@ -821,14 +826,31 @@ def d_backward_joint(P, firsts, dbl=None):
         G4, cvec = outs[i]
         specs.append(dict(dy=ops.ActOperand(c["ys"][2], sc, sh, NEG), W=G4, y_ref=c["ys"][2], scale=sc, shift=sh, mean=mu, invstd=inv, slope=NEG,
                           bias=cvec, rowadd=Es[i], with_colsum=True, coef_bn=(P[bn3 + ".weight"], M)))
+    pair = ops.collapsed_pair_preferred(M, W4.shape[1])
+    pair_res = []
+    if pair:
+        # split-bf16 mode: the first-order passes' two products on the mode's own kernels, exactly as d_backward issues them
+        for sp in specs:
+            x3, pro3 = sp["y_ref"], (sp["scale"], sp["shift"], NEG)
+            gram, cs3 = ops.gemm_tn(x3, x3, a_pro=pro3, pro=pro3, with_colsum=True)
+            g, s0, s1, coef = ops.gemm_nt_bnbwd(x3, sp["W"], x3, sp["scale"], sp["shift"], sp["mean"], sp["invstd"], NEG, pro=pro3, bias=sp["bias"],
+                                                rowadd=sp["rowadd"], coef_bn=sp["coef_bn"])
+            pair_res.append((gram, g, s0, s1, coef, cs3))
+        specs = []
     if hot is not None:
         psc, psh, pinv, pmu = hctx["bns"][2]
         G1, (G2, cvec) = outs[nf], outs[nf + 1]
         part = ops.gemm_nt(hot["q3"], G1, rowbias=Es[nf], rows_per_group=1)
         pb, gout = _phaseb_below(P, hctx["bns"], coeffs, xbarA, 3, M)
-        specs.append(dict(dy=ops.ActOperand(hctx["ys"][2], psc, psh, NEG), W=G2, y_ref=hctx["ys"][2], scale=psc, shift=psh, mean=pmu, invstd=pinv,
-                          slope=NEG, bias=cvec, rowadd=part, with_colsum=True, phaseb=pb, gout=gout))
-    res = ops.gemm_dual_multi(specs, defer=False)
+        if pair:
+            x3, pro3 = hctx["ys"][2], (psc, psh, NEG)
+            gram, cs3 = ops.gemm_tn(x3, x3, a_pro=pro3, pro=pro3, with_colsum=True)
+            g_, s0_, s1_, *pbr = ops.gemm_nt_bnbwd(x3, G2, x3, psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part, phaseb=pb, gout=gout)
+            pair_res.append((gram, g_, s0_, s1_, cs3) + tuple(pbr))
+        else:
+            specs.append(dict(dy=ops.ActOperand(hctx["ys"][2], psc, psh, NEG), W=G2, y_ref=hctx["ys"][2], scale=psc, shift=psh, mean=pmu, invstd=pinv,
+                              slope=NEG, bias=cvec, rowadd=part, with_colsum=True, phaseb=pb, gout=gout))
+    res = pair_res + (ops.gemm_dual_multi(specs, defer=False) if specs else [])
     wspecs, lazies, abar_g = [], [], None
     for i, (c, _) in enumerate(firsts):
         gram, g, s0, s1, coef, cs3 = res[i]

@@ -620,12 +620,16 @@ def bn_dbl_phaseb(coeffs, gamma: Tensor, invstd: Tensor, s0: Optional[Tensor], s
 
 
 def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, slope: float,
-                  edge=None, pro=None, bias: Optional[Tensor] = None, rowadd: Optional[Tensor] = None, coef_bn=None):
+                  edge=None, pro=None, bias: Optional[Tensor] = None, rowadd: Optional[Tensor] = None, coef_bn=None, phaseb=None, gout=None):
     """g = (pro(A) @ W^T + bias + rowadd) * lrelu'(z), z = y*scale+shift; returns (g, sum_c g, sum_c g*xhat), xhat = (y-mean)*invstd.
     With edge=(idx, ebias) y is the per-edge difference y[e] = P[idx[e]] - P[i] + ebias of the point tensor P=y_ref.
     A may be a SparseAffine or an Affine2 operand; pro=(scale[K], shift[K], slope) as in gemm_nt; rowadd is a dense [M,N] addend.
     coef_bn = (gamma | None, count): also return the BatchNorm-backward coefficients coef [3,N] of bn_bwd_lazy(g, y_ref, mean, invstd,
-    gamma, [sum g | sum g*xhat], count) as a fourth result -- emitted by the launch that finishes the column sums (not with edge)."""
+    gamma, [sum g | sum g*xhat], count) as a fourth result -- emitted by the launch that finishes the column sums (not with edge).
+    phaseb / gout: as gemm_dual's (the double backward's phase B: the finalize launch also runs bn_dbl_phaseb on the sums it merges, the
+    stored tensor is gout[0] + gout[1]*g) -> (g, s0, s1, sums, dgamma [, coef]); M > 64, no per-edge operand, not together with coef_bn."""
+    if (phaseb is not None or gout is not None) and (edge is not None or coef_bn is not None):
+        raise ValueError("gemm_nt_bnbwd: phaseb / gout take neither a per-edge operand nor coef_bn")
     sa = A if isinstance(A, SparseAffine) else None
     a2 = A if isinstance(A, Affine2) else None
     if sa is not None:
@@ -674,6 +678,12 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
     a.b_scale = _p(_vec(scale, N, "scale")); a.b_shift = _p(_vec(shift, N, "shift"))
     a.b_mean = _p(_vec(mean, N, "mean")); a.b_invstd = _p(_vec(invstd, N, "invstd")); a.b_slope = float(slope)
     a.stats = _p(part)
+    if gout is not None:
+        gadd, gsc = gout
+        _rowmajor2d(gadd, "gout.add")
+        if gadd.shape != (M_, N):
+            raise ValueError("gout add must be [M,N]")
+        a.gout_add = _p(gadd); a.ld_gout_add = _ld(gadd); a.gout_scale = _p(_vec(gsc, N, "gout.scale"))
     if edge is None:
         a.epi_mode = EPI_BNBWD
     else:
@@ -682,6 +692,8 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
         a.epi_mode = EPI_EDGE_BNBWD; a.e_idx = _p(idx); a.e_k = idx.shape[1]; a.e_bias2 = _p(_vec(ebias, N, "ebias"))
     lib = _lib.load()
     res = None
+    if phaseb is not None and M_ <= 64:
+        raise ValueError("gemm_nt_bnbwd: phaseb needs the tile partials of the M > 64 kernels")
     if _owns_columns(lib, a):
         res = torch.empty((2, N), dtype=torch.float32, device=A.device)          # [sum g | sum g*xhat], contiguous (nets._cat2)
         a.tail.enabled = 1; a.tail.mode = 1; a.tail.out0 = _p(res[0]); a.tail.out1 = _p(res[1])
@@ -690,6 +702,27 @@ def gemm_nt_bnbwd(A, W: Tensor, y_ref: Tensor, scale: Tensor, shift: Tensor, mea
     check(lib.spgan_gemm_nt(C.byref(a), _s()), "gemm_nt_bnbwd", M=M_, N=N, K=K)
     if done is not None:
         done()
+    if phaseb is not None:
+        # one finalize launch: the plain sums, bn_dbl_phaseb on them and (4-tuple) the lazy-operand coefficients, as gemm_dual_multi issues it
+        from ._lib import ColFinalizeArgs
+        (U0, U1, Ugz, S0, S1, count), pg, pinv = phaseb[:3]
+        fa = (ColFinalizeArgs * 1)()
+        f = fa[0]
+        fin = torch.empty((2, N), dtype=torch.float32, device=A.device)
+        sums = torch.empty((2 * N,), dtype=torch.float32, device=A.device)
+        dg = torch.empty((N,), dtype=torch.float32, device=A.device)
+        vs = [_vec(t.contiguous(), N, nm) for t, nm in ((U0, "U0"), (U1, "U1"), (Ugz, "Ugz"), (S0, "S0"), (S1, "S1"), (pg, "gamma"), (pinv, "invstd"))]
+        f.partials = _p(part); f.tiles = tiles; f.C = N; f.G = M_; f.tile_rows = 0; f.s0 = _p(fin[0]); f.s1 = _p(fin[1])
+        f.kind = 2; f.U0, f.U1, f.Ugz, f.S0, f.S1, f.gamma, f.invstd = [_p(t) for t in vs]
+        f.count = float(count); f.sums = _p(sums); f.dgamma = _p(dg)
+        tail = (sums, dg)
+        if len(phaseb) == 4:
+            pmean = _vec(phaseb[3].contiguous(), N, "mean")
+            coefB = torch.empty((3, N), dtype=torch.float32, device=A.device)
+            f.mean = _p(pmean); f.pb_coef = _p(coefB)
+            tail = (sums, dg, coefB)
+        check(lib.spgan_colstats_finalize_multi(fa, 1, _s()), "colstats_finalize_multi", count=1)
+        return (g, fin[0], fin[1]) + tail
     if coef_bn is not None:
         gamma, count = coef_bn
         if res is not None:                     # the M <= 64 kernel finished its sums itself: coefficients by the small kernel
@@ -734,6 +767,18 @@ def gemm_dual_ok(dy, W: Tensor, y_ref: Tensor, edge=None) -> bool:
         return False
     ek = 0 if edge is None else int(edge[0].shape[1])
     return bool(_lib.load().spgan_gemm_dual_wgs(g.shape[0], W.shape[0], W.shape[1], ek))
+
+
+# "bf16x3": the collapsed 256 -> 1024 layer's two products (Gram matrix a3^T a3, input gradient a3.G4) as ONE exact-fp32 gemm_dual launch or as a
+# pair on the split-bf16 kernels (gemm_tn_wide3 + gemm_wide3): the pair is faster (step 7.75 -> 7.63 ms for the two first-order passes alone,
+# profiles/r06_split_pair_ab.txt).  SPGAN_SPLIT_PAIR=0 / SPLIT_PAIR[0] = False: the fused launch (A/B switch).
+SPLIT_PAIR = [os.environ.get("SPGAN_SPLIT_PAIR", "1") != "0"]
+
+
+def collapsed_pair_preferred(M: int, K: int) -> bool:
+    """True when the collapsed layer's backward should run as gemm_tn + gemm_nt_bnbwd although gemm_dual would take it: the split-bf16
+    mode, with both products on its 256-row-tile kernels."""
+    return _MFMA_F16[0] == 2 and SPLIT_PAIR[0] and TN_SPLIT_BF16[0] and _NT_TILE_HINT[0] == 0 and M % 256 == 0 and M >= 32768 and K % 128 == 0
 
 
 GEMM_DUAL = [True]      # test hook: False sends every layer backward through the two separate launches (tests compare the two routes)

@@ -210,7 +210,7 @@ def _dense(A):
     return A
 
 
-def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None, pro=None, bias=None, rowadd=None, coef_bn=None):
+def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None, pro=None, bias=None, rowadd=None, coef_bn=None, phaseb=None, gout=None):
     A = _dense(A)
     if pro is not None:
         A = _lrelu(A * pro[0] + pro[1], pro[2])
@@ -233,7 +233,19 @@ def gemm_nt_bnbwd(A, W, y_ref, scale, shift, mean, invstd, slope, edge=None, pro
     if coef_bn is not None:
         s0, s1 = g.sum(0), (g * xh).sum(0)
         return g.contiguous(), s0, s1, bn_bwd_lazy(g, y, mean, invstd, coef_bn[0], torch.cat([s0, s1]), coef_bn[1]).coef
-    return g.contiguous(), g.sum(0), (g * xh).sum(0)
+    s0, s1 = g.sum(0), (g * xh).sum(0)
+    tail = ()
+    if phaseb is not None:
+        co, pg, pinv = phaseb[:3]
+        sums, dgam = bn_dbl_phaseb(co, pg, pinv, s0, s1)
+        tail = (sums, dgam)
+        if len(phaseb) == 4:       # coefficients of p*X + q*y + r = pinv*(X - S0/M - xhat*S1/M)
+            C_, rM = pinv.numel(), 1.0 / co[5]
+            q_ = -(pinv * pinv) * (sums[C_:] * rM)
+            tail = tail + (torch.stack([pinv, q_, -(pinv * (sums[:C_] * rM)) - q_ * phaseb[3]]),)
+    if gout is not None:
+        g = gout[0] + gout[1] * g
+    return (g.contiguous(), s0, s1) + tail
 
 
 def _sparse_dense(val, arg, rows):
@@ -796,6 +808,13 @@ class ActOperand:
 
     def dense(self):
         return _lrelu(self.x * self.scale + self.shift, self.slope)
+
+
+SPLIT_PAIR = [False]    # tests: True sends the collapsed layer's backward through gemm_tn + gemm_nt_bnbwd (the split-bf16 mode's route)
+
+
+def collapsed_pair_preferred(M, K):
+    return bool(SPLIT_PAIR[0])
 
 
 def gemm_dual_ok(dy, W, y_ref, edge=None):

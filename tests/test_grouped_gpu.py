@@ -68,6 +68,35 @@ def test_gemm_dual_stored_adjoint_and_phase_b_coefficients(ops, M, Nb, mode):
     close(ops.Affine2(X, y, coef).dense(), ref, rtol=2e-6, atol=2e-6 * float(ref.abs().max()), what="lazy phase-B operand vs bn_bwd_apply")
 
 
+def test_collapsed_layer_pair_of_split_launches_equals_the_fused_launch(ops):
+    """The split-bf16 mode's route through the collapsed 256 -> 1024 layer backward (ops.collapsed_pair_preferred): gemm_tn + gemm_nt_bnbwd with the
+    phase-B tail and the stored tile X = add + scale*g (spgan_gemm_nt_args.gout_add, an epilogue of csrc/gemm_wide3.hip) against the ONE exact-fp32
+    gemm_dual launch it replaces -- every result at fp32-product tolerance; the stored-tile epilogue is refused where that kernel does not run."""
+    M, Nb = 32768, 256
+    sp = _dual_spec(ops, "pair%d" % M, M, Nb, "act", "phaseb")
+    add, scale = rnd("pair.add", (M, Nb)), rnd("pair.scale", (Nb,)).abs() + 0.5
+    ymean = rnd("pair.ymean", (Nb,), 0.2)
+    sp = dict(sp, phaseb=tuple(sp["phaseb"]) + (ymean,), gout=(add, scale))
+    gram, X, s0, s1, cs, sums, dg, coef = ops.gemm_dual(defer=False, **sp)
+    y3, pro3 = sp["y_ref"], (sp["scale"], sp["shift"], sp["slope"])
+    kw = dict(pro=pro3, bias=sp["bias"], rowadd=sp["rowadd"], phaseb=sp["phaseb"], gout=sp["gout"])
+    with pytest.raises(Exception):      # fp32 operands: no kernel with that epilogue
+        ops.gemm_nt_bnbwd(y3, sp["W"], y3, sp["scale"], sp["shift"], sp["mean"], sp["invstd"], sp["slope"], **kw)
+    ops.set_mfma_operands("bf16x3")
+    try:
+        assert ops.collapsed_pair_preferred(M, Nb) == ops.SPLIT_PAIR[0]
+        gram2, cs2 = ops.gemm_tn(y3, y3, a_pro=pro3, pro=pro3, with_colsum=True)
+        X2, s02, s12, sums2, dg2, coef2 = ops.gemm_nt_bnbwd(y3, sp["W"], y3, sp["scale"], sp["shift"], sp["mean"], sp["invstd"], sp["slope"], **kw)
+        plain = ops.gemm_nt_bnbwd(y3, sp["W"], y3, sp["scale"], sp["shift"], sp["mean"], sp["invstd"], sp["slope"], pro=pro3, bias=sp["bias"], rowadd=sp["rowadd"])
+    finally:
+        ops.set_mfma_operands("f32")
+    assert torch.equal(s02, plain[1]) and torch.equal(s12, plain[2])            # the statistics are those of g, not of the stored tile
+    close(X2, add.double() + scale.double() * plain[0].double(), rtol=1e-6, atol=1e-6, what="stored tile = add + scale*g")
+    for a, b, what in ((gram2, gram, "gram"), (cs2, cs, "colsum"), (X2, X, "stored tile"), (s02, s0, "s0"), (s12, s1, "s1"), (sums2, sums, "phase-B sums"),
+                       (dg2, dg, "dgamma"), (coef2, coef, "lazy coefficients")):
+        close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()), what=what)
+
+
 @pytest.mark.parametrize("M,Nb,modes", [(16384, 256, ("act", "act", "act")), (65536, 128, ("lazy", "lazy", "dense")), (16384, 64, ("lazy", "lazy", "dense")),
                                         (8192, 128, ("lazy", "dense"))])
 def test_gemm_dual_multi_equals_separate_launches(ops, M, Nb, modes):

@@ -8,6 +8,7 @@ from helpers import check, check_adam_updates, golden, load_mid_state, measured_
 from oracle import spgan_oracle as orc
 from spgan import fixture_rng as fr
 from test_host_cpu import Opts, ZERO_GRAD_BIASES, spgan_cpu, _load   # noqa: F401  (fixture import)
+import kernel_model as km
 
 
 def test_losses_golden(spgan_cpu):
@@ -287,6 +288,38 @@ def test_joint_d_backward_equals_one_node_per_pass(spgan_cpu, monkeypatch, gan, 
     for k in sa:      # (the G step's D passes run on the UPDATED weights, which carry the other summation order: not bit-equal)
         if "running" in k or "num_batches" in k:
             assert torch.allclose(sa[k].float(), sb[k].float(), rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.parametrize("joint", [True, False])
+def test_collapsed_layer_as_a_pair_of_launches_equals_the_fused_launch(spgan_cpu, monkeypatch, joint):
+    """The split-bf16 mode's route through the collapsed 256 -> 1024 layer backward (ops.collapsed_pair_preferred: gemm_tn + gemm_nt_bnbwd with the
+    phase-B tail and the stored X = xbarA + gamma*g, instead of ONE gemm_dual launch): same step, in the joint D-step node and with one node per
+    pass; the double backward's lazy phase B stays on (the pair returns the coefficient tail)."""
+    import spgan
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    real = fr.synthetic_real(B, N, seed=91)
+    z_d, z_g = fr.latent(B, N, seed=92), fr.latent(B, N, seed=93)
+    alpha = fr.uniform("joint.alpha", (B, 1, 1), 0.0, 1.0)
+    seen = []
+    real_bnbwd = spgan_cpu.ops.gemm_nt_bnbwd
+    monkeypatch.setattr(spgan_cpu.ops, "gemm_nt_bnbwd", lambda *a, **k: (seen.append((k.get("phaseb") is not None, k.get("gout") is not None)), real_bnbwd(*a, **k))[1])
+    outs = []
+    for pair in (False, True):
+        monkeypatch.setattr(km, "SPLIT_PAIR", [pair])
+        seen.clear()
+        G = _load(spgan.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=9))
+        D = _load(spgan.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=9))
+        tr = spgan.TrainStep(G, D, gan="wgan", use_gp=True, lambda_gp=10.0)
+        tr.joint_d_backward = joint
+        outs.append(tr.step(x, real, z_d, z_g, alpha=alpha, keep_grads=True))
+        if pair:      # the penalty pass's launch carried phase B's sums and the stored adjoint
+            assert (True, True) in seen, seen
+    a, b = outs
+    np.testing.assert_allclose(a["loss_d"].item(), b["loss_d"].item(), rtol=1e-6)
+    for n in a["d_grads"]:
+        ga, gb = a["d_grads"][n], b["d_grads"][n]
+        assert (ga - gb).norm().item() <= 2e-6 * gb.norm().item() + 1e-12, n
 
 
 @pytest.mark.parametrize("gan,use_gp", [("wgan", True), ("ls", False)])
