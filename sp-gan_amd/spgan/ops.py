@@ -773,12 +773,21 @@ def gemm_dual_ok(dy, W: Tensor, y_ref: Tensor, edge=None) -> bool:
 # pair on the split-bf16 kernels (gemm_tn_wide3 + gemm_wide3): the pair is faster (step 7.75 -> 7.63 ms for the two first-order passes alone,
 # profiles/r06_split_pair_ab.txt).  SPGAN_SPLIT_PAIR=0 / SPLIT_PAIR[0] = False: the fused launch (A/B switch).
 SPLIT_PAIR = [os.environ.get("SPGAN_SPLIT_PAIR", "1") != "0"]
+_PAIR_OK: dict = {}
 
 
 def collapsed_pair_preferred(M: int, K: int) -> bool:
     """True when the collapsed layer's backward should run as gemm_tn + gemm_nt_bnbwd although gemm_dual would take it: the split-bf16
     mode, with both products on its 256-row-tile kernels."""
-    return _MFMA_F16[0] == 2 and SPLIT_PAIR[0] and TN_SPLIT_BF16[0] and _NT_TILE_HINT[0] == 0 and M % 256 == 0 and M >= 32768 and K % 128 == 0
+    if not (_MFMA_F16[0] == 2 and SPLIT_PAIR[0] and TN_SPLIT_BF16[0] and _NT_TILE_HINT[0] == 0 and M >= 32768):
+        return False
+    key = (int(M), int(K))
+    if key not in _PAIR_OK:
+        # the input-gradient launch carries the stored-tile epilogue (gout), which only gemm_wide3.hip has: ask the library whether it runs there
+        a = GemmNTArgs(); a.mfma_f16 = 2; a.M, a.N, a.K = key[0], key[1], key[1]; a.lda = a.ldw = a.ldy = a.ld_ref = a.ld_rowbias = key[1]
+        a.a_mode = A_AFFINE_LRELU; a.p_slope = 0.2; a.epi_mode = EPI_BNBWD; a.rows_per_group = 1
+        _PAIR_OK[key] = bool(_lib.load().spgan_gemm_nt_uses_w_image(C.byref(a)))
+    return _PAIR_OK[key]
 
 
 GEMM_DUAL = [True]      # test hook: False sends every layer backward through the two separate launches (tests compare the two routes)
