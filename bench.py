@@ -173,7 +173,11 @@ def _pmc_traffic():
     for name in PMC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["kernels"][DOMINANT["pmc_key"]]["hbm_bytes_per_launch_corrected"], name
+                k = json.load(f)["kernels"][DOMINANT["pmc_key"]]
+            hbm, algo = int(k["hbm_bytes_per_launch_corrected"]), int(k["algorithmic_bytes_per_launch"])
+            if not 0.5 * algo <= hbm <= 4 * algo:      # a mis-parsed summary (a duration column read as a counter) must not reach the line
+                continue
+            return hbm, name
         except Exception:
             continue
     return None, None
@@ -295,8 +299,8 @@ class MfmaAccounting:
                 "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "launches_timed": len(dom), "per_shape": per_shape,
                 "traffic": None if t1 is None else int(t1 * rows_avg / self.M),
                 "traffic_note": ("HBM bytes per launch: measured for the one-pass launch (M=%d) in separate rocprofv3 --pmc passes (profiles/%s: %s B "
-                                 "= 1.10x its algorithmic 80.7 MB: A 67.1 MB + W 1.0 MB read once + own statistics/pooling records 12.6 MB written), scaled by the "
-                                 "average rows per launch (operand and records grow with the rows)" % (self.M, t1_file, t1)) if t1 is not None else
+                                 "= %.2fx its algorithmic 80.7 MB: A 67.1 MB + W 1.0 MB read once + own statistics/pooling records 12.6 MB written), scaled by the "
+                                 "average rows per launch (operand and records grow with the rows)" % (self.M, t1_file, t1, t1 / 80740352.0)) if t1 is not None else
                                 "not measured for this operand mode (the committed PMC passes are of the fp32-operand kernel; operands and records are the same bytes)"}
 
     def summary(self, steps, step_ms):

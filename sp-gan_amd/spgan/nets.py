@@ -832,7 +832,7 @@ def d_backward_joint(P, firsts, dbl=None):
         # split-bf16 mode: the first-order passes' two products on the mode's own kernels, exactly as d_backward issues them
         for sp in specs:
             x3, pro3 = sp["y_ref"], (sp["scale"], sp["shift"], NEG)
-            gram, cs3 = ops.gemm_tn(x3, x3, a_pro=pro3, pro=pro3, with_colsum=True)
+            gram, cs3 = ops.gemm_tn(x3, x3, a_pro=pro3, pro=pro3, with_colsum=True, defer=True)      # (one split reduction for all passes, below)
             g, s0, s1, coef = ops.gemm_nt_bnbwd(x3, sp["W"], x3, sp["scale"], sp["shift"], sp["mean"], sp["invstd"], NEG, pro=pro3, bias=sp["bias"],
                                                 rowadd=sp["rowadd"], coef_bn=sp["coef_bn"])
             pair_res.append((gram, g, s0, s1, coef, cs3))
@@ -844,12 +844,14 @@ def d_backward_joint(P, firsts, dbl=None):
         pb, gout = _phaseb_below(P, hctx["bns"], coeffs, xbarA, 3, M)
         if pair:
             x3, pro3 = hctx["ys"][2], (psc, psh, NEG)
-            gram, cs3 = ops.gemm_tn(x3, x3, a_pro=pro3, pro=pro3, with_colsum=True)
+            gram, cs3 = ops.gemm_tn(x3, x3, a_pro=pro3, pro=pro3, with_colsum=True, defer=True)
             g_, s0_, s1_, *pbr = ops.gemm_nt_bnbwd(x3, G2, x3, psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part, phaseb=pb, gout=gout)
             pair_res.append((gram, g_, s0_, s1_, cs3) + tuple(pbr))
         else:
             specs.append(dict(dy=ops.ActOperand(hctx["ys"][2], psc, psh, NEG), W=G2, y_ref=hctx["ys"][2], scale=psc, shift=psh, mean=pmu, invstd=pinv,
                               slope=NEG, bias=cvec, rowadd=part, with_colsum=True, phaseb=pb, gout=gout))
+    if pair:
+        ops.flush_tn()
     res = pair_res + (ops.gemm_dual_multi(specs, defer=False) if specs else [])
     wspecs, lazies, abar_g = [], [], None
     for i, (c, _) in enumerate(firsts):
