@@ -617,11 +617,12 @@ def test_gemm_tn_bf16x3_is_fp32_equivalent(b3, M, Na, Nb):
     the SAME fp32 operands the result is as close as the exact-fp32-MFMA one; per-point gradients of magnitude 1e-7 survive; every A-side /
     B-side operand mode and by-product; short reductions and exact=True keep fp32 operands."""
     ops = b3
+    was = ops.TN_SPLIT_BF16[0]
     ops.TN_SPLIT_BF16[0] = True
     try:
         _gemm_tn_bf16x3(ops, M, Na, Nb)
     finally:
-        ops.TN_SPLIT_BF16[0] = False
+        ops.TN_SPLIT_BF16[0] = was
 
 
 def _gemm_tn_bf16x3(ops, M, Na, Nb):
