@@ -70,7 +70,7 @@ PEAK_OF_MODE = {"f32": FP32_MATRIX_PEAK_TFLOPS, "f16": FP16_MATRIX_PEAK_TFLOPS, 
 DTYPE_OF_MODE = {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate/epilogues/weight-gradients",
                  "bf16x3": "f32 storage and accumulation; the large gemm_nt products and the weight gradients with 256/128-tileable outputs with every f32 "
                            "operand split exactly into 3 bf16 terms (6 bf16 MFMA cross products: f32-equivalent, dropped terms <= 2^-26 relative); "
-                           "layer-backward pairs (gemm_dual) and the remaining products on the exact f32 MFMA"}
+                           "the fused layer-backward launches (gemm_dual: D's 128- and 64-channel layers, EdgeConv2) and the remaining small products on the exact f32 MFMA"}
 # algorithmic FLOPs per shape per step, reference formulation: WGAN-GP at N=2048
 GF_PER_SHAPE_STEP = 67.3 if CONFIG == "c4" else 32.6     # 2 F_Gf + 4N*779,520 + 15 F_Df at N = 4096 / 2048
 
