@@ -10,6 +10,7 @@ formulas in the WGAN-GP double backward.
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Dict, List, Optional, Tuple
 
@@ -767,13 +768,47 @@ def d_joint_ok(P, ctxs) -> bool:
         return False
     ys = c0["ys"]
     sc3, sh3 = c0["bns"][2][0], c0["bns"][2][1]
-    if not ops.gemm_dual_ok(ops.ActOperand(ys[2], sc3, sh3, NEG), W4[:W4.shape[1]], ys[2]):       # the collapsed layer: dy := a3, W := a [K,K] matrix
+    two = _joint_two_launch()
+    if not (two or ops.gemm_dual_ok(ops.ActOperand(ys[2], sc3, sh3, NEG), W4[:W4.shape[1]], ys[2])):       # the collapsed layer: dy := a3, W := a [K,K] matrix
         return False
     for li in (2, 1):
         W = _w2(P[D_LAYERS[li][0] + ".weight"])
-        if not (_lazy_ok(M, W.shape[0]) and ops.gemm_dual_ok(ys[li], W, ys[li - 1])):
+        if not (_lazy_ok(M, W.shape[0]) and (two or ops.gemm_dual_ok(ys[li], W, ys[li - 1]))):
             return False
     return _lazy_ok(M, ys[0].shape[1]) and ys[2].shape[1] % 32 == 0
+
+
+JOINT_TWO_LAUNCH = [os.environ.get("SPGAN_JOINT_PAIRS", "1") != "0"]     # A/B hook: False keeps one node per pass in the "f16" operand mode
+
+
+def _joint_two_launch() -> bool:
+    """The "f16" operand mode has no fused layer-backward kernel (ops.gemm_dual_ok is False for every layer): d_backward_joint then issues each
+    layer's two launches per pass and keeps what else it groups (the pool / collapse / weight-gradient-collapse launches of all passes as one)."""
+    return JOINT_TWO_LAUNCH[0] and ops.get_mfma_operands() == "f16"
+
+
+def _layer_backward_multi(specs, defer: bool = True):
+    """ops.gemm_dual_multi(specs), or -- where the fused kernel does not take the layer (the "f16" operand mode) -- per problem the two launches it
+    stands for: gemm_tn (deferred split sum) + gemm_nt_bnbwd, with the finalize tails computed from their sums.  Same result tuples, except that
+    a phase-B problem comes back without the stored-tile / lazy-coefficient tail ((dW, g, s0, s1, sums, dgamma): the caller's bn_bwd_apply route)."""
+    d0 = specs[0]
+    if ops.gemm_dual_ok(d0["dy"], d0["W"], d0["y_ref"]):
+        return ops.gemm_dual_multi(specs, defer=defer)
+    res = []
+    for sp in specs:
+        pro = (sp["scale"], sp["shift"], sp["slope"])
+        dW = ops.gemm_tn(sp["dy"], sp["y_ref"], pro=pro, out=sp.get("out"), beta=sp.get("beta", 0.0), defer=True)
+        kw = dict(coef_bn=sp["coef_bn"]) if sp.get("coef_bn") is not None else {}
+        g, s0, s1, *coef = ops.gemm_nt_bnbwd(sp["dy"], _t(sp["W"]), sp["y_ref"], sp["scale"], sp["shift"], sp["mean"], sp["invstd"], sp["slope"], **kw)
+        pb = sp.get("phaseb")
+        if pb is not None:
+            sums, dgam = ops.bn_dbl_phaseb(pb[0], pb[1], pb[2], s0, s1)
+            res.append((dW, g, s0, s1, sums, dgam))
+        else:
+            res.append((dW, g, s0, s1) + tuple(coef))
+    if not defer:
+        ops.flush_tn()
+    return res
 
 
 def d_backward_joint(P, firsts, dbl=None):
@@ -826,7 +861,8 @@ def d_backward_joint(P, firsts, dbl=None):
         G4, cvec = outs[i]
         specs.append(dict(dy=ops.ActOperand(c["ys"][2], sc, sh, NEG), W=G4, y_ref=c["ys"][2], scale=sc, shift=sh, mean=mu, invstd=inv, slope=NEG,
                           bias=cvec, rowadd=Es[i], with_colsum=True, coef_bn=(P[bn3 + ".weight"], M)))
-    pair = ops.collapsed_pair_preferred(M, W4.shape[1])
+    gout_ok = ops.collapsed_pair_preferred(M, W4.shape[1])      # the split-bf16 pair: its input-gradient launch carries the stored tile (gout)
+    pair = gout_ok or not ops.gemm_dual_ok(ops.ActOperand(c0["ys"][2], c0["bns"][2][0], c0["bns"][2][1], NEG), W4[:W4.shape[1]], c0["ys"][2])
     pair_res = []
     if pair:
         # split-bf16 mode: the first-order passes' two products on the mode's own kernels, exactly as d_backward issues them
@@ -845,7 +881,11 @@ def d_backward_joint(P, firsts, dbl=None):
         if pair:
             x3, pro3 = hctx["ys"][2], (psc, psh, NEG)
             gram, cs3 = ops.gemm_tn(x3, x3, a_pro=pro3, pro=pro3, with_colsum=True, defer=True)
-            g_, s0_, s1_, *pbr = ops.gemm_nt_bnbwd(x3, G2, x3, psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part, phaseb=pb, gout=gout)
+            if gout_ok:
+                g_, s0_, s1_, *pbr = ops.gemm_nt_bnbwd(x3, G2, x3, psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part, phaseb=pb, gout=gout)
+            else:      # no kernel with the stored-tile epilogue: phase B's sums by their own launch, the adjoint goes through bn_bwd_apply below
+                g_, s0_, s1_ = ops.gemm_nt_bnbwd(x3, G2, x3, psc, psh, pmu, pinv, NEG, pro=pro3, bias=cvec, rowadd=part)
+                pbr = ops.bn_dbl_phaseb(pb[0], pb[1], pb[2], s0_, s1_) if pb is not None else ()
             pair_res.append((gram, g_, s0_, s1_, cs3) + tuple(pbr))
         else:
             specs.append(dict(dy=ops.ActOperand(hctx["ys"][2], psc, psh, NEG), W=G2, y_ref=hctx["ys"][2], scale=psc, shift=psh, mean=pmu, invstd=pinv,
@@ -899,7 +939,7 @@ def d_backward_joint(P, firsts, dbl=None):
             pb, gout = _phaseb_below(P, hctx["bns"], coeffs, xbarA, li, M)
             specs.append(dict(dy=ybar, W=W, y_ref=hctx["ys"][li - 1], scale=psc, shift=psh, mean=pmu, invstd=pinv, slope=NEG, out=G[nf][conv + ".weight"],
                               beta=1.0, phaseb=pb, gout=gout))
-        res = ops.gemm_dual_multi(specs)
+        res = _layer_backward_multi(specs)
         for i, (c, _) in enumerate(firsts):
             dW, g, s0, s1, coef = res[i]
             G[i][conv + ".weight"] = dW.view_as(P[conv + ".weight"]); G[i][conv + ".bias"] = ZERO_GRAD

@@ -218,10 +218,20 @@ def _d_setup(B, N, salt):
     return nets, P, xs
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16"])
 @pytest.mark.parametrize("B,N,with_dbl", [(8, 2048, True), (32, 2048, True), (16, 1024, False)])
-def test_d_backward_joint_equals_separate_calls(ops, B, N, with_dbl):
+def test_d_backward_joint_equals_separate_calls(ops, B, N, with_dbl, mode):
     """nets.d_backward_joint (the real pass, the fake pass and the penalty's double backward in lock step, every layer's launch issued once) gives,
-    per pass, the gradients of nets.d_backward / nets.d_double_backward bit for bit."""
+    per pass, the gradients of nets.d_backward / nets.d_double_backward bit for bit.  mode "f16": no fused layer-backward kernel -- the joint node
+    issues each layer's two launches per pass (nets._layer_backward_multi) and groups the rest."""
+    ops.set_mfma_operands(mode)
+    try:
+        _joint_equals_separate(ops, B, N, with_dbl)
+    finally:
+        ops.set_mfma_operands("f32")
+
+
+def _joint_equals_separate(ops, B, N, with_dbl):
     nets, P, xs = _d_setup(B, N, 31)
     M = B * N
 

@@ -323,6 +323,37 @@ def test_collapsed_layer_as_a_pair_of_launches_equals_the_fused_launch(spgan_cpu
 
 
 @pytest.mark.parametrize("gan,use_gp", [("wgan", True), ("ls", False)])
+def test_joint_d_backward_with_two_launch_layers(spgan_cpu, monkeypatch, gan, use_gp):
+    """The joint D-step node where no fused layer-backward kernel exists (the "f16" operand mode: nets._joint_two_launch): every layer as gemm_tn +
+    gemm_nt_bnbwd per pass, phase B's sums from the finalize tail, the grouped pool / collapse launches kept -- against one node per pass."""
+    import spgan
+    from spgan import nets
+    monkeypatch.setattr(km, "GEMM_DUAL", [False])
+    monkeypatch.setattr(nets, "_joint_two_launch", lambda: True)
+    calls = []
+    real_joint = nets.d_backward_joint
+    monkeypatch.setattr(nets, "d_backward_joint", lambda P, firsts, dbl=None: (calls.append((len(firsts), dbl is not None)), real_joint(P, firsts, dbl))[1])
+    B, N = 4, 256
+    x = fr.sphere_template(N)[None].repeat(B, 1, 1)
+    real = fr.synthetic_real(B, N, seed=91)
+    z_d, z_g = fr.latent(B, N, seed=92), fr.latent(B, N, seed=93)
+    alpha = fr.uniform("joint.alpha", (B, 1, 1), 0.0, 1.0)
+    outs = []
+    for joint in (True, False):
+        G = _load(spgan.Generator(Opts), fr.init_params(orc.generator_shapes(), salt=9))
+        D = _load(spgan.Discriminator(Opts), fr.init_params(orc.discriminator_shapes(), salt=9))
+        tr = spgan.TrainStep(G, D, gan=gan, use_gp=use_gp, lambda_gp=10.0)
+        tr.joint_d_backward = joint
+        outs.append(tr.step(x, real, z_d, z_g, alpha=alpha, keep_grads=True))
+    assert calls == [(2, use_gp)], calls
+    a, b = outs
+    np.testing.assert_allclose(a["loss_d"].item(), b["loss_d"].item(), rtol=1e-6)
+    for n in a["d_grads"]:
+        ga, gb = a["d_grads"][n], b["d_grads"][n]
+        assert (ga - gb).norm().item() <= 2e-6 * gb.norm().item() + 1e-12, n
+
+
+@pytest.mark.parametrize("gan,use_gp", [("wgan", True), ("ls", False)])
 def test_paired_generator_forwards_equal_separate_forwards(spgan_cpu, monkeypatch, gan, use_gp):
     """TrainStep with the step's two generator forwards evaluated as ONE pipeline (Generator.forward_pair -> nets.g_pair_forward: the per-point /
     per-shape stages once on the rows of both passes, the BatchNorm stages per pass) against two separate forwards: two steps, same losses,
