@@ -52,6 +52,7 @@ python $R/tools/dual_bench.py > $O/${TAG}_dual_bench.txt 2>/dev/null
 rm -rf /tmp/prof_c4; rocprofv3 --kernel-trace --stats -d /tmp/prof_c4 -o r -- python $R/bench.py --config c4 --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/bench_c4.log 2>&1
 python $R/tools/rocprof_summary.py $(find /tmp/prof_c4 -name "*.db" | head -1) 31 > $O/${TAG}_bench_c4_kernel_stats.txt
 bash $R/tools/profile_f16.sh $TAG > /dev/null 2>&1      # kernel table of the "f16" operand mode
+python $R/tools/step_sequence.py $(find /tmp/prof_h -name "*.db" | head -1) -8 > $O/${TAG}_step_sequence_f16.txt      # ... and its ordered step sequence
 python $R/tools/exp/wide_k_sweep.py > $O/${TAG}_wide_k_sweep.txt 2>/dev/null
 python $R/tools/exp/mid_k_sweep.py > $O/${TAG}_mid_k_sweep.txt 2>/dev/null
 bash $R/tools/knn_pmc.sh > $O/${TAG}_knn_pmc.txt 2>&1                      # PMC passes over the kNN launches (both routes)
